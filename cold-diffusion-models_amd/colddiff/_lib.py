@@ -1,0 +1,104 @@
+"""ctypes binding of libcolddiff_hip.so.
+
+The C header ``include/colddiff.h`` is the single source of truth for the ABI: its prototypes
+are parsed here into ctypes signatures, so a symbol that is declared but not exported (or the
+other way round) fails at load time.  There is NO fallback: if the gfx950 library cannot be
+loaded, :func:`get` raises and every operator of the package is unusable.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG_ROOT = os.path.dirname(_HERE)
+_REPO = os.path.dirname(_PKG_ROOT)
+HEADER = os.path.join(_REPO, "include", "colddiff.h")
+LIB_PATH = os.path.join(_PKG_ROOT, "csrc", "libcolddiff_hip.so")
+
+_CTYPES = {
+    "int": ctypes.c_int,
+    "long long": ctypes.c_longlong,
+    "int64_t": ctypes.c_int64,
+    "size_t": ctypes.c_size_t,
+    "float": ctypes.c_float,
+    "double": ctypes.c_double,
+}
+
+
+def _ctype_of(decl):
+    decl = decl.strip()
+    if "*" in decl:
+        return ctypes.c_char_p if decl.replace(" ", "") == "constchar*" else ctypes.c_void_p
+    decl = re.sub(r"\bconst\b", "", decl).strip()
+    # drop the parameter name
+    for name, ct in sorted(_CTYPES.items(), key=lambda kv: -len(kv[0])):
+        if decl == name or decl.startswith(name + " "):
+            return ct
+    raise ValueError("colddiff.h: unsupported C type in %r" % decl)
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtypes])} for every prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r"^\s*#.*$", "", src, flags=re.M)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(cdf_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        restype = _ctype_of(ret + " x") if "*" not in ret else _ctype_of(ret)
+        argtypes = [] if args in ("", "void") else [_ctype_of(a) for a in args.split(",")]
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+class CdfError(RuntimeError):
+    pass
+
+
+class Lib:
+    """A loaded colddiff kernel library with checked call wrappers."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise CdfError(
+                "colddiff: %s not found — build it with `python __graft_entry__.py` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+        self.path = path
+        self._dll = ctypes.CDLL(path)
+        self.protos = parse_header()
+        for name, (restype, argtypes) in self.protos.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError:
+                raise CdfError("colddiff: %s does not export %s declared in colddiff.h" % (path, name))
+            fn.restype = restype
+            fn.argtypes = argtypes
+            if restype is ctypes.c_int and name not in ("cdf_abi_version", "cdf_is_device_build"):
+                setattr(self, name, self._checked(name, fn))
+            else:
+                setattr(self, name, fn)
+
+    def _checked(self, name, fn):
+        last_error = self._dll.cdf_last_error
+        last_error.restype = ctypes.c_char_p
+
+        def call(*args):
+            rc = fn(*args)
+            if rc != 0:
+                raise CdfError("%s failed (%d): %s" % (name, rc, last_error().decode()))
+            return rc
+
+        call.__name__ = name
+        return call
+
+
+_instance = None
+
+
+def get():
+    """The process-wide library handle (loads on first use; raises if the .so is missing)."""
+    global _instance
+    if _instance is None:
+        _instance = Lib(LIB_PATH)
+    return _instance

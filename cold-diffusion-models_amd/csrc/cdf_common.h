@@ -1,0 +1,78 @@
+// cdf_common.h — shared definitions for the colddiff gfx950 kernels.
+//
+// Two build modes:
+//   * default  : hipcc --offload-arch=gfx950 (the product; libcolddiff_hip.so)
+//   * CDF_EMU  : host clang++ build against tests/emu/hipemu.h, a fiber-based SIMT
+//                simulator used ONLY by the CPU test-suite to check kernel indexing
+//                (wave64 shuffles, MFMA fragment layouts, LDS tiling) without a GPU.
+//                It is test infrastructure: nothing in the Python package loads it.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef CDF_EMU
+#include "hipemu.h"
+#else
+#include <hip/hip_runtime.h>
+#define CDF_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
+#define CDF_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+#endif
+
+// ---- status codes (returned by every extern "C" entry point) -------------------------
+#define CDF_OK 0
+#define CDF_E_INVALID (-1)      // bad argument (shape, alignment, null pointer)
+#define CDF_E_UNSUPPORTED (-2)  // valid request this build has no kernel for
+#define CDF_E_LAUNCH (-3)       // hipLaunch / runtime error
+
+#define CDF_WAVE 64
+// C-ABI entry points take the stream as an opaque `void* stream`
+#define CDF_S ((hipStream_t)stream)
+
+void cdf_set_error(const char* fmt, ...);
+int cdf_check_launch(const char* what);
+
+#define CDF_REQUIRE(cond, ...)                  \
+    do {                                        \
+        if (!(cond)) {                          \
+            cdf_set_error(__VA_ARGS__);         \
+            return CDF_E_INVALID;               \
+        }                                       \
+    } while (0)
+
+static inline int cdf_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers ---------------------------------------------------------------------
+__device__ __forceinline__ float cdf_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float cdf_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// sum over aligned sub-groups of `width` lanes (width power of two <= 64)
+__device__ __forceinline__ float cdf_group_sum(float v, int width) {
+    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// exact (erf) GELU, matches torch.nn.GELU(approximate='none')
+__device__ __forceinline__ float cdf_gelu(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float cdf_gelu_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float cdf_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float cdf_silu(float x) { return x * cdf_sigmoid(x); }
+__device__ __forceinline__ float cdf_silu_grad(float x) {
+    const float s = cdf_sigmoid(x);
+    return s * (1.0f + x * (1.0f - s));
+}
