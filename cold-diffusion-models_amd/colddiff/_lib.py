@@ -52,6 +52,10 @@ def parse_header(path=HEADER):
     return protos
 
 
+# int-returning entry points that are pure host-side queries (sizes / counts), not status codes
+_QUERY = re.compile(r"(_blocks|_nchunk|_nsplit|_abi_version|_is_device_build)$")
+
+
 class CdfError(RuntimeError):
     pass
 
@@ -74,7 +78,7 @@ class Lib:
                 raise CdfError("colddiff: %s does not export %s declared in colddiff.h" % (path, name))
             fn.restype = restype
             fn.argtypes = argtypes
-            if restype is ctypes.c_int and name not in ("cdf_abi_version", "cdf_is_device_build"):
+            if restype is ctypes.c_int and not _QUERY.search(name):
                 setattr(self, name, self._checked(name, fn))
             else:
                 setattr(self, name, fn)

@@ -1,0 +1,442 @@
+// k_norm.hip — normalisation layers on NHWC feature maps (pixel pitch ld).
+//
+//   channel LayerNorm  : deblurring_diffusion_pytorch.py:111-121  (biased var, eps 1e-5,
+//                        (x-mean)/sqrt(var+eps)*g+b) — per-pixel reduction over C, contiguous in
+//                        NHWC, done with wave64 sub-group shuffles (LP lanes per pixel).
+//   GroupNorm(32)+SiLU : Model2.py:27-33,116-123 (eps 1e-6, affine, swish) — per (sample, group)
+//                        statistics over (C/32 channels x all pixels); two-level reduction.
+// Both are HBM-bound: forward = 1 read + 1 write, backward = 2 reads + 1 write (+ small stats).
+#include "cdf_common.h"
+#include "colddiff.h"
+
+// ------------------------------------------------------------------------------------------------
+// channel LayerNorm
+// ------------------------------------------------------------------------------------------------
+template <int NV>
+__global__ void __launch_bounds__(256) layernorm_c_fwd_kernel(const float* x, int ldx, float* y, int ldy, const float* g,
+                                                              const float* bta, float* mean_out, float* rstd_out,
+                                                              long long M, int C, int LP, float eps) {
+    const int lane = threadIdx.x & 63, sub = lane / LP, li = lane - sub * LP;
+    const int groups_per_wave = 64 / LP;
+    const long long wave_global = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const long long npg = (M + groups_per_wave - 1) / groups_per_wave;  // pixel groups
+    for (long long pg = wave_global; pg < npg; pg += nwaves) {
+        const long long m = pg * groups_per_wave + sub;
+        const bool valid = m < M;
+        float4 v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = (li + j * LP) * 4;
+            if (valid && c < C) v[j] = *(const float4*)(x + m * ldx + c);
+            else v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+        s = cdf_group_sum(s, LP);
+        const float mean = s / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = (li + j * LP) * 4;
+            if (c < C) {
+                const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        }
+        q = cdf_group_sum(q, LP);
+        const float sd = sqrtf(q / (float)C + eps);
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = (li + j * LP) * 4;
+                if (c < C) {
+                    const float4 gg = *(const float4*)(g + c), bb = *(const float4*)(bta + c);
+                    float4 o;
+                    o.x = (v[j].x - mean) / sd * gg.x + bb.x;
+                    o.y = (v[j].y - mean) / sd * gg.y + bb.y;
+                    o.z = (v[j].z - mean) / sd * gg.z + bb.z;
+                    o.w = (v[j].w - mean) / sd * gg.w + bb.w;
+                    *(float4*)(y + m * ldy + c) = o;
+                }
+            }
+            if (li == 0 && mean_out) {
+                mean_out[m] = mean;
+                rstd_out[m] = 1.0f / sd;
+            }
+        }
+    }
+}
+
+// backward: dx, and per-block partial sums of dg / db in part[block][2][C]
+template <int NV>
+__global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const float* dy, int lddy, const float* x, int ldx,
+                                                              const float* g, const float* mean_in, const float* rstd_in,
+                                                              float* dx, int lddx, float* part, long long M, int C,
+                                                              int LP, int accumulate_dx) {
+    CDF_DYN_SMEM(smem);
+    float* sred = (float*)smem;  // [G][2][C]
+    const int lane = threadIdx.x & 63, sub = lane / LP, li = lane - sub * LP;
+    const int groups_per_wave = 64 / LP;
+    const int G = (blockDim.x >> 6) * groups_per_wave;
+    const int gidx = (threadIdx.x >> 6) * groups_per_wave + sub;
+    const long long wave_global = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const long long npg = (M + groups_per_wave - 1) / groups_per_wave;
+    float4 adg[NV], adb[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        adg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        adb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (long long pg = wave_global; pg < npg; pg += nwaves) {
+        const long long m = pg * groups_per_wave + sub;
+        const bool valid = m < M;
+        const float mean = valid ? mean_in[m] : 0.f, rstd = valid ? rstd_in[m] : 0.f;
+        float4 xh[NV], dg_[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = (li + j * LP) * 4;
+            xh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            dg_[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid && c < C) {
+                const float4 xv = *(const float4*)(x + m * ldx + c), dv = *(const float4*)(dy + m * lddy + c);
+                const float4 gg = *(const float4*)(g + c);
+                xh[j].x = (xv.x - mean) * rstd; xh[j].y = (xv.y - mean) * rstd;
+                xh[j].z = (xv.z - mean) * rstd; xh[j].w = (xv.w - mean) * rstd;
+                adg[j].x += dv.x * xh[j].x; adg[j].y += dv.y * xh[j].y; adg[j].z += dv.z * xh[j].z; adg[j].w += dv.w * xh[j].w;
+                adb[j].x += dv.x; adb[j].y += dv.y; adb[j].z += dv.z; adb[j].w += dv.w;
+                dg_[j].x = dv.x * gg.x; dg_[j].y = dv.y * gg.y; dg_[j].z = dv.z * gg.z; dg_[j].w = dv.w * gg.w;
+                s1 += (dg_[j].x + dg_[j].y) + (dg_[j].z + dg_[j].w);
+                s2 += (dg_[j].x * xh[j].x + dg_[j].y * xh[j].y) + (dg_[j].z * xh[j].z + dg_[j].w * xh[j].w);
+            }
+        }
+        s1 = cdf_group_sum(s1, LP) / (float)C;
+        s2 = cdf_group_sum(s2, LP) / (float)C;
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = (li + j * LP) * 4;
+                if (c < C) {
+                    float4 o;
+                    o.x = rstd * (dg_[j].x - s1 - xh[j].x * s2);
+                    o.y = rstd * (dg_[j].y - s1 - xh[j].y * s2);
+                    o.z = rstd * (dg_[j].z - s1 - xh[j].z * s2);
+                    o.w = rstd * (dg_[j].w - s1 - xh[j].w * s2);
+                    float* dst = dx + m * lddx + c;
+                    if (accumulate_dx) {
+                        const float4 old = *(const float4*)dst;
+                        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                    }
+                    *(float4*)dst = o;
+                }
+            }
+        }
+    }
+    // block reduction of the per-lane dg/db partials: sred[g][0/1][c]
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (li + j * LP) * 4;
+        if (c < C) {
+            *(float4*)(sred + ((size_t)gidx * 2 + 0) * C + c) = adg[j];
+            *(float4*)(sred + ((size_t)gidx * 2 + 1) * C + c) = adb[j];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        float s = 0.f;
+        for (int gg = 0; gg < G; ++gg) s += sred[(size_t)gg * 2 * C + i];
+        part[(size_t)blockIdx.x * 2 * C + i] = s;
+    }
+}
+
+// out[c] (+)= sum_blocks part[block][which][c]
+__global__ void norm_param_reduce_kernel(const float* part, int nblocks, int C, float* dg, float* db, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * C) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * 2 * C + i];
+    float* dst = i < C ? dg + i : db + (i - C);
+    *dst = accumulate ? *dst + s : s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(32 groups) [+ SiLU]
+// ------------------------------------------------------------------------------------------------
+// Per-(sample, chunk, channel) partial sums of two quantities:
+//   mode 0 (fwd stats) : p0 = sum x            p1 = sum x^2
+//   mode 1 (bwd)       : p0 = sum dz           p1 = sum dz * xhat,  dz = dy * act'(xhat*gamma+beta)
+// part layout [B][nchunk][2][C]; grid = (ceil(C/64), nchunk, B); block 256 = 4 row lanes x 64 ch
+__global__ void groupnorm_partial_kernel(const float* x, int ldx, const float* dy, int lddy, const float* gamma,
+                                         const float* beta, const float* mean, const float* rstd, float* part, int HW,
+                                         int rows_per_chunk, int C, int groups, int mode, int silu) {
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, b = blockIdx.z;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    int r1 = r0 + rows_per_chunk;
+    if (r1 > HW) r1 = HW;
+    float p0 = 0.f, p1 = 0.f;
+    if (c < C) {
+        const float* xp = x + (long long)b * HW * ldx + c;
+        if (mode == 0) {
+            for (int r = r0 + rl; r < r1; r += 4) {
+                const float v = xp[(long long)r * ldx];
+                p0 += v;
+                p1 += v * v;
+            }
+        } else {
+            const int gi = c / (C / groups);
+            const float mu = mean[b * groups + gi], rs = rstd[b * groups + gi], ga = gamma[c], be = beta[c];
+            const float* dp = dy + (long long)b * HW * lddy + c;
+            for (int r = r0 + rl; r < r1; r += 4) {
+                const float xh = (xp[(long long)r * ldx] - mu) * rs;
+                float dz = dp[(long long)r * lddy];
+                if (silu) dz *= cdf_silu_grad(xh * ga + be);
+                p0 += dz;
+                p1 += dz * xh;
+            }
+        }
+    }
+    red[0][rl][threadIdx.x & 63] = p0;
+    red[1][rl][threadIdx.x & 63] = p1;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const int l = threadIdx.x;
+        float* dst = part + (((long long)b * gridDim.y + blockIdx.y) * 2) * C + c;
+        dst[0] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+        dst[C] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+    }
+}
+
+// forward finalize: mean/rstd per (b, group). grid = B, block = 64 (>= groups... loops)
+__global__ void groupnorm_stats_kernel(const float* part, int nchunk, int C, int groups, int HW, float eps, float* mean,
+                                       float* rstd) {
+    const int b = blockIdx.x, cg = C / groups;
+    for (int gi = threadIdx.x; gi < groups; gi += blockDim.x) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < nchunk; ++k) {
+            const float* p = part + (((long long)b * nchunk + k) * 2) * C;
+            for (int c = gi * cg; c < (gi + 1) * cg; ++c) {
+                s += (double)p[c];
+                q += (double)p[C + c];
+            }
+        }
+        const double n = (double)HW * cg;
+        const double mu = s / n;
+        double var = q / n - mu * mu;
+        if (var < 0.0) var = 0.0;
+        mean[b * groups + gi] = (float)mu;
+        rstd[b * groups + gi] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// backward finalize: per (b, c) sums A = sum dz, Bc = sum dz*xhat (chunk-reduced into ab[B][2][C]);
+// per (b, group): s1 = sum_c gamma*A / n, s2 = sum_c gamma*Bc / n ; dgamma[c] (+)= sum_b Bc, dbeta (+)= sum_b A
+__global__ void groupnorm_bwd_finalize_kernel(const float* part, int nchunk, int B, int C, int groups, int HW,
+                                              const float* gamma, float* s12 /*[B][groups][2]*/, float* dgamma,
+                                              float* dbeta, float* ab, int accumulate) {
+    // phase 1: chunk reduce -> ab   (grid-stride over B*2*C)
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;  // single block launch
+    for (int i = tid; i < B * 2 * C; i += blockDim.x * gridDim.x) {
+        const int b = i / (2 * C), j = i - b * 2 * C;
+        float s = 0.f;
+        for (int k = 0; k < nchunk; ++k) s += part[(((long long)b * nchunk + k) * 2) * C + j];
+        ab[i] = s;
+    }
+    __syncthreads();
+    const int cg = C / groups;
+    for (int i = tid; i < B * groups; i += blockDim.x * gridDim.x) {
+        const int b = i / groups, gi = i - b * groups;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = gi * cg; c < (gi + 1) * cg; ++c) {
+            s1 += gamma[c] * ab[(long long)b * 2 * C + c];
+            s2 += gamma[c] * ab[(long long)b * 2 * C + C + c];
+        }
+        const float n = (float)HW * (float)cg;
+        s12[2 * i] = s1 / n;
+        s12[2 * i + 1] = s2 / n;
+    }
+    for (int c = tid; c < C; c += blockDim.x * gridDim.x) {
+        float a = 0.f, bc = 0.f;
+        for (int b = 0; b < B; ++b) {
+            a += ab[(long long)b * 2 * C + c];
+            bc += ab[(long long)b * 2 * C + C + c];
+        }
+        dgamma[c] = accumulate ? dgamma[c] + bc : bc;
+        dbeta[c] = accumulate ? dbeta[c] + a : a;
+    }
+}
+
+// y = act((x-mean)*rstd*gamma+beta); float4 over channels
+__global__ void groupnorm_apply_kernel(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
+                                       const float* mean, const float* rstd, int B, int HW, int C, int groups, int silu) {
+    const int c4n = C / 4, cg = C / groups;
+    const long long n = (long long)B * HW * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const long long pix = i / c4n;
+        const int b = (int)(pix / HW);
+        const float4 v = *(const float4*)(x + pix * ldx + c);
+        const float4 ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
+        float in[4] = {v.x, v.y, v.z, v.w}, gaa[4] = {ga.x, ga.y, ga.z, ga.w}, bee[4] = {be.x, be.y, be.z, be.w}, o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int gi = (c + e) / cg;
+            const float z = (in[e] - mean[b * groups + gi]) * rstd[b * groups + gi] * gaa[e] + bee[e];
+            o[e] = silu ? cdf_silu(z) : z;
+        }
+        *(float4*)(y + pix * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// dx = rstd * (dz*gamma - s1 - xhat*s2)
+__global__ void groupnorm_bwd_apply_kernel(const float* dy, int lddy, const float* x, int ldx, const float* gamma,
+                                           const float* beta, const float* mean, const float* rstd, const float* s12,
+                                           float* dx, int lddx, int B, int HW, int C, int groups, int silu,
+                                           int accumulate) {
+    const int c4n = C / 4, cg = C / groups;
+    const long long n = (long long)B * HW * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const long long pix = i / c4n;
+        const int b = (int)(pix / HW);
+        const float4 v = *(const float4*)(x + pix * ldx + c), d = *(const float4*)(dy + pix * lddy + c);
+        const float4 ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
+        float in[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d.x, d.y, d.z, d.w}, gaa[4] = {ga.x, ga.y, ga.z, ga.w},
+              bee[4] = {be.x, be.y, be.z, be.w}, o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int gi = (c + e) / cg, sg = b * groups + gi;
+            const float rs = rstd[sg], xh = (in[e] - mean[sg]) * rs;
+            float dz = dd[e];
+            if (silu) dz *= cdf_silu_grad(xh * gaa[e] + bee[e]);
+            o[e] = rs * (dz * gaa[e] - s12[2 * sg] - xh * s12[2 * sg + 1]);
+        }
+        float* dst = dx + pix * lddx + c;
+        if (accumulate) {
+            const float4 old = *(const float4*)dst;
+            o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
+        }
+        *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+static int ln_geometry(int C, int* LP, int* NV) {
+    int lp = 1;
+    while (lp < 64 && lp * 4 < C) lp <<= 1;
+    *LP = lp;
+    *NV = cdf_cdiv(C, 4 * lp);
+    return (*NV >= 1 && *NV <= 4) ? CDF_OK : CDF_E_UNSUPPORTED;
+}
+
+extern "C" int cdf_layernorm_blocks(long long M, int C) {
+    int LP, NV;
+    if (ln_geometry(C, &LP, &NV)) return 0;
+    const long long groups_per_block = 4 * (64 / LP);
+    long long nb = (M + groups_per_block - 1) / groups_per_block;
+    if (nb > 2048) nb = 2048;
+    return nb < 1 ? 1 : (int)nb;
+}
+
+extern "C" int cdf_layernorm_c_fwd(const float* x, int ldx, float* y, int ldy, const float* g, const float* b,
+                                   float* mean, float* rstd, long long M, int C, float eps, void* stream) {
+    CDF_REQUIRE(x && y && g && b && M > 0, "cdf_layernorm_c_fwd: null / empty");
+    CDF_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && C <= 1024, "cdf_layernorm_c_fwd: C=%d must be a multiple of 4 and <= 1024", C);
+    int LP, NV;
+    CDF_REQUIRE(ln_geometry(C, &LP, &NV) == CDF_OK, "cdf_layernorm_c_fwd: unsupported C=%d", C);
+    const int nb = cdf_layernorm_blocks(M, C);
+#define CDF_LN_FWD(N) CDF_LAUNCH((layernorm_c_fwd_kernel<N>), dim3(nb), dim3(256), 0, CDF_S, x, ldx, y, ldy, g, b, mean, rstd, M, C, LP, eps)
+    switch (NV) {
+        case 1: CDF_LN_FWD(1); break;
+        case 2: CDF_LN_FWD(2); break;
+        case 3: CDF_LN_FWD(3); break;
+        default: CDF_LN_FWD(4); break;
+    }
+#undef CDF_LN_FWD
+    return cdf_check_launch("layernorm_c_fwd");
+}
+
+// part: >= cdf_layernorm_blocks(M, C) * 2 * C floats
+extern "C" int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, int ldx, const float* g,
+                                   const float* mean, const float* rstd, float* dx, int lddx, float* dg, float* db,
+                                   float* part, long long M, int C, int accumulate_dx, int accumulate_param,
+                                   void* stream) {
+    CDF_REQUIRE(dy && x && g && mean && rstd && dx && dg && db && part && M > 0, "cdf_layernorm_c_bwd: null / empty");
+    CDF_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && C <= 1024, "cdf_layernorm_c_bwd: bad C / pitch");
+    int LP, NV;
+    CDF_REQUIRE(ln_geometry(C, &LP, &NV) == CDF_OK, "cdf_layernorm_c_bwd: unsupported C=%d", C);
+    const int nb = cdf_layernorm_blocks(M, C);
+    const int G = 4 * (64 / LP);
+    const size_t lds = (size_t)G * 2 * C * sizeof(float);
+#ifndef CDF_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)layernorm_c_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)layernorm_c_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)layernorm_c_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)layernorm_c_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+#endif
+#define CDF_LN_BWD(N) CDF_LAUNCH((layernorm_c_bwd_kernel<N>), dim3(nb), dim3(256), lds, CDF_S, dy, lddy, x, ldx, g, mean, rstd, dx, lddx, part, M, C, LP, accumulate_dx)
+    switch (NV) {
+        case 1: CDF_LN_BWD(1); break;
+        case 2: CDF_LN_BWD(2); break;
+        case 3: CDF_LN_BWD(3); break;
+        default: CDF_LN_BWD(4); break;
+    }
+#undef CDF_LN_BWD
+    CDF_LAUNCH(norm_param_reduce_kernel, dim3(cdf_cdiv(2 * C, 256)), dim3(256), 0, CDF_S, (const float*)part, nb, C, dg, db, accumulate_param);
+    return cdf_check_launch("layernorm_c_bwd");
+}
+
+extern "C" int cdf_groupnorm_nchunk(int HW) {
+    int n = HW / 256;
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    return n;
+}
+
+// ws: >= B * nchunk * 2 * C floats ; mean/rstd: [B][groups]
+extern "C" int cdf_groupnorm_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
+                                 float* mean, float* rstd, float* ws, int B, int HW, int C, int groups, float eps,
+                                 int silu, void* stream) {
+    CDF_REQUIRE(x && y && gamma && beta && mean && rstd && ws, "cdf_groupnorm_fwd: null pointer");
+    CDF_REQUIRE(C % groups == 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "cdf_groupnorm_fwd: C=%d groups=%d", C, groups);
+    const int nchunk = cdf_groupnorm_nchunk(HW), rpc = cdf_cdiv(HW, nchunk);
+    CDF_LAUNCH(groupnorm_partial_kernel, dim3(cdf_cdiv(C, 64), nchunk, B), dim3(256), 0, CDF_S, x, ldx, (const float*)nullptr, 0,
+               gamma, beta, (const float*)nullptr, (const float*)nullptr, ws, HW, rpc, C, groups, 0, 0);
+    CDF_LAUNCH(groupnorm_stats_kernel, dim3(B), dim3(64), 0, CDF_S, (const float*)ws, nchunk, C, groups, HW, eps, mean, rstd);
+    const long long n = (long long)B * HW * (C / 4);
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    CDF_LAUNCH(groupnorm_apply_kernel, dim3(grid), dim3(256), 0, CDF_S, x, ldx, y, ldy, gamma, beta, (const float*)mean, (const float*)rstd, B, HW, C, groups, silu);
+    return cdf_check_launch("groupnorm_fwd");
+}
+
+// ws: >= B*nchunk*2*C + B*2*C + B*groups*2 floats
+extern "C" int cdf_groupnorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma,
+                                 const float* beta, const float* mean, const float* rstd, float* dx, int lddx,
+                                 float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int groups, int silu,
+                                 int accumulate_dx, int accumulate_param, void* stream) {
+    CDF_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta && ws, "cdf_groupnorm_bwd: null pointer");
+    CDF_REQUIRE(C % groups == 0 && C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "cdf_groupnorm_bwd: bad C / pitch");
+    const int nchunk = cdf_groupnorm_nchunk(HW), rpc = cdf_cdiv(HW, nchunk);
+    float* part = ws;
+    float* ab = part + (size_t)B * nchunk * 2 * C;
+    float* s12 = ab + (size_t)B * 2 * C;
+    CDF_LAUNCH(groupnorm_partial_kernel, dim3(cdf_cdiv(C, 64), nchunk, B), dim3(256), 0, CDF_S, x, ldx, dy, lddy, gamma, beta, mean, rstd,
+               part, HW, rpc, C, groups, 1, silu);
+    CDF_LAUNCH(groupnorm_bwd_finalize_kernel, dim3(1), dim3(1024), 0, CDF_S, (const float*)part, nchunk, B, C, groups, HW, gamma, s12,
+               dgamma, dbeta, ab, accumulate_param);
+    const long long n = (long long)B * HW * (C / 4);
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    CDF_LAUNCH(groupnorm_bwd_apply_kernel, dim3(grid), dim3(256), 0, CDF_S, dy, lddy, x, ldx, gamma, beta, mean, rstd, (const float*)s12,
+               dx, lddx, B, HW, C, groups, silu, accumulate_dx);
+    return cdf_check_launch("groupnorm_bwd");
+}

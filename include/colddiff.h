@@ -84,6 +84,120 @@ int cdf_loss_bwd(const float* x, const float* y, const float* gout, float* gy, l
 int cdf_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, int ldy, void* stream);
 int cdf_nhwc_to_nchw(const float* x, float* y, const float* add, int B, int C, int HW, int ldx, void* stream);
 
+/* ---- dense convolutions / linear layers as MFMA implicit GEMM ---------------------------------
+ * Replaces nn.Conv2d (3x3, 1x1, 4x4 stride 2), nn.ConvTranspose2d (4x4 stride 2) and nn.Linear
+ * forward and backward: deblurring_diffusion_pytorch.py:105-109,140-154,173-174,211-216,253 and
+ * Model2.py:36-73,85-112,148-163.
+ *
+ * cdf_conv_gemm:  Y[m,co] = epi( sum_{tap,ci} X[pix(m,tap),ci] * Wp[wi(tap)][ci][co] )
+ *   m = (b,qy,qx) over a per-phase QHxQW grid; input pixel (qy*is+dy, qx*is+dx), zero outside HxW;
+ *   output pixel (qy*os+oy, qx*os+ox) of an OHxOW map.  phase_desc = per phase
+ *   [oy, ox, ntaps, (dy, dx, wi) x ntaps] (ints, host memory).  Wp is [tap][Cin][ldw] (cdf_pack_weight)
+ *   or, with b_trans, a plain [Cout][ldw>=Cin] matrix (one tap).  Epilogue, in order:
+ *   v = acc + bias[co] + sbias[b][co]; pre = v; v = act(v) (1 GELU, 2 SiLU);
+ *   v *= {1: gelu'(mul), 2: silu'(mul), 3: mul}; v += res; accumulate ? y += v : y = v.
+ *   batch > 1 runs independent GEMMs (blockIdx.z) with element strides x_bs / w_bs / y_bs. */
+int cdf_conv_gemm(const float* x, int ldx, const float* w, int ldw, float* y, int ldy, int B, int H, int W, int Cin,
+                  int OH, int OW, int Cout, int QH, int QW, int os, int is, int nphase, const int* phase_desc,
+                  const float* bias, const float* sbias, int ld_sbias, const float* res, int ldr, float* pre, int ldp,
+                  const float* mul, int ldm, int act, int mul_mode, int accumulate, int b_trans, int batch,
+                  long long x_bs, long long w_bs, long long y_bs, void* stream);
+
+/* cdf_conv_wgrad: ws[z][tap][ca][cb] = sum_{m in split z} XA[pixA(m,tap)][ca] * XB[pixB(m,tap)][cb]
+ *   m = (b,qy,qx); pixA = (qy*sa+day, qx*sa+dax) in HAxWA, pixB likewise; tap_desc = (day,dax,dby,dbx) x ntaps.
+ *   ws holds nsplit (x batch) slabs of [ntaps][CA][ldo]; cdf_unpack_reduce sums the slabs into the
+ *   parameter-gradient tensor in its PyTorch layout. */
+int cdf_wgrad_nsplit(int M, int CA, int CB, int ntaps);
+int cdf_conv_wgrad(const float* xa, int lda, const float* xb, int ldb, float* ws, int ldo, int B, int QH, int QW,
+                   int HA, int WA, int sa, int HB, int WB, int sb, int CA, int CB, int ntaps, const int* tap_desc,
+                   int nsplit, int batch, long long a_bs, long long b_bs, long long o_bs, void* stream);
+
+/* parameter layout <-> GEMM layout: dst[t][r][c] = src[c*s_c + r*s_r + t*s_t] (c >= C zero-filled up to ldc);
+ * g[c*s_c + r*s_r + t*s_t] (+)= sum_z ws[z][t][r][c] */
+int cdf_pack_weight(const float* src, float* dst, int T, int R, int C, int ldc, long long s_t, long long s_r,
+                    long long s_c, void* stream);
+int cdf_unpack_reduce(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t,
+                      long long s_r, long long s_c, int accumulate, void* stream);
+
+/* out[seg][c] (+)= sum over the rows of segment seg of x[r*ld + c]  (bias / time-bias gradients);
+ * ws >= nseg * cdf_colsum_nchunk(rows_per_seg) * C floats */
+int cdf_colsum_nchunk(int rows_per_seg);
+int cdf_colsum(const float* x, float* out, float* ws, int nseg, int rows_per_seg, int C, int ld, int ldo,
+               int accumulate, void* stream);
+
+/* ---- normalisation ------------------------------------------------------------------------------
+ * channel LayerNorm (deblurring_diffusion_pytorch.py:111-121): per-pixel over C, biased variance,
+ * y = (x-mean)/sqrt(var+eps)*g+b; mean/rstd [M] are saved for backward (nullable in inference).
+ * backward also produces dg/db; part >= cdf_layernorm_blocks(M,C)*2*C floats of scratch. */
+int cdf_layernorm_blocks(long long M, int C);
+int cdf_layernorm_c_fwd(const float* x, int ldx, float* y, int ldy, const float* g, const float* b, float* mean,
+                        float* rstd, long long M, int C, float eps, void* stream);
+int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, int ldx, const float* g, const float* mean,
+                        const float* rstd, float* dx, int lddx, float* dg, float* db, float* part, long long M, int C,
+                        int accumulate_dx, int accumulate_param, void* stream);
+/* GroupNorm(groups) [+ SiLU] (Model2.py:27-33): statistics per (sample, group) over C/groups channels
+ * and all HW pixels; mean/rstd [B][groups].  fwd ws >= B*nchunk*2*C floats;
+ * bwd ws >= B*nchunk*2*C + B*2*C + B*groups*2 floats, nchunk = cdf_groupnorm_nchunk(HW). */
+int cdf_groupnorm_nchunk(int HW);
+int cdf_groupnorm_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta, float* mean,
+                      float* rstd, float* ws, int B, int HW, int C, int groups, float eps, int silu, void* stream);
+int cdf_groupnorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta,
+                      const float* mean, const float* rstd, float* dx, int lddx, float* dgamma, float* dbeta, float* ws,
+                      int B, int HW, int C, int groups, int silu, int accumulate_dx, int accumulate_param,
+                      void* stream);
+
+/* ---- depthwise 7x7 (ConvNeXt ds_conv + time bias, deblurring_diffusion_pytorch.py:145,157-162) ---
+ * w packed [49][ldw] (cdf_pack_weight, R=1); flip=1 mirrors the taps (data gradient).
+ * wgrad: dw in the parameter layout [C][1][7][7], dbias [C], dsb [B][ld_dsb] (time-bias gradient,
+ * overwritten); ws >= B * cdf_dwconv7_wgrad_nchunk(H) * 50 * C floats. */
+int cdf_dwconv7(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias, int ld_sbias,
+                float* y, int ldy, int B, int H, int W, int C, int flip, int accumulate, void* stream);
+int cdf_dwconv7_wgrad_nchunk(int H);
+int cdf_dwconv7_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* dbias, float* dsb,
+                      int ld_dsb, float* ws, int B, int H, int W, int C, int accumulate, void* stream);
+
+/* ---- attention -------------------------------------------------------------------------------------
+ * LinearAttention core (deblurring_diffusion_pytorch.py:176-187) on qkv [B,n,ld] = (q|k|v), each
+ * heads*32 channels: out [B,n,ldo]; ctx [B,heads,32,32], kmax/ksum [B,heads*32] saved for backward.
+ * ws >= cdf_linattn_ws_floats(B,n,heads) floats.  bwd writes dqkv = (dq|dk|dv). */
+int cdf_linattn_nsplit(int n);
+size_t cdf_linattn_ws_floats(int B, int n, int heads);
+int cdf_linattn_fwd(const float* qkv, int ld, float* out, int ldo, float* ctx, float* kmax, float* ksum, float* ws,
+                    int B, int n, int heads, float scale, void* stream);
+int cdf_linattn_bwd(const float* qkv, int ld, const float* dout, int lddo, const float* ctx, const float* kmax,
+                    const float* ksum, float* dqkv, int lddq, float* dctx, float* rvec, float* ws, int B, int n,
+                    int heads, float scale, void* stream);
+/* AttnBlock (Model2.py:164-188) row softmax of the score matrix: p = softmax(scale*s) per row;
+ * ds = scale * p * (dp - sum(dp*p)) */
+int cdf_softmax_rows_fwd(const float* s, float* p, long long rows, int n, int ld, float scale, void* stream);
+int cdf_softmax_rows_bwd(const float* p, const float* dp, float* ds, long long rows, int n, int ld, float scale,
+                         void* stream);
+
+/* ---- small fused ops ---------------------------------------------------------------------------------
+ * sinusoidal time embedding (DEBLUR:91-103, MODEL2:6-24): out[b] = (sin(t f_j) | cos(t f_j)) */
+int cdf_sinusoidal(const int64_t* t, float* out, int ldo, int B, int dim, void* stream);
+/* act 1 = exact GELU, 2 = SiLU on [rows, C] with pitches */
+int cdf_act_fwd(const float* x, int ldx, float* y, int ldy, long long rows, int C, int act, void* stream);
+int cdf_act_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, long long rows, int C, int act,
+                int accumulate, void* stream);
+/* dst = alpha*dst + beta*src (alpha == 0 ignores the old dst) */
+int cdf_axpby(float* dst, int ldd, const float* src, int lds, long long rows, int C, float alpha, float beta,
+              void* stream);
+/* nearest x2 upsample (Model2.py:47) and its adjoint */
+int cdf_upsample2(const float* x, int ldx, float* y, int ldy, int B, int H, int W, int C, void* stream);
+int cdf_upsample2_bwd(const float* dy, int lddy, float* dx, int lddx, int B, int H, int W, int C, int accumulate,
+                      void* stream);
+/* dropout with a counter-based mask (same seed => same mask, used again in backward) */
+int cdf_dropout(const float* x, int ldx, float* y, int ldy, long long rows, int C, float p, long long seed,
+                void* stream);
+/* torch.optim.Adam defaults over a flat arena (DEBLUR:1117,1200); `step` is the 1-based step count */
+int cdf_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2,
+                  double eps, int step, void* stream);
+/* EMA.update_average (DEBLUR:78-81): ma = ma*beta + (1-beta)*p */
+int cdf_ema_update(float* ma, const float* p, long long n, double beta, void* stream);
+int cdf_scale(float* x, long long n, float s, void* stream);
+int cdf_zero(void* p, long long bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,70 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(REPO, "cold-diffusion-models_amd"), os.path.join(REPO, "tests"), REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Backend:
+    """Where a kernel-level test runs.
+
+    'hip' : the product library libcolddiff_hip.so on cuda:0 (tests marked gpu)
+    'emu' : the same kernel sources compiled against the host SIMT simulator (tests/emu) on CPU
+            tensors — CPU-only test infrastructure for the kernels' indexing logic.
+    """
+
+    def __init__(self, kind):
+        import torch
+        self.kind = kind
+        self._keep = []
+        if kind == "hip":
+            from colddiff import _lib
+            self.L = _lib.get()
+            assert self.L.cdf_is_device_build() == 1
+            self.device = torch.device("cuda:0")
+        else:
+            from emu_util import emu_lib
+            self.L = emu_lib()
+            self.device = torch.device("cpu")
+
+    def to(self, t):
+        """Device copy of t; kept alive until the end of the test (tests pass raw pointers inline)."""
+        out = t.detach().to(self.device).contiguous().clone()
+        self._keep.append(out)
+        return out
+
+    def empty(self, *shape):
+        import torch
+        return torch.empty(*shape, device=self.device, dtype=torch.float32)
+
+    def zeros(self, *shape):
+        import torch
+        return torch.zeros(*shape, device=self.device, dtype=torch.float32)
+
+    def stream(self):
+        import torch
+        return torch.cuda.current_stream().cuda_stream if self.kind == "hip" else 0
+
+
+@pytest.fixture(scope="session", params=[pytest.param("emu"), pytest.param("hip", marks=pytest.mark.gpu)])
+def be(request):
+    return Backend(request.param)
+
+
+@pytest.fixture(autouse=True)
+def _release_kept_tensors(request):
+    yield
+    if "be" in request.fixturenames:
+        import torch
+        b = request.getfixturevalue("be")
+        if b.kind == "hip":
+            torch.cuda.synchronize()
+        b._keep.clear()

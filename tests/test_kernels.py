@@ -1,0 +1,428 @@
+"""Kernel-level parity tests: every C-ABI entry point against a plain torch fp32 CPU reference of
+the reference op it replaces.  Each test runs on two backends (see conftest.Backend):
+  emu : host SIMT simulator build, small shapes (not gpu)       — indexing logic
+  hip : libcolddiff_hip.so on a real MI355X (@pytest.mark.gpu)  — the product
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from colddiff import convdesc as cd
+
+
+def P(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def r4(c):
+    return (c + 3) // 4 * 4
+
+
+def nhwc(x, ld=None):
+    B, C, H, W = x.shape
+    ld = ld or r4(C)
+    out = torch.zeros(B, H, W, ld)
+    out[..., :C] = x.detach().permute(0, 2, 3, 1)
+    return out
+
+
+def err(a, b):
+    return (a.cpu() - b.cpu()).abs().max().item()
+
+
+# ---------------------------------------------------------------------------------------------
+# degradations
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H,k,mode", [(16, 3, "circular"), (16, 11, "reflect"), (32, 11, "circular"), (16, 5, "reflect"),
+                                      (32, 15, "reflect"), (12, 3, "reflect")])
+def test_blur_chain(be, H, k, mode):
+    torch.manual_seed(0)
+    B, C, T = 3, 3, 5
+    x = torch.randn(B, C, H, H)
+    taps = torch.rand(T, C, k, k)
+    taps /= taps.sum((2, 3), keepdim=True)
+    t = torch.tensor([4, 2, 0])
+    xd, tapsd, td = be.to(x), be.to(taps), t.to(be.device)
+    y, snap = be.empty(B, C, H, H), be.empty(B, C, H, H)
+    be.L.cdf_blur_chain(P(xd), P(y), P(snap), 0, P(tapsd), P(td), B, C, H, H, k, 0, 0, 0 if mode == "circular" else 1, -1, 0, be.stream())
+
+    def step(z, i):
+        return F.conv2d(F.pad(z, (k // 2,) * 4, mode=mode), taps[i].unsqueeze(1), groups=C)
+
+    ref, refp = [], []
+    for b in range(B):
+        z = x[b:b + 1]
+        prev = z
+        for i in range(int(t[b]) + 1):
+            prev, z = z, step(z, i)
+        ref.append(z)
+        refp.append(prev)
+    ref, refp = torch.cat(ref), torch.cat(refp)
+    assert err(y, ref) <= 2e-6 and err(snap, refp) <= 2e-6
+    # Algorithm-2 combine: img - D_t + D_{t-1}
+    img = torch.randn(B, C, H, H)
+    out = be.empty(B, C, H, H)
+    be.L.cdf_blur_chain(P(xd), P(out), 0, P(be.to(img)), P(tapsd), P(td), B, C, H, H, k, 0, 0, 0 if mode == "circular" else 1, -1, 0, be.stream())
+    assert err(out, img - ref + refp) <= 4e-6
+    # discrete: mean collapse after step 2 + 8-bit truncation
+    yq = be.empty(B, C, H, H)
+    be.L.cdf_blur_chain(P(xd), P(yq), 0, 0, P(tapsd), 0, B, C, H, H, k, 0, 2, 0 if mode == "circular" else 1, 2, 1, be.stream())
+    z = x
+    for i in range(3):
+        z = step(z, i)
+    z = z.mean((2, 3), keepdim=True).expand_as(x)
+    zq = ((z + 1) * 0.5 * 255).int().float() / 255 * 2 - 1
+    d = (yq.cpu() - zq).abs()
+    # truncation may flip one 8-bit level (2/255) where the mean differs in the last ulp
+    assert (d <= 1e-6).logical_or((d - 2 / 255).abs() <= 1e-6).all()
+
+
+def test_blur_step_global(be):
+    torch.manual_seed(1)
+    B, C, H, W, k = 2, 3, 10, 14, 5
+    x, taps = torch.randn(B, C, H, W), torch.rand(C, k, k)
+    y = be.empty(B, C, H, W)
+    be.L.cdf_blur_step(P(be.to(x)), P(y), P(be.to(taps)), B, C, H, W, k, 1, be.stream())
+    ref = F.conv2d(F.pad(x, (k // 2,) * 4, mode="reflect"), taps.unsqueeze(1), groups=C)
+    assert err(y, ref) <= 2e-6
+
+
+@pytest.mark.parametrize("H", [16, 32])
+@pytest.mark.parametrize("mode_i,mode", [(0, "area"), (1, "bilinear"), (2, "bicubic")])
+@pytest.mark.parametrize("routine", ["factor2", "incr"])
+def test_pixelate_chain(be, H, mode_i, mode, routine):
+    torch.manual_seed(0)
+    B, C = 2, 3
+    T = 3 if routine == "factor2" else 6
+    sizes = [H // 2 ** (i + 1) for i in range(T)] if routine == "factor2" else [H - i for i in range(T)]
+    x = torch.randn(B, C, H, H)
+    t = torch.tensor([T - 1, 1])
+    y, snap = be.empty(B, C, H, H), be.empty(B, C, H, H)
+    sz = torch.tensor(sizes, dtype=torch.int32).to(be.device)
+    be.L.cdf_pixelate_chain(P(be.to(x)), P(y), P(snap), 0, P(sz), P(t.to(be.device)), B, C, H, 0, 0, mode_i, be.stream())
+
+    def step(z, i):
+        z1 = F.interpolate(z, size=sizes[i], mode=mode, antialias=False)
+        return F.interpolate(z1, size=H, mode="nearest-exact")
+
+    ref, refp = [], []
+    for b in range(B):
+        z = x[b:b + 1]
+        prev = z
+        for i in range(int(t[b]) + 1):
+            prev, z = z, step(z, i)
+        ref.append(z)
+        refp.append(prev)
+    tol = 0.0 if mode == "area" else 1e-5   # area + nearest-exact indexing is bit-exact
+    assert err(y, torch.cat(ref)) <= tol and err(snap, torch.cat(refp)) <= tol
+
+
+def test_mask_noise_loss_layout(be):
+    torch.manual_seed(0)
+    L, S = be.L, be.stream()
+    B, C, H, T = 3, 3, 16, 6
+    x, masks = torch.randn(B, C, H, H), torch.rand(T, 2 * H + 1, 2 * H + 1)
+    t, oy, ox = torch.tensor([5, 0, 3]), torch.tensor([0, 7, 16]), torch.tensor([3, 0, 16])
+    y, snap = be.empty(B, C, H, H), be.empty(B, C, H, H)
+    L.cdf_mask_chain(P(be.to(x)), P(y), P(snap), 0, P(be.to(masks)), P(t.to(be.device)), P(oy.to(be.device)), P(ox.to(be.device)),
+                     B, C, H, H, 2 * H + 1, 2 * H + 1, 0, 0, 0, S)
+    ref = []
+    for b in range(B):
+        z = x[b]
+        for i in range(int(t[b]) + 1):
+            z = masks[i][oy[b]:oy[b] + H, ox[b]:ox[b] + H] * z
+        ref.append(z)
+    assert err(y, torch.stack(ref)) == 0.0          # sequential products, bit-exact
+    ca, cb = torch.rand(10), torch.rand(10)
+    x0, eps, t = torch.randn(B, C, H, H), torch.randn(B, C, H, H), torch.tensor([9, 0, 4])
+    out = be.empty(B, C, H, H)
+    L.cdf_noise_qsample(P(be.to(x0)), P(be.to(eps)), P(be.to(ca)), P(be.to(cb)), P(t.to(be.device)), P(out), B, C * H * H, S)
+    assert err(out, ca[t].view(-1, 1, 1, 1) * x0 + cb[t].view(-1, 1, 1, 1) * eps) == 0.0
+    for tt in (5, 1):
+        for est in (0, 1):
+            img, x1 = torch.randn(B, C, H, H), torch.randn(B, C, H, H)
+            L.cdf_noise_step(P(be.to(img)), P(be.to(x1)), P(be.to(eps)), P(be.to(ca)), P(be.to(cb)), tt, est, P(out), img.numel(), S)
+            x2 = (img - ca[tt - 1] * x1) / cb[tt - 1] if est else eps
+            xt = ca[tt - 1] * x1 + cb[tt - 1] * x2
+            xs = ca[tt - 2] * x1 + cb[tt - 2] * x2 if tt - 1 != 0 else x1
+            assert err(out, img - xt + xs) <= (2e-6 if est else 0.0)
+    a, b = torch.randn(4, 3, 16, 16), torch.randn(4, 3, 16, 16)
+    for l2 in (0, 1):
+        o, part, g, gy = be.zeros(1), be.zeros(1024), be.to(torch.tensor([0.5])), be.empty(4, 3, 16, 16)
+        L.cdf_loss_fwd(P(be.to(a)), P(be.to(b)), P(o), P(part), a.numel(), l2, S)
+        L.cdf_loss_bwd(P(be.to(a)), P(be.to(b)), P(g), P(gy), a.numel(), l2, S)
+        bb = b.clone().requires_grad_()
+        ref = (a - bb).abs().mean() if not l2 else F.mse_loss(a, bb)
+        (ref * 0.5).backward()
+        assert abs(o.item() - ref.item()) <= 1e-6 * max(1, abs(ref.item())) and err(gy, bb.grad) <= 1e-7
+    xx, yy = torch.randn(2, 5, 4, 4), be.zeros(2, 4, 4, 8)
+    L.cdf_nchw_to_nhwc(P(be.to(xx)), P(yy), 2, 5, 16, 8, S)
+    assert err(yy[..., :5], xx.permute(0, 2, 3, 1)) == 0.0
+    zz = be.empty(2, 5, 4, 4)
+    L.cdf_nhwc_to_nchw(P(yy), P(zz), P(be.to(xx)), 2, 5, 16, 8, S)
+    assert err(zz, 2 * xx) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------
+# MFMA implicit-GEMM convolutions (fwd / dgrad / wgrad)
+# ---------------------------------------------------------------------------------------------
+def _pack(be, w, T, R, C, s_t, s_r, s_c):
+    dst = be.empty(T, R, r4(C))
+    be.L.cdf_pack_weight(P(be.to(w)), P(dst), T, R, C, r4(C), s_t, s_r, s_c, be.stream())
+    return dst
+
+
+def _gemm(be, plan, x, w, B, Cin, Cout, bias=None, sbias=None, res=None, pre=None, mul=None, act=0, mul_mode=0, acc=0, y=None):
+    if y is None:
+        y = be.zeros(B, plan.OH, plan.OW, r4(Cout))
+    ld = lambda t_: 0 if t_ is None else t_.shape[-1]
+    be.L.cdf_conv_gemm(P(x), x.shape[-1], P(w), w.shape[-1], P(y), y.shape[-1], B, plan.H, plan.W, Cin, plan.OH, plan.OW, Cout,
+                       plan.QH, plan.QW, plan.os, plan.istride, plan.nphase, plan.desc, P(bias), P(sbias), ld(sbias), P(res), ld(res),
+                       P(pre), ld(pre), P(mul), ld(mul), act, mul_mode, acc, 0, 1, 0, 0, 0, be.stream())
+    return y
+
+
+CONV_CASES = [(2, 8, 8, 8, 3, 1, 1, False), (1, 3, 20, 8, 3, 1, 1, False), (2, 16, 40, 8, 1, 1, 0, False), (1, 8, 8, 8, 4, 2, 1, False),
+              (1, 8, 8, 4, 4, 2, 1, True), (1, 36, 130, 8, 3, 1, 1, False), (3, 20, 3, 4, 1, 1, 0, False)]
+CONV_CASES_GPU = [(4, 64, 128, 32, 3, 1, 1, False), (2, 128, 64, 32, 3, 1, 1, False), (2, 64, 64, 32, 4, 2, 1, False),
+                  (2, 64, 64, 16, 4, 2, 1, True), (2, 256, 512, 16, 3, 1, 1, False), (3, 64, 3, 32, 1, 1, 0, False), (2, 3, 128, 64, 3, 1, 1, False)]
+
+
+def _conv_case(be, B, Cin, Cout, H, k, s, p, transposed):
+    torch.manual_seed(0)
+    x = torch.randn(B, Cin, H, H, requires_grad=True)
+    wshape = (Cin, Cout, k, k) if transposed else (Cout, Cin, k, k)
+    w = (torch.randn(*wshape) * (1.0 / math.sqrt(Cin * k * k))).requires_grad_()
+    bias = torch.randn(Cout)
+    yref = F.conv_transpose2d(x, w, bias, stride=s, padding=p) if transposed else F.conv2d(x, w, bias, stride=s, padding=p)
+    gy = torch.randn_like(yref)
+    yref.backward(gy)
+    xn, gyn, KK = be.to(nhwc(x)), be.to(nhwc(gy)), k * k
+    if not transposed:
+        plan, pd, wg = cd.conv_fwd(H, H, k, k, s, p, p, p, p), cd.conv_dgrad(H, H, k, k, s, p, p, p, p), cd.conv_wgrad(H, H, k, k, s, p, p, p, p)
+        wp, wd = _pack(be, w, KK, Cin, Cout, 1, KK, Cin * KK), _pack(be, w, KK, Cout, Cin, 1, Cin * KK, KK)
+        s_r, s_c = KK, Cin * KK
+    else:
+        plan, pd, wg = cd.convT_fwd(H, H, k, k, s, p), cd.convT_dgrad(H, H, k, k, s, p), cd.convT_wgrad(H, H, k, k, s, p)
+        wp, wd = _pack(be, w, KK, Cin, Cout, 1, Cout * KK, KK), _pack(be, w, KK, Cout, Cin, 1, KK, Cout * KK)
+        s_r, s_c = Cout * KK, KK
+    y = _gemm(be, plan, xn, wp, B, Cin, Cout, bias=be.to(bias))
+    dx = _gemm(be, pd, gyn, wd, B, Cout, Cin)
+    M = B * wg.QH * wg.QW
+    ns = max(1, min(be.L.cdf_wgrad_nsplit(M, Cin, Cout, KK), M // 16))
+    ldo = r4(Cout)
+    ws = be.empty(ns, KK, Cin, ldo)
+    be.L.cdf_conv_wgrad(P(xn), xn.shape[-1], P(gyn), gyn.shape[-1], P(ws), ldo, B, wg.QH, wg.QW, wg.HA, wg.WA, wg.sa, wg.HB, wg.WB, wg.sb,
+                        Cin, Cout, wg.ntaps, wg.desc, ns, 1, 0, 0, 0, be.stream())
+    dw = be.zeros(*wshape)
+    be.L.cdf_unpack_reduce(P(ws), P(dw), ns, KK, Cin, Cout, ldo, 1, s_r, s_c, 0, be.stream())
+    tol = lambda ref: 2e-6 * max(1.0, ref.abs().max().item()) * math.sqrt(max(Cin * KK, 16))
+    assert err(y[..., :Cout].permute(0, 3, 1, 2), yref) <= tol(yref)
+    assert err(dx[..., :Cin].permute(0, 3, 1, 2), x.grad) <= tol(x.grad)
+    assert err(dw, w.grad) <= 2e-6 * max(1.0, w.grad.abs().max().item()) * math.sqrt(M)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_gemm(be, case):
+    _conv_case(be, *case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CONV_CASES_GPU)
+def test_conv_gemm_large(case):
+    from conftest import Backend
+    _conv_case(Backend("hip"), *case)
+
+
+def test_conv_epilogue_and_batched(be):
+    """bias + per-sample bias + GELU (+pre) + residual; activation-gradient multiply; batched NT GEMM."""
+    torch.manual_seed(0)
+    B, Cin, Cout, H = 2, 8, 12, 4
+    x, w = torch.randn(B, Cin, H, H), torch.randn(Cout, Cin, 3, 3) * 0.2
+    bias, sb, res = torch.randn(Cout), torch.randn(B, Cout), torch.randn(B, Cout, H, H)
+    plan = cd.conv_fwd(H, H, 3, 3, 1, 1, 1, 1, 1)
+    wp = _pack(be, w, 9, Cin, Cout, 1, 9, Cin * 9)
+    pre = be.zeros(B, H, H, r4(Cout))
+    y = _gemm(be, plan, be.to(nhwc(x)), wp, B, Cin, Cout, bias=be.to(bias), sbias=be.to(sb), res=be.to(nhwc(res)), pre=pre, act=1)
+    z = F.conv2d(x, w, bias, padding=1) + sb[:, :, None, None]
+    assert err(pre[..., :Cout].permute(0, 3, 1, 2), z) <= 1e-5
+    assert err(y[..., :Cout].permute(0, 3, 1, 2), F.gelu(z) + res) <= 1e-5
+    mulsrc = torch.randn(B, Cout, H, H)
+    for mode, fn in ((1, lambda v: torch.autograd.functional.jvp(F.gelu, v, torch.ones_like(v))[1]),
+                     (2, lambda v: torch.autograd.functional.jvp(F.silu, v, torch.ones_like(v))[1]), (3, lambda v: v)):
+        y2 = _gemm(be, plan, be.to(nhwc(x)), wp, B, Cin, Cout, mul=be.to(nhwc(mulsrc)), mul_mode=mode)
+        assert err(y2[..., :Cout].permute(0, 3, 1, 2), F.conv2d(x, w, padding=1) * fn(mulsrc)) <= 1e-5
+    y3 = _gemm(be, plan, be.to(nhwc(x)), wp, B, Cin, Cout, acc=1, y=be.to(nhwc(res)))
+    assert err(y3[..., :Cout].permute(0, 3, 1, 2), F.conv2d(x, w, padding=1) + res) <= 1e-5
+    # batched S[b] = q[b] @ k[b]^T  (b_trans) and O[b] = P[b] @ v[b]
+    nb, n, C = 3, 20, 16
+    q, k = torch.randn(nb, n, C), torch.randn(nb, n, C)
+    S = be.zeros(nb, n, r4(n))
+    one = cd.conv_fwd(1, n, 1, 1, 1, 0, 0, 0, 0)
+    qd, kd = be.to(q), be.to(k)
+    be.L.cdf_conv_gemm(P(qd), C, P(kd), C, P(S), r4(n), 1, 1, n, C, 1, n, n, 1, n, 1, 1, 1, one.desc, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                       0, 0, 0, 1, nb, n * C, n * C, n * r4(n), be.stream())
+    assert err(S[..., :n], q @ k.transpose(1, 2)) <= 1e-5
+    # wgrad kernel as batched A^T B:  dv[b] = P[b]^T dO[b]
+    Pm, dO = torch.randn(nb, n, r4(n)), torch.randn(nb, n, C)
+    ws = be.empty(nb, n, C)
+    tap = cd.conv_wgrad(1, n, 1, 1, 1, 0, 0, 0, 0)
+    be.L.cdf_conv_wgrad(P(be.to(Pm)), r4(n), P(be.to(dO)), C, P(ws), C, 1, 1, n, 1, n, 1, 1, n, 1, n, C, 1, tap.desc, 1, nb,
+                        n * r4(n), n * C, n * C, be.stream())
+    assert err(ws, Pm[..., :n].transpose(1, 2) @ dO) <= 1e-5
+
+
+def test_colsum(be):
+    torch.manual_seed(0)
+    x = torch.randn(3, 700, 72)
+    nch = be.L.cdf_colsum_nchunk(700)
+    ws, out = be.empty(3 * nch * 70), be.zeros(3, 72)
+    be.L.cdf_colsum(P(be.to(x)), P(out), P(ws), 3, 700, 70, 72, 72, 0, be.stream())
+    assert err(out[:, :70], x[..., :70].sum(1)) <= 2e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# norms, depthwise conv, attention, small ops
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,C", [(37, 8), (20, 64), (9, 128), (5, 512), (3, 1024), (6, 96)])
+def test_layernorm_c(be, M, C):
+    torch.manual_seed(0)
+    x, g, b = torch.randn(M, C, requires_grad=True), torch.randn(C, requires_grad=True), torch.randn(C, requires_grad=True)
+    var, mean = torch.var(x, dim=1, unbiased=False, keepdim=True), x.mean(1, keepdim=True)
+    yref = (x - mean) / (var + 1e-5).sqrt() * g + b
+    dy = torch.randn(M, C)
+    yref.backward(dy)
+    xd, gd, bd = be.to(x), be.to(g), be.to(b)
+    y, mo, ro = be.empty(M, C), be.empty(M), be.empty(M)
+    be.L.cdf_layernorm_c_fwd(P(xd), C, P(y), C, P(gd), P(bd), P(mo), P(ro), M, C, 1e-5, be.stream())
+    nb = be.L.cdf_layernorm_blocks(M, C)
+    part, dx, dg, db = be.empty(nb * 2 * C), be.empty(M, C), be.zeros(C), be.zeros(C)
+    be.L.cdf_layernorm_c_bwd(P(be.to(dy)), C, P(xd), C, P(gd), P(mo), P(ro), P(dx), C, P(dg), P(db), P(part), M, C, 0, 0, be.stream())
+    assert err(y, yref) <= 5e-6 and err(dx, x.grad) <= 1e-5 and err(dg, g.grad) <= 2e-5 and err(db, b.grad) <= 2e-5
+
+
+@pytest.mark.parametrize("B,HW,C,silu", [(2, 16, 32, 1), (3, 64, 64, 1), (1, 16, 128, 0), (2, 300, 96, 1)])
+def test_groupnorm(be, B, HW, C, silu):
+    torch.manual_seed(0)
+    x, ga, bt = torch.randn(B, HW, C, requires_grad=True), torch.randn(C, requires_grad=True), torch.randn(C, requires_grad=True)
+    z = F.group_norm(x.permute(0, 2, 1).reshape(B, C, HW, 1), 32, ga, bt, eps=1e-6)
+    yref = (z * torch.sigmoid(z) if silu else z).reshape(B, C, HW).permute(0, 2, 1)
+    dy = torch.randn(B, HW, C)
+    yref.backward(dy)
+    nch = be.L.cdf_groupnorm_nchunk(HW)
+    ws, mean, rstd, y = be.empty(B * nch * 2 * C + B * 2 * C + B * 64), be.empty(B * 32), be.empty(B * 32), be.empty(B, HW, C)
+    xd, gd, bd = be.to(x), be.to(ga), be.to(bt)
+    be.L.cdf_groupnorm_fwd(P(xd), C, P(y), C, P(gd), P(bd), P(mean), P(rstd), P(ws), B, HW, C, 32, 1e-6, silu, be.stream())
+    dx, dga, dbe = be.empty(B, HW, C), be.zeros(C), be.zeros(C)
+    be.L.cdf_groupnorm_bwd(P(be.to(dy)), C, P(xd), C, P(gd), P(bd), P(mean), P(rstd), P(dx), C, P(dga), P(dbe), P(ws), B, HW, C, 32, silu, 0, 0, be.stream())
+    assert err(y, yref) <= 1e-5 and err(dx, x.grad) <= 2e-5 and err(dga, ga.grad) <= 1e-4 and err(dbe, bt.grad) <= 1e-4
+
+
+@pytest.mark.parametrize("B,C,H", [(2, 8, 8), (1, 3, 8), (2, 64, 4), (1, 68, 12)])
+def test_dwconv7(be, B, C, H):
+    torch.manual_seed(0)
+    Cp = r4(C)
+    x, w = torch.randn(B, C, H, H, requires_grad=True), (torch.randn(C, 1, 7, 7) / 7).requires_grad_()
+    bias, sb = torch.randn(C, requires_grad=True), torch.randn(B, C, requires_grad=True)
+    yref = F.conv2d(x, w, bias, padding=3, groups=C) + sb[:, :, None, None]
+    dy = torch.randn_like(yref)
+    yref.backward(dy)
+    xn, dyn = be.to(nhwc(x)), be.to(nhwc(dy))
+    wp = be.empty(49, Cp)
+    be.L.cdf_pack_weight(P(be.to(w)), P(wp), 49, 1, C, Cp, 1, 0, 49, be.stream())
+    bp, sbp = torch.zeros(Cp), torch.zeros(B, Cp)
+    bp[:C], sbp[:, :C] = bias.detach(), sb.detach()
+    y, dx = be.empty(B, H, H, Cp), be.empty(B, H, H, Cp)
+    be.L.cdf_dwconv7(P(xn), Cp, P(wp), Cp, P(be.to(bp)), P(be.to(sbp)), Cp, P(y), Cp, B, H, H, Cp, 0, 0, be.stream())
+    be.L.cdf_dwconv7(P(dyn), Cp, P(wp), Cp, 0, 0, 0, P(dx), Cp, B, H, H, Cp, 1, 0, be.stream())
+    nch = be.L.cdf_dwconv7_wgrad_nchunk(H)
+    ws, dw, dbias, dsb = be.empty(B * nch * 50 * C), be.zeros(C, 1, 7, 7), be.zeros(C), be.zeros(B, Cp)
+    be.L.cdf_dwconv7_wgrad(P(xn), Cp, P(dyn), Cp, P(dw), P(dbias), P(dsb), Cp, P(ws), B, H, H, C, 0, be.stream())
+    assert err(y[..., :C].permute(0, 3, 1, 2), yref) <= 1e-5 and err(dx[..., :C].permute(0, 3, 1, 2), x.grad) <= 1e-5
+    assert err(dw, w.grad) <= 5e-5 and err(dbias, bias.grad) <= 5e-5 and err(dsb[:, :C], sb.grad) <= 5e-5
+
+
+@pytest.mark.parametrize("B,n", [(1, 16), (2, 64), (1, 600)])
+def test_linear_attention(be, B, n):
+    from einops import rearrange
+    torch.manual_seed(0)
+    heads, HD, scale = 4, 128, 32 ** -0.5
+    qkv = torch.randn(B, n, 3 * HD, requires_grad=True)
+    q, k, v = [rearrange(t_, "b n (h c) -> b h c n", h=heads) for t_ in qkv.chunk(3, dim=2)]
+    q, k = q * scale, k.softmax(dim=-1)
+    ctxr = torch.einsum("b h d n, b h e n -> b h d e", k, v)
+    outr = rearrange(torch.einsum("b h d e, b h d n -> b h e n", ctxr, q), "b h c n -> b n (h c)")
+    do = torch.randn(B, n, HD)
+    outr.backward(do)
+    qd = be.to(qkv)
+    out, ctx, kmax, ksum = be.empty(B, n, HD), be.empty(B, heads, 32, 32), be.empty(B, HD), be.empty(B, HD)
+    ws = be.empty(be.L.cdf_linattn_ws_floats(B, n, heads))
+    be.L.cdf_linattn_fwd(P(qd), 3 * HD, P(out), HD, P(ctx), P(kmax), P(ksum), P(ws), B, n, heads, scale, be.stream())
+    dqkv, dctx, rv = be.empty(B, n, 3 * HD), be.empty(B, heads, 32, 32), be.empty(B, HD)
+    be.L.cdf_linattn_bwd(P(qd), 3 * HD, P(be.to(do)), HD, P(ctx), P(kmax), P(ksum), P(dqkv), 3 * HD, P(dctx), P(rv), P(ws), B, n, heads, scale, be.stream())
+    assert err(out, outr) <= 2e-6 and err(ctx, ctxr) <= 2e-6 and err(dqkv, qkv.grad) <= 5e-6
+
+
+def test_small_ops(be):
+    torch.manual_seed(0)
+    L, S = be.L, be.stream()
+    s, sc = torch.randn(3, 50, 50, requires_grad=True), 0.3
+    pr = F.softmax(s * sc, dim=2)
+    dp = torch.randn(3, 50, 50)
+    pr.backward(dp)
+    sp, dpp = torch.zeros(3, 50, 52), torch.zeros(3, 50, 52)
+    sp[..., :50], dpp[..., :50] = s.detach(), dp
+    p, ds = be.empty(3, 50, 52), be.empty(3, 50, 52)
+    L.cdf_softmax_rows_fwd(P(be.to(sp)), P(p), 150, 50, 52, sc, S)
+    L.cdf_softmax_rows_bwd(P(p), P(be.to(dpp)), P(ds), 150, 50, 52, sc, S)
+    assert err(p[..., :50], pr) <= 1e-6 and err(ds[..., :50], s.grad) <= 1e-6
+    t = torch.tensor([0, 5, 199, 999])
+    out = be.empty(4, 64)
+    L.cdf_sinusoidal(P(t.to(be.device)), P(out), 64, 4, 64, S)
+    e = torch.exp(torch.arange(32) * -(math.log(10000) / 31))
+    e = t[:, None] * e[None, :]
+    assert err(out, torch.cat((e.sin(), e.cos()), -1)) <= 5e-6
+    x = torch.randn(5, 7, requires_grad=True)
+    for act, fn in ((1, F.gelu), (2, F.silu)):
+        y = be.empty(5, 8)
+        L.cdf_act_fwd(P(be.to(x)), 7, P(y), 8, 5, 7, act, S)
+        yr, dy = fn(x), torch.randn(5, 7)
+        x.grad = None
+        yr.backward(dy)
+        dx = be.empty(5, 7)
+        L.cdf_act_bwd(P(be.to(x)), 7, P(be.to(dy)), 7, P(dx), 7, 5, 7, act, 0, S)
+        assert err(y[:, :7], yr) <= 1e-6 and err(dx, x.grad) <= 1e-6
+    xx = torch.randn(2, 3, 5, 8)
+    y, dx = be.empty(2, 6, 10, 8), be.empty(2, 3, 5, 8)
+    L.cdf_upsample2(P(be.to(xx)), 8, P(y), 8, 2, 3, 5, 8, S)
+    L.cdf_upsample2_bwd(P(y), 8, P(dx), 8, 2, 3, 5, 8, 0, S)
+    assert err(y, F.interpolate(xx.permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest").permute(0, 2, 3, 1)) == 0.0
+    assert err(dx, 4 * xx) <= 1e-6
+    ones, y = be.to(torch.ones(100, 10)), be.empty(100, 10)
+    L.cdf_dropout(P(ones), 10, P(y), 10, 100, 10, 0.1, 1234, S)
+    assert 0.85 <= (y > 0).float().mean().item() <= 0.95 and abs(y.max().item() - 1 / 0.9) < 1e-6
+    d = be.to(torch.ones(4, 6))
+    L.cdf_axpby(P(d), 6, P(be.to(torch.full((4, 6), 2.0))), 6, 4, 6, 1.0, 0.5, S)
+    assert err(d, torch.full((4, 6), 2.0)) == 0.0
+
+
+def test_adam_ema_match_torch(be):
+    """cdf_adam_step / cdf_ema_update reproduce torch.optim.Adam (defaults) and EMA bit for bit."""
+    torch.manual_seed(0)
+    n = 1000
+    p = torch.randn(n)
+    p0 = p.clone().requires_grad_()
+    opt = torch.optim.Adam([p0], lr=2e-5)
+    pd, m, v = be.to(p), be.zeros(n), be.zeros(n)
+    for step in range(1, 5):
+        g = torch.randn(n)
+        p0.grad = g.clone()
+        opt.step()
+        be.L.cdf_adam_step(P(pd), P(be.to(g)), P(m), P(v), n, 2e-5, 0.9, 0.999, 1e-8, step, be.stream())
+        assert err(pd, p0.detach()) <= 1e-9
+    ma = torch.randn(n)
+    mad = be.to(ma)
+    be.L.cdf_ema_update(P(mad), P(pd), n, 0.995, be.stream())
+    assert err(mad, ma * 0.995 + (1 - 0.995) * pd.cpu()) <= 1e-9
