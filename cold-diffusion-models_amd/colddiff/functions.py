@@ -1,0 +1,277 @@
+"""Block-level autograd nodes of the UNets.
+
+Each node runs a fused chain of HIP kernels in forward and a hand-written backward; parameter
+gradients are accumulated by the kernels straight into ``param.grad`` (one flat arena, see
+``colddiff.flat``), so autograd only carries activation gradients between blocks.  Every node takes
+an ``anchor`` (a dummy scalar that requires grad) first, so its backward also runs when the
+activation input itself does not require grad (the first block sees the image).
+"""
+import torch
+
+from . import convdesc as cd
+from . import ops
+from . import runtime as rt
+from .runtime import P, r4
+
+ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+
+
+def _conv_plans(kind, H, W, k, stride, pad):
+    """(fwd plan, dgrad plan, wgrad plan, packed-kind prefix, (s_r, s_c) factory) for a conv module."""
+    if kind == "conv":
+        pt, pl, pb, pr = pad
+        return (cd.conv_fwd(H, W, k, k, stride, pt, pl, pb, pr), cd.conv_dgrad(H, W, k, k, stride, pt, pl, pb, pr),
+                cd.conv_wgrad(H, W, k, k, stride, pt, pl, pb, pr))
+    return cd.convT_fwd(H, W, k, k, stride, pad[0]), cd.convT_dgrad(H, W, k, k, stride, pad[0]), cd.convT_wgrad(H, W, k, k, stride, pad[0])
+
+
+def conv_forward(x, Cin, weight, bias, kind="conv", stride=1, pad=None, **epi):
+    """x [B,H,W,*] -> conv(x) with the weight in its PyTorch layout ([Cout,Cin,k,k] or [Cin,Cout,k,k])."""
+    k = weight.shape[-1]
+    if pad is None:
+        pad = (k // 2,) * 4
+    _, H, W, _ = x.shape
+    plan = _conv_plans(kind, H, W, k, stride, pad)[0]
+    Cout = weight.shape[0] if kind == "conv" else weight.shape[1]
+    wp = ops.packed(weight, "conv_fwd" if kind == "conv" else "convT_fwd")
+    return ops.conv_gemm(plan, x, Cin, wp, Cout, bias=bias, **epi)
+
+
+def conv_backward(x, Cin, dy, weight, bias, kind="conv", stride=1, pad=None, need_dx=True, dx=None, dx_accumulate=0, mul=None,
+                  mul_mode=0):
+    """Gradients of conv_forward: returns dx (optionally fused with an activation-gradient multiply),
+    accumulates into weight.grad / bias.grad."""
+    k = weight.shape[-1]
+    if pad is None:
+        pad = (k // 2,) * 4
+    _, H, W, _ = x.shape
+    _, pd, pw = _conv_plans(kind, H, W, k, stride, pad)
+    KK = k * k
+    if kind == "conv":
+        Cout = weight.shape[0]
+        s_r, s_c = KK, Cin * KK
+    else:
+        Cout = weight.shape[1]
+        s_r, s_c = Cout * KK, KK
+    ops.wgrad_into(ops.grad_of(weight), pw, x, Cin, dy, Cout, 1, s_r, s_c)
+    if bias is not None:
+        ops.colsum_into(ops.grad_of(bias), dy, Cout)
+    if not need_dx:
+        return None
+    wd = ops.packed(weight, "conv_dgrad" if kind == "conv" else "convT_dgrad")
+    return ops.conv_gemm(pd, dy, Cout, wd, Cin, y=dx, mul=mul, mul_mode=mul_mode, accumulate=dx_accumulate)
+
+
+class ToNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.C = x.shape[1]
+        return ops.nchw_to_nhwc(rt.check(x.contiguous()))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.nhwc_to_nchw(dy, ctx.C)
+
+
+class ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, C, add):
+        ctx.has_add = add is not None
+        return ops.nhwc_to_nchw(x, C, add)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        return ops.nchw_to_nhwc(dy), None, (dy if ctx.has_add else None)
+
+
+class Concat(torch.autograd.Function):
+    """torch.cat((a, b), dim=channel) on NHWC maps; the backward hands out channel-slice views."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        B, H, W, Ca = a.shape
+        Cb = b.shape[-1]
+        ctx.Ca = Ca
+        out = torch.empty((B, H, W, Ca + Cb), device=a.device, dtype=torch.float32)
+        L, S = rt.lib(), rt.stream(a)
+        rows = B * H * W
+        L.cdf_axpby(P(out), Ca + Cb, P(a), ops.ld_of(a), rows, Ca, 0.0, 1.0, S)
+        L.cdf_axpby(P(out) + 4 * Ca, Ca + Cb, P(b), ops.ld_of(b), rows, Cb, 0.0, 1.0, S)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return d[..., :ctx.Ca], d[..., ctx.Ca:]
+
+
+class Sinusoidal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, freq, dim):
+        out = torch.empty((t.shape[0], dim), device=freq.device, dtype=torch.float32)
+        rt.lib().cdf_sinusoidal(P(t), P(freq), P(out), dim, t.shape[0], dim, rt.stream(out))
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return None, None, None
+
+
+class Act(torch.autograd.Function):
+    """GELU / SiLU on a [B, K] vector (time-embedding MLPs)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        ctx.act = act
+        ctx.save_for_backward(x)
+        y = torch.empty_like(x)
+        rt.lib().cdf_act_fwd(P(x), x.stride(0), P(y), y.stride(0), x.shape[0], x.shape[1], act, rt.stream(x))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        rt.lib().cdf_act_bwd(P(x), x.stride(0), P(dy), dy.stride(0), P(dx), dx.stride(0), x.shape[0], x.shape[1], ctx.act, 0, rt.stream(x))
+        return dx, None
+
+
+class Linear(torch.autograd.Function):
+    """y = x @ W^T + b on [B, K] -> [B, r4(N)] (padded so the result can serve as a per-sample bias)."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, lin):
+        W, b = lin.weight, lin.bias
+        N, K = W.shape
+        B = x.shape[0]
+        plan = cd.conv_fwd(1, 1, 1, 1, 1, 0, 0, 0, 0)
+        x4 = x.view(B, 1, 1, x.shape[1])
+        y = ops.conv_gemm(plan, x4, K, ops.packed(W, "lin_fwd"), N, bias=b)
+        ctx.lin = lin
+        ctx.save_for_backward(x)
+        return y.view(B, r4(N))
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        lin = ctx.lin
+        W, b = lin.weight, lin.bias
+        N, K = W.shape
+        B = x.shape[0]
+        dy = dy.contiguous()
+        dy4, x4 = dy.view(B, 1, 1, dy.shape[1]), x.view(B, 1, 1, x.shape[1])
+        wp = cd.conv_wgrad(1, 1, 1, 1, 1, 0, 0, 0, 0)
+        ops.wgrad_into(ops.grad_of(W), wp, dy4, N, x4, K, 0, K, 1)          # dW[n][k] += dy[b][n] x[b][k]
+        if b is not None:
+            ops.colsum_into(ops.grad_of(b), dy4, N)
+        dx = None
+        if ctx.needs_input_grad[1]:
+            plan = cd.conv_fwd(1, 1, 1, 1, 1, 0, 0, 0, 0)
+            dx = ops.conv_gemm(plan, dy4, N, W.detach().view(1, N, K), K).view(B, r4(K))[:, :x.shape[1]]
+        return None, dx, None
+
+
+class ConvFn(torch.autograd.Function):
+    """A single dense convolution module (Down/Upsample, final 1x1, conv_in/out ...)."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, mod, Cin, kind, stride, pad):
+        y = conv_forward(x, Cin, mod.weight, mod.bias, kind, stride, pad)
+        ctx.mod, ctx.cfg = mod, (Cin, kind, stride, pad)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        Cin, kind, stride, pad = ctx.cfg
+        dx = conv_backward(x, Cin, dy, ctx.mod.weight, ctx.mod.bias, kind, stride, pad, need_dx=ctx.needs_input_grad[1])
+        return None, dx, None, None, None, None, None
+
+
+class ConvNextBlockFn(torch.autograd.Function):
+    """ConvNextBlock.forward (deblurring_diffusion_pytorch.py:156-165) as one node:
+    h = ds_conv(x) + b + mlp(t); hn = LayerNorm(h); a = GELU(conv3x3(hn)); o = conv3x3(a) + res_conv(x)."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, tbias, m):
+        dim, dim_out = m.dim, m.dim_out
+        Cp = x.shape[-1]
+        grad_on = ctx.needs_input_grad[0]   # anchor: True iff autograd is recording
+        wdw = ops.packed(m.ds_conv.weight, "dw")
+        h = ops.dwconv7(x, wdw, ops.padded_vec(m.ds_conv.bias, Cp), tbias)
+        if m.has_norm:
+            hn, mean, rstd = ops.layernorm_fwd(h, m.net[0].g, m.net[0].b, m.net[0].eps, grad_on)
+        else:
+            hn, mean, rstd = h, None, None
+        c1, c2 = m.net[1], m.net[3]
+        B, H, W, _ = x.shape
+        pre = ops.new_feat(x, B, H, W, c1.weight.shape[0]) if grad_on else None
+        a = conv_forward(hn, dim, c1.weight, c1.bias, act=ACT_GELU, pre=pre)
+        if m.has_res_conv:
+            res = conv_forward(x, dim, m.res_conv.weight, m.res_conv.bias)
+        else:
+            res = x
+        o = conv_forward(a, c1.weight.shape[0], c2.weight, c2.bias, res=res)
+        ctx.m = m
+        ctx.has_t = tbias is not None
+        ctx.save_for_backward(x, h, hn if m.has_norm else None, mean, rstd, pre, a)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        x, h, hn, mean, rstd, pre, a = ctx.saved_tensors
+        m = ctx.m
+        if hn is None:
+            hn = h
+        dim = m.dim
+        c1, c2 = m.net[1], m.net[3]
+        mid = c1.weight.shape[0]
+        need_dx = ctx.needs_input_grad[1]
+        # residual branch
+        dx = None
+        if m.has_res_conv:
+            dx = conv_backward(x, dim, do, m.res_conv.weight, m.res_conv.bias, need_dx=need_dx)
+        elif need_dx:
+            dx = ops.copy_feat(do)
+        # conv2 -> (fused GELU') -> conv1
+        dpre = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=1)
+        dhn = conv_backward(hn, dim, dpre, c1.weight, c1.bias)
+        if m.has_norm:
+            dh = ops.layernorm_bwd(dhn, h, m.net[0].g, m.net[0].b, mean, rstd)
+        else:
+            dh = dhn
+        dtb = ops.dwconv7_wgrad(x, dh, m.ds_conv.weight, m.ds_conv.bias, ctx.has_t)
+        if need_dx:
+            ops.dwconv7(dh, ops.packed(m.ds_conv.weight, "dw"), None, None, flip=1, y=dx, accumulate=1)
+        return None, dx, dtb, None
+
+
+class LinAttnBlockFn(torch.autograd.Function):
+    """Residual(PreNorm(dim, LinearAttention(dim))) (deblurring_diffusion_pytorch.py:83-89,123-131,167-187)."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, m):
+        norm, att = m.fn.norm, m.fn.fn
+        dim = x.shape[-1]
+        grad_on = ctx.needs_input_grad[0]   # anchor: True iff autograd is recording
+        xn, mean, rstd = ops.layernorm_fwd(x, norm.g, norm.b, norm.eps, grad_on)
+        qkv = conv_forward(xn, dim, att.to_qkv.weight, None)
+        o, cx, kmax, ksum = ops.linattn_fwd(qkv, att.heads, att.scale)
+        y = conv_forward(o, att.heads * 32, att.to_out.weight, att.to_out.bias, res=x)
+        ctx.m = m
+        ctx.save_for_backward(x, xn, mean, rstd, qkv, o, cx, kmax, ksum)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xn, mean, rstd, qkv, o, cx, kmax, ksum = ctx.saved_tensors
+        norm, att = ctx.m.fn.norm, ctx.m.fn.fn
+        dim, HD = x.shape[-1], att.heads * 32
+        do = conv_backward(o, HD, dy, att.to_out.weight, att.to_out.bias)
+        dqkv = ops.linattn_bwd(qkv, do, cx, kmax, ksum, att.heads, att.scale)
+        dxn = conv_backward(xn, dim, dqkv, att.to_qkv.weight, None)
+        dx = ops.copy_feat(dy)
+        ops.layernorm_bwd(dxn, x, norm.g, norm.b, mean, rstd, dx=dx)
+        return None, dx, None

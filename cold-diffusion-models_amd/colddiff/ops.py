@@ -1,0 +1,232 @@
+"""Functional (non-autograd) wrappers over the colddiff C ABI operating on torch HIP tensors.
+
+Feature maps are NHWC views ``[B, H, W, C]`` with unit channel stride and an arbitrary pixel pitch
+(``t.stride(-2)``), so a channel slice of a wider buffer is a valid operand.  Tensors whose logical
+channel count is not a multiple of 4 are stored padded to 4 with zero pad channels.
+"""
+import torch
+
+from . import convdesc as cd
+from . import runtime as rt
+from .runtime import P, r4
+
+
+def ld_of(t):
+    assert t.stride(-1) == 1, "feature maps need unit channel stride"
+    if t.dim() == 4:
+        B, H, W, _ = t.shape
+        ld = t.stride(2) if W > 1 else (t.stride(1) if H > 1 else t.stride(0))
+        assert (W == 1 or t.stride(2) == ld) and (H == 1 or t.stride(1) == W * ld) and (B == 1 or t.stride(0) == H * W * ld), \
+            "feature map is not pixel-contiguous: %s %s" % (tuple(t.shape), t.stride())
+        return ld
+    return t.stride(-2) if t.shape[-2] > 1 else t.shape[-1]
+
+
+def new_feat(ref, B, H, W, C, zero=False):
+    f = torch.zeros if (zero or C % 4) else torch.empty
+    return f((B, H, W, r4(C)), device=ref.device, dtype=torch.float32)
+
+
+# ---------------------------------------------------------------------------------------------------
+# packed-weight cache
+# ---------------------------------------------------------------------------------------------------
+_pack_cache = {}
+
+
+def _pack(src, T, R, C, s_t, s_r, s_c):
+    dst = torch.empty((T, R, r4(C)), device=src.device, dtype=torch.float32)
+    rt.lib().cdf_pack_weight(P(src), P(dst), T, R, C, r4(C), s_t, s_r, s_c, rt.stream(src))
+    return dst
+
+
+def packed(param, kind):
+    """GEMM-layout copy of a parameter, cached until the parameter changes.
+
+    kinds: conv_fwd  [KK][Cin][Cout]   conv_dgrad  [KK][Cout][Cin]   (weight [Cout,Cin,KH,KW])
+           convT_fwd [KK][Cin][Cout]   convT_dgrad [KK][Cout][Cin]   (weight [Cin,Cout,KH,KW])
+           dw        [49][C]                                          (weight [C,1,7,7])
+           lin_fwd   [1][K][N]                                        (weight [N,K])
+    """
+    key = (param.data_ptr(), param._version, rt.weights_epoch, kind)
+    hit = _pack_cache.get((id(param), kind))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    w = param.detach()
+    if kind in ("conv_fwd", "conv_dgrad"):
+        Co, Ci, KH, KW = w.shape
+        KK = KH * KW
+        out = _pack(w, KK, Ci, Co, 1, KK, Ci * KK) if kind == "conv_fwd" else _pack(w, KK, Co, Ci, 1, Ci * KK, KK)
+    elif kind in ("convT_fwd", "convT_dgrad"):
+        Ci, Co, KH, KW = w.shape
+        KK = KH * KW
+        out = _pack(w, KK, Ci, Co, 1, Co * KK, KK) if kind == "convT_fwd" else _pack(w, KK, Co, Ci, 1, KK, Co * KK)
+    elif kind == "dw":
+        C = w.shape[0]
+        out = _pack(w, 49, 1, C, 1, 0, 49)
+    elif kind == "lin_fwd":
+        N, K = w.shape
+        out = _pack(w, 1, K, N, 0, 1, K)
+    else:
+        raise ValueError(kind)
+    _pack_cache[(id(param), kind)] = (key, out)
+    return out
+
+
+def padded_vec(v, n):
+    """1-D parameter zero-padded to n entries (for C % 4 != 0 biases)."""
+    if v is None or v.shape[-1] == n:
+        return v
+    out = torch.zeros(v.shape[:-1] + (n,), device=v.device, dtype=torch.float32)
+    out[..., :v.shape[-1]] = v.detach()
+    return out
+
+
+def grad_of(p):
+    """The gradient buffer kernels accumulate into (allocated on first use)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+# ---------------------------------------------------------------------------------------------------
+# conv / linear primitives
+# ---------------------------------------------------------------------------------------------------
+def conv_gemm(plan, x, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None, pre=None, mul=None, act=0, mul_mode=0,
+              accumulate=0):
+    B = x.shape[0]
+    if y is None:
+        y = new_feat(x, B, plan.OH, plan.OW, Cout)
+    ldv = lambda t: 0 if t is None else ld_of(t)
+    rt.lib().cdf_conv_gemm(P(x), ld_of(x), P(wp), wp.shape[-1], P(y), ld_of(y), B, plan.H, plan.W, Cin, plan.OH, plan.OW, Cout,
+                           plan.QH, plan.QW, plan.os, plan.istride, plan.nphase, plan.desc, P(bias), P(sbias),
+                           0 if sbias is None else sbias.stride(0), P(res), ldv(res), P(pre), ldv(pre), P(mul), ldv(mul),
+                           act, mul_mode, accumulate, 0, 1, 0, 0, 0, rt.stream(x))
+    return y
+
+
+def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c):
+    """gparam[c*s_c + r*s_r + t*s_t] += sum_m xa[pixA(m,t)][r] * xb[pixB(m,t)][c]"""
+    L = rt.lib()
+    B = xa.shape[0]
+    M = B * wplan.QH * wplan.QW
+    ns = max(1, min(L.cdf_wgrad_nsplit(M, CA, CB, wplan.ntaps), M // 16 if M >= 16 else 1))
+    ldo = r4(CB)
+    ws = torch.empty((ns, wplan.ntaps, CA, ldo), device=xa.device, dtype=torch.float32)
+    S = rt.stream(xa)
+    L.cdf_conv_wgrad(P(xa), ld_of(xa), P(xb), ld_of(xb), P(ws), ldo, B, wplan.QH, wplan.QW, wplan.HA, wplan.WA, wplan.sa,
+                     wplan.HB, wplan.WB, wplan.sb, CA, CB, wplan.ntaps, wplan.desc, ns, 1, 0, 0, 0, S)
+    L.cdf_unpack_reduce(P(ws), P(gparam), ns, wplan.ntaps, CA, CB, ldo, s_t, s_r, s_c, 1, S)
+
+
+def colsum_into(gvec, x, C, nseg=1):
+    """gvec[seg][c] += sum over the rows of segment seg of x (x: [..., C] pitched rows)."""
+    L = rt.lib()
+    ld = ld_of(x)
+    rows = x.numel() // x.shape[-1]
+    rps = rows // nseg
+    nch = L.cdf_colsum_nchunk(rps)
+    ws = torch.empty((nseg * nch * C,), device=x.device, dtype=torch.float32)
+    L.cdf_colsum(P(x), P(gvec), P(ws), nseg, rps, C, ld, gvec.stride(0) if gvec.dim() == 2 else C, 1, rt.stream(x))
+
+
+def copy_feat(src, C=None):
+    C = src.shape[-1] if C is None else C
+    dst = torch.empty(src.shape, device=src.device, dtype=torch.float32)
+    rows = src.numel() // src.shape[-1]
+    rt.lib().cdf_axpby(P(dst), ld_of(dst), P(src), ld_of(src), rows, src.shape[-1], 0.0, 1.0, rt.stream(src))
+    return dst
+
+
+def add_into(dst, src):
+    rows = dst.numel() // dst.shape[-1]
+    rt.lib().cdf_axpby(P(dst), ld_of(dst), P(src), ld_of(src), rows, dst.shape[-1], 1.0, 1.0, rt.stream(dst))
+    return dst
+
+
+# ---------------------------------------------------------------------------------------------------
+# norms / depthwise / attention primitives
+# ---------------------------------------------------------------------------------------------------
+def layernorm_fwd(x, g, b, eps, save):
+    B, H, W, C = x.shape
+    M = B * H * W
+    y = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+    mean = torch.empty((M,), device=x.device, dtype=torch.float32) if save else None
+    rstd = torch.empty((M,), device=x.device, dtype=torch.float32) if save else None
+    rt.lib().cdf_layernorm_c_fwd(P(x), ld_of(x), P(y), C, P(g), P(b), P(mean), P(rstd), M, C, eps, rt.stream(x))
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, g_param, b_param, mean, rstd, dx=None):
+    """returns dx (accumulating into `dx` if given); accumulates g/b gradients into the params."""
+    L = rt.lib()
+    B, H, W, C = x.shape
+    M = B * H * W
+    acc = 1 if dx is not None else 0
+    if dx is None:
+        dx = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+    part = torch.empty((L.cdf_layernorm_blocks(M, C) * 2 * C,), device=x.device, dtype=torch.float32)
+    L.cdf_layernorm_c_bwd(P(dy), ld_of(dy), P(x), ld_of(x), P(g_param), P(mean), P(rstd), P(dx), ld_of(dx), P(grad_of(g_param)),
+                          P(grad_of(b_param)), P(part), M, C, acc, 1, rt.stream(x))
+    return dx
+
+
+def dwconv7(x, wp, bias, sbias, flip=0, y=None, accumulate=0):
+    B, H, W, Cp = x.shape
+    if y is None:
+        y = torch.empty((B, H, W, Cp), device=x.device, dtype=torch.float32)
+    rt.lib().cdf_dwconv7(P(x), ld_of(x), P(wp), wp.shape[-1], P(bias), P(sbias), 0 if sbias is None else sbias.stride(0), P(y),
+                         ld_of(y), B, H, W, Cp, flip, accumulate, rt.stream(x))
+    return y
+
+
+def dwconv7_wgrad(x, dy, w_param, b_param, want_dsb):
+    L = rt.lib()
+    B, H, W, Cp = x.shape
+    C = w_param.shape[0]
+    ws = torch.empty((B * L.cdf_dwconv7_wgrad_nchunk(H) * 50 * C,), device=x.device, dtype=torch.float32)
+    dsb = torch.zeros((B, Cp), device=x.device, dtype=torch.float32) if want_dsb else None
+    L.cdf_dwconv7_wgrad(P(x), ld_of(x), P(dy), ld_of(dy), P(grad_of(w_param)), P(grad_of(b_param)), P(dsb), Cp, P(ws), B, H, W, C,
+                        1, rt.stream(x))
+    return dsb
+
+
+def linattn_fwd(qkv, heads, scale):
+    L = rt.lib()
+    B, H, W, _ = qkv.shape
+    n, HD = H * W, heads * 32
+    dev = qkv.device
+    out = torch.empty((B, H, W, HD), device=dev, dtype=torch.float32)
+    ctx = torch.empty((B, heads, 32, 32), device=dev, dtype=torch.float32)
+    kmax = torch.empty((B, HD), device=dev, dtype=torch.float32)
+    ksum = torch.empty((B, HD), device=dev, dtype=torch.float32)
+    ws = torch.empty((L.cdf_linattn_ws_floats(B, n, heads),), device=dev, dtype=torch.float32)
+    L.cdf_linattn_fwd(P(qkv), ld_of(qkv), P(out), HD, P(ctx), P(kmax), P(ksum), P(ws), B, n, heads, scale, rt.stream(qkv))
+    return out, ctx, kmax, ksum
+
+
+def linattn_bwd(qkv, dout, ctx, kmax, ksum, heads, scale):
+    L = rt.lib()
+    B, H, W, _ = qkv.shape
+    n, HD = H * W, heads * 32
+    dev = qkv.device
+    dqkv = torch.empty((B, H, W, 3 * HD), device=dev, dtype=torch.float32)
+    dctx = torch.empty_like(ctx)
+    rvec = torch.empty((B, HD), device=dev, dtype=torch.float32)
+    ws = torch.empty((L.cdf_linattn_ws_floats(B, n, heads),), device=dev, dtype=torch.float32)
+    L.cdf_linattn_bwd(P(qkv), ld_of(qkv), P(dout), ld_of(dout), P(ctx), P(kmax), P(ksum), P(dqkv), 3 * HD, P(dctx), P(rvec), P(ws),
+                      B, n, heads, scale, rt.stream(qkv))
+    return dqkv
+
+
+def nchw_to_nhwc(x):
+    B, C, H, W = x.shape
+    y = new_feat(x, B, H, W, C)
+    rt.lib().cdf_nchw_to_nhwc(P(x), P(y), B, C, H * W, y.shape[-1], rt.stream(x))
+    return y
+
+
+def nhwc_to_nchw(x, C, add=None):
+    B, H, W, _ = x.shape
+    y = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
+    rt.lib().cdf_nhwc_to_nchw(P(x), P(y), P(add), B, C, H * W, ld_of(x), rt.stream(x))
+    return y

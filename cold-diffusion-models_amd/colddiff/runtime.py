@@ -1,0 +1,42 @@
+"""Process-wide handles: the kernel library, the HIP stream of the current torch context, and the
+packed-weight cache.  There is no CPU fallback: tensors must live on a HIP device."""
+import torch
+
+from . import _lib
+
+# Set ONLY by the CPU test-suite (tests/emu_util.install_emu) to run the host SIMT-simulator build
+# of the very same kernels on CPU tensors.  Never set by the package itself.
+_lib_override = None
+
+# Bumped whenever parameters are rewritten behind torch's back (fused Adam / EMA kernels write
+# through raw pointers and do not touch Tensor._version); invalidates the packed-weight cache.
+weights_epoch = 0
+
+
+def lib():
+    return _lib_override if _lib_override is not None else _lib.get()
+
+
+def stream(t=None):
+    if _lib_override is not None:
+        return 0
+    return torch.cuda.current_stream(t.device if t is not None else None).cuda_stream
+
+
+def check(t):
+    if t is not None and not t.is_cuda and _lib_override is None:
+        raise RuntimeError("colddiff: operators run on the MI355X only (tensor is on %s; no CPU fallback)" % t.device)
+    return t
+
+
+def bump_weights_epoch():
+    global weights_epoch
+    weights_epoch += 1
+
+
+def P(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def r4(c):
+    return (c + 3) // 4 * 4

@@ -21,7 +21,7 @@ __device__ __forceinline__ void f4_fma(float4& acc, const float4& a, const float
 __global__ void __launch_bounds__(256) dwconv7_kernel(const float* x, int ldx, const float* w, int ldw, const float* bias,
                                                       const float* sbias, int ld_sbias, float* y, int ldy, int B, int H,
                                                       int W, int C4, int flip, int accumulate) {
-    const int strips_w = W / 4;
+    const int strips_w = (W + 3) / 4;
     const long long n = (long long)B * H * strips_w * C4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(256) dwconv7_kernel(const float* x, int ldx, c
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if (xs + j >= W) break;
             float* dst = y + (((long long)b * H + yy) * W + xs + j) * ldy + c;
             float4 o = make_float4(acc[j].x + add.x, acc[j].y + add.y, acc[j].z + add.z, acc[j].w + add.w);
             if (accumulate) {
@@ -83,7 +84,7 @@ __global__ void __launch_bounds__(256) dwconv7_wgrad_partial_kernel(const float*
     const int y0 = blockIdx.y * rows_per_chunk;
     int y1 = y0 + rows_per_chunk;
     if (y1 > H) y1 = H;
-    const int strips_w = W / 4, nstrips = (y1 - y0) * strips_w;
+    const int strips_w = (W + 3) / 4, nstrips = (y1 - y0) * strips_w;
     float acc[DW_TAPS + 1];
 #pragma unroll
     for (int t = 0; t <= DW_TAPS; ++t) acc[t] = 0.f;
@@ -92,7 +93,7 @@ __global__ void __launch_bounds__(256) dwconv7_wgrad_partial_kernel(const float*
         float d[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            d[j] = cv ? dy[(((long long)b * H + yy) * W + xs + j) * lddy + c] : 0.f;
+            d[j] = (cv && xs + j < W) ? dy[(((long long)b * H + yy) * W + xs + j) * lddy + c] : 0.f;
             acc[DW_TAPS] += d[j];
         }
 #pragma unroll
@@ -150,11 +151,10 @@ extern "C" int cdf_dwconv7(const float* x, int ldx, const float* w, int ldw, con
                            int ld_sbias, float* y, int ldy, int B, int H, int W, int C, int flip, int accumulate,
                            void* stream) {
     CDF_REQUIRE(x && w && y, "cdf_dwconv7: null pointer");
-    CDF_REQUIRE(W % 4 == 0, "cdf_dwconv7: W=%d must be a multiple of 4", W);
     const int Cp = (C + 3) & ~3;
     CDF_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldw % 4 == 0 && ldx >= Cp && ldy >= Cp && ldw >= Cp, "cdf_dwconv7: pitches must be multiples of 4 and >= roundup4(C)");
     CDF_REQUIRE(!bias || (C % 4 == 0), "cdf_dwconv7: bias with C %% 4 != 0 needs a padded bias (pass a padded vector and C rounded up)");
-    const long long n = (long long)B * H * (W / 4) * (Cp / 4);
+    const long long n = (long long)B * H * ((W + 3) / 4) * (Cp / 4);
     long long grid = (n + 255) / 256;
     if (grid > 8192) grid = 8192;
     CDF_LAUNCH(dwconv7_kernel, dim3((int)grid), dim3(256), 0, CDF_S, x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate);
@@ -173,7 +173,6 @@ extern "C" int cdf_dwconv7_wgrad(const float* x, int ldx, const float* dy, int l
                                  float* dsb, int ld_dsb, float* ws, int B, int H, int W, int C, int accumulate,
                                  void* stream) {
     CDF_REQUIRE(x && dy && dw && ws, "cdf_dwconv7_wgrad: null pointer");
-    CDF_REQUIRE(W % 4 == 0, "cdf_dwconv7_wgrad: W=%d must be a multiple of 4", W);
     const int nchunk = cdf_dwconv7_wgrad_nchunk(H), rpc = cdf_cdiv(H, nchunk);
     CDF_LAUNCH(dwconv7_wgrad_partial_kernel, dim3(cdf_cdiv(C, 64), nchunk, B), dim3(256), 0, CDF_S, x, ldx, dy, lddy, ws, H, W, C, rpc);
     CDF_LAUNCH(dwconv7_wgrad_final_kernel, dim3(cdf_cdiv(50 * C, 256)), dim3(256), 0, CDF_S, (const float*)ws, B, nchunk, C, dw, dbias, dsb, ld_dsb, accumulate);

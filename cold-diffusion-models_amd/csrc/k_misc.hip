@@ -16,14 +16,14 @@ static inline int ew_grid(long long n) {
 #define CDF_EW_LOOP(i, n) \
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
 
-// emb[b][j] = sin(t[b] * f_j), emb[b][half + j] = cos(t[b] * f_j), f_j = exp(-j * ln(10000)/(half-1))
-__global__ void sinusoidal_kernel(const int64_t* t, float* out, int ldo, int B, int dim) {
+// emb[b][j] = sin(t[b] * f_j), emb[b][half + j] = cos(t[b] * f_j); the frequency table
+// f_j = exp(-j * ln(10000)/(half-1)) is an init-time constant supplied by the caller (a 1e-7 relative
+// difference in f_j is amplified by t ~ 1000 into a 1e-4 phase error, so it is taken as data).
+__global__ void sinusoidal_kernel(const int64_t* t, const float* freq, float* out, int ldo, int B, int dim) {
     const int half = dim / 2;
-    const float scale = logf(10000.0f) / (float)(half - 1);
     CDF_EW_LOOP(i, (long long)B * half) {
         const int b = (int)(i / half), j = (int)(i % half);
-        const float f = expf((float)j * -scale);
-        const float a = (float)t[b] * f;
+        const float a = (float)t[b] * freq[j];
         out[(long long)b * ldo + j] = sinf(a);
         out[(long long)b * ldo + half + j] = cosf(a);
     }
@@ -144,9 +144,9 @@ __global__ void scale_kernel(float* x, long long n, float s) {
 }
 
 // ================================================================================================
-extern "C" int cdf_sinusoidal(const int64_t* t, float* out, int ldo, int B, int dim, void* stream) {
-    CDF_REQUIRE(t && out && B > 0 && dim >= 4 && (dim & 1) == 0 && ldo >= dim, "cdf_sinusoidal: bad args");
-    CDF_LAUNCH(sinusoidal_kernel, dim3(ew_grid((long long)B * dim / 2)), dim3(256), 0, CDF_S, t, out, ldo, B, dim);
+extern "C" int cdf_sinusoidal(const int64_t* t, const float* freq, float* out, int ldo, int B, int dim, void* stream) {
+    CDF_REQUIRE(t && freq && out && B > 0 && dim >= 4 && (dim & 1) == 0 && ldo >= dim, "cdf_sinusoidal: bad args");
+    CDF_LAUNCH(sinusoidal_kernel, dim3(ew_grid((long long)B * dim / 2)), dim3(256), 0, CDF_S, t, freq, out, ldo, B, dim);
     return cdf_check_launch("sinusoidal");
 }
 extern "C" int cdf_act_fwd(const float* x, int ldx, float* y, int ldy, long long rows, int C, int act, void* stream) {

@@ -174,8 +174,9 @@ int cdf_softmax_rows_bwd(const float* p, const float* dp, float* ds, long long r
                          void* stream);
 
 /* ---- small fused ops ---------------------------------------------------------------------------------
- * sinusoidal time embedding (DEBLUR:91-103, MODEL2:6-24): out[b] = (sin(t f_j) | cos(t f_j)) */
-int cdf_sinusoidal(const int64_t* t, float* out, int ldo, int B, int dim, void* stream);
+ * sinusoidal time embedding (DEBLUR:91-103, MODEL2:6-24): out[b] = (sin(t f_j) | cos(t f_j)),
+ * freq[dim/2] = the init-time frequency table exp(-j ln(1e4)/(dim/2-1)) */
+int cdf_sinusoidal(const int64_t* t, const float* freq, float* out, int ldo, int B, int dim, void* stream);
 /* act 1 = exact GELU, 2 = SiLU on [rows, C] with pitches */
 int cdf_act_fwd(const float* x, int ldx, float* y, int ldy, long long rows, int C, int act, void* stream);
 int cdf_act_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, long long rows, int C, int act,

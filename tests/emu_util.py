@@ -35,3 +35,15 @@ def emu_lib():
 def P(t):
     """device/host pointer of a tensor (0 for None)."""
     return 0 if t is None else t.data_ptr()
+
+
+def install_emu():
+    """Route the colddiff Python layer to the simulator build (CPU tensors). Tests only."""
+    from colddiff import runtime
+    runtime._lib_override = emu_lib()
+    return runtime._lib_override
+
+
+def uninstall_emu():
+    from colddiff import runtime
+    runtime._lib_override = None

@@ -44,7 +44,7 @@ def test_blur_chain(be, H, k, mode):
     taps = torch.rand(T, C, k, k)
     taps /= taps.sum((2, 3), keepdim=True)
     t = torch.tensor([4, 2, 0])
-    xd, tapsd, td = be.to(x), be.to(taps), t.to(be.device)
+    xd, tapsd, td = be.to(x), be.to(taps), be.to(t)
     y, snap = be.empty(B, C, H, H), be.empty(B, C, H, H)
     be.L.cdf_blur_chain(P(xd), P(y), P(snap), 0, P(tapsd), P(td), B, C, H, H, k, 0, 0, 0 if mode == "circular" else 1, -1, 0, be.stream())
 
@@ -100,8 +100,8 @@ def test_pixelate_chain(be, H, mode_i, mode, routine):
     x = torch.randn(B, C, H, H)
     t = torch.tensor([T - 1, 1])
     y, snap = be.empty(B, C, H, H), be.empty(B, C, H, H)
-    sz = torch.tensor(sizes, dtype=torch.int32).to(be.device)
-    be.L.cdf_pixelate_chain(P(be.to(x)), P(y), P(snap), 0, P(sz), P(t.to(be.device)), B, C, H, 0, 0, mode_i, be.stream())
+    sz = be.to(torch.tensor(sizes, dtype=torch.int32))
+    be.L.cdf_pixelate_chain(P(be.to(x)), P(y), P(snap), 0, P(sz), P(be.to(t)), B, C, H, 0, 0, mode_i, be.stream())
 
     def step(z, i):
         z1 = F.interpolate(z, size=sizes[i], mode=mode, antialias=False)
@@ -126,7 +126,7 @@ def test_mask_noise_loss_layout(be):
     x, masks = torch.randn(B, C, H, H), torch.rand(T, 2 * H + 1, 2 * H + 1)
     t, oy, ox = torch.tensor([5, 0, 3]), torch.tensor([0, 7, 16]), torch.tensor([3, 0, 16])
     y, snap = be.empty(B, C, H, H), be.empty(B, C, H, H)
-    L.cdf_mask_chain(P(be.to(x)), P(y), P(snap), 0, P(be.to(masks)), P(t.to(be.device)), P(oy.to(be.device)), P(ox.to(be.device)),
+    L.cdf_mask_chain(P(be.to(x)), P(y), P(snap), 0, P(be.to(masks)), P(be.to(t)), P(be.to(oy)), P(be.to(ox)),
                      B, C, H, H, 2 * H + 1, 2 * H + 1, 0, 0, 0, S)
     ref = []
     for b in range(B):
@@ -138,7 +138,7 @@ def test_mask_noise_loss_layout(be):
     ca, cb = torch.rand(10), torch.rand(10)
     x0, eps, t = torch.randn(B, C, H, H), torch.randn(B, C, H, H), torch.tensor([9, 0, 4])
     out = be.empty(B, C, H, H)
-    L.cdf_noise_qsample(P(be.to(x0)), P(be.to(eps)), P(be.to(ca)), P(be.to(cb)), P(t.to(be.device)), P(out), B, C * H * H, S)
+    L.cdf_noise_qsample(P(be.to(x0)), P(be.to(eps)), P(be.to(ca)), P(be.to(cb)), P(be.to(t)), P(out), B, C * H * H, S)
     assert err(out, ca[t].view(-1, 1, 1, 1) * x0 + cb[t].view(-1, 1, 1, 1) * eps) == 0.0
     for tt in (5, 1):
         for est in (0, 1):
@@ -380,8 +380,8 @@ def test_small_ops(be):
     assert err(p[..., :50], pr) <= 1e-6 and err(ds[..., :50], s.grad) <= 1e-6
     t = torch.tensor([0, 5, 199, 999])
     out = be.empty(4, 64)
-    L.cdf_sinusoidal(P(t.to(be.device)), P(out), 64, 4, 64, S)
     e = torch.exp(torch.arange(32) * -(math.log(10000) / 31))
+    L.cdf_sinusoidal(P(be.to(t)), P(be.to(e)), P(out), 64, 4, 64, S)
     e = t[:, None] * e[None, :]
     assert err(out, torch.cat((e.sin(), e.cos()), -1)) <= 5e-6
     x = torch.randn(5, 7, requires_grad=True)
