@@ -1,0 +1,603 @@
+"""The four `GaussianDiffusion` classes of the cold-diffusion packages, on the HIP degradation kernels.
+
+Constructor arguments, attribute names, method names, return values and `state_dict` layout follow
+  deblurring  : deblurring_diffusion_pytorch.py:311-981
+  denoising   : denoising_diffusion_pytorch.py:310-542
+  resolution  : resolution_diffusion_pytorch.py:325-767
+  defading    : defading_diffusion_gaussian.py:298-554
+What differs is the execution: q_sample and every Alg.1/Alg.2 sampler step is ONE fused kernel
+launch (the whole step chain runs with the image plane resident in LDS) instead of O(T) convs, a
+torch.stack of T images and B python-level gathers, and nothing synchronises with the host
+(the reference's `torch.max(t)` -> `range()` does).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import degrade as D
+from . import runtime as rt
+
+
+def _full_step(batch_size, value, device):
+    return torch.full((batch_size,), value, dtype=torch.long, device=device)
+
+
+# ===================================================================================================
+# deblurring
+# ===================================================================================================
+class DeblurDiffusion(nn.Module):
+    def __init__(self, denoise_fn, *, image_size, device_of_kernel, channels=3, timesteps=1000, loss_type='l1', kernel_std=0.1,
+                 kernel_size=3, blur_routine='Incremental', train_routine='Final', sampling_routine='default', discrete=False):
+        super().__init__()
+        self.channels = channels
+        self.image_size = image_size
+        self.denoise_fn = denoise_fn
+        self.device_of_kernel = device_of_kernel
+        self.num_timesteps = int(timesteps)
+        self.loss_type = loss_type
+        self.kernel_std = kernel_std
+        self.kernel_size = kernel_size
+        self.blur_routine = blur_routine
+        self.gaussian_kernels = nn.ModuleList(self.get_kernels())
+        self.train_routine = train_routine
+        self.sampling_routine = sampling_routine
+        self.discrete = discrete
+        self._taps_cache = None
+
+    # -- kernel construction (DEBLUR:348-389) -------------------------------------------------------
+    def blur(self, dims, std):
+        return D.gaussian_kernel2d(dims, std)
+
+    def get_conv(self, dims, std, mode='circular'):
+        kernel = self.blur(dims, std)
+        conv = nn.Conv2d(in_channels=self.channels, out_channels=self.channels, kernel_size=dims, padding=int((dims[0] - 1) / 2),
+                         padding_mode=mode, bias=False, groups=self.channels)
+        with torch.no_grad():
+            conv.weight = nn.Parameter(kernel[None, None].repeat(self.channels, 1, 1, 1))
+        return conv
+
+    def get_kernels(self):
+        kernels, ks, std = [], self.kernel_size, self.kernel_std
+        for i in range(self.num_timesteps):
+            r = self.blur_routine
+            if r == 'Incremental':
+                kernels.append(self.get_conv((ks, ks), (std * (i + 1), std * (i + 1))))
+            elif r == 'Constant':
+                kernels.append(self.get_conv((ks, ks), (std, std)))
+            elif r == 'Constant_reflect':
+                kernels.append(self.get_conv((ks, ks), (std, std), mode='reflect'))
+            elif r == 'Exponential_reflect':
+                kstd = np.exp(std * i)
+                kernels.append(self.get_conv((ks, ks), (kstd, kstd), mode='reflect'))
+            elif r == 'Exponential':
+                kstd = np.exp(std * i)
+                kernels.append(self.get_conv((ks, ks), (kstd, kstd)))
+            elif r == 'Individual_Incremental':
+                k = 2 * i + 1
+                kernels.append(self.get_conv((k, k), (2 * k, 2 * k)))
+            elif r == 'Special_6_routine':
+                kstd = i / 100 + 0.35
+                kernels.append(self.get_conv((11, 11), (kstd, kstd), mode='reflect'))
+        return kernels
+
+    # -- fused application of the kernel stack -----------------------------------------------------------
+    def _pad_mode(self):
+        return D.PAD_MODES[self.gaussian_kernels[0].padding_mode]
+
+    def _uniform(self):
+        return self.blur_routine != 'Individual_Incremental'
+
+    def _taps(self, device):
+        """[T, C, k, k] stack of the (state_dict) kernel weights on the image's device."""
+        ws = [m.weight for m in self.gaussian_kernels]
+        key = (str(device), tuple((w.data_ptr(), w._version) for w in ws))
+        if self._taps_cache is None or self._taps_cache[0] != key:
+            self._taps_cache = (key, torch.stack([w.detach()[:, 0] for w in ws]).to(device).contiguous())
+        return self._taps_cache[1]
+
+    def _apply_one(self, i, x):
+        """gaussian_kernels[i](x) (any kernel size)."""
+        m = self.gaussian_kernels[i]
+        k = m.weight.shape[-1]
+        return D.blur_step(x, m.weight.detach()[:, 0].contiguous(), k, D.PAD_MODES[m.padding_mode])
+
+    def _degrade(self, x, nsteps, t=None, img=None, want_prev=False, quantise=False):
+        """D(x, nsteps): kernels 0..nsteps-1 (or 0..t[b] per sample), discrete mean-collapse included."""
+        _, _, H, W = x.shape
+        collapse = self.num_timesteps - 1 if self.discrete else -1
+        if self._uniform() and D.blur_fits_lds(H, W, self.gaussian_kernels[0].weight.shape[-1]):
+            k = self.gaussian_kernels[0].weight.shape[-1]
+            return D.blur_chain(x, self._taps(x.device), k, self._pad_mode(), t=t, step_lo=0, step_hi=nsteps - 1, img=img,
+                                want_prev=want_prev, collapse_step=collapse, quantise=quantise)
+        assert t is None and not quantise, "per-sample t needs the LDS-resident path"
+        prev = x
+        for i in range(nsteps):
+            prev = x
+            x = self._apply_one(i, x)
+            if i == collapse:
+                x = D.plane_mean_(x)
+        if img is not None:
+            return D.x0_step_down(img, x, prev)
+        return (x, prev) if want_prev else x
+
+    def _collapse(self, img):
+        return D.plane_mean_(img.clone()) if self.discrete else img
+
+    # -- samplers (DEBLUR:393-689) --------------------------------------------------------------------
+    def _forward_process(self, img, t):
+        if self.blur_routine == 'Individual_Incremental':
+            return self._apply_one(t - 1, img)
+        saved, self.discrete = self.discrete, False          # the forward pass never mean-collapses inside the loop
+        try:
+            return self._degrade(img, t)
+        finally:
+            self.discrete = saved
+
+    def _reverse_step(self, img, x, t):
+        if self.sampling_routine == 'default':
+            if self.blur_routine == 'Individual_Incremental':
+                return self._apply_one(t - 2, x)
+            saved, self.discrete = self.discrete, False      # Alg.1 chain has no collapse (DEBLUR:432-434)
+            try:
+                return self._degrade(x, t - 1)
+            finally:
+                self.discrete = saved
+        if self.sampling_routine == 'x0_step_down':
+            return self._degrade(x, t, img=img)              # img - D(x,t) + D(x,t-1)
+        return x
+
+    @torch.no_grad()
+    def _sample_impl(self, batch_size, img, t, noise_level):
+        self.denoise_fn.eval()
+        if t is None:
+            t = self.num_timesteps
+        img = self._forward_process(rt.check(img), t)
+        img = self._collapse(img)
+        if noise_level is not None:
+            img = img + torch.randn_like(img) * noise_level
+        xt, direct_recons = img, None
+        while t:
+            step = _full_step(batch_size, t - 1, img.device)
+            x = self.denoise_fn(img, step)
+            if self.train_routine == 'Final':
+                if direct_recons is None:
+                    direct_recons = x
+                x = self._reverse_step(img, x, t)
+            img = x
+            t = t - 1
+        return xt, direct_recons, img
+
+    def sample(self, batch_size=16, img=None, t=None):
+        out = self._sample_impl(batch_size, img, t, None)
+        self.denoise_fn.train()
+        return out
+
+    def gen_sample(self, batch_size=16, img=None, t=None, noise_level=0):
+        return self._sample_impl(batch_size, img, t, noise_level)
+
+    gen_sample_2 = gen_sample
+
+    @torch.no_grad()
+    def opt(self, img, t=None):
+        if t is None:
+            t = self.num_timesteps
+        return self._forward_process(rt.check(img), t)
+
+    @torch.no_grad()
+    def all_sample(self, batch_size=16, img=None, t=None, times=None, eval=True):
+        if eval:
+            self.denoise_fn.eval()
+        if t is None:
+            t = self.num_timesteps
+        if times is None:
+            times = t
+        img = self._forward_process(rt.check(img), t)
+        X_0s, X_ts = [], []
+        noise = None
+        if self.discrete:
+            img = self._collapse(img)
+            noise = torch.randn_like(img) * 0.001
+            img = img + noise
+        while times:
+            step = _full_step(batch_size, times - 1, img.device)
+            x = self.denoise_fn(img, step)
+            X_0s.append(x)
+            X_ts.append(img)
+            if self.train_routine == 'Final':
+                if self.blur_routine == 'Individual_Incremental':
+                    if times - 2 >= 0:
+                        x = self._apply_one(times - 2, img)       # reference quirk: blurs x_t (DEBLUR:645-647)
+                else:
+                    x = self._reverse_step(img, x, times)
+            img = x
+            times = times - 1
+        if self.discrete:
+            img = img - noise
+        X_0s.append(img)
+        self.denoise_fn.train()
+        return X_0s, X_ts
+
+    # -- training (DEBLUR:927-981) --------------------------------------------------------------------------
+    def q_sample(self, x_start, t):
+        x_start = rt.check(x_start)
+        if self._uniform() and D.blur_fits_lds(x_start.shape[2], x_start.shape[3], self.gaussian_kernels[0].weight.shape[-1]):
+            return self._degrade(x_start, 0, t=t.contiguous(), quantise=self.discrete)
+        # per-step fallback (varying kernel size / planes larger than LDS): blur to max(t), pick per sample
+        max_iters = int(torch.max(t))
+        x, out = x_start, torch.empty_like(x_start)
+        for i in range(max_iters + 1):
+            x = self._apply_one(i, x)
+            if self.discrete and i == self.num_timesteps - 1:
+                x = D.plane_mean_(x)
+            sel = (t == i).view(-1, 1, 1, 1)
+            out = torch.where(sel, x, out)
+        if self.discrete:
+            out = ((out + 1) * 0.5 * 255).int().float() / 255 * 2 - 1
+        return out
+
+    def p_losses(self, x_start, t):
+        if self.train_routine == 'Final':
+            x_blur = self.q_sample(x_start=x_start, t=t)
+            x_recon = self.denoise_fn(x_blur, t)
+            return D.loss(x_start, x_recon, self.loss_type)
+        raise NotImplementedError()
+
+    def forward(self, x, *args, **kwargs):
+        b, c, h, w, device, img_size = *x.shape, x.device, self.image_size
+        assert h == img_size and w == img_size, f'height and width of image must be {img_size}'
+        t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
+        return self.p_losses(x, t, *args, **kwargs)
+
+
+# ===================================================================================================
+# denoising ("hot" Gaussian-noise baseline with cold-style samplers)
+# ===================================================================================================
+def cosine_beta_schedule(timesteps, s=0.008):
+    steps = timesteps + 1
+    x = torch.linspace(0, steps, steps)
+    alphas_cumprod = torch.cos(((x / steps) + s) / (1 + s) * torch.pi * 0.5) ** 2
+    alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
+    betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
+    return torch.clip(betas, 0, 0.999)
+
+
+class DenoiseDiffusion(nn.Module):
+    def __init__(self, denoise_fn, *, image_size, channels=3, timesteps=1000, loss_type='l1', train_routine='Final',
+                 sampling_routine='default', discrete=False):
+        super().__init__()
+        self.channels = channels
+        self.image_size = image_size
+        self.denoise_fn = denoise_fn
+        self.num_timesteps = int(timesteps)
+        self.loss_type = loss_type
+        betas = cosine_beta_schedule(timesteps)
+        alphas_cumprod = torch.cumprod(1. - betas, axis=0)
+        self.register_buffer('alphas_cumprod', alphas_cumprod)
+        self.register_buffer('sqrt_alphas_cumprod', torch.sqrt(alphas_cumprod))
+        self.register_buffer('sqrt_one_minus_alphas_cumprod', torch.sqrt(1. - alphas_cumprod))
+        self.train_routine = train_routine
+        self.sampling_routine = sampling_routine
+
+    def _tables(self):
+        return self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod
+
+    def q_sample(self, x_start, x_end, t):
+        ca, cb = self._tables()
+        return D.noise_qsample(rt.check(x_start), x_end, ca, cb, t.contiguous())
+
+    def get_x2_bar_from_xt(self, x1_bar, xt, t):
+        ca, cb = self._tables()
+        return (xt - ca.gather(-1, t).view(-1, 1, 1, 1) * x1_bar) / cb.gather(-1, t).view(-1, 1, 1, 1)
+
+    @torch.no_grad()
+    def _reverse(self, batch_size, img, t, est_noise, noise):
+        ca, cb = self._tables()
+        direct_recons = None
+        while t:
+            step = _full_step(batch_size, t - 1, img.device)
+            x1_bar = self.denoise_fn(img, step)
+            if direct_recons is None:
+                direct_recons = x1_bar
+            img = D.noise_step(img, x1_bar, noise, ca, cb, t, est_noise)
+            t = t - 1
+        return direct_recons, img
+
+    def sample(self, batch_size=16, img=None, t=None):
+        # always the estimated-noise form, whatever sampling_routine says (DENOISE:342-375)
+        self.denoise_fn.eval()
+        t = self.num_timesteps if t is None else t
+        xt = rt.check(img)
+        direct_recons, img = self._reverse(batch_size, xt, t, True, None)
+        self.denoise_fn.train()
+        return xt, direct_recons, img
+
+    def gen_sample(self, batch_size=16, img=None, t=None):
+        self.denoise_fn.eval()
+        t = self.num_timesteps if t is None else t
+        noise = rt.check(img)
+        direct_recons = None
+        if self.sampling_routine == 'ddim':
+            direct_recons, img = self._reverse(batch_size, noise, t, True, None)
+        elif self.sampling_routine == 'x0_step_down':
+            direct_recons, img = self._reverse(batch_size, noise, t, False, noise)
+        return noise, direct_recons, img
+
+    @torch.no_grad()
+    def all_sample(self, batch_size=16, img=None, t=None, times=None, eval=True):
+        if eval:
+            self.denoise_fn.eval()
+        t = self.num_timesteps if t is None else t
+        ca, cb = self._tables()
+        X1_0s, X2_0s, X_ts = [], [], []
+        while t:
+            step = _full_step(batch_size, t - 1, img.device)
+            x1_bar = self.denoise_fn(img, step)
+            x2_bar = self.get_x2_bar_from_xt(x1_bar, img, step)
+            X1_0s.append(x1_bar.detach().cpu())
+            X2_0s.append(x2_bar.detach().cpu())
+            X_ts.append(img.detach().cpu())
+            img = D.noise_step(img, x1_bar, None, ca, cb, t, True)
+            t = t - 1
+        return X1_0s, X2_0s, X_ts
+
+    def p_losses(self, x_start, x_end, t):
+        if self.train_routine == 'Final':
+            x_mix = self.q_sample(x_start=x_start, x_end=x_end, t=t)
+            x_recon = self.denoise_fn(x_mix, t)
+            return D.loss(x_start, x_recon, self.loss_type)
+        raise NotImplementedError()
+
+    def forward(self, x1, x2, *args, **kwargs):
+        b, c, h, w, device, img_size = *x1.shape, x1.device, self.image_size
+        assert h == img_size and w == img_size, f'height and width of image must be {img_size}'
+        t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
+        return self.p_losses(x1, x2, t, *args, **kwargs)
+
+
+# ===================================================================================================
+# resolution (pixelation)
+# ===================================================================================================
+class ResolutionDiffusion(nn.Module):
+    _MODES = {'': 'bicubic', '_bilinear': 'bilinear', '_area': 'area', '_bicubic': 'bicubic'}
+
+    def __init__(self, denoise_fn, *, image_size, device_of_kernel, channels=3, timesteps=1000, loss_type='l1',
+                 resolution_routine='Incremental', train_routine='Final', sampling_routine='default'):
+        super().__init__()
+        self.channels = channels
+        self.image_size = image_size
+        self.denoise_fn = denoise_fn
+        self.device_of_kernel = device_of_kernel
+        self.num_timesteps = int(timesteps)
+        self.loss_type = loss_type
+        self.resolution_routine = resolution_routine
+        self.train_routine = train_routine
+        self.sampling_routine = sampling_routine
+        self._parse_routine()
+        self.func = self.get_funcs()
+        self._sizes_cache = {}
+
+    def _parse_routine(self):
+        r = self.resolution_routine
+        assert r.startswith('Incremental'), r
+        rest = r[len('Incremental'):]
+        self._with_blur = rest.endswith('_with_blur')
+        if self._with_blur:
+            rest = rest[:-len('_with_blur')]
+        self._factor2 = rest.endswith('_factor_2')
+        if self._factor2:
+            rest = rest[:-len('_factor_2')]
+        self._mode = D.PIX_MODES[self._MODES[rest]]
+        if self._factor2:
+            dec = [self.image_size - self.image_size // 2 ** (i + 1) for i in range(self.num_timesteps)]
+        else:
+            dec = list(range(self.num_timesteps))
+        self._sizes_host = [self.image_size - d for d in dec]      # F.interpolate(size = H - dec_size)
+        self._blur_taps = D.gaussian_kernel2d((3, 3), (0.5, 0.5))[None].repeat(self.channels, 1, 1).contiguous()
+
+    def _sizes(self, device):
+        key = str(device)
+        if key not in self._sizes_cache:
+            self._sizes_cache[key] = torch.tensor(self._sizes_host, dtype=torch.int32, device=device)
+        return self._sizes_cache[key]
+
+    def transform_func(self, img, i):
+        """One degradation step func[i] (RESOL:354-385)."""
+        img = rt.check(img)
+        if self._with_blur:
+            taps = self._blur_taps.to(img.device)
+            img = D.blur_step(img, taps, 3, 1)
+        img = D.pixelate_chain(img, self._sizes(img.device), self._mode, step_lo=i, step_hi=i)
+        if self._with_blur:
+            img = D.blur_step(img, taps, 3, 1)
+        return img
+
+    def get_funcs(self):
+        return [(lambda img, i=i: self.transform_func(img, i)) for i in range(self.num_timesteps)]
+
+    def _degrade(self, x, nsteps, t=None, img=None):
+        if not self._with_blur:
+            return D.pixelate_chain(x, self._sizes(x.device), self._mode, t=t, step_lo=0, step_hi=nsteps - 1, img=img)
+        assert t is None
+        prev = x
+        for i in range(nsteps):
+            prev = x
+            x = self.transform_func(x, i)
+        return D.x0_step_down(img, x, prev) if img is not None else x
+
+    @torch.no_grad()
+    def sample(self, batch_size=16, img=None, t=None):
+        if t is None:
+            t = self.num_timesteps
+        img = self._degrade(rt.check(img), t)
+        xt, direct_recons = img, None
+        while t:
+            step = _full_step(batch_size, t - 1, img.device)
+            x = self.denoise_fn(img, step)
+            if self.train_routine == 'Final':
+                if direct_recons is None:
+                    direct_recons = x
+                if self.sampling_routine == 'default':
+                    x = self._degrade(x, t - 1)
+                elif self.sampling_routine == 'x0_step_down':
+                    x = self._degrade(x, t, img=img)
+            img = x
+            t = t - 1
+        return xt, direct_recons, img
+
+    @torch.no_grad()
+    def gen_sample(self, batch_size=16, img=None, t=None, times=None, noise_level=0):
+        if t is None:
+            t = self.num_timesteps
+        img = rt.check(img)
+        img = img + torch.randn_like(img) * noise_level
+        direct_recons = None
+        xt = img
+        while t:
+            step = _full_step(batch_size, t - 1, img.device)
+            x = self.denoise_fn(img, step)
+            if direct_recons is None:
+                direct_recons = x
+            if self.sampling_routine == 'default':
+                x = self._degrade(x, t - 1)
+            elif self.sampling_routine == 'x0_step_down':
+                x = self._degrade(x, t, img=img)
+            img = x
+            t = t - 1
+        return xt, direct_recons, img
+
+    @torch.no_grad()
+    def opt(self, img, t=None):
+        if t is None:
+            t = self.num_timesteps
+        return self._degrade(rt.check(img), t)
+
+    def q_sample(self, x_start, t):
+        x_start = rt.check(x_start)
+        if not self._with_blur:
+            return self._degrade(x_start, 0, t=t.contiguous())
+        max_iters = int(torch.max(t))
+        x, out = x_start, torch.empty_like(x_start)
+        for i in range(max_iters + 1):
+            x = self.transform_func(x, i)
+            out = torch.where((t == i).view(-1, 1, 1, 1), x, out)
+        return out
+
+    def p_losses(self, x_start, t):
+        if self.train_routine == 'Final':
+            x_blur = self.q_sample(x_start=x_start, t=t)
+            x_recon = self.denoise_fn(x_blur, t)
+            return D.loss(x_start, x_recon, self.loss_type)
+        if self.train_routine == 'Step':
+            x_blur = self.q_sample(x_start=x_start, t=t)
+            x_blur_sub = self.q_sample(x_start=x_start, t=t - 1)
+            return D.loss(x_blur_sub, self.denoise_fn(x_blur, t), self.loss_type)
+        raise NotImplementedError(self.train_routine)
+
+    def forward(self, x, *args, **kwargs):
+        b, c, h, w, device, img_size = *x.shape, x.device, self.image_size
+        assert h == img_size and w == img_size, f'height and width of image must be {img_size}'
+        t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
+        return self.p_losses(x, t, *args, **kwargs)
+
+
+# ===================================================================================================
+# defading (Gaussian-mask inpainting)
+# ===================================================================================================
+class DefadeDiffusion(nn.Module):
+    def __init__(self, defade_fn, *, image_size, device_of_kernel, channels=3, timesteps=1000, loss_type='l1', kernel_std=0.1,
+                 initial_mask=11, fade_routine='Incremental', sampling_routine='default', discrete=False):
+        super().__init__()
+        self.channels = channels
+        self.image_size = image_size
+        self.defade_fn = defade_fn
+        self.device_of_kernel = device_of_kernel
+        self.num_timesteps = int(timesteps)
+        self.loss_type = loss_type
+        self.kernel_std = kernel_std
+        self.initial_mask = initial_mask
+        self.fade_routine = fade_routine
+        self.fade_kernels = self.get_kernels()
+        self.sampling_routine = sampling_routine
+        self.discrete = discrete
+
+    def get_fade_kernel(self, dims, std):
+        fade_kernel = D.gaussian_kernel2d(dims, std)
+        fade_kernel = fade_kernel / torch.max(fade_kernel)
+        fade_kernel = torch.ones_like(fade_kernel) - fade_kernel
+        return fade_kernel[1:, 1:]
+
+    def get_kernels(self):
+        kernels, n = [], self.image_size
+        for i in range(self.num_timesteps):
+            if self.fade_routine == 'Incremental':
+                s = self.kernel_std * (i + self.initial_mask)
+                kernels.append(self.get_fade_kernel((n + 1, n + 1), (s, s)))
+            elif self.fade_routine == 'Constant':
+                kernels.append(self.get_fade_kernel((n + 1, n + 1), (self.kernel_std, self.kernel_std)))
+            elif self.fade_routine == 'Random_Incremental':
+                s = self.kernel_std * (i + self.initial_mask)
+                kernels.append(self.get_fade_kernel((2 * n + 1, 2 * n + 1), (s, s)))
+        return torch.stack(kernels)
+
+    def _masks(self, device):
+        if self.fade_kernels.device != device:
+            self.fade_kernels = self.fade_kernels.to(device)
+        return self.fade_kernels.contiguous()
+
+    def _offsets(self, batch_size, device):
+        if 'Random' not in self.fade_routine:
+            return None, None
+        assert self.channels == 3, "the Random_* routines stack exactly three mask channels (DEFADE:514-516)"
+        rand_x = torch.randint(0, self.image_size + 1, (batch_size,), device=device).long()
+        rand_y = torch.randint(0, self.image_size + 1, (batch_size,), device=device).long()
+        return rand_x, rand_y        # rows are cropped at rand_x, columns at rand_y (DEFADE:503-507)
+
+    @torch.no_grad()
+    def _sample_impl(self, batch_size, faded, t, times, collect):
+        faded = rt.check(faded)
+        masks = self._masks(faded.device)
+        oy, ox = self._offsets(batch_size, faded.device)
+        if t is None:
+            t = self.num_timesteps
+        if times is None:
+            times = t
+        faded = D.mask_chain(faded, masks, step_lo=0, step_hi=t - 1, off_y=oy, off_x=ox, quantise=self.discrete)
+        xt, direct_recons, recon = faded, None, None
+        x0_list, xt_list = [], []
+        while times:
+            step = _full_step(batch_size, times - 1, faded.device)
+            recon = self.defade_fn(faded, step)
+            x0_list.append(recon)
+            if direct_recons is None:
+                direct_recons = recon
+            if self.sampling_routine == 'default':
+                faded = D.mask_chain(recon, masks, step_lo=0, step_hi=times - 2, off_y=oy, off_x=ox)
+            elif self.sampling_routine == 'x0_step_down':
+                faded = D.mask_chain(recon, masks, step_lo=0, step_hi=times - 1, img=faded, off_y=oy, off_x=ox)
+            recon = faded
+            xt_list.append(faded)
+            times -= 1
+        return (x0_list, xt_list) if collect else (xt, direct_recons, recon)
+
+    def sample(self, batch_size=16, faded_recon_sample=None, t=None):
+        return self._sample_impl(batch_size, faded_recon_sample, t, None, False)
+
+    def all_sample(self, batch_size=16, faded_recon_sample=None, t=None, times=None):
+        return self._sample_impl(batch_size, faded_recon_sample, t, times, True)
+
+    def q_sample(self, x_start, t):
+        x_start = rt.check(x_start)
+        oy, ox = self._offsets(x_start.size(0), x_start.device)
+        return D.mask_chain(x_start, self._masks(x_start.device), t=t.contiguous(), off_y=oy, off_x=ox, quantise=self.discrete)
+
+    def p_losses(self, x_start, t):
+        x_fade = self.q_sample(x_start=x_start, t=t)
+        x_recon = self.defade_fn(x_fade, t)
+        return D.loss(x_start, x_recon, self.loss_type)
+
+    def forward(self, x, *args, **kwargs):
+        b, c, h, w, device, img_size = *x.shape, x.device, self.image_size
+        assert h == img_size and w == img_size, f'height and width of image must be {img_size}'
+        t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
+        self.fade_kernels = self.fade_kernels.to(device)
+        return self.p_losses(x, t, *args, **kwargs)

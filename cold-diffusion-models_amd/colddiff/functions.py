@@ -10,8 +10,17 @@ import torch
 
 from . import convdesc as cd
 from . import ops
+from . import parallel
 from . import runtime as rt
 from .runtime import P, r4
+
+
+def _done(*mods):
+    """Tell the data-parallel engine that the gradients of these modules' own parameters are final."""
+    if parallel._engine is not None:
+        for m in mods:
+            if m is not None:
+                parallel.grads_ready(list(m.parameters(recurse=False)))
 
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
 
@@ -169,6 +178,7 @@ class Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             plan = cd.conv_fwd(1, 1, 1, 1, 1, 0, 0, 0, 0)
             dx = ops.conv_gemm(plan, dy4, N, W.detach().view(1, N, K), K).view(B, r4(K))[:, :x.shape[1]]
+        _done(lin)
         return None, dx, None
 
 
@@ -187,6 +197,7 @@ class ConvFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         Cin, kind, stride, pad = ctx.cfg
         dx = conv_backward(x, Cin, dy, ctx.mod.weight, ctx.mod.bias, kind, stride, pad, need_dx=ctx.needs_input_grad[1])
+        _done(ctx.mod)
         return None, dx, None, None, None, None, None
 
 
@@ -245,6 +256,7 @@ class ConvNextBlockFn(torch.autograd.Function):
         dtb = ops.dwconv7_wgrad(x, dh, m.ds_conv.weight, m.ds_conv.bias, ctx.has_t)
         if need_dx:
             ops.dwconv7(dh, ops.packed(m.ds_conv.weight, "dw"), None, None, flip=1, y=dx, accumulate=1)
+        _done(m.ds_conv, m.net[0] if m.has_norm else None, c1, c2, m.res_conv if m.has_res_conv else None)
         return None, dx, dtb, None
 
 
@@ -274,4 +286,141 @@ class LinAttnBlockFn(torch.autograd.Function):
         dxn = conv_backward(xn, dim, dqkv, att.to_qkv.weight, None)
         dx = ops.copy_feat(dy)
         ops.layernorm_bwd(dxn, x, norm.g, norm.b, mean, rstd, dx=dx)
+        _done(norm, att.to_qkv, att.to_out)
+        return None, dx, None
+
+
+# ===================================================================================================
+# DDPM `Model` family (Model2.py)
+# ===================================================================================================
+GN_GROUPS, GN_EPS = 32, 1e-6
+
+
+def _seed():
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+class GroupNormFn(torch.autograd.Function):
+    """Normalize(C) [+ swish] as a standalone node (norm_out -> nonlinearity, Model2.py:329-330)."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, norm, silu):
+        y, mean, rstd = ops.groupnorm_fwd(x, norm.weight, norm.bias, GN_GROUPS, GN_EPS, silu)
+        ctx.norm, ctx.silu = norm, silu
+        ctx.save_for_backward(x, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        dx = ops.groupnorm_bwd(dy, x, ctx.norm.weight, ctx.norm.bias, mean, rstd, GN_GROUPS, ctx.silu)
+        _done(ctx.norm)
+        return None, dx, None, None
+
+
+class UpsampleConvFn(torch.autograd.Function):
+    """F.interpolate(scale 2, nearest) -> Conv2d 3x3 (Model2.py:36-50); the x2 map is rebuilt in backward."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, conv):
+        up = ops.upsample2(x)
+        y = conv_forward(up, x.shape[-1], conv.weight, conv.bias)
+        ctx.conv = conv
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        up = ops.upsample2(x)
+        dup = conv_backward(up, x.shape[-1], dy, ctx.conv.weight, ctx.conv.bias)
+        _done(ctx.conv)
+        return None, ops.upsample2_bwd(dup), None
+
+
+class ResnetBlockFn(torch.autograd.Function):
+    """ResnetBlock.forward (Model2.py:114-133): GN+swish -> conv1 (+temb bias) -> GN+swish -> dropout -> conv2 (+shortcut)."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, tbias, m):
+        cin, cout = m.in_channels, m.out_channels
+        h1, mean1, rstd1 = ops.groupnorm_fwd(x, m.norm1.weight, m.norm1.bias, GN_GROUPS, GN_EPS, True)
+        h2 = conv_forward(h1, cin, m.conv1.weight, m.conv1.bias, sbias=tbias)
+        h3, mean2, rstd2 = ops.groupnorm_fwd(h2, m.norm2.weight, m.norm2.bias, GN_GROUPS, GN_EPS, True)
+        p = m.dropout.p if m.training else 0.0
+        seed = 0
+        if p > 0:
+            seed = _seed()
+            h3 = ops.dropout(h3, p, seed)
+        if cin != cout:
+            sc_mod = m.conv_shortcut if m.use_conv_shortcut else m.nin_shortcut
+            sc = conv_forward(x, cin, sc_mod.weight, sc_mod.bias)
+        else:
+            sc = x
+        o = conv_forward(h3, cout, m.conv2.weight, m.conv2.bias, res=sc)
+        ctx.m, ctx.drop = m, (p, seed)
+        ctx.save_for_backward(x, h1, h2, h3, mean1, rstd1, mean2, rstd2)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        x, h1, h2, h3, mean1, rstd1, mean2, rstd2 = ctx.saved_tensors
+        m = ctx.m
+        cin, cout = m.in_channels, m.out_channels
+        p, seed = ctx.drop
+        sc_mod = None
+        if cin != cout:
+            sc_mod = m.conv_shortcut if m.use_conv_shortcut else m.nin_shortcut
+            dx = conv_backward(x, cin, do, sc_mod.weight, sc_mod.bias)
+        else:
+            dx = ops.copy_feat(do)
+        dh3 = conv_backward(h3, cout, do, m.conv2.weight, m.conv2.bias)
+        if p > 0:
+            dh3 = ops.dropout(dh3, p, seed)
+        dh2 = ops.groupnorm_bwd(dh3, h2, m.norm2.weight, m.norm2.bias, mean2, rstd2, GN_GROUPS, True)
+        dtb = ops.colsum_new(dh2, cout, dh2.shape[0])
+        dh1 = conv_backward(h1, cin, dh2, m.conv1.weight, m.conv1.bias)
+        ops.groupnorm_bwd(dh1, x, m.norm1.weight, m.norm1.bias, mean1, rstd1, GN_GROUPS, True, dx=dx)
+        _done(m.norm1, m.conv1, m.norm2, m.conv2, sc_mod)
+        return None, dx, dtb, None
+
+
+class AttnBlockFn(torch.autograd.Function):
+    """AttnBlock.forward (Model2.py:164-188): GN -> q,k,v 1x1 -> softmax(q k^T C^-0.5) v -> proj_out + x."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, m):
+        B, H, W, C = x.shape
+        n = H * W
+        hn, mean, rstd = ops.groupnorm_fwd(x, m.norm.weight, m.norm.bias, GN_GROUPS, GN_EPS, False)
+        q = conv_forward(hn, C, m.q.weight, m.q.bias).view(B, n, C)
+        k = conv_forward(hn, C, m.k.weight, m.k.bias).view(B, n, C)
+        v = conv_forward(hn, C, m.v.weight, m.v.bias).view(B, n, C)
+        s = ops.bgemm_nt(q, k)                               # [B, n, n]  w_[b,i,j] = sum_c q[b,i,c] k[b,j,c]
+        pm = ops.softmax_rows(s, n, float(int(C) ** (-0.5)))
+        o = ops.bgemm_nn(pm, v, K=n).view(B, H, W, C)        # h_[b,i,c] = sum_j P[b,i,j] v[b,j,c]
+        y = conv_forward(o, C, m.proj_out.weight, m.proj_out.bias, res=x)
+        ctx.m = m
+        ctx.save_for_backward(x, hn, mean, rstd, q, k, v, pm, o)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, hn, mean, rstd, q, k, v, pm, o = ctx.saved_tensors
+        m = ctx.m
+        B, H, W, C = x.shape
+        n = H * W
+        scale = float(int(C) ** (-0.5))
+        do = conv_backward(o, C, dy, m.proj_out.weight, m.proj_out.bias).view(B, n, C)
+        dp = ops.bgemm_nt(do, v)                              # dP[b,i,j] = sum_c dO[b,i,c] v[b,j,c]
+        dv = ops.bgemm_tn(pm, do, CA=n)                       # dv[b,j,c] = sum_i P[b,i,j] dO[b,i,c]
+        ds = ops.softmax_rows_bwd(pm, dp, n, scale)
+        dq = ops.bgemm_nn(ds, k, K=n)                         # dq[b,i,c] = sum_j dS[b,i,j] k[b,j,c]
+        dk = ops.bgemm_tn(ds, q, CA=n)                        # dk[b,j,c] = sum_i dS[b,i,j] q[b,i,c]
+        dhn = conv_backward(hn, C, dq.view(B, H, W, C), m.q.weight, m.q.bias)
+        conv_backward(hn, C, dk.view(B, H, W, C), m.k.weight, m.k.bias, dx=dhn, dx_accumulate=1)
+        conv_backward(hn, C, dv.view(B, H, W, C), m.v.weight, m.v.bias, dx=dhn, dx_accumulate=1)
+        dx = ops.copy_feat(dy)
+        ops.groupnorm_bwd(dhn, x, m.norm.weight, m.norm.bias, mean, rstd, GN_GROUPS, False, dx=dx)
+        _done(m.norm, m.q, m.k, m.v, m.proj_out)
         return None, dx, None

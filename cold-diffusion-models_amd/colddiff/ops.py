@@ -230,3 +230,120 @@ def nhwc_to_nchw(x, C, add=None):
     y = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
     rt.lib().cdf_nhwc_to_nchw(P(x), P(y), P(add), B, C, H * W, ld_of(x), rt.stream(x))
     return y
+
+
+# ---------------------------------------------------------------------------------------------------
+# GroupNorm / batched GEMMs / resampling (the DDPM `Model` family)
+# ---------------------------------------------------------------------------------------------------
+def groupnorm_fwd(x, gamma, beta, groups, eps, silu):
+    L = rt.lib()
+    B, H, W, C = x.shape
+    HW = H * W
+    nch = L.cdf_groupnorm_nchunk(HW)
+    y = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+    mean = torch.empty((B * groups,), device=x.device, dtype=torch.float32)
+    rstd = torch.empty((B * groups,), device=x.device, dtype=torch.float32)
+    ws = torch.empty((B * nch * 2 * C,), device=x.device, dtype=torch.float32)
+    L.cdf_groupnorm_fwd(P(x), ld_of(x), P(y), C, P(gamma), P(beta), P(mean), P(rstd), P(ws), B, HW, C, groups, eps, 1 if silu else 0,
+                        rt.stream(x))
+    return y, mean, rstd
+
+
+def groupnorm_bwd(dy, x, gamma_p, beta_p, mean, rstd, groups, silu, dx=None):
+    L = rt.lib()
+    B, H, W, C = x.shape
+    HW = H * W
+    nch = L.cdf_groupnorm_nchunk(HW)
+    acc = 1 if dx is not None else 0
+    if dx is None:
+        dx = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+    ws = torch.empty((B * nch * 2 * C + B * 2 * C + B * groups * 2,), device=x.device, dtype=torch.float32)
+    L.cdf_groupnorm_bwd(P(dy), ld_of(dy), P(x), ld_of(x), P(gamma_p), P(beta_p), P(mean), P(rstd), P(dx), ld_of(dx),
+                        P(grad_of(gamma_p)), P(grad_of(beta_p)), P(ws), B, HW, C, groups, 1 if silu else 0, acc, 1, rt.stream(x))
+    return dx
+
+
+_ONE_TAP = None
+
+
+def _one_tap(n):
+    return cd.conv_fwd(1, n, 1, 1, 1, 0, 0, 0, 0)
+
+
+def bgemm_nt(a, b):
+    """[nb, n, K] x [nb, m, K]^T -> [nb, n, r4(m)] (valid columns :m)."""
+    nb, n, K = a.shape
+    m = b.shape[1]
+    out = new_feat(a, nb, 1, n, m).view(nb, n, r4(m))
+    plan = _one_tap(n)
+    rt.lib().cdf_conv_gemm(P(a), a.stride(1), P(b), b.stride(1), P(out), r4(m), 1, 1, n, K, 1, n, m, 1, n, 1, 1, 1, plan.desc,
+                           0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, nb, a.stride(0), b.stride(0), n * r4(m), rt.stream(a))
+    return out
+
+
+def bgemm_nn(a, b, K=None):
+    """[nb, n, K] x [nb, K, m] -> [nb, n, r4(m)]; b is [K][m] row-major with pitch b.stride(1)."""
+    nb, n = a.shape[0], a.shape[1]
+    K = a.shape[2] if K is None else K
+    m = b.shape[2]
+    out = new_feat(a, nb, 1, n, m).view(nb, n, r4(m))
+    plan = _one_tap(n)
+    rt.lib().cdf_conv_gemm(P(a), a.stride(1), P(b), b.stride(1), P(out), r4(m), 1, 1, n, K, 1, n, m, 1, n, 1, 1, 1, plan.desc,
+                           0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, nb, a.stride(0), b.stride(0), n * r4(m), rt.stream(a))
+    return out
+
+
+def bgemm_tn(a, b, CA=None):
+    """[nb, K, n]^T x [nb, K, m] -> [nb, n(:CA), r4(m)]  (reduction over the row index)."""
+    nb, K = a.shape[0], a.shape[1]
+    CA = a.shape[2] if CA is None else CA
+    m = b.shape[2]
+    out = torch.empty((nb, CA, r4(m)), device=a.device, dtype=torch.float32)
+    tap = cd.conv_wgrad(1, K, 1, 1, 1, 0, 0, 0, 0)
+    rt.lib().cdf_conv_wgrad(P(a), a.stride(1), P(b), b.stride(1), P(out), r4(m), 1, 1, K, 1, K, 1, 1, K, 1, CA, m, 1, tap.desc, 1, nb,
+                            a.stride(0), b.stride(0), CA * r4(m), rt.stream(a))
+    return out
+
+
+def softmax_rows(s, n, scale):
+    p = torch.empty_like(s)
+    rows = s.numel() // s.shape[-1]
+    rt.lib().cdf_softmax_rows_fwd(P(s), P(p), rows, n, s.shape[-1], scale, rt.stream(s))
+    return p
+
+
+def softmax_rows_bwd(p, dp, n, scale):
+    ds = torch.zeros_like(p) if p.shape[-1] != n else torch.empty_like(p)
+    rows = p.numel() // p.shape[-1]
+    rt.lib().cdf_softmax_rows_bwd(P(p), P(dp), P(ds), rows, n, p.shape[-1], scale, rt.stream(p))
+    return ds
+
+
+def upsample2(x):
+    B, H, W, C = x.shape
+    y = torch.empty((B, 2 * H, 2 * W, C), device=x.device, dtype=torch.float32)
+    rt.lib().cdf_upsample2(P(x), ld_of(x), P(y), C, B, H, W, C, rt.stream(x))
+    return y
+
+
+def upsample2_bwd(dy, dx=None):
+    B, H2, W2, C = dy.shape
+    acc = 1 if dx is not None else 0
+    if dx is None:
+        dx = torch.empty((B, H2 // 2, W2 // 2, C), device=dy.device, dtype=torch.float32)
+    rt.lib().cdf_upsample2_bwd(P(dy), ld_of(dy), P(dx), ld_of(dx), B, H2 // 2, W2 // 2, C, acc, rt.stream(dy))
+    return dx
+
+
+def dropout(x, p, seed):
+    y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    rows = x.numel() // x.shape[-1]
+    rt.lib().cdf_dropout(P(x), ld_of(x), P(y), x.shape[-1], rows, x.shape[-1], p, seed, rt.stream(x))
+    return y
+
+
+def colsum_new(x, C, nseg):
+    """[nseg, r4(C)] column sums per segment (fresh tensor)."""
+    out = torch.zeros((nseg, r4(C)), device=x.device, dtype=torch.float32)
+    colsum_into(out, x, C, nseg)
+    return out

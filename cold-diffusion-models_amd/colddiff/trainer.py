@@ -1,0 +1,265 @@
+"""`Trainer` — the training loop of the cold-diffusion packages on the fused optimizer tail.
+
+Follows deblurring_diffusion_pytorch.py:1057-1235 (and the denoising variant,
+denoising_diffusion_pytorch.py:620-789): same constructor, `train() / save() / load() / step_ema()
+/ reset_parameters()`, same checkpoint dict (`step`, `model`, `ema` state_dicts with the
+DataParallel `module.` prefix when the model was wrapped), gradient accumulation, Adam(lr) defaults,
+EMA copy-then-lerp schedule and milestone sampling.  Differences, all performance-only:
+  * Adam / EMA / zero_grad are single kernel launches over a flat parameter arena (colddiff.flat)
+  * multi-GPU = one process per GPU + RCCL all-reduce (colddiff.parallel) instead of DataParallel
+  * the loss is logged without a host sync on every micro-step (the reference calls loss.item() twice)
+"""
+import copy
+import glob
+import os
+from functools import partial
+from pathlib import Path
+
+import torch
+from torch.utils import data
+
+from . import flat, parallel
+from . import runtime as rt
+
+
+def cycle(dl):
+    while True:
+        for d in dl:
+            yield d
+
+
+def unwrap(model):
+    """The reference scripts hand the Trainer a torch.nn.DataParallel wrapper; compute on its module."""
+    if isinstance(model, (torch.nn.DataParallel, torch.nn.parallel.DistributedDataParallel)):
+        return model.module
+    return model
+
+
+class EMA:
+    def __init__(self, beta):
+        self.beta = beta
+
+    def update_model_average(self, ma_arena, model_arena):
+        flat.ema_update(ma_arena, model_arena, self.beta)
+
+
+# -- image folder datasets (DEBLUR:983-1026) with PIL only (torchvision is not a dependency) ----------
+def _load_image(path, size, augment):
+    from PIL import Image
+    import numpy as np
+    img = Image.open(path)
+    big = int(size * 1.12)
+    img = img.resize((big, big), Image.BILINEAR)
+    if augment:
+        ox, oy = (int(torch.randint(0, big - size + 1, (1,))) for _ in range(2))
+    else:
+        ox = oy = (big - size) // 2          # CenterCrop
+    img = img.crop((ox, oy, ox + size, oy + size))
+    if augment and torch.rand(1).item() < 0.5:
+        img = img.transpose(Image.FLIP_LEFT_RIGHT)
+    arr = np.asarray(img, dtype=np.float32) / 255.0
+    if arr.ndim == 2:
+        arr = arr[:, :, None]
+    return torch.from_numpy(arr).permute(2, 0, 1).contiguous() * 2 - 1
+
+
+class Dataset(data.Dataset):
+    augment = False
+
+    def __init__(self, folder, image_size, exts=('jpg', 'jpeg', 'png')):
+        super().__init__()
+        self.folder, self.image_size = folder, image_size
+        self.paths = [p for ext in exts for p in Path(f'{folder}').glob(f'**/*.{ext}')]
+
+    def __len__(self):
+        return len(self.paths)
+
+    def __getitem__(self, index):
+        return _load_image(self.paths[index], self.image_size, self.augment)
+
+
+class Dataset_Aug1(Dataset):
+    augment = True
+
+
+class SyntheticImages:
+    """Endless 8-bit-quantised uniform images generated on the device (benchmarks, smoke tests)."""
+
+    def __init__(self, batch_size, channels, image_size, device, seed=123457):
+        self.shape = (batch_size, channels, image_size, image_size)
+        self.device = device
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(seed)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return torch.randint(0, 256, self.shape, generator=self.gen, device=self.device).float() / 255 * 2 - 1
+
+
+def save_image(tensor, path, nrow=6):
+    """Minimal torchvision.utils.save_image: [B,C,H,W] in [0,1] -> PNG grid."""
+    from PIL import Image
+    t = tensor.detach().float().clamp(0, 1).cpu()
+    B, C, H, W = t.shape
+    ncol = min(nrow, B)
+    nr = (B + ncol - 1) // ncol
+    pad = 2
+    grid = torch.zeros(C, nr * (H + pad) + pad, ncol * (W + pad) + pad)
+    for i in range(B):
+        r, c = divmod(i, ncol)
+        grid[:, pad + r * (H + pad): pad + r * (H + pad) + H, pad + c * (W + pad): pad + c * (W + pad) + W] = t[i]
+    arr = (grid * 255 + 0.5).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).numpy()
+    Image.fromarray(arr[:, :, 0] if C == 1 else arr).save(str(path))
+
+
+class Trainer(object):
+    AUG_DATASETS = ('mnist', 'cifar10', 'flower', 'celebA', 'AFHQ', 'train')
+
+    def __init__(self, diffusion_model, folder, *, ema_decay=0.995, image_size=128, train_batch_size=32, train_lr=2e-5,
+                 train_num_steps=100000, gradient_accumulate_every=2, fp16=False, step_start_ema=2000, update_ema_every=10,
+                 save_and_sample_every=1000, results_folder='./results', load_path=None, dataset=None, shuffle=True,
+                 num_workers=8):
+        super().__init__()
+        assert not fp16, "apex fp16 is not supported (every reference script passes fp16=False)"
+        self.model = diffusion_model
+        self.ema = EMA(ema_decay)
+        self.ema_model = copy.deepcopy(self.model)
+        self.update_ema_every = update_ema_every
+        self.step_start_ema = step_start_ema
+        self.save_and_sample_every = save_and_sample_every
+        self.batch_size = train_batch_size
+        self.image_size = image_size
+        self.gradient_accumulate_every = gradient_accumulate_every
+        self.train_num_steps = train_num_steps
+        self.core = unwrap(self.model)
+        self.ema_core = unwrap(self.ema_model)
+        # the denoising package feeds (image, fresh Gaussian noise) pairs (DENOISE:738-742)
+        self.pair_noise = hasattr(self.core, 'sqrt_alphas_cumprod')
+        self.device = next(self.core.parameters()).device
+
+        if dataset == 'synthetic' or folder is None:
+            self.ds = None
+            self.dl = SyntheticImages(train_batch_size, self.core.channels, image_size, self.device)
+        else:
+            aug = dataset in self.AUG_DATASETS
+            print(dataset, "DA used" if aug else "")
+            self.ds = (Dataset_Aug1 if aug else Dataset)(folder, image_size)
+            sampler = None
+            if parallel.world_size() > 1:
+                sampler = data.distributed.DistributedSampler(self.ds, shuffle=shuffle)
+            self.dl = cycle(data.DataLoader(self.ds, batch_size=train_batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
+                                            pin_memory=True, num_workers=num_workers, drop_last=True))
+
+        # Adam(diffusion_model.parameters(), lr): one flat arena over every parameter of the model
+        self.arena = flat.FlatArena(list(self.core.parameters()))
+        self.ema_arena = flat.FlatArena(list(self.ema_core.parameters()))
+        self.opt = flat.FusedAdam(self.arena, lr=train_lr)
+        self.step = 0
+        self.results_folder = Path(results_folder)
+        self.results_folder.mkdir(exist_ok=True)
+        self.fp16 = fp16
+        self.quiet = False
+
+        parallel.init_distributed()
+        self.sync = None
+        if parallel.world_size() > 1:
+            self.sync = parallel.GradSync(self.arena)
+            parallel.set_engine(self.sync)
+            # every rank starts from rank 0's weights (the reference replicates GPU 0's module)
+            torch.distributed.broadcast(self.arena.data, src=0)
+        self.reset_parameters()
+        if load_path is not None:
+            self.load(load_path)
+
+    # -- EMA / checkpoint --------------------------------------------------------------------------------
+    def reset_parameters(self):
+        self.ema_model.load_state_dict(self.model.state_dict())
+        rt.bump_weights_epoch()
+
+    def step_ema(self):
+        if self.step < self.step_start_ema:
+            self.reset_parameters()
+            return
+        self.ema.update_model_average(self.ema_arena, self.arena)
+
+    def save(self, itrs=None):
+        if parallel.rank() != 0:
+            return
+        ckpt = {'step': self.step, 'model': self.model.state_dict(), 'ema': self.ema_model.state_dict()}
+        name = 'model.pt' if itrs is None else f'model_{itrs}.pt'
+        torch.save(ckpt, str(self.results_folder / name))
+
+    def load(self, load_path):
+        print("Loading : ", load_path)
+        ckpt = torch.load(load_path, map_location=self.device)
+        self.step = ckpt['step']
+        self.model.load_state_dict(ckpt['model'])
+        self.ema_model.load_state_dict(ckpt['ema'])
+        rt.bump_weights_epoch()
+
+    # -- the hot loop (DEBLUR:1183-1235) -----------------------------------------------------------------
+    def _next_batch(self):
+        d = next(self.dl)
+        if isinstance(d, (list, tuple)):
+            d = d[0]
+        return d.to(self.device, non_blocking=True)
+
+    def _loss(self, batch):
+        if self.pair_noise:
+            return self.core(batch, torch.randn_like(batch))
+        return self.core(batch)
+
+    def train_step(self):
+        """One optimizer step = gradient_accumulate_every micro-steps + Adam (+ EMA); returns the
+        mean micro-step loss as a 0-dim device tensor (no host sync)."""
+        acc = self.gradient_accumulate_every
+        scale = 1.0 / (acc * parallel.world_size())
+        total = None
+        for i in range(acc):
+            loss = torch.mean(self._loss(self._next_batch()))
+            if self.sync is not None and i == acc - 1:
+                self.sync.arm()
+            (loss * scale).backward()
+            total = loss.detach() if total is None else total + loss.detach()
+        if self.sync is not None:
+            self.sync.finish()
+        self.opt.step()
+        self.opt.zero_grad()
+        if self.step % self.update_ema_every == 0:
+            self.step_ema()
+        return total / acc
+
+    def train(self):
+        acc_loss = 0
+        while self.step < self.train_num_steps:
+            u_loss = self.train_step()
+            if self.step % 100 == 0 and parallel.rank() == 0 and not self.quiet:
+                print(f'{self.step}: {u_loss.item()}')
+            acc_loss = acc_loss + u_loss
+            if self.step != 0 and self.step % self.save_and_sample_every == 0:
+                self._milestone(acc_loss)
+                acc_loss = 0
+            self.step += 1
+        print('training completed')
+
+    def _milestone(self, acc_loss):
+        milestone = self.step // self.save_and_sample_every
+        if parallel.rank() == 0:                       # sampling and checkpointing stay on one GPU
+            og_img = self._next_batch()
+            if self.pair_noise:
+                og_img = torch.randn_like(og_img)
+            if hasattr(self.ema_core, 'defade_fn'):
+                xt, direct_recons, all_images = self.ema_core.sample(batch_size=self.batch_size, faded_recon_sample=og_img)
+            else:
+                xt, direct_recons, all_images = self.ema_core.sample(batch_size=self.batch_size, img=og_img)
+            for name, im in (('og', og_img), ('recon', all_images), ('direct_recons', direct_recons), ('xt', xt)):
+                save_image((im + 1) * 0.5, self.results_folder / f'sample-{name}-{milestone}.png', nrow=6)
+            mean = float(acc_loss) / (self.save_and_sample_every + 1)
+            print(f'Mean of last {self.step}: {mean}')
+            self.save()
+            if self.step % (self.save_and_sample_every * 100) == 0:
+                self.save(self.step)
+        if parallel.world_size() > 1:
+            torch.distributed.barrier()
