@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py — CelebA-128 cold-diffusion training throughput (+ 200-step sampling latency) on MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json config 3, the single-GPU CelebA-128 case):
+  Unet(dim=64, dim_mults=(1,2,4,8), channels=3) at 128x128, denoising GaussianDiffusion(T=200,
+  x0_step_down), synthetic 8-bit-quantised images, random-init weights.
+A *step* is one optimizer step exactly as Trainer.train() does it (DEBLUR:1188-1204): 2 accumulation
+micro-steps of 32 images (q_sample -> UNet fwd -> L1 -> bwd) + Adam (+ EMA every 10th step); with
+N > 1 each rank does the same work on its own shard and gradients are all-reduced over RCCL
+(weak scaling).  `value` = images/s over all ranks.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(REPO, "cold-diffusion-models_amd"), REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+def log(msg):
+    sys.stderr.write("[bench %7.1fs] %s\n" % (time.perf_counter() - _T0, msg))
+    sys.stderr.flush()
+
+
+_T0 = time.perf_counter()
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+UNET128_FWD_GFLOP = 67.41          # SURVEY.md §8(d), per image
+TIMESTEPS = 200
+
+
+def build_workload(args, device):
+    from denoising_diffusion_pytorch import GaussianDiffusion, Trainer, Unet
+    import contextlib
+    import io
+    torch.manual_seed(123457)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=3).to(device)
+    diffusion = GaussianDiffusion(model, image_size=128, channels=3, timesteps=TIMESTEPS, loss_type='l1',
+                                  sampling_routine='x0_step_down').to(device)
+    trainer = Trainer(diffusion, None, image_size=128, train_batch_size=args.batch, train_lr=2e-5, train_num_steps=10 ** 9,
+                      gradient_accumulate_every=args.accum, ema_decay=0.995, fp16=False, dataset='synthetic',
+                      results_folder=os.path.join(REPO, "gpurun_out", "bench_results"))
+    trainer.quiet = True
+    return model, diffusion, trainer
+
+
+class ConvTimer:
+    """HIP-event timing of every cdf_conv_gemm launch (the MFMA implicit-GEMM kernel: all dense conv
+    forward + data-gradient work) on the stream it is launched on, with its algorithmic FLOPs."""
+
+    def __init__(self, lib):
+        self.lib, self.orig = lib, lib.cdf_conv_gemm
+        self.records, self.taps = [], {}
+        self.enabled = False
+        lib.cdf_conv_gemm = self
+
+    def _ntaps(self, desc, nphase):
+        key = id(desc)
+        if key not in self.taps:
+            tot, i = 0, 0
+            for _ in range(nphase):
+                tot += desc[i + 2]
+                i += 3 + 3 * desc[i + 2]
+            self.taps[key] = (tot, desc)          # keep desc alive so id() stays unique
+        return self.taps[key][0]
+
+    def __call__(self, *a):
+        if not self.enabled:
+            return self.orig(*a)
+        B, Cin, Cout, QH, QW, nphase, desc, batch = a[6], a[9], a[12], a[13], a[14], a[17], a[18], a[32]
+        flops = 2.0 * B * QH * QW * self._ntaps(desc, nphase) * Cin * Cout * batch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = self.orig(*a)
+        e1.record()
+        self.records.append((e0, e1, flops))
+        return r
+
+    def summary(self):
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        return len(self.records), ms, fl
+
+
+def cpu_baseline(args):
+    """The CPU oracle (port of the reference's PyTorch path) on the host cores: the same optimizer
+    step on a bounded sample (2 micro-steps x 2 images)."""
+    from oracle import cold_oracle as O
+    from colddiff.unet import Unet
+    import contextlib
+    import io
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncores = max(1, min(ncores, 64))
+    torch.set_num_threads(ncores)
+    torch.manual_seed(123457)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sd = {k: v.clone() for k, v in Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=3).state_dict().items()}
+    ca, cb = O.cosine_tables(TIMESTEPS)
+    Bc = 2
+
+    def loss_of_batch(params, x, eps, t):
+        return O.loss_fn(x, O.unet_forward(params, O.noise_q_sample(x, eps, t, ca, cb), t))
+
+    tr = O.OracleTrainer(sd, loss_of_batch, lr=2e-5, accumulate=args.accum)
+    g = torch.Generator().manual_seed(123457)
+
+    def batches():
+        out = []
+        for _ in range(args.accum):
+            x = torch.randint(0, 256, (Bc, 3, 128, 128), generator=g).float() / 255 * 2 - 1
+            out.append((x, torch.randn(Bc, 3, 128, 128, generator=g), torch.randint(0, TIMESTEPS, (Bc,), generator=g)))
+        return out
+
+    t0 = time.perf_counter()
+    tr.train_step(batches())                     # warm-up
+    warm = time.perf_counter() - t0
+    log(f"cpu baseline warm-up step: {warm:.1f}s on {ncores} threads")
+    n = 2 if warm < 12 else 1                    # keep the whole leg within ~30 s
+    t0 = time.perf_counter()
+    for _ in range(n):
+        tr.train_step(batches())
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(Bc * args.accum / dt, 3), "unit": "img/s", "cores": ncores, "kind": "port",
+            "sample": f"oracle/cold_oracle.py (PyTorch CPU fp32) optimizer step, {args.accum} micro-steps x {Bc} images at 128x128, "
+                      f"{n} timed steps after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="images per micro-step per GPU (reference scripts: 32)")
+    ap.add_argument("--accum", type=int, default=2, help="gradient_accumulate_every (reference scripts: 2)")
+    ap.add_argument("--sample-batch", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sample", action="store_true")
+    args = ap.parse_args()
+
+    from colddiff import parallel, runtime
+    world = parallel.world_size()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    if world > 1:
+        parallel.init_distributed("nccl")
+    device = torch.device("cuda", parallel.local_rank())
+    torch.cuda.set_device(device)
+
+    log(f"building workload on {device} (world {world})")
+    model, diffusion, trainer = build_workload(args, device)
+    timer = ConvTimer(runtime.lib())
+    log("workload built")
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.train_step()
+        trainer.step += 1
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_step()
+        trainer.step += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    log(f"timed {args.steps} steps: {elapsed:.3f}s")
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = tt.item()
+
+    imgs_per_step = args.batch * args.accum * world
+    value = imgs_per_step * args.steps / elapsed
+    nlaunch, conv_ms, conv_fl = timer.summary()
+
+    out = {
+        "metric": "unet_train_imgs_per_sec", "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "CelebA-128 denoising cold diffusion (BASELINE config 3): Unet(dim=64,(1,2,4,8),ch=3) @128x128, T=200, "
+                               "optimizer step = 2 micro-steps x 32 img + Adam + EMA/10", "per_gpu_batch": args.batch,
+                   "gradient_accumulate_every": args.accum, "global_images_per_step": imgs_per_step,
+                   "parallelism": f"dp{world}" if world > 1 else "single"},
+    }
+    if parallel.rank() == 0:
+        achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (cdf_conv_gemm: dense conv fwd + dgrad)",
+                           "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": nlaunch // max(1, args.steps),
+                           "avg_launch_ms": round(conv_ms / max(1, nlaunch), 4),
+                           "algorithmic_gflop_per_step": round(conv_fl / max(1, args.steps) / 1e9, 1),
+                           "conv_igemm_share_of_step": round(conv_ms / (1000 * elapsed), 3)}
+        # whole-step view: 3 x F_fwd per image against the same MFMA peak
+        step_tflops = 3 * UNET128_FWD_GFLOP * args.batch * args.accum * args.steps / elapsed / 1e3
+        out["step_mfma_frac"] = round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)
+        if world == 1 and not args.no_sample:
+            with torch.no_grad():
+                noise = torch.randn(args.sample_batch, 3, 128, 128, device=device)
+                trainer.ema_core.gen_sample(batch_size=args.sample_batch, img=noise, t=2)      # warm-up
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                trainer.ema_core.gen_sample(batch_size=args.sample_batch, img=noise)
+                torch.cuda.synchronize()
+                out["sample_ms_per_img_200step"] = round(1000 * (time.perf_counter() - ts) / args.sample_batch, 2)
+                log(f"200-step gen_sample of {args.sample_batch} images: {time.perf_counter() - ts:.2f}s")
+                out["sample_batch"] = args.sample_batch
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

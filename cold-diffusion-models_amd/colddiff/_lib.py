@@ -9,6 +9,12 @@ import ctypes
 import os
 import re
 
+# torch must be imported BEFORE libcolddiff_hip.so is dlopen'ed: the wheel bundles its own HIP runtime
+# (torch/lib/libamdhip64.so, soname libamdhip64.so.7) and our library's NEEDED libamdhip64.so.7 then binds
+# to that already-loaded copy.  Loaded the other way round the process ends up with two HIP runtimes and
+# every launch from this library fails with "no ROCm-capable device is detected".
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG_ROOT = os.path.dirname(_HERE)
 _REPO = os.path.dirname(_PKG_ROOT)
