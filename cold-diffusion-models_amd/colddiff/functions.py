@@ -270,19 +270,19 @@ class LinAttnBlockFn(torch.autograd.Function):
         grad_on = ctx.needs_input_grad[0]   # anchor: True iff autograd is recording
         xn, mean, rstd = ops.layernorm_fwd(x, norm.g, norm.b, norm.eps, grad_on)
         qkv = conv_forward(xn, dim, att.to_qkv.weight, None)
-        o, cx, kmax, ksum = ops.linattn_fwd(qkv, att.heads, att.scale)
+        o, cx, cxs, kmax, ksum = ops.linattn_fwd(qkv, att.heads, att.scale)
         y = conv_forward(o, att.heads * 32, att.to_out.weight, att.to_out.bias, res=x)
         ctx.m = m
-        ctx.save_for_backward(x, xn, mean, rstd, qkv, o, cx, kmax, ksum)
+        ctx.save_for_backward(x, xn, mean, rstd, qkv, o, cx, cxs, kmax, ksum)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, xn, mean, rstd, qkv, o, cx, kmax, ksum = ctx.saved_tensors
+        x, xn, mean, rstd, qkv, o, cx, cxs, kmax, ksum = ctx.saved_tensors
         norm, att = ctx.m.fn.norm, ctx.m.fn.fn
         dim, HD = x.shape[-1], att.heads * 32
         do = conv_backward(o, HD, dy, att.to_out.weight, att.to_out.bias)
-        dqkv = ops.linattn_bwd(qkv, do, cx, kmax, ksum, att.heads, att.scale)
+        dqkv = ops.linattn_bwd(qkv, do, cx, cxs, kmax, ksum, att.heads, att.scale)
         dxn = conv_backward(xn, dim, dqkv, att.to_qkv.weight, None)
         dx = ops.copy_feat(dy)
         ops.layernorm_bwd(dxn, x, norm.g, norm.b, mean, rstd, dx=dx)

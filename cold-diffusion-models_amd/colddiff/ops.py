@@ -190,31 +190,52 @@ def dwconv7_wgrad(x, dy, w_param, b_param, want_dsb):
     return dsb
 
 
+def _head_gemm(x, x_off, w, out, out_off, B, n, heads, b_trans):
+    """out[b, :, out_off + h*32 + j] = sum_k x[b, :, x_off + h*32 + k] * (w[b,h,k,j] | w[b,h,j,k] if b_trans),
+    one batched K=32 GEMM per head (batch = B)."""
+    L, S = rt.lib(), rt.stream(x)
+    plan = _one_tap(n)
+    ldx, ldo = ld_of(x), ld_of(out)
+    for h in range(heads):
+        L.cdf_conv_gemm(P(x) + 4 * (x_off + h * 32), ldx, P(w) + 4 * h * 1024, 32, P(out) + 4 * (out_off + h * 32), ldo, 1, 1, n, 32,
+                        1, n, 32, 1, n, 1, 1, 1, plan.desc, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1 if b_trans else 0, B,
+                        n * ldx, heads * 1024, n * ldo, S)
+
+
 def linattn_fwd(qkv, heads, scale):
+    """LinearAttention core: returns (out [B,H,W,HD], ctx, ctxs, kmax, ksum)."""
     L = rt.lib()
     B, H, W, _ = qkv.shape
     n, HD = H * W, heads * 32
     dev = qkv.device
     out = torch.empty((B, H, W, HD), device=dev, dtype=torch.float32)
     ctx = torch.empty((B, heads, 32, 32), device=dev, dtype=torch.float32)
+    ctxs = torch.empty_like(ctx)
     kmax = torch.empty((B, HD), device=dev, dtype=torch.float32)
     ksum = torch.empty((B, HD), device=dev, dtype=torch.float32)
     ws = torch.empty((L.cdf_linattn_ws_floats(B, n, heads),), device=dev, dtype=torch.float32)
-    L.cdf_linattn_fwd(P(qkv), ld_of(qkv), P(out), HD, P(ctx), P(kmax), P(ksum), P(ws), B, n, heads, scale, rt.stream(qkv))
-    return out, ctx, kmax, ksum
+    L.cdf_linattn_context(P(qkv), ld_of(qkv), P(ctx), P(ctxs), P(kmax), P(ksum), P(ws), B, n, heads, scale, rt.stream(qkv))
+    _head_gemm(qkv, 0, ctxs, out, 0, B, n, heads, False)          # out = q . (scale*ctx)
+    return out, ctx, ctxs, kmax, ksum
 
 
-def linattn_bwd(qkv, dout, ctx, kmax, ksum, heads, scale):
+def linattn_bwd(qkv, dout, ctx, ctxs, kmax, ksum, heads, scale):
     L = rt.lib()
     B, H, W, _ = qkv.shape
     n, HD = H * W, heads * 32
-    dev = qkv.device
+    dev, S = qkv.device, rt.stream(qkv)
     dqkv = torch.empty((B, H, W, 3 * HD), device=dev, dtype=torch.float32)
     dctx = torch.empty_like(ctx)
     rvec = torch.empty((B, HD), device=dev, dtype=torch.float32)
     ws = torch.empty((L.cdf_linattn_ws_floats(B, n, heads),), device=dev, dtype=torch.float32)
-    L.cdf_linattn_bwd(P(qkv), ld_of(qkv), P(dout), ld_of(dout), P(ctx), P(kmax), P(ksum), P(dqkv), 3 * HD, P(dctx), P(rvec), P(ws),
-                      B, n, heads, scale, rt.stream(qkv))
+    L.cdf_linattn_dcontext(P(qkv), ld_of(qkv), P(dout), ld_of(dout), P(ctx), P(dctx), P(rvec), P(ws), B, n, heads, scale, S)
+    pn = torch.empty((B, H, W, HD), device=dev, dtype=torch.float32)
+    dp = torch.empty((B, H, W, HD), device=dev, dtype=torch.float32)
+    L.cdf_linattn_softk(P(qkv), ld_of(qkv), P(kmax), P(ksum), P(pn), HD, B, n, heads, S)
+    _head_gemm(dout, 0, ctxs, dqkv, 0, B, n, heads, True)          # dq[n,d] = sum_e dout[n,e] ctxs[d,e]
+    _head_gemm(qkv, 2 * HD, dctx, dp, 0, B, n, heads, True)        # dP[n,d] = sum_e v[n,e] dctx[d,e]
+    _head_gemm(pn, 0, dctx, dqkv, 2 * HD, B, n, heads, False)      # dv[n,e] = sum_d P[n,d] dctx[d,e]
+    L.cdf_linattn_dk(P(pn), HD, P(dp), HD, P(rvec), P(dqkv) + 4 * HD, 3 * HD, B, n, heads, S)
     return dqkv
 
 

@@ -88,7 +88,8 @@ __global__ void __launch_bounds__(256) linattn_ctx_kernel(const float* a_ptr, in
 // ---- finalize (forward): kmax, ksum, ctx = sum_split part / ksum ---------------------------------
 // grid = (heads, B), block 256
 __global__ void linattn_ctx_final_kernel(const float* ctx_part, const float* sum_part, const float* kmax_part,
-                                         int nsplit, int nchunk_max, int HD, float* ctx, float* kmax, float* ksum) {
+                                         int nsplit, int nchunk_max, int HD, float* ctx, float* ctxs, float scale,
+                                         float* kmax, float* ksum) {
     __shared__ float ssum[LA_D];
     const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
     if (threadIdx.x < LA_D) {
@@ -105,7 +106,9 @@ __global__ void linattn_ctx_final_kernel(const float* ctx_part, const float* sum
     for (int k = threadIdx.x; k < LA_D * LA_D; k += blockDim.x) {
         float s = 0.f;
         for (int sp = 0; sp < nsplit; ++sp) s += ctx_part[((((long long)b * nsplit + sp) * heads + h) * LA_D) * LA_D + k];
-        ctx[(((long long)b * heads + h) * LA_D) * LA_D + k] = s / ssum[k / LA_D];
+        const float c = s / ssum[k / LA_D];
+        ctx[(((long long)b * heads + h) * LA_D) * LA_D + k] = c;
+        ctxs[(((long long)b * heads + h) * LA_D) * LA_D + k] = c * scale;   // q *= scale folded into the context
     }
 }
 
@@ -130,122 +133,33 @@ __global__ void linattn_dctx_final_kernel(const float* part, int nsplit, const f
     }
 }
 
-// ---- out[n][h*32+e] = scale * sum_d q[n][h*32+d] * ctx[h][d][e] -----------------------------------
-// grid = (row blocks, B); block 256: thread = (row-in-block, head, e-quad); ctx[b] staged in LDS.
-__global__ void __launch_bounds__(256) linattn_out_kernel(const float* qkv, int ld, const float* ctx, float* out, int ldo,
-                                                          int n, int heads, float scale) {
-    CDF_DYN_SMEM(smem);
-    float* sctx = (float*)smem;  // [heads][32][32]
-    const int b = blockIdx.y;
-    for (int k = threadIdx.x; k < heads * LA_D * LA_D; k += blockDim.x) sctx[k] = ctx[(long long)b * heads * LA_D * LA_D + k];
-    __syncthreads();
-    const int quads = heads * 8;              // e-quads per row
-    const int rows_per_block = 256 / quads;   // heads=4 -> 8 rows
-    const int tq = threadIdx.x % quads, tr = threadIdx.x / quads;
-    const int h = tq / 8, e0 = (tq & 7) * 4;
-    for (int row = blockIdx.x * rows_per_block + tr; row < n; row += gridDim.x * rows_per_block) {
-        if (tr >= rows_per_block) break;
-        const float* qp = qkv + ((long long)b * n + row) * ld + h * LA_D;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int d4 = 0; d4 < 8; ++d4) {
-            const float4 qv = *(const float4*)(qp + d4 * 4);
-            const float qs[4] = {qv.x, qv.y, qv.z, qv.w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float4 cv = *(const float4*)(sctx + (h * LA_D + d4 * 4 + u) * LA_D + e0);
-                acc.x = fmaf(qs[u], cv.x, acc.x);
-                acc.y = fmaf(qs[u], cv.y, acc.y);
-                acc.z = fmaf(qs[u], cv.z, acc.z);
-                acc.w = fmaf(qs[u], cv.w, acc.w);
-            }
-        }
-        *(float4*)(out + ((long long)b * n + row) * ldo + h * LA_D + e0) = make_float4(acc.x * scale, acc.y * scale, acc.z * scale, acc.w * scale);
+// ---- P[n][c] = exp(k[n][c] - kmax[c]) / ksum[c]  (the softmax over n, materialised for backward) --------
+__global__ void linattn_softk_kernel(const float* qkv, int ld, const float* kmax, const float* ksum, float* pn, int ldp,
+                                     int B, int n, int HD) {
+    const int c4n = HD / 4;
+    const long long total = (long long)B * n * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const long long row = i / c4n;
+        const int b = (int)(row / n);
+        const float4 kv = *(const float4*)(qkv + row * ld + HD + c);
+        const float4 mx = *(const float4*)(kmax + (long long)b * HD + c), sm = *(const float4*)(ksum + (long long)b * HD + c);
+        *(float4*)(pn + row * ldp + c) = make_float4(expf(kv.x - mx.x) / sm.x, expf(kv.y - mx.y) / sm.y, expf(kv.z - mx.z) / sm.z,
+                                                     expf(kv.w - mx.w) / sm.w);
     }
 }
-
-// ---- backward per-row kernel: writes dqkv [B, n, 3*HD] ---------------------------------------------
-//   dq[d] = scale * sum_e ctx[d,e] dout[e] ; P[d] = exp(k[d]-kmax[d])/ksum[d]
-//   dv[e] = sum_d P[d] dctx[d,e] ; dP[d] = sum_e dctx[d,e] v[e] ; dk[d] = P[d] (dP[d] - r[d])
-__global__ void __launch_bounds__(256) linattn_bwd_rows_kernel(const float* qkv, int ld, const float* dout, int lddo,
-                                                               const float* ctx, const float* dctx, const float* kmax,
-                                                               const float* ksum, const float* rvec, float* dqkv,
-                                                               int lddq, int n, int heads, float scale) {
-    CDF_DYN_SMEM(smem);
-    const int HD = heads * LA_D;
-    float* sctx = (float*)smem;              // [heads][32][32]
-    float* sdctx = sctx + heads * LA_D * LA_D;
-    float* smx = sdctx + heads * LA_D * LA_D;  // [HD]
-    float* ssm = smx + HD;
-    float* srv = ssm + HD;
-    const int b = blockIdx.y;
-    for (int k = threadIdx.x; k < heads * LA_D * LA_D; k += blockDim.x) {
-        sctx[k] = ctx[(long long)b * heads * LA_D * LA_D + k];
-        sdctx[k] = dctx[(long long)b * heads * LA_D * LA_D + k];
-    }
-    for (int k = threadIdx.x; k < HD; k += blockDim.x) {
-        smx[k] = kmax[(long long)b * HD + k];
-        ssm[k] = ksum[(long long)b * HD + k];
-        srv[k] = rvec[(long long)b * HD + k];
-    }
-    __syncthreads();
-    const int quads = heads * 8, rows_per_block = 256 / quads;
-    const int tq = threadIdx.x % quads, tr = threadIdx.x / quads;
-    const int h = tq / 8, j0 = (tq & 7) * 4;
-    for (int row = blockIdx.x * rows_per_block + tr; row < n; row += gridDim.x * rows_per_block) {
-        if (tr >= rows_per_block) break;
-        const long long rbase = (long long)b * n + row;
-        const float* kp = qkv + rbase * ld + HD + h * LA_D;
-        const float* vp = qkv + rbase * ld + 2 * HD + h * LA_D;
-        const float* dop = dout + rbase * lddo + h * LA_D;
-        float dov[LA_D], vv[LA_D], pn[LA_D];
-#pragma unroll
-        for (int q4 = 0; q4 < 8; ++q4) {
-            const float4 a = *(const float4*)(dop + q4 * 4), c = *(const float4*)(vp + q4 * 4), kk = *(const float4*)(kp + q4 * 4);
-            dov[q4 * 4] = a.x; dov[q4 * 4 + 1] = a.y; dov[q4 * 4 + 2] = a.z; dov[q4 * 4 + 3] = a.w;
-            vv[q4 * 4] = c.x; vv[q4 * 4 + 1] = c.y; vv[q4 * 4 + 2] = c.z; vv[q4 * 4 + 3] = c.w;
-            const float kr[4] = {kk.x, kk.y, kk.z, kk.w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int d = q4 * 4 + u;
-                pn[d] = expf(kr[u] - smx[h * LA_D + d]) / ssm[h * LA_D + d];
-            }
-        }
-        // dq[j0..j0+3], dP[j0..j0+3]: dot products over e with rows d = j0+u of ctx / dctx
-        float dq[4], dp[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float* cr = sctx + (h * LA_D + j0 + u) * LA_D;
-            const float* dr = sdctx + (h * LA_D + j0 + u) * LA_D;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int e4 = 0; e4 < 8; ++e4) {
-                const float4 c4 = *(const float4*)(cr + e4 * 4), d4 = *(const float4*)(dr + e4 * 4);
-                s1 = fmaf(c4.x, dov[e4 * 4], s1); s1 = fmaf(c4.y, dov[e4 * 4 + 1], s1);
-                s1 = fmaf(c4.z, dov[e4 * 4 + 2], s1); s1 = fmaf(c4.w, dov[e4 * 4 + 3], s1);
-                s2 = fmaf(d4.x, vv[e4 * 4], s2); s2 = fmaf(d4.y, vv[e4 * 4 + 1], s2);
-                s2 = fmaf(d4.z, vv[e4 * 4 + 2], s2); s2 = fmaf(d4.w, vv[e4 * 4 + 3], s2);
-            }
-            dq[u] = s1 * scale;
-            dp[u] = s2;
-        }
-        // dv[e = j0..j0+3] = sum_d P[d] dctx[d][e]
-        float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int d = 0; d < LA_D; ++d) {
-            const float4 d4 = *(const float4*)(sdctx + (h * LA_D + d) * LA_D + j0);
-            dv.x = fmaf(pn[d], d4.x, dv.x);
-            dv.y = fmaf(pn[d], d4.y, dv.y);
-            dv.z = fmaf(pn[d], d4.z, dv.z);
-            dv.w = fmaf(pn[d], d4.w, dv.w);
-        }
-        float* o = dqkv + rbase * lddq + h * LA_D + j0;
-        *(float4*)o = make_float4(dq[0], dq[1], dq[2], dq[3]);
-        float dk[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) dk[u] = pn[j0 + u] * (dp[u] - srv[h * LA_D + j0 + u]);
-        *(float4*)(o + HD) = make_float4(dk[0], dk[1], dk[2], dk[3]);
-        *(float4*)(o + 2 * HD) = dv;
+// ---- dk[n][c] = P[n][c] * (dP[n][c] - r[b][c]) ---------------------------------------------------------
+__global__ void linattn_dk_kernel(const float* pn, int ldp, const float* dp, int lddp, const float* rvec, float* dk, int lddk,
+                                  int B, int n, int HD) {
+    const int c4n = HD / 4;
+    const long long total = (long long)B * n * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const long long row = i / c4n;
+        const int b = (int)(row / n);
+        const float4 p = *(const float4*)(pn + row * ldp + c), d = *(const float4*)(dp + row * lddp + c);
+        const float4 r = *(const float4*)(rvec + (long long)b * HD + c);
+        *(float4*)(dk + row * lddk + c) = make_float4(p.x * (d.x - r.x), p.y * (d.y - r.y), p.z * (d.z - r.z), p.w * (d.w - r.w));
     }
 }
 
@@ -297,44 +211,56 @@ extern "C" size_t cdf_linattn_ws_floats(int B, int n, int heads) {
     return (size_t)B * ns * (2 * HD + (size_t)heads * LA_D * LA_D);
 }
 
-// qkv [B,n,ld] ; out [B,n,ldo] (HD channels) ; ctx [B,heads,32,32] ; kmax, ksum [B,HD]
-extern "C" int cdf_linattn_fwd(const float* qkv, int ld, float* out, int ldo, float* ctx, float* kmax, float* ksum,
-                               float* ws, int B, int n, int heads, float scale, void* stream) {
-    CDF_REQUIRE(qkv && out && ctx && kmax && ksum && ws, "cdf_linattn_fwd: null pointer");
+// Context pass: ctx[b,h,d,e] = sum_n softmax_n(k)[d,n] v[e,n]; ctxs = scale*ctx; kmax/ksum [B,HD] saved.
+// The output  out[n, h*32+e] = sum_d q[n, h*32+d] ctxs[h,d,e]  is a K=32 GEMM per (b, head): cdf_conv_gemm.
+extern "C" int cdf_linattn_context(const float* qkv, int ld, float* ctx, float* ctxs, float* kmax, float* ksum, float* ws,
+                                   int B, int n, int heads, float scale, void* stream) {
+    CDF_REQUIRE(qkv && ctx && ctxs && kmax && ksum && ws, "cdf_linattn_context: null pointer");
     const int HD = heads * LA_D;
-    CDF_REQUIRE(HD % 64 == 0 && ld % 4 == 0 && ldo % 4 == 0 && ld >= 3 * HD && ldo >= HD && heads * 8 <= 256, "cdf_linattn_fwd: heads=%d unsupported / bad pitch", heads);
+    CDF_REQUIRE(HD % 64 == 0 && ld % 4 == 0 && ld >= 3 * HD, "cdf_linattn_context: heads=%d unsupported / bad pitch", heads);
     const int ns = cdf_linattn_nsplit(n), rps = cdf_cdiv(cdf_cdiv(n, ns), 2) * 2;
     float* kmax_part = ws;
     float* ctx_part = kmax_part + (size_t)B * ns * HD;
     float* sum_part = ctx_part + (size_t)B * ns * heads * LA_D * LA_D;
     CDF_LAUNCH(linattn_kmax_kernel, dim3(HD / 64, ns, B), dim3(256), 0, CDF_S, qkv, ld, kmax_part, n, rps, HD);
     CDF_LAUNCH((linattn_ctx_kernel<true>), dim3(heads, ns, B), dim3(256), 0, CDF_S, qkv + HD, ld, qkv + 2 * HD, ld, (const float*)kmax_part, ns, ctx_part, sum_part, n, rps, HD);
-    CDF_LAUNCH(linattn_ctx_final_kernel, dim3(heads, B), dim3(256), 0, CDF_S, (const float*)ctx_part, (const float*)sum_part, (const float*)kmax_part, ns, ns, HD, ctx, kmax, ksum);
-    const size_t lds = (size_t)heads * LA_D * LA_D * sizeof(float);
-    const int rows_per_block = 256 / (heads * 8);
-    int gx = cdf_cdiv(n, rows_per_block);
-    if (gx > 1024) gx = 1024;
-    CDF_LAUNCH(linattn_out_kernel, dim3(gx, B), dim3(256), lds, CDF_S, qkv, ld, (const float*)ctx, out, ldo, n, heads, scale);
-    return cdf_check_launch("linattn_fwd");
+    CDF_LAUNCH(linattn_ctx_final_kernel, dim3(heads, B), dim3(256), 0, CDF_S, (const float*)ctx_part, (const float*)sum_part, (const float*)kmax_part, ns, ns, HD, ctx, ctxs, scale, kmax, ksum);
+    return cdf_check_launch("linattn_context");
 }
 
-// dctx, rvec are scratch outputs ([B,heads,32,32], [B,HD]); dqkv [B,n,lddq] receives (dq | dk | dv)
-extern "C" int cdf_linattn_bwd(const float* qkv, int ld, const float* dout, int lddo, const float* ctx,
-                               const float* kmax, const float* ksum, float* dqkv, int lddq, float* dctx, float* rvec,
-                               float* ws, int B, int n, int heads, float scale, void* stream) {
-    CDF_REQUIRE(qkv && dout && ctx && kmax && ksum && dqkv && dctx && rvec && ws, "cdf_linattn_bwd: null pointer");
+// Backward context pass: dctx[b,h,d,e] = scale * sum_n q[n,d] dout[n,e];  rvec[b, h*32+d] = sum_e dctx*ctx.
+extern "C" int cdf_linattn_dcontext(const float* qkv, int ld, const float* dout, int lddo, const float* ctx, float* dctx,
+                                    float* rvec, float* ws, int B, int n, int heads, float scale, void* stream) {
+    CDF_REQUIRE(qkv && dout && ctx && dctx && rvec && ws, "cdf_linattn_dcontext: null pointer");
     const int HD = heads * LA_D;
-    CDF_REQUIRE(HD % 64 == 0 && ld % 4 == 0 && lddo % 4 == 0 && lddq % 4 == 0 && lddq >= 3 * HD, "cdf_linattn_bwd: bad pitch");
+    CDF_REQUIRE(HD % 64 == 0 && ld % 4 == 0 && lddo % 4 == 0, "cdf_linattn_dcontext: bad pitch");
     const int ns = cdf_linattn_nsplit(n), rps = cdf_cdiv(cdf_cdiv(n, ns), 2) * 2;
     float* ctx_part = ws + (size_t)B * ns * HD;
     CDF_LAUNCH((linattn_ctx_kernel<false>), dim3(heads, ns, B), dim3(256), 0, CDF_S, qkv, ld, dout, lddo, (const float*)nullptr, 0, ctx_part, (float*)nullptr, n, rps, HD);
     CDF_LAUNCH(linattn_dctx_final_kernel, dim3(heads, B), dim3(256), 0, CDF_S, (const float*)ctx_part, ns, ctx, scale, dctx, rvec, HD);
-    const size_t lds = ((size_t)2 * heads * LA_D * LA_D + 3 * HD) * sizeof(float);
-    const int rows_per_block = 256 / (heads * 8);
-    int gx = cdf_cdiv(n, rows_per_block);
-    if (gx > 1024) gx = 1024;
-    CDF_LAUNCH(linattn_bwd_rows_kernel, dim3(gx, B), dim3(256), lds, CDF_S, qkv, ld, dout, lddo, ctx, (const float*)dctx, kmax, ksum, (const float*)rvec, dqkv, lddq, n, heads, scale);
-    return cdf_check_launch("linattn_bwd");
+    return cdf_check_launch("linattn_dcontext");
+}
+
+static inline int la_grid(long long n) {
+    long long g = (n + 255) / 256;
+    if (g > 8192) g = 8192;
+    return g < 1 ? 1 : (int)g;
+}
+
+extern "C" int cdf_linattn_softk(const float* qkv, int ld, const float* kmax, const float* ksum, float* pn, int ldp, int B,
+                                 int n, int heads, void* stream) {
+    CDF_REQUIRE(qkv && kmax && ksum && pn && ld % 4 == 0 && ldp % 4 == 0, "cdf_linattn_softk: bad args");
+    const int HD = heads * LA_D;
+    CDF_LAUNCH(linattn_softk_kernel, dim3(la_grid((long long)B * n * HD / 4)), dim3(256), 0, CDF_S, qkv, ld, kmax, ksum, pn, ldp, B, n, HD);
+    return cdf_check_launch("linattn_softk");
+}
+
+extern "C" int cdf_linattn_dk(const float* pn, int ldp, const float* dp, int lddp, const float* rvec, float* dk, int lddk,
+                              int B, int n, int heads, void* stream) {
+    CDF_REQUIRE(pn && dp && rvec && dk && ldp % 4 == 0 && lddp % 4 == 0 && lddk % 4 == 0, "cdf_linattn_dk: bad args");
+    const int HD = heads * LA_D;
+    CDF_LAUNCH(linattn_dk_kernel, dim3(la_grid((long long)B * n * HD / 4)), dim3(256), 0, CDF_S, pn, ldp, dp, lddp, rvec, dk, lddk, B, n, HD);
+    return cdf_check_launch("linattn_dk");
 }
 
 extern "C" int cdf_softmax_rows_fwd(const float* s, float* p, long long rows, int n, int ld, float scale, void* stream) {

@@ -432,13 +432,20 @@ __global__ void colsum_partial_kernel(const float* x, float* part, int rows_per_
     }
 }
 __global__ void colsum_final_kernel(const float* part, float* out, int nchunk, int C, int ldo, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float* p = part + (long long)blockIdx.y * nchunk * C + c;
+    __shared__ float red[4][64];
+    const int l = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + l;
     float s = 0.f;
-    for (int k = 0; k < nchunk; ++k) s += p[(long long)k * C];
-    float* dst = out + (long long)blockIdx.y * ldo + c;
-    *dst = accumulate ? *dst + s : s;
+    if (c < C) {
+        const float* p = part + (long long)blockIdx.y * nchunk * C + c;
+        for (int k = rl; k < nchunk; k += 4) s += p[(long long)k * C];
+    }
+    red[rl][l] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const float t = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        float* dst = out + (long long)blockIdx.y * ldo + c;
+        *dst = accumulate ? *dst + t : t;
+    }
 }
 
 // ================================================================================================
@@ -576,9 +583,9 @@ extern "C" int cdf_unpack_reduce(const float* ws, float* g, int nsplit, int T, i
 }
 
 extern "C" int cdf_colsum_nchunk(int rows_per_seg) {
-    int n = rows_per_seg / 512;
+    int n = rows_per_seg / 1024;
     if (n < 1) n = 1;
-    if (n > 1024) n = 1024;
+    if (n > 256) n = 256;
     return n;
 }
 
@@ -589,6 +596,6 @@ extern "C" int cdf_colsum(const float* x, float* out, float* ws, int nseg, int r
     const int nchunk = cdf_colsum_nchunk(rows_per_seg);
     const int rpc = cdf_cdiv(rows_per_seg, nchunk);
     CDF_LAUNCH(colsum_partial_kernel, dim3(cdf_cdiv(C, 64), nseg, nchunk), dim3(256), 0, CDF_S, x, ws, rows_per_seg, rpc, C, ld);
-    CDF_LAUNCH(colsum_final_kernel, dim3(cdf_cdiv(C, 256), nseg), dim3(256), 0, CDF_S, (const float*)ws, out, nchunk, C, ldo, accumulate);
+    CDF_LAUNCH(colsum_final_kernel, dim3(cdf_cdiv(C, 64), nseg), dim3(256), 0, CDF_S, (const float*)ws, out, nchunk, C, ldo, accumulate);
     return cdf_check_launch("colsum");
 }

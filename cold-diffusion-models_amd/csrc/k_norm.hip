@@ -151,14 +151,20 @@ __global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const float* dy, i
     }
 }
 
-// out[c] (+)= sum_blocks part[block][which][c]
+// out[c] (+)= sum_blocks part[block][which][c]; block 256 = 4 partial lanes x 64 columns of the [2C] vector
 __global__ void norm_param_reduce_kernel(const float* part, int nblocks, int C, float* dg, float* db, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * C) return;
+    __shared__ float red[4][64];
+    const int l = threadIdx.x & 63, rl = threadIdx.x >> 6, i = blockIdx.x * 64 + l;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * 2 * C + i];
-    float* dst = i < C ? dg + i : db + (i - C);
-    *dst = accumulate ? *dst + s : s;
+    if (i < 2 * C)
+        for (int b = rl; b < nblocks; b += 4) s += part[(size_t)b * 2 * C + i];
+    red[rl][l] = s;
+    __syncthreads();
+    if (rl == 0 && i < 2 * C) {
+        const float t = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        float* dst = i < C ? dg + i : db + (i - C);
+        *dst = accumulate ? *dst + t : t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -338,7 +344,7 @@ extern "C" int cdf_layernorm_blocks(long long M, int C) {
     if (ln_geometry(C, &LP, &NV)) return 0;
     const long long groups_per_block = 4 * (64 / LP);
     long long nb = (M + groups_per_block - 1) / groups_per_block;
-    if (nb > 2048) nb = 2048;
+    if (nb > 512) nb = 512;
     return nb < 1 ? 1 : (int)nb;
 }
 
@@ -390,7 +396,7 @@ extern "C" int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, in
         default: CDF_LN_BWD(4); break;
     }
 #undef CDF_LN_BWD
-    CDF_LAUNCH(norm_param_reduce_kernel, dim3(cdf_cdiv(2 * C, 256)), dim3(256), 0, CDF_S, (const float*)part, nb, C, dg, db, accumulate_param);
+    CDF_LAUNCH(norm_param_reduce_kernel, dim3(cdf_cdiv(2 * C, 64)), dim3(256), 0, CDF_S, (const float*)part, nb, C, dg, db, accumulate_param);
     return cdf_check_launch("layernorm_c_bwd");
 }
 

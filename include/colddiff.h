@@ -158,15 +158,24 @@ int cdf_dwconv7_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
 
 /* ---- attention -------------------------------------------------------------------------------------
  * LinearAttention core (deblurring_diffusion_pytorch.py:176-187) on qkv [B,n,ld] = (q|k|v), each
- * heads*32 channels: out [B,n,ldo]; ctx [B,heads,32,32], kmax/ksum [B,heads*32] saved for backward.
- * ws >= cdf_linattn_ws_floats(B,n,heads) floats.  bwd writes dqkv = (dq|dk|dv). */
+ * heads*32 channels, n = H*W tokens.  The softmax over n and the context are column reductions:
+ *   cdf_linattn_context : kmax/ksum [B,HD], ctx[b,h,d,e] = sum_n softmax_n(k)[d,n] v[e,n], ctxs = scale*ctx
+ *   out[n, h*32+e] = sum_d q[n, h*32+d] ctxs[h,d,e]   -> a K=32 GEMM per (b, head): cdf_conv_gemm
+ * backward:
+ *   cdf_linattn_dcontext: dctx = scale * sum_n q[n,d] dout[n,e] ; rvec[d] = sum_e dctx*ctx
+ *   dq = dout . ctxs^T, dP = v . dctx^T, dv = P . dctx  (cdf_conv_gemm) with P from cdf_linattn_softk,
+ *   dk = P * (dP - rvec)                                  (cdf_linattn_dk)
+ * ws >= cdf_linattn_ws_floats(B,n,heads) floats. */
 int cdf_linattn_nsplit(int n);
 size_t cdf_linattn_ws_floats(int B, int n, int heads);
-int cdf_linattn_fwd(const float* qkv, int ld, float* out, int ldo, float* ctx, float* kmax, float* ksum, float* ws,
-                    int B, int n, int heads, float scale, void* stream);
-int cdf_linattn_bwd(const float* qkv, int ld, const float* dout, int lddo, const float* ctx, const float* kmax,
-                    const float* ksum, float* dqkv, int lddq, float* dctx, float* rvec, float* ws, int B, int n,
-                    int heads, float scale, void* stream);
+int cdf_linattn_context(const float* qkv, int ld, float* ctx, float* ctxs, float* kmax, float* ksum, float* ws, int B,
+                        int n, int heads, float scale, void* stream);
+int cdf_linattn_dcontext(const float* qkv, int ld, const float* dout, int lddo, const float* ctx, float* dctx,
+                         float* rvec, float* ws, int B, int n, int heads, float scale, void* stream);
+int cdf_linattn_softk(const float* qkv, int ld, const float* kmax, const float* ksum, float* pn, int ldp, int B, int n,
+                      int heads, void* stream);
+int cdf_linattn_dk(const float* pn, int ldp, const float* dp, int lddp, const float* rvec, float* dk, int lddk, int B,
+                   int n, int heads, void* stream);
 /* AttnBlock (Model2.py:164-188) row softmax of the score matrix: p = softmax(scale*s) per row;
  * ds = scale * p * (dp - sum(dp*p)) */
 int cdf_softmax_rows_fwd(const float* s, float* p, long long rows, int n, int ld, float scale, void* stream);

@@ -1,0 +1,40 @@
+"""Summarise a rocprofv3 rocpd sqlite database (kernel trace) into a per-kernel table:
+   python tools/prof_summary.py gpurun_out/prof/x_results.db [out.md]"""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name)
+    name = re.sub(r"^void ", "", name)
+    return name[:90]
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = db.execute(f"select {name_col}, start, end from kernels").fetchall()
+    agg = {}
+    for n, s, e in rows:
+        k = short(n)
+        a = agg.setdefault(k, [0, 0.0, 1e30, 0.0])
+        d = (e - s) / 1e3
+        a[0] += 1
+        a[1] += d
+        a[2] = min(a[2], d)
+        a[3] = max(a[3], d)
+    total = sum(a[1] for a in agg.values())
+    lines = ["| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        lines.append(f"| {k} | {a[0]} | {a[1] / 1e3:.3f} | {a[1] / a[0]:.1f} | {a[2]:.1f} | {a[3]:.1f} | {100 * a[1] / total:.1f} |")
+    lines.append(f"\ntotal GPU kernel time: {total / 1e3:.3f} ms over {len(rows)} dispatches")
+    txt = "\n".join(lines)
+    print(txt)
+    if len(sys.argv) > 2:
+        open(sys.argv[2], "w").write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main()
