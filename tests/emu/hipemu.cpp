@@ -6,10 +6,33 @@ namespace hipemu {
 State g;
 dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 
+asm(R"(
+.text
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hipemu_switch,.-hipemu_switch
+)");
+
 void trampoline() {
     g.body();
     g.fibers[g.cur].done = true;
-    // returning switches to uc_link (= scheduler)
+    for (;;) hipemu_switch(&g.fibers[g.cur].sp, g.sched_sp);   // never returns
 }
 
 static void run_block(dim3 block) {
@@ -23,11 +46,14 @@ static void run_block(dim3 block) {
         if (!f.stack) f.stack = (char*)malloc(kStack);
         f.done = false;
         f.tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack;
-        f.ctx.uc_stack.ss_size = kStack;
-        f.ctx.uc_link = &g.sched;
-        makecontext(&f.ctx, (void (*)())trampoline, 0);
+        // initial frame: six callee-saved registers, then the entry address that `ret` jumps to
+        uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+        void** sp = (void**)(top - 16);
+        sp[0] = (void*)trampoline;
+        sp[1] = nullptr;
+        sp -= 6;
+        for (int r = 0; r < 6; ++r) sp[r] = nullptr;
+        f.sp = (void*)sp;
     }
     int remaining = n;
     long idle_passes = 0;
@@ -39,7 +65,7 @@ static void run_block(dim3 block) {
             if (f.done) continue;
             g.cur = i;
             g_threadIdx = f.tid;
-            swapcontext(&g.sched, &f.ctx);
+            hipemu_switch(&g.sched_sp, f.sp);
             if (f.done) { --remaining; ++finished; }
         }
         if (g.progress == before && finished == 0) {

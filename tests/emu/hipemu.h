@@ -12,7 +12,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <ucontext.h>
 #include <functional>
 #include <vector>
 
@@ -50,8 +49,11 @@ typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 
 namespace hipemu {
 
+// x86-64 stack switch (callee-saved registers only; no signal-mask syscalls like swapcontext)
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+
 struct Fiber {
-    ucontext_t ctx;
+    void* sp = nullptr;
     char* stack = nullptr;
     bool done = false;
     dim3 tid;
@@ -59,7 +61,7 @@ struct Fiber {
 
 struct State {
     std::vector<Fiber> fibers;
-    ucontext_t sched;
+    void* sched_sp = nullptr;
     int cur = 0;
     int nthreads = 0;
     std::function<void()> body;
@@ -81,7 +83,7 @@ extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 
 static const size_t kStack = 256 * 1024;
 
-inline void yield() { swapcontext(&g.fibers[g.cur].ctx, &g.sched); }
+inline void yield() { hipemu_switch(&g.fibers[g.cur].sp, g.sched_sp); }
 
 inline int lin_tid() {
     return (int)(g_threadIdx.x + g_blockDim.x * (g_threadIdx.y + g_blockDim.y * g_threadIdx.z));

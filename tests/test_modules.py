@@ -1,0 +1,212 @@
+"""Product parity: the drop-in packages (Unet / Model / GaussianDiffusion / Trainer on the HIP kernels)
+against the reference-generated golden vectors and the CPU oracle.
+
+Backends (fixture `mbe`):  emu = kernels on the host SIMT simulator, CPU tensors (not gpu)
+                           hip = libcolddiff_hip.so on cuda:0 (@pytest.mark.gpu)
+Tolerances are fp32: 1e-4 max-abs on outputs (north_star), relative 1e-3 on gradients whose true
+value is not ~0; q_sample / mask / area-pixelate / schedules are compared exactly where the
+reference arithmetic is reproduced op for op.
+"""
+import contextlib
+import io
+import os
+
+import pytest
+import torch
+
+from oracle import cold_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return torch.load(os.path.join(GOLD, name), weights_only=False)
+
+
+class MBE:
+    def __init__(self, kind):
+        self.kind = kind
+        self.device = torch.device("cuda:0" if kind == "hip" else "cpu")
+
+    def to(self, t):
+        return t.to(self.device)
+
+
+@pytest.fixture(params=[pytest.param("emu"), pytest.param("hip", marks=pytest.mark.gpu)])
+def mbe(request):
+    from colddiff import runtime
+    if request.param == "emu":
+        from emu_util import install_emu
+        install_emu()
+    else:
+        runtime._lib_override = None
+    yield MBE(request.param)
+    runtime._lib_override = None
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def grad_check(named_params, ref_grads, tol=1e-3):
+    gmax = max(v.abs().max().item() for v in ref_grads.values())
+    for name, p in named_params:
+        r = ref_grads[name]
+        e = (p.grad.detach().cpu() - r).abs().max().item()
+        assert e <= tol * max(r.abs().max().item(), 1e-3 * gmax), (name, e, r.abs().max().item())
+
+
+def test_unet_golden(mbe):
+    from deblurring_diffusion_pytorch import Unet
+    g = load("unet_dim8.pt")
+    net = quiet(Unet, **g["cfg"])
+    assert list(net.state_dict().keys()) == list(g["sd"].keys())
+    net.load_state_dict(g["sd"])
+    net = net.to(mbe.device)
+    y = net(mbe.to(g["x"]), mbe.to(g["t"]))
+    assert (y.cpu() - g["y"]).abs().max() <= 1e-4
+    y.backward(mbe.to(g["gy"]))
+    grad_check(net.named_parameters(), g["grads"])
+
+
+def test_model_golden(mbe):
+    from deblurring_diffusion_pytorch import Model
+    g = load("model_ch32.pt")
+    net = Model(**g["cfg"])
+    assert list(net.state_dict().keys()) == list(g["sd"].keys())
+    net.load_state_dict(g["sd"])
+    net = net.to(mbe.device)
+    y = net(mbe.to(g["x"]), mbe.to(g["t"]))
+    assert (y.cpu() - g["y"]).abs().max() <= 1e-4
+    y.backward(mbe.to(g["gy"]))
+    grad_check(net.named_parameters(), g["grads"], tol=2e-3)
+
+
+def _net(mbe, sd):
+    from deblurring_diffusion_pytorch import Unet
+    net = quiet(Unet, dim=8, dim_mults=(1, 2), channels=3)
+    net.load_state_dict(sd)
+    return net.to(mbe.device)
+
+
+def test_deblurring_golden(mbe):
+    from deblurring_diffusion_pytorch import GaussianDiffusion
+    g = load("diffusion.pt")
+    net = _net(mbe, g["deblur/net_sd"])
+    for key, c in g.items():
+        if not key.startswith("deblur/") or key == "deblur/net_sd":
+            continue
+        _, routine, sampling = key.split("/")
+        d = GaussianDiffusion(net, image_size=16, device_of_kernel="cuda", channels=3, timesteps=c["T"], kernel_std=c["std"],
+                              kernel_size=c["ks"], blur_routine=routine, sampling_routine=sampling).to(mbe.device)
+        for m, w in zip(d.gaussian_kernels, c["kernels"]):          # same generator as the reference's (torchgeometry) kernels
+            assert torch.equal(m.weight.detach().cpu(), w)
+        with torch.no_grad():
+            q = d.q_sample(mbe.to(c["x"]), mbe.to(c["t"]))
+            assert (q.cpu() - c["q"]).abs().max() <= 2e-6, key
+            xt, direct, img = d.sample(batch_size=3, img=mbe.to(c["x"]))
+        assert (xt.cpu() - c["xt"]).abs().max() <= 2e-6 and (img.cpu() - c["img"]).abs().max() <= 1e-4, key
+
+
+def test_denoising_golden(mbe):
+    from denoising_diffusion_pytorch import GaussianDiffusion
+    g = load("diffusion.pt")
+    net = _net(mbe, g["deblur/net_sd"])
+    for sampling in ("x0_step_down", "ddim"):
+        c = g[f"denoise/{sampling}"]
+        d = GaussianDiffusion(net, image_size=16, channels=3, timesteps=c["T"], sampling_routine=sampling).to(mbe.device)
+        assert torch.equal(d.sqrt_alphas_cumprod.cpu(), c["ca"]) and torch.equal(d.sqrt_one_minus_alphas_cumprod.cpu(), c["cb"])
+        with torch.no_grad():
+            assert torch.equal(d.q_sample(mbe.to(c["x"]), mbe.to(c["eps"]), mbe.to(c["t"])).cpu(), c["q"])
+            assert (d.gen_sample(batch_size=3, img=mbe.to(c["eps"]))[2].cpu() - c["gen"]).abs().max() <= 1e-4
+            assert (d.sample(batch_size=3, img=mbe.to(c["eps"]))[2].cpu() - c["sample"]).abs().max() <= 1e-4
+
+
+def test_resolution_golden(mbe):
+    from resolution_diffusion_pytorch import GaussianDiffusion
+    g = load("diffusion.pt")
+    net = _net(mbe, g["deblur/net_sd"])
+    for key, c in g.items():
+        if not key.startswith("resolution/"):
+            continue
+        routine = key.split("/")[1]
+        d = GaussianDiffusion(net, image_size=16, device_of_kernel="cuda", channels=3, timesteps=c["T"], resolution_routine=routine,
+                              sampling_routine="x0_step_down")
+        with torch.no_grad():
+            q = d.q_sample(mbe.to(c["x"]), mbe.to(c["t"]))
+            exact = "_area" in routine                      # avg-pool down + nearest-exact up: bit-exact indexing and sums
+            assert (q.cpu() - c["q"]).abs().max() <= (0.0 if exact else 1e-5), key
+            xt, _, img = d.sample(batch_size=3, img=mbe.to(c["x"]))
+        assert (xt.cpu() - c["xt"]).abs().max() <= (0.0 if exact else 1e-5) and (img.cpu() - c["img"]).abs().max() <= 1e-4, key
+
+
+def test_defading_golden(mbe):
+    from defading_diffusion_pytorch import GaussianDiffusion
+    g = load("diffusion.pt")
+    net = _net(mbe, g["deblur/net_sd"])
+    for sampling in ("default", "x0_step_down"):
+        c = g[f"defade/{sampling}"]
+        d = GaussianDiffusion(net, image_size=16, device_of_kernel="cuda", channels=3, timesteps=c["T"], kernel_std=0.6, initial_mask=1,
+                              fade_routine="Incremental", sampling_routine=sampling)
+        assert torch.equal(d.fade_kernels, c["masks"])
+        with torch.no_grad():
+            assert torch.equal(d.q_sample(mbe.to(c["x"]), mbe.to(c["t"])).cpu(), c["q"])      # sequential products: bit-exact
+            xt, _, img = d.sample(batch_size=3, faded_recon_sample=mbe.to(c["x"]))
+        assert torch.equal(xt.cpu(), c["xt"]) and (img.cpu() - c["img"]).abs().max() <= 1e-4
+    # Random_Incremental: per-sample crop offsets, checked against the oracle with the same offsets
+    torch.manual_seed(3)
+    d = GaussianDiffusion(net, image_size=16, device_of_kernel="cuda", channels=3, timesteps=4, kernel_std=0.5, initial_mask=1,
+                          fade_routine="Random_Incremental", discrete=True)
+    x, t = torch.rand(3, 3, 16, 16) * 2 - 1, torch.tensor([3, 0, 2])
+    torch.manual_seed(11)
+    q = d.q_sample(mbe.to(x), mbe.to(t)).cpu()
+    torch.manual_seed(11)
+    rx = torch.randint(0, 17, (3,), device=mbe.device).cpu()
+    ry = torch.randint(0, 17, (3,), device=mbe.device).cpu()
+    assert torch.equal(q, O.fade_q_sample(x, t, d.fade_kernels.cpu(), rx, ry, discrete=True))
+
+
+def test_trainer_matches_oracle(mbe, tmp_path):
+    """3 optimizer steps (2 micro-steps each, fused Adam over the flat arena, EMA copy phase) and the
+    checkpoint round trip, against the oracle's torch.optim.Adam loop."""
+    from denoising_diffusion_pytorch import GaussianDiffusion, Trainer, Unet
+    torch.manual_seed(0)
+    net = quiet(Unet, dim=8, dim_mults=(1, 2), channels=3).to(mbe.device)
+    diff = GaussianDiffusion(net, image_size=8, channels=3, timesteps=10, sampling_routine="x0_step_down").to(mbe.device)
+    wrapped = torch.nn.DataParallel(diff, device_ids=[0]) if mbe.kind == "hip" else diff
+    sd0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    tr = Trainer(wrapped, None, image_size=8, train_batch_size=2, train_lr=2e-5, train_num_steps=3, gradient_accumulate_every=2,
+                 dataset="synthetic", results_folder=str(tmp_path / "res"))
+    g = torch.Generator().manual_seed(1)
+    batches = [[(torch.rand(2, 3, 8, 8, generator=g) * 2 - 1, torch.randn(2, 3, 8, 8, generator=g), torch.randint(0, 10, (2,), generator=g))
+                for _ in range(2)] for _ in range(3)]
+    ca, cb = O.cosine_tables(10)
+    otr = O.OracleTrainer(sd0, lambda p, x, e, t: O.loss_fn(x, O.unet_forward(p, O.noise_q_sample(x, e, t, ca, cb), t)), lr=2e-5, accumulate=2)
+    for s in range(3):
+        it = iter(batches[s])
+        tr._loss = lambda batch, it=it: tr.core.p_losses(*[mbe.to(v) for v in next(it)])
+        loss = tr.train_step()
+        tr.step += 1
+        lo = otr.train_step(batches[s])
+        assert abs(loss.item() - lo) <= 1e-5
+        for k in sd0:
+            assert (net.state_dict()[k].cpu() - otr.params[k].detach()).abs().max() <= 1e-6, k
+    ema_sd = tr.ema_core.denoise_fn.state_dict()
+    for k in sd0:      # step 0 EMA = copy of the weights after step 0; later steps (1, 2) do not touch it (update every 10)
+        assert (ema_sd[k].cpu() - otr.ema[k]).abs().max() <= 1e-6
+    tr.save()
+    ck = torch.load(str(tmp_path / "res" / "model.pt"), map_location="cpu", weights_only=False)
+    prefix = "module." if mbe.kind == "hip" else ""
+    assert ck["step"] == 3 and f"{prefix}denoise_fn.time_mlp.1.weight" in ck["model"] and f"{prefix}alphas_cumprod" in ck["ema"]
+    tr.load(str(tmp_path / "res" / "model.pt"))
+
+
+def test_no_cpu_fallback():
+    """Without the test-only simulator override the operators refuse CPU tensors."""
+    from colddiff import runtime
+    from deblurring_diffusion_pytorch import Unet
+    assert runtime._lib_override is None
+    net = quiet(Unet, dim=8, dim_mults=(1, 2), channels=3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.randn(1, 3, 8, 8), torch.tensor([1]))
