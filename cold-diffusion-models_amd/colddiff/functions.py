@@ -62,8 +62,9 @@ def conv_backward(x, Cin, dy, weight, bias, kind="conv", stride=1, pad=None, nee
     else:
         Cout = weight.shape[1]
         s_r, s_c = Cout * KK, KK
-    ops.wgrad_into(ops.grad_of(weight), pw, x, Cin, dy, Cout, 1, s_r, s_c)
-    if bias is not None:
+    fuse_bias = bias is not None and kind == "conv"        # dY rows stream through the wgrad kernel exactly once
+    ops.wgrad_into(ops.grad_of(weight), pw, x, Cin, dy, Cout, 1, s_r, s_c, gbias=ops.grad_of(bias) if fuse_bias else None)
+    if bias is not None and not fuse_bias:
         ops.colsum_into(ops.grad_of(bias), dy, Cout)
     if not need_dx:
         return None

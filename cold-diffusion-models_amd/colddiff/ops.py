@@ -104,8 +104,9 @@ def conv_gemm(plan, x, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None, p
     return y
 
 
-def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c):
-    """gparam[c*s_c + r*s_r + t*s_t] += sum_m xa[pixA(m,t)][r] * xb[pixB(m,t)][c]"""
+def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None):
+    """gparam[c*s_c + r*s_r + t*s_t] += sum_m xa[pixA(m,t)][r] * xb[pixB(m,t)][c]
+    gbias (optional, only when xb = dY is visited row by row): gbias[c] += sum_m xb[m][c], fused into the same pass."""
     L = rt.lib()
     B = xa.shape[0]
     M = B * wplan.QH * wplan.QW
@@ -113,9 +114,12 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c):
     ldo = r4(CB)
     ws = torch.empty((ns, wplan.ntaps, CA, ldo), device=xa.device, dtype=torch.float32)
     S = rt.stream(xa)
+    bsum = torch.empty((ns, ldo), device=xa.device, dtype=torch.float32) if gbias is not None else None
     L.cdf_conv_wgrad(P(xa), ld_of(xa), P(xb), ld_of(xb), P(ws), ldo, B, wplan.QH, wplan.QW, wplan.HA, wplan.WA, wplan.sa,
-                     wplan.HB, wplan.WB, wplan.sb, CA, CB, wplan.ntaps, wplan.desc, ns, 1, 0, 0, 0, S)
+                     wplan.HB, wplan.WB, wplan.sb, CA, CB, wplan.ntaps, wplan.desc, ns, 1, 0, 0, 0, P(bsum), S)
     L.cdf_unpack_reduce(P(ws), P(gparam), ns, wplan.ntaps, CA, CB, ldo, s_t, s_r, s_c, 1, S)
+    if gbias is not None:
+        L.cdf_unpack_reduce(P(bsum), P(gbias), ns, 1, 1, CB, ldo, 0, 0, 1, 1, S)
 
 
 def colsum_into(gvec, x, C, nseg=1):
@@ -322,7 +326,7 @@ def bgemm_tn(a, b, CA=None):
     out = torch.empty((nb, CA, r4(m)), device=a.device, dtype=torch.float32)
     tap = cd.conv_wgrad(1, K, 1, 1, 1, 0, 0, 0, 0)
     rt.lib().cdf_conv_wgrad(P(a), a.stride(1), P(b), b.stride(1), P(out), r4(m), 1, 1, K, 1, K, 1, 1, K, 1, CA, m, 1, tap.desc, 1, nb,
-                            a.stride(0), b.stride(0), CA * r4(m), rt.stream(a))
+                            a.stride(0), b.stride(0), CA * r4(m), 0, rt.stream(a))
     return out
 
 

@@ -56,7 +56,7 @@ __device__ __forceinline__ int cdf_xcd_swizzle(int bid, int nblk) {
 }
 
 template <int BM, int BN, int WM, int WN, bool BT>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
+__global__ void __launch_bounds__(256, 4) conv_igemm_kernel(ConvArgs a) {
     constexpr int BK = 16, AS = BK + 4;
     constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN;
     constexpr int APASS = BM / 64;
@@ -251,11 +251,12 @@ struct WgradArgs {
     int ntaps;
     int nsplit, m_per_split;
     long long a_bs, b_bs, o_bs;  // batch strides (blockIdx.z / nsplit)
+    float* bsum;                 // nullable: [nsplit][ldo] column sums of XB (bias gradient), written by tile_a == 0, tap == 0
     signed char day[CDF_MAX_TAPS], dax[CDF_MAX_TAPS], dby[CDF_MAX_TAPS], dbx[CDF_MAX_TAPS];
 };
 
 template <int BMC, int BNC, int WM, int WN>
-__global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
+__global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(WgradArgs a) {
     constexpr int BK = 16;
     constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BNC / WN;
     constexpr int AVEC = BK * BMC / 4, BVEC = BK * BNC / 4;
@@ -279,6 +280,31 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
     const int niter = m_hi > m_lo ? (m_hi - m_lo + BK - 1) / BK : 0;
     const int day = a.day[tap], dax = a.dax[tap], dby = a.dby[tap], dbx = a.dbx[tap];
 
+    // per-thread load slots: the pixel (b, qy, qx) of each slot is decoded once and then advanced
+    // incrementally by BK rows per main-loop step (no integer divisions in the loop)
+    int a_q[APASS][3], b_q[BPASS][3];   // qx, qy, b
+    auto decode = [&](int m, int* q) {
+        q[0] = m % a.QW;
+        const int t2 = m / a.QW;
+        q[1] = t2 % a.QH;
+        q[2] = t2 / a.QH;
+    };
+    auto advance = [&](int* q) {
+        q[0] += BK;
+        while (q[0] >= a.QW) {
+            q[0] -= a.QW;
+            if (++q[1] >= a.QH) { q[1] = 0; ++q[2]; }
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) decode(m_lo + (tid + 256 * p) / (BMC / 4), a_q[p]);
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p) decode(m_lo + (tid + 256 * p) / (BNC / 4), b_q[p]);
+    const bool do_bsum = a.bsum != nullptr && tile_a == 0 && tap == 0;
+    float4 bs_acc[BPASS];
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p) bs_acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+
     float4 ra[APASS], rb[BPASS];
     auto load_global = [&](int it) {
         const int m0 = m_lo + it * BK;
@@ -290,12 +316,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
                 const int k = idx / (BMC / 4), c4 = idx - k * (BMC / 4);
                 const int m = m0 + k, ca = tile_a * BMC + c4 * 4;
                 if (m < m_hi && ca < a.CA) {
-                    const int qx = m % a.QW, t2 = m / a.QW, qy = t2 % a.QH, b = t2 / a.QH;
+                    const int qx = a_q[p][0], qy = a_q[p][1], b = a_q[p][2];
                     const int ay = qy * a.sa + day, ax = qx * a.sa + dax;
                     const int by = qy * a.sb + dby, bx = qx * a.sb + dbx;
                     if (ay >= 0 && ay < a.HA && ax >= 0 && ax < a.WA && by >= 0 && by < a.HB && bx >= 0 && bx < a.WB)
                         ra[p] = *(const float4*)(XA + (((long long)b * a.HA + ay) * a.WA + ax) * a.lda + ca);
                 }
+                advance(a_q[p]);
             }
         }
 #pragma unroll
@@ -306,10 +333,14 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
                 const int k = idx / (BNC / 4), c4 = idx - k * (BNC / 4);
                 const int m = m0 + k, cb = tile_b * BNC + c4 * 4;
                 if (m < m_hi && cb < a.CB) {
-                    const int qx = m % a.QW, t2 = m / a.QW, qy = t2 % a.QH, b = t2 / a.QH;
+                    const int qx = b_q[p][0], qy = b_q[p][1], b = b_q[p][2];
                     const int by = qy * a.sb + dby, bx = qx * a.sb + dbx;
                     if (by >= 0 && by < a.HB && bx >= 0 && bx < a.WB)
                         rb[p] = *(const float4*)(XB + (((long long)b * a.HB + by) * a.WB + bx) * a.ldb + cb);
+                }
+                advance(b_q[p]);
+                if (do_bsum) {
+                    bs_acc[p].x += rb[p].x; bs_acc[p].y += rb[p].y; bs_acc[p].z += rb[p].z; bs_acc[p].w += rb[p].w;
                 }
             }
         }
@@ -364,6 +395,23 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
         __syncthreads();
     }
 
+    if (do_bsum) {
+        // column sums of the XB rows this split visited: reduce the BK/… row lanes that share a column quad through LDS
+        __syncthreads();
+        float* red = &Ys[0][0];                    // reuse: [rows = 256*BPASS / (BNC/4)][BNC]
+#pragma unroll
+        for (int p = 0; p < BPASS; ++p) {
+            const int idx = tid + 256 * p;
+            if (idx < BVEC) *(float4*)(red + idx * 4) = bs_acc[p];
+        }
+        __syncthreads();
+        for (int c = tid; c < BNC; c += 256) {
+            float t = 0.f;
+            for (int k = 0; k < BK; ++k) t += red[k * BNC + c];
+            const int cb = tile_b * BNC + c;
+            if (cb < a.ldo) a.bsum[(long long)(batch * a.nsplit + split) * a.ldo + cb] = cb < a.CB ? t : 0.f;
+        }
+    }
     float* O = a.out + (long long)batch * a.o_bs + ((long long)split * a.ntaps + tap) * a.CA * a.ldo;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -531,7 +579,7 @@ extern "C" int cdf_wgrad_nsplit(int M, int CA, int CB, int ntaps) {
 extern "C" int cdf_conv_wgrad(const float* xa, int lda, const float* xb, int ldb, float* ws, int ldo, int B, int QH,
                               int QW, int HA, int WA, int sa, int HB, int WB, int sb, int CA, int CB, int ntaps,
                               const int* tap_desc, int nsplit, int batch, long long a_bs, long long b_bs,
-                              long long o_bs, void* stream) {
+                              long long o_bs, float* bsum, void* stream) {
     int rc;
     if ((rc = check_feat("cdf_conv_wgrad(xa)", xa, lda, CA))) return rc;
     if ((rc = check_feat("cdf_conv_wgrad(xb)", xb, ldb, CB))) return rc;
@@ -544,7 +592,7 @@ extern "C" int cdf_conv_wgrad(const float* xa, int lda, const float* xb, int ldb
     a.CA = CA; a.CB = CB; a.ntaps = ntaps; a.nsplit = nsplit;
     const int M = B * QH * QW;
     a.m_per_split = cdf_cdiv(cdf_cdiv(M, nsplit), 16) * 16;
-    a.a_bs = a_bs; a.b_bs = b_bs; a.o_bs = o_bs;
+    a.a_bs = a_bs; a.b_bs = b_bs; a.o_bs = o_bs; a.bsum = bsum;
     for (int t = 0; t < ntaps; ++t) {
         a.day[t] = (signed char)tap_desc[4 * t + 0];
         a.dax[t] = (signed char)tap_desc[4 * t + 1];

@@ -106,11 +106,14 @@ int cdf_conv_gemm(const float* x, int ldx, const float* w, int ldw, float* y, in
 /* cdf_conv_wgrad: ws[z][tap][ca][cb] = sum_{m in split z} XA[pixA(m,tap)][ca] * XB[pixB(m,tap)][cb]
  *   m = (b,qy,qx); pixA = (qy*sa+day, qx*sa+dax) in HAxWA, pixB likewise; tap_desc = (day,dax,dby,dbx) x ntaps.
  *   ws holds nsplit (x batch) slabs of [ntaps][CA][ldo]; cdf_unpack_reduce sums the slabs into the
- *   parameter-gradient tensor in its PyTorch layout. */
+ *   parameter-gradient tensor in its PyTorch layout.  bsum (nullable, [nsplit*batch][ldo]) receives the
+ *   per-split column sums of XB's rows as they stream through (the bias gradient when XB = dY with
+ *   sb = 1 and a zero tap offset, so that every row is visited exactly once); reduce it with
+ *   cdf_unpack_reduce(T=1, R=1). */
 int cdf_wgrad_nsplit(int M, int CA, int CB, int ntaps);
 int cdf_conv_wgrad(const float* xa, int lda, const float* xb, int ldb, float* ws, int ldo, int B, int QH, int QW,
                    int HA, int WA, int sa, int HB, int WB, int sb, int CA, int CB, int ntaps, const int* tap_desc,
-                   int nsplit, int batch, long long a_bs, long long b_bs, long long o_bs, void* stream);
+                   int nsplit, int batch, long long a_bs, long long b_bs, long long o_bs, float* bsum, void* stream);
 
 /* parameter layout <-> GEMM layout: dst[t][r][c] = src[c*s_c + r*s_r + t*s_t] (c >= C zero-filled up to ldc);
  * g[c*s_c + r*s_r + t*s_t] (+)= sum_z ws[z][t][r][c] */

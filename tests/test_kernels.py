@@ -214,10 +214,15 @@ def _conv_case(be, B, Cin, Cout, H, k, s, p, transposed):
     ns = max(1, min(be.L.cdf_wgrad_nsplit(M, Cin, Cout, KK), M // 16))
     ldo = r4(Cout)
     ws = be.empty(ns, KK, Cin, ldo)
+    bsum = be.empty(ns, ldo) if not transposed else None
     be.L.cdf_conv_wgrad(P(xn), xn.shape[-1], P(gyn), gyn.shape[-1], P(ws), ldo, B, wg.QH, wg.QW, wg.HA, wg.WA, wg.sa, wg.HB, wg.WB, wg.sb,
-                        Cin, Cout, wg.ntaps, wg.desc, ns, 1, 0, 0, 0, be.stream())
+                        Cin, Cout, wg.ntaps, wg.desc, ns, 1, 0, 0, 0, P(bsum), be.stream())
     dw = be.zeros(*wshape)
     be.L.cdf_unpack_reduce(P(ws), P(dw), ns, KK, Cin, Cout, ldo, 1, s_r, s_c, 0, be.stream())
+    if bsum is not None:                        # fused bias gradient = column sums of dY
+        db = be.zeros(Cout)
+        be.L.cdf_unpack_reduce(P(bsum), P(db), ns, 1, 1, Cout, ldo, 0, 0, 1, 0, be.stream())
+        assert err(db, gy.sum((0, 2, 3))) <= 2e-6 * max(1.0, gy.sum((0, 2, 3)).abs().max().item()) * math.sqrt(M)
     tol = lambda ref: 2e-6 * max(1.0, ref.abs().max().item()) * math.sqrt(max(Cin * KK, 16))
     assert err(y[..., :Cout].permute(0, 3, 1, 2), yref) <= tol(yref)
     assert err(dx[..., :Cin].permute(0, 3, 1, 2), x.grad) <= tol(x.grad)
@@ -270,7 +275,7 @@ def test_conv_epilogue_and_batched(be):
     ws = be.empty(nb, n, C)
     tap = cd.conv_wgrad(1, n, 1, 1, 1, 0, 0, 0, 0)
     be.L.cdf_conv_wgrad(P(be.to(Pm)), r4(n), P(be.to(dO)), C, P(ws), C, 1, 1, n, 1, n, 1, 1, n, 1, n, C, 1, tap.desc, 1, nb,
-                        n * r4(n), n * C, n * C, be.stream())
+                        n * r4(n), n * C, n * C, 0, be.stream())
     assert err(ws, Pm[..., :n].transpose(1, 2) @ dO) <= 1e-5
 
 

@@ -1,0 +1,31 @@
+"""Time cdf_conv_gemm / cdf_conv_wgrad at the CelebA-128 layer shapes (B from env KB_B, default 32)."""
+import json, os, sys, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "cold-diffusion-models_amd"))
+from colddiff import _lib, convdesc as cd
+L = _lib.get(); dev = torch.device("cuda:0")
+S = lambda: torch.cuda.current_stream().cuda_stream
+P = lambda t: 0 if t is None else t.data_ptr()
+r4 = lambda c: (c + 3) // 4 * 4
+B = int(os.environ.get("KB_B", "32")); iters = int(os.environ.get("KB_ITERS", "5"))
+def timeit(fn):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+shapes = [(64,128,128,3),(128,64,128,3),(128,256,64,3),(256,128,64,3),(256,512,32,3),(512,256,32,3),(512,1024,16,3),(1024,512,16,3),(1024,2048,16,3),(64,384,128,1)]
+only = os.environ.get("KB_ONLY")
+for (Cin,Cout,H,k) in shapes:
+    if only and only != f"{Cin}-{Cout}-{H}": continue
+    x = torch.randn(B,H,H,r4(Cin),device=dev); w = torch.randn(k*k,Cin,r4(Cout),device=dev)*0.05; y = torch.empty(B,H,H,r4(Cout),device=dev)
+    p = cd.conv_fwd(H,H,k,k,1,k//2,k//2,k//2,k//2)
+    ms = timeit(lambda: L.cdf_conv_gemm(P(x),x.shape[-1],P(w),w.shape[-1],P(y),y.shape[-1],B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,0,0,0,0,0,0,0,0,0,0,0,0,0,1,0,0,0,S()))
+    fl = 2.0*B*H*H*Cin*Cout*k*k
+    print(f"fwd   {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF", flush=True)
+    if os.environ.get("KB_WGRAD","1") == "1":
+        wg = cd.conv_wgrad(H,H,k,k,1,k//2,k//2,k//2,k//2); M=B*H*H
+        ns = L.cdf_wgrad_nsplit(M,Cin,Cout,k*k); ws = torch.empty(ns,k*k,Cin,r4(Cout),device=dev)
+        ms = timeit(lambda: L.cdf_conv_wgrad(P(x),x.shape[-1],P(y),y.shape[-1],P(ws),r4(Cout),B,H,H,H,H,1,H,H,1,Cin,Cout,k*k,wg.desc,ns,1,0,0,0,0,S()))
+        print(f"wgrad {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF (ns={ns})", flush=True)

@@ -59,7 +59,7 @@ def conv_bench(B, Cin, Cout, H, k, tag):
     ns = L.cdf_wgrad_nsplit(M, Cin, Cout, k * k)
     ws = torch.empty(ns, k * k, Cin, r4(Cout), device=dev)
     fn2 = lambda: L.cdf_conv_wgrad(P(x), x.shape[-1], P(y), y.shape[-1], P(ws), r4(Cout), B, H, H, H, H, 1, H, H, 1, Cin, Cout, k * k,
-                                   wg.desc, ns, 1, 0, 0, 0, S())
+                                   wg.desc, ns, 1, 0, 0, 0, 0, S())
     ms = timeit(fn2)
     rec(f"conv{k}x{k}_wgrad_{tag}_B{B}_{Cin}->{Cout}@{H}_ns{ns}", ms, flops=fl)
 
