@@ -53,15 +53,23 @@ def build_workload(args, device):
     return model, diffusion, trainer
 
 
-class ConvTimer:
-    """HIP-event timing of every cdf_conv_gemm launch (the MFMA implicit-GEMM kernel: all dense conv
-    forward + data-gradient work) on the stream it is launched on, with its algorithmic FLOPs."""
+class GemmTimer:
+    """HIP-event timing (on the launch stream) of every MFMA GEMM launch of the step with its
+    ALGORITHMIC FLOPs (zero-padded taps / channels are not counted):
+      conv_igemm_sp  cdf_conv_gemm_bf16  dense conv fwd + dgrad, bf16x3 split-precision MFMA
+      conv_igemm     cdf_conv_gemm       exact-fp32 MFMA (short-K 1x1 convs, K=32 attention GEMMs, linears)
+      conv_wgrad     cdf_conv_wgrad      weight gradients, exact-fp32 MFMA
+    """
+    PEAK = {"conv_igemm_sp": 2500.0, "conv_igemm": 157.3, "conv_wgrad": 157.3}   # dense TFLOP/s, MI355X_MICROARCH.md
+    DTYPE = {"conv_igemm_sp": "bf16 MFMA, 3 MFMAs per product (hi/lo split operands, fp32 accumulate)",
+             "conv_igemm": "f32 MFMA", "conv_wgrad": "f32 MFMA"}
 
     def __init__(self, lib):
-        self.lib, self.orig = lib, lib.cdf_conv_gemm
-        self.records, self.taps = [], {}
-        self.enabled = False
-        lib.cdf_conv_gemm = self
+        self.lib, self.enabled, self.records, self.taps = lib, False, {k: [] for k in self.PEAK}, {}
+        self.orig = {"conv_igemm": lib.cdf_conv_gemm, "conv_igemm_sp": lib.cdf_conv_gemm_bf16, "conv_wgrad": lib.cdf_conv_wgrad}
+        lib.cdf_conv_gemm = lambda *a: self._call("conv_igemm", a)
+        lib.cdf_conv_gemm_bf16 = lambda *a: self._call("conv_igemm_sp", a)
+        lib.cdf_conv_wgrad = lambda *a: self._call("conv_wgrad", a)
 
     def _ntaps(self, desc, nphase):
         key = id(desc)
@@ -73,22 +81,37 @@ class ConvTimer:
             self.taps[key] = (tot, desc)          # keep desc alive so id() stays unique
         return self.taps[key][0]
 
-    def __call__(self, *a):
+    def _flops(self, kind, a):
+        if kind == "conv_igemm":       # (x,ldx,w,ldw,y,ldy,B,H,W,Cin,OH,OW,Cout,QH,QW,os,is,nphase,desc,...,batch@32)
+            return 2.0 * a[6] * a[13] * a[14] * self._ntaps(a[18], a[17]) * a[9] * a[12] * a[32]
+        if kind == "conv_igemm_sp":    # (x,ldx,whi,wlo,ldk,y,ldy,B,H,W,Cin,OH,OW,Cout,QH,QW,os,is,nphase,desc,...)
+            return 2.0 * a[7] * a[14] * a[15] * self._ntaps(a[19], a[18]) * a[10] * a[13]
+        # conv_wgrad: (xa,lda,xb,ldb,ws,ldo,B,QH,QW,HA,WA,sa,HB,WB,sb,CA,CB,ntaps,desc,nsplit,batch,...)
+        return 2.0 * a[6] * a[7] * a[8] * a[15] * a[16] * a[17] * a[20]
+
+    def _call(self, kind, a):
         if not self.enabled:
-            return self.orig(*a)
-        B, Cin, Cout, QH, QW, nphase, desc, batch = a[6], a[9], a[12], a[13], a[14], a[17], a[18], a[32]
-        flops = 2.0 * B * QH * QW * self._ntaps(desc, nphase) * Cin * Cout * batch
+            return self.orig[kind](*a)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        r = self.orig(*a)
+        r = self.orig[kind](*a)
         e1.record()
-        self.records.append((e0, e1, flops))
+        self.records[kind].append((e0, e1, self._flops(kind, a)))
         return r
 
-    def summary(self):
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
-        fl = sum(f for _, _, f in self.records)
-        return len(self.records), ms, fl
+    def summary(self, steps, elapsed_s):
+        out = {}
+        for kind, recs in self.records.items():
+            if not recs:
+                continue
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out[kind] = {"arithmetic": self.DTYPE[kind], "achieved": round(tf, 2), "peak": self.PEAK[kind], "unit": "TFLOP/s",
+                         "frac": round(tf / self.PEAK[kind], 4), "launches_per_step": len(recs) // max(1, steps),
+                         "avg_launch_ms": round(ms / len(recs), 4), "algorithmic_gflop_per_step": round(fl / max(1, steps) / 1e9, 1),
+                         "share_of_step": round(ms / (1000 * elapsed_s), 3)}
+        return out
 
 
 def cpu_baseline(args):
@@ -157,7 +180,8 @@ def main():
 
     log(f"building workload on {device} (world {world})")
     model, diffusion, trainer = build_workload(args, device)
-    timer = ConvTimer(runtime.lib())
+    timer = GemmTimer(runtime.lib())
+    use_timer = os.environ.get("CDF_BENCH_NOTIMER", "0") != "1"
     log("workload built")
 
     def barrier():
@@ -171,7 +195,7 @@ def main():
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
     barrier()
-    timer.enabled = True
+    timer.enabled = use_timer
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.train_step()
@@ -187,29 +211,31 @@ def main():
 
     imgs_per_step = args.batch * args.accum * world
     value = imgs_per_step * args.steps / elapsed
-    nlaunch, conv_ms, conv_fl = timer.summary()
+    kernels = timer.summary(args.steps, elapsed)
 
     out = {
         "metric": "unet_train_imgs_per_sec", "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if runtime.precision == "f32" else ("f32 storage/accumulate; dense-conv fwd+dgrad operands " + runtime.precision),
+        "data": "synthetic",
         "config": {"workload": "CelebA-128 denoising cold diffusion (BASELINE config 3): Unet(dim=64,(1,2,4,8),ch=3) @128x128, T=200, "
                                "optimizer step = 2 micro-steps x 32 img + Adam + EMA/10", "per_gpu_batch": args.batch,
                    "gradient_accumulate_every": args.accum, "global_images_per_step": imgs_per_step,
                    "parallelism": f"dp{world}" if world > 1 else "single"},
     }
     if parallel.rank() == 0:
-        achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (cdf_conv_gemm: dense conv fwd + dgrad)",
-                           "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                           "launches_per_step": nlaunch // max(1, args.steps),
-                           "avg_launch_ms": round(conv_ms / max(1, nlaunch), 4),
-                           "algorithmic_gflop_per_step": round(conv_fl / max(1, args.steps) / 1e9, 1),
-                           "conv_igemm_share_of_step": round(conv_ms / (1000 * elapsed), 3)}
+        dom = max(kernels, key=lambda k: kernels[k]["share_of_step"]) if kernels else None
+        if dom:
+            d = kernels[dom]
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "arithmetic": d["arithmetic"], "achieved": d["achieved"], "peak": d["peak"],
+                               "unit": "TFLOP/s", "frac": d["frac"], "traffic": None, "launches_per_step": d["launches_per_step"],
+                               "avg_launch_ms": d["avg_launch_ms"], "algorithmic_gflop_per_step": d["algorithmic_gflop_per_step"],
+                               "share_of_step": d["share_of_step"]}
+        out["gemm_kernels"] = kernels
         # whole-step view: 3 x F_fwd per image against the same MFMA peak
         step_tflops = 3 * UNET128_FWD_GFLOP * args.batch * args.accum * args.steps / elapsed / 1e3
-        out["step_mfma_frac"] = round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)
+        out["step_algorithmic_tflops"] = round(step_tflops, 2)
+        out["step_frac_of_f32_mfma_peak"] = round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)
         if world == 1 and not args.no_sample:
             with torch.no_grad():
                 noise = torch.randn(args.sample_batch, 3, 128, 128, device=device)

@@ -42,8 +42,15 @@ def conv_forward(x, Cin, weight, bias, kind="conv", stride=1, pad=None, **epi):
     _, H, W, _ = x.shape
     plan = _conv_plans(kind, H, W, k, stride, pad)[0]
     Cout = weight.shape[0] if kind == "conv" else weight.shape[1]
-    wp = ops.packed(weight, "conv_fwd" if kind == "conv" else "convT_fwd")
+    wp = ops.packed(weight, ("conv_fwd" if kind == "conv" else "convT_fwd") + _sp_suffix(Cin * k * k, Cout))
     return ops.conv_gemm(plan, x, Cin, wp, Cout, bias=bias, **epi)
+
+
+def _sp_suffix(K, N):
+    """Route a dense conv to the split-precision bf16 MFMA kernel when enabled and the GEMM is deep and
+    wide enough to fill its 128x128x32 tiles (K = taps*Cin); short-K 1x1 convs and the tiny first/last
+    layers stay on the exact-fp32 kernel, which is faster there."""
+    return "_sp" if (rt.precision != "f32" and K >= 256 and N >= 64) else ""
 
 
 def conv_backward(x, Cin, dy, weight, bias, kind="conv", stride=1, pad=None, need_dx=True, dx=None, dx_accumulate=0, mul=None,
@@ -68,7 +75,7 @@ def conv_backward(x, Cin, dy, weight, bias, kind="conv", stride=1, pad=None, nee
         ops.colsum_into(ops.grad_of(bias), dy, Cout)
     if not need_dx:
         return None
-    wd = ops.packed(weight, "conv_dgrad" if kind == "conv" else "convT_dgrad")
+    wd = ops.packed(weight, ("conv_dgrad" if kind == "conv" else "convT_dgrad") + _sp_suffix(Cout * KK, Cin))
     return ops.conv_gemm(pd, dy, Cout, wd, Cin, y=dx, mul=mul, mul_mode=mul_mode, accumulate=dx_accumulate)
 
 

@@ -60,6 +60,23 @@ def packed(param, kind):
         Ci, Co, KH, KW = w.shape
         KK = KH * KW
         out = _pack(w, KK, Ci, Co, 1, Co * KK, KK) if kind == "convT_fwd" else _pack(w, KK, Co, Ci, 1, KK, Co * KK)
+    elif kind in ("conv_fwd_sp", "conv_dgrad_sp", "convT_fwd_sp", "convT_dgrad_sp"):
+        # bf16 hi/lo planes [KK][N][ldk] (K contiguous) for the split-precision kernel
+        if kind.startswith("convT"):
+            Ci, Co, KH, KW = w.shape
+            KK = KH * KW
+            geo = (Co, Ci, Ci * 0 + KK, Co * KK) if kind == "convT_fwd_sp" else (Ci, Co, Co * KK, KK)
+            # (N, K, s_n, s_k): fwd: N=Cout (stride KK), K=Cin (stride Co*KK); dgrad: N=Cin (stride Co*KK), K=Cout (stride KK)
+        else:
+            Co, Ci, KH, KW = w.shape
+            KK = KH * KW
+            geo = (Co, Ci, Ci * KK, KK) if kind == "conv_fwd_sp" else (Ci, Co, KK, Ci * KK)
+        N, K, s_n, s_k = geo
+        ldk = (K + 31) // 32 * 32
+        hi = torch.empty((KK, N, ldk), device=w.device, dtype=torch.int16)
+        lo = torch.empty((KK, N, ldk), device=w.device, dtype=torch.int16)
+        rt.lib().cdf_pack_weight_bf16(P(w), P(hi), P(lo), KK, N, K, ldk, 1, s_n, s_k, rt.stream(w))
+        out = (hi, lo)
     elif kind == "dw":
         C = w.shape[0]
         out = _pack(w, 49, 1, C, 1, 0, 49)
@@ -97,6 +114,13 @@ def conv_gemm(plan, x, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None, p
     if y is None:
         y = new_feat(x, B, plan.OH, plan.OW, Cout)
     ldv = lambda t: 0 if t is None else ld_of(t)
+    if isinstance(wp, tuple):                     # (hi, lo) bf16 planes -> split-precision kernel
+        hi, lo = wp
+        rt.lib().cdf_conv_gemm_bf16(P(x), ld_of(x), P(hi), P(lo), hi.shape[-1], P(y), ld_of(y), B, plan.H, plan.W, Cin, plan.OH,
+                                    plan.OW, Cout, plan.QH, plan.QW, plan.os, plan.istride, plan.nphase, plan.desc, P(bias),
+                                    P(sbias), 0 if sbias is None else sbias.stride(0), P(res), ldv(res), P(pre), ldv(pre), P(mul),
+                                    ldv(mul), act, mul_mode, accumulate, 3 if rt.precision == "bf16x3" else 1, rt.stream(x))
+        return y
     rt.lib().cdf_conv_gemm(P(x), ld_of(x), P(wp), wp.shape[-1], P(y), ld_of(y), B, plan.H, plan.W, Cin, plan.OH, plan.OW, Cout,
                            plan.QH, plan.QW, plan.os, plan.istride, plan.nphase, plan.desc, P(bias), P(sbias),
                            0 if sbias is None else sbias.stride(0), P(res), ldv(res), P(pre), ldv(pre), P(mul), ldv(mul),

@@ -13,6 +13,23 @@ _lib_override = None
 weights_epoch = 0
 
 
+# Arithmetic of the dense-conv GEMMs (forward + data gradient):
+#   "bf16x3" (default) split-precision bf16 MFMA: every fp32 operand = bf16 hi + bf16 lo, a*b ~ ah*bh+ah*bl+al*bh,
+#            fp32 accumulate; meets the same 1e-4 parity bound as exact fp32 (tests run in this mode)
+#   "f32"    exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
+#   "bf16"   plain bf16 operands, fp32 accumulate (NOT parity-grade: ~1e-2)
+# Weight gradients, norms, attention, degradations, optimizer are fp32 in every mode.
+import os as _os
+
+precision = _os.environ.get("COLDDIFF_PRECISION", "bf16x3")
+
+
+def set_precision(p):
+    global precision
+    assert p in ("f32", "bf16x3", "bf16"), p
+    precision = p
+
+
 def lib():
     return _lib_override if _lib_override is not None else _lib.get()
 

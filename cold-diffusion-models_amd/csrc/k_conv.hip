@@ -565,10 +565,12 @@ static int launch_wgrad(const WgradArgs& a, int batch, hipStream_t s) {
 }
 
 extern "C" int cdf_wgrad_nsplit(int M, int CA, int CB, int ntaps) {
-    // enough workgroups to fill 256 CUs a few times over, but keep >= 256 pixels per split
-    auto tiles_of = [&](int c) { return c <= 32 ? 1 : (c <= 64 ? 1 : cdf_cdiv(c, 128)); };
+    // One full wave of workgroups: the 128x128 wgrad kernel is resident 4x per CU (1024 slots on 256 CUs).
+    // tiles * nsplit must not spill a handful of blocks into a second round (a straggler round costs a whole
+    // block time), so round DOWN to fill at most one round; keep >= 256 pixels per split.
+    auto tiles_of = [&](int c) { return c <= 64 ? 1 : cdf_cdiv(c, 128); };
     const int tiles = tiles_of(CA) * tiles_of(CB) * ntaps;
-    int ns = cdf_cdiv(1024, tiles);
+    int ns = 1024 / tiles;
     const int max_by_m = M / 256 > 0 ? M / 256 : 1;
     if (ns > max_by_m) ns = max_by_m;
     if (ns < 1) ns = 1;

@@ -1,0 +1,337 @@
+// k_conv_sp.hip — the dense-conv gather-GEMM on the bf16 matrix cores with SPLIT-PRECISION operands.
+//
+// gfx950 runs v_mfma_f32_32x32x16_bf16 at 16x the rate of the exact-fp32 MFMA and has no TF32-like
+// mode.  To stay inside the fp32 parity budget (1e-4 on UNet outputs) every fp32 operand is split
+// into two bf16 terms, x = hi + lo (hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits), and a product
+// is evaluated as  a*b ~= ah*bh + ah*bl + al*bh  with fp32 accumulation in the MFMA ("bf16x3",
+// relative error ~2^-16 per product instead of bf16's 2^-8): 3 MFMAs at 16x the rate = 5.3x the fp32
+// MFMA throughput.  split = 1 uses only the hi terms (plain bf16 operands, fp32 accumulate).
+//
+// Same tap-table / phase / epilogue semantics as conv_igemm_kernel (k_conv.hip); differences:
+//   * weights arrive pre-split and pre-transposed: w_hi / w_lo are bf16 [tap][Cout][ldk] (K contiguous,
+//     ldk = Cin rounded up to 32, zero padded) from cdf_pack_weight_bf16, so the B tile is a straight
+//     16-byte copy into LDS;
+//   * activations stay fp32 in HBM and are split while being written to LDS (VALU work hidden under MFMA);
+//   * BK = 32, LDS rows are 40 bf16 (80 B) so that every ds_read_b128 fragment read is conflict-free.
+#include "cdf_common.h"
+#include "colddiff.h"
+
+#define CDF_MAX_TAPS 16
+
+#ifdef CDF_EMU
+#define CDF_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+typedef short bf16x8_v __attribute__((ext_vector_type(8)));
+#else
+typedef short bf16x8_v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
+#define CDF_MFMA_BF16(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0)
+#endif
+
+struct SpPhase {
+    int oy, ox, ntaps;
+    signed char dy[CDF_MAX_TAPS], dx[CDF_MAX_TAPS], wi[CDF_MAX_TAPS];
+};
+
+struct SpArgs {
+    const float* x;
+    const unsigned short* w_hi;
+    const unsigned short* w_lo;
+    float* y;
+    const float* bias;
+    const float* sbias;
+    const float* res;
+    float* pre;
+    const float* mul;
+    int ldx, ldk, ldy, ld_sbias, ldr, ldp, ldm;
+    int B, H, W, Cin, OH, OW, Cout, QH, QW, os, is;
+    int act, mul_mode, accumulate, nphase;
+    SpPhase ph[4];
+};
+
+__device__ __forceinline__ unsigned cdf_f2bf(float x) {        // round-to-nearest-even bf16 (finite inputs)
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float cdf_bf2f(unsigned h) { return __uint_as_float(h << 16); }
+
+// In-kernel split of an activation quad, kept to ~4 VALU ops per element (the kernel is VALU-, not
+// MFMA-bound): hi = x truncated to bf16 (the residual x - hi is exact in fp32 and lands in lo, so
+// truncating hi costs nothing), lo = (x - hi) truncated to bf16: x = hi + lo + O(2^-16 |x|).
+__device__ __forceinline__ unsigned cdf_pack_hi16(unsigned u0, unsigned u1) { return (u0 >> 16) | (u1 & 0xFFFF0000u); }
+__device__ __forceinline__ void cdf_split4(const float4& v, uint2& hi, uint2& lo) {
+    const unsigned u0 = __float_as_uint(v.x), u1 = __float_as_uint(v.y), u2 = __float_as_uint(v.z), u3 = __float_as_uint(v.w);
+    hi.x = cdf_pack_hi16(u0, u1);
+    hi.y = cdf_pack_hi16(u2, u3);
+    const unsigned r0 = __float_as_uint(v.x - __uint_as_float(u0 & 0xFFFF0000u));
+    const unsigned r1 = __float_as_uint(v.y - __uint_as_float(u1 & 0xFFFF0000u));
+    const unsigned r2 = __float_as_uint(v.z - __uint_as_float(u2 & 0xFFFF0000u));
+    const unsigned r3 = __float_as_uint(v.w - __uint_as_float(u3 & 0xFFFF0000u));
+    lo.x = cdf_pack_hi16(r0, r1);
+    lo.y = cdf_pack_hi16(r2, r3);
+}
+
+__device__ __forceinline__ int cdf_sp_swizzle(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// 256 threads = 4 waves (2x2), block tile 128x128, wave tile 64x64 = 2x2 MFMA 32x32 tiles.
+template <int SPLIT>
+__global__ void __launch_bounds__(256, 2) conv_igemm_sp_kernel(SpArgs a) {
+    constexpr int BM = 128, BN = 128, BK = 32, AS = 40;      // AS: LDS row stride in bf16 elements (80 B)
+    constexpr int NPL = SPLIT == 1 ? 1 : 2;                  // operand planes (hi [, lo])
+    constexpr int PLANE = BM * AS;                           // elements per plane (BM == BN)
+    constexpr int STAGE = 2 * NPL * PLANE;                   // A planes then B planes
+    CDF_DYN_SMEM(smem_raw);
+    unsigned short* smem = (unsigned short*)smem_raw;        // [2 stages][STAGE]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M = a.B * a.QH * a.QW;
+    const int tiles_n = (a.Cout + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    const int tile = cdf_sp_swizzle(blockIdx.x, tiles_m * tiles_n);
+    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+    const SpPhase& ph = a.ph[blockIdx.y];
+
+    // A rows of this thread: row = (tid >> 3) + 32 p, float4 column (tid & 7)
+    const int a_c4 = (tid & 7) * 4;
+    int a_iy0[4], a_ix0[4];
+    unsigned a_pix[4];          // pixel index of (b, iy0, ix0); the tap adds a wave-uniform dy*W + dx
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int m = tile_m * BM + (tid >> 3) + 32 * p;
+        if (m < M) {
+            const int qx = m % a.QW, t2 = m / a.QW;
+            a_iy0[p] = (t2 % a.QH) * a.is;
+            a_ix0[p] = qx * a.is;
+            a_pix[p] = (unsigned)(((t2 / a.QH) * a.H + a_iy0[p]) * a.W + a_ix0[p]);
+        } else {
+            a_iy0[p] = -(1 << 28);
+            a_ix0[p] = 0;
+            a_pix[p] = 0;
+        }
+    }
+    // B rows of this thread: n = (tid >> 2) + 64 p, 16-byte column (tid & 3)
+    const int b_q = tid & 3;
+    const int nchunks = (a.Cin + BK - 1) / BK;
+    const int niter = ph.ntaps * nchunks;
+
+    float4 ra[4];
+    uint4 rbh[2], rbl[2];
+    auto load_global = [&](int it) {
+        const int tap = it / nchunks, c0 = (it - tap * nchunks) * BK;
+        const int dy = ph.dy[tap], dx = ph.dx[tap], wi = ph.wi[tap];
+        const int tap_pix = dy * a.W + dx;
+        const bool cok = (c0 + a_c4) < a.Cin;
+        const float* xc = a.x + c0 + a_c4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const unsigned iy = (unsigned)(a_iy0[p] + dy), ix = (unsigned)(a_ix0[p] + dx);     // unsigned compare folds the >= 0 test
+            const bool ok = iy < (unsigned)a.H && ix < (unsigned)a.W && cok;
+            ra[p] = ok ? *(const float4*)(xc + (size_t)(a_pix[p] + (unsigned)tap_pix) * (unsigned)a.ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int n = tile_n * BN + (tid >> 2) + 64 * p;
+            rbh[p] = make_uint4(0u, 0u, 0u, 0u);
+            rbl[p] = make_uint4(0u, 0u, 0u, 0u);
+            if (n < a.Cout) {
+                const long long off = ((long long)wi * a.Cout + n) * a.ldk + c0 + b_q * 8;
+                rbh[p] = *(const uint4*)(a.w_hi + off);
+                if (SPLIT > 1) rbl[p] = *(const uint4*)(a.w_lo + off);
+            }
+        }
+    };
+    auto store_lds = [&](int buf) {
+        unsigned short* st = smem + buf * STAGE;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint2 hi, lo;
+            if (SPLIT > 1) {
+                cdf_split4(ra[p], hi, lo);
+            } else {      // plain bf16 operands: round to nearest even
+                hi.x = cdf_f2bf(ra[p].x) | (cdf_f2bf(ra[p].y) << 16);
+                hi.y = cdf_f2bf(ra[p].z) | (cdf_f2bf(ra[p].w) << 16);
+                lo = hi;
+            }
+            const int off = ((tid >> 3) + 32 * p) * AS + a_c4;
+            *(uint2*)(st + off) = hi;
+            if (SPLIT > 1) *(uint2*)(st + PLANE + off) = lo;
+        }
+        unsigned short* sb = st + NPL * PLANE;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int off = ((tid >> 2) + 64 * p) * AS + b_q * 8;
+            *(uint4*)(sb + off) = rbh[p];
+            if (SPLIT > 1) *(uint4*)(sb + PLANE + off) = rbl[p];
+        }
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int half = lane >> 5, l31 = lane & 31;
+    if (niter > 0) {
+        load_global(0);
+        store_lds(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < niter) load_global(it + 1);
+        const unsigned short* sa = smem + buf * STAGE;
+        const unsigned short* sb = sa + NPL * PLANE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int k0 = ks * 16 + half * 8;
+            bf16x8_v ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = (wm * 64 + i * 32 + l31) * AS + k0;
+                ah[i] = *(const bf16x8_v*)(sa + off);
+                if (SPLIT > 1) al[i] = *(const bf16x8_v*)(sa + PLANE + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int off = (wn * 64 + j * 32 + l31) * AS + k0;
+                bh[j] = *(const bf16x8_v*)(sb + off);
+                if (SPLIT > 1) bl[j] = *(const bf16x8_v*)(sb + PLANE + off);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (SPLIT > 1) {
+                        // small cross terms first, the dominant hi*hi term last
+                        acc[i][j] = CDF_MFMA_BF16(al[i], bh[j], acc[i][j]);
+                        acc[i][j] = CDF_MFMA_BF16(ah[i], bl[j], acc[i][j]);
+                    }
+                    acc[i][j] = CDF_MFMA_BF16(ah[i], bh[j], acc[i][j]);
+                }
+        }
+        if (it + 1 < niter) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    const bool direct = (a.os == 1 && a.QH == a.OH && a.QW == a.OW);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int m = tile_m * BM + row;
+            if (m >= M) continue;
+            long long opix;
+            int b;
+            if (direct) {
+                opix = m;
+                b = m / (a.QH * a.QW);
+            } else {
+                const int qx = m % a.QW, t2 = m / a.QW;
+                const int qy = t2 % a.QH;
+                b = t2 / a.QH;
+                opix = ((long long)b * a.OH + qy * a.os + ph.oy) * a.OW + qx * a.os + ph.ox;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int co = tile_n * BN + wn * 64 + j * 32 + l31;
+                if (co >= a.Cout) continue;
+                float v = acc[i][j][r];
+                if (a.bias) v += a.bias[co];
+                if (a.sbias) v += a.sbias[(long long)b * a.ld_sbias + co];
+                if (a.pre) a.pre[opix * a.ldp + co] = v;
+                if (a.act == 1) v = cdf_gelu(v);
+                else if (a.act == 2) v = cdf_silu(v);
+                if (a.mul_mode) {
+                    const float mv = a.mul[opix * a.ldm + co];
+                    v *= (a.mul_mode == 1 ? cdf_gelu_grad(mv) : (a.mul_mode == 2 ? cdf_silu_grad(mv) : mv));
+                }
+                if (a.res) v += a.res[opix * a.ldr + co];
+                float* dst = a.y + opix * a.ldy + co;
+                if (a.accumulate) v += *dst;
+                *dst = v;
+            }
+        }
+    }
+}
+
+// dst_hi/lo[t][r][c] (c < ldc, zero padded) = split(src[c*s_c + r*s_r + t*s_t])
+__global__ void pack_weight_bf16_kernel(const float* src, unsigned short* dst_hi, unsigned short* dst_lo, int T, int R, int C,
+                                        int ldc, long long s_t, long long s_r, long long s_c) {
+    const long long n = (long long)T * R * ldc;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ldc);
+        const long long tr = i / ldc;
+        const int r = (int)(tr % R), t = (int)(tr / R);
+        const float v = c < C ? src[c * s_c + r * s_r + t * s_t] : 0.f;
+        const unsigned h = cdf_f2bf(v);
+        dst_hi[i] = (unsigned short)h;
+        dst_lo[i] = (unsigned short)cdf_f2bf(v - cdf_bf2f(h));
+    }
+}
+
+// ================================================================================================
+extern "C" int cdf_pack_weight_bf16(const float* src, void* dst_hi, void* dst_lo, int T, int R, int C, int ldc, long long s_t,
+                                    long long s_r, long long s_c, void* stream) {
+    CDF_REQUIRE(src && dst_hi && dst_lo && T > 0 && R > 0 && C > 0 && ldc >= C && ldc % 32 == 0, "cdf_pack_weight_bf16: bad args (ldc must be a multiple of 32)");
+    long long g = ((long long)T * R * ldc + 255) / 256;
+    if (g > 4096) g = 4096;
+    CDF_LAUNCH(pack_weight_bf16_kernel, dim3((int)g), dim3(256), 0, CDF_S, src, (unsigned short*)dst_hi, (unsigned short*)dst_lo, T, R, C, ldc, s_t, s_r, s_c);
+    return cdf_check_launch("pack_weight_bf16");
+}
+
+extern "C" int cdf_conv_gemm_bf16(const float* x, int ldx, const void* w_hi, const void* w_lo, int ldk, float* y, int ldy, int B,
+                                  int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW, int os, int is, int nphase,
+                                  const int* phase_desc, const float* bias, const float* sbias, int ld_sbias, const float* res,
+                                  int ldr, float* pre, int ldp, const float* mul, int ldm, int act, int mul_mode, int accumulate,
+                                  int split, void* stream) {
+    CDF_REQUIRE(x && w_hi && y && (((uintptr_t)x) & 15) == 0 && ldx % 4 == 0 && ldx >= Cin, "cdf_conv_gemm_bf16: bad x");
+    CDF_REQUIRE((split == 1 || split == 3) && (split == 1 || w_lo), "cdf_conv_gemm_bf16: split must be 1 (bf16) or 3 (hi/lo bf16x3)");
+    CDF_REQUIRE((((uintptr_t)w_hi) & 15) == 0 && ldk % 32 == 0 && ldk >= Cin, "cdf_conv_gemm_bf16: weights must be 16B aligned with ldk %% 32 == 0");
+    CDF_REQUIRE(nphase >= 1 && nphase <= 4 && phase_desc && ldy >= Cout, "cdf_conv_gemm_bf16: bad geometry");
+    CDF_REQUIRE(!mul_mode || mul, "cdf_conv_gemm_bf16: mul_mode without mul tensor");
+    SpArgs a;
+    a.x = x; a.w_hi = (const unsigned short*)w_hi; a.w_lo = (const unsigned short*)w_lo; a.y = y;
+    a.bias = bias; a.sbias = sbias; a.res = res; a.pre = pre; a.mul = mul;
+    a.ldx = ldx; a.ldk = ldk; a.ldy = ldy; a.ld_sbias = ld_sbias; a.ldr = ldr; a.ldp = ldp; a.ldm = ldm;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.QH = QH; a.QW = QW; a.os = os; a.is = is;
+    a.act = act; a.mul_mode = mul_mode; a.accumulate = accumulate; a.nphase = nphase;
+    const int* pd = phase_desc;
+    for (int p = 0; p < nphase; ++p) {
+        a.ph[p].oy = pd[0]; a.ph[p].ox = pd[1]; a.ph[p].ntaps = pd[2];
+        CDF_REQUIRE(pd[2] >= 0 && pd[2] <= CDF_MAX_TAPS, "cdf_conv_gemm_bf16: too many taps (%d)", pd[2]);
+        for (int t = 0; t < pd[2]; ++t) {
+            a.ph[p].dy[t] = (signed char)pd[3 + 3 * t];
+            a.ph[p].dx[t] = (signed char)pd[4 + 3 * t];
+            a.ph[p].wi[t] = (signed char)pd[5 + 3 * t];
+        }
+        pd += 3 + 3 * pd[2];
+    }
+    const int M = B * QH * QW;
+    const int tiles = cdf_cdiv(M, 128) * cdf_cdiv(Cout, 128);
+#ifndef CDF_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_sp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_sp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+#endif
+    if (split == 1) {
+        const size_t lds = (size_t)2 * 2 * 1 * 128 * 40 * sizeof(unsigned short);
+        CDF_LAUNCH((conv_igemm_sp_kernel<1>), dim3(tiles, nphase), dim3(256), lds, CDF_S, a);
+    } else {
+        const size_t lds = (size_t)2 * 2 * 2 * 128 * 40 * sizeof(unsigned short);
+        CDF_LAUNCH((conv_igemm_sp_kernel<3>), dim3(tiles, nphase), dim3(256), lds, CDF_S, a);
+    }
+    return cdf_check_launch("conv_igemm_sp");
+}

@@ -115,6 +115,20 @@ int cdf_conv_wgrad(const float* xa, int lda, const float* xb, int ldb, float* ws
                    int HA, int WA, int sa, int HB, int WB, int sb, int CA, int CB, int ntaps, const int* tap_desc,
                    int nsplit, int batch, long long a_bs, long long b_bs, long long o_bs, float* bsum, void* stream);
 
+/* ---- split-precision bf16 MFMA path of the same gather-GEMM (csrc/k_conv_sp.hip) ---------------------
+ * Same geometry / epilogue contract as cdf_conv_gemm (no batch / b_trans).  Operands are fp32 in
+ * HBM; x is split on the fly into bf16 hi + lo, the weights arrive pre-split from
+ * cdf_pack_weight_bf16 as bf16 [tap][Cout][ldk] planes (K contiguous, ldk = Cin rounded up to 32):
+ *   split = 3 : a*b ~= ah*bh + ah*bl + al*bh   (fp32-grade parity, 5.3x the fp32-MFMA rate)
+ *   split = 1 : plain bf16 operands (w_lo may be NULL), fp32 accumulate. */
+int cdf_pack_weight_bf16(const float* src, void* dst_hi, void* dst_lo, int T, int R, int C, int ldc, long long s_t,
+                         long long s_r, long long s_c, void* stream);
+int cdf_conv_gemm_bf16(const float* x, int ldx, const void* w_hi, const void* w_lo, int ldk, float* y, int ldy, int B, int H,
+                       int W, int Cin, int OH, int OW, int Cout, int QH, int QW, int os, int is, int nphase,
+                       const int* phase_desc, const float* bias, const float* sbias, int ld_sbias, const float* res, int ldr,
+                       float* pre, int ldp, const float* mul, int ldm, int act, int mul_mode, int accumulate, int split,
+                       void* stream);
+
 /* parameter layout <-> GEMM layout: dst[t][r][c] = src[c*s_c + r*s_r + t*s_t] (c >= C zero-filled up to ldc);
  * g[c*s_c + r*s_r + t*s_t] (+)= sum_z ws[z][t][r][c] */
 int cdf_pack_weight(const float* src, float* dst, int T, int R, int C, int ldc, long long s_t, long long s_r,

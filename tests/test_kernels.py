@@ -436,3 +436,68 @@ def test_adam_ema_match_torch(be):
     mad = be.to(ma)
     be.L.cdf_ema_update(P(mad), P(pd), n, 0.995, be.stream())
     assert err(mad, ma * 0.995 + (1 - 0.995) * pd.cpu()) <= 1e-9
+
+
+# ---------------------------------------------------------------------------------------------
+# split-precision bf16 MFMA conv (bf16x3: fp32-grade parity; bf16: plain)
+# ---------------------------------------------------------------------------------------------
+SP_CASES = [(2, 32, 40, 8, 3, 1, 1, False), (1, 64, 32, 8, 1, 1, 0, False), (1, 36, 130, 8, 3, 1, 1, False), (1, 32, 32, 8, 4, 2, 1, False),
+            (1, 32, 32, 4, 4, 2, 1, True)]
+SP_CASES_GPU = [(4, 64, 128, 32, 3, 1, 1, False), (2, 128, 64, 32, 3, 1, 1, False), (2, 64, 64, 32, 4, 2, 1, False),
+                (2, 64, 64, 16, 4, 2, 1, True), (2, 256, 512, 16, 3, 1, 1, False), (3, 64, 384, 32, 1, 1, 0, False)]
+
+
+def _sp_case(be, split, B, Cin, Cout, H, k, s, p, transposed):
+    torch.manual_seed(0)
+    x = torch.randn(B, Cin, H, H, requires_grad=True)
+    wshape = (Cin, Cout, k, k) if transposed else (Cout, Cin, k, k)
+    w = (torch.randn(*wshape) * (1.0 / math.sqrt(Cin * k * k))).requires_grad_()
+    bias = torch.randn(Cout)
+    yref = F.conv_transpose2d(x, w, bias, stride=s, padding=p) if transposed else F.conv2d(x, w, bias, stride=s, padding=p)
+    gy = torch.randn_like(yref)
+    yref.backward(gy)
+    KK = k * k
+
+    def pack_sp(N, K, s_n, s_k):
+        ldk = (K + 31) // 32 * 32
+        hi = torch.empty(KK, N, ldk, dtype=torch.int16, device=be.device)
+        lo = torch.empty(KK, N, ldk, dtype=torch.int16, device=be.device)
+        be.L.cdf_pack_weight_bf16(P(wd_), P(hi), P(lo), KK, N, K, ldk, 1, s_n, s_k, be.stream())
+        be._keep += [hi, lo]
+        return hi, lo
+
+    wd_ = be.to(w)
+    if not transposed:
+        plan, pd = cd.conv_fwd(H, H, k, k, s, p, p, p, p), cd.conv_dgrad(H, H, k, k, s, p, p, p, p)
+        wf, wb = pack_sp(Cout, Cin, Cin * KK, KK), pack_sp(Cin, Cout, KK, Cin * KK)
+    else:
+        plan, pd = cd.convT_fwd(H, H, k, k, s, p), cd.convT_dgrad(H, H, k, k, s, p)
+        wf, wb = pack_sp(Cout, Cin, KK, Cout * KK), pack_sp(Cin, Cout, Cout * KK, KK)
+
+    def run(pl, xin, wpair, Ci, Co, bias_):
+        y = be.zeros(B, pl.OH, pl.OW, r4(Co))
+        be.L.cdf_conv_gemm_bf16(P(xin), xin.shape[-1], P(wpair[0]), P(wpair[1]), wpair[0].shape[-1], P(y), y.shape[-1], B, pl.H, pl.W, Ci,
+                                pl.OH, pl.OW, Co, pl.QH, pl.QW, pl.os, pl.istride, pl.nphase, pl.desc, P(bias_), 0, 0, 0, 0, 0, 0, 0, 0,
+                                0, 0, 0, split, be.stream())
+        return y
+
+    y = run(plan, be.to(nhwc(x)), wf, Cin, Cout, be.to(bias))
+    dx = run(pd, be.to(nhwc(gy)), wb, Cout, Cin, None)
+    rel = 3e-5 if split == 3 else 2e-2            # bf16x3 keeps 16 mantissa bits per operand; bf16 keeps 8
+    tol = lambda ref: rel * max(1.0, ref.abs().max().item())
+    assert err(y[..., :Cout].permute(0, 3, 1, 2), yref) <= tol(yref)
+    assert err(dx[..., :Cin].permute(0, 3, 1, 2), x.grad) <= tol(x.grad)
+
+
+@pytest.mark.parametrize("split", [3, 1])
+@pytest.mark.parametrize("case", SP_CASES)
+def test_conv_gemm_bf16(be, split, case):
+    _sp_case(be, split, *case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", [3, 1])
+@pytest.mark.parametrize("case", SP_CASES_GPU)
+def test_conv_gemm_bf16_large(split, case):
+    from conftest import Backend
+    _sp_case(Backend("hip"), split, *case)

@@ -29,3 +29,17 @@ for (Cin,Cout,H,k) in shapes:
         ns = L.cdf_wgrad_nsplit(M,Cin,Cout,k*k); ws = torch.empty(ns,k*k,Cin,r4(Cout),device=dev)
         ms = timeit(lambda: L.cdf_conv_wgrad(P(x),x.shape[-1],P(y),y.shape[-1],P(ws),r4(Cout),B,H,H,H,H,1,H,H,1,Cin,Cout,k*k,wg.desc,ns,1,0,0,0,0,S()))
         print(f"wgrad {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF (ns={ns})", flush=True)
+# ---- split-precision bf16 MFMA variants --------------------------------------------------------------
+if os.environ.get("KB_SP", "1") == "1":
+    for (Cin,Cout,H,k) in shapes:
+        if only and only != f"{Cin}-{Cout}-{H}": continue
+        x = torch.randn(B,H,H,r4(Cin),device=dev); y = torch.empty(B,H,H,r4(Cout),device=dev)
+        ldk = (Cin+31)//32*32
+        hi = torch.zeros(k*k,Cout,ldk,dtype=torch.int16,device=dev); lo = torch.zeros_like(hi)
+        w = torch.randn(Cout,Cin,k,k,device=dev)*0.05
+        L.cdf_pack_weight_bf16(P(w),P(hi),P(lo),k*k,Cout,Cin,ldk,1,Cin*k*k,k*k,S())
+        p = cd.conv_fwd(H,H,k,k,1,k//2,k//2,k//2,k//2)
+        fl = 2.0*B*H*H*Cin*Cout*k*k
+        for split in (3,1):
+            ms = timeit(lambda: L.cdf_conv_gemm_bf16(P(x),x.shape[-1],P(hi),P(lo),ldk,P(y),y.shape[-1],B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,0,0,0,0,0,0,0,0,0,0,0,0,split,S()))
+            print(f"sp{split}   {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv", flush=True)
