@@ -134,8 +134,21 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None):
     L = rt.lib()
     B = xa.shape[0]
     M = B * wplan.QH * wplan.QW
-    ns = max(1, min(L.cdf_wgrad_nsplit(M, CA, CB, wplan.ntaps), M // 16 if M >= 16 else 1))
     ldo = r4(CB)
+    if rt.precision != "f32" and CA >= 128 and CB >= 128 and M >= 2048:   # full 128x128 tiles only; thinner layers are faster on the fp32 kernel
+        # split-precision bf16 MFMA kernel: 128x128 tiles, resident twice per CU (512 slots)
+        tiles = ((CA + 127) // 128) * ((CB + 127) // 128) * wplan.ntaps
+        ns = max(1, min(512 // tiles if tiles <= 512 else 1, M // 512))
+        ws = torch.empty((ns, wplan.ntaps, CA, ldo), device=xa.device, dtype=torch.float32)
+        S = rt.stream(xa)
+        bsum = torch.empty((ns, ldo), device=xa.device, dtype=torch.float32) if gbias is not None else None
+        L.cdf_conv_wgrad_bf16(P(xa), ld_of(xa), P(xb), ld_of(xb), P(ws), ldo, B, wplan.QH, wplan.QW, wplan.HA, wplan.WA, wplan.sa,
+                              wplan.HB, wplan.WB, wplan.sb, CA, CB, wplan.ntaps, wplan.desc, ns, P(bsum), S)
+        L.cdf_unpack_reduce(P(ws), P(gparam), ns, wplan.ntaps, CA, CB, ldo, s_t, s_r, s_c, 1, S)
+        if gbias is not None:
+            L.cdf_unpack_reduce(P(bsum), P(gbias), ns, 1, 1, CB, ldo, 0, 0, 1, 1, S)
+        return
+    ns = max(1, min(L.cdf_wgrad_nsplit(M, CA, CB, wplan.ntaps), M // 16 if M >= 16 else 1))
     ws = torch.empty((ns, wplan.ntaps, CA, ldo), device=xa.device, dtype=torch.float32)
     S = rt.stream(xa)
     bsum = torch.empty((ns, ldo), device=xa.device, dtype=torch.float32) if gbias is not None else None

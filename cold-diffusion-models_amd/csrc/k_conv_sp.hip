@@ -264,6 +264,180 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_sp_kernel(SpArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient on the bf16 matrix cores, split precision (same contract as conv_wgrad_kernel):
+//   out[z][tap][ca][cb] = sum_{m in split z} XA[pixA(m,tap)][ca] * XB[pixB(m,tap)][cb]
+// The contraction runs over PIXELS, which are the slow index of both NHWC operands, so the LDS tiles
+// stay pixel-major ([32 px][128 ch] bf16 hi / lo, split while being stored) and each lane assembles
+// its 8-pixel MFMA fragment from eight 16-bit LDS reads (32 consecutive channels per half-wave:
+// conflict-free).  Tile 128 (ca) x 128 (cb), BK = 32 pixels, 4 waves of 64x64.
+// ------------------------------------------------------------------------------------------------
+struct SpWgradArgs {
+    const float* xa;
+    const float* xb;
+    float* out;
+    float* bsum;
+    int lda, ldb, ldo;
+    int B, QH, QW;
+    int HA, WA, sa, HB, WB, sb;
+    int CA, CB;
+    int ntaps, nsplit, m_per_split;
+    signed char day[CDF_MAX_TAPS], dax[CDF_MAX_TAPS], dby[CDF_MAX_TAPS], dbx[CDF_MAX_TAPS];
+};
+
+__global__ void __launch_bounds__(256, 2) conv_wgrad_sp_kernel(SpWgradArgs a) {
+    constexpr int BC = 128, BK = 32;
+    constexpr int PLANE = BK * BC;                 // bf16 elements per plane
+    constexpr int STAGE = 4 * PLANE;               // A hi, A lo, B hi, B lo
+    CDF_DYN_SMEM(smem_raw);
+    unsigned short* smem = (unsigned short*)smem_raw;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_b = (a.CB + BC - 1) / BC;
+    const int tile_a = blockIdx.x / tiles_b, tile_b = blockIdx.x - tile_a * tiles_b;
+    const int tap = blockIdx.y, split = blockIdx.z;
+    const int M = a.B * a.QH * a.QW;
+    const int m_lo = split * a.m_per_split;
+    int m_hi = m_lo + a.m_per_split;
+    if (m_hi > M) m_hi = M;
+    const int niter = m_hi > m_lo ? (m_hi - m_lo + BK - 1) / BK : 0;
+    const int day = a.day[tap], dax = a.dax[tap], dby = a.dby[tap], dbx = a.dbx[tap];
+
+    // load slots: pixel k = (tid >> 5) + 8 p, channel quad c4 = tid & 31 (both operands)
+    const int c4 = (tid & 31) * 4;
+    int q[4][3];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int m = m_lo + (tid >> 5) + 8 * p;
+        q[p][0] = m % a.QW;
+        const int t2 = m / a.QW;
+        q[p][1] = t2 % a.QH;
+        q[p][2] = t2 / a.QH;
+    }
+    const bool do_bsum = a.bsum != nullptr && tile_a == 0 && tap == 0;
+    float4 bs_acc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) bs_acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ca = tile_a * BC + c4, cb = tile_b * BC + c4;
+
+    float4 ra[4], rb[4];
+    auto load_global = [&](int it) {
+        const int m0 = m_lo + it * BK;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int m = m0 + (tid >> 5) + 8 * p;
+            ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_hi) {
+                const int qx = q[p][0], qy = q[p][1], b = q[p][2];
+                const unsigned ay = (unsigned)(qy * a.sa + day), ax = (unsigned)(qx * a.sa + dax);
+                const unsigned by = (unsigned)(qy * a.sb + dby), bx = (unsigned)(qx * a.sb + dbx);
+                const bool bok = by < (unsigned)a.HB && bx < (unsigned)a.WB;
+                if (bok && ay < (unsigned)a.HA && ax < (unsigned)a.WA && ca < a.CA)
+                    ra[p] = *(const float4*)(a.xa + (((long long)b * a.HA + ay) * a.WA + ax) * a.lda + ca);
+                if (bok && cb < a.CB)
+                    rb[p] = *(const float4*)(a.xb + (((long long)b * a.HB + by) * a.WB + bx) * a.ldb + cb);
+            }
+            q[p][0] += BK;
+            while (q[p][0] >= a.QW) {
+                q[p][0] -= a.QW;
+                if (++q[p][1] >= a.QH) { q[p][1] = 0; ++q[p][2]; }
+            }
+            if (do_bsum) {
+                bs_acc[p].x += rb[p].x; bs_acc[p].y += rb[p].y; bs_acc[p].z += rb[p].z; bs_acc[p].w += rb[p].w;
+            }
+        }
+    };
+    auto store_lds = [&](int buf) {
+        unsigned short* st = smem + buf * STAGE;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int off = ((tid >> 5) + 8 * p) * BC + c4;
+            uint2 hi, lo;
+            cdf_split4(ra[p], hi, lo);
+            *(uint2*)(st + off) = hi;
+            *(uint2*)(st + PLANE + off) = lo;
+            cdf_split4(rb[p], hi, lo);
+            *(uint2*)(st + 2 * PLANE + off) = hi;
+            *(uint2*)(st + 3 * PLANE + off) = lo;
+        }
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int half = lane >> 5, l31 = lane & 31;
+    if (niter > 0) {
+        load_global(0);
+        store_lds(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < niter) load_global(it + 1);
+        const unsigned short* st = smem + buf * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int k0 = ks * 16 + half * 8;
+            bf16x8_v ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned short* pa = st + k0 * BC + wm * 64 + i * 32 + l31;
+                const unsigned short* pb = st + 2 * PLANE + k0 * BC + wn * 64 + i * 32 + l31;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    ah[i][e] = (short)pa[e * BC];
+                    al[i][e] = (short)pa[PLANE + e * BC];
+                    bh[i][e] = (short)pb[e * BC];
+                    bl[i][e] = (short)pb[PLANE + e * BC];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = CDF_MFMA_BF16(al[i], bh[j], acc[i][j]);
+                    acc[i][j] = CDF_MFMA_BF16(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = CDF_MFMA_BF16(ah[i], bh[j], acc[i][j]);
+                }
+        }
+        if (it + 1 < niter) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (do_bsum) {
+        float* red = (float*)smem;                 // [32 px][128] floats = 16 KB (stage 0 is idle now)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *(float4*)(red + ((tid >> 5) + 8 * p) * BC + c4) = bs_acc[p];
+        __syncthreads();
+        for (int c = tid; c < BC; c += 256) {
+            float t = 0.f;
+            for (int k = 0; k < BK; ++k) t += red[k * BC + c];
+            const int cc = tile_b * BC + c;
+            if (cc < a.ldo) a.bsum[(long long)split * a.ldo + cc] = cc < a.CB ? t : 0.f;
+        }
+    }
+    float* O = a.out + ((long long)split * a.ntaps + tap) * a.CA * a.ldo;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tile_a * BC + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row >= a.CA) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = tile_b * BC + wn * 64 + j * 32 + l31;
+                if (col < a.ldo) O[(long long)row * a.ldo + col] = col < a.CB ? acc[i][j][r] : 0.f;
+            }
+        }
+}
+
 // dst_hi/lo[t][r][c] (c < ldc, zero padded) = split(src[c*s_c + r*s_r + t*s_t])
 __global__ void pack_weight_bf16_kernel(const float* src, unsigned short* dst_hi, unsigned short* dst_lo, int T, int R, int C,
                                         int ldc, long long s_t, long long s_r, long long s_c) {
@@ -334,4 +508,35 @@ extern "C" int cdf_conv_gemm_bf16(const float* x, int ldx, const void* w_hi, con
         CDF_LAUNCH((conv_igemm_sp_kernel<3>), dim3(tiles, nphase), dim3(256), lds, CDF_S, a);
     }
     return cdf_check_launch("conv_igemm_sp");
+}
+
+extern "C" int cdf_conv_wgrad_bf16(const float* xa, int lda, const float* xb, int ldb, float* ws, int ldo, int B, int QH, int QW,
+                                   int HA, int WA, int sa, int HB, int WB, int sb, int CA, int CB, int ntaps, const int* tap_desc,
+                                   int nsplit, float* bsum, void* stream) {
+    CDF_REQUIRE(xa && xb && ws && (((uintptr_t)xa) & 15) == 0 && (((uintptr_t)xb) & 15) == 0, "cdf_conv_wgrad_bf16: null / unaligned operand");
+    CDF_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= CA && ldb >= CB && ldo % 4 == 0 && ldo >= CB, "cdf_conv_wgrad_bf16: bad pitch");
+    CDF_REQUIRE(ntaps >= 1 && ntaps <= CDF_MAX_TAPS && tap_desc && nsplit >= 1, "cdf_conv_wgrad_bf16: bad tap / split count");
+    SpWgradArgs a;
+    a.xa = xa; a.xb = xb; a.out = ws; a.bsum = bsum; a.lda = lda; a.ldb = ldb; a.ldo = ldo;
+    a.B = B; a.QH = QH; a.QW = QW; a.HA = HA; a.WA = WA; a.sa = sa; a.HB = HB; a.WB = WB; a.sb = sb;
+    a.CA = CA; a.CB = CB; a.ntaps = ntaps; a.nsplit = nsplit;
+    const int M = B * QH * QW;
+    a.m_per_split = cdf_cdiv(cdf_cdiv(M, nsplit), 32) * 32;
+    for (int t = 0; t < ntaps; ++t) {
+        a.day[t] = (signed char)tap_desc[4 * t + 0];
+        a.dax[t] = (signed char)tap_desc[4 * t + 1];
+        a.dby[t] = (signed char)tap_desc[4 * t + 2];
+        a.dbx[t] = (signed char)tap_desc[4 * t + 3];
+    }
+#ifndef CDF_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_sp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+#endif
+    const size_t lds = (size_t)2 * 4 * 32 * 128 * sizeof(unsigned short);
+    const int tiles = cdf_cdiv(CA, 128) * cdf_cdiv(CB, 128);
+    CDF_LAUNCH(conv_wgrad_sp_kernel, dim3(tiles, ntaps, nsplit), dim3(256), lds, CDF_S, a);
+    return cdf_check_launch("conv_wgrad_sp");
 }

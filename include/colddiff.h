@@ -128,6 +128,11 @@ int cdf_conv_gemm_bf16(const float* x, int ldx, const void* w_hi, const void* w_
                        const int* phase_desc, const float* bias, const float* sbias, int ld_sbias, const float* res, int ldr,
                        float* pre, int ldp, const float* mul, int ldm, int act, int mul_mode, int accumulate, int split,
                        void* stream);
+/* Weight gradient on the same split-precision bf16 MFMA path (contract of cdf_conv_wgrad, no batch):
+ * both operands are fp32 NHWC activations, split into bf16 hi/lo while staged in LDS. */
+int cdf_conv_wgrad_bf16(const float* xa, int lda, const float* xb, int ldb, float* ws, int ldo, int B, int QH, int QW, int HA,
+                        int WA, int sa, int HB, int WB, int sb, int CA, int CB, int ntaps, const int* tap_desc, int nsplit,
+                        float* bsum, void* stream);
 
 /* parameter layout <-> GEMM layout: dst[t][r][c] = src[c*s_c + r*s_r + t*s_t] (c >= C zero-filled up to ldc);
  * g[c*s_c + r*s_r + t*s_t] (+)= sum_z ws[z][t][r][c] */

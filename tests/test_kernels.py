@@ -483,6 +483,22 @@ def _sp_case(be, split, B, Cin, Cout, H, k, s, p, transposed):
 
     y = run(plan, be.to(nhwc(x)), wf, Cin, Cout, be.to(bias))
     dx = run(pd, be.to(nhwc(gy)), wb, Cout, Cin, None)
+    if split == 3 and Cin % 4 == 0:               # weight gradient on the split-precision path (+ fused bias gradient)
+        wg = cd.convT_wgrad(H, H, k, k, s, p) if transposed else cd.conv_wgrad(H, H, k, k, s, p, p, p, p)
+        M = B * wg.QH * wg.QW
+        ns, ldo = max(1, min(3, M // 32)), r4(Cout)
+        ws, bsum = be.empty(ns, KK, Cin, ldo), be.empty(ns, ldo)
+        xn, gyn = be.to(nhwc(x)), be.to(nhwc(gy))
+        be.L.cdf_conv_wgrad_bf16(P(xn), xn.shape[-1], P(gyn), gyn.shape[-1], P(ws), ldo, B, wg.QH, wg.QW, wg.HA, wg.WA, wg.sa, wg.HB, wg.WB,
+                                 wg.sb, Cin, Cout, wg.ntaps, wg.desc, ns, 0 if transposed else P(bsum), be.stream())
+        dw = be.zeros(*wshape)
+        s_r, s_c = (Cout * KK, KK) if transposed else (KK, Cin * KK)
+        be.L.cdf_unpack_reduce(P(ws), P(dw), ns, KK, Cin, Cout, ldo, 1, s_r, s_c, 0, be.stream())
+        assert err(dw, w.grad) <= 3e-5 * max(1.0, w.grad.abs().max().item()) * math.sqrt(M / 16)
+        if not transposed:
+            db = be.zeros(Cout)
+            be.L.cdf_unpack_reduce(P(bsum), P(db), ns, 1, 1, Cout, ldo, 0, 0, 1, 0, be.stream())
+            assert err(db, gy.sum((0, 2, 3))) <= 1e-5 * max(1.0, gy.sum((0, 2, 3)).abs().max().item()) * math.sqrt(M)
     rel = 3e-5 if split == 3 else 2e-2            # bf16x3 keeps 16 mantissa bits per operand; bf16 keeps 8
     tol = lambda ref: rel * max(1.0, ref.abs().max().item())
     assert err(y[..., :Cout].permute(0, 3, 1, 2), yref) <= tol(yref)

@@ -43,3 +43,15 @@ if os.environ.get("KB_SP", "1") == "1":
         for split in (3,1):
             ms = timeit(lambda: L.cdf_conv_gemm_bf16(P(x),x.shape[-1],P(hi),P(lo),ldk,P(y),y.shape[-1],B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,0,0,0,0,0,0,0,0,0,0,0,0,split,S()))
             print(f"sp{split}   {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv", flush=True)
+if os.environ.get("KB_SPW", "1") == "1":
+    for (Cin,Cout,H,k) in shapes:
+        if only and only != f"{Cin}-{Cout}-{H}": continue
+        if Cin < 64 or Cout < 64: continue
+        x = torch.randn(B,H,H,r4(Cin),device=dev); y = torch.randn(B,H,H,r4(Cout),device=dev)
+        wg = cd.conv_wgrad(H,H,k,k,1,k//2,k//2,k//2,k//2); M=B*H*H
+        tiles = ((Cin+127)//128)*((Cout+127)//128)*k*k
+        ns = max(1, min(512//tiles if tiles <= 512 else 1, M//512))
+        ws = torch.empty(ns,k*k,Cin,r4(Cout),device=dev)
+        ms = timeit(lambda: L.cdf_conv_wgrad_bf16(P(x),x.shape[-1],P(y),y.shape[-1],P(ws),r4(Cout),B,H,H,H,H,1,H,H,1,Cin,Cout,k*k,wg.desc,ns,0,S()))
+        fl = 2.0*B*H*H*Cin*Cout*k*k
+        print(f"spW   {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv (ns={ns})", flush=True)
