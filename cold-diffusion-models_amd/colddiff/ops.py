@@ -128,6 +128,17 @@ def conv_gemm(plan, x, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None, p
     return y
 
 
+def best_nsplit(tiles, slots, max_ns):
+    """Split-K factor minimising the number of (equal-length) block rounds per unit of work:
+    time ~ ceil(tiles*ns / slots) / ns; ties go to the smaller ns (less slab traffic)."""
+    best, best_cost = 1, None
+    for ns in range(1, max(1, min(max_ns, 256)) + 1):
+        cost = -(-tiles * ns // slots) / ns
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = ns, cost
+    return best
+
+
 def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None):
     """gparam[c*s_c + r*s_r + t*s_t] += sum_m xa[pixA(m,t)][r] * xb[pixB(m,t)][c]
     gbias (optional, only when xb = dY is visited row by row): gbias[c] += sum_m xb[m][c], fused into the same pass."""
@@ -138,7 +149,7 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None):
     if rt.precision != "f32" and CA >= 128 and CB >= 128 and M >= 2048:   # full 128x128 tiles only; thinner layers are faster on the fp32 kernel
         # split-precision bf16 MFMA kernel: 128x128 tiles, resident twice per CU (512 slots)
         tiles = ((CA + 127) // 128) * ((CB + 127) // 128) * wplan.ntaps
-        ns = max(1, min(512 // tiles if tiles <= 512 else 1, M // 512))
+        ns = best_nsplit(tiles, 512, M // 512)
         ws = torch.empty((ns, wplan.ntaps, CA, ldo), device=xa.device, dtype=torch.float32)
         S = rt.stream(xa)
         bsum = torch.empty((ns, ldo), device=xa.device, dtype=torch.float32) if gbias is not None else None
@@ -148,7 +159,8 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None):
         if gbias is not None:
             L.cdf_unpack_reduce(P(bsum), P(gbias), ns, 1, 1, CB, ldo, 0, 0, 1, 1, S)
         return
-    ns = max(1, min(L.cdf_wgrad_nsplit(M, CA, CB, wplan.ntaps), M // 16 if M >= 16 else 1))
+    tiles_f32 = (1 if CA <= 64 else (CA + 127) // 128) * (1 if CB <= 64 else (CB + 127) // 128) * wplan.ntaps
+    ns = best_nsplit(tiles_f32, 1024, max(1, M // 256))
     ws = torch.empty((ns, wplan.ntaps, CA, ldo), device=xa.device, dtype=torch.float32)
     S = rt.stream(xa)
     bsum = torch.empty((ns, ldo), device=xa.device, dtype=torch.float32) if gbias is not None else None

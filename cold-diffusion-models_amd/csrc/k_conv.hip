@@ -99,6 +99,8 @@ __global__ void __launch_bounds__(256, 4) conv_igemm_kernel(ConvArgs a) {
     const int nchunks = (a.Cin + BK - 1) / BK;
     const int niter = ph.ntaps * nchunks;
 
+    // Loads are unconditional (a load inside a divergent branch makes hipcc wait vmcnt(0) per load and
+    // serialises the prefetch): invalid elements read a clamped, always-valid address and are zeroed by a select.
     float4 ra[APASS], rb[BPASS];
     auto load_global = [&](int it) {
         const int tap = it / nchunks, c0 = (it - tap * nchunks) * BK;
@@ -107,10 +109,9 @@ __global__ void __launch_bounds__(256, 4) conv_igemm_kernel(ConvArgs a) {
         for (int p = 0; p < APASS; ++p) {
             const int iy = a_iy0[p] + dy, ix = a_ix0[p] + dx;
             const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && (c0 + a_col) < a.Cin;
-            if (ok)
-                ra[p] = *(const float4*)(X + ((a_img[p] + iy) * a.W + ix) * a.ldx + c0 + a_col);
-            else
-                ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* ptr = ok ? X + ((a_img[p] + iy) * a.W + ix) * a.ldx + c0 + a_col : X;
+            const float4 v = *(const float4*)ptr;
+            ra[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int p = 0; p < BPASS; ++p) {
@@ -120,13 +121,18 @@ __global__ void __launch_bounds__(256, 4) conv_igemm_kernel(ConvArgs a) {
                 if (!BT) {
                     const int k = idx / (BN / 4), n4 = idx - k * (BN / 4);
                     const int ci = c0 + k, co = tile_n * BN + n4 * 4;
-                    if (ci < a.Cin && co < a.Cout)
-                        rb[p] = *(const float4*)(Wt + ((long long)wi * a.Cin + ci) * a.ldw + co);
+                    const bool ok = ci < a.Cin && co < a.Cout;
+                    const float* ptr = ok ? Wt + ((long long)wi * a.Cin + ci) * a.ldw + co : Wt;
+                    const float4 v = *(const float4*)ptr;
+                    rb[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {
                     // B given as [N][K] (K contiguous): read 4 consecutive k of one output column
                     const int n = idx / (BK / 4), k4 = idx - n * (BK / 4);
                     const int ci = c0 + k4 * 4, co = tile_n * BN + n;
-                    if (ci < a.Cin && co < a.Cout) rb[p] = *(const float4*)(Wt + (long long)co * a.ldw + ci);
+                    const bool ok = ci < a.Cin && co < a.Cout;
+                    const float* ptr = ok ? Wt + (long long)co * a.ldw + ci : Wt;
+                    const float4 v = *(const float4*)ptr;
+                    rb[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         }
@@ -315,13 +321,13 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(WgradArgs a) {
             if (idx < AVEC) {
                 const int k = idx / (BMC / 4), c4 = idx - k * (BMC / 4);
                 const int m = m0 + k, ca = tile_a * BMC + c4 * 4;
-                if (m < m_hi && ca < a.CA) {
-                    const int qx = a_q[p][0], qy = a_q[p][1], b = a_q[p][2];
-                    const int ay = qy * a.sa + day, ax = qx * a.sa + dax;
-                    const int by = qy * a.sb + dby, bx = qx * a.sb + dbx;
-                    if (ay >= 0 && ay < a.HA && ax >= 0 && ax < a.WA && by >= 0 && by < a.HB && bx >= 0 && bx < a.WB)
-                        ra[p] = *(const float4*)(XA + (((long long)b * a.HA + ay) * a.WA + ax) * a.lda + ca);
-                }
+                const int qx = a_q[p][0], qy = a_q[p][1], b = a_q[p][2];
+                const int ay = qy * a.sa + day, ax = qx * a.sa + dax;
+                const int by = qy * a.sb + dby, bx = qx * a.sb + dbx;
+                const bool ok = m < m_hi && ca < a.CA && ay >= 0 && ay < a.HA && ax >= 0 && ax < a.WA && by >= 0 && by < a.HB && bx >= 0 && bx < a.WB;
+                const float* ptr = ok ? XA + (((long long)b * a.HA + ay) * a.WA + ax) * a.lda + ca : XA;   // unconditional load, select after
+                const float4 v = *(const float4*)ptr;
+                ra[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
                 advance(a_q[p]);
             }
         }
@@ -332,12 +338,12 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(WgradArgs a) {
             if (idx < BVEC) {
                 const int k = idx / (BNC / 4), c4 = idx - k * (BNC / 4);
                 const int m = m0 + k, cb = tile_b * BNC + c4 * 4;
-                if (m < m_hi && cb < a.CB) {
-                    const int qx = b_q[p][0], qy = b_q[p][1], b = b_q[p][2];
-                    const int by = qy * a.sb + dby, bx = qx * a.sb + dbx;
-                    if (by >= 0 && by < a.HB && bx >= 0 && bx < a.WB)
-                        rb[p] = *(const float4*)(XB + (((long long)b * a.HB + by) * a.WB + bx) * a.ldb + cb);
-                }
+                const int qx = b_q[p][0], qy = b_q[p][1], b = b_q[p][2];
+                const int by = qy * a.sb + dby, bx = qx * a.sb + dbx;
+                const bool ok = m < m_hi && cb < a.CB && by >= 0 && by < a.HB && bx >= 0 && bx < a.WB;
+                const float* ptr = ok ? XB + (((long long)b * a.HB + by) * a.WB + bx) * a.ldb + cb : XB;
+                const float4 v = *(const float4*)ptr;
+                rb[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
                 advance(b_q[p]);
                 if (do_bsum) {
                     bs_acc[p].x += rb[p].x; bs_acc[p].y += rb[p].y; bs_acc[p].z += rb[p].z; bs_acc[p].w += rb[p].w;

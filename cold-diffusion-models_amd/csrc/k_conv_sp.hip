@@ -120,30 +120,42 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_sp_kernel(SpArgs a) {
     const int nchunks = (a.Cin + BK - 1) / BK;
     const int niter = ph.ntaps * nchunks;
 
+    // Loads are UNCONDITIONAL (a load inside a divergent branch makes hipcc wait vmcnt(0) per load and
+    // serialises the whole prefetch): out-of-image / tail elements read a clamped, always-valid address and
+    // are zeroed by a select when they are written to LDS.  Weight rows/columns outside the tile are clamped
+    // too; they only feed output columns that are never stored.
     float4 ra[4];
-    uint4 rbh[2], rbl[2];
+    uint4 rbh0, rbh1, rbl0, rbl1;          // named registers (an array of HIP vector structs ends up in scratch here)
+    rbl0 = rbl1 = make_uint4(0u, 0u, 0u, 0u);
+    unsigned a_ok = 0;
+    int b_row[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int n = tile_n * BN + (tid >> 2) + 64 * p;
+        b_row[p] = n < a.Cout ? n : a.Cout - 1;
+    }
     auto load_global = [&](int it) {
         const int tap = it / nchunks, c0 = (it - tap * nchunks) * BK;
         const int dy = ph.dy[tap], dx = ph.dx[tap], wi = ph.wi[tap];
         const int tap_pix = dy * a.W + dx;
         const bool cok = (c0 + a_c4) < a.Cin;
         const float* xc = a.x + c0 + a_c4;
+        a_ok = 0;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const unsigned iy = (unsigned)(a_iy0[p] + dy), ix = (unsigned)(a_ix0[p] + dx);     // unsigned compare folds the >= 0 test
             const bool ok = iy < (unsigned)a.H && ix < (unsigned)a.W && cok;
-            ra[p] = ok ? *(const float4*)(xc + (size_t)(a_pix[p] + (unsigned)tap_pix) * (unsigned)a.ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* ptr = ok ? xc + (size_t)(a_pix[p] + (unsigned)tap_pix) * (unsigned)a.ldx : a.x;
+            ra[p] = *(const float4*)ptr;
+            a_ok |= (ok ? 1u : 0u) << p;
         }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int n = tile_n * BN + (tid >> 2) + 64 * p;
-            rbh[p] = make_uint4(0u, 0u, 0u, 0u);
-            rbl[p] = make_uint4(0u, 0u, 0u, 0u);
-            if (n < a.Cout) {
-                const long long off = ((long long)wi * a.Cout + n) * a.ldk + c0 + b_q * 8;
-                rbh[p] = *(const uint4*)(a.w_hi + off);
-                if (SPLIT > 1) rbl[p] = *(const uint4*)(a.w_lo + off);
-            }
+        const long long off0 = ((long long)wi * a.Cout + b_row[0]) * a.ldk + c0 + b_q * 8;
+        const long long off1 = ((long long)wi * a.Cout + b_row[1]) * a.ldk + c0 + b_q * 8;
+        rbh0 = *(const uint4*)(a.w_hi + off0);
+        rbh1 = *(const uint4*)(a.w_hi + off1);
+        if (SPLIT > 1) {
+            rbl0 = *(const uint4*)(a.w_lo + off0);
+            rbl1 = *(const uint4*)(a.w_lo + off1);
         }
     };
     auto store_lds = [&](int buf) {
@@ -151,11 +163,13 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_sp_kernel(SpArgs a) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             uint2 hi, lo;
+            const float keep = ((a_ok >> p) & 1u) ? 1.0f : 0.0f;       // loaded values are finite: zeroing by multiplication
+            const float4 v = make_float4(ra[p].x * keep, ra[p].y * keep, ra[p].z * keep, ra[p].w * keep);
             if (SPLIT > 1) {
-                cdf_split4(ra[p], hi, lo);
+                cdf_split4(v, hi, lo);
             } else {      // plain bf16 operands: round to nearest even
-                hi.x = cdf_f2bf(ra[p].x) | (cdf_f2bf(ra[p].y) << 16);
-                hi.y = cdf_f2bf(ra[p].z) | (cdf_f2bf(ra[p].w) << 16);
+                hi.x = cdf_f2bf(v.x) | (cdf_f2bf(v.y) << 16);
+                hi.y = cdf_f2bf(v.z) | (cdf_f2bf(v.w) << 16);
                 lo = hi;
             }
             const int off = ((tid >> 3) + 32 * p) * AS + a_c4;
@@ -163,11 +177,12 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_sp_kernel(SpArgs a) {
             if (SPLIT > 1) *(uint2*)(st + PLANE + off) = lo;
         }
         unsigned short* sb = st + NPL * PLANE;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int off = ((tid >> 2) + 64 * p) * AS + b_q * 8;
-            *(uint4*)(sb + off) = rbh[p];
-            if (SPLIT > 1) *(uint4*)(sb + PLANE + off) = rbl[p];
+        const int offb0 = (tid >> 2) * AS + b_q * 8, offb1 = ((tid >> 2) + 64) * AS + b_q * 8;
+        *(uint4*)(sb + offb0) = rbh0;
+        *(uint4*)(sb + offb1) = rbh1;
+        if (SPLIT > 1) {
+            *(uint4*)(sb + PLANE + offb0) = rbl0;
+            *(uint4*)(sb + PLANE + offb1) = rbl1;
         }
     };
 
@@ -322,23 +337,24 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_sp_kernel(SpWgradArgs a) {
     const int ca = tile_a * BC + c4, cb = tile_b * BC + c4;
 
     float4 ra[4], rb[4];
+    const int ca_l = ca < a.CA ? ca : 0, cb_l = cb < a.CB ? cb : 0;      // clamped (always readable) channel offsets
     auto load_global = [&](int it) {
         const int m0 = m_lo + it * BK;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int m = m0 + (tid >> 5) + 8 * p;
-            ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < m_hi) {
-                const int qx = q[p][0], qy = q[p][1], b = q[p][2];
-                const unsigned ay = (unsigned)(qy * a.sa + day), ax = (unsigned)(qx * a.sa + dax);
-                const unsigned by = (unsigned)(qy * a.sb + dby), bx = (unsigned)(qx * a.sb + dbx);
-                const bool bok = by < (unsigned)a.HB && bx < (unsigned)a.WB;
-                if (bok && ay < (unsigned)a.HA && ax < (unsigned)a.WA && ca < a.CA)
-                    ra[p] = *(const float4*)(a.xa + (((long long)b * a.HA + ay) * a.WA + ax) * a.lda + ca);
-                if (bok && cb < a.CB)
-                    rb[p] = *(const float4*)(a.xb + (((long long)b * a.HB + by) * a.WB + bx) * a.ldb + cb);
-            }
+            const int qx = q[p][0], qy = q[p][1], b = q[p][2];
+            const unsigned ay = (unsigned)(qy * a.sa + day), ax = (unsigned)(qx * a.sa + dax);
+            const unsigned by = (unsigned)(qy * a.sb + dby), bx = (unsigned)(qx * a.sb + dbx);
+            const bool bok = m < m_hi && by < (unsigned)a.HB && bx < (unsigned)a.WB;
+            const bool aok = bok && ay < (unsigned)a.HA && ax < (unsigned)a.WA && ca < a.CA;
+            const bool bok2 = bok && cb < a.CB;
+            // unconditional loads from clamped addresses, zero-select afterwards (no divergent branch around a load)
+            const float* pa = aok ? a.xa + (((long long)b * a.HA + ay) * a.WA + ax) * a.lda + ca_l : a.xa;
+            const float* pb = bok2 ? a.xb + (((long long)b * a.HB + by) * a.WB + bx) * a.ldb + cb_l : a.xb;
+            const float4 va = *(const float4*)pa, vb = *(const float4*)pb;
+            ra[p] = aok ? va : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[p] = bok2 ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
             q[p][0] += BK;
             while (q[p][0] >= a.QW) {
                 q[p][0] -= a.QW;
