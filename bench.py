@@ -82,8 +82,8 @@ class GemmTimer:
         return self.taps[key][0]
 
     def _flops(self, kind, a):
-        if kind == "conv_igemm":       # (x,ldx,w,ldw,y,ldy,B,H,W,Cin,OH,OW,Cout,QH,QW,os,is,nphase,desc,...,batch@32)
-            return 2.0 * a[6] * a[13] * a[14] * self._ntaps(a[18], a[17]) * a[9] * a[12] * a[32]
+        if kind == "conv_igemm":       # (x,ldx,w,ldw,y,ldy,B,H,W,Cin,OH,OW,Cout,QH,QW,os,is,nphase,desc,...,batch@32,...,batch2@36)
+            return 2.0 * a[6] * a[13] * a[14] * self._ntaps(a[18], a[17]) * a[9] * a[12] * a[32] * a[36]
         if kind == "conv_igemm_sp":    # (x,ldx,whi,wlo,ldk,y,ldy,B,H,W,Cin,OH,OW,Cout,QH,QW,os,is,nphase,desc,...)
             return 2.0 * a[7] * a[14] * a[15] * self._ntaps(a[19], a[18]) * a[10] * a[13]
         # conv_wgrad: (xa,lda,xb,ldb,ws,ldo,B,QH,QW,HA,WA,sa,HB,WB,sb,CA,CB,ntaps,desc,nsplit,batch,...)

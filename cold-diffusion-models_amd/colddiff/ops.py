@@ -124,7 +124,7 @@ def conv_gemm(plan, x, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None, p
     rt.lib().cdf_conv_gemm(P(x), ld_of(x), P(wp), wp.shape[-1], P(y), ld_of(y), B, plan.H, plan.W, Cin, plan.OH, plan.OW, Cout,
                            plan.QH, plan.QW, plan.os, plan.istride, plan.nphase, plan.desc, P(bias), P(sbias),
                            0 if sbias is None else sbias.stride(0), P(res), ldv(res), P(pre), ldv(pre), P(mul), ldv(mul),
-                           act, mul_mode, accumulate, 0, 1, 0, 0, 0, rt.stream(x))
+                           act, mul_mode, accumulate, 0, 1, 0, 0, 0, 1, 0, 0, 0, rt.stream(x))
     return y
 
 
@@ -249,10 +249,9 @@ def _head_gemm(x, x_off, w, out, out_off, B, n, heads, b_trans):
     L, S = rt.lib(), rt.stream(x)
     plan = _one_tap(n)
     ldx, ldo = ld_of(x), ld_of(out)
-    for h in range(heads):
-        L.cdf_conv_gemm(P(x) + 4 * (x_off + h * 32), ldx, P(w) + 4 * h * 1024, 32, P(out) + 4 * (out_off + h * 32), ldo, 1, 1, n, 32,
-                        1, n, 32, 1, n, 1, 1, 1, plan.desc, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1 if b_trans else 0, B,
-                        n * ldx, heads * 1024, n * ldo, S)
+    # one launch: blockIdx.z = b * heads + h
+    L.cdf_conv_gemm(P(x) + 4 * x_off, ldx, P(w), 32, P(out) + 4 * out_off, ldo, 1, 1, n, 32, 1, n, 32, 1, n, 1, 1, 1, plan.desc,
+                    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1 if b_trans else 0, B, n * ldx, heads * 1024, n * ldo, heads, 32, 1024, 32, S)
 
 
 def linattn_fwd(qkv, heads, scale):
@@ -351,7 +350,7 @@ def bgemm_nt(a, b):
     out = new_feat(a, nb, 1, n, m).view(nb, n, r4(m))
     plan = _one_tap(n)
     rt.lib().cdf_conv_gemm(P(a), a.stride(1), P(b), b.stride(1), P(out), r4(m), 1, 1, n, K, 1, n, m, 1, n, 1, 1, 1, plan.desc,
-                           0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, nb, a.stride(0), b.stride(0), n * r4(m), rt.stream(a))
+                           0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, nb, a.stride(0), b.stride(0), n * r4(m), 1, 0, 0, 0, rt.stream(a))
     return out
 
 
@@ -363,7 +362,7 @@ def bgemm_nn(a, b, K=None):
     out = new_feat(a, nb, 1, n, m).view(nb, n, r4(m))
     plan = _one_tap(n)
     rt.lib().cdf_conv_gemm(P(a), a.stride(1), P(b), b.stride(1), P(out), r4(m), 1, 1, n, K, 1, n, m, 1, n, 1, 1, 1, plan.desc,
-                           0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, nb, a.stride(0), b.stride(0), n * r4(m), rt.stream(a))
+                           0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, nb, a.stride(0), b.stride(0), n * r4(m), 1, 0, 0, 0, rt.stream(a))
     return out
 
 

@@ -43,7 +43,9 @@ struct ConvArgs {
     int mul_mode;    // 0 none, 1 v*=gelu'(mul), 2 v*=silu'(mul), 3 v*=mul
     int accumulate;  // y += v
     int nphase;
-    long long x_bs, w_bs, y_bs;  // blockIdx.z batch strides (elements)
+    long long x_bs, w_bs, y_bs;     // blockIdx.z = outer*batch2 + inner: outer batch strides (elements)
+    long long x_bs2, w_bs2, y_bs2;  // inner batch strides (e.g. attention heads)
+    int batch2;
     ConvPhase ph[4];
 };
 
@@ -73,9 +75,10 @@ __global__ void __launch_bounds__(256, 4) conv_igemm_kernel(ConvArgs a) {
     const int tile = cdf_xcd_swizzle(blockIdx.x, tiles_m * tiles_n);
     const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
     const ConvPhase& ph = a.ph[blockIdx.y];
-    const float* X = a.x + (long long)blockIdx.z * a.x_bs;
-    const float* Wt = a.w + (long long)blockIdx.z * a.w_bs;
-    float* Y = a.y + (long long)blockIdx.z * a.y_bs;
+    const int zo = blockIdx.z / a.batch2, zi = blockIdx.z - zo * a.batch2;
+    const float* X = a.x + (long long)zo * a.x_bs + (long long)zi * a.x_bs2;
+    const float* Wt = a.w + (long long)zo * a.w_bs + (long long)zi * a.w_bs2;
+    float* Y = a.y + (long long)zo * a.y_bs + (long long)zi * a.y_bs2;
 
     // ---- A-operand row bookkeeping ----------------------------------------------------------
     const int a_col = (tid & 3) * 4;
@@ -529,14 +532,14 @@ extern "C" int cdf_conv_gemm(const float* x, int ldx, const float* w, int ldw, f
                              const int* phase_desc, const float* bias, const float* sbias, int ld_sbias,
                              const float* res, int ldr, float* pre, int ldp, const float* mul, int ldm, int act,
                              int mul_mode, int accumulate, int b_trans, int batch, long long x_bs, long long w_bs,
-                             long long y_bs, void* stream) {
+                             long long y_bs, int batch2, long long x_bs2, long long w_bs2, long long y_bs2, void* stream) {
     int rc;
     if ((rc = check_feat("cdf_conv_gemm(x)", x, ldx, Cin))) return rc;
     if ((rc = check_feat("cdf_conv_gemm(y)", y, 4, 0))) return rc;
     CDF_REQUIRE(w && (((uintptr_t)w) & 15) == 0 && ldw % 4 == 0, "cdf_conv_gemm: weights must be 16B aligned, ldw%%4==0");
     CDF_REQUIRE(ldy >= Cout, "cdf_conv_gemm: ldy < Cout");
     CDF_REQUIRE(nphase >= 1 && nphase <= 4 && phase_desc, "cdf_conv_gemm: nphase must be 1..4");
-    CDF_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && QH > 0 && QW > 0 && batch >= 1, "cdf_conv_gemm: bad shape");
+    CDF_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && QH > 0 && QW > 0 && batch >= 1 && batch2 >= 1, "cdf_conv_gemm: bad shape");
     CDF_REQUIRE(!b_trans || (Cin % 4 == 0), "cdf_conv_gemm: b_trans needs K %% 4 == 0");
     CDF_REQUIRE(!mul_mode || mul, "cdf_conv_gemm: mul_mode without mul tensor");
     ConvArgs a;
@@ -545,6 +548,8 @@ extern "C" int cdf_conv_gemm(const float* x, int ldx, const float* w, int ldw, f
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.QH = QH; a.QW = QW;
     a.os = os; a.is = is; a.act = act; a.mul_mode = mul_mode; a.accumulate = accumulate; a.nphase = nphase;
     a.x_bs = x_bs; a.w_bs = w_bs; a.y_bs = y_bs;
+    a.x_bs2 = x_bs2; a.w_bs2 = w_bs2; a.y_bs2 = y_bs2; a.batch2 = batch2;
+    batch *= batch2;
     // phase_desc: per phase [oy, ox, ntaps, (dy, dx, wi) * ntaps]
     const int* pd = phase_desc;
     for (int p = 0; p < nphase; ++p) {

@@ -125,23 +125,34 @@ __global__ void __launch_bounds__(256) dwconv7_wgrad_partial_kernel(const float*
 }
 
 // dw[c*49 + tap] (+)= sum_{b,chunk} part ; dbias[c] (+)= sum part[..][49] ; dsb[b][c] = sum_chunk part[b][..][49]
+// grid = (ceil(C/64), 50 taps); block 256 = 4 partial lanes x 64 channels (lanes split the b*nchunk partials)
 __global__ void dwconv7_wgrad_final_kernel(const float* part, int B, int nchunk, int C, float* dw, float* dbias,
                                            float* dsb, int ld_dsb, int accumulate) {
-    const int n = (DW_TAPS + 1) * C;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int t = i / C, c = i - t * C;
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) {
-            float sb = 0.f;
-            for (int k = 0; k < nchunk; ++k) sb += part[(((long long)b * nchunk + k) * (DW_TAPS + 1) + t) * C + c];
-            if (t == DW_TAPS && dsb) dsb[(long long)b * ld_dsb + c] = sb;
-            s += sb;
-        }
+    __shared__ float red[4][64];
+    const int l = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + l, t = blockIdx.y;
+    const int n = B * nchunk;
+    float s = 0.f;
+    if (c < C)
+        for (int i = rl; i < n; i += 4) s += part[((long long)i * (DW_TAPS + 1) + t) * C + c];
+    red[rl][l] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const float tot = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
         if (t < DW_TAPS) {
             float* dst = dw + (long long)c * DW_TAPS + t;
-            *dst = accumulate ? *dst + s : s;
+            *dst = accumulate ? *dst + tot : tot;
         } else if (dbias) {
-            dbias[c] = accumulate ? dbias[c] + s : s;
+            dbias[c] = accumulate ? dbias[c] + tot : tot;
+        }
+    }
+    if (t == DW_TAPS && dsb) {          // per-sample time-bias gradient: sum over the chunks of each sample
+        __syncthreads();
+        for (int b = rl; b < B; b += 4) {
+            if (c < C) {
+                float sb = 0.f;
+                for (int k = 0; k < nchunk; ++k) sb += part[(((long long)b * nchunk + k) * (DW_TAPS + 1) + DW_TAPS) * C + c];
+                dsb[(long long)b * ld_dsb + c] = sb;
+            }
         }
     }
 }
@@ -175,6 +186,6 @@ extern "C" int cdf_dwconv7_wgrad(const float* x, int ldx, const float* dy, int l
     CDF_REQUIRE(x && dy && dw && ws, "cdf_dwconv7_wgrad: null pointer");
     const int nchunk = cdf_dwconv7_wgrad_nchunk(H), rpc = cdf_cdiv(H, nchunk);
     CDF_LAUNCH(dwconv7_wgrad_partial_kernel, dim3(cdf_cdiv(C, 64), nchunk, B), dim3(256), 0, CDF_S, x, ldx, dy, lddy, ws, H, W, C, rpc);
-    CDF_LAUNCH(dwconv7_wgrad_final_kernel, dim3(cdf_cdiv(50 * C, 256)), dim3(256), 0, CDF_S, (const float*)ws, B, nchunk, C, dw, dbias, dsb, ld_dsb, accumulate);
+    CDF_LAUNCH(dwconv7_wgrad_final_kernel, dim3(cdf_cdiv(C, 64), DW_TAPS + 1), dim3(256), 0, CDF_S, (const float*)ws, B, nchunk, C, dw, dbias, dsb, ld_dsb, accumulate);
     return cdf_check_launch("dwconv7_wgrad");
 }

@@ -96,12 +96,14 @@ int cdf_nhwc_to_nchw(const float* x, float* y, const float* add, int B, int C, i
  *   or, with b_trans, a plain [Cout][ldw>=Cin] matrix (one tap).  Epilogue, in order:
  *   v = acc + bias[co] + sbias[b][co]; pre = v; v = act(v) (1 GELU, 2 SiLU);
  *   v *= {1: gelu'(mul), 2: silu'(mul), 3: mul}; v += res; accumulate ? y += v : y = v.
- *   batch > 1 runs independent GEMMs (blockIdx.z) with element strides x_bs / w_bs / y_bs. */
+ *   batch * batch2 independent GEMMs run in one launch (blockIdx.z = outer*batch2 + inner) with element
+ *   strides x_bs / w_bs / y_bs (outer) and x_bs2 / w_bs2 / y_bs2 (inner, e.g. attention heads). */
 int cdf_conv_gemm(const float* x, int ldx, const float* w, int ldw, float* y, int ldy, int B, int H, int W, int Cin,
                   int OH, int OW, int Cout, int QH, int QW, int os, int is, int nphase, const int* phase_desc,
                   const float* bias, const float* sbias, int ld_sbias, const float* res, int ldr, float* pre, int ldp,
                   const float* mul, int ldm, int act, int mul_mode, int accumulate, int b_trans, int batch,
-                  long long x_bs, long long w_bs, long long y_bs, void* stream);
+                  long long x_bs, long long w_bs, long long y_bs, int batch2, long long x_bs2, long long w_bs2,
+                  long long y_bs2, void* stream);
 
 /* cdf_conv_wgrad: ws[z][tap][ca][cb] = sum_{m in split z} XA[pixA(m,tap)][ca] * XB[pixB(m,tap)][cb]
  *   m = (b,qy,qx); pixA = (qy*sa+day, qx*sa+dax) in HAxWA, pixB likewise; tap_desc = (day,dax,dby,dbx) x ntaps.

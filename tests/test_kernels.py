@@ -180,7 +180,7 @@ def _gemm(be, plan, x, w, B, Cin, Cout, bias=None, sbias=None, res=None, pre=Non
     ld = lambda t_: 0 if t_ is None else t_.shape[-1]
     be.L.cdf_conv_gemm(P(x), x.shape[-1], P(w), w.shape[-1], P(y), y.shape[-1], B, plan.H, plan.W, Cin, plan.OH, plan.OW, Cout,
                        plan.QH, plan.QW, plan.os, plan.istride, plan.nphase, plan.desc, P(bias), P(sbias), ld(sbias), P(res), ld(res),
-                       P(pre), ld(pre), P(mul), ld(mul), act, mul_mode, acc, 0, 1, 0, 0, 0, be.stream())
+                       P(pre), ld(pre), P(mul), ld(mul), act, mul_mode, acc, 0, 1, 0, 0, 0, 1, 0, 0, 0, be.stream())
     return y
 
 
@@ -268,7 +268,7 @@ def test_conv_epilogue_and_batched(be):
     one = cd.conv_fwd(1, n, 1, 1, 1, 0, 0, 0, 0)
     qd, kd = be.to(q), be.to(k)
     be.L.cdf_conv_gemm(P(qd), C, P(kd), C, P(S), r4(n), 1, 1, n, C, 1, n, n, 1, n, 1, 1, 1, one.desc, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                       0, 0, 0, 1, nb, n * C, n * C, n * r4(n), be.stream())
+                       0, 0, 0, 1, nb, n * C, n * C, n * r4(n), 1, 0, 0, 0, be.stream())
     assert err(S[..., :n], q @ k.transpose(1, 2)) <= 1e-5
     # wgrad kernel as batched A^T B:  dv[b] = P[b]^T dO[b]
     Pm, dO = torch.randn(nb, n, r4(n)), torch.randn(nb, n, C)

@@ -21,7 +21,7 @@ for (Cin,Cout,H,k) in shapes:
     if only and only != f"{Cin}-{Cout}-{H}": continue
     x = torch.randn(B,H,H,r4(Cin),device=dev); w = torch.randn(k*k,Cin,r4(Cout),device=dev)*0.05; y = torch.empty(B,H,H,r4(Cout),device=dev)
     p = cd.conv_fwd(H,H,k,k,1,k//2,k//2,k//2,k//2)
-    ms = timeit(lambda: L.cdf_conv_gemm(P(x),x.shape[-1],P(w),w.shape[-1],P(y),y.shape[-1],B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,0,0,0,0,0,0,0,0,0,0,0,0,0,1,0,0,0,S()))
+    ms = timeit(lambda: L.cdf_conv_gemm(P(x),x.shape[-1],P(w),w.shape[-1],P(y),y.shape[-1],B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,0,0,0,0,0,0,0,0,0,0,0,0,0,1,0,0,0,1,0,0,0,S()))
     fl = 2.0*B*H*H*Cin*Cout*k*k
     print(f"fwd   {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF", flush=True)
     if os.environ.get("KB_WGRAD","1") == "1":

@@ -49,7 +49,7 @@ def conv_bench(B, Cin, Cout, H, k, tag):
     y = torch.empty(B, H, H, r4(Cout), device=dev)
     p = cd.conv_fwd(H, H, k, k, 1, k // 2, k // 2, k // 2, k // 2)
     fn = lambda: L.cdf_conv_gemm(P(x), x.shape[-1], P(w), w.shape[-1], P(y), y.shape[-1], B, H, H, Cin, H, H, Cout, H, H, 1, 1, 1, p.desc,
-                                 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, S())
+                                 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, S())
     ms = timeit(fn)
     fl = 2.0 * B * H * H * Cin * Cout * k * k
     rec(f"conv{k}x{k}_fwd_{tag}_B{B}_{Cin}->{Cout}@{H}", ms, flops=fl, bytes_=4.0 * B * H * H * (Cin + Cout))
