@@ -451,19 +451,38 @@ __global__ void pack_weight_kernel(const float* src, float* dst, int T, int R, i
         dst[i] = c < C ? src[c * s_c + r * s_r + t * s_t] : 0.f;
     }
 }
+// block 256 = 4 slab lanes x 64 consecutive output elements (element index runs over [T][R][C], C fastest)
 __global__ void unpack_reduce_kernel(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc,
                                      long long s_t, long long s_r, long long s_c, int accumulate) {
+    __shared__ float red[4][64];
     const long long n = (long long)T * R * C;
     const long long slab = (long long)T * R * ldc;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const long long tr = i / C;
-        const int r = (int)(tr % R), t = (int)(tr / R);
-        const float* p = ws + ((long long)t * R + r) * ldc + c;
-        float s = 0.f;
-        for (int z = 0; z < nsplit; ++z) s += p[z * slab];
-        float* dst = g + c * s_c + r * s_r + t * s_t;
-        *dst = accumulate ? *dst + s : s;
+    const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    for (long long base = (long long)blockIdx.x * 64; base < n; base += (long long)gridDim.x * 64) {
+        const long long i = base + l;
+        float s0 = 0.f, s1 = 0.f;
+        int c = 0, r = 0, t = 0;
+        if (i < n) {
+            c = (int)(i % C);
+            const long long tr = i / C;
+            r = (int)(tr % R);
+            t = (int)(tr / R);
+            const float* p = ws + ((long long)t * R + r) * ldc + c;
+            int z = rl;
+            for (; z + 4 < nsplit; z += 8) {          // two independent chains per lane
+                s0 += p[z * slab];
+                s1 += p[(z + 4) * slab];
+            }
+            if (z < nsplit) s0 += p[z * slab];
+        }
+        __syncthreads();
+        red[rl][l] = s0 + s1;
+        __syncthreads();
+        if (rl == 0 && i < n) {
+            const float tot = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+            float* dst = g + c * s_c + r * s_r + t * s_t;
+            *dst = accumulate ? *dst + tot : tot;
+        }
     }
 }
 
@@ -639,7 +658,7 @@ extern "C" int cdf_pack_weight(const float* src, float* dst, int T, int R, int C
 extern "C" int cdf_unpack_reduce(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t,
                                  long long s_r, long long s_c, int accumulate, void* stream) {
     CDF_REQUIRE(ws && g && nsplit > 0 && T > 0 && R > 0 && C > 0 && ldc >= C, "cdf_unpack_reduce: bad args");
-    CDF_LAUNCH(unpack_reduce_kernel, dim3(ew_grid2((long long)T * R * C)), dim3(256), 0, CDF_S, ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate);
+    CDF_LAUNCH(unpack_reduce_kernel, dim3(ew_grid2((long long)T * R * C * 4)), dim3(256), 0, CDF_S, ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate);
     return cdf_check_launch("unpack_reduce");
 }
 
