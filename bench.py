@@ -56,20 +56,23 @@ def build_workload(args, device):
 class GemmTimer:
     """HIP-event timing (on the launch stream) of every MFMA GEMM launch of the step with its
     ALGORITHMIC FLOPs (zero-padded taps / channels are not counted):
-      conv_igemm_sp  cdf_conv_gemm_bf16  dense conv fwd + dgrad, bf16x3 split-precision MFMA
-      conv_igemm     cdf_conv_gemm       exact-fp32 MFMA (short-K 1x1 convs, K=32 attention GEMMs, linears)
-      conv_wgrad     cdf_conv_wgrad      weight gradients, exact-fp32 MFMA
+      conv_igemm_sp   cdf_conv_gemm_bf16(x)   dense conv fwd + dgrad, bf16x3 split-precision MFMA
+      conv_wgrad_sp   cdf_conv_wgrad_bf16(x)  weight gradients of the wide layers, bf16x3 MFMA
+      conv_igemm      cdf_conv_gemm           exact-fp32 MFMA (short-K 1x1 convs, K=32 attention GEMMs, linears)
+      conv_wgrad      cdf_conv_wgrad          weight gradients of the thin layers, exact-fp32 MFMA
     """
-    PEAK = {"conv_igemm_sp": 2500.0, "conv_igemm": 157.3, "conv_wgrad": 157.3}   # dense TFLOP/s, MI355X_MICROARCH.md
-    DTYPE = {"conv_igemm_sp": "bf16 MFMA, 3 MFMAs per product (hi/lo split operands, fp32 accumulate)",
-             "conv_igemm": "f32 MFMA", "conv_wgrad": "f32 MFMA"}
+    PEAK = {"conv_igemm_sp": 2500.0, "conv_wgrad_sp": 2500.0, "conv_igemm": 157.3, "conv_wgrad": 157.3}   # dense TFLOP/s, MI355X_MICROARCH.md
+    _SP = "bf16 MFMA, 3 MFMAs per product (hi/lo split operands, fp32 accumulate)"
+    DTYPE = {"conv_igemm_sp": _SP, "conv_wgrad_sp": _SP, "conv_igemm": "f32 MFMA", "conv_wgrad": "f32 MFMA"}
+    ENTRY = {"cdf_conv_gemm": "conv_igemm", "cdf_conv_gemm_bf16": "conv_igemm_sp", "cdf_conv_gemm_bf16x": "conv_igemm_sp",
+             "cdf_conv_wgrad": "conv_wgrad", "cdf_conv_wgrad_bf16": "conv_wgrad_sp", "cdf_conv_wgrad_bf16x": "conv_wgrad_sp"}
 
     def __init__(self, lib):
         self.lib, self.enabled, self.records, self.taps = lib, False, {k: [] for k in self.PEAK}, {}
-        self.orig = {"conv_igemm": lib.cdf_conv_gemm, "conv_igemm_sp": lib.cdf_conv_gemm_bf16, "conv_wgrad": lib.cdf_conv_wgrad}
-        lib.cdf_conv_gemm = lambda *a: self._call("conv_igemm", a)
-        lib.cdf_conv_gemm_bf16 = lambda *a: self._call("conv_igemm_sp", a)
-        lib.cdf_conv_wgrad = lambda *a: self._call("conv_wgrad", a)
+        self.orig = {}
+        for entry in self.ENTRY:
+            self.orig[entry] = getattr(lib, entry)
+            setattr(lib, entry, (lambda e: lambda *a: self._call(e, a))(entry))
 
     def _ntaps(self, desc, nphase):
         key = id(desc)
@@ -82,21 +85,27 @@ class GemmTimer:
         return self.taps[key][0]
 
     def _flops(self, kind, a):
-        if kind == "conv_igemm":       # (x,ldx,w,ldw,y,ldy,B,H,W,Cin,OH,OW,Cout,QH,QW,os,is,nphase,desc,...,batch@32,...,batch2@36)
+        if kind == "cdf_conv_gemm_bf16x":   # (xhi,xlo,ldx,zero,whi,wlo,ldk,y,ldy,B,H,W,Cin,OH,OW,Cout,QH,QW,os,is,nphase,desc,...)
+            return 2.0 * a[9] * a[16] * a[17] * self._ntaps(a[21], a[20]) * a[12] * a[15]
+        if kind == "cdf_conv_wgrad_bf16x":  # (ahi,alo,lda,bhi,blo,ldb,zero,ws,ldo,B,QH,QW,HA,WA,sa,HB,WB,sb,CA,CB,ntaps,...)
+            return 2.0 * a[9] * a[10] * a[11] * a[18] * a[19] * a[20]
+        if kind == "cdf_conv_wgrad_bf16":   # (xa,lda,xb,ldb,ws,ldo,B,QH,QW,HA,WA,sa,HB,WB,sb,CA,CB,ntaps,...)
+            return 2.0 * a[6] * a[7] * a[8] * a[15] * a[16] * a[17]
+        if kind == "cdf_conv_gemm":       # (x,ldx,w,ldw,y,ldy,B,H,W,Cin,OH,OW,Cout,QH,QW,os,is,nphase,desc,...,batch@32,...,batch2@36)
             return 2.0 * a[6] * a[13] * a[14] * self._ntaps(a[18], a[17]) * a[9] * a[12] * a[32] * a[36]
-        if kind == "conv_igemm_sp":    # (x,ldx,whi,wlo,ldk,y,ldy,B,H,W,Cin,OH,OW,Cout,QH,QW,os,is,nphase,desc,...)
+        if kind == "cdf_conv_gemm_bf16":    # (x,ldx,whi,wlo,ldk,y,ldy,B,H,W,Cin,OH,OW,Cout,QH,QW,os,is,nphase,desc,...)
             return 2.0 * a[7] * a[14] * a[15] * self._ntaps(a[19], a[18]) * a[10] * a[13]
         # conv_wgrad: (xa,lda,xb,ldb,ws,ldo,B,QH,QW,HA,WA,sa,HB,WB,sb,CA,CB,ntaps,desc,nsplit,batch,...)
         return 2.0 * a[6] * a[7] * a[8] * a[15] * a[16] * a[17] * a[20]
 
-    def _call(self, kind, a):
+    def _call(self, entry, a):
         if not self.enabled:
-            return self.orig[kind](*a)
+            return self.orig[entry](*a)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        r = self.orig[kind](*a)
+        r = self.orig[entry](*a)
         e1.record()
-        self.records[kind].append((e0, e1, self._flops(kind, a)))
+        self.records[self.ENTRY[entry]].append((e0, e1, self._flops(entry, a)))
         return r
 
     def summary(self, steps, elapsed_s):

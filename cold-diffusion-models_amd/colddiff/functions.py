@@ -34,16 +34,26 @@ def _conv_plans(kind, H, W, k, stride, pad):
     return cd.convT_fwd(H, W, k, k, stride, pad[0]), cd.convT_dgrad(H, W, k, k, stride, pad[0]), cd.convT_wgrad(H, W, k, k, stride, pad[0])
 
 
-def conv_forward(x, Cin, weight, bias, kind="conv", stride=1, pad=None, **epi):
-    """x [B,H,W,*] -> conv(x) with the weight in its PyTorch layout ([Cout,Cin,k,k] or [Cin,Cout,k,k])."""
+def conv_forward(x, Cin, weight, bias, kind="conv", stride=1, pad=None, xs=None, **epi):
+    """x [B,H,W,*] -> conv(x) with the weight in its PyTorch layout ([Cout,Cin,k,k] or [Cin,Cout,k,k]).
+    xs: optional pre-split (hi, lo) bf16 planes of x (see want_presplit)."""
     k = weight.shape[-1]
     if pad is None:
         pad = (k // 2,) * 4
     _, H, W, _ = x.shape
     plan = _conv_plans(kind, H, W, k, stride, pad)[0]
     Cout = weight.shape[0] if kind == "conv" else weight.shape[1]
-    wp = ops.packed(weight, ("conv_fwd" if kind == "conv" else "convT_fwd") + _sp_suffix(Cin * k * k, Cout))
+    sfx = _sp_suffix(Cin * k * k, Cout)
+    wp = ops.packed(weight, ("conv_fwd" if kind == "conv" else "convT_fwd") + sfx)
+    if xs is not None and sfx:
+        return ops.conv_gemm_presplit(plan, xs, Cin, wp, Cout, bias=bias, **epi)
     return ops.conv_gemm(plan, x, Cin, wp, Cout, bias=bias, **epi)
+
+
+def want_presplit(Cin, Cout, k):
+    """True when a conv's operands should be split once up front (bf16x3 mode, GEMM routed to the
+    split-precision kernels, channel counts vector-friendly)."""
+    return rt.precision == "bf16x3" and Cin % 8 == 0 and Cout % 8 == 0 and bool(_sp_suffix(Cin * k * k, Cout)) and bool(_sp_suffix(Cout * k * k, Cin))
 
 
 def _sp_suffix(K, N):
@@ -54,7 +64,7 @@ def _sp_suffix(K, N):
 
 
 def conv_backward(x, Cin, dy, weight, bias, kind="conv", stride=1, pad=None, need_dx=True, dx=None, dx_accumulate=0, mul=None,
-                  mul_mode=0):
+                  mul_mode=0, xs=None, dys=None):
     """Gradients of conv_forward: returns dx (optionally fused with an activation-gradient multiply),
     accumulates into weight.grad / bias.grad."""
     k = weight.shape[-1]
@@ -70,12 +80,16 @@ def conv_backward(x, Cin, dy, weight, bias, kind="conv", stride=1, pad=None, nee
         Cout = weight.shape[1]
         s_r, s_c = Cout * KK, KK
     fuse_bias = bias is not None and kind == "conv"        # dY rows stream through the wgrad kernel exactly once
-    ops.wgrad_into(ops.grad_of(weight), pw, x, Cin, dy, Cout, 1, s_r, s_c, gbias=ops.grad_of(bias) if fuse_bias else None)
+    ops.wgrad_into(ops.grad_of(weight), pw, x, Cin, dy, Cout, 1, s_r, s_c, gbias=ops.grad_of(bias) if fuse_bias else None,
+                   xa_s=xs, xb_s=dys)
     if bias is not None and not fuse_bias:
         ops.colsum_into(ops.grad_of(bias), dy, Cout)
     if not need_dx:
         return None
-    wd = ops.packed(weight, ("conv_dgrad" if kind == "conv" else "convT_dgrad") + _sp_suffix(Cout * KK, Cin))
+    sfx = _sp_suffix(Cout * KK, Cin)
+    wd = ops.packed(weight, ("conv_dgrad" if kind == "conv" else "convT_dgrad") + sfx)
+    if dys is not None and sfx:
+        return ops.conv_gemm_presplit(pd, dys, Cout, wd, Cin, y=dx, mul=mul, mul_mode=mul_mode, accumulate=dx_accumulate)
     return ops.conv_gemm(pd, dy, Cout, wd, Cin, y=dx, mul=mul, mul_mode=mul_mode, accumulate=dx_accumulate)
 
 
@@ -226,24 +240,31 @@ class ConvNextBlockFn(torch.autograd.Function):
             hn, mean, rstd = h, None, None
         c1, c2 = m.net[1], m.net[3]
         B, H, W, _ = x.shape
-        pre = ops.new_feat(x, B, H, W, c1.weight.shape[0]) if grad_on else None
-        a = conv_forward(hn, dim, c1.weight, c1.bias, act=ACT_GELU, pre=pre)
+        mid = c1.weight.shape[0]
+        pre = ops.new_feat(x, B, H, W, mid) if grad_on else None
+        # operands that feed several GEMMs (fwd now, dgrad/wgrad later, every N tile) are split into bf16 hi/lo once
+        hn_s = ops.split_bf16(hn) if want_presplit(dim, mid, 3) else None
+        a = conv_forward(hn, dim, c1.weight, c1.bias, act=ACT_GELU, pre=pre, xs=hn_s)
         if m.has_res_conv:
             res = conv_forward(x, dim, m.res_conv.weight, m.res_conv.bias)
         else:
             res = x
-        o = conv_forward(a, c1.weight.shape[0], c2.weight, c2.bias, res=res)
+        a_s = ops.split_bf16(a) if want_presplit(mid, dim_out, 3) else None
+        o = conv_forward(a, mid, c2.weight, c2.bias, res=res, xs=a_s)
         ctx.m = m
         ctx.has_t = tbias is not None
-        ctx.save_for_backward(x, h, hn if m.has_norm else None, mean, rstd, pre, a)
+        ctx.split = (hn_s is not None, a_s is not None)
+        ctx.save_for_backward(x, h, hn if m.has_norm else None, mean, rstd, pre, a, *(hn_s or (None, None)), *(a_s or (None, None)))
         return o
 
     @staticmethod
     def backward(ctx, do):
-        x, h, hn, mean, rstd, pre, a = ctx.saved_tensors
+        x, h, hn, mean, rstd, pre, a, hn_hi, hn_lo, a_hi, a_lo = ctx.saved_tensors
         m = ctx.m
         if hn is None:
             hn = h
+        hn_s = (hn_hi, hn_lo) if ctx.split[0] else None
+        a_s = (a_hi, a_lo) if ctx.split[1] else None
         dim = m.dim
         c1, c2 = m.net[1], m.net[3]
         mid = c1.weight.shape[0]
@@ -255,8 +276,10 @@ class ConvNextBlockFn(torch.autograd.Function):
         elif need_dx:
             dx = ops.copy_feat(do)
         # conv2 -> (fused GELU') -> conv1
-        dpre = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=1)
-        dhn = conv_backward(hn, dim, dpre, c1.weight, c1.bias)
+        do_s = ops.split_bf16(do) if a_s is not None else None
+        dpre = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=1, xs=a_s, dys=do_s)
+        dpre_s = ops.split_bf16(dpre) if hn_s is not None else None
+        dhn = conv_backward(hn, dim, dpre, c1.weight, c1.bias, xs=hn_s, dys=dpre_s)
         if m.has_norm:
             dh = ops.layernorm_bwd(dhn, h, m.net[0].g, m.net[0].b, mean, rstd)
         else:

@@ -4,6 +4,8 @@ Feature maps are NHWC views ``[B, H, W, C]`` with unit channel stride and an arb
 (``t.stride(-2)``), so a channel slice of a wider buffer is a valid operand.  Tensors whose logical
 channel count is not a multiple of 4 are stored padded to 4 with zero pad channels.
 """
+import weakref
+
 import torch
 
 from . import convdesc as cd
@@ -48,8 +50,9 @@ def packed(param, kind):
            lin_fwd   [1][K][N]                                        (weight [N,K])
     """
     key = (param.data_ptr(), param._version, rt.weights_epoch, kind)
-    hit = _pack_cache.get((id(param), kind))
-    if hit is not None and hit[0] == key:
+    slot = (id(param), kind)
+    hit = _pack_cache.get(slot)
+    if hit is not None and hit[0] == key and hit[2]() is param:   # the weakref guards against id()/address reuse by a new tensor
         return hit[1]
     w = param.detach()
     if kind in ("conv_fwd", "conv_dgrad"):
@@ -85,7 +88,7 @@ def packed(param, kind):
         out = _pack(w, 1, K, N, 0, 1, K)
     else:
         raise ValueError(kind)
-    _pack_cache[(id(param), kind)] = (key, out)
+    _pack_cache[slot] = (key, out, weakref.ref(param, lambda _r, slot=slot: _pack_cache.pop(slot, None)))
     return out
 
 
@@ -108,6 +111,43 @@ def grad_of(p):
 # ---------------------------------------------------------------------------------------------------
 # conv / linear primitives
 # ---------------------------------------------------------------------------------------------------
+_zero_pages = {}
+
+
+def zero_page(device):
+    z = _zero_pages.get(str(device))
+    if z is None:
+        z = torch.zeros(64, device=device, dtype=torch.float32)
+        _zero_pages[str(device)] = z
+    return z
+
+
+def split_bf16(x):
+    """fp32 feature map [.., C] (any pixel pitch) -> (hi, lo) bf16 planes, contiguous, pitch roundup8(C)."""
+    C = x.shape[-1]
+    ld = (C + 7) // 8 * 8
+    f = torch.zeros if ld != C else torch.empty
+    hi = f(x.shape[:-1] + (ld,), device=x.device, dtype=torch.int16)
+    lo = f(x.shape[:-1] + (ld,), device=x.device, dtype=torch.int16)
+    rt.lib().cdf_split_bf16(P(x), ld_of(x), P(hi), P(lo), ld, x.numel() // C, C, rt.stream(x))
+    return hi, lo
+
+
+def conv_gemm_presplit(plan, xs, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None, pre=None, mul=None, act=0, mul_mode=0,
+                       accumulate=0):
+    """conv_gemm with the activation already split into bf16 hi/lo planes (xs) and (hi, lo) packed weights (wp)."""
+    hi, lo = xs
+    B = hi.shape[0]
+    if y is None:
+        y = new_feat(hi, B, plan.OH, plan.OW, Cout)
+    ldv = lambda t: 0 if t is None else ld_of(t)
+    rt.lib().cdf_conv_gemm_bf16x(P(hi), P(lo), hi.shape[-1], P(zero_page(hi.device)), P(wp[0]), P(wp[1]), wp[0].shape[-1], P(y), ld_of(y),
+                                 B, plan.H, plan.W, Cin, plan.OH, plan.OW, Cout, plan.QH, plan.QW, plan.os, plan.istride, plan.nphase,
+                                 plan.desc, P(bias), P(sbias), 0 if sbias is None else sbias.stride(0), P(res), ldv(res), P(pre),
+                                 ldv(pre), P(mul), ldv(mul), act, mul_mode, accumulate, rt.stream(hi))
+    return y
+
+
 def conv_gemm(plan, x, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None, pre=None, mul=None, act=0, mul_mode=0,
               accumulate=0):
     B = x.shape[0]
@@ -139,13 +179,27 @@ def best_nsplit(tiles, slots, max_ns):
     return best
 
 
-def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None):
+def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None, xa_s=None, xb_s=None):
     """gparam[c*s_c + r*s_r + t*s_t] += sum_m xa[pixA(m,t)][r] * xb[pixB(m,t)][c]
     gbias (optional, only when xb = dY is visited row by row): gbias[c] += sum_m xb[m][c], fused into the same pass."""
     L = rt.lib()
     B = xa.shape[0]
     M = B * wplan.QH * wplan.QW
     ldo = r4(CB)
+    if xa_s is not None and xb_s is not None and CA >= 128 and CB >= 128 and M >= 2048:
+        # both operands already split into bf16 hi/lo planes: copy + MFMA only
+        tiles = ((CA + 127) // 128) * ((CB + 127) // 128) * wplan.ntaps
+        ns = best_nsplit(tiles, 512, M // 512)
+        ws = torch.empty((ns, wplan.ntaps, CA, ldo), device=xa.device, dtype=torch.float32)
+        S = rt.stream(xa)
+        bsum = torch.empty((ns, ldo), device=xa.device, dtype=torch.float32) if gbias is not None else None
+        L.cdf_conv_wgrad_bf16x(P(xa_s[0]), P(xa_s[1]), xa_s[0].shape[-1], P(xb_s[0]), P(xb_s[1]), xb_s[0].shape[-1], P(zero_page(xa.device)),
+                               P(ws), ldo, B, wplan.QH, wplan.QW, wplan.HA, wplan.WA, wplan.sa, wplan.HB, wplan.WB, wplan.sb, CA, CB,
+                               wplan.ntaps, wplan.desc, ns, P(bsum), S)
+        L.cdf_unpack_reduce(P(ws), P(gparam), ns, wplan.ntaps, CA, CB, ldo, s_t, s_r, s_c, 1, S)
+        if gbias is not None:
+            L.cdf_unpack_reduce(P(bsum), P(gbias), ns, 1, 1, CB, ldo, 0, 0, 1, 1, S)
+        return
     if rt.precision != "f32" and CA >= 128 and CB >= 128 and M >= 2048:   # full 128x128 tiles only; thinner layers are faster on the fp32 kernel
         # split-precision bf16 MFMA kernel: 128x128 tiles, resident twice per CU (512 slots)
         tiles = ((CA + 127) // 128) * ((CB + 127) // 128) * wplan.ntaps

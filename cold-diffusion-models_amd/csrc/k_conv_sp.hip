@@ -115,8 +115,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_sp_kernel(SpArgs a) {
             a_pix[p] = 0;
         }
     }
-    // B rows of this thread: n = (tid >> 2) + 64 p, 16-byte column (tid & 3)
+    // B rows of this thread: n = brow + 64 p, 16-byte column (tid & 3); brow pairs rows R and R+4 inside each
+    // 8-lane ds_write_b128 group (conflict-free stores, see conv_igemm_spx_kernel)
     const int b_q = tid & 3;
+    const int bg8 = tid >> 3, brow = ((bg8 >> 2) << 3) + (bg8 & 3) + (((tid >> 2) & 1) << 2);
     const int nchunks = (a.Cin + BK - 1) / BK;
     const int niter = ph.ntaps * nchunks;
 
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_sp_kernel(SpArgs a) {
     int b_row[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const int n = tile_n * BN + (tid >> 2) + 64 * p;
+        const int n = tile_n * BN + brow + 64 * p;
         b_row[p] = n < a.Cout ? n : a.Cout - 1;
     }
     auto load_global = [&](int it) {
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_sp_kernel(SpArgs a) {
             if (SPLIT > 1) *(uint2*)(st + PLANE + off) = lo;
         }
         unsigned short* sb = st + NPL * PLANE;
-        const int offb0 = (tid >> 2) * AS + b_q * 8, offb1 = ((tid >> 2) + 64) * AS + b_q * 8;
+        const int offb0 = brow * AS + b_q * 8, offb1 = (brow + 64) * AS + b_q * 8;
         *(uint4*)(sb + offb0) = rbh0;
         *(uint4*)(sb + offb1) = rbh1;
         if (SPLIT > 1) {
@@ -454,6 +456,399 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_sp_kernel(SpWgradArgs a) {
         }
 }
 
+// ================================================================================================
+// PRE-SPLIT operand variants.  Splitting inside the GEMM costs ~9 VALU instructions per MFMA and is
+// repeated by every N tile and again by dgrad / wgrad, which makes the in-kernel-split kernels
+// issue-slot bound (measured: MFMA pipe 33 % busy).  Here the activation has been split ONCE by
+// split_bf16_kernel into bf16 hi / lo planes ([rows][ld] each, same bytes as the fp32 tensor) and the
+// GEMM main loop is pure 16-byte copies global -> LDS plus MFMAs.  Out-of-image taps read from a
+// caller-provided zero page, so there is no masking arithmetic at all.
+// ================================================================================================
+__global__ void split_bf16_kernel(const float* x, int ldx, unsigned short* hi, unsigned short* lo, int ldo, long long rows, int C4) {
+    const long long n = rows * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const long long r = i / C4;
+        const float4 v = *(const float4*)(x + r * ldx + c);
+        const unsigned h0 = cdf_f2bf(v.x), h1 = cdf_f2bf(v.y), h2 = cdf_f2bf(v.z), h3 = cdf_f2bf(v.w);
+        const unsigned l0 = cdf_f2bf(v.x - cdf_bf2f(h0)), l1 = cdf_f2bf(v.y - cdf_bf2f(h1));
+        const unsigned l2 = cdf_f2bf(v.z - cdf_bf2f(h2)), l3 = cdf_f2bf(v.w - cdf_bf2f(h3));
+        *(uint2*)(hi + r * ldo + c) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+        *(uint2*)(lo + r * ldo + c) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+    }
+}
+
+struct SpxArgs {
+    const unsigned short* x_hi;
+    const unsigned short* x_lo;
+    const unsigned short* zero;    // >= 16 zero bytes, 16-byte aligned
+    const unsigned short* w_hi;
+    const unsigned short* w_lo;
+    float* y;
+    const float* bias;
+    const float* sbias;
+    const float* res;
+    float* pre;
+    const float* mul;
+    int ldx, ldk, ldy, ld_sbias, ldr, ldp, ldm;
+    int B, H, W, Cin, OH, OW, Cout, QH, QW, os, is;
+    int act, mul_mode, accumulate, nphase;
+    SpPhase ph[4];
+};
+
+__global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
+    constexpr int BM = 128, BN = 128, BK = 32, AS = 40;
+    constexpr int PLANE = BM * AS;
+    constexpr int STAGE = 4 * PLANE;                         // A hi, A lo, B hi, B lo
+    CDF_DYN_SMEM(smem_raw);
+    unsigned short* smem = (unsigned short*)smem_raw;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M = a.B * a.QH * a.QW;
+    const int tiles_n = (a.Cout + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    const int tile = cdf_sp_swizzle(blockIdx.x, tiles_m * tiles_n);
+    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+    const SpPhase& ph = a.ph[blockIdx.y];
+
+    // both operands: 16-byte column q = tid & 3 (8 bf16), row = rowmap(tid) + 64 p.  The 8 lanes of one
+    // ds_write_b128 group cover rows R and R+4 (320 B apart = bank offset 16) instead of R and R+1
+    // (80 B apart: banks wrap onto each other, 2-way conflict on every store).
+    const int q8 = (tid & 3) * 8;
+    const int g8 = tid >> 3, trow = ((g8 >> 2) << 3) + (g8 & 3) + (((tid >> 2) & 1) << 2);
+    int a_iy0[2], a_ix0[2], b_row[2];
+    unsigned a_pix[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int m = tile_m * BM + trow + 64 * p;
+        if (m < M) {
+            const int qx = m % a.QW, t2 = m / a.QW;
+            a_iy0[p] = (t2 % a.QH) * a.is;
+            a_ix0[p] = qx * a.is;
+            a_pix[p] = (unsigned)(((t2 / a.QH) * a.H + a_iy0[p]) * a.W + a_ix0[p]);
+        } else {
+            a_iy0[p] = -(1 << 28);
+            a_ix0[p] = 0;
+            a_pix[p] = 0;
+        }
+        const int n = tile_n * BN + trow + 64 * p;
+        b_row[p] = n < a.Cout ? n : a.Cout - 1;
+    }
+    const int nchunks = (a.Cin + BK - 1) / BK;
+    const int niter = ph.ntaps * nchunks;
+
+    uint4 rah0, rah1, ral0, ral1, rbh0, rbh1, rbl0, rbl1;
+    int tap = 0, c0 = 0;                                     // incremental (tap, channel chunk) counters
+    auto load_global = [&]() {
+        const int dy = ph.dy[tap], dx = ph.dx[tap], wi = ph.wi[tap];
+        const int tap_pix = dy * a.W + dx;
+        const bool cok = (c0 + q8) < a.Cin;
+        {
+            const unsigned iy = (unsigned)(a_iy0[0] + dy), ix = (unsigned)(a_ix0[0] + dx);
+            const bool ok = iy < (unsigned)a.H && ix < (unsigned)a.W && cok;
+            const size_t off = (size_t)(a_pix[0] + (unsigned)tap_pix) * (unsigned)a.ldx + c0 + q8;
+            rah0 = *(const uint4*)(ok ? a.x_hi + off : a.zero);
+            ral0 = *(const uint4*)(ok ? a.x_lo + off : a.zero);
+        }
+        {
+            const unsigned iy = (unsigned)(a_iy0[1] + dy), ix = (unsigned)(a_ix0[1] + dx);
+            const bool ok = iy < (unsigned)a.H && ix < (unsigned)a.W && cok;
+            const size_t off = (size_t)(a_pix[1] + (unsigned)tap_pix) * (unsigned)a.ldx + c0 + q8;
+            rah1 = *(const uint4*)(ok ? a.x_hi + off : a.zero);
+            ral1 = *(const uint4*)(ok ? a.x_lo + off : a.zero);
+        }
+        const long long off0 = ((long long)wi * a.Cout + b_row[0]) * a.ldk + c0 + q8;
+        const long long off1 = ((long long)wi * a.Cout + b_row[1]) * a.ldk + c0 + q8;
+        rbh0 = *(const uint4*)(a.w_hi + off0);
+        rbh1 = *(const uint4*)(a.w_hi + off1);
+        rbl0 = *(const uint4*)(a.w_lo + off0);
+        rbl1 = *(const uint4*)(a.w_lo + off1);
+        c0 += BK;
+        if (c0 >= a.Cin) { c0 = 0; ++tap; }
+    };
+    const int off0 = trow * AS + q8, off1 = (trow + 64) * AS + q8;
+    auto store_lds = [&](int buf) {
+        unsigned short* st = smem + buf * STAGE;
+        *(uint4*)(st + off0) = rah0;
+        *(uint4*)(st + off1) = rah1;
+        *(uint4*)(st + PLANE + off0) = ral0;
+        *(uint4*)(st + PLANE + off1) = ral1;
+        *(uint4*)(st + 2 * PLANE + off0) = rbh0;
+        *(uint4*)(st + 2 * PLANE + off1) = rbh1;
+        *(uint4*)(st + 3 * PLANE + off0) = rbl0;
+        *(uint4*)(st + 3 * PLANE + off1) = rbl1;
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int half = lane >> 5, l31 = lane & 31;
+    if (niter > 0) {
+        load_global();
+        store_lds(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < niter) load_global();
+        const unsigned short* sa = smem + buf * STAGE;
+        const unsigned short* sb = sa + 2 * PLANE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int k0 = ks * 16 + half * 8;
+            bf16x8_v ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = (wm * 64 + i * 32 + l31) * AS + k0;
+                ah[i] = *(const bf16x8_v*)(sa + off);
+                al[i] = *(const bf16x8_v*)(sa + PLANE + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int off = (wn * 64 + j * 32 + l31) * AS + k0;
+                bh[j] = *(const bf16x8_v*)(sb + off);
+                bl[j] = *(const bf16x8_v*)(sb + PLANE + off);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = CDF_MFMA_BF16(al[i], bh[j], acc[i][j]);
+                    acc[i][j] = CDF_MFMA_BF16(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = CDF_MFMA_BF16(ah[i], bh[j], acc[i][j]);
+                }
+        }
+        if (it + 1 < niter) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    const bool direct = (a.os == 1 && a.QH == a.OH && a.QW == a.OW);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int m = tile_m * BM + row;
+            if (m >= M) continue;
+            long long opix;
+            int b;
+            if (direct) {
+                opix = m;
+                b = m / (a.QH * a.QW);
+            } else {
+                const int qx = m % a.QW, t2 = m / a.QW;
+                const int qy = t2 % a.QH;
+                b = t2 / a.QH;
+                opix = ((long long)b * a.OH + qy * a.os + ph.oy) * a.OW + qx * a.os + ph.ox;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int co = tile_n * BN + wn * 64 + j * 32 + l31;
+                if (co >= a.Cout) continue;
+                float v = acc[i][j][r];
+                if (a.bias) v += a.bias[co];
+                if (a.sbias) v += a.sbias[(long long)b * a.ld_sbias + co];
+                if (a.pre) a.pre[opix * a.ldp + co] = v;
+                if (a.act == 1) v = cdf_gelu(v);
+                else if (a.act == 2) v = cdf_silu(v);
+                if (a.mul_mode) {
+                    const float mv = a.mul[opix * a.ldm + co];
+                    v *= (a.mul_mode == 1 ? cdf_gelu_grad(mv) : (a.mul_mode == 2 ? cdf_silu_grad(mv) : mv));
+                }
+                if (a.res) v += a.res[opix * a.ldr + co];
+                float* dst = a.y + opix * a.ldy + co;
+                if (a.accumulate) v += *dst;
+                *dst = v;
+            }
+        }
+    }
+}
+
+// weight gradient with both operands pre-split ([pixels][ld] bf16 hi / lo planes)
+struct SpxWgradArgs {
+    const unsigned short* a_hi;
+    const unsigned short* a_lo;
+    const unsigned short* b_hi;
+    const unsigned short* b_lo;
+    const unsigned short* zero;
+    float* out;
+    float* bsum;
+    int lda, ldb, ldo;
+    int B, QH, QW;
+    int HA, WA, sa, HB, WB, sb;
+    int CA, CB;
+    int ntaps, nsplit, m_per_split;
+    signed char day[CDF_MAX_TAPS], dax[CDF_MAX_TAPS], dby[CDF_MAX_TAPS], dbx[CDF_MAX_TAPS];
+};
+
+__device__ __forceinline__ void cdf_bf16x8_accum(float* acc8, const uint4& h, const uint4& l) {
+    const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        acc8[2 * e] += __uint_as_float(hw[e] << 16) + __uint_as_float(lw[e] << 16);
+        acc8[2 * e + 1] += __uint_as_float(hw[e] & 0xFFFF0000u) + __uint_as_float(lw[e] & 0xFFFF0000u);
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) {
+    constexpr int BC = 128, BK = 32;
+    constexpr int PLANE = BK * BC;
+    constexpr int STAGE = 4 * PLANE;
+    CDF_DYN_SMEM(smem_raw);
+    unsigned short* smem = (unsigned short*)smem_raw;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_b = (a.CB + BC - 1) / BC;
+    const int tile_a = blockIdx.x / tiles_b, tile_b = blockIdx.x - tile_a * tiles_b;
+    const int tap = blockIdx.y, split = blockIdx.z;
+    const int M = a.B * a.QH * a.QW;
+    const int m_lo = split * a.m_per_split;
+    int m_hi = m_lo + a.m_per_split;
+    if (m_hi > M) m_hi = M;
+    const int niter = m_hi > m_lo ? (m_hi - m_lo + BK - 1) / BK : 0;
+    const int day = a.day[tap], dax = a.dax[tap], dby = a.dby[tap], dbx = a.dbx[tap];
+
+    // load slots: pixel k = (tid >> 4) + 16 p (p = 0, 1), 16-byte channel column c8 = (tid & 15) * 8
+    const int c8 = (tid & 15) * 8;
+    int q[2][3];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int m = m_lo + (tid >> 4) + 16 * p;
+        q[p][0] = m % a.QW;
+        const int t2 = m / a.QW;
+        q[p][1] = t2 % a.QH;
+        q[p][2] = t2 / a.QH;
+    }
+    const bool do_bsum = a.bsum != nullptr && tile_a == 0 && tap == 0;
+    float bs_acc[2][8];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs_acc[p][e] = 0.f;
+    const int ca = tile_a * BC + c8, cb = tile_b * BC + c8;
+
+    uint4 rah0, rah1, ral0, ral1, rbh0, rbh1, rbl0, rbl1;
+    auto load_one = [&](int p, int m0, uint4& ah, uint4& al, uint4& bh, uint4& bl) {
+        const int m = m0 + (tid >> 4) + 16 * p;
+        const int qx = q[p][0], qy = q[p][1], b = q[p][2];
+        const unsigned ay = (unsigned)(qy * a.sa + day), ax = (unsigned)(qx * a.sa + dax);
+        const unsigned by = (unsigned)(qy * a.sb + dby), bx = (unsigned)(qx * a.sb + dbx);
+        const bool bok = m < m_hi && by < (unsigned)a.HB && bx < (unsigned)a.WB;
+        const bool aok = bok && ay < (unsigned)a.HA && ax < (unsigned)a.WA && ca < a.CA;
+        const bool bok2 = bok && cb < a.CB;
+        const long long offa = (((long long)b * a.HA + ay) * a.WA + ax) * a.lda + ca;
+        const long long offb = (((long long)b * a.HB + by) * a.WB + bx) * a.ldb + cb;
+        ah = *(const uint4*)(aok ? a.a_hi + offa : a.zero);
+        al = *(const uint4*)(aok ? a.a_lo + offa : a.zero);
+        bh = *(const uint4*)(bok2 ? a.b_hi + offb : a.zero);
+        bl = *(const uint4*)(bok2 ? a.b_lo + offb : a.zero);
+        q[p][0] += BK;
+        while (q[p][0] >= a.QW) {
+            q[p][0] -= a.QW;
+            if (++q[p][1] >= a.QH) { q[p][1] = 0; ++q[p][2]; }
+        }
+        if (do_bsum) cdf_bf16x8_accum(bs_acc[p], bh, bl);
+    };
+    auto load_global = [&](int it) {
+        const int m0 = m_lo + it * BK;
+        load_one(0, m0, rah0, ral0, rbh0, rbl0);
+        load_one(1, m0, rah1, ral1, rbh1, rbl1);
+    };
+    const int so0 = (tid >> 4) * BC + c8, so1 = ((tid >> 4) + 16) * BC + c8;
+    auto store_lds = [&](int buf) {
+        unsigned short* st = smem + buf * STAGE;
+        *(uint4*)(st + so0) = rah0;
+        *(uint4*)(st + so1) = rah1;
+        *(uint4*)(st + PLANE + so0) = ral0;
+        *(uint4*)(st + PLANE + so1) = ral1;
+        *(uint4*)(st + 2 * PLANE + so0) = rbh0;
+        *(uint4*)(st + 2 * PLANE + so1) = rbh1;
+        *(uint4*)(st + 3 * PLANE + so0) = rbl0;
+        *(uint4*)(st + 3 * PLANE + so1) = rbl1;
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int half = lane >> 5, l31 = lane & 31;
+    if (niter > 0) {
+        load_global(0);
+        store_lds(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < niter) load_global(it + 1);
+        const unsigned short* st = smem + buf * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int k0 = ks * 16 + half * 8;
+            bf16x8_v ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned short* pa = st + k0 * BC + wm * 64 + i * 32 + l31;
+                const unsigned short* pb = st + 2 * PLANE + k0 * BC + wn * 64 + i * 32 + l31;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    ah[i][e] = (short)pa[e * BC];
+                    al[i][e] = (short)pa[PLANE + e * BC];
+                    bh[i][e] = (short)pb[e * BC];
+                    bl[i][e] = (short)pb[PLANE + e * BC];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = CDF_MFMA_BF16(al[i], bh[j], acc[i][j]);
+                    acc[i][j] = CDF_MFMA_BF16(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = CDF_MFMA_BF16(ah[i], bh[j], acc[i][j]);
+                }
+        }
+        if (it + 1 < niter) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (do_bsum) {
+        float* red = (float*)smem;                 // [32 px][128] floats (stage 0 is idle now)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[((tid >> 4) + 16 * p) * BC + c8 + e] = bs_acc[p][e];
+        __syncthreads();
+        for (int c = tid; c < BC; c += 256) {
+            float t = 0.f;
+            for (int k = 0; k < BK; ++k) t += red[k * BC + c];
+            const int cc = tile_b * BC + c;
+            if (cc < a.ldo) a.bsum[(long long)split * a.ldo + cc] = cc < a.CB ? t : 0.f;
+        }
+    }
+    float* O = a.out + ((long long)split * a.ntaps + tap) * a.CA * a.ldo;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tile_a * BC + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row >= a.CA) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = tile_b * BC + wn * 64 + j * 32 + l31;
+                if (col < a.ldo) O[(long long)row * a.ldo + col] = col < a.CB ? acc[i][j][r] : 0.f;
+            }
+        }
+}
+
 // dst_hi/lo[t][r][c] (c < ldc, zero padded) = split(src[c*s_c + r*s_r + t*s_t])
 __global__ void pack_weight_bf16_kernel(const float* src, unsigned short* dst_hi, unsigned short* dst_lo, int T, int R, int C,
                                         int ldc, long long s_t, long long s_r, long long s_c) {
@@ -555,4 +950,94 @@ extern "C" int cdf_conv_wgrad_bf16(const float* xa, int lda, const float* xb, in
     const int tiles = cdf_cdiv(CA, 128) * cdf_cdiv(CB, 128);
     CDF_LAUNCH(conv_wgrad_sp_kernel, dim3(tiles, ntaps, nsplit), dim3(256), lds, CDF_S, a);
     return cdf_check_launch("conv_wgrad_sp");
+}
+
+// ---- pre-split operand entry points ---------------------------------------------------------------------
+extern "C" int cdf_split_bf16(const float* x, int ldx, void* hi, void* lo, int ldo, long long rows, int C, void* stream) {
+    CDF_REQUIRE(x && hi && lo && rows > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldo % 8 == 0 && ldo >= C, "cdf_split_bf16: bad args (C %% 4, ldo %% 8)");
+    long long g = (rows * (C / 4) + 255) / 256;
+    if (g > 8192) g = 8192;
+    CDF_LAUNCH(split_bf16_kernel, dim3((int)g), dim3(256), 0, CDF_S, x, ldx, (unsigned short*)hi, (unsigned short*)lo, ldo, rows, C / 4);
+    return cdf_check_launch("split_bf16");
+}
+
+static int fill_phases(SpPhase* ph, int nphase, const int* pd, const char* who) {
+    for (int p = 0; p < nphase; ++p) {
+        ph[p].oy = pd[0]; ph[p].ox = pd[1]; ph[p].ntaps = pd[2];
+        CDF_REQUIRE(pd[2] >= 0 && pd[2] <= CDF_MAX_TAPS, "%s: too many taps (%d)", who, pd[2]);
+        for (int t = 0; t < pd[2]; ++t) {
+            ph[p].dy[t] = (signed char)pd[3 + 3 * t];
+            ph[p].dx[t] = (signed char)pd[4 + 3 * t];
+            ph[p].wi[t] = (signed char)pd[5 + 3 * t];
+        }
+        pd += 3 + 3 * pd[2];
+    }
+    return CDF_OK;
+}
+
+extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo,
+                                   int ldk, float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW,
+                                   int os, int is, int nphase, const int* phase_desc, const float* bias, const float* sbias,
+                                   int ld_sbias, const float* res, int ldr, float* pre, int ldp, const float* mul, int ldm, int act,
+                                   int mul_mode, int accumulate, void* stream) {
+    CDF_REQUIRE(x_hi && x_lo && zero && w_hi && w_lo && y, "cdf_conv_gemm_bf16x: null pointer");
+    CDF_REQUIRE(((((uintptr_t)x_hi) | ((uintptr_t)x_lo) | ((uintptr_t)zero) | ((uintptr_t)w_hi) | ((uintptr_t)w_lo)) & 15) == 0, "cdf_conv_gemm_bf16x: operands must be 16B aligned");
+    CDF_REQUIRE(ldx % 8 == 0 && Cin % 8 == 0 && ldx >= Cin && ldk % 32 == 0 && ldk >= Cin, "cdf_conv_gemm_bf16x: Cin and pitches must be multiples of 8 (ldk of 32)");
+    CDF_REQUIRE(nphase >= 1 && nphase <= 4 && phase_desc && ldy >= Cout, "cdf_conv_gemm_bf16x: bad geometry");
+    CDF_REQUIRE(!mul_mode || mul, "cdf_conv_gemm_bf16x: mul_mode without mul tensor");
+    SpxArgs a;
+    a.x_hi = (const unsigned short*)x_hi; a.x_lo = (const unsigned short*)x_lo; a.zero = (const unsigned short*)zero;
+    a.w_hi = (const unsigned short*)w_hi; a.w_lo = (const unsigned short*)w_lo; a.y = y;
+    a.bias = bias; a.sbias = sbias; a.res = res; a.pre = pre; a.mul = mul;
+    a.ldx = ldx; a.ldk = ldk; a.ldy = ldy; a.ld_sbias = ld_sbias; a.ldr = ldr; a.ldp = ldp; a.ldm = ldm;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.QH = QH; a.QW = QW; a.os = os; a.is = is;
+    a.act = act; a.mul_mode = mul_mode; a.accumulate = accumulate; a.nphase = nphase;
+    int rc = fill_phases(a.ph, nphase, phase_desc, "cdf_conv_gemm_bf16x");
+    if (rc) return rc;
+#ifndef CDF_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_spx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+#endif
+    const int M = B * QH * QW;
+    const int tiles = cdf_cdiv(M, 128) * cdf_cdiv(Cout, 128);
+    const size_t lds = (size_t)2 * 4 * 128 * 40 * sizeof(unsigned short);
+    CDF_LAUNCH(conv_igemm_spx_kernel, dim3(tiles, nphase), dim3(256), lds, CDF_S, a);
+    return cdf_check_launch("conv_igemm_spx");
+}
+
+extern "C" int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, int ldb,
+                                    const void* zero, float* ws, int ldo, int B, int QH, int QW, int HA, int WA, int sa, int HB, int WB,
+                                    int sb, int CA, int CB, int ntaps, const int* tap_desc, int nsplit, float* bsum, void* stream) {
+    CDF_REQUIRE(a_hi && a_lo && b_hi && b_lo && zero && ws, "cdf_conv_wgrad_bf16x: null pointer");
+    CDF_REQUIRE(((((uintptr_t)a_hi) | ((uintptr_t)a_lo) | ((uintptr_t)b_hi) | ((uintptr_t)b_lo) | ((uintptr_t)zero)) & 15) == 0, "cdf_conv_wgrad_bf16x: operands must be 16B aligned");
+    CDF_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && CA % 8 == 0 && CB % 8 == 0 && lda >= CA && ldb >= CB && ldo % 4 == 0 && ldo >= CB, "cdf_conv_wgrad_bf16x: channels / pitches must be multiples of 8");
+    CDF_REQUIRE(ntaps >= 1 && ntaps <= CDF_MAX_TAPS && tap_desc && nsplit >= 1, "cdf_conv_wgrad_bf16x: bad tap / split count");
+    SpxWgradArgs a;
+    a.a_hi = (const unsigned short*)a_hi; a.a_lo = (const unsigned short*)a_lo; a.b_hi = (const unsigned short*)b_hi;
+    a.b_lo = (const unsigned short*)b_lo; a.zero = (const unsigned short*)zero; a.out = ws; a.bsum = bsum;
+    a.lda = lda; a.ldb = ldb; a.ldo = ldo;
+    a.B = B; a.QH = QH; a.QW = QW; a.HA = HA; a.WA = WA; a.sa = sa; a.HB = HB; a.WB = WB; a.sb = sb;
+    a.CA = CA; a.CB = CB; a.ntaps = ntaps; a.nsplit = nsplit;
+    const int M = B * QH * QW;
+    a.m_per_split = cdf_cdiv(cdf_cdiv(M, nsplit), 32) * 32;
+    for (int t = 0; t < ntaps; ++t) {
+        a.day[t] = (signed char)tap_desc[4 * t + 0];
+        a.dax[t] = (signed char)tap_desc[4 * t + 1];
+        a.dby[t] = (signed char)tap_desc[4 * t + 2];
+        a.dbx[t] = (signed char)tap_desc[4 * t + 3];
+    }
+#ifndef CDF_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_spx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+#endif
+    const size_t lds = (size_t)2 * 4 * 32 * 128 * sizeof(unsigned short);
+    const int tiles = cdf_cdiv(CA, 128) * cdf_cdiv(CB, 128);
+    CDF_LAUNCH(conv_wgrad_spx_kernel, dim3(tiles, ntaps, nsplit), dim3(256), lds, CDF_S, a);
+    return cdf_check_launch("conv_wgrad_spx");
 }

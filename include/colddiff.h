@@ -135,6 +135,19 @@ int cdf_conv_gemm_bf16(const float* x, int ldx, const void* w_hi, const void* w_
 int cdf_conv_wgrad_bf16(const float* xa, int lda, const float* xb, int ldb, float* ws, int ldo, int B, int QH, int QW, int HA,
                         int WA, int sa, int HB, int WB, int sb, int CA, int CB, int ntaps, const int* tap_desc, int nsplit,
                         float* bsum, void* stream);
+/* Pre-split operand variants: an activation that feeds several GEMMs (forward, data gradient, weight
+ * gradient, every N tile) is split ONCE into bf16 hi / lo planes [rows][ld] by cdf_split_bf16; the GEMMs
+ * then only copy and multiply.  `zero` = any 16-byte-aligned device buffer of >= 16 zero bytes (out-of-image
+ * taps load from it).  Channel counts and pitches must be multiples of 8. */
+int cdf_split_bf16(const float* x, int ldx, void* hi, void* lo, int ldo, long long rows, int C, void* stream);
+int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo, int ldk,
+                        float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW, int os, int is,
+                        int nphase, const int* phase_desc, const float* bias, const float* sbias, int ld_sbias, const float* res,
+                        int ldr, float* pre, int ldp, const float* mul, int ldm, int act, int mul_mode, int accumulate,
+                        void* stream);
+int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, int ldb, const void* zero,
+                         float* ws, int ldo, int B, int QH, int QW, int HA, int WA, int sa, int HB, int WB, int sb, int CA, int CB,
+                         int ntaps, const int* tap_desc, int nsplit, float* bsum, void* stream);
 
 /* parameter layout <-> GEMM layout: dst[t][r][c] = src[c*s_c + r*s_r + t*s_t] (c >= C zero-filled up to ldc);
  * g[c*s_c + r*s_r + t*s_t] (+)= sum_z ws[z][t][r][c] */

@@ -517,3 +517,86 @@ def test_conv_gemm_bf16(be, split, case):
 def test_conv_gemm_bf16_large(split, case):
     from conftest import Backend
     _sp_case(Backend("hip"), split, *case)
+
+
+# ---------------------------------------------------------------------------------------------
+# pre-split operand variants (activation split once by cdf_split_bf16)
+# ---------------------------------------------------------------------------------------------
+SPX_CASES = [(2, 32, 40, 8, 3, 1, 1), (1, 64, 32, 8, 1, 1, 0), (1, 40, 136, 8, 3, 1, 1), (1, 32, 32, 8, 4, 2, 1)]
+SPX_CASES_GPU = [(4, 64, 128, 32, 3, 1, 1), (2, 128, 64, 32, 3, 1, 1), (2, 256, 512, 16, 3, 1, 1), (2, 64, 64, 32, 4, 2, 1)]
+
+
+def _split(be, t):
+    """fp32 NHWC [.., C] -> (hi, lo) bf16 planes with pitch roundup8(C)."""
+    C = t.shape[-1]
+    ld = (C + 7) // 8 * 8
+    rows = t.numel() // C
+    hi = torch.zeros(t.shape[:-1] + (ld,), dtype=torch.int16, device=be.device)
+    lo = torch.zeros_like(hi)
+    be.L.cdf_split_bf16(P(t), C, P(hi), P(lo), ld, rows, C, be.stream())
+    be._keep += [hi, lo]
+    return hi, lo
+
+
+def _spx_case(be, B, Cin, Cout, H, k, s, p):
+    torch.manual_seed(0)
+    x = torch.randn(B, Cin, H, H, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k) * (1.0 / math.sqrt(Cin * k * k))).requires_grad_()
+    bias = torch.randn(Cout)
+    yref = F.conv2d(x, w, bias, stride=s, padding=p)
+    gy = torch.randn_like(yref)
+    yref.backward(gy)
+    KK = k * k
+    zero = be.zeros(16)
+    wd_ = be.to(w)
+
+    def pack_sp(N, K, s_n, s_k):
+        ldk = (K + 31) // 32 * 32
+        hi = torch.empty(KK, N, ldk, dtype=torch.int16, device=be.device)
+        lo = torch.empty(KK, N, ldk, dtype=torch.int16, device=be.device)
+        be.L.cdf_pack_weight_bf16(P(wd_), P(hi), P(lo), KK, N, K, ldk, 1, s_n, s_k, be.stream())
+        be._keep += [hi, lo]
+        return hi, lo
+
+    plan, pd, wg = cd.conv_fwd(H, H, k, k, s, p, p, p, p), cd.conv_dgrad(H, H, k, k, s, p, p, p, p), cd.conv_wgrad(H, H, k, k, s, p, p, p, p)
+    wf, wb = pack_sp(Cout, Cin, Cin * KK, KK), pack_sp(Cin, Cout, KK, Cin * KK)
+    xn = torch.zeros(B, H, H, Cin)
+    xn[...] = x.detach().permute(0, 2, 3, 1)
+    gyn = torch.zeros(B, plan.OH, plan.OW, Cout)
+    gyn[...] = gy.permute(0, 2, 3, 1)
+    xs, gs = _split(be, be.to(xn)), _split(be, be.to(gyn))
+
+    def run(pl, xsplit, wpair, Ci, Co, bias_):
+        y = be.zeros(B, pl.OH, pl.OW, r4(Co))
+        be.L.cdf_conv_gemm_bf16x(P(xsplit[0]), P(xsplit[1]), xsplit[0].shape[-1], P(zero), P(wpair[0]), P(wpair[1]), wpair[0].shape[-1], P(y),
+                                 y.shape[-1], B, pl.H, pl.W, Ci, pl.OH, pl.OW, Co, pl.QH, pl.QW, pl.os, pl.istride, pl.nphase, pl.desc,
+                                 P(bias_), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, be.stream())
+        return y
+
+    y = run(plan, xs, wf, Cin, Cout, be.to(bias))
+    dx = run(pd, gs, wb, Cout, Cin, None)
+    M = B * wg.QH * wg.QW
+    ns, ldo = max(1, min(3, M // 32)), r4(Cout)
+    ws, bsum = be.empty(ns, KK, Cin, ldo), be.empty(ns, ldo)
+    be.L.cdf_conv_wgrad_bf16x(P(xs[0]), P(xs[1]), xs[0].shape[-1], P(gs[0]), P(gs[1]), gs[0].shape[-1], P(zero), P(ws), ldo, B, wg.QH, wg.QW,
+                              wg.HA, wg.WA, wg.sa, wg.HB, wg.WB, wg.sb, Cin, Cout, wg.ntaps, wg.desc, ns, P(bsum), be.stream())
+    dw, db = be.zeros(Cout, Cin, k, k), be.zeros(Cout)
+    be.L.cdf_unpack_reduce(P(ws), P(dw), ns, KK, Cin, Cout, ldo, 1, KK, Cin * KK, 0, be.stream())
+    be.L.cdf_unpack_reduce(P(bsum), P(db), ns, 1, 1, Cout, ldo, 0, 0, 1, 0, be.stream())
+    tol = lambda ref: 3e-5 * max(1.0, ref.abs().max().item())
+    assert err(y[..., :Cout].permute(0, 3, 1, 2), yref) <= tol(yref)
+    assert err(dx[..., :Cin].permute(0, 3, 1, 2), x.grad) <= tol(x.grad)
+    assert err(dw, w.grad) <= 3e-5 * max(1.0, w.grad.abs().max().item()) * math.sqrt(M / 16)
+    assert err(db, gy.sum((0, 2, 3))) <= 3e-5 * max(1.0, gy.sum((0, 2, 3)).abs().max().item()) * math.sqrt(M)
+
+
+@pytest.mark.parametrize("case", SPX_CASES)
+def test_conv_presplit(be, case):
+    _spx_case(be, *case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", SPX_CASES_GPU)
+def test_conv_presplit_large(case):
+    from conftest import Backend
+    _spx_case(Backend("hip"), *case)

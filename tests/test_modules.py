@@ -210,3 +210,49 @@ def test_no_cpu_fallback():
     net = quiet(Unet, dim=8, dim_mults=(1, 2), channels=3)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(torch.randn(1, 3, 8, 8), torch.tensor([1]))
+
+
+def test_packed_cache_drops_dead_params(mbe):
+    """A packed weight must not outlive its parameter: a new tensor can reuse both id() and the address."""
+    import gc
+    from colddiff import ops
+    gc.collect()
+    w = torch.nn.Parameter(mbe.to(torch.randn(8, 4, 3, 3)))
+    n0 = len(ops._pack_cache)
+    ops.packed(w, "conv_fwd")
+    assert len(ops._pack_cache) == n0 + 1
+    del w
+    gc.collect()
+    assert len(ops._pack_cache) == n0
+
+
+def test_convnext_block_presplit_operands(mbe):
+    """Wide ConvNeXt block: the 3x3 convs run on pre-split bf16 hi/lo planes (fwd, dgrad and wgrad).
+    Forward and every gradient must still meet the fp32 parity bound against the oracle (DEBLUR:156-165)."""
+    from colddiff.unet import ConvNextBlock
+    from colddiff import functions as F_
+    from oracle import cold_oracle as O
+    assert F_.want_presplit(128, 128, 3)
+    torch.manual_seed(3)
+    blk = ConvNextBlock(128, 128, time_emb_dim=16, mult=1)
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.mul_(2.0)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    blk = blk.to(mbe.device)
+    x = torch.randn(2, 128, 32, 32)
+    temb = torch.randn(2, 16)
+    g = torch.randn(2, 128, 32, 32)
+    xr = x.clone().requires_grad_(True)
+    yr = O.convnext_block(sd, xr, temb)
+    yr.backward(g)
+    xd = mbe.to(x).requires_grad_(True)
+    xn = F_.ToNHWC.apply(xd)
+    y = F_.ToNCHW.apply(blk(xn, mbe.to(torch.nn.functional.gelu(temb))), 128, None)
+    y.backward(mbe.to(g))
+    tol = 1e-4
+    assert (y.detach().cpu() - yr.detach()).abs().max().item() <= tol * yr.abs().max().item()
+    assert (xd.grad.cpu() - xr.grad).abs().max().item() <= tol * xr.grad.abs().max().item()
+    for n, p_ in blk.named_parameters():
+        r = sd[n].grad
+        assert (p_.grad.cpu() - r).abs().max().item() <= tol * max(r.abs().max().item(), 1e-3), n

@@ -55,3 +55,33 @@ if os.environ.get("KB_SPW", "1") == "1":
         ms = timeit(lambda: L.cdf_conv_wgrad_bf16(P(x),x.shape[-1],P(y),y.shape[-1],P(ws),r4(Cout),B,H,H,H,H,1,H,H,1,Cin,Cout,k*k,wg.desc,ns,0,S()))
         fl = 2.0*B*H*H*Cin*Cout*k*k
         print(f"spW   {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv (ns={ns})", flush=True)
+# ---- pre-split operand kernels ---------------------------------------------------------------------------
+if os.environ.get("KB_SPX", "1") == "1":
+    zero = torch.zeros(64, device=dev)
+    def split(t):
+        C = t.shape[-1]; hi = torch.empty(t.shape, dtype=torch.int16, device=dev); lo = torch.empty_like(hi)
+        L.cdf_split_bf16(P(t), C, P(hi), P(lo), C, t.numel()//C, C, S()); return hi, lo
+    for (Cin,Cout,H,k) in shapes:
+        if only and only != f"{Cin}-{Cout}-{H}": continue
+        if Cin % 8 or Cout % 8: continue
+        x = torch.randn(B,H,H,Cin,device=dev); y = torch.empty(B,H,H,r4(Cout),device=dev); gy = torch.randn(B,H,H,Cout,device=dev)
+        ldk = (Cin+31)//32*32
+        hi = torch.zeros(k*k,Cout,ldk,dtype=torch.int16,device=dev); lo = torch.zeros_like(hi)
+        w = torch.randn(Cout,Cin,k,k,device=dev)*0.05
+        L.cdf_pack_weight_bf16(P(w),P(hi),P(lo),k*k,Cout,Cin,ldk,1,Cin*k*k,k*k,S())
+        ms = timeit(lambda: split(x)); print(f"split {Cin:5d} ch @{H:3d}: {ms:8.3f} ms {8.0*x.numel()/ms/1e6:7.1f} GB/s", flush=True)
+        xs = split(x); gs = split(gy)
+        p = cd.conv_fwd(H,H,k,k,1,k//2,k//2,k//2,k//2)
+        fl = 2.0*B*H*H*Cin*Cout*k*k
+        ms = timeit(lambda: L.cdf_conv_gemm_bf16x(P(xs[0]),P(xs[1]),Cin,P(zero),P(hi),P(lo),ldk,P(y),y.shape[-1],B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,0,0,0,0,0,0,0,0,0,0,0,0,S()))
+        print(f"spx   {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv", flush=True)
+        wg = cd.conv_wgrad(H,H,k,k,1,k//2,k//2,k//2,k//2); M=B*H*H
+        tiles = ((Cin+127)//128)*((Cout+127)//128)*k*k
+        best, bc = 1, None
+        for ns_ in range(1, min(M//512, 256)+1):
+            c_ = -(-tiles*ns_//512)/ns_
+            if bc is None or c_ < bc - 1e-9: best, bc = ns_, c_
+        ns = best
+        ws = torch.empty(ns,k*k,Cin,r4(Cout),device=dev)
+        ms = timeit(lambda: L.cdf_conv_wgrad_bf16x(P(xs[0]),P(xs[1]),Cin,P(gs[0]),P(gs[1]),Cout,P(zero),P(ws),r4(Cout),B,H,H,H,H,1,H,H,1,Cin,Cout,k*k,wg.desc,ns,0,S()))
+        print(f"spxW  {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv (ns={ns})", flush=True)
