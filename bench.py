@@ -105,16 +105,26 @@ class GemmTimer:
         e0.record()
         r = self.orig[entry](*a)
         e1.record()
-        self.records[self.ENTRY[entry]].append((e0, e1, self._flops(entry, a)))
+        self.records[self.ENTRY[entry]].append((e0, e1, self._flops(entry, a), (entry,) + tuple(x for x in a[6:21] if isinstance(x, int) and x < 1 << 20)))
         return r
+
+    def dump_shapes(self, steps):
+        """Per-shape time table (stderr) — which GEMMs the step spends its time in."""
+        agg = {}
+        for recs in self.records.values():
+            for e0, e1, f, key in recs:
+                t, n, fl = agg.get(key, (0.0, 0, 0.0))
+                agg[key] = (t + e0.elapsed_time(e1), n + 1, fl + f)
+        for key, (t, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
+            log("%8.3f ms/step %4d launches %7.1f TF  %s" % (t / steps, n // steps, fl / (t * 1e-3) / 1e12 if t > 0 else 0, key))
 
     def summary(self, steps, elapsed_s):
         out = {}
         for kind, recs in self.records.items():
             if not recs:
                 continue
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
-            fl = sum(f for _, _, f in recs)
+            ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in recs)
+            fl = sum(r[2] for r in recs)
             tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             out[kind] = {"arithmetic": self.DTYPE[kind], "achieved": round(tf, 2), "peak": self.PEAK[kind], "unit": "TFLOP/s",
                          "frac": round(tf / self.PEAK[kind], 4), "launches_per_step": len(recs) // max(1, steps),
@@ -221,6 +231,8 @@ def main():
     imgs_per_step = args.batch * args.accum * world
     value = imgs_per_step * args.steps / elapsed
     kernels = timer.summary(args.steps, elapsed)
+    if os.environ.get("CDF_BENCH_SHAPES"):
+        timer.dump_shapes(args.steps)
 
     out = {
         "metric": "unet_train_imgs_per_sec", "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG_ROOT = os.path.dirname(_HERE)
 _REPO = os.path.dirname(_PKG_ROOT)
 HEADER = os.path.join(_REPO, "include", "colddiff.h")
-LIB_PATH = os.path.join(_PKG_ROOT, "csrc", "libcolddiff_hip.so")
+LIB_PATH = os.environ.get("COLDDIFF_LIB") or os.path.join(_PKG_ROOT, "csrc", "libcolddiff_hip.so")   # env: an alternative gfx950 build
 
 _CTYPES = {
     "int": ctypes.c_int,
