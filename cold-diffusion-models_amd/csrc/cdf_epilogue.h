@@ -1,0 +1,104 @@
+// Shared GEMM epilogue: accumulator tile -> LDS transpose -> float4 rows.
+//
+// The MFMA 32x32 accumulator layout gives each lane ONE channel of 16 scattered pixels, i.e. dword stores
+// of two 128-byte pieces per instruction.  Measured on MI355X that pattern writes at ~1 TB/s and was 40 % of
+// the whole conv kernel on the 128x128-pixel layers.  The tile is therefore transposed through LDS (free once
+// the K loop is over): [rows][BN + 8] fp32 (pitch BN+8: the two half-waves of a ds_write_b32 land 32 banks
+// apart), after which every lane owns 4 consecutive channels of one pixel: float4 loads/stores of the output
+// and of every fused operand (bias, per-sample bias, pre-activation, activation-gradient source, residual),
+// BN/4 lanes = one contiguous pixel row.
+// Args::vec (host-computed, cdf_epi_vec_ok) = all pitches % 4 == 0, Cout % 4 == 0, 16-byte-aligned pointers;
+// otherwise the same code runs with per-element accesses.
+#pragma once
+#include "cdf_common.h"
+
+static inline int cdf_epi_vec_ok(int Cout, const float* y, int ldy, const float* bias, const float* sbias, int ld_sbias, const float* res,
+                                 int ldr, const float* pre, int ldp, const float* mul, int ldm) {
+    const uintptr_t ptrs = (uintptr_t)y | (uintptr_t)bias | (uintptr_t)sbias | (uintptr_t)res | (uintptr_t)pre | (uintptr_t)mul;
+    const int pitches = ldy | (sbias ? ld_sbias : 0) | (res ? ldr : 0) | (pre ? ldp : 0) | (mul ? ldm : 0);
+    return (Cout % 4 == 0 && (ptrs & 15) == 0 && (pitches & 3) == 0) ? 1 : 0;
+}
+
+__device__ __forceinline__ void cdf_ld4(float* v, const float* p, int n, bool vec) {
+    if (vec) {
+        const float4 t = *(const float4*)p;
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = e < n ? p[e] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void cdf_st4(float* p, const float* v, int n, bool vec) {
+    if (vec) {
+        *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < n) p[e] = v[e];
+    }
+}
+
+// One pass over RP transposed rows held in cs ([RP][BN + 8]); rowmap(p) = row of pass-row p inside the block tile.
+// 256 threads.  Contains no barrier (callers sync around it).
+template <int BN, int RP, class Args, class Phase, class RowMap>
+__device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph, float* Y, const float* cs, int m_base, int n_base, int M,
+                                                  int tid, RowMap rowmap) {
+    constexpr int CP = BN + 8, TPR = BN / 4, RPS = 256 / TPR;
+    const int c4 = (tid % TPR) * 4, co = n_base + c4;
+    if (co >= a.Cout) return;
+    const int nval = a.Cout - co < 4 ? a.Cout - co : 4;
+    const bool vec = a.vec != 0;
+    const bool direct = (a.os == 1 && a.QH == a.OH && a.QW == a.OW);
+    const int qhw = a.QH * a.QW;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) cdf_ld4(bv, a.bias + co, nval, vec);
+    for (int p = tid / TPR; p < RP; p += RPS) {
+        const int m = m_base + rowmap(p);
+        if (m >= M) continue;
+        long long opix;
+        int b;
+        if (direct) {
+            opix = m;
+            b = m / qhw;
+        } else {
+            const int qx = m % a.QW, t2 = m / a.QW;
+            const int qy = t2 % a.QH;
+            b = t2 / a.QH;
+            opix = ((long long)b * a.OH + qy * a.os + ph.oy) * a.OW + qx * a.os + ph.ox;
+        }
+        const float4 t = *(const float4*)(cs + p * CP + c4);
+        float v[4] = {t.x + bv[0], t.y + bv[1], t.z + bv[2], t.w + bv[3]};
+        float u[4];
+        if (a.sbias) {
+            cdf_ld4(u, a.sbias + (long long)b * a.ld_sbias + co, nval, vec);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += u[e];
+        }
+        if (a.pre) cdf_st4(a.pre + opix * a.ldp + co, v, nval, vec);
+        if (a.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = cdf_gelu(v[e]);
+        } else if (a.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = cdf_silu(v[e]);
+        }
+        if (a.mul_mode) {
+            cdf_ld4(u, a.mul + opix * a.ldm + co, nval, vec);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= (a.mul_mode == 1 ? cdf_gelu_grad(u[e]) : (a.mul_mode == 2 ? cdf_silu_grad(u[e]) : u[e]));
+        }
+        if (a.res) {
+            cdf_ld4(u, a.res + opix * a.ldr + co, nval, vec);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += u[e];
+        }
+        float* dst = Y + opix * a.ldy + co;
+        if (a.accumulate) {
+            cdf_ld4(u, dst, nval, vec);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += u[e];
+        }
+        cdf_st4(dst, v, nval, vec);
+    }
+}

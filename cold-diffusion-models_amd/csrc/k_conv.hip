@@ -19,6 +19,7 @@
 // The MFMA k index is free as long as A and B agree, so lane half h owns k = 8h..8h+7 of the
 // chunk: its A fragment is two ds_read_b128 (row stride 20 floats -> conflict-free).
 #include "cdf_common.h"
+#include "cdf_epilogue.h"
 #include "colddiff.h"
 
 #define CDF_MAX_TAPS 16
@@ -42,7 +43,7 @@ struct ConvArgs {
     int act;         // 0 none, 1 GELU, 2 SiLU
     int mul_mode;    // 0 none, 1 v*=gelu'(mul), 2 v*=silu'(mul), 3 v*=mul
     int accumulate;  // y += v
-    int nphase;
+    int nphase, vec;
     long long x_bs, w_bs, y_bs;     // blockIdx.z = outer*batch2 + inner: outer batch strides (elements)
     long long x_bs2, w_bs2, y_bs2;  // inner batch strides (e.g. attention heads)
     int batch2;
@@ -65,8 +66,12 @@ __global__ void __launch_bounds__(256, 4) conv_igemm_kernel(ConvArgs a) {
     constexpr int BVEC = BK * BN / 4;               // float4 per B tile
     constexpr int BPASS = (BVEC + 255) / 256;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
-    __shared__ __attribute__((aligned(16))) float As[2][BM * AS];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+    constexpr int ASZ = BM * AS, BSZ = BK * BN;
+    constexpr int EPI_ROWS = (BM / WM) * 32, EPI_SZ = EPI_ROWS * (BN + 8);      // one 32-row slab per wave row, see epilogue
+    constexpr int SMEM = 2 * (ASZ + BSZ) > EPI_SZ ? 2 * (ASZ + BSZ) : EPI_SZ;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float (*As)[ASZ] = (float (*)[ASZ])smem;
+    float (*Bs)[BSZ] = (float (*)[BSZ])(smem + 2 * ASZ);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -201,46 +206,19 @@ __global__ void __launch_bounds__(256, 4) conv_igemm_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue ---------------------------------------------------------------------------------
-    const bool direct = (a.os == 1 && a.QH == a.OH && a.QW == a.OW);
+    // ---- epilogue: MT passes of one 32-row slab per wave through LDS, float4 rows out (cdf_epilogue.h) ----
+    constexpr int CP = BN + 8;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+        if (i > 0) __syncthreads();          // previous pass fully read (the K loop itself ends with a barrier)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int m = tile_m * BM + row;
-            if (m >= M) continue;
-            long long opix;
-            int b;
-            if (direct) {
-                opix = m;
-                b = m / (a.QH * a.QW);
-            } else {
-                const int qx = m % a.QW, t2 = m / a.QW;
-                const int qy = t2 % a.QH;
-                b = t2 / a.QH;
-                opix = ((long long)b * a.OH + qy * a.os + ph.oy) * a.OW + qx * a.os + ph.ox;
-            }
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int co = tile_n * BN + wn * WN + j * 32 + l31;
-                if (co >= a.Cout) continue;
-                float v = acc[i][j][r];
-                if (a.bias) v += a.bias[co];
-                if (a.sbias) v += a.sbias[(long long)b * a.ld_sbias + co];
-                if (a.pre) a.pre[opix * a.ldp + co] = v;
-                if (a.act == 1) v = cdf_gelu(v);
-                else if (a.act == 2) v = cdf_silu(v);
-                if (a.mul_mode) {
-                    const float mv = a.mul[opix * a.ldm + co];
-                    v *= (a.mul_mode == 1 ? cdf_gelu_grad(mv) : (a.mul_mode == 2 ? cdf_silu_grad(mv) : mv));
-                }
-                if (a.res) v += a.res[opix * a.ldr + co];
-                float* dst = Y + opix * a.ldy + co;
-                if (a.accumulate) v += *dst;
-                *dst = v;
-            }
-        }
+            for (int r = 0; r < 16; ++r)
+                smem[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * WN + j * 32 + l31] = acc[i][j][r];
+        __syncthreads();
+        cdf_epilogue_rows<BN, EPI_ROWS>(a, ph, Y, smem, tile_m * BM, tile_n * BN, M, tid,
+                                        [i](int p) { return (p >> 5) * WM + i * 32 + (p & 31); });
     }
 }
 
@@ -568,6 +546,7 @@ extern "C" int cdf_conv_gemm(const float* x, int ldx, const float* w, int ldw, f
     a.os = os; a.is = is; a.act = act; a.mul_mode = mul_mode; a.accumulate = accumulate; a.nphase = nphase;
     a.x_bs = x_bs; a.w_bs = w_bs; a.y_bs = y_bs;
     a.x_bs2 = x_bs2; a.w_bs2 = w_bs2; a.y_bs2 = y_bs2; a.batch2 = batch2;
+    a.vec = cdf_epi_vec_ok(Cout, y, ldy, bias, sbias, ld_sbias, res, ldr, pre, ldp, mul, ldm) && y_bs % 4 == 0 && y_bs2 % 4 == 0;
     batch *= batch2;
     // phase_desc: per phase [oy, ox, ntaps, (dy, dx, wi) * ntaps]
     const int* pd = phase_desc;

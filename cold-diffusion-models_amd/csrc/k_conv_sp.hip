@@ -14,6 +14,7 @@
 //   * activations stay fp32 in HBM and are split while being written to LDS (VALU work hidden under MFMA);
 //   * BK = 32, LDS rows are 40 bf16 (80 B) so that every ds_read_b128 fragment read is conflict-free.
 #include "cdf_common.h"
+#include "cdf_epilogue.h"
 #include "colddiff.h"
 
 #define CDF_MAX_TAPS 16
@@ -37,39 +38,9 @@ struct SpPhase {
 #define CDF_ABLATE 0     // tuning aid (tools/ablate.py): bit 0 no global loads in the K loop, 1 no MFMA, 2 no epilogue stores,
 #endif                   // 3 no LDS stores in the K loop, 4 no LDS fragment reads.  Always 0 in the product build.
 
-// ------------------------------------------------------------------------------------------------
-// Shared epilogue of the 128x128 bf16 GEMM tiles.  The MFMA accumulator layout gives each lane ONE
-// channel of 16 scattered pixels, i.e. dword stores of two 128-byte pieces per instruction -- measured at
-// ~1 TB/s, 40 % of the whole kernel on the 128x128-pixel layers.  The tile is therefore transposed through
-// LDS (free once the K loop is over): [128 px][136] fp32 (pitch 136: the two half-waves of a ds_write_b32
-// land 32 banks apart), then every lane owns 4 consecutive channels of a pixel -> float4 loads/stores of the
-// output and of every fused operand (bias, per-sample bias, pre-activation, activation-gradient source,
-// residual), 32 lanes = one full 512-byte pixel row.
-// `vec` (host-computed) = all pitches % 4 == 0, Cout % 4 == 0 and 16-byte-aligned pointers; otherwise the
-// same code runs with per-element accesses.
-// ------------------------------------------------------------------------------------------------
+// 128x128 tile, 4 waves of 64x64: the whole tile goes through LDS in one pass (cdf_epilogue.h).
 constexpr int CDF_SP_CPITCH = 136;
 constexpr size_t CDF_SP_EPI_LDS = (size_t)128 * CDF_SP_CPITCH * sizeof(float);
-
-__device__ __forceinline__ void cdf_ld4(float* v, const float* p, int n, bool vec) {
-    if (vec) {
-        const float4 t = *(const float4*)p;
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = e < n ? p[e] : 0.f;
-    }
-}
-
-__device__ __forceinline__ void cdf_st4(float* p, const float* v, int n, bool vec) {
-    if (vec) {
-        *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (e < n) p[e] = v[e];
-    }
-}
 
 template <class Args>
 __device__ __forceinline__ void cdf_sp_epilogue(const Args& a, const SpPhase& ph, const f32x16_t (&acc)[2][2], float* cs, int tile_m,
@@ -88,64 +59,8 @@ __device__ __forceinline__ void cdf_sp_epilogue(const Args& a, const SpPhase& ph
 #if CDF_ABLATE & 4
     if (acc[0][0][0] != 12345.678f) return;
 #endif
-    const int c4 = (tid & 31) * 4, co = tile_n * 128 + c4;
-    if (co >= a.Cout) return;
-    const int nval = a.Cout - co < 4 ? a.Cout - co : 4;
-    const bool vec = a.vec != 0;
-    const bool direct = (a.os == 1 && a.QH == a.OH && a.QW == a.OW);
-    const int qhw = a.QH * a.QW;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias) cdf_ld4(bv, a.bias + co, nval, vec);
-    for (int rr = tid >> 5; rr < 128; rr += 8) {
-        const int m = tile_m * 128 + rr;
-        if (m >= M) break;
-        long long opix;
-        int b;
-        if (direct) {
-            opix = m;
-            b = m / qhw;
-        } else {
-            const int qx = m % a.QW, t2 = m / a.QW;
-            const int qy = t2 % a.QH;
-            b = t2 / a.QH;
-            opix = ((long long)b * a.OH + qy * a.os + ph.oy) * a.OW + qx * a.os + ph.ox;
-        }
-        const float4 t = *(const float4*)(cs + rr * CP + c4);
-        float v[4] = {t.x + bv[0], t.y + bv[1], t.z + bv[2], t.w + bv[3]};
-        float u[4];
-        if (a.sbias) {
-            cdf_ld4(u, a.sbias + (long long)b * a.ld_sbias + co, nval, vec);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += u[e];
-        }
-        if (a.pre) cdf_st4(a.pre + opix * a.ldp + co, v, nval, vec);
-        if (a.act == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = cdf_gelu(v[e]);
-        } else if (a.act == 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = cdf_silu(v[e]);
-        }
-        if (a.mul_mode) {
-            cdf_ld4(u, a.mul + opix * a.ldm + co, nval, vec);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= (a.mul_mode == 1 ? cdf_gelu_grad(u[e]) : (a.mul_mode == 2 ? cdf_silu_grad(u[e]) : u[e]));
-        }
-        if (a.res) {
-            cdf_ld4(u, a.res + opix * a.ldr + co, nval, vec);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += u[e];
-        }
-        float* dst = a.y + opix * a.ldy + co;
-        if (a.accumulate) {
-            cdf_ld4(u, dst, nval, vec);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += u[e];
-        }
-        cdf_st4(dst, v, nval, vec);
-    }
+    cdf_epilogue_rows<128, 128>(a, ph, a.y, cs, tile_m * 128, tile_n * 128, M, tid, [](int p) { return p; });
 }
-
 
 struct SpArgs {
     const float* x;
@@ -934,13 +849,6 @@ extern "C" int cdf_pack_weight_bf16(const float* src, void* dst_hi, void* dst_lo
     return cdf_check_launch("pack_weight_bf16");
 }
 
-static int cdf_sp_vec_ok(int Cout, const float* y, int ldy, const float* bias, const float* sbias, int ld_sbias, const float* res, int ldr,
-                         const float* pre, int ldp, const float* mul, int ldm) {
-    const uintptr_t ptrs = (uintptr_t)y | (uintptr_t)bias | (uintptr_t)sbias | (uintptr_t)res | (uintptr_t)pre | (uintptr_t)mul;
-    const int pitches = ldy | (sbias ? ld_sbias : 0) | (res ? ldr : 0) | (pre ? ldp : 0) | (mul ? ldm : 0);
-    return (Cout % 4 == 0 && (ptrs & 15) == 0 && (pitches & 3) == 0) ? 1 : 0;
-}
-
 extern "C" int cdf_conv_gemm_bf16(const float* x, int ldx, const void* w_hi, const void* w_lo, int ldk, float* y, int ldy, int B,
                                   int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW, int os, int is, int nphase,
                                   const int* phase_desc, const float* bias, const float* sbias, int ld_sbias, const float* res,
@@ -957,7 +865,7 @@ extern "C" int cdf_conv_gemm_bf16(const float* x, int ldx, const void* w_hi, con
     a.ldx = ldx; a.ldk = ldk; a.ldy = ldy; a.ld_sbias = ld_sbias; a.ldr = ldr; a.ldp = ldp; a.ldm = ldm;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.QH = QH; a.QW = QW; a.os = os; a.is = is;
     a.act = act; a.mul_mode = mul_mode; a.accumulate = accumulate; a.nphase = nphase;
-    a.vec = cdf_sp_vec_ok(Cout, y, ldy, bias, sbias, ld_sbias, res, ldr, pre, ldp, mul, ldm);
+    a.vec = cdf_epi_vec_ok(Cout, y, ldy, bias, sbias, ld_sbias, res, ldr, pre, ldp, mul, ldm);
     const int* pd = phase_desc;
     for (int p = 0; p < nphase; ++p) {
         a.ph[p].oy = pd[0]; a.ph[p].ox = pd[1]; a.ph[p].ntaps = pd[2];
@@ -1060,7 +968,7 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
     a.ldx = ldx; a.ldk = ldk; a.ldy = ldy; a.ld_sbias = ld_sbias; a.ldr = ldr; a.ldp = ldp; a.ldm = ldm;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.QH = QH; a.QW = QW; a.os = os; a.is = is;
     a.act = act; a.mul_mode = mul_mode; a.accumulate = accumulate; a.nphase = nphase;
-    a.vec = cdf_sp_vec_ok(Cout, y, ldy, bias, sbias, ld_sbias, res, ldr, pre, ldp, mul, ldm);
+    a.vec = cdf_epi_vec_ok(Cout, y, ldy, bias, sbias, ld_sbias, res, ldr, pre, ldp, mul, ldm);
     int rc = fill_phases(a.ph, nphase, phase_desc, "cdf_conv_gemm_bf16x");
     if (rc) return rc;
 #ifndef CDF_EMU
