@@ -186,9 +186,9 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None, xa_s=No
     B = xa.shape[0]
     M = B * wplan.QH * wplan.QW
     ldo = r4(CB)
-    if xa_s is not None and xb_s is not None and CA >= 128 and CB >= 128 and M >= 2048:
-        # both operands already split into bf16 hi/lo planes: copy + MFMA only
-        tiles = ((CA + 127) // 128) * ((CB + 127) // 128) * wplan.ntaps
+    if xa_s is not None and xb_s is not None and CA >= 64 and CB >= 64 and M >= 2048:
+        # both operands already split into bf16 hi/lo planes: copy + MFMA only (64-wide tiles for 64-channel sides)
+        tiles = (1 if CA <= 64 else (CA + 127) // 128) * (1 if CB <= 64 else (CB + 127) // 128) * wplan.ntaps
         ns = best_nsplit(tiles, 512, M // 512)
         ws = torch.empty((ns, wplan.ntaps, CA, ldo), device=xa.device, dtype=torch.float32)
         S = rt.stream(xa)

@@ -19,14 +19,21 @@
 
 #define CDF_MAX_TAPS 16
 
+typedef short bf16x8_v __attribute__((ext_vector_type(8)));
+typedef short bf16x4_v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_v __attribute__((ext_vector_type(4)));
 #ifdef CDF_EMU
 #define CDF_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
-typedef short bf16x8_v __attribute__((ext_vector_type(8)));
+static inline bf16x4_v cdf_lds_read_tr16(const unsigned short* p) { return hipemu::ds_read_tr16_b64(p); }
 #else
-typedef short bf16x8_v __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
 #define CDF_MFMA_BF16(a, b, c) \
     __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0)
+// ds_read_b64_tr_b16: the 16 lanes of a group pass the addresses of a [4 rows][16 cols] bf16 block (lane t: row t >> 2,
+// cols 4 (t & 3) .. +3, 8-byte aligned, any row pitch); lane t gets column t's 4 rows.
+__device__ __forceinline__ bf16x4_v cdf_lds_read_tr16(const unsigned short* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_v*)p);
+}
 #endif
 
 struct SpPhase {
@@ -661,25 +668,46 @@ struct SpxWgradArgs {
     signed char day[CDF_MAX_TAPS], dax[CDF_MAX_TAPS], dby[CDF_MAX_TAPS], dbx[CDF_MAX_TAPS];
 };
 
-__device__ __forceinline__ void cdf_bf16x8_accum(float* acc8, const uint4& h, const uint4& l) {
-    const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+__device__ __forceinline__ void cdf_bf16x8_accum(float* acc8, const u32x4_v& h, const u32x4_v& l) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        acc8[2 * e] += __uint_as_float(hw[e] << 16) + __uint_as_float(lw[e] << 16);
-        acc8[2 * e + 1] += __uint_as_float(hw[e] & 0xFFFF0000u) + __uint_as_float(lw[e] & 0xFFFF0000u);
+        acc8[2 * e] += __uint_as_float(h[e] << 16) + __uint_as_float(l[e] << 16);
+        acc8[2 * e + 1] += __uint_as_float(h[e] & 0xFFFF0000u) + __uint_as_float(l[e] & 0xFFFF0000u);
     }
 }
 
+// Tile TA (ca) x TB (cb), each 64 or 128; 4 waves as 2 x 2 of (TA/2) x (TB/2); BK = 32 pixels.
+// The contraction index (pixels) is the SLOW index of both NHWC operands, so the LDS tiles stay pixel-major,
+// [32 px][T + 32] bf16 per plane, written with ds_write_b128 exactly as loaded.  The MFMA fragment (8
+// consecutive pixels of one channel per lane) comes out of two ds_read_b64_tr_b16 -- gfx950's transposing LDS
+// read: the 16 lanes of a group hand in the addresses of a [4 px][16 ch] block (lane t: pixel t>>2, channels
+// 4(t&3)..+3) and lane t receives channel t's 4 pixels.  Pitch T+32 puts the 4 pixel rows of a group 16 banks
+// apart and the second group of the 32-lane pass 8 banks further: conflict-free.
+#ifndef CDF_WGRAD_TR
+#define CDF_WGRAD_TR 1
+#endif
+
+template <int T>
+struct SpxWgradSlot {                  // one operand's share of a thread's loads for a 32-pixel chunk
+    static constexpr int VPR = T / 8;              // uint4 per pixel row
+    static constexpr int PASS = 32 * VPR / 256;    // T/64
+    static constexpr int PPP = 256 / VPR;          // pixels per pass
+    static constexpr int PITCH = T + 32;
+};
+
+template <int TA, int TB>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) {
-    constexpr int BC = 128, BK = 32;
-    constexpr int PLANE = BK * BC;
-    constexpr int STAGE = 4 * PLANE;
+    using SA = SpxWgradSlot<TA>;
+    using SB = SpxWgradSlot<TB>;
+    constexpr int BK = 32, MT = TA / 64, NT = TB / 64;
+    constexpr int PLANE_A = BK * SA::PITCH, PLANE_B = BK * SB::PITCH;
+    constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;
     CDF_DYN_SMEM(smem_raw);
     unsigned short* smem = (unsigned short*)smem_raw;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_b = (a.CB + BC - 1) / BC;
+    const int tiles_b = (a.CB + TB - 1) / TB;
     const int tile_a = blockIdx.x / tiles_b, tile_b = blockIdx.x - tile_a * tiles_b;
     const int tap = blockIdx.y, split = blockIdx.z;
     const int M = a.B * a.QH * a.QW;
@@ -689,74 +717,105 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
     const int niter = m_hi > m_lo ? (m_hi - m_lo + BK - 1) / BK : 0;
     const int day = a.day[tap], dax = a.dax[tap], dby = a.dby[tap], dbx = a.dbx[tap];
 
-    // load slots: pixel k = (tid >> 4) + 16 p (p = 0, 1), 16-byte channel column c8 = (tid & 15) * 8
-    const int c8 = (tid & 15) * 8;
-    int q[2][3];
+    // load slots: operand X, pass p: pixel (tid / VPR) + PPP p of the chunk, 16-byte channel column (tid % VPR) * 8
+    const int ca = tile_a * TA + (tid % SA::VPR) * 8, cb = tile_b * TB + (tid % SB::VPR) * 8;
+    int qa[SA::PASS][3], qb[SB::PASS][3];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int m = m_lo + (tid >> 4) + 16 * p;
-        q[p][0] = m % a.QW;
+    for (int p = 0; p < SA::PASS; ++p) {
+        const int m = m_lo + tid / SA::VPR + SA::PPP * p;
+        qa[p][0] = m % a.QW;
         const int t2 = m / a.QW;
-        q[p][1] = t2 % a.QH;
-        q[p][2] = t2 / a.QH;
+        qa[p][1] = t2 % a.QH;
+        qa[p][2] = t2 / a.QH;
+    }
+#pragma unroll
+    for (int p = 0; p < SB::PASS; ++p) {
+        const int m = m_lo + tid / SB::VPR + SB::PPP * p;
+        qb[p][0] = m % a.QW;
+        const int t2 = m / a.QW;
+        qb[p][1] = t2 % a.QH;
+        qb[p][2] = t2 / a.QH;
     }
     const bool do_bsum = a.bsum != nullptr && tile_a == 0 && tap == 0;
-    float bs_acc[2][8];
+    float bs_acc[SB::PASS][8];
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < SB::PASS; ++p)
 #pragma unroll
         for (int e = 0; e < 8; ++e) bs_acc[p][e] = 0.f;
-    const int ca = tile_a * BC + c8, cb = tile_b * BC + c8;
 
-    uint4 rah0, rah1, ral0, ral1, rbh0, rbh1, rbl0, rbl1;
-    auto load_one = [&](int p, int m0, uint4& ah, uint4& al, uint4& bh, uint4& bl) {
-        const int m = m0 + (tid >> 4) + 16 * p;
-        const int qx = q[p][0], qy = q[p][1], b = q[p][2];
-        const unsigned ay = (unsigned)(qy * a.sa + day), ax = (unsigned)(qx * a.sa + dax);
-        const unsigned by = (unsigned)(qy * a.sb + dby), bx = (unsigned)(qx * a.sb + dbx);
-        const bool bok = m < m_hi && by < (unsigned)a.HB && bx < (unsigned)a.WB;
-        const bool aok = bok && ay < (unsigned)a.HA && ax < (unsigned)a.WA && ca < a.CA;
-        const bool bok2 = bok && cb < a.CB;
-        const long long offa = (((long long)b * a.HA + ay) * a.WA + ax) * a.lda + ca;
-        const long long offb = (((long long)b * a.HB + by) * a.WB + bx) * a.ldb + cb;
-        ah = *(const uint4*)(aok ? a.a_hi + offa : a.zero);
-        al = *(const uint4*)(aok ? a.a_lo + offa : a.zero);
-        bh = *(const uint4*)(bok2 ? a.b_hi + offb : a.zero);
-        bl = *(const uint4*)(bok2 ? a.b_lo + offb : a.zero);
-        q[p][0] += BK;
-        while (q[p][0] >= a.QW) {
-            q[p][0] -= a.QW;
-            if (++q[p][1] >= a.QH) { q[p][1] = 0; ++q[p][2]; }
-        }
-        if (do_bsum) cdf_bf16x8_accum(bs_acc[p], bh, bl);
+    // Everything below is straight-line code on purpose: a divergent branch or loop between the loads makes hipcc
+    // wait for the loads already in flight before it (measured: the prefetch of a chunk degenerates into four
+    // dependent round trips).  The (qx, qy, b) carry uses an exact float reciprocal: q + 0.5 is never a multiple
+    // of the divisor and both stay tiny (q < QW + 32), so the truncation is exact.
+    const float rcp_qw = 1.0f / (float)a.QW, rcp_qh = 1.0f / (float)a.QH;
+    auto advance = [&](int* q) {
+        const int x = q[0] + BK;
+        const int cx = (int)(((float)x + 0.5f) * rcp_qw);
+        q[0] = x - cx * a.QW;
+        const int y = q[1] + cx;
+        const int cy = (int)(((float)y + 0.5f) * rcp_qh);
+        q[1] = y - cy * a.QH;
+        q[2] += cy;
     };
+    u32x4_v rah[SA::PASS], ral[SA::PASS], rbh[SB::PASS], rbl[SB::PASS];   // (arrays of HIP uint4 structs would live in scratch)
     auto load_global = [&](int it) {
         const int m0 = m_lo + it * BK;
-        load_one(0, m0, rah0, ral0, rbh0, rbl0);
-        load_one(1, m0, rah1, ral1, rbh1, rbl1);
+#pragma unroll
+        for (int p = 0; p < SA::PASS; ++p) {
+            // an operand row is zero when its own tap falls outside its image: the product then vanishes whatever
+            // the other side holds (and the B rows stay intact for the fused bias gradient)
+            const int m = m0 + tid / SA::VPR + SA::PPP * p;
+            const unsigned ay = (unsigned)(qa[p][1] * a.sa + day), ax = (unsigned)(qa[p][0] * a.sa + dax);
+            const bool ok = m < m_hi && ay < (unsigned)a.HA && ax < (unsigned)a.WA && ca < a.CA;
+            const unsigned pix = ((unsigned)qa[p][2] * (unsigned)a.HA + ay) * (unsigned)a.WA + ax;
+            const size_t off = (size_t)pix * (unsigned)a.lda + (unsigned)ca;
+            rah[p] = *(const u32x4_v*)(ok ? a.a_hi + off : a.zero);
+            ral[p] = *(const u32x4_v*)(ok ? a.a_lo + off : a.zero);
+            advance(qa[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < SB::PASS; ++p) {
+            const int m = m0 + tid / SB::VPR + SB::PPP * p;
+            const unsigned by = (unsigned)(qb[p][1] * a.sb + dby), bx = (unsigned)(qb[p][0] * a.sb + dbx);
+            const bool ok = m < m_hi && by < (unsigned)a.HB && bx < (unsigned)a.WB && cb < a.CB;
+            const unsigned pix = ((unsigned)qb[p][2] * (unsigned)a.HB + by) * (unsigned)a.WB + bx;
+            const size_t off = (size_t)pix * (unsigned)a.ldb + (unsigned)cb;
+            rbh[p] = *(const u32x4_v*)(ok ? a.b_hi + off : a.zero);
+            rbl[p] = *(const u32x4_v*)(ok ? a.b_lo + off : a.zero);
+            advance(qb[p]);
+        }
     };
-    const int so0 = (tid >> 4) * BC + c8, so1 = ((tid >> 4) + 16) * BC + c8;
     auto store_lds = [&](int buf) {
         unsigned short* st = smem + buf * STAGE;
-        *(uint4*)(st + so0) = rah0;
-        *(uint4*)(st + so1) = rah1;
-        *(uint4*)(st + PLANE + so0) = ral0;
-        *(uint4*)(st + PLANE + so1) = ral1;
-        *(uint4*)(st + 2 * PLANE + so0) = rbh0;
-        *(uint4*)(st + 2 * PLANE + so1) = rbh1;
-        *(uint4*)(st + 3 * PLANE + so0) = rbl0;
-        *(uint4*)(st + 3 * PLANE + so1) = rbl1;
+#pragma unroll
+        for (int p = 0; p < SA::PASS; ++p) {
+            const int so = (tid / SA::VPR + SA::PPP * p) * SA::PITCH + (tid % SA::VPR) * 8;
+            *(u32x4_v*)(st + so) = rah[p];
+            *(u32x4_v*)(st + PLANE_A + so) = ral[p];
+        }
+#pragma unroll
+        for (int p = 0; p < SB::PASS; ++p) {
+            const int so = (tid / SB::VPR + SB::PPP * p) * SB::PITCH + (tid % SB::VPR) * 8;
+            *(u32x4_v*)(st + 2 * PLANE_A + so) = rbh[p];
+            *(u32x4_v*)(st + 2 * PLANE_A + PLANE_B + so) = rbl[p];
+            if (do_bsum) cdf_bf16x8_accum(bs_acc[p], rbh[p], rbl[p]);     // here the loads have landed anyway
+        }
     };
 
-    f32x16_t acc[2][2];
+    f32x16_t acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int half = lane >> 5, l31 = lane & 31;
+    // transposing-read lane geometry: group g = lane >> 4 -> channel block 16 (g & 1), pixel block 8 (g >> 1)
+    const int t16 = lane & 15, g16 = lane >> 4;
+    const int tr_row = (g16 >> 1) * 8 + (t16 >> 2), tr_col = (g16 & 1) * 16 + (t16 & 3) * 4;
+    const int tra = tr_row * SA::PITCH + wm * (TA / 2) + tr_col;
+    const int trb = tr_row * SB::PITCH + wn * (TB / 2) + tr_col;
     if (niter > 0) {
         load_global(0);
         store_lds(0);
@@ -765,27 +824,49 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
     for (int it = 0; it < niter; ++it) {
         const int buf = it & 1;
         if (it + 1 < niter) load_global(it + 1);
-        const unsigned short* st = smem + buf * STAGE;
+        const unsigned short* sa = smem + buf * STAGE;
+        const unsigned short* sb = sa + 2 * PLANE_A;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int k0 = ks * 16 + half * 8;
-            bf16x8_v ah[2], al[2], bh[2], bl[2];
+            bf16x8_v ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const unsigned short* pa = st + k0 * BC + wm * 64 + i * 32 + l31;
-                const unsigned short* pb = st + 2 * PLANE + k0 * BC + wn * 64 + i * 32 + l31;
+            for (int i = 0; i < MT; ++i) {
+#if CDF_WGRAD_TR
+                const unsigned short* pa = sa + tra + ks * 16 * SA::PITCH + i * 32;
+                const bf16x4_v h0 = cdf_lds_read_tr16(pa), h1 = cdf_lds_read_tr16(pa + 4 * SA::PITCH);
+                const bf16x4_v l0 = cdf_lds_read_tr16(pa + PLANE_A), l1 = cdf_lds_read_tr16(pa + PLANE_A + 4 * SA::PITCH);
+                ah[i] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                al[i] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+#else
+                const unsigned short* pa = sa + (ks * 16 + half * 8) * SA::PITCH + wm * (TA / 2) + i * 32 + l31;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    ah[i][e] = (short)pa[e * BC];
-                    al[i][e] = (short)pa[PLANE + e * BC];
-                    bh[i][e] = (short)pb[e * BC];
-                    bl[i][e] = (short)pb[PLANE + e * BC];
+                    ah[i][e] = (short)pa[e * SA::PITCH];
+                    al[i][e] = (short)pa[PLANE_A + e * SA::PITCH];
                 }
+#endif
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < NT; ++j) {
+#if CDF_WGRAD_TR
+                const unsigned short* pb = sb + trb + ks * 16 * SB::PITCH + j * 32;
+                const bf16x4_v h0 = cdf_lds_read_tr16(pb), h1 = cdf_lds_read_tr16(pb + 4 * SB::PITCH);
+                const bf16x4_v l0 = cdf_lds_read_tr16(pb + PLANE_B), l1 = cdf_lds_read_tr16(pb + PLANE_B + 4 * SB::PITCH);
+                bh[j] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                bl[j] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+#else
+                const unsigned short* pb = sb + (ks * 16 + half * 8) * SB::PITCH + wn * (TB / 2) + j * 32 + l31;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int e = 0; e < 8; ++e) {
+                    bh[j][e] = (short)pb[e * SB::PITCH];
+                    bl[j][e] = (short)pb[PLANE_B + e * SB::PITCH];
+                }
+#endif
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
                     acc[i][j] = CDF_MFMA_BF16(al[i], bh[j], acc[i][j]);
                     acc[i][j] = CDF_MFMA_BF16(ah[i], bl[j], acc[i][j]);
                     acc[i][j] = CDF_MFMA_BF16(ah[i], bh[j], acc[i][j]);
@@ -795,33 +876,48 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
         __syncthreads();
     }
 
-    if (do_bsum) {
-        float* red = (float*)smem;                 // [32 px][128] floats (stage 0 is idle now)
+    float* red = (float*)smem_raw;
+    if (do_bsum) {                                 // [32 px][TB] partial column sums -> one row
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < SB::PASS; ++p)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[((tid >> 4) + 16 * p) * BC + c8 + e] = bs_acc[p][e];
+            for (int e = 0; e < 8; ++e) red[(tid / SB::VPR + SB::PPP * p) * TB + (tid % SB::VPR) * 8 + e] = bs_acc[p][e];
         __syncthreads();
-        for (int c = tid; c < BC; c += 256) {
+        for (int c = tid; c < TB; c += 256) {
             float t = 0.f;
-            for (int k = 0; k < BK; ++k) t += red[k * BC + c];
-            const int cc = tile_b * BC + c;
+            for (int k = 0; k < BK; ++k) t += red[k * TB + c];
+            const int cc = tile_b * TB + c;
             if (cc < a.ldo) a.bsum[(long long)split * a.ldo + cc] = cc < a.CB ? t : 0.f;
         }
+        __syncthreads();
     }
+    // accumulators -> LDS [TA][TB + 8] -> float4 rows of the split's partial-sum slab (see cdf_epilogue.h)
+    constexpr int CP = TB + 8;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                red[(wm * (TA / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * (TB / 2) + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
     float* O = a.out + ((long long)split * a.ntaps + tap) * a.CA * a.ldo;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = tile_a * BC + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (row >= a.CA) continue;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = tile_b * BC + wn * 64 + j * 32 + l31;
-                if (col < a.ldo) O[(long long)row * a.ldo + col] = col < a.CB ? acc[i][j][r] : 0.f;
+    constexpr int TPR = TB / 4, RPS = 256 / TPR;
+    const int c4 = (tid % TPR) * 4, col = tile_b * TB + c4;
+    if (col < a.ldo) {
+        for (int r = tid / TPR; r < TA; r += RPS) {
+            const int row = tile_a * TA + r;
+            if (row >= a.CA) break;
+            float4 v = *(const float4*)(red + r * CP + c4);
+            if (col + 3 >= a.CB) {                 // zero the pitch padding (ldo % 4 == 0 keeps the store in bounds)
+                if (col + 0 >= a.CB) v.x = 0.f;
+                if (col + 1 >= a.CB) v.y = 0.f;
+                if (col + 2 >= a.CB) v.z = 0.f;
+                v.w = 0.f;
             }
+            *(float4*)(O + (long long)row * a.ldo + col) = v;
         }
+    }
 }
 
 // dst_hi/lo[t][r][c] (c < ldc, zero padded) = split(src[c*s_c + r*s_r + t*s_t])
@@ -985,6 +1081,23 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
     return cdf_check_launch("conv_igemm_spx");
 }
 
+template <int TA, int TB>
+static int launch_wgrad_spx(const SpxWgradArgs& a, hipStream_t s) {
+    constexpr size_t stage = (size_t)2 * 32 * ((TA + 32) + (TB + 32)) * sizeof(unsigned short);
+    constexpr size_t epi = (size_t)TA * (TB + 8) * sizeof(float);
+    constexpr size_t lds = 2 * stage > epi ? 2 * stage : epi;
+#ifndef CDF_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_spx_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+#endif
+    const int tiles = cdf_cdiv(a.CA, TA) * cdf_cdiv(a.CB, TB);
+    CDF_LAUNCH((conv_wgrad_spx_kernel<TA, TB>), dim3(tiles, a.ntaps, a.nsplit), dim3(256), lds, s, a);
+    return cdf_check_launch("conv_wgrad_spx");
+}
+
 extern "C" int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, int ldb,
                                     const void* zero, float* ws, int ldo, int B, int QH, int QW, int HA, int WA, int sa, int HB, int WB,
                                     int sb, int CA, int CB, int ntaps, const int* tap_desc, int nsplit, float* bsum, void* stream) {
@@ -1006,15 +1119,9 @@ extern "C" int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda,
         a.dby[t] = (signed char)tap_desc[4 * t + 2];
         a.dbx[t] = (signed char)tap_desc[4 * t + 3];
     }
-#ifndef CDF_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_spx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-#endif
-    const size_t lds = (size_t)2 * 4 * 32 * 128 * sizeof(unsigned short);
-    const int tiles = cdf_cdiv(CA, 128) * cdf_cdiv(CB, 128);
-    CDF_LAUNCH(conv_wgrad_spx_kernel, dim3(tiles, ntaps, nsplit), dim3(256), lds, CDF_S, a);
-    return cdf_check_launch("conv_wgrad_spx");
+    // thin layers get 64-wide tiles so that no half of a tile multiplies padding
+    if (CA <= 64 && CB <= 64) return launch_wgrad_spx<64, 64>(a, CDF_S);
+    if (CA <= 64) return launch_wgrad_spx<64, 128>(a, CDF_S);
+    if (CB <= 64) return launch_wgrad_spx<128, 64>(a, CDF_S);
+    return launch_wgrad_spx<128, 128>(a, CDF_S);
 }

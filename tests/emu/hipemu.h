@@ -143,6 +143,24 @@ inline T shfl_from(T v, int src_lane) {
     return r;
 }
 
+// gfx950 ds_read_b64_tr_b16: within each 16-lane group the lanes hand in the addresses of a [4 rows][16 cols]
+// block of 16-bit elements (lane t: row t >> 2, cols 4 (t & 3) .. +3) and lane t receives column t's 4 rows.
+// (semantics pinned on hardware with a probe kernel: see DESIGN.md, wgrad section)
+typedef short emu_s4 __attribute__((ext_vector_type(4)));
+inline emu_s4 ds_read_tr16_b64(const unsigned short* p) {
+    int w = wave_id(), l = lane_id();
+    g.wave_u[w][l] = (unsigned long long)(uintptr_t)p;
+    wave_barrier();
+    int grp = l & ~15, t = l & 15;
+    emu_s4 r;
+    for (int j = 0; j < 4; ++j) {
+        const unsigned short* q = (const unsigned short*)(uintptr_t)g.wave_u[w][grp + j * 4 + (t >> 2)];
+        r[j] = (short)q[t & 3];
+    }
+    wave_barrier();
+    return r;
+}
+
 }  // namespace hipemu
 
 #define threadIdx hipemu::g_threadIdx

@@ -522,7 +522,8 @@ def test_conv_gemm_bf16_large(split, case):
 # ---------------------------------------------------------------------------------------------
 # pre-split operand variants (activation split once by cdf_split_bf16)
 # ---------------------------------------------------------------------------------------------
-SPX_CASES = [(2, 32, 40, 8, 3, 1, 1), (1, 64, 32, 8, 1, 1, 0), (1, 40, 136, 8, 3, 1, 1), (1, 32, 32, 8, 4, 2, 1)]
+SPX_CASES = [(2, 32, 40, 8, 3, 1, 1), (1, 64, 32, 8, 1, 1, 0), (1, 40, 136, 8, 3, 1, 1), (1, 32, 32, 8, 4, 2, 1),
+             (1, 72, 24, 8, 3, 1, 1), (1, 136, 72, 6, 3, 1, 1)]   # wgrad tiles 64x64, 64x128, 128x64, 128x128
 SPX_CASES_GPU = [(4, 64, 128, 32, 3, 1, 1), (2, 128, 64, 32, 3, 1, 1), (2, 256, 512, 16, 3, 1, 1), (2, 64, 64, 32, 4, 2, 1)]
 
 

@@ -1,5 +1,6 @@
 """Summarise a rocprofv3 rocpd sqlite database (kernel trace) into a per-kernel table:
    python tools/prof_summary.py gpurun_out/prof/x_results.db [out.md]"""
+import os
 import re
 import sqlite3
 import sys
@@ -12,7 +13,13 @@ def short(name):
 
 
 def main():
-    db = sqlite3.connect(sys.argv[1])
+    path = sys.argv[1]
+    if os.path.isdir(path):                       # rocprofv3 -d <dir>: find the rocpd database below it
+        hits = [os.path.join(r, f) for r, _, fs in os.walk(path) for f in fs if f.endswith(".db")]
+        if not hits:
+            sys.exit("no .db under " + path)
+        path = hits[0]
+    db = sqlite3.connect(path)
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
     rows = db.execute(f"select {name_col}, start, end from kernels").fetchall()
