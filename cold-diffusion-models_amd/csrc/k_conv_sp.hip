@@ -534,46 +534,69 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
     const int nchunks = (a.Cin + BK - 1) / BK;
     const int niter = ph.ntaps * nchunks;
 
-    uint4 rah0, rah1, ral0, ral1, rbh0, rbh1, rbl0, rbl1;
+    // Tap table -> LDS once (a dynamic index into the by-value kernel argument compiles to per-iteration global byte
+    // loads sitting in front of the tile loads); the next tap's entry is fetched when the tap counter advances, a
+    // whole iteration before it is needed.
+    // The table lives in the 16-byte row padding of the first A plane (entry t behind row t): the two operand
+    // stages fill the 80 KB that let two blocks share a CU, one more byte would halve the occupancy.
+    // CDF_MAX_TAPS + 1 entries: the fetch one past the end is harmless.
+    auto tap_entry = [&](int t) -> int* { return (int*)(smem + t * AS + BK); };
+    if (tid <= CDF_MAX_TAPS)
+        *tap_entry(tid) = tid < ph.ntaps ? (ph.dy[tid] & 0xFF) | ((ph.dx[tid] & 0xFF) << 8) | ((ph.wi[tid] & 0xFF) << 16) : 0;
+    __syncthreads();
+    int tap_cur = *tap_entry(0);
+
+    // Straight-line prefetch: no branch may sit between the loads (hipcc would wait for the loads in flight first).
+    u32x4_v rah0, rah1, ral0, ral1, rbh0, rbh1, rbl0, rbl1;
     int tap = 0, c0 = 0;                                     // incremental (tap, channel chunk) counters
     auto load_global = [&]() {
-        const int dy = ph.dy[tap], dx = ph.dx[tap], wi = ph.wi[tap];
+        // keep the entry in a VGPR: as a (provably uniform) scalar it would be pulled through v_readfirstlane right
+        // behind its ds_read, i.e. an LDS round trip on the critical path of every iteration
+        int tc = tap_cur;
+#ifndef CDF_EMU
+        asm volatile("" : "+v"(tc));
+#endif
+        const int dy = (int)(signed char)(tc & 0xFF), dx = (int)(signed char)((tc >> 8) & 0xFF), wi = (tc >> 16) & 0xFF;
         const int tap_pix = dy * a.W + dx;
+        const unsigned cc = (unsigned)(c0 + q8);
         const bool cok = (c0 + q8) < a.Cin;
         {
             const unsigned iy = (unsigned)(a_iy0[0] + dy), ix = (unsigned)(a_ix0[0] + dx);
             const bool ok = iy < (unsigned)a.H && ix < (unsigned)a.W && cok;
-            const size_t off = (size_t)(a_pix[0] + (unsigned)tap_pix) * (unsigned)a.ldx + c0 + q8;
-            rah0 = *(const uint4*)(ok ? a.x_hi + off : a.zero);
-            ral0 = *(const uint4*)(ok ? a.x_lo + off : a.zero);
+            const size_t off = (size_t)(a_pix[0] + (unsigned)tap_pix) * (unsigned)a.ldx + cc;
+            rah0 = *(const u32x4_v*)(ok ? a.x_hi + off : a.zero);
+            ral0 = *(const u32x4_v*)(ok ? a.x_lo + off : a.zero);
         }
         {
             const unsigned iy = (unsigned)(a_iy0[1] + dy), ix = (unsigned)(a_ix0[1] + dx);
             const bool ok = iy < (unsigned)a.H && ix < (unsigned)a.W && cok;
-            const size_t off = (size_t)(a_pix[1] + (unsigned)tap_pix) * (unsigned)a.ldx + c0 + q8;
-            rah1 = *(const uint4*)(ok ? a.x_hi + off : a.zero);
-            ral1 = *(const uint4*)(ok ? a.x_lo + off : a.zero);
+            const size_t off = (size_t)(a_pix[1] + (unsigned)tap_pix) * (unsigned)a.ldx + cc;
+            rah1 = *(const u32x4_v*)(ok ? a.x_hi + off : a.zero);
+            ral1 = *(const u32x4_v*)(ok ? a.x_lo + off : a.zero);
         }
-        const long long off0 = ((long long)wi * a.Cout + b_row[0]) * a.ldk + c0 + q8;
-        const long long off1 = ((long long)wi * a.Cout + b_row[1]) * a.ldk + c0 + q8;
-        rbh0 = *(const uint4*)(a.w_hi + off0);
-        rbh1 = *(const uint4*)(a.w_hi + off1);
-        rbl0 = *(const uint4*)(a.w_lo + off0);
-        rbl1 = *(const uint4*)(a.w_lo + off1);
+        const size_t woff0 = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)b_row[0]) * (unsigned)a.ldk + cc;
+        const size_t woff1 = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)b_row[1]) * (unsigned)a.ldk + cc;
+        rbh0 = *(const u32x4_v*)(a.w_hi + woff0);
+        rbh1 = *(const u32x4_v*)(a.w_hi + woff1);
+        rbl0 = *(const u32x4_v*)(a.w_lo + woff0);
+        rbl1 = *(const u32x4_v*)(a.w_lo + woff1);
         c0 += BK;
-        if (c0 >= a.Cin) { c0 = 0; ++tap; }
+        const bool wrap = c0 >= a.Cin;                       // block-uniform
+        c0 = wrap ? 0 : c0;
+        tap += wrap ? 1 : 0;
+        tap_cur = *tap_entry(tap);
     };
     const int off0 = trow * AS + q8, off1 = (trow + 64) * AS + q8;
     auto store_lds = [&](int buf) {
         unsigned short* st = smem + buf * STAGE;
-        *(uint4*)(st + off0) = rah0;
-        *(uint4*)(st + off1) = rah1;
-        *(uint4*)(st + PLANE + off0) = ral0;
-        *(uint4*)(st + PLANE + off1) = ral1;
-        *(uint4*)(st + 2 * PLANE + off0) = rbh0;
-        *(uint4*)(st + 2 * PLANE + off1) = rbh1;
-        *(uint4*)(st + 3 * PLANE + off0) = rbl0;
-        *(uint4*)(st + 3 * PLANE + off1) = rbl1;
+        *(u32x4_v*)(st + off0) = rah0;
+        *(u32x4_v*)(st + off1) = rah1;
+        *(u32x4_v*)(st + PLANE + off0) = ral0;
+        *(u32x4_v*)(st + PLANE + off1) = ral1;
+        *(u32x4_v*)(st + 2 * PLANE + off0) = rbh0;
+        *(u32x4_v*)(st + 2 * PLANE + off1) = rbh1;
+        *(u32x4_v*)(st + 3 * PLANE + off0) = rbl0;
+        *(u32x4_v*)(st + 3 * PLANE + off1) = rbl1;
     };
 
     f32x16_t acc[2][2];
@@ -1076,7 +1099,7 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
 #endif
     const int M = B * QH * QW;
     const int tiles = cdf_cdiv(M, 128) * cdf_cdiv(Cout, 128);
-    const size_t lds = (size_t)2 * 4 * 128 * 40 * sizeof(unsigned short);        // 80 KB >= CDF_SP_EPI_LDS
+    const size_t lds = (size_t)2 * 4 * 128 * 40 * sizeof(unsigned short);        // 80 KB >= CDF_SP_EPI_LDS; 2 blocks per CU
     CDF_LAUNCH(conv_igemm_spx_kernel, dim3(tiles, nphase), dim3(256), lds, CDF_S, a);
     return cdf_check_launch("conv_igemm_spx");
 }
