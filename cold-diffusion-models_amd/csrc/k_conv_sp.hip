@@ -42,31 +42,31 @@ struct SpPhase {
 };
 
 #ifndef CDF_ABLATE
-#define CDF_ABLATE 0     // tuning aid (tools/ablate.py): bit 0 no global loads in the K loop, 1 no MFMA, 2 no epilogue stores,
-#endif                   // 3 no LDS stores in the K loop, 4 no LDS fragment reads.  Always 0 in the product build.
+#define CDF_ABLATE 0     // tuning aid (tools/ablate.py): bit 0 no global loads in the K loop, bit 2 no epilogue stores,
+#endif                   // bit 3 no LDS stores in the K loop.  Always 0 in the product build.
 
-// 128x128 tile, 4 waves of 64x64: the whole tile goes through LDS in one pass (cdf_epilogue.h).
+// Block tile BM x BN, 4 waves as 2 x 2 of (BM/2) x (BN/2): the whole tile goes through LDS in one pass (cdf_epilogue.h).
 constexpr int CDF_SP_CPITCH = 136;
 constexpr size_t CDF_SP_EPI_LDS = (size_t)128 * CDF_SP_CPITCH * sizeof(float);
 
-template <class Args>
-__device__ __forceinline__ void cdf_sp_epilogue(const Args& a, const SpPhase& ph, const f32x16_t (&acc)[2][2], float* cs, int tile_m,
-                                                int tile_n, int M, int tid) {
-    constexpr int CP = CDF_SP_CPITCH;
+template <int BM, int BN, class Args>
+__device__ __forceinline__ void cdf_sp_epilogue(const Args& a, const SpPhase& ph, const f32x16_t (&acc)[BM / 64][BN / 64], float* cs,
+                                                int tile_m, int tile_n, int M, int tid) {
+    constexpr int CP = BN + 8;
     const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
     // (the K loop ends with a barrier: every wave is done with the operand tiles)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < BM / 64; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < BN / 64; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                cs[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * 64 + j * 32 + l31] = acc[i][j][r];
+                cs[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * (BN / 2) + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
 #if CDF_ABLATE & 4
     if (acc[0][0][0] != 12345.678f) return;
 #endif
-    cdf_epilogue_rows<128, 128>(a, ph, a.y, cs, tile_m * 128, tile_n * 128, M, tid, [](int p) { return p; });
+    cdf_epilogue_rows<BN, BM>(a, ph, a.y, cs, tile_m * BM, tile_n * BN, M, tid, [](int p) { return p; });
 }
 
 struct SpArgs {
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_sp_kernel(SpArgs a) {
         __syncthreads();
     }
 
-    cdf_sp_epilogue(a, ph, acc, (float*)smem_raw, tile_m, tile_n, M, tid);
+    cdf_sp_epilogue<128, 128>(a, ph, acc, (float*)smem_raw, tile_m, tile_n, M, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -493,10 +493,11 @@ struct SpxArgs {
     SpPhase ph[4];
 };
 
+template <int BM, int BN>
 __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
-    constexpr int BM = 128, BN = 128, BK = 32, AS = 40;
-    constexpr int PLANE = BM * AS;
-    constexpr int STAGE = 4 * PLANE;                         // A hi, A lo, B hi, B lo
+    constexpr int BK = 32, AS = 40, MT = BM / 64, NT = BN / 64;      // block tile BM x BN (64 or 128 each), waves 2 x 2
+    constexpr int PLANE_A = BM * AS, PLANE_B = BN * AS;
+    constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;                  // A hi, A lo, B hi, B lo
     CDF_DYN_SMEM(smem_raw);
     unsigned short* smem = (unsigned short*)smem_raw;
 
@@ -513,10 +514,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
     // (80 B apart: banks wrap onto each other, 2-way conflict on every store).
     const int q8 = (tid & 3) * 8;
     const int g8 = tid >> 3, trow = ((g8 >> 2) << 3) + (g8 & 3) + (((tid >> 2) & 1) << 2);
-    int a_iy0[2], a_ix0[2], b_row[2];
-    unsigned a_pix[2];
+    int a_iy0[MT], a_ix0[MT], b_row[NT];
+    unsigned a_pix[MT];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < MT; ++p) {
         const int m = tile_m * BM + trow + 64 * p;
         if (m < M) {
             const int qx = m % a.QW, t2 = m / a.QW;
@@ -528,6 +529,9 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
             a_ix0[p] = 0;
             a_pix[p] = 0;
         }
+    }
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
         const int n = tile_n * BN + trow + 64 * p;
         b_row[p] = n < a.Cout ? n : a.Cout - 1;
     }
@@ -537,9 +541,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
     // Tap table -> LDS once (a dynamic index into the by-value kernel argument compiles to per-iteration global byte
     // loads sitting in front of the tile loads); the next tap's entry is fetched when the tap counter advances, a
     // whole iteration before it is needed.
-    // The table lives in the 16-byte row padding of the first A plane (entry t behind row t): the two operand
-    // stages fill the 80 KB that let two blocks share a CU, one more byte would halve the occupancy.
+    // The table lives in the 16-byte row padding of the first A plane (entry t behind row t): at 128 x 128 the two
+    // operand stages fill the 80 KB that let two blocks share a CU, one more byte would halve the occupancy.
     // CDF_MAX_TAPS + 1 entries: the fetch one past the end is harmless.
+    static_assert(BM > CDF_MAX_TAPS, "tap table needs one padded row per entry");
     auto tap_entry = [&](int t) -> int* { return (int*)(smem + t * AS + BK); };
     if (tid <= CDF_MAX_TAPS)
         *tap_entry(tid) = tid < ph.ntaps ? (ph.dy[tid] & 0xFF) | ((ph.dx[tid] & 0xFF) << 8) | ((ph.wi[tid] & 0xFF) << 16) : 0;
@@ -547,7 +552,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
     int tap_cur = *tap_entry(0);
 
     // Straight-line prefetch: no branch may sit between the loads (hipcc would wait for the loads in flight first).
-    u32x4_v rah0, rah1, ral0, ral1, rbh0, rbh1, rbl0, rbl1;
+    u32x4_v rah[MT], ral[MT], rbh[NT], rbl[NT];
     int tap = 0, c0 = 0;                                     // incremental (tap, channel chunk) counters
     auto load_global = [&]() {
         // keep the entry in a VGPR: as a (provably uniform) scalar it would be pulled through v_readfirstlane right
@@ -560,50 +565,45 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
         const int tap_pix = dy * a.W + dx;
         const unsigned cc = (unsigned)(c0 + q8);
         const bool cok = (c0 + q8) < a.Cin;
-        {
-            const unsigned iy = (unsigned)(a_iy0[0] + dy), ix = (unsigned)(a_ix0[0] + dx);
+#pragma unroll
+        for (int p = 0; p < MT; ++p) {
+            const unsigned iy = (unsigned)(a_iy0[p] + dy), ix = (unsigned)(a_ix0[p] + dx);
             const bool ok = iy < (unsigned)a.H && ix < (unsigned)a.W && cok;
-            const size_t off = (size_t)(a_pix[0] + (unsigned)tap_pix) * (unsigned)a.ldx + cc;
-            rah0 = *(const u32x4_v*)(ok ? a.x_hi + off : a.zero);
-            ral0 = *(const u32x4_v*)(ok ? a.x_lo + off : a.zero);
+            const size_t off = (size_t)(a_pix[p] + (unsigned)tap_pix) * (unsigned)a.ldx + cc;
+            rah[p] = *(const u32x4_v*)(ok ? a.x_hi + off : a.zero);
+            ral[p] = *(const u32x4_v*)(ok ? a.x_lo + off : a.zero);
         }
-        {
-            const unsigned iy = (unsigned)(a_iy0[1] + dy), ix = (unsigned)(a_ix0[1] + dx);
-            const bool ok = iy < (unsigned)a.H && ix < (unsigned)a.W && cok;
-            const size_t off = (size_t)(a_pix[1] + (unsigned)tap_pix) * (unsigned)a.ldx + cc;
-            rah1 = *(const u32x4_v*)(ok ? a.x_hi + off : a.zero);
-            ral1 = *(const u32x4_v*)(ok ? a.x_lo + off : a.zero);
+#pragma unroll
+        for (int p = 0; p < NT; ++p) {
+            const size_t woff = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)b_row[p]) * (unsigned)a.ldk + cc;
+            rbh[p] = *(const u32x4_v*)(a.w_hi + woff);
+            rbl[p] = *(const u32x4_v*)(a.w_lo + woff);
         }
-        const size_t woff0 = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)b_row[0]) * (unsigned)a.ldk + cc;
-        const size_t woff1 = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)b_row[1]) * (unsigned)a.ldk + cc;
-        rbh0 = *(const u32x4_v*)(a.w_hi + woff0);
-        rbh1 = *(const u32x4_v*)(a.w_hi + woff1);
-        rbl0 = *(const u32x4_v*)(a.w_lo + woff0);
-        rbl1 = *(const u32x4_v*)(a.w_lo + woff1);
         c0 += BK;
         const bool wrap = c0 >= a.Cin;                       // block-uniform
         c0 = wrap ? 0 : c0;
         tap += wrap ? 1 : 0;
         tap_cur = *tap_entry(tap);
     };
-    const int off0 = trow * AS + q8, off1 = (trow + 64) * AS + q8;
     auto store_lds = [&](int buf) {
-        unsigned short* st = smem + buf * STAGE;
-        *(u32x4_v*)(st + off0) = rah0;
-        *(u32x4_v*)(st + off1) = rah1;
-        *(u32x4_v*)(st + PLANE + off0) = ral0;
-        *(u32x4_v*)(st + PLANE + off1) = ral1;
-        *(u32x4_v*)(st + 2 * PLANE + off0) = rbh0;
-        *(u32x4_v*)(st + 2 * PLANE + off1) = rbh1;
-        *(u32x4_v*)(st + 3 * PLANE + off0) = rbl0;
-        *(u32x4_v*)(st + 3 * PLANE + off1) = rbl1;
+        unsigned short* st = smem + buf * STAGE + trow * AS + q8;
+#pragma unroll
+        for (int p = 0; p < MT; ++p) {
+            *(u32x4_v*)(st + 64 * p * AS) = rah[p];
+            *(u32x4_v*)(st + PLANE_A + 64 * p * AS) = ral[p];
+        }
+#pragma unroll
+        for (int p = 0; p < NT; ++p) {
+            *(u32x4_v*)(st + 2 * PLANE_A + 64 * p * AS) = rbh[p];
+            *(u32x4_v*)(st + 2 * PLANE_A + PLANE_B + 64 * p * AS) = rbl[p];
+        }
     };
 
-    f32x16_t acc[2][2];
+    f32x16_t acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -613,57 +613,37 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
         store_lds(0);
     }
     __syncthreads();
-#if CDF_ABLATE & 16
-    bf16x8_v ah[2], al[2], bh[2], bl[2];
-    for (int i = 0; i < 2; ++i) {
-        ah[i] = *(const bf16x8_v*)(smem + (wm * 64 + i * 32 + l31) * AS + half * 8);
-        al[i] = *(const bf16x8_v*)(smem + PLANE + (wm * 64 + i * 32 + l31) * AS + half * 8);
-        bh[i] = *(const bf16x8_v*)(smem + 2 * PLANE + (wn * 64 + i * 32 + l31) * AS + half * 8);
-        bl[i] = *(const bf16x8_v*)(smem + 3 * PLANE + (wn * 64 + i * 32 + l31) * AS + half * 8);
-    }
-#endif
     for (int it = 0; it < niter; ++it) {
         const int buf = it & 1;
 #if !(CDF_ABLATE & 1)
         if (it + 1 < niter) load_global();
 #endif
         const unsigned short* sa = smem + buf * STAGE;
-        const unsigned short* sb = sa + 2 * PLANE;
+        const unsigned short* sb = sa + 2 * PLANE_A;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int k0 = ks * 16 + half * 8;
-#if !(CDF_ABLATE & 16)
-            bf16x8_v ah[2], al[2], bh[2], bl[2];
-            {
+            bf16x8_v ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int off = (wm * 64 + i * 32 + l31) * AS + k0;
+            for (int i = 0; i < MT; ++i) {
+                const int off = (wm * (BM / 2) + i * 32 + l31) * AS + k0;
                 ah[i] = *(const bf16x8_v*)(sa + off);
-                al[i] = *(const bf16x8_v*)(sa + PLANE + off);
+                al[i] = *(const bf16x8_v*)(sa + PLANE_A + off);
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int off = (wn * 64 + j * 32 + l31) * AS + k0;
+            for (int j = 0; j < NT; ++j) {
+                const int off = (wn * (BN / 2) + j * 32 + l31) * AS + k0;
                 bh[j] = *(const bf16x8_v*)(sb + off);
-                bl[j] = *(const bf16x8_v*)(sb + PLANE + off);
+                bl[j] = *(const bf16x8_v*)(sb + PLANE_B + off);
             }
-            }
-#endif
-#if !(CDF_ABLATE & 2)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NT; ++j) {
                     acc[i][j] = CDF_MFMA_BF16(al[i], bh[j], acc[i][j]);
                     acc[i][j] = CDF_MFMA_BF16(ah[i], bl[j], acc[i][j]);
                     acc[i][j] = CDF_MFMA_BF16(ah[i], bh[j], acc[i][j]);
                 }
-#else
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j][0] += (float)(ah[i][0] + al[i][1] + bh[j][2] + bl[j][3]);
-#endif
         }
 #if !(CDF_ABLATE & 8)
         if (it + 1 < niter) store_lds(buf ^ 1);
@@ -671,7 +651,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
         __syncthreads();
     }
 
-    cdf_sp_epilogue(a, ph, acc, (float*)smem_raw, tile_m, tile_n, M, tid);
+    cdf_sp_epilogue<BM, BN>(a, ph, acc, (float*)smem_raw, tile_m, tile_n, M, tid);
 }
 
 // weight gradient with both operands pre-split ([pixels][ld] bf16 hi / lo planes)
@@ -1070,6 +1050,32 @@ static int fill_phases(SpPhase* ph, int nphase, const int* pd, const char* who) 
     return CDF_OK;
 }
 
+static int g_spx_bm = 0, g_spx_bn = 0;     // 0 = automatic
+
+extern "C" int cdf_conv_gemm_bf16x_tile(int bm, int bn) {
+    CDF_REQUIRE((bm == 0 || bm == 64 || bm == 128) && (bn == 0 || bn == 64 || bn == 128), "cdf_conv_gemm_bf16x_tile: tile sides are 0 (auto), 64 or 128");
+    g_spx_bm = bm;
+    g_spx_bn = bn;
+    return 0;
+}
+
+template <int BM, int BN>
+static int launch_igemm_spx(const SpxArgs& a, int M, hipStream_t s) {
+    constexpr size_t stages = (size_t)2 * 2 * (BM + BN) * 40 * sizeof(unsigned short);
+    constexpr size_t epi = (size_t)BM * (BN + 8) * sizeof(float);
+    constexpr size_t lds = stages > epi ? stages : epi;      // 128 x 128: 80 KB, two blocks per CU
+#ifndef CDF_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_spx_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+#endif
+    const int tiles = cdf_cdiv(M, BM) * cdf_cdiv(a.Cout, BN);
+    CDF_LAUNCH((conv_igemm_spx_kernel<BM, BN>), dim3(tiles, a.nphase), dim3(256), lds, s, a);
+    return cdf_check_launch("conv_igemm_spx");
+}
+
 extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo,
                                    int ldk, float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW,
                                    int os, int is, int nphase, const int* phase_desc, const float* bias, const float* sbias,
@@ -1090,18 +1096,15 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
     a.vec = cdf_epi_vec_ok(Cout, y, ldy, bias, sbias, ld_sbias, res, ldr, pre, ldp, mul, ldm);
     int rc = fill_phases(a.ph, nphase, phase_desc, "cdf_conv_gemm_bf16x");
     if (rc) return rc;
-#ifndef CDF_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_spx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-#endif
+    // Tile choice: 64-wide N for Cout <= 64 (no half-empty MFMA columns); 64-row M tiles when 128-row tiles would
+    // leave most of the 256 CUs x 2 resident blocks idle (deep, small-image layers: M = 8192 at 16 x 16).
     const int M = B * QH * QW;
-    const int tiles = cdf_cdiv(M, 128) * cdf_cdiv(Cout, 128);
-    const size_t lds = (size_t)2 * 4 * 128 * 40 * sizeof(unsigned short);        // 80 KB >= CDF_SP_EPI_LDS; 2 blocks per CU
-    CDF_LAUNCH(conv_igemm_spx_kernel, dim3(tiles, nphase), dim3(256), lds, CDF_S, a);
-    return cdf_check_launch("conv_igemm_spx");
+    const bool n64 = g_spx_bn ? g_spx_bn == 64 : Cout <= 64;
+    const long long tiles128 = (long long)cdf_cdiv(M, 128) * cdf_cdiv(Cout, n64 ? 64 : 128) * nphase;
+    bool m64 = tiles128 < 384;
+    if (g_spx_bm) m64 = g_spx_bm == 64;
+    if (n64) return m64 ? launch_igemm_spx<64, 64>(a, M, CDF_S) : launch_igemm_spx<128, 64>(a, M, CDF_S);
+    return m64 ? launch_igemm_spx<64, 128>(a, M, CDF_S) : launch_igemm_spx<128, 128>(a, M, CDF_S);
 }
 
 template <int TA, int TB>

@@ -596,6 +596,17 @@ def test_conv_presplit(be, case):
     _spx_case(be, *case)
 
 
+@pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 128), (64, 64)])
+def test_conv_presplit_forced_tiles(be, tile):
+    """Every block-tile instantiation of the pre-split GEMM on a shape with ragged M and N tiles (the automatic
+    choice would only ever pick the 64-row tiles at emulator-sized problems)."""
+    be.L.cdf_conv_gemm_bf16x_tile(*tile)
+    try:
+        _spx_case(be, 3, 40, 72, 7, 3, 1, 1)
+    finally:
+        be.L.cdf_conv_gemm_bf16x_tile(0, 0)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", SPX_CASES_GPU)
 def test_conv_presplit_large(case):
