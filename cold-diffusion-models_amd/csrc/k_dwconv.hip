@@ -18,110 +18,216 @@ __device__ __forceinline__ void f4_fma(float4& acc, const float4& a, const float
 }
 
 // y[b,y,x,c] = sum_k x[b,y+ky-3,x+kx-3,c] * w[k][c] (+ bias[c] + sbias[b][c]);  flip => mirrored taps (dgrad)
-__global__ void __launch_bounds__(256) dwconv7_kernel(const float* x, int ldx, const float* w, int ldw, const float* bias,
-                                                      const float* sbias, int ld_sbias, float* y, int ldy, int B, int H,
-                                                      int W, int C4, int flip, int accumulate) {
-    const int strips_w = (W + 3) / 4;
-    const long long n = (long long)B * H * strips_w * C4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4) * 4;
-        long long r = i / C4;
-        const int xs = (int)(r % strips_w) * 4;
-        r /= strips_w;
-        const int yy = (int)(r % H), b = (int)(r / H);
-        float4 acc[4];
+//
+// Per layer: 8 B/element of HBM traffic against 49 FMA/element -- on MI355X the two floors are about equal
+// (134 MB in + 134 MB out = 54 us, 1.6 G FMA = 42 us at 128x128x64, batch 32), so neither may be wasted, and the
+// loads must not be latency-bound (a register-window version with 10 dependent-ish loads per row ran at 4x the
+// floor).  Stencil through LDS:
+//   block = 256 threads = 32 channels (8 float4 lanes, 128 B coalesced) x 32 thread tiles of 4 x 2 output pixels,
+//   i.e. a TBW x TBH = 256-pixel output tile (32 x 8, or 16 x 16 for narrow images);
+//   the (TBW+6) x (TBH+6) input halo goes to LDS with ~17 independent, unconditional float4 loads per thread
+//   (clamped address + select), 2.1x the tile's own bytes and L2/MALL-resident for the neighbours;
+//   each thread then slides a 10-wide register window over 8 halo rows: 80 ds_read_b128 + 49 weight reads per 8
+//   outputs.  Row pitch = (TBW+6) pixels + 64 B: the two thread rows inside a 16-lane ds_read_b128 group land 32
+//   banks apart (conflict-free).  68 KB + 6 KB of weights: two blocks per CU overlap one's loads with the other's FMAs.
+// grid = (tiles_x * tiles_y * B, ceil(C4 / 8)).
+template <int TBW, int TBH>
+__global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx, const float* w, int ldw, const float* bias,
+                                                         const float* sbias, int ld_sbias, float* y, int ldy, int B, int H,
+                                                         int W, int C4, int flip, int accumulate) {
+    constexpr int HW_ = TBW + 6, HH_ = TBH + 6;              // halo extent
+    constexpr int RP = HW_ * 8 + 4;                          // row pitch in float4 (pixels x 8 channel quads + 64 B)
+    constexpr int TX = TBW / 4, TY = TBH / 2;                // thread tiles
+    static_assert(TX * TY == 32, "256 output pixels per block");
+    CDF_DYN_SMEM(smem_raw);
+    float4* halo = (float4*)smem_raw;                        // [HH_][RP]
+    float4* wl = halo + HH_ * RP;                            // [49][8]
+
+    const int tid = threadIdx.x;
+    const int tiles_w = (W + TBW - 1) / TBW, tiles_h = (H + TBH - 1) / TBH;
+    int t = blockIdx.x;
+    const int bx = t % tiles_w;
+    t /= tiles_w;
+    const int by = t % tiles_h, b = t / tiles_h;
+    const int X0 = bx * TBW, Y0 = by * TBH;
+    const int cq0 = blockIdx.y * 8;
+
+    for (int i = tid; i < DW_TAPS * 8; i += 256) {
+        const int tp = i >> 3, l = i & 7;
+        const int tap = flip ? DW_TAPS - 1 - tp : tp;
+        wl[i] = (cq0 + l) < C4 ? *(const float4*)(w + (long long)tap * ldw + (cq0 + l) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // all of a thread's halo loads are issued before the first LDS store (a rolled loop would wait for each load in turn)
+    const float* xb = x + (long long)b * H * W * ldx;
+    constexpr int NHALO = HH_ * HW_ * 8, NIT = (NHALO + 255) / 256;
+    float4 hv[NIT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int ky = 0; ky < DW_K; ++ky) {
-            const int iy = yy + ky - 3;
-            if (iy < 0 || iy >= H) continue;
-            const float* row = x + (((long long)b * H + iy) * W) * ldx + c;
-            float4 win[10];
+    for (int k = 0; k < NIT; ++k) {
+        const int i = tid + 256 * k;
+        const int l = i & 7, p = i >> 3;
+        const int hy = p / HW_, hx = p - hy * HW_;
+        const int iy = Y0 + hy - 3, ix = X0 + hx - 3;
+        const bool ok = i < NHALO && iy >= 0 && iy < H && ix >= 0 && ix < W && (cq0 + l) < C4;
+        const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+        const int lc = (cq0 + l) < C4 ? cq0 + l : 0;
+        const float4 v = *(const float4*)(xb + ((long long)iyc * W + ixc) * ldx + lc * 4);
+        hv[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
-            for (int q = 0; q < 10; ++q) {
-                const int ix = xs + q - 3;
-                win[q] = (ix >= 0 && ix < W) ? *(const float4*)(row + (long long)ix * ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+    for (int k = 0; k < NIT; ++k) {
+        const int i = tid + 256 * k;
+        const int l = i & 7, p = i >> 3;
+        const int hy = p / HW_, hx = p - hy * HW_;
+        if (i < NHALO) halo[hy * RP + hx * 8 + l] = hv[k];
+    }
+    __syncthreads();
+
+    // lanes: channel quad (8) fastest, then thread row (TY), then thread column (TX)
+    const int l8 = tid & 7, ty = (tid >> 3) % TY, tx = (tid >> 3) / TY;
+    const int cq = cq0 + l8;
+    const int x0 = tx * 4, y0 = ty * 2;                      // inside the tile
+    float4 acc[2][4];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[o][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // rolled on purpose: unrolled, hipcc hoists all 80 window reads + 49 weight reads to the top and spills
+#pragma unroll 1
+    for (int r = 0; r < 8; ++r) {                            // halo row y0 + r feeds output row o through ky = r - o
+        float4 win[10];
+        const float4* hrow = halo + (y0 + r) * RP + x0 * 8 + l8;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) win[q] = hrow[q * 8];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int ky = r - o;
+            const bool kv = ky >= 0 && ky < DW_K;            // uniform; the two invalid (r, o) pairs multiply by zero weights
+            const float4* wrow = wl + (kv ? ky : 0) * DW_K * 8 + l8;
 #pragma unroll
             for (int kx = 0; kx < DW_K; ++kx) {
-                const int tap = flip ? (6 - ky) * DW_K + (6 - kx) : ky * DW_K + kx;
-                const float4 wv = *(const float4*)(w + (long long)tap * ldw + c);
+                float4 wv = wrow[kx * 8];
+                if (!kv) wv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) f4_fma(acc[j], win[kx + j], wv);
+                for (int j = 0; j < 4; ++j) f4_fma(acc[o][j], win[kx + j], wv);
             }
         }
-        float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias) {
-            const float4 bv = *(const float4*)(bias + c);
-            add.x += bv.x; add.y += bv.y; add.z += bv.z; add.w += bv.w;
-        }
-        if (sbias) {
-            const float4 sv = *(const float4*)(sbias + (long long)b * ld_sbias + c);
-            add.x += sv.x; add.y += sv.y; add.z += sv.z; add.w += sv.w;
-        }
+    }
+    if (cq >= C4) return;
+    const int c = cq * 4;
+    float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) {
+        const float4 bv = *(const float4*)(bias + c);
+        add.x += bv.x; add.y += bv.y; add.z += bv.z; add.w += bv.w;
+    }
+    if (sbias) {
+        const float4 sv = *(const float4*)(sbias + (long long)b * ld_sbias + c);
+        add.x += sv.x; add.y += sv.y; add.z += sv.z; add.w += sv.w;
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int oy = Y0 + y0 + o;
+        if (oy >= H) break;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (xs + j >= W) break;
-            float* dst = y + (((long long)b * H + yy) * W + xs + j) * ldy + c;
-            float4 o = make_float4(acc[j].x + add.x, acc[j].y + add.y, acc[j].z + add.z, acc[j].w + add.w);
+            const int ox = X0 + x0 + j;
+            if (ox >= W) break;
+            float* dst = y + (((long long)b * H + oy) * W + ox) * ldy + c;
+            float4 v = make_float4(acc[o][j].x + add.x, acc[o][j].y + add.y, acc[o][j].z + add.z, acc[o][j].w + add.w);
             if (accumulate) {
                 const float4 old = *(const float4*)dst;
-                o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
             }
-            *(float4*)dst = o;
+            *(float4*)dst = v;
         }
     }
 }
 
-// weight gradient partials: part[((b*nchunk + chunk)*50 + tap)*C + c], tap 49 = sum of dy
-// grid = (ceil(C/64), nchunk, B), block 256 = 4 waves; lane = channel.
+// Weight gradient partials: part[((b*nchunk + chunk)*50 + tap)*C + c], tap 49 = sum of dy (bias gradients).
+//   dw[c][ky][kx] = sum_{b,y,x} x[b, y+ky-3, x+kx-3, c] * dy[b, y, x, c]
+// Same two floors as the forward kernel (read x and dy once, 49 FMA per element).  grid = (ceil(C/64), nchunk, B),
+// block 256 = 4 waves.  Wave w owns kernel rows ky = 2w, 2w+1 (wave 3: ky = 6 and the dy sum): 14 taps x 4 channels
+// of accumulators per lane.  Lanes: 16 channel-quads (float4, 256 B coalesced) x 4 strips of 8 pixels in flight;
+// per strip a wave loads the dy strip (8 float4) and one 14-wide x window per kernel row, all unconditionally.
+// The 4 strip slots are folded with two cross-lane adds at the end.
 __global__ void __launch_bounds__(256) dwconv7_wgrad_partial_kernel(const float* x, int ldx, const float* dy, int lddy,
                                                                    float* part, int H, int W, int C, int rows_per_chunk) {
-    __shared__ float red[4][DW_TAPS + 1][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane, b = blockIdx.z;
-    const bool cv = c < C;
+    constexpr int TW = 8;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: branches on it are uniform
+    const int l16 = lane & 15, slot = lane >> 4;
+    const int c = blockIdx.x * 64 + l16 * 4, b = blockIdx.z;
+    const int C4r = (C + 3) & ~3;
+    const bool cv = c < C4r;
+    const int cc = cv ? c : 0;
     const int y0 = blockIdx.y * rows_per_chunk;
     int y1 = y0 + rows_per_chunk;
     if (y1 > H) y1 = H;
-    const int strips_w = (W + 3) / 4, nstrips = (y1 - y0) * strips_w;
-    float acc[DW_TAPS + 1];
+    const int strips_w = (W + TW - 1) / TW, nstrips = (y1 - y0) * strips_w;
+    const int ky0 = 2 * wave, nky = wave == 3 ? 1 : 2;
+
+    float4 acc[2][DW_K], dsum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int t = 0; t <= DW_TAPS; ++t) acc[t] = 0.f;
-    for (int s = wave; s < nstrips; s += 4) {
-        const int yy = y0 + s / strips_w, xs = (s % strips_w) * 4;
-        float d[4];
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            d[j] = (cv && xs + j < W) ? dy[(((long long)b * H + yy) * W + xs + j) * lddy + c] : 0.f;
-            acc[DW_TAPS] += d[j];
+        for (int k = 0; k < DW_K; ++k) acc[r][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int s = slot; s < nstrips; s += 4) {
+        const int yy = y0 + s / strips_w, xs = (s % strips_w) * TW;
+        float4 d[TW];
+        const float* drow = dy + (((long long)b * H + yy) * W) * lddy + cc;
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            const int ix = xs + j;
+            const float4 v = *(const float4*)(drow + (long long)(ix < W ? ix : W - 1) * lddy);
+            d[j] = (cv && ix < W) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int ky = 0; ky < DW_K; ++ky) {
-            const int iy = yy + ky - 3;
+        for (int r = 0; r < 2; ++r) {
+            if (r >= nky) break;                               // wave-uniform
+            const int iy = yy + ky0 + r - 3;
             const bool rowok = iy >= 0 && iy < H;
-            const float* row = x + (((long long)b * H + (rowok ? iy : 0)) * W) * ldx + c;
-            float win[10];
+            const float* row = x + (((long long)b * H + (iy < 0 ? 0 : (iy >= H ? H - 1 : iy))) * W) * ldx + cc;
+            float4 win[TW + 6];
 #pragma unroll
-            for (int q = 0; q < 10; ++q) {
+            for (int q = 0; q < TW + 6; ++q) {
                 const int ix = xs + q - 3;
-                win[q] = (cv && rowok && ix >= 0 && ix < W) ? row[(long long)ix * ldx] : 0.f;
+                const float4 v = *(const float4*)(row + (long long)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * ldx);
+                win[q] = (rowok && ix >= 0 && ix < W) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int kx = 0; kx < DW_K; ++kx)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[ky * DW_K + kx] = fmaf(win[kx + j], d[j], acc[ky * DW_K + kx]);
+                for (int j = 0; j < TW; ++j) f4_fma(acc[r][kx], win[kx + j], d[j]);
         }
-    }
-    // cross-wave reduction through LDS (static indices only: acc[] must stay in registers)
 #pragma unroll
-    for (int t = 0; t <= DW_TAPS; ++t) red[wave][t][lane] = acc[t];
-    __syncthreads();
-    float* dst = part + (((long long)b * gridDim.y + blockIdx.y) * (DW_TAPS + 1)) * C;
-    for (int i = threadIdx.x; i < (DW_TAPS + 1) * 64; i += 256) {
-        const int t = i >> 6, l = i & 63, cc = blockIdx.x * 64 + l;
-        if (cc < C) dst[(long long)t * C + cc] = (red[0][t][l] + red[1][t][l]) + (red[2][t][l] + red[3][t][l]);
+        for (int j = 0; j < TW; ++j) { dsum.x += d[j].x; dsum.y += d[j].y; dsum.z += d[j].z; dsum.w += d[j].w; }   // (only wave 3's is stored)
     }
+    // fold the 4 strip slots (lane bits 4, 5), then slot 0 writes 16 lanes x float4 = 64 channels per tap
+    auto fold = [&](float4& v) {
+        v.x += __shfl_xor(v.x, 16); v.y += __shfl_xor(v.y, 16); v.z += __shfl_xor(v.z, 16); v.w += __shfl_xor(v.w, 16);
+        v.x += __shfl_xor(v.x, 32); v.y += __shfl_xor(v.y, 32); v.z += __shfl_xor(v.z, 32); v.w += __shfl_xor(v.w, 32);
+    };
+    float* dst = part + (((long long)b * gridDim.y + blockIdx.y) * (DW_TAPS + 1)) * C;
+    auto put = [&](int tap, const float4& v) {
+        if (slot != 0 || !cv) return;
+        float* p = dst + (long long)tap * C + c;
+        if (c + 3 < C && (C & 3) == 0) {
+            *(float4*)p = v;
+        } else {
+            if (c + 0 < C) p[0] = v.x;
+            if (c + 1 < C) p[1] = v.y;
+            if (c + 2 < C) p[2] = v.z;
+            if (c + 3 < C) p[3] = v.w;
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int kx = 0; kx < DW_K; ++kx) {
+            fold(acc[r][kx]);
+            if (r < nky) put((ky0 + r) * DW_K + kx, acc[r][kx]);
+        }
+    fold(dsum);
+    if (wave == 3) put(DW_TAPS, dsum);
 }
 
 // dw[c*49 + tap] (+)= sum_{b,chunk} part ; dbias[c] (+)= sum part[..][49] ; dsb[b][c] = sum_chunk part[b][..][49]
@@ -157,6 +263,23 @@ __global__ void dwconv7_wgrad_final_kernel(const float* part, int B, int nchunk,
     }
 }
 
+template <int TBW, int TBH>
+static int launch_dwconv7(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias, int ld_sbias, float* y,
+                          int ldy, int B, int H, int W, int C4, int flip, int accumulate, hipStream_t s) {
+    constexpr size_t lds = ((size_t)(TBH + 6) * ((TBW + 6) * 8 + 4) + DW_TAPS * 8) * sizeof(float4);
+#ifndef CDF_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)dwconv7_kernel<TBW, TBH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+#endif
+    const long long tiles = (long long)B * cdf_cdiv(H, TBH) * cdf_cdiv(W, TBW);
+    CDF_LAUNCH((dwconv7_kernel<TBW, TBH>), dim3((unsigned)tiles, cdf_cdiv(C4, 8)), dim3(256), lds, s, x, ldx, w, ldw, bias, sbias, ld_sbias, y,
+               ldy, B, H, W, C4, flip, accumulate);
+    return cdf_check_launch("dwconv7");
+}
+
 // ================================================================================================
 extern "C" int cdf_dwconv7(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias,
                            int ld_sbias, float* y, int ldy, int B, int H, int W, int C, int flip, int accumulate,
@@ -165,11 +288,8 @@ extern "C" int cdf_dwconv7(const float* x, int ldx, const float* w, int ldw, con
     const int Cp = (C + 3) & ~3;
     CDF_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldw % 4 == 0 && ldx >= Cp && ldy >= Cp && ldw >= Cp, "cdf_dwconv7: pitches must be multiples of 4 and >= roundup4(C)");
     CDF_REQUIRE(!bias || (C % 4 == 0), "cdf_dwconv7: bias with C %% 4 != 0 needs a padded bias (pass a padded vector and C rounded up)");
-    const long long n = (long long)B * H * ((W + 3) / 4) * (Cp / 4);
-    long long grid = (n + 255) / 256;
-    if (grid > 8192) grid = 8192;
-    CDF_LAUNCH(dwconv7_kernel, dim3((int)grid), dim3(256), 0, CDF_S, x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate);
-    return cdf_check_launch("dwconv7");
+    if (W <= 16) return launch_dwconv7<16, 16>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, CDF_S);
+    return launch_dwconv7<32, 8>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, CDF_S);
 }
 
 extern "C" int cdf_dwconv7_wgrad_nchunk(int H) {
@@ -184,6 +304,8 @@ extern "C" int cdf_dwconv7_wgrad(const float* x, int ldx, const float* dy, int l
                                  float* dsb, int ld_dsb, float* ws, int B, int H, int W, int C, int accumulate,
                                  void* stream) {
     CDF_REQUIRE(x && dy && dw && ws, "cdf_dwconv7_wgrad: null pointer");
+    CDF_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && ldx >= ((C + 3) & ~3) && lddy >= ((C + 3) & ~3) && ((((uintptr_t)x) | ((uintptr_t)dy)) & 15) == 0,
+                "cdf_dwconv7_wgrad: pitches must be multiples of 4 and >= roundup4(C), pointers 16B aligned");
     const int nchunk = cdf_dwconv7_wgrad_nchunk(H), rpc = cdf_cdiv(H, nchunk);
     CDF_LAUNCH(dwconv7_wgrad_partial_kernel, dim3(cdf_cdiv(C, 64), nchunk, B), dim3(256), 0, CDF_S, x, ldx, dy, lddy, ws, H, W, C, rpc);
     CDF_LAUNCH(dwconv7_wgrad_final_kernel, dim3(cdf_cdiv(C, 64), DW_TAPS + 1), dim3(256), 0, CDF_S, (const float*)ws, B, nchunk, C, dw, dbias, dsb, ld_dsb, accumulate);
