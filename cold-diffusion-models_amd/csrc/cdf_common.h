@@ -17,6 +17,9 @@
 #define CDF_LAUNCH(kernel, grid, block, shmem, stream, ...) \
     hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
 #define CDF_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains every global load in flight
+// (vmcnt(0)), which would serialise a register prefetch that is meant to stay in flight across the barrier.
+#define CDF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 #endif

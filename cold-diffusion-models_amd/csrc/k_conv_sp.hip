@@ -551,10 +551,15 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
     __syncthreads();
     int tap_cur = *tap_entry(0);
 
-    // Straight-line prefetch: no branch may sit between the loads (hipcc would wait for the loads in flight first).
-    u32x4_v rah[MT], ral[MT], rbh[NT], rbl[NT];
-    int tap = 0, c0 = 0;                                     // incremental (tap, channel chunk) counters
-    auto load_global = [&]() {
+    // Register prefetch ring of depth 2: the loads of chunk it+2 are issued at the top of iteration it and only
+    // written to LDS at the end of iteration it+1 -- a global load takes ~1-2 us under load, one iteration's MFMAs
+    // 0.3 us, so a depth-1 prefetch left the matrix cores waiting on memory.  Straight-line code: no branch may sit
+    // between the loads (hipcc would wait for the loads in flight first); past the last chunk the loader simply
+    // re-reads the last one (never stored).
+    struct Regs { u32x4_v ah[MT], al[MT], bh[NT], bl[NT]; };
+    Regs R0, R1;
+    int tap = 0, c0 = 0, issued = 0;                         // incremental (tap, channel chunk) counters of the NEXT load
+    auto load_global = [&](Regs& R) {
         // keep the entry in a VGPR: as a (provably uniform) scalar it would be pulled through v_readfirstlane right
         // behind its ds_read, i.e. an LDS round trip on the critical path of every iteration
         int tc = tap_cur;
@@ -570,32 +575,34 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
             const unsigned iy = (unsigned)(a_iy0[p] + dy), ix = (unsigned)(a_ix0[p] + dx);
             const bool ok = iy < (unsigned)a.H && ix < (unsigned)a.W && cok;
             const size_t off = (size_t)(a_pix[p] + (unsigned)tap_pix) * (unsigned)a.ldx + cc;
-            rah[p] = *(const u32x4_v*)(ok ? a.x_hi + off : a.zero);
-            ral[p] = *(const u32x4_v*)(ok ? a.x_lo + off : a.zero);
+            R.ah[p] = *(const u32x4_v*)(ok ? a.x_hi + off : a.zero);
+            R.al[p] = *(const u32x4_v*)(ok ? a.x_lo + off : a.zero);
         }
 #pragma unroll
         for (int p = 0; p < NT; ++p) {
             const size_t woff = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)b_row[p]) * (unsigned)a.ldk + cc;
-            rbh[p] = *(const u32x4_v*)(a.w_hi + woff);
-            rbl[p] = *(const u32x4_v*)(a.w_lo + woff);
+            R.bh[p] = *(const u32x4_v*)(a.w_hi + woff);
+            R.bl[p] = *(const u32x4_v*)(a.w_lo + woff);
         }
-        c0 += BK;
-        const bool wrap = c0 >= a.Cin;                       // block-uniform
-        c0 = wrap ? 0 : c0;
-        tap += wrap ? 1 : 0;
+        const bool more = issued + 1 < niter;                // block-uniform
+        issued += more ? 1 : 0;
+        const int c1 = c0 + BK;
+        const bool wrap = c1 >= a.Cin;
+        c0 = more ? (wrap ? 0 : c1) : c0;
+        tap += (more && wrap) ? 1 : 0;
         tap_cur = *tap_entry(tap);
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int buf, const Regs& R) {
         unsigned short* st = smem + buf * STAGE + trow * AS + q8;
 #pragma unroll
         for (int p = 0; p < MT; ++p) {
-            *(u32x4_v*)(st + 64 * p * AS) = rah[p];
-            *(u32x4_v*)(st + PLANE_A + 64 * p * AS) = ral[p];
+            *(u32x4_v*)(st + 64 * p * AS) = R.ah[p];
+            *(u32x4_v*)(st + PLANE_A + 64 * p * AS) = R.al[p];
         }
 #pragma unroll
         for (int p = 0; p < NT; ++p) {
-            *(u32x4_v*)(st + 2 * PLANE_A + 64 * p * AS) = rbh[p];
-            *(u32x4_v*)(st + 2 * PLANE_A + PLANE_B + 64 * p * AS) = rbl[p];
+            *(u32x4_v*)(st + 2 * PLANE_A + 64 * p * AS) = R.bh[p];
+            *(u32x4_v*)(st + 2 * PLANE_A + PLANE_B + 64 * p * AS) = R.bl[p];
         }
     };
 
@@ -608,16 +615,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int half = lane >> 5, l31 = lane & 31;
-    if (niter > 0) {
-        load_global();
-        store_lds(0);
-    }
-    __syncthreads();
-    for (int it = 0; it < niter; ++it) {
-        const int buf = it & 1;
-#if !(CDF_ABLATE & 1)
-        if (it + 1 < niter) load_global();
-#endif
+    auto compute = [&](int buf) {
         const unsigned short* sa = smem + buf * STAGE;
         const unsigned short* sb = sa + 2 * PLANE_A;
 #pragma unroll
@@ -645,11 +643,34 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
                     acc[i][j] = CDF_MFMA_BF16(ah[i], bh[j], acc[i][j]);
                 }
         }
-#if !(CDF_ABLATE & 8)
-        if (it + 1 < niter) store_lds(buf ^ 1);
-#endif
-        __syncthreads();
+    };
+    // chunk c lives in ring slot c & 1 and in LDS stage c & 1
+    if (niter > 0) {
+        load_global(R0);                                     // chunk 0
+        store_lds(0, R0);
+        load_global(R1);                                     // chunk 1 (or chunk 0 again)
     }
+    CDF_LDS_BARRIER();
+    for (int it = 0; it < niter; it += 2) {
+#if !(CDF_ABLATE & 1)
+        load_global(R0);                                     // chunk it + 2
+#endif
+        compute(0);
+#if !(CDF_ABLATE & 8)
+        if (it + 1 < niter) store_lds(1, R1);                // chunk it + 1, issued one iteration ago
+#endif
+        CDF_LDS_BARRIER();
+        if (it + 1 >= niter) break;
+#if !(CDF_ABLATE & 1)
+        load_global(R1);                                     // chunk it + 3
+#endif
+        compute(1);
+#if !(CDF_ABLATE & 8)
+        if (it + 2 < niter) store_lds(0, R0);                // chunk it + 2
+#endif
+        CDF_LDS_BARRIER();
+    }
+    __syncthreads();                                         // drain the tail prefetch before LDS is reused
 
     cdf_sp_epilogue<BM, BN>(a, ph, acc, (float*)smem_raw, tile_m, tile_n, M, tid);
 }

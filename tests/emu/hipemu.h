@@ -171,6 +171,7 @@ inline emu_s4 ds_read_tr16_b64(const unsigned short* p) {
 #define CDF_LAUNCH(kernel, grid, block, shmem, stream, ...) \
     hipemu::launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), stream, __VA_ARGS__)
 #define CDF_DYN_SMEM(name) unsigned char* name = hipemu::g.dyn_smem
+#define CDF_LDS_BARRIER() hipemu::block_barrier()
 
 static inline void __syncthreads() { hipemu::block_barrier(); }
 
