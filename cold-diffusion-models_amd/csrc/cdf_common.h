@@ -20,8 +20,24 @@
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains every global load in flight
 // (vmcnt(0)), which would serialise a register prefetch that is meant to stay in flight across the barrier.
 #define CDF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// LDS-DMA (global_load_lds_dwordx4): every lane fetches 16 bytes from its own global address; the wave's 64 pieces land
+// at lds_base + 16 * lane (lds_base wave-uniform).  No VGPR staging, no ds_write (a ds_write_b128 costs 13 LDS-path
+// cycles per wave -- ~80 B/clk/CU).  hipcc does not count these loads: wait with CDF_WAIT_DMA() and pass a barrier
+// before reading the data.
+#define CDF_GLDS16(gptr, lds_base)                                                                            \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                    \
+                                     (__attribute__((address_space(3))) void*)(lds_base), 16, 0, 0)
+#define CDF_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+#endif
+
+// 256 zero bytes: out-of-range operand elements are loaded from here, so that loads never sit behind a branch.
+// (one copy per translation unit; the contents never change)
+#ifdef CDF_EMU
+static const float cdf_zero_page[64] = {0};
+#else
+static __device__ float cdf_zero_page[64];     // (not const: a constant-address-space pointer would turn the selected loads into flat loads)
 #endif
 
 // ---- status codes (returned by every extern "C" entry point) -------------------------

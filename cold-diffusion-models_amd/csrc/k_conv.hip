@@ -88,79 +88,94 @@ __global__ void __launch_bounds__(256, 4) conv_igemm_kernel(ConvArgs a) {
     // ---- A-operand row bookkeeping ----------------------------------------------------------
     const int a_col = (tid & 3) * 4;
     int a_iy0[APASS], a_ix0[APASS];
-    long long a_img[APASS];
+    unsigned a_pix[APASS];                                   // pixel index of (b, iy0, ix0); the tap adds dy*W + dx
 #pragma unroll
     for (int p = 0; p < APASS; ++p) {
         const int m = tile_m * BM + (tid >> 2) + 64 * p;
         if (m < M) {
             const int qx = m % a.QW, t2 = m / a.QW;
-            const int qy = t2 % a.QH, b = t2 / a.QH;
-            a_iy0[p] = qy * a.is;
+            a_iy0[p] = (t2 % a.QH) * a.is;
             a_ix0[p] = qx * a.is;
-            a_img[p] = (long long)b * a.H;
+            a_pix[p] = (unsigned)(((t2 / a.QH) * a.H + a_iy0[p]) * a.W + a_ix0[p]);
         } else {
             a_iy0[p] = -(1 << 28);
             a_ix0[p] = 0;
-            a_img[p] = 0;
+            a_pix[p] = 0;
         }
     }
     const int nchunks = (a.Cin + BK - 1) / BK;
     const int niter = ph.ntaps * nchunks;
 
-    // Loads are unconditional (a load inside a divergent branch makes hipcc wait vmcnt(0) per load and
-    // serialises the prefetch): invalid elements read a clamped, always-valid address and are zeroed by a select.
-    float4 ra[APASS], rb[BPASS];
-    auto load_global = [&](int it) {
-        const int tap = it / nchunks, c0 = (it - tap * nchunks) * BK;
-        const int dy = ph.dy[tap], dx = ph.dx[tap], wi = ph.wi[tap];
+    // Tap table -> LDS once (a dynamic index into the by-value kernel argument compiles to global byte loads in front
+    // of every chunk's tile loads); the next entry is fetched when the tap counter advances, an iteration ahead.
+    // CDF_MAX_TAPS + 1 entries: the fetch one past the end is harmless.
+    __shared__ int tap_lds[CDF_MAX_TAPS + 1];
+    if (tid <= CDF_MAX_TAPS)
+        tap_lds[tid] = tid < ph.ntaps ? (ph.dy[tid] & 0xFF) | ((ph.dx[tid] & 0xFF) << 8) | ((ph.wi[tid] & 0xFF) << 16) : 0;
+    __syncthreads();
+    int tap_cur = tap_lds[0];
+
+    // Straight-line prefetch: every load is unconditional -- an element outside the image / channel range reads the
+    // library's zero page instead (pointer select, no value select: hipcc turns "ok ? load : 0" back into a branch, and
+    // a load inside a divergent branch waits for everything in flight first).
+    f32x4_t ra[APASS], rb[BPASS];                            // (arrays of HIP float4 structs would live in scratch)
+    int tap = 0, c0 = 0, issued = 0;                         // (tap, channel chunk) of the NEXT load
+    auto load_global = [&]() {
+        int tc = tap_cur;                                    // stays in a VGPR (see k_conv_sp.hip)
+#ifndef CDF_EMU
+        asm volatile("" : "+v"(tc));
+#endif
+        const int dy = (int)(signed char)(tc & 0xFF), dx = (int)(signed char)((tc >> 8) & 0xFF), wi = (tc >> 16) & 0xFF;
+        const int tap_pix = dy * a.W + dx;
 #pragma unroll
         for (int p = 0; p < APASS; ++p) {
-            const int iy = a_iy0[p] + dy, ix = a_ix0[p] + dx;
-            const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && (c0 + a_col) < a.Cin;
-            const float* ptr = ok ? X + ((a_img[p] + iy) * a.W + ix) * a.ldx + c0 + a_col : X;
-            const float4 v = *(const float4*)ptr;
-            ra[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned iy = (unsigned)(a_iy0[p] + dy), ix = (unsigned)(a_ix0[p] + dx);
+            const bool ok = iy < (unsigned)a.H && ix < (unsigned)a.W && (c0 + a_col) < a.Cin;
+            const size_t off = (size_t)(a_pix[p] + (unsigned)tap_pix) * (unsigned)a.ldx + (unsigned)(c0 + a_col);
+            ra[p] = *(const f32x4_t*)(ok ? X + off : cdf_zero_page);
         }
 #pragma unroll
         for (int p = 0; p < BPASS; ++p) {
             const int idx = tid + 256 * p;
-            rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < BVEC) {
-                if (!BT) {
-                    const int k = idx / (BN / 4), n4 = idx - k * (BN / 4);
-                    const int ci = c0 + k, co = tile_n * BN + n4 * 4;
-                    const bool ok = ci < a.Cin && co < a.Cout;
-                    const float* ptr = ok ? Wt + ((long long)wi * a.Cin + ci) * a.ldw + co : Wt;
-                    const float4 v = *(const float4*)ptr;
-                    rb[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-                } else {
-                    // B given as [N][K] (K contiguous): read 4 consecutive k of one output column
-                    const int n = idx / (BK / 4), k4 = idx - n * (BK / 4);
-                    const int ci = c0 + k4 * 4, co = tile_n * BN + n;
-                    const bool ok = ci < a.Cin && co < a.Cout;
-                    const float* ptr = ok ? Wt + (long long)co * a.ldw + ci : Wt;
-                    const float4 v = *(const float4*)ptr;
-                    rb[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+            if (!BT) {
+                const int k = idx / (BN / 4), n4 = idx - k * (BN / 4);
+                const int ci = c0 + k, co = tile_n * BN + n4 * 4;
+                const bool ok = idx < BVEC && ci < a.Cin && co < a.Cout;
+                const size_t off = (size_t)((unsigned)wi * (unsigned)a.Cin + (unsigned)ci) * (unsigned)a.ldw + (unsigned)co;
+                rb[p] = *(const f32x4_t*)(ok ? Wt + off : cdf_zero_page);
+            } else {
+                // B given as [N][K] (K contiguous): read 4 consecutive k of one output column
+                const int n = idx / (BK / 4), k4 = idx - n * (BK / 4);
+                const int ci = c0 + k4 * 4, co = tile_n * BN + n;
+                const bool ok = idx < BVEC && ci < a.Cin && co < a.Cout;
+                const size_t off = (size_t)(unsigned)co * (unsigned)a.ldw + (unsigned)ci;
+                rb[p] = *(const f32x4_t*)(ok ? Wt + off : cdf_zero_page);
             }
         }
+        const bool more = issued + 1 < niter;                // block-uniform
+        issued += more ? 1 : 0;
+        const int c1 = c0 + BK;
+        const bool wrap = c1 >= a.Cin;
+        c0 = more ? (wrap ? 0 : c1) : c0;
+        tap += (more && wrap) ? 1 : 0;
+        tap_cur = tap_lds[tap];
     };
     auto store_lds = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < APASS; ++p) *(float4*)(&As[buf][((tid >> 2) + 64 * p) * AS + a_col]) = ra[p];
+        for (int p = 0; p < APASS; ++p) *(f32x4_t*)(&As[buf][((tid >> 2) + 64 * p) * AS + a_col]) = ra[p];
 #pragma unroll
         for (int p = 0; p < BPASS; ++p) {
             const int idx = tid + 256 * p;
             if (idx < BVEC) {
                 if (!BT) {
                     const int k = idx / (BN / 4), n4 = idx - k * (BN / 4);
-                    *(float4*)(&Bs[buf][k * BN + n4 * 4]) = rb[p];
+                    *(f32x4_t*)(&Bs[buf][k * BN + n4 * 4]) = rb[p];
                 } else {
                     const int n = idx / (BK / 4), k4 = idx - n * (BK / 4);
-                    Bs[buf][(k4 * 4 + 0) * BN + n] = rb[p].x;
-                    Bs[buf][(k4 * 4 + 1) * BN + n] = rb[p].y;
-                    Bs[buf][(k4 * 4 + 2) * BN + n] = rb[p].z;
-                    Bs[buf][(k4 * 4 + 3) * BN + n] = rb[p].w;
+                    Bs[buf][(k4 * 4 + 0) * BN + n] = rb[p][0];
+                    Bs[buf][(k4 * 4 + 1) * BN + n] = rb[p][1];
+                    Bs[buf][(k4 * 4 + 2) * BN + n] = rb[p][2];
+                    Bs[buf][(k4 * 4 + 3) * BN + n] = rb[p][3];
                 }
             }
         }
@@ -176,13 +191,13 @@ __global__ void __launch_bounds__(256, 4) conv_igemm_kernel(ConvArgs a) {
 
     const int half = lane >> 5, l31 = lane & 31;
     if (niter > 0) {
-        load_global(0);
+        load_global();
         store_lds(0);
     }
     __syncthreads();
     for (int it = 0; it < niter; ++it) {
         const int buf = it & 1;
-        if (it + 1 < niter) load_global(it + 1);
+        load_global();                                       // chunk it + 1 (past the end: the last chunk again, never stored)
         float af[MT][8], bf[NT][8];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {

@@ -495,13 +495,20 @@ struct SpxArgs {
 
 template <int BM, int BN>
 __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
-    constexpr int BK = 32, AS = 40, MT = BM / 64, NT = BN / 64;      // block tile BM x BN (64 or 128 each), waves 2 x 2
-    constexpr int PLANE_A = BM * AS, PLANE_B = BN * AS;
+    // Block tile BM x BN (64 or 128 each), 4 waves as 2 x 2, BK = 32.  Operand tiles go global -> LDS by LDS-DMA
+    // (CDF_GLDS16): the register-staged version spent as long in ds_write_b128 (13 LDS-path cycles per wave
+    // instruction) as in the MFMAs.  DMA images are lane-linear, so a stage plane is [rows][64 B] without padding and
+    // the bank spreading is an XOR swizzle applied on BOTH sides: the 16-byte column c of row r lives at column
+    // c ^ ((r >> 2) & 3) -- the lane that fills LDS slot (r, c') fetches global column c' ^ ((r >> 2) & 3), the
+    // fragment read of (r, c) goes to c ^ ((r >> 2) & 3).  With that the 16 rows of every ds_read_b128 lane group
+    // (rows = r mod 4 classes x 4 distinct (r >> 2) & 3) cover all 64 banks exactly once.
+    constexpr int BK = 32, RE = 32, MT = BM / 64, NT = BN / 64;       // RE: row elements (64 bytes)
+    constexpr int PLANE_A = BM * RE, PLANE_B = BN * RE;
     constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;                  // A hi, A lo, B hi, B lo
     CDF_DYN_SMEM(smem_raw);
     unsigned short* smem = (unsigned short*)smem_raw;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int M = a.B * a.QH * a.QW;
     const int tiles_n = (a.Cout + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
@@ -509,16 +516,15 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
     const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
     const SpPhase& ph = a.ph[blockIdx.y];
 
-    // both operands: 16-byte column q = tid & 3 (8 bf16), row = rowmap(tid) + 64 p.  The 8 lanes of one
-    // ds_write_b128 group cover rows R and R+4 (320 B apart = bank offset 16) instead of R and R+1
-    // (80 B apart: banks wrap onto each other, 2-way conflict on every store).
-    const int q8 = (tid & 3) * 8;
-    const int g8 = tid >> 3, trow = ((g8 >> 2) << 3) + (g8 & 3) + (((tid >> 2) & 1) << 2);
+    // DMA slots of this lane: wave w fills the 16-row segments w*MT + p of both A planes and w*NT + p of both B planes;
+    // inside a segment lane l is row l >> 2, LDS column l & 3, i.e. global column (l & 3) ^ ((l >> 4) & 3).
+    const int srow = lane >> 2;
+    const int q8 = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
     int a_iy0[MT], a_ix0[MT], b_row[NT];
     unsigned a_pix[MT];
 #pragma unroll
     for (int p = 0; p < MT; ++p) {
-        const int m = tile_m * BM + trow + 64 * p;
+        const int m = tile_m * BM + (wave * MT + p) * 16 + srow;
         if (m < M) {
             const int qx = m % a.QW, t2 = m / a.QW;
             a_iy0[p] = (t2 % a.QH) * a.is;
@@ -532,34 +538,25 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
     }
 #pragma unroll
     for (int p = 0; p < NT; ++p) {
-        const int n = tile_n * BN + trow + 64 * p;
+        const int n = tile_n * BN + (wave * NT + p) * 16 + srow;
         b_row[p] = n < a.Cout ? n : a.Cout - 1;
     }
     const int nchunks = (a.Cin + BK - 1) / BK;
     const int niter = ph.ntaps * nchunks;
 
-    // Tap table -> LDS once (a dynamic index into the by-value kernel argument compiles to per-iteration global byte
-    // loads sitting in front of the tile loads); the next tap's entry is fetched when the tap counter advances, a
-    // whole iteration before it is needed.
-    // The table lives in the 16-byte row padding of the first A plane (entry t behind row t): at 128 x 128 the two
-    // operand stages fill the 80 KB that let two blocks share a CU, one more byte would halve the occupancy.
-    // CDF_MAX_TAPS + 1 entries: the fetch one past the end is harmless.
-    static_assert(BM > CDF_MAX_TAPS, "tap table needs one padded row per entry");
-    auto tap_entry = [&](int t) -> int* { return (int*)(smem + t * AS + BK); };
+    // Tap table -> LDS once, behind the two stages (a dynamic index into the by-value kernel argument compiles to
+    // per-iteration global byte loads in front of the tile loads); the next entry is fetched when the tap counter
+    // advances, an iteration before it is needed.  CDF_MAX_TAPS + 1 entries: the fetch one past the end is harmless.
+    int* tap_lds = (int*)(smem + 2 * STAGE);
     if (tid <= CDF_MAX_TAPS)
-        *tap_entry(tid) = tid < ph.ntaps ? (ph.dy[tid] & 0xFF) | ((ph.dx[tid] & 0xFF) << 8) | ((ph.wi[tid] & 0xFF) << 16) : 0;
-    __syncthreads();
-    int tap_cur = *tap_entry(0);
+        tap_lds[tid] = tid < ph.ntaps ? (ph.dy[tid] & 0xFF) | ((ph.dx[tid] & 0xFF) << 8) | ((ph.wi[tid] & 0xFF) << 16) : 0;
+    CDF_LDS_BARRIER();
+    int tap_cur = tap_lds[0];
 
-    // Register prefetch ring of depth 2: the loads of chunk it+2 are issued at the top of iteration it and only
-    // written to LDS at the end of iteration it+1 -- a global load takes ~1-2 us under load, one iteration's MFMAs
-    // 0.3 us, so a depth-1 prefetch left the matrix cores waiting on memory.  Straight-line code: no branch may sit
-    // between the loads (hipcc would wait for the loads in flight first); past the last chunk the loader simply
-    // re-reads the last one (never stored).
-    struct Regs { u32x4_v ah[MT], al[MT], bh[NT], bl[NT]; };
-    Regs R0, R1;
-    int tap = 0, c0 = 0, issued = 0;                         // incremental (tap, channel chunk) counters of the NEXT load
-    auto load_global = [&](Regs& R) {
+    // Straight-line DMA issue: every lane always fetches -- outside the image / channel range from the zero page.
+    // Past the last chunk the last one is simply fetched again into the idle stage (never read).
+    int tap = 0, c0 = 0, issued = 0;                         // (tap, channel chunk) of the NEXT fetch
+    auto fetch = [&](int buf) {
         // keep the entry in a VGPR: as a (provably uniform) scalar it would be pulled through v_readfirstlane right
         // behind its ds_read, i.e. an LDS round trip on the critical path of every iteration
         int tc = tap_cur;
@@ -570,19 +567,22 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
         const int tap_pix = dy * a.W + dx;
         const unsigned cc = (unsigned)(c0 + q8);
         const bool cok = (c0 + q8) < a.Cin;
+        unsigned short* st = smem + buf * STAGE;
 #pragma unroll
         for (int p = 0; p < MT; ++p) {
             const unsigned iy = (unsigned)(a_iy0[p] + dy), ix = (unsigned)(a_ix0[p] + dx);
             const bool ok = iy < (unsigned)a.H && ix < (unsigned)a.W && cok;
             const size_t off = (size_t)(a_pix[p] + (unsigned)tap_pix) * (unsigned)a.ldx + cc;
-            R.ah[p] = *(const u32x4_v*)(ok ? a.x_hi + off : a.zero);
-            R.al[p] = *(const u32x4_v*)(ok ? a.x_lo + off : a.zero);
+            unsigned short* seg = st + (wave * MT + p) * 16 * RE;
+            CDF_GLDS16(ok ? a.x_hi + off : a.zero, seg);
+            CDF_GLDS16(ok ? a.x_lo + off : a.zero, seg + PLANE_A);
         }
 #pragma unroll
         for (int p = 0; p < NT; ++p) {
             const size_t woff = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)b_row[p]) * (unsigned)a.ldk + cc;
-            R.bh[p] = *(const u32x4_v*)(a.w_hi + woff);
-            R.bl[p] = *(const u32x4_v*)(a.w_lo + woff);
+            unsigned short* seg = st + 2 * PLANE_A + (wave * NT + p) * 16 * RE;
+            CDF_GLDS16(a.w_hi + woff, seg);
+            CDF_GLDS16(a.w_lo + woff, seg + PLANE_B);
         }
         const bool more = issued + 1 < niter;                // block-uniform
         issued += more ? 1 : 0;
@@ -590,20 +590,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
         const bool wrap = c1 >= a.Cin;
         c0 = more ? (wrap ? 0 : c1) : c0;
         tap += (more && wrap) ? 1 : 0;
-        tap_cur = *tap_entry(tap);
-    };
-    auto store_lds = [&](int buf, const Regs& R) {
-        unsigned short* st = smem + buf * STAGE + trow * AS + q8;
-#pragma unroll
-        for (int p = 0; p < MT; ++p) {
-            *(u32x4_v*)(st + 64 * p * AS) = R.ah[p];
-            *(u32x4_v*)(st + PLANE_A + 64 * p * AS) = R.al[p];
-        }
-#pragma unroll
-        for (int p = 0; p < NT; ++p) {
-            *(u32x4_v*)(st + 2 * PLANE_A + 64 * p * AS) = R.bh[p];
-            *(u32x4_v*)(st + 2 * PLANE_A + PLANE_B + 64 * p * AS) = R.bl[p];
-        }
+        tap_cur = tap_lds[tap];
     };
 
     f32x16_t acc[MT][NT];
@@ -615,22 +602,28 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int half = lane >> 5, l31 = lane & 31;
-    auto compute = [&](int buf) {
+    const int sw = (l31 >> 2) & 3;                           // read-side swizzle (tile row offsets are multiples of 32)
+    if (niter > 0) fetch(0);
+    CDF_WAIT_DMA();
+    CDF_LDS_BARRIER();
+    for (int it = 0; it < niter; ++it) {
+        const int buf = it & 1;
+        fetch(buf ^ 1);                                      // chunk it + 1 lands while chunk it is multiplied
         const unsigned short* sa = smem + buf * STAGE;
         const unsigned short* sb = sa + 2 * PLANE_A;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int k0 = ks * 16 + half * 8;
+            const int kc = ((ks * 2 + half) ^ sw) * 8;
             bf16x8_v ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const int off = (wm * (BM / 2) + i * 32 + l31) * AS + k0;
+                const int off = (wm * (BM / 2) + i * 32 + l31) * RE + kc;
                 ah[i] = *(const bf16x8_v*)(sa + off);
                 al[i] = *(const bf16x8_v*)(sa + PLANE_A + off);
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const int off = (wn * (BN / 2) + j * 32 + l31) * AS + k0;
+                const int off = (wn * (BN / 2) + j * 32 + l31) * RE + kc;
                 bh[j] = *(const bf16x8_v*)(sb + off);
                 bl[j] = *(const bf16x8_v*)(sb + PLANE_B + off);
             }
@@ -643,34 +636,9 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
                     acc[i][j] = CDF_MFMA_BF16(ah[i], bh[j], acc[i][j]);
                 }
         }
-    };
-    // chunk c lives in ring slot c & 1 and in LDS stage c & 1
-    if (niter > 0) {
-        load_global(R0);                                     // chunk 0
-        store_lds(0, R0);
-        load_global(R1);                                     // chunk 1 (or chunk 0 again)
+        CDF_WAIT_DMA();                                      // this wave's pieces of chunk it + 1 have landed ...
+        CDF_LDS_BARRIER();                                   // ... and so have everybody else's; chunk it is fully consumed
     }
-    CDF_LDS_BARRIER();
-    for (int it = 0; it < niter; it += 2) {
-#if !(CDF_ABLATE & 1)
-        load_global(R0);                                     // chunk it + 2
-#endif
-        compute(0);
-#if !(CDF_ABLATE & 8)
-        if (it + 1 < niter) store_lds(1, R1);                // chunk it + 1, issued one iteration ago
-#endif
-        CDF_LDS_BARRIER();
-        if (it + 1 >= niter) break;
-#if !(CDF_ABLATE & 1)
-        load_global(R1);                                     // chunk it + 3
-#endif
-        compute(1);
-#if !(CDF_ABLATE & 8)
-        if (it + 2 < niter) store_lds(0, R0);                // chunk it + 2
-#endif
-        CDF_LDS_BARRIER();
-    }
-    __syncthreads();                                         // drain the tail prefetch before LDS is reused
 
     cdf_sp_epilogue<BM, BN>(a, ph, acc, (float*)smem_raw, tile_m, tile_n, M, tid);
 }
@@ -1082,9 +1050,9 @@ extern "C" int cdf_conv_gemm_bf16x_tile(int bm, int bn) {
 
 template <int BM, int BN>
 static int launch_igemm_spx(const SpxArgs& a, int M, hipStream_t s) {
-    constexpr size_t stages = (size_t)2 * 2 * (BM + BN) * 40 * sizeof(unsigned short);
+    constexpr size_t stages = (size_t)2 * 2 * (BM + BN) * 32 * sizeof(unsigned short) + (CDF_MAX_TAPS + 1) * sizeof(int);
     constexpr size_t epi = (size_t)BM * (BN + 8) * sizeof(float);
-    constexpr size_t lds = stages > epi ? stages : epi;      // 128 x 128: 80 KB, two blocks per CU
+    constexpr size_t lds = stages > epi ? stages : epi;      // 128 x 128: 68 KB (epilogue tile), two blocks per CU
 #ifndef CDF_EMU
     static bool attr_done = false;
     if (!attr_done) {

@@ -172,6 +172,8 @@ inline emu_s4 ds_read_tr16_b64(const unsigned short* p) {
     hipemu::launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), stream, __VA_ARGS__)
 #define CDF_DYN_SMEM(name) unsigned char* name = hipemu::g.dyn_smem
 #define CDF_LDS_BARRIER() hipemu::block_barrier()
+#define CDF_GLDS16(gptr, lds_base) memcpy((unsigned char*)(lds_base) + 16 * hipemu::lane_id(), (const void*)(gptr), 16)
+#define CDF_WAIT_DMA() ((void)0)
 
 static inline void __syncthreads() { hipemu::block_barrier(); }
 
