@@ -35,17 +35,39 @@ def _img(x):
     return x.contiguous().float()
 
 
-def blur_chain(x, taps, k, pad_mode, t=None, step_lo=0, step_hi=0, img=None, want_prev=False, collapse_step=-1, quantise=False):
+def blur_chain(x, taps, k, pad_mode, t=None, step_lo=0, step_hi=0, img=None, want_prev=False, collapse_step=-1, quantise=False,
+               taps1d=None):
     """Apply blur steps step_lo..hi(b) (hi = t[b] or step_hi) with the plane resident in LDS.
-    Returns y (or the Alg.2 combination img - D_hi + D_{hi-1} when img is given) [, D_{hi-1}]."""
+    Returns y (or the Alg.2 combination img - D_hi + D_{hi-1} when img is given) [, D_{hi-1}].
+    taps1d ([T, C, 2, k], see separable_taps) selects the separable kernel: 2k instead of k*k FMAs per pixel."""
     x = _img(x)
     B, C, H, W = x.shape
     y = torch.empty_like(x)
     snap = torch.empty_like(x) if want_prev else None
     img = None if img is None else _img(img)     # keep the (possibly converted) tensor alive over the launch
-    rt.lib().cdf_blur_chain(P(x), P(y), P(snap), P(img), P(taps), P(t), B, C, H, W, k, step_lo, step_hi,
-                            pad_mode, collapse_step, 1 if quantise else 0, rt.stream(x))
+    L = rt.lib()
+    if taps1d is not None and k <= 64 and k // 2 < min(H, W) and L.cdf_blur_sep_lds_bytes(H, W) <= 160 * 1024:
+        L.cdf_blur_chain_sep(P(x), P(y), P(snap), P(img), P(taps1d), P(t), B, C, H, W, k, step_lo, step_hi,
+                             pad_mode, collapse_step, 1 if quantise else 0, rt.stream(x))
+    else:
+        L.cdf_blur_chain(P(x), P(y), P(snap), P(img), P(taps), P(t), B, C, H, W, k, step_lo, step_hi,
+                         pad_mode, collapse_step, 1 if quantise else 0, rt.stream(x))
     return (y, snap) if want_prev else y
+
+
+def separable_taps(taps):
+    """[T, C, k, k] kernel stack -> [T, C, 2, k] (factor along y, factor along x) if EVERY kernel is an outer product of
+    its row sums and column sums to fp32 rounding (true for the reference's Gaussians g (x) g, whose taps sum to 1:
+    DEBLUR:363-389), else None.  The weights are state_dict data, so this is checked, not assumed."""
+    w = taps.double()
+    tot = w.sum((-1, -2), keepdim=True)
+    if not bool((tot.abs() > 1e-12).all()):
+        return None
+    gy, gx = w.sum(-1), w.sum(-2) / tot.squeeze(-1)           # w ~ gy[:, None] * gx[None, :]
+    resid = (w - gy.unsqueeze(-1) * gx.unsqueeze(-2)).abs().amax((-1, -2))
+    if not bool((resid <= 1e-7 * w.abs().amax((-1, -2))).all()):
+        return None
+    return torch.stack([gy, gx], dim=-2).float().contiguous()
 
 
 def blur_fits_lds(H, W, k):

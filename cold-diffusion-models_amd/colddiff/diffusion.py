@@ -92,8 +92,14 @@ class DeblurDiffusion(nn.Module):
         ws = [m.weight for m in self.gaussian_kernels]
         key = (str(device), tuple((w.data_ptr(), w._version) for w in ws))
         if self._taps_cache is None or self._taps_cache[0] != key:
-            self._taps_cache = (key, torch.stack([w.detach()[:, 0] for w in ws]).to(device).contiguous())
+            taps = torch.stack([w.detach()[:, 0] for w in ws]).to(device).contiguous()
+            self._taps_cache = (key, taps, D.separable_taps(taps))
         return self._taps_cache[1]
+
+    def _taps1d(self, device):
+        """[T, C, 2, k] 1-D factors of the kernels when all of them are rank one (the Gaussians are), else None."""
+        self._taps(device)
+        return self._taps_cache[2]
 
     def _apply_one(self, i, x):
         """gaussian_kernels[i](x) (any kernel size)."""
@@ -108,7 +114,7 @@ class DeblurDiffusion(nn.Module):
         if self._uniform() and D.blur_fits_lds(H, W, self.gaussian_kernels[0].weight.shape[-1]):
             k = self.gaussian_kernels[0].weight.shape[-1]
             return D.blur_chain(x, self._taps(x.device), k, self._pad_mode(), t=t, step_lo=0, step_hi=nsteps - 1, img=img,
-                                want_prev=want_prev, collapse_step=collapse, quantise=quantise)
+                                want_prev=want_prev, collapse_step=collapse, quantise=quantise, taps1d=self._taps1d(x.device))
         assert t is None and not quantise, "per-sample t needs the LDS-resident path"
         prev = x
         for i in range(nsteps):

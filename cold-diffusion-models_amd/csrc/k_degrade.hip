@@ -175,6 +175,127 @@ __global__ void __launch_bounds__(1024) blur_plane_lds_kernel(BlurArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Separable variant.  The reference's kernels are Gaussians g (x) g (DEBLUR:363-389), so a step is a 1-D pass along
+// x followed by a 1-D pass along y: 2k instead of k^2 FMAs per pixel (30 vs 225 at k = 15 -- the dense version is
+// VALU-bound at ~80 us per step and 128x128 plane, and a q_sample at T = 200 runs up to 200 of them back to back).
+// taps = [nsteps][C][2][k] (row 0: factor along y, row 1: along x), supplied by the host only when every kernel is
+// rank one to fp32 rounding (|w - gy gx^T| <= 1e-7 max w); results differ from the dense conv by rounding only.
+// LDS: U = state [H][W], T = row-pass output [H][W]; border handling by index mapping (no padded copy).
+// The state BEFORE the last step (needed by snap / Alg. 2) is written to global memory just before that step.
+// ------------------------------------------------------------------------------------------------
+// border index for -n < i < 2n (k/2 < n is required by the caller): no integer division
+__device__ __forceinline__ int cdf_pad_near(int i, int n, int mode) {
+    if (mode == 0) return i < 0 ? i + n : (i >= n ? i - n : i);
+    return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i);
+}
+
+template <int K>
+__global__ void __launch_bounds__(1024) blur_plane_sep_kernel(BlurArgs a) {
+    CDF_DYN_SMEM(smem);
+    const int H = a.H, W = a.W, k = (K > 0 ? K : a.k), h = k / 2;
+    float* U = (float*)smem;
+    float* T = U + (size_t)H * W;
+    float* red = T + (size_t)H * W;                 // 32 floats
+    float* wt = red + 32;                           // [2 stages][2][64]: the step's 1-D factors (k <= 64), double buffered
+    const int plane = blockIdx.x, b = plane / a.C, c = plane % a.C;
+    const int nt = blockDim.x, tid = threadIdx.x;
+    const size_t poff = (size_t)plane * H * W;
+    const int hi = a.t ? (int)a.t[b] : a.step_hi;
+    float* prev_out = a.snap ? a.snap : (a.img ? a.y : nullptr);      // Alg. 2 without snap: y doubles as scratch
+
+    for (int i = tid; i < H * W; i += nt) U[i] = a.x[poff + i];
+    // the factors of step s live in wt[(s & 1)]: fetched by the first 2k threads one step ahead (a uniform scalar read of
+    // them inside the strip loops turns into per-strip global loads with a full round trip each)
+    auto fetch_w = [&](int s) {
+        if (tid < 2 * k && s <= hi) {
+            const int r = tid >= k ? 1 : 0, e = tid - r * k;
+            wt[((s & 1) * 2 + r) * 64 + e] = a.taps[(((size_t)s * a.C + c) * 2 + r) * k + e];
+        }
+    };
+    fetch_w(a.step_lo);
+    __syncthreads();
+    const int strips_per_row = W / 4, nstrips = strips_per_row * H;
+    constexpr int H4 = K > 0 ? ((K / 2 + 3) & ~3) : 0;               // aligned left reach of the fast row pass
+    constexpr int NV = K > 0 ? (2 * H4 + 4) / 4 : 1;                 // float4s covering [x0 - H4, x0 + 4 + H4)
+    for (int s = a.step_lo; s <= hi; ++s) {
+        if (s == hi && prev_out)
+            for (int i = tid; i < H * W; i += nt) prev_out[poff + i] = U[i];
+        const float* gy = wt + (s & 1) * 128;
+        const float* gx = gy + 64;
+        // pass along x: T[y][x] = sum_kx gx[kx] U[y][map(x + kx - h)]
+        for (int st = tid; st < nstrips; st += nt) {
+            const int y = st / strips_per_row, x0 = (st - y * strips_per_row) * 4;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            const float* row = U + y * W;
+            if (K > 0 && x0 >= H4 && x0 + 4 + H4 <= W) {
+                float r[NV * 4];
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    const float4 v = *(const float4*)(row + x0 - H4 + 4 * q);
+                    r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+                }
+#pragma unroll
+                for (int kx = 0; kx < (K > 0 ? K : 1); ++kx) {
+                    const float wv = gx[kx];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(wv, r[H4 - K / 2 + kx + j], acc[j]);
+                }
+            } else {
+                for (int e = 0; e < k + 3; ++e) {            // the strip's k + 3 source pixels, each mapped once
+                    const float v = row[cdf_pad_near(x0 + e - h, W, a.pad_mode)];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int kx = e - j;
+                        if (kx >= 0 && kx < k) acc[j] = fmaf(gx[kx], v, acc[j]);
+                    }
+                }
+            }
+            *(float4*)(T + y * W + x0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+        fetch_w(s + 1);                                      // lands before the barrier that ends this step
+        __syncthreads();
+        // pass along y: U[y][x] = sum_ky gy[ky] T[map(y + ky - h)][x]
+        for (int st = tid; st < nstrips; st += nt) {
+            const int y = st / strips_per_row, x0 = (st - y * strips_per_row) * 4;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 5
+            for (int ky = 0; ky < k; ++ky) {
+                const int sy = cdf_pad_near(y + ky - h, H, a.pad_mode);
+                const float4 v = *(const float4*)(T + sy * W + x0);
+                const float wv = gy[ky];
+                acc.x = fmaf(wv, v.x, acc.x); acc.y = fmaf(wv, v.y, acc.y); acc.z = fmaf(wv, v.z, acc.z); acc.w = fmaf(wv, v.w, acc.w);
+            }
+            *(float4*)(U + y * W + x0) = acc;
+        }
+        __syncthreads();
+        if (s == a.collapse_step) {
+            float part = 0.f;
+            for (int i = tid; i < H * W; i += nt) part += U[i];
+            const float mean = cdf_block_sum(part, red) / (float)(H * W);
+            for (int i = tid; i < H * W; i += nt) U[i] = mean;
+            __syncthreads();
+        }
+    }
+    const bool stepped = hi >= a.step_lo;
+    if (!stepped && a.snap)
+        for (int i = tid; i < H * W; i += nt) a.snap[poff + i] = U[i];
+    if (a.img) {
+        // Alg. 2: x = img - D(x0,t) + D(x0,t-1)   (DEBLUR:451); D(x0,t-1) was parked in prev_out by this same thread
+        for (int i = tid; i < H * W; i += nt) {
+            const float prev = stepped ? prev_out[poff + i] : U[i];
+            const float v = a.img[poff + i] - U[i];
+            a.y[poff + i] = v + prev;
+        }
+    } else {
+        for (int i = tid; i < H * W; i += nt) {
+            float v = U[i];
+            if (a.quantise) v = cdf_quantise8(v);
+            a.y[poff + i] = v;
+        }
+    }
+}
+
 // Generic single-step blur straight from global memory (any plane size / per-step kernel size).
 __global__ void blur_step_global_kernel(const float* x, float* y, const float* taps /*[C][k][k]*/, int B, int C, int H,
                                          int W, int k, int pad_mode) {
@@ -548,6 +669,45 @@ extern "C" int cdf_blur_chain(const float* x, float* y, float* snap, const float
             return sw8 ? launch_blur_plane<0, 8>(a, nt, lds, CDF_S) : launch_blur_plane<0, 4>(a, nt, lds, CDF_S);
     }
 #undef CDF_BLUR_CASE
+}
+
+template <int K>
+static int launch_blur_sep(const BlurArgs& a, int nt, size_t lds, hipStream_t s) {
+#ifndef CDF_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)blur_plane_sep_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+#endif
+    CDF_LAUNCH((blur_plane_sep_kernel<K>), dim3(a.B * a.C), dim3(nt), lds, s, a);
+    return cdf_check_launch("blur_plane_sep");
+}
+
+extern "C" size_t cdf_blur_sep_lds_bytes(int H, int W) { return ((size_t)2 * H * W + 32 + 256) * sizeof(float); }
+
+// taps1d = [nsteps][C][2][k]: per step and channel the factor along y, then the factor along x
+extern "C" int cdf_blur_chain_sep(const float* x, float* y, float* snap, const float* img, const float* taps1d,
+                                  const int64_t* t, int B, int C, int H, int W, int k, int step_lo, int step_hi,
+                                  int pad_mode, int collapse_step, int quantise, void* stream) {
+    CDF_REQUIRE(x && y && taps1d, "cdf_blur_chain_sep: null pointer");
+    CDF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && k > 0 && (k & 1), "cdf_blur_chain_sep: bad shape B=%d C=%d H=%d W=%d k=%d", B, C, H, W, k);
+    CDF_REQUIRE(pad_mode == 0 || pad_mode == 1, "cdf_blur_chain_sep: pad_mode must be 0 (circular) or 1 (reflect)");
+    CDF_REQUIRE(k / 2 < H && k / 2 < W && k <= 64, "cdf_blur_chain_sep: needs k/2 < H,W and k <= 64");
+    CDF_REQUIRE(!img || (x != y && img != y), "cdf_blur_chain_sep: y must not alias x / img in the Alg. 2 form");
+    const size_t lds = cdf_blur_sep_lds_bytes(H, W);
+    CDF_REQUIRE(lds <= 160 * 1024 && (W % 4) == 0, "cdf_blur_chain_sep: plane %dx%d does not fit the LDS-resident kernel", H, W);
+    BlurArgs a{x, y, snap, img, taps1d, t, B, C, H, W, k, step_lo, step_hi, pad_mode, collapse_step, quantise};
+    int nt = ((H * W / 4 + 63) / 64) * 64;
+    if (nt > 1024) nt = 1024;
+    if (nt < 64) nt = 64;
+    switch (k) {
+        case 3: return launch_blur_sep<3>(a, nt, lds, CDF_S);
+        case 11: return launch_blur_sep<11>(a, nt, lds, CDF_S);
+        case 15: return launch_blur_sep<15>(a, nt, lds, CDF_S);
+        case 27: return launch_blur_sep<27>(a, nt, lds, CDF_S);
+        default: return launch_blur_sep<0>(a, nt, lds, CDF_S);
+    }
 }
 
 extern "C" int cdf_blur_step(const float* x, float* y, const float* taps, int B, int C, int H, int W, int k,

@@ -49,6 +49,14 @@ int cdf_blur_chain(const float* x, float* y, float* snap, const float* img, cons
                    int B, int C, int H, int W, int k, int step_lo, int step_hi, int pad_mode, int collapse_step,
                    int quantise, void* stream);
 /* one blur step from global memory (any plane size, per-step kernel size); x != y */
+/* Separable form of cdf_blur_chain for rank-one (Gaussian g (x) g) kernels: taps1d = [nsteps][C][2][k], per step and
+ * channel the 1-D factor along y followed by the factor along x.  2k instead of k*k FMAs per pixel and step; same
+ * arguments and semantics otherwise (results equal cdf_blur_chain up to fp32 rounding of the taps' outer product).
+ * In the Alg. 2 form (img != NULL) y must not alias x or img. */
+size_t cdf_blur_sep_lds_bytes(int H, int W);
+int cdf_blur_chain_sep(const float* x, float* y, float* snap, const float* img, const float* taps1d, const int64_t* t,
+                       int B, int C, int H, int W, int k, int step_lo, int step_hi, int pad_mode, int collapse_step,
+                       int quantise, void* stream);
 int cdf_blur_step(const float* x, float* y, const float* taps, int B, int C, int H, int W, int k, int pad_mode,
                   void* stream);
 int cdf_plane_mean(float* x, int planes, int HW, void* stream);

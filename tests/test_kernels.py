@@ -4,6 +4,7 @@ the reference op it replaces.  Each test runs on two backends (see conftest.Back
   hip : libcolddiff_hip.so on a real MI355X (@pytest.mark.gpu)  — the product
 """
 import math
+import os
 
 import pytest
 import torch
@@ -76,6 +77,59 @@ def test_blur_chain(be, H, k, mode):
     zq = ((z + 1) * 0.5 * 255).int().float() / 255 * 2 - 1
     d = (yq.cpu() - zq).abs()
     # truncation may flip one 8-bit level (2/255) where the mean differs in the last ulp
+    assert (d <= 1e-6).logical_or((d - 2 / 255).abs() <= 1e-6).all()
+
+
+@pytest.mark.parametrize("H,k,mode", [(16, 3, "circular"), (16, 11, "reflect"), (32, 15, "reflect"), (32, 15, "circular"),
+                                      (12, 5, "reflect"), (40, 27, "reflect")])
+def test_blur_chain_separable(be, H, k, mode):
+    """Rank-one (Gaussian g (x) g) kernels through the separable LDS-resident chain: same semantics as cdf_blur_chain
+    (per-sample t, snapshot of the previous state, Alg. 2 combine, discrete collapse + quantise), results equal to the
+    dense depthwise conv of the reference (DEBLUR:351-361) up to rounding."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "cold-diffusion-models_amd"))
+    from colddiff import degrade as D
+    torch.manual_seed(0)
+    B, C, T = 3, 3, 5
+    x = torch.randn(B, C, H, H)
+    taps = torch.stack([torch.stack([D.gaussian_kernel2d(k, 0.6 + 0.7 * i + 0.1 * c) for c in range(C)]) for i in range(T)])
+    t1 = D.separable_taps(taps)
+    assert t1 is not None and t1.shape == (T, C, 2, k)
+    assert D.separable_taps(torch.rand(T, C, k, k)) is None          # generic kernels must be refused
+    t = torch.tensor([4, 2, 0])
+    pm = 0 if mode == "circular" else 1
+    xd, t1d, td = be.to(x), be.to(t1), be.to(t)
+    y, snap = be.empty(B, C, H, H), be.empty(B, C, H, H)
+    be.L.cdf_blur_chain_sep(P(xd), P(y), P(snap), 0, P(t1d), P(td), B, C, H, H, k, 0, 0, pm, -1, 0, be.stream())
+
+    def step(z, i):
+        return F.conv2d(F.pad(z, (k // 2,) * 4, mode=mode), taps[i].unsqueeze(1), groups=C)
+
+    ref, refp = [], []
+    for b in range(B):
+        z = x[b:b + 1]
+        prev = z
+        for i in range(int(t[b]) + 1):
+            prev, z = z, step(z, i)
+        ref.append(z)
+        refp.append(prev)
+    ref, refp = torch.cat(ref), torch.cat(refp)
+    assert err(y, ref) <= 3e-6 and err(snap, refp) <= 3e-6
+    img = torch.randn(B, C, H, H)
+    out = be.empty(B, C, H, H)
+    be.L.cdf_blur_chain_sep(P(xd), P(out), 0, P(be.to(img)), P(t1d), P(td), B, C, H, H, k, 0, 0, pm, -1, 0, be.stream())
+    assert err(out, img - ref + refp) <= 6e-6
+    out2, snap2 = be.empty(B, C, H, H), be.empty(B, C, H, H)
+    be.L.cdf_blur_chain_sep(P(xd), P(out2), P(snap2), P(be.to(img)), P(t1d), P(td), B, C, H, H, k, 0, 0, pm, -1, 0, be.stream())
+    assert err(out2, img - ref + refp) <= 6e-6 and err(snap2, refp) <= 3e-6
+    yq = be.empty(B, C, H, H)
+    be.L.cdf_blur_chain_sep(P(xd), P(yq), 0, 0, P(t1d), 0, B, C, H, H, k, 0, 2, pm, 2, 1, be.stream())
+    z = x
+    for i in range(3):
+        z = step(z, i)
+    z = z.mean((2, 3), keepdim=True).expand_as(x)
+    zq = ((z + 1) * 0.5 * 255).int().float() / 255 * 2 - 1
+    d = (yq.cpu() - zq).abs()
     assert (d <= 1e-6).logical_or((d - 2 / 255).abs() <= 1e-6).all()
 
 
