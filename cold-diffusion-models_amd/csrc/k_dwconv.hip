@@ -231,19 +231,28 @@ __global__ void __launch_bounds__(256) dwconv7_wgrad_partial_kernel(const float*
 }
 
 // dw[c*49 + tap] (+)= sum_{b,chunk} part ; dbias[c] (+)= sum part[..][49] ; dsb[b][c] = sum_chunk part[b][..][49]
-// grid = (ceil(C/64), 50 taps); block 256 = 4 partial lanes x 64 channels (lanes split the b*nchunk partials)
-__global__ void dwconv7_wgrad_final_kernel(const float* part, int B, int nchunk, int C, float* dw, float* dbias,
-                                           float* dsb, int ld_dsb, int accumulate) {
-    __shared__ float red[4][64];
+// grid = (ceil(C/64), 50 taps); block 1024 = 16 partial lanes x 64 channels (the lanes split the b*nchunk partials,
+// two independent loads in flight each)
+__global__ void __launch_bounds__(1024) dwconv7_wgrad_final_kernel(const float* part, int B, int nchunk, int C, float* dw, float* dbias,
+                                                                  float* dsb, int ld_dsb, int accumulate) {
+    __shared__ float red[16][64];
     const int l = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + l, t = blockIdx.y;
     const int n = B * nchunk;
-    float s = 0.f;
-    if (c < C)
-        for (int i = rl; i < n; i += 4) s += part[((long long)i * (DW_TAPS + 1) + t) * C + c];
-    red[rl][l] = s;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        int i = rl;
+        for (; i + 16 < n; i += 32) {
+            s0 += part[((long long)i * (DW_TAPS + 1) + t) * C + c];
+            s1 += part[((long long)(i + 16) * (DW_TAPS + 1) + t) * C + c];
+        }
+        if (i < n) s0 += part[((long long)i * (DW_TAPS + 1) + t) * C + c];
+    }
+    red[rl][l] = s0 + s1;
     __syncthreads();
     if (rl == 0 && c < C) {
-        const float tot = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        float tot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot += red[r][l];
         if (t < DW_TAPS) {
             float* dst = dw + (long long)c * DW_TAPS + t;
             *dst = accumulate ? *dst + tot : tot;
@@ -253,7 +262,7 @@ __global__ void dwconv7_wgrad_final_kernel(const float* part, int B, int nchunk,
     }
     if (t == DW_TAPS && dsb) {          // per-sample time-bias gradient: sum over the chunks of each sample
         __syncthreads();
-        for (int b = rl; b < B; b += 4) {
+        for (int b = rl; b < B; b += 16) {
             if (c < C) {
                 float sb = 0.f;
                 for (int k = 0; k < nchunk; ++k) sb += part[(((long long)b * nchunk + k) * (DW_TAPS + 1) + DW_TAPS) * C + c];
@@ -308,6 +317,6 @@ extern "C" int cdf_dwconv7_wgrad(const float* x, int ldx, const float* dy, int l
                 "cdf_dwconv7_wgrad: pitches must be multiples of 4 and >= roundup4(C), pointers 16B aligned");
     const int nchunk = cdf_dwconv7_wgrad_nchunk(H), rpc = cdf_cdiv(H, nchunk);
     CDF_LAUNCH(dwconv7_wgrad_partial_kernel, dim3(cdf_cdiv(C, 64), nchunk, B), dim3(256), 0, CDF_S, x, ldx, dy, lddy, ws, H, W, C, rpc);
-    CDF_LAUNCH(dwconv7_wgrad_final_kernel, dim3(cdf_cdiv(C, 64), DW_TAPS + 1), dim3(256), 0, CDF_S, (const float*)ws, B, nchunk, C, dw, dbias, dsb, ld_dsb, accumulate);
+    CDF_LAUNCH(dwconv7_wgrad_final_kernel, dim3(cdf_cdiv(C, 64), DW_TAPS + 1), dim3(1024), 0, CDF_S, (const float*)ws, B, nchunk, C, dw, dbias, dsb, ld_dsb, accumulate);
     return cdf_check_launch("dwconv7_wgrad");
 }

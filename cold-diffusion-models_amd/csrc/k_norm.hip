@@ -12,57 +12,76 @@
 // ------------------------------------------------------------------------------------------------
 // channel LayerNorm
 // ------------------------------------------------------------------------------------------------
+// HBM-bound (8 B / element forward, 12-16 B backward).  Each wave handles 64/LP pixels at a time, and every lane keeps
+// the loads of U consecutive pixel groups in flight (unconditional: clamped address + select) -- with one load per
+// lane in flight and the 512-block grid the kernels sat at a quarter of the HBM rate.
 template <int NV>
 __global__ void __launch_bounds__(256) layernorm_c_fwd_kernel(const float* x, int ldx, float* y, int ldy, const float* g,
                                                               const float* bta, float* mean_out, float* rstd_out,
                                                               long long M, int C, int LP, float eps) {
+    constexpr int U = NV <= 2 ? 4 : 2;
     const int lane = threadIdx.x & 63, sub = lane / LP, li = lane - sub * LP;
     const int groups_per_wave = 64 / LP;
     const long long wave_global = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
     const long long npg = (M + groups_per_wave - 1) / groups_per_wave;  // pixel groups
-    for (long long pg = wave_global; pg < npg; pg += nwaves) {
-        const long long m = pg * groups_per_wave + sub;
-        const bool valid = m < M;
-        float4 v[NV];
-        float s = 0.f;
+    float4 gg[NV], bb[NV];
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int c = (li + j * LP) * 4;
-            if (valid && c < C) v[j] = *(const float4*)(x + m * ldx + c);
-            else v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-        }
-        s = cdf_group_sum(s, LP);
-        const float mean = s / (float)C;
-        float q = 0.f;
+    for (int j = 0; j < NV; ++j) {
+        const int c = (li + j * LP) * 4;
+        gg[j] = *(const float4*)(g + (c < C ? c : 0));
+        bb[j] = *(const float4*)(bta + (c < C ? c : 0));
+    }
+    for (long long pg0 = wave_global * U; pg0 < npg; pg0 += nwaves * U) {
+        float4 v[U][NV];
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int c = (li + j * LP) * 4;
-            if (c < C) {
-                const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
-                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        for (int u = 0; u < U; ++u) {
+            const long long m = (pg0 + u) * groups_per_wave + sub;
+            const long long mc = m < M ? m : M - 1;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = (li + j * LP) * 4;
+                const float4 t = *(const float4*)(x + mc * ldx + (c < C ? c : 0));
+                v[u][j] = (m < M && c < C) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        q = cdf_group_sum(q, LP);
-        const float sd = sqrtf(q / (float)C + eps);
-        if (valid) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long m = (pg0 + u) * groups_per_wave + sub;
+            const bool valid = m < M;
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) s += (v[u][j].x + v[u][j].y) + (v[u][j].z + v[u][j].w);
+            s = cdf_group_sum(s, LP);
+            const float mean = s / (float)C;
+            float q = 0.f;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int c = (li + j * LP) * 4;
                 if (c < C) {
-                    const float4 gg = *(const float4*)(g + c), bb = *(const float4*)(bta + c);
-                    float4 o;
-                    o.x = (v[j].x - mean) / sd * gg.x + bb.x;
-                    o.y = (v[j].y - mean) / sd * gg.y + bb.y;
-                    o.z = (v[j].z - mean) / sd * gg.z + bb.z;
-                    o.w = (v[j].w - mean) / sd * gg.w + bb.w;
-                    *(float4*)(y + m * ldy + c) = o;
+                    const float a0 = v[u][j].x - mean, a1 = v[u][j].y - mean, a2 = v[u][j].z - mean, a3 = v[u][j].w - mean;
+                    q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
                 }
             }
-            if (li == 0 && mean_out) {
-                mean_out[m] = mean;
-                rstd_out[m] = 1.0f / sd;
+            q = cdf_group_sum(q, LP);
+            const float sd = sqrtf(q / (float)C + eps);
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int c = (li + j * LP) * 4;
+                    if (c < C) {
+                        float4 o;
+                        o.x = (v[u][j].x - mean) / sd * gg[j].x + bb[j].x;
+                        o.y = (v[u][j].y - mean) / sd * gg[j].y + bb[j].y;
+                        o.z = (v[u][j].z - mean) / sd * gg[j].z + bb[j].z;
+                        o.w = (v[u][j].w - mean) / sd * gg[j].w + bb[j].w;
+                        *(float4*)(y + m * ldy + c) = o;
+                    }
+                }
+                if (li == 0 && mean_out) {
+                    mean_out[m] = mean;
+                    rstd_out[m] = 1.0f / sd;
+                }
             }
         }
     }
@@ -74,6 +93,7 @@ __global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const float* dy, i
                                                               const float* g, const float* mean_in, const float* rstd_in,
                                                               float* dx, int lddx, float* part, long long M, int C,
                                                               int LP, int accumulate_dx) {
+    constexpr int U = NV <= 2 ? 2 : 1;
     CDF_DYN_SMEM(smem);
     float* sred = (float*)smem;  // [G][2][C]
     const int lane = threadIdx.x & 63, sub = lane / LP, li = lane - sub * LP;
@@ -83,53 +103,66 @@ __global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const float* dy, i
     const long long wave_global = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
     const long long npg = (M + groups_per_wave - 1) / groups_per_wave;
-    float4 adg[NV], adb[NV];
+    float4 adg[NV], adb[NV], gg[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
+        const int c = (li + j * LP) * 4;
         adg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         adb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gg[j] = *(const float4*)(g + (c < C ? c : 0));
     }
-    for (long long pg = wave_global; pg < npg; pg += nwaves) {
-        const long long m = pg * groups_per_wave + sub;
-        const bool valid = m < M;
-        const float mean = valid ? mean_in[m] : 0.f, rstd = valid ? rstd_in[m] : 0.f;
-        float4 xh[NV], dg_[NV];
-        float s1 = 0.f, s2 = 0.f;
+    for (long long pg0 = wave_global * U; pg0 < npg; pg0 += nwaves * U) {
+        float4 xv[U][NV], dv[U][NV], old[U][NV];
+        float mean[U], rstd[U];
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int c = (li + j * LP) * 4;
-            xh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            dg_[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid && c < C) {
-                const float4 xv = *(const float4*)(x + m * ldx + c), dv = *(const float4*)(dy + m * lddy + c);
-                const float4 gg = *(const float4*)(g + c);
-                xh[j].x = (xv.x - mean) * rstd; xh[j].y = (xv.y - mean) * rstd;
-                xh[j].z = (xv.z - mean) * rstd; xh[j].w = (xv.w - mean) * rstd;
-                adg[j].x += dv.x * xh[j].x; adg[j].y += dv.y * xh[j].y; adg[j].z += dv.z * xh[j].z; adg[j].w += dv.w * xh[j].w;
-                adb[j].x += dv.x; adb[j].y += dv.y; adb[j].z += dv.z; adb[j].w += dv.w;
-                dg_[j].x = dv.x * gg.x; dg_[j].y = dv.y * gg.y; dg_[j].z = dv.z * gg.z; dg_[j].w = dv.w * gg.w;
+        for (int u = 0; u < U; ++u) {
+            const long long m = (pg0 + u) * groups_per_wave + sub;
+            const long long mc = m < M ? m : M - 1;
+            const bool valid = m < M;
+            mean[u] = mean_in[mc];
+            rstd[u] = valid ? rstd_in[mc] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = (li + j * LP) * 4, cc = c < C ? c : 0;
+                const bool ok = valid && c < C;
+                const float4 tx = *(const float4*)(x + mc * ldx + cc), td = *(const float4*)(dy + mc * lddy + cc);
+                xv[u][j] = ok ? tx : make_float4(mean[u], mean[u], mean[u], mean[u]);      // => xhat = 0
+                dv[u][j] = ok ? td : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (accumulate_dx) old[u][j] = *(const float4*)(dx + mc * lddx + cc);      // block-uniform branch
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long m = (pg0 + u) * groups_per_wave + sub;
+            const bool valid = m < M;
+            float4 xh[NV], dg_[NV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                xh[j].x = (xv[u][j].x - mean[u]) * rstd[u]; xh[j].y = (xv[u][j].y - mean[u]) * rstd[u];
+                xh[j].z = (xv[u][j].z - mean[u]) * rstd[u]; xh[j].w = (xv[u][j].w - mean[u]) * rstd[u];
+                const float4 d = dv[u][j];
+                adg[j].x += d.x * xh[j].x; adg[j].y += d.y * xh[j].y; adg[j].z += d.z * xh[j].z; adg[j].w += d.w * xh[j].w;
+                adb[j].x += d.x; adb[j].y += d.y; adb[j].z += d.z; adb[j].w += d.w;
+                dg_[j].x = d.x * gg[j].x; dg_[j].y = d.y * gg[j].y; dg_[j].z = d.z * gg[j].z; dg_[j].w = d.w * gg[j].w;
                 s1 += (dg_[j].x + dg_[j].y) + (dg_[j].z + dg_[j].w);
                 s2 += (dg_[j].x * xh[j].x + dg_[j].y * xh[j].y) + (dg_[j].z * xh[j].z + dg_[j].w * xh[j].w);
             }
-        }
-        s1 = cdf_group_sum(s1, LP) / (float)C;
-        s2 = cdf_group_sum(s2, LP) / (float)C;
-        if (valid) {
+            s1 = cdf_group_sum(s1, LP) / (float)C;
+            s2 = cdf_group_sum(s2, LP) / (float)C;
+            if (valid) {
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int c = (li + j * LP) * 4;
-                if (c < C) {
-                    float4 o;
-                    o.x = rstd * (dg_[j].x - s1 - xh[j].x * s2);
-                    o.y = rstd * (dg_[j].y - s1 - xh[j].y * s2);
-                    o.z = rstd * (dg_[j].z - s1 - xh[j].z * s2);
-                    o.w = rstd * (dg_[j].w - s1 - xh[j].w * s2);
-                    float* dst = dx + m * lddx + c;
-                    if (accumulate_dx) {
-                        const float4 old = *(const float4*)dst;
-                        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                for (int j = 0; j < NV; ++j) {
+                    const int c = (li + j * LP) * 4;
+                    if (c < C) {
+                        float4 o;
+                        o.x = rstd[u] * (dg_[j].x - s1 - xh[j].x * s2);
+                        o.y = rstd[u] * (dg_[j].y - s1 - xh[j].y * s2);
+                        o.z = rstd[u] * (dg_[j].z - s1 - xh[j].z * s2);
+                        o.w = rstd[u] * (dg_[j].w - s1 - xh[j].w * s2);
+                        if (accumulate_dx) { o.x += old[u][j].x; o.y += old[u][j].y; o.z += old[u][j].z; o.w += old[u][j].w; }
+                        *(float4*)(dx + m * lddx + c) = o;
                     }
-                    *(float4*)dst = o;
                 }
             }
         }
@@ -146,22 +179,31 @@ __global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const float* dy, i
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
         float s = 0.f;
-        for (int gg = 0; gg < G; ++gg) s += sred[(size_t)gg * 2 * C + i];
+        for (int gg2 = 0; gg2 < G; ++gg2) s += sred[(size_t)gg2 * 2 * C + i];
         part[(size_t)blockIdx.x * 2 * C + i] = s;
     }
 }
 
-// out[c] (+)= sum_blocks part[block][which][c]; block 256 = 4 partial lanes x 64 columns of the [2C] vector
-__global__ void norm_param_reduce_kernel(const float* part, int nblocks, int C, float* dg, float* db, int accumulate) {
-    __shared__ float red[4][64];
+// out[c] (+)= sum_blocks part[block][which][c]; block 1024 = 16 partial lanes x 64 columns of the [2C] vector
+// (the vector is short -- 2 blocks at C = 64 -- so the parallelism has to come from splitting the partials)
+__global__ void __launch_bounds__(1024) norm_param_reduce_kernel(const float* part, int nblocks, int C, float* dg, float* db, int accumulate) {
+    __shared__ float red[16][64];
     const int l = threadIdx.x & 63, rl = threadIdx.x >> 6, i = blockIdx.x * 64 + l;
-    float s = 0.f;
-    if (i < 2 * C)
-        for (int b = rl; b < nblocks; b += 4) s += part[(size_t)b * 2 * C + i];
-    red[rl][l] = s;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < 2 * C) {
+        int b = rl;
+        for (; b + 16 < nblocks; b += 32) {                  // two independent loads in flight
+            s0 += part[(size_t)b * 2 * C + i];
+            s1 += part[(size_t)(b + 16) * 2 * C + i];
+        }
+        if (b < nblocks) s0 += part[(size_t)b * 2 * C + i];
+    }
+    red[rl][l] = s0 + s1;
     __syncthreads();
     if (rl == 0 && i < 2 * C) {
-        const float t = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][l];
         float* dst = i < C ? dg + i : db + (i - C);
         *dst = accumulate ? *dst + t : t;
     }
@@ -344,7 +386,7 @@ extern "C" int cdf_layernorm_blocks(long long M, int C) {
     if (ln_geometry(C, &LP, &NV)) return 0;
     const long long groups_per_block = 4 * (64 / LP);
     long long nb = (M + groups_per_block - 1) / groups_per_block;
-    if (nb > 512) nb = 512;
+    if (nb > 1024) nb = 1024;                     // 4 blocks per CU (the backward's partial sums are [nb][2][C])
     return nb < 1 ? 1 : (int)nb;
 }
 
@@ -396,7 +438,7 @@ extern "C" int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, in
         default: CDF_LN_BWD(4); break;
     }
 #undef CDF_LN_BWD
-    CDF_LAUNCH(norm_param_reduce_kernel, dim3(cdf_cdiv(2 * C, 64)), dim3(256), 0, CDF_S, (const float*)part, nb, C, dg, db, accumulate_param);
+    CDF_LAUNCH(norm_param_reduce_kernel, dim3(cdf_cdiv(2 * C, 64)), dim3(1024), 0, CDF_S, (const float*)part, nb, C, dg, db, accumulate_param);
     return cdf_check_launch("layernorm_c_bwd");
 }
 
