@@ -611,31 +611,35 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
         fetch(buf ^ 1);                                      // chunk it + 1 lands while chunk it is multiplied
         const unsigned short* sa = smem + buf * STAGE;
         const unsigned short* sb = sa + 2 * PLANE_A;
+        // all fragment reads of the chunk are issued up front: the second k-step's LDS latency hides behind the first
+        // k-step's MFMAs (the registers are there -- LDS, not VGPRs, limits the residency to two blocks per CU)
+        bf16x8_v ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int kc = ((ks * 2 + half) ^ sw) * 8;
-            bf16x8_v ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int off = (wm * (BM / 2) + i * 32 + l31) * RE + kc;
-                ah[i] = *(const bf16x8_v*)(sa + off);
-                al[i] = *(const bf16x8_v*)(sa + PLANE_A + off);
+                ah[ks][i] = *(const bf16x8_v*)(sa + off);
+                al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int off = (wn * (BN / 2) + j * 32 + l31) * RE + kc;
-                bh[j] = *(const bf16x8_v*)(sb + off);
-                bl[j] = *(const bf16x8_v*)(sb + PLANE_B + off);
+                bh[ks][j] = *(const bf16x8_v*)(sb + off);
+                bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + off);
             }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = CDF_MFMA_BF16(al[i], bh[j], acc[i][j]);
-                    acc[i][j] = CDF_MFMA_BF16(ah[i], bl[j], acc[i][j]);
-                    acc[i][j] = CDF_MFMA_BF16(ah[i], bh[j], acc[i][j]);
+                    acc[i][j] = CDF_MFMA_BF16(al[ks][i], bh[ks][j], acc[i][j]);
+                    acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bl[ks][j], acc[i][j]);
+                    acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bh[ks][j], acc[i][j]);
                 }
-        }
         CDF_WAIT_DMA();                                      // this wave's pieces of chunk it + 1 have landed ...
         CDF_LDS_BARRIER();                                   // ... and so have everybody else's; chunk it is fully consumed
     }
