@@ -28,6 +28,8 @@
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                    \
                                      (__attribute__((address_space(3))) void*)(lds_base), 16, 0, 0)
 #define CDF_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// wait until at most N (a compile-time constant) of this wave's DMA / global loads are still outstanding
+#define CDF_WAIT_DMA_LEAVE(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 #endif

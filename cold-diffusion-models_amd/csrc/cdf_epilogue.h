@@ -40,11 +40,11 @@ __device__ __forceinline__ void cdf_st4(float* p, const float* v, int n, bool ve
 }
 
 // One pass over RP transposed rows held in cs ([RP][BN + 8]); rowmap(p) = row of pass-row p inside the block tile.
-// 256 threads.  Contains no barrier (callers sync around it).
-template <int BN, int RP, class Args, class Phase, class RowMap>
+// NTHR threads (default 256).  Contains no barrier (callers sync around it).
+template <int BN, int RP, int NTHR = 256, class Args, class Phase, class RowMap>
 __device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph, float* Y, const float* cs, int m_base, int n_base, int M,
                                                   int tid, RowMap rowmap) {
-    constexpr int CP = BN + 8, TPR = BN / 4, RPS = 256 / TPR;
+    constexpr int CP = BN + 8, TPR = BN / 4, RPS = NTHR / TPR;
     const int c4 = (tid % TPR) * 4, co = n_base + c4;
     if (co >= a.Cout) return;
     const int nval = a.Cout - co < 4 ? a.Cout - co : 4;

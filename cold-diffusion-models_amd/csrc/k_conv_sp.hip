@@ -45,28 +45,28 @@ struct SpPhase {
 #define CDF_ABLATE 0     // tuning aid (tools/ablate.py): bit 0 no global loads in the K loop, bit 2 no epilogue stores,
 #endif                   // bit 3 no LDS stores in the K loop.  Always 0 in the product build.
 
-// Block tile BM x BN, 4 waves as 2 x 2 of (BM/2) x (BN/2): the whole tile goes through LDS in one pass (cdf_epilogue.h).
+// Block tile BM x BN, WM x WN waves of (BM/WM) x (BN/WN): the whole tile goes through LDS in one pass (cdf_epilogue.h).
 constexpr int CDF_SP_CPITCH = 136;
 constexpr size_t CDF_SP_EPI_LDS = (size_t)128 * CDF_SP_CPITCH * sizeof(float);
 
-template <int BM, int BN, class Args>
-__device__ __forceinline__ void cdf_sp_epilogue(const Args& a, const SpPhase& ph, const f32x16_t (&acc)[BM / 64][BN / 64], float* cs,
+template <int BM, int BN, int WM = 2, int WN = 2, class Args>
+__device__ __forceinline__ void cdf_sp_epilogue(const Args& a, const SpPhase& ph, const f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], float* cs,
                                                 int tile_m, int tile_n, int M, int tid) {
-    constexpr int CP = BN + 8;
-    const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    constexpr int CP = BN + 8, TM = BM / WM, TN = BN / WN;
+    const int lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN, half = lane >> 5, l31 = lane & 31;
     // (the K loop ends with a barrier: every wave is done with the operand tiles)
 #pragma unroll
-    for (int i = 0; i < BM / 64; ++i)
+    for (int i = 0; i < TM / 32; ++i)
 #pragma unroll
-        for (int j = 0; j < BN / 64; ++j)
+        for (int j = 0; j < TN / 32; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                cs[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * (BN / 2) + j * 32 + l31] = acc[i][j][r];
+                cs[(wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * TN + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
 #if CDF_ABLATE & 4
     if (acc[0][0][0] != 12345.678f) return;
 #endif
-    cdf_epilogue_rows<BN, BM>(a, ph, a.y, cs, tile_m * BM, tile_n * BN, M, tid, [](int p) { return p; });
+    cdf_epilogue_rows<BN, BM, 64 * WM * WN>(a, ph, a.y, cs, tile_m * BM, tile_n * BN, M, tid, [](int p) { return p; });
 }
 
 struct SpArgs {
@@ -493,38 +493,45 @@ struct SpxArgs {
     SpPhase ph[4];
 };
 
-template <int BM, int BN>
-__global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
-    // Block tile BM x BN (64 or 128 each), 4 waves as 2 x 2, BK = 32.  Operand tiles go global -> LDS by LDS-DMA
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ void __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) conv_igemm_spx_kernel(SpxArgs a) {
+    // Block tile BM x BN, WM x WN waves of (BM/WM) x (BN/WN), BK = 32, NSTAGE LDS stages.  Two shapes of the template are
+    // used: 4 waves (2 x 2) on a 64/128 x 64/128 tile with 2 stages, two blocks per CU; and 8 waves (4 x 2) on a
+    // 256 x 128 tile with 3 stages, one block per CU -- the same 8 waves per CU, but the DMA of chunk it+2 is in flight
+    // while chunk it is multiplied (a global fetch takes longer than one chunk's MFMAs) and each B tile feeds twice the
+    // MFMAs.  Operand tiles go global -> LDS by LDS-DMA
     // (CDF_GLDS16): the register-staged version spent as long in ds_write_b128 (13 LDS-path cycles per wave
     // instruction) as in the MFMAs.  DMA images are lane-linear, so a stage plane is [rows][64 B] without padding and
     // the bank spreading is an XOR swizzle applied on BOTH sides: the 16-byte column c of row r lives at column
     // c ^ ((r >> 2) & 3) -- the lane that fills LDS slot (r, c') fetches global column c' ^ ((r >> 2) & 3), the
     // fragment read of (r, c) goes to c ^ ((r >> 2) & 3).  With that the 16 rows of every ds_read_b128 lane group
     // (rows = r mod 4 classes x 4 distinct (r >> 2) & 3) cover all 64 banks exactly once.
-    constexpr int BK = 32, RE = 32, MT = BM / 64, NT = BN / 64;       // RE: row elements (64 bytes)
+    constexpr int BK = 32, RE = 32, NW = WM * WN, NTHR = 64 * NW;     // RE: row elements (64 bytes)
+    constexpr int MT = BM / WM / 32, NT = BN / WN / 32;               // 32 x 32 MFMA tiles per wave
+    constexpr int SA = BM / 16 / NW, SB = BN / 16 / NW;               // 16-row DMA segments per wave and plane
+    static_assert(SA >= 1 && SB >= 1 && SA * NW * 16 == BM && SB * NW * 16 == BN, "tile must split into 16-row segments per wave");
     constexpr int PLANE_A = BM * RE, PLANE_B = BN * RE;
     constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;                  // A hi, A lo, B hi, B lo
     CDF_DYN_SMEM(smem_raw);
     unsigned short* smem = (unsigned short*)smem_raw;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int M = a.B * a.QH * a.QW;
     const int tiles_n = (a.Cout + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
     const int tile = cdf_sp_swizzle(blockIdx.x, tiles_m * tiles_n);
     const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
     const SpPhase& ph = a.ph[blockIdx.y];
 
-    // DMA slots of this lane: wave w fills the 16-row segments w*MT + p of both A planes and w*NT + p of both B planes;
+    // DMA slots of this lane: wave w fills the 16-row segments w*SA + p of both A planes and w*SB + p of both B planes;
     // inside a segment lane l is row l >> 2, LDS column l & 3, i.e. global column (l & 3) ^ ((l >> 4) & 3).
     const int srow = lane >> 2;
     const int q8 = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
-    int a_iy0[MT], a_ix0[MT], b_row[NT];
-    unsigned a_pix[MT];
+    int a_iy0[SA], a_ix0[SA], b_row[SB];
+    unsigned a_pix[SA];
 #pragma unroll
-    for (int p = 0; p < MT; ++p) {
-        const int m = tile_m * BM + (wave * MT + p) * 16 + srow;
+    for (int p = 0; p < SA; ++p) {
+        const int m = tile_m * BM + (wave * SA + p) * 16 + srow;
         if (m < M) {
             const int qx = m % a.QW, t2 = m / a.QW;
             a_iy0[p] = (t2 % a.QH) * a.is;
@@ -537,17 +544,17 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
         }
     }
 #pragma unroll
-    for (int p = 0; p < NT; ++p) {
-        const int n = tile_n * BN + (wave * NT + p) * 16 + srow;
+    for (int p = 0; p < SB; ++p) {
+        const int n = tile_n * BN + (wave * SB + p) * 16 + srow;
         b_row[p] = n < a.Cout ? n : a.Cout - 1;
     }
     const int nchunks = (a.Cin + BK - 1) / BK;
     const int niter = ph.ntaps * nchunks;
 
-    // Tap table -> LDS once, behind the two stages (a dynamic index into the by-value kernel argument compiles to
+    // Tap table -> LDS once, behind the stages (a dynamic index into the by-value kernel argument compiles to
     // per-iteration global byte loads in front of the tile loads); the next entry is fetched when the tap counter
     // advances, an iteration before it is needed.  CDF_MAX_TAPS + 1 entries: the fetch one past the end is harmless.
-    int* tap_lds = (int*)(smem + 2 * STAGE);
+    int* tap_lds = (int*)(smem + NSTAGE * STAGE);
     if (tid <= CDF_MAX_TAPS)
         tap_lds[tid] = tid < ph.ntaps ? (ph.dy[tid] & 0xFF) | ((ph.dx[tid] & 0xFF) << 8) | ((ph.wi[tid] & 0xFF) << 16) : 0;
     CDF_LDS_BARRIER();
@@ -569,18 +576,18 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
         const bool cok = (c0 + q8) < a.Cin;
         unsigned short* st = smem + buf * STAGE;
 #pragma unroll
-        for (int p = 0; p < MT; ++p) {
+        for (int p = 0; p < SA; ++p) {
             const unsigned iy = (unsigned)(a_iy0[p] + dy), ix = (unsigned)(a_ix0[p] + dx);
             const bool ok = iy < (unsigned)a.H && ix < (unsigned)a.W && cok;
             const size_t off = (size_t)(a_pix[p] + (unsigned)tap_pix) * (unsigned)a.ldx + cc;
-            unsigned short* seg = st + (wave * MT + p) * 16 * RE;
+            unsigned short* seg = st + (wave * SA + p) * 16 * RE;
             CDF_GLDS16(ok ? a.x_hi + off : a.zero, seg);
             CDF_GLDS16(ok ? a.x_lo + off : a.zero, seg + PLANE_A);
         }
 #pragma unroll
-        for (int p = 0; p < NT; ++p) {
+        for (int p = 0; p < SB; ++p) {
             const size_t woff = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)b_row[p]) * (unsigned)a.ldk + cc;
-            unsigned short* seg = st + 2 * PLANE_A + (wave * NT + p) * 16 * RE;
+            unsigned short* seg = st + 2 * PLANE_A + (wave * SB + p) * 16 * RE;
             CDF_GLDS16(a.w_hi + woff, seg);
             CDF_GLDS16(a.w_lo + woff, seg + PLANE_B);
         }
@@ -603,29 +610,39 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
 
     const int half = lane >> 5, l31 = lane & 31;
     const int sw = (l31 >> 2) & 3;                           // read-side swizzle (tile row offsets are multiples of 32)
-    if (niter > 0) fetch(0);
-    CDF_WAIT_DMA();
+    // chunk c lives in stage c % NSTAGE; NSTAGE - 1 chunks are in flight ahead of the one being multiplied
+    int fbuf = 0;                                            // stage of the next fetch
+    if (niter > 0) {
+#pragma unroll
+        for (int d = 0; d < NSTAGE - 1; ++d) {
+            fetch(fbuf);
+            fbuf = fbuf + 1 == NSTAGE ? 0 : fbuf + 1;
+        }
+    }
+    CDF_WAIT_DMA_LEAVE((NSTAGE - 2) * 2 * (SA + SB));         // chunk 0 has landed; later ones may still be in flight
     CDF_LDS_BARRIER();
+    int buf = 0;
     for (int it = 0; it < niter; ++it) {
-        const int buf = it & 1;
-        fetch(buf ^ 1);                                      // chunk it + 1 lands while chunk it is multiplied
+        fetch(fbuf);                                         // chunk it + NSTAGE - 1
+        fbuf = fbuf + 1 == NSTAGE ? 0 : fbuf + 1;
         const unsigned short* sa = smem + buf * STAGE;
         const unsigned short* sb = sa + 2 * PLANE_A;
+        buf = buf + 1 == NSTAGE ? 0 : buf + 1;
         // all fragment reads of the chunk are issued up front: the second k-step's LDS latency hides behind the first
-        // k-step's MFMAs (the registers are there -- LDS, not VGPRs, limits the residency to two blocks per CU)
+        // k-step's MFMAs (the registers are there -- LDS, not VGPRs, limits the residency)
         bf16x8_v ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int kc = ((ks * 2 + half) ^ sw) * 8;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const int off = (wm * (BM / 2) + i * 32 + l31) * RE + kc;
+                const int off = (wm * (BM / WM) + i * 32 + l31) * RE + kc;
                 ah[ks][i] = *(const bf16x8_v*)(sa + off);
                 al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const int off = (wn * (BN / 2) + j * 32 + l31) * RE + kc;
+                const int off = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
                 bh[ks][j] = *(const bf16x8_v*)(sb + off);
                 bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + off);
             }
@@ -640,11 +657,13 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_spx_kernel(SpxArgs a) {
                     acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bl[ks][j], acc[i][j]);
                     acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bh[ks][j], acc[i][j]);
                 }
-        CDF_WAIT_DMA();                                      // this wave's pieces of chunk it + 1 have landed ...
+        CDF_WAIT_DMA_LEAVE((NSTAGE - 2) * 2 * (SA + SB));     // this wave's pieces of chunk it + 1 have landed ...
         CDF_LDS_BARRIER();                                   // ... and so have everybody else's; chunk it is fully consumed
     }
+    CDF_WAIT_DMA_LEAVE(0);                                   // the tail fetches (never read) must not land in the epilogue tile
+    CDF_LDS_BARRIER();
 
-    cdf_sp_epilogue<BM, BN>(a, ph, acc, (float*)smem_raw, tile_m, tile_n, M, tid);
+    cdf_sp_epilogue<BM, BN, WM, WN>(a, ph, acc, (float*)smem_raw, tile_m, tile_n, M, tid);
 }
 
 // weight gradient with both operands pre-split ([pixels][ld] bf16 hi / lo planes)
@@ -1046,26 +1065,28 @@ static int fill_phases(SpPhase* ph, int nphase, const int* pd, const char* who) 
 static int g_spx_bm = 0, g_spx_bn = 0;     // 0 = automatic
 
 extern "C" int cdf_conv_gemm_bf16x_tile(int bm, int bn) {
-    CDF_REQUIRE((bm == 0 || bm == 64 || bm == 128) && (bn == 0 || bn == 64 || bn == 128), "cdf_conv_gemm_bf16x_tile: tile sides are 0 (auto), 64 or 128");
+    CDF_REQUIRE((bm == 0 || bm == 64 || bm == 128 || bm == 256) && (bn == 0 || bn == 64 || bn == 128), "cdf_conv_gemm_bf16x_tile: bm is 0 (auto), 64, 128 or 256 (with bn = 128), bn 0, 64 or 128");
     g_spx_bm = bm;
     g_spx_bn = bn;
     return 0;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WM, int WN, int NSTAGE>
 static int launch_igemm_spx(const SpxArgs& a, int M, hipStream_t s) {
-    constexpr size_t stages = (size_t)2 * 2 * (BM + BN) * 32 * sizeof(unsigned short) + (CDF_MAX_TAPS + 1) * sizeof(int);
+    constexpr size_t stages = (size_t)NSTAGE * 2 * (BM + BN) * 32 * sizeof(unsigned short) + (CDF_MAX_TAPS + 1) * sizeof(int);
     constexpr size_t epi = (size_t)BM * (BN + 8) * sizeof(float);
-    constexpr size_t lds = stages > epi ? stages : epi;      // 128 x 128: 68 KB (epilogue tile), two blocks per CU
+    constexpr size_t lds = stages > epi ? stages : epi;      // 128 x 128 x 2 stages: 68 KB (epilogue tile), two blocks per CU;
+                                                             // 256 x 128 x 3 stages: 144 KB, one block per CU
+    static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
 #ifndef CDF_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_spx_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_spx_kernel<BM, BN, WM, WN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
 #endif
     const int tiles = cdf_cdiv(M, BM) * cdf_cdiv(a.Cout, BN);
-    CDF_LAUNCH((conv_igemm_spx_kernel<BM, BN>), dim3(tiles, a.nphase), dim3(256), lds, s, a);
+    CDF_LAUNCH((conv_igemm_spx_kernel<BM, BN, WM, WN, NSTAGE>), dim3(tiles, a.nphase), dim3(64 * WM * WN), lds, s, a);
     return cdf_check_launch("conv_igemm_spx");
 }
 
@@ -1090,14 +1111,17 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
     int rc = fill_phases(a.ph, nphase, phase_desc, "cdf_conv_gemm_bf16x");
     if (rc) return rc;
     // Tile choice: 64-wide N for Cout <= 64 (no half-empty MFMA columns); 64-row M tiles when 128-row tiles would
-    // leave most of the 256 CUs x 2 resident blocks idle (deep, small-image layers: M = 8192 at 16 x 16).
+    // leave most of the 256 CUs x 2 resident blocks idle (deep, small-image layers: M = 8192 at 16 x 16); the 8-wave
+    // 256 x 128 tile (3 stages, one block per CU) when it still gives every CU at least ~2 tiles.
     const int M = B * QH * QW;
     const bool n64 = g_spx_bn ? g_spx_bn == 64 : Cout <= 64;
     const long long tiles128 = (long long)cdf_cdiv(M, 128) * cdf_cdiv(Cout, n64 ? 64 : 128) * nphase;
     bool m64 = tiles128 < 384;
-    if (g_spx_bm) m64 = g_spx_bm == 64;
-    if (n64) return m64 ? launch_igemm_spx<64, 64>(a, M, CDF_S) : launch_igemm_spx<128, 64>(a, M, CDF_S);
-    return m64 ? launch_igemm_spx<64, 128>(a, M, CDF_S) : launch_igemm_spx<128, 128>(a, M, CDF_S);
+    bool m256 = !n64 && tiles128 >= 1024;
+    if (g_spx_bm) { m64 = g_spx_bm == 64; m256 = g_spx_bm == 256 && !n64; }
+    if (m256) return launch_igemm_spx<256, 128, 4, 2, 3>(a, M, CDF_S);
+    if (n64) return m64 ? launch_igemm_spx<64, 64, 2, 2, 2>(a, M, CDF_S) : launch_igemm_spx<128, 64, 2, 2, 2>(a, M, CDF_S);
+    return m64 ? launch_igemm_spx<64, 128, 2, 2, 2>(a, M, CDF_S) : launch_igemm_spx<128, 128, 2, 2, 2>(a, M, CDF_S);
 }
 
 template <int TA, int TB>

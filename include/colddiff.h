@@ -153,8 +153,9 @@ int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void*
                         int nphase, const int* phase_desc, const float* bias, const float* sbias, int ld_sbias, const float* res,
                         int ldr, float* pre, int ldp, const float* mul, int ldm, int act, int mul_mode, int accumulate,
                         void* stream);
-/* Tuning / test hook: force the block tile of cdf_conv_gemm_bf16x (rows of pixels x output channels; each side 64 or
- * 128, 0 = automatic choice from the problem size).  Process-wide; results do not depend on it. */
+/* Tuning / test hook: force the block tile of cdf_conv_gemm_bf16x (rows of pixels x output channels; bm 64, 128 or
+ * 256 -- the latter with bn = 128 --, bn 64 or 128; 0 = automatic choice from the problem size).  Process-wide; results
+ * do not depend on it. */
 int cdf_conv_gemm_bf16x_tile(int bm, int bn);
 int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, int ldb, const void* zero,
                          float* ws, int ldo, int B, int QH, int QW, int HA, int WA, int sa, int HB, int WB, int sb, int CA, int CB,

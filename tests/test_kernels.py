@@ -650,7 +650,7 @@ def test_conv_presplit(be, case):
     _spx_case(be, *case)
 
 
-@pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 128), (64, 64)])
+@pytest.mark.parametrize("tile", [(256, 128), (128, 128), (128, 64), (64, 128), (64, 64)])
 def test_conv_presplit_forced_tiles(be, tile):
     """Every block-tile instantiation of the pre-split GEMM on a shape with ragged M and N tiles (the automatic
     choice would only ever pick the 64-row tiles at emulator-sized problems)."""

@@ -1,9 +1,13 @@
+import os
 """Time cdf_conv_gemm / cdf_conv_wgrad at the CelebA-128 layer shapes (B from env KB_B, default 32)."""
 import json, os, sys, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "cold-diffusion-models_amd"))
 from colddiff import _lib, convdesc as cd
 L = _lib.get(); dev = torch.device("cuda:0")
+if os.environ.get('KB_TILE'):
+    L.cdf_conv_gemm_bf16x_tile(*[int(v) for v in os.environ['KB_TILE'].split('x')])
+
 S = lambda: torch.cuda.current_stream().cuda_stream
 P = lambda t: 0 if t is None else t.data_ptr()
 r4 = lambda c: (c + 3) // 4 * 4
