@@ -552,52 +552,82 @@ __global__ void __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) conv_igemm
     const int niter = ph.ntaps * nchunks;
 
     // Tap table -> LDS once, behind the stages (a dynamic index into the by-value kernel argument compiles to
-    // per-iteration global byte loads in front of the tile loads); the next entry is fetched when the tap counter
-    // advances, an iteration before it is needed.  CDF_MAX_TAPS + 1 entries: the fetch one past the end is harmless.
+    // per-iteration global byte loads in front of the tile loads).  CDF_MAX_TAPS + 1 entries: reading one past the
+    // end is harmless.
     int* tap_lds = (int*)(smem + NSTAGE * STAGE);
     if (tid <= CDF_MAX_TAPS)
         tap_lds[tid] = tid < ph.ntaps ? (ph.dy[tid] & 0xFF) | ((ph.dx[tid] & 0xFF) << 8) | ((ph.wi[tid] & 0xFF) << 16) : 0;
     CDF_LDS_BARRIER();
-    int tap_cur = tap_lds[0];
 
-    // Straight-line DMA issue: every lane always fetches -- outside the image / channel range from the zero page.
-    // Past the last chunk the last one is simply fetched again into the idle stage (never read).
-    int tap = 0, c0 = 0, issued = 0;                         // (tap, channel chunk) of the NEXT fetch
-    auto fetch = [&](int buf) {
-        // keep the entry in a VGPR: as a (provably uniform) scalar it would be pulled through v_readfirstlane right
-        // behind its ds_read, i.e. an LDS round trip on the critical path of every iteration
-        int tc = tap_cur;
-#ifndef CDF_EMU
-        asm volatile("" : "+v"(tc));
-#endif
+    // DMA source pointers of this lane, valid for the current tap and advanced by one K chunk per fetch.  The address
+    // generation (bounds test, 64-bit multiply, zero-page select) runs once per TAP, not per chunk: per-chunk it was
+    // 3.6 vector instructions per MFMA (PMC), all competing with the MFMAs for issue slots.  An element outside the
+    // image fetches the zero page (pointer does not advance); all fetches are unconditional.
+    const unsigned short* pa_hi[SA];
+    const unsigned short* pa_lo[SA];
+    const unsigned short* pb_hi[SB];
+    const unsigned short* pb_lo[SB];
+    int a_inc[SA];
+    const bool ragged = (a.Cin & (BK - 1)) != 0;             // last chunk of a tap only partly inside the channel range
+    auto retap = [&](int tap) {
+        const int tc = tap_lds[tap];
         const int dy = (int)(signed char)(tc & 0xFF), dx = (int)(signed char)((tc >> 8) & 0xFF), wi = (tc >> 16) & 0xFF;
         const int tap_pix = dy * a.W + dx;
-        const unsigned cc = (unsigned)(c0 + q8);
-        const bool cok = (c0 + q8) < a.Cin;
-        unsigned short* st = smem + buf * STAGE;
 #pragma unroll
         for (int p = 0; p < SA; ++p) {
             const unsigned iy = (unsigned)(a_iy0[p] + dy), ix = (unsigned)(a_ix0[p] + dx);
-            const bool ok = iy < (unsigned)a.H && ix < (unsigned)a.W && cok;
-            const size_t off = (size_t)(a_pix[p] + (unsigned)tap_pix) * (unsigned)a.ldx + cc;
-            unsigned short* seg = st + (wave * SA + p) * 16 * RE;
-            CDF_GLDS16(ok ? a.x_hi + off : a.zero, seg);
-            CDF_GLDS16(ok ? a.x_lo + off : a.zero, seg + PLANE_A);
+            const bool ok = iy < (unsigned)a.H && ix < (unsigned)a.W && q8 < a.Cin;
+            const size_t off = (size_t)(a_pix[p] + (unsigned)tap_pix) * (unsigned)a.ldx + (unsigned)q8;
+            pa_hi[p] = ok ? a.x_hi + off : a.zero;
+            pa_lo[p] = ok ? a.x_lo + off : a.zero;
+            a_inc[p] = ok ? BK : 0;
         }
 #pragma unroll
         for (int p = 0; p < SB; ++p) {
-            const size_t woff = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)b_row[p]) * (unsigned)a.ldk + cc;
+            const size_t woff = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)b_row[p]) * (unsigned)a.ldk + (unsigned)q8;
+            pb_hi[p] = a.w_hi + woff;
+            pb_lo[p] = a.w_lo + woff;
+        }
+    };
+    // Past the last chunk the last one is simply fetched again into an idle stage (never read).
+    int tap = 0, c0 = 0, issued = 0;                         // (tap, channel chunk) of the NEXT fetch
+    retap(0);
+    auto fetch = [&](int buf) {
+        unsigned short* st = smem + buf * STAGE;
+        const bool cok = !ragged || (c0 + q8) < a.Cin;       // (false only in the ragged last chunk of a tap)
+#pragma unroll
+        for (int p = 0; p < SA; ++p) {
+            unsigned short* seg = st + (wave * SA + p) * 16 * RE;
+            CDF_GLDS16(cok ? pa_hi[p] : a.zero, seg);
+            CDF_GLDS16(cok ? pa_lo[p] : a.zero, seg + PLANE_A);
+        }
+#pragma unroll
+        for (int p = 0; p < SB; ++p) {
             unsigned short* seg = st + 2 * PLANE_A + (wave * SB + p) * 16 * RE;
-            CDF_GLDS16(a.w_hi + woff, seg);
-            CDF_GLDS16(a.w_lo + woff, seg + PLANE_B);
+            CDF_GLDS16(pb_hi[p], seg);                       // (weights are zero padded along K to the chunk size)
+            CDF_GLDS16(pb_lo[p], seg + PLANE_B);
         }
         const bool more = issued + 1 < niter;                // block-uniform
         issued += more ? 1 : 0;
-        const int c1 = c0 + BK;
-        const bool wrap = c1 >= a.Cin;
-        c0 = more ? (wrap ? 0 : c1) : c0;
-        tap += (more && wrap) ? 1 : 0;
-        tap_cur = tap_lds[tap];
+        if (more) {
+            c0 += BK;
+            if (c0 >= a.Cin) {                               // next tap: block-uniform branch, no load inside
+                c0 = 0;
+                ++tap;
+                retap(tap);
+            } else {
+#pragma unroll
+                for (int p = 0; p < SA; ++p) {
+                    pa_hi[p] += a_inc[p];
+                    pa_lo[p] += a_inc[p];
+                }
+#pragma unroll
+                for (int p = 0; p < SB; ++p) {
+                    pb_hi[p] += BK;
+                    pb_lo[p] += BK;
+                }
+            }
+        }
     };
 
     f32x16_t acc[MT][NT];
