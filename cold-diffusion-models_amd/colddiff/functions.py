@@ -6,6 +6,8 @@ gradients are accumulated by the kernels straight into ``param.grad`` (one flat 
 an ``anchor`` (a dummy scalar that requires grad) first, so its backward also runs when the
 activation input itself does not require grad (the first block sees the image).
 """
+import os
+
 import torch
 
 from . import convdesc as cd
@@ -56,11 +58,14 @@ def want_presplit(Cin, Cout, k):
     return rt.precision == "bf16x3" and Cin % 8 == 0 and Cout % 8 == 0 and bool(_sp_suffix(Cin * k * k, Cout)) and bool(_sp_suffix(Cout * k * k, Cin))
 
 
+_SP_KMIN = int(os.environ.get("CDF_SP_KMIN", "128"))     # tuning knob: smallest K routed to the bf16 matrix cores
+
+
 def _sp_suffix(K, N):
     """Route a dense conv to the split-precision bf16 MFMA kernel when enabled and the GEMM is deep and
-    wide enough to fill its 128x128x32 tiles (K = taps*Cin); short-K 1x1 convs and the tiny first/last
-    layers stay on the exact-fp32 kernel, which is faster there."""
-    return "_sp" if (rt.precision != "f32" and K >= 256 and N >= 64) else ""
+    wide enough (K = taps*Cin >= 128, N >= 64); the tiny first/last layers, K = 32 attention products and
+    the time-embedding linears stay on the exact-fp32 kernel."""
+    return "_sp" if (rt.precision != "f32" and K >= _SP_KMIN and N >= 64) else ""
 
 
 def conv_backward(x, Cin, dy, weight, bias, kind="conv", stride=1, pad=None, need_dx=True, dx=None, dx_accumulate=0, mul=None,
