@@ -36,9 +36,10 @@ def _conv_plans(kind, H, W, k, stride, pad):
     return cd.convT_fwd(H, W, k, k, stride, pad[0]), cd.convT_dgrad(H, W, k, k, stride, pad[0]), cd.convT_wgrad(H, W, k, k, stride, pad[0])
 
 
-def conv_forward(x, Cin, weight, bias, kind="conv", stride=1, pad=None, xs=None, **epi):
+def conv_forward(x, Cin, weight, bias, kind="conv", stride=1, pad=None, xs=None, split_out=False, **epi):
     """x [B,H,W,*] -> conv(x) with the weight in its PyTorch layout ([Cout,Cin,k,k] or [Cin,Cout,k,k]).
-    xs: optional pre-split (hi, lo) bf16 planes of x (see want_presplit)."""
+    xs: optional pre-split (hi, lo) bf16 planes of x (see want_presplit).
+    split_out: return (y, (hi, lo) planes of y) -- fused into the epilogue on the pre-split path."""
     k = weight.shape[-1]
     if pad is None:
         pad = (k // 2,) * 4
@@ -48,8 +49,9 @@ def conv_forward(x, Cin, weight, bias, kind="conv", stride=1, pad=None, xs=None,
     sfx = _sp_suffix(Cin * k * k, Cout)
     wp = ops.packed(weight, ("conv_fwd" if kind == "conv" else "convT_fwd") + sfx)
     if xs is not None and sfx:
-        return ops.conv_gemm_presplit(plan, xs, Cin, wp, Cout, bias=bias, **epi)
-    return ops.conv_gemm(plan, x, Cin, wp, Cout, bias=bias, **epi)
+        return ops.conv_gemm_presplit(plan, xs, Cin, wp, Cout, bias=bias, split_out=split_out, **epi)
+    y = ops.conv_gemm(plan, x, Cin, wp, Cout, bias=bias, **epi)
+    return (y, ops.split_bf16(y)) if split_out else y
 
 
 def want_presplit(Cin, Cout, k):
@@ -69,7 +71,7 @@ def _sp_suffix(K, N):
 
 
 def conv_backward(x, Cin, dy, weight, bias, kind="conv", stride=1, pad=None, need_dx=True, dx=None, dx_accumulate=0, mul=None,
-                  mul_mode=0, xs=None, dys=None):
+                  mul_mode=0, xs=None, dys=None, split_dx=False):
     """Gradients of conv_forward: returns dx (optionally fused with an activation-gradient multiply),
     accumulates into weight.grad / bias.grad."""
     k = weight.shape[-1]
@@ -94,8 +96,10 @@ def conv_backward(x, Cin, dy, weight, bias, kind="conv", stride=1, pad=None, nee
     sfx = _sp_suffix(Cout * KK, Cin)
     wd = ops.packed(weight, ("conv_dgrad" if kind == "conv" else "convT_dgrad") + sfx)
     if dys is not None and sfx:
-        return ops.conv_gemm_presplit(pd, dys, Cout, wd, Cin, y=dx, mul=mul, mul_mode=mul_mode, accumulate=dx_accumulate)
-    return ops.conv_gemm(pd, dy, Cout, wd, Cin, y=dx, mul=mul, mul_mode=mul_mode, accumulate=dx_accumulate)
+        return ops.conv_gemm_presplit(pd, dys, Cout, wd, Cin, y=dx, mul=mul, mul_mode=mul_mode, accumulate=dx_accumulate,
+                                      split_out=split_dx)
+    g = ops.conv_gemm(pd, dy, Cout, wd, Cin, y=dx, mul=mul, mul_mode=mul_mode, accumulate=dx_accumulate)
+    return (g, ops.split_bf16(g)) if split_dx else g
 
 
 class ToNHWC(torch.autograd.Function):
@@ -239,22 +243,30 @@ class ConvNextBlockFn(torch.autograd.Function):
         grad_on = ctx.needs_input_grad[0]   # anchor: True iff autograd is recording
         wdw = ops.packed(m.ds_conv.weight, "dw")
         h = ops.dwconv7(x, wdw, ops.padded_vec(m.ds_conv.bias, Cp), tbias)
-        if m.has_norm:
-            hn, mean, rstd = ops.layernorm_fwd(h, m.net[0].g, m.net[0].b, m.net[0].eps, grad_on)
-        else:
-            hn, mean, rstd = h, None, None
         c1, c2 = m.net[1], m.net[3]
         B, H, W, _ = x.shape
         mid = c1.weight.shape[0]
+        # operands that feed several GEMMs (fwd now, dgrad/wgrad later, every N tile) are split into bf16 hi/lo ONCE, by
+        # the kernel that produces them (LayerNorm, the GELU epilogue of conv1, the GELU' epilogue of conv2's dgrad)
+        sp1, sp2 = want_presplit(dim, mid, 3), want_presplit(mid, dim_out, 3)
+        hn_s = None
+        if m.has_norm:
+            if sp1:
+                hn, mean, rstd, hn_s = ops.layernorm_fwd(h, m.net[0].g, m.net[0].b, m.net[0].eps, grad_on, split_out=True)
+            else:
+                hn, mean, rstd = ops.layernorm_fwd(h, m.net[0].g, m.net[0].b, m.net[0].eps, grad_on)
+        else:
+            hn, mean, rstd = h, None, None
+            hn_s = ops.split_bf16(hn) if sp1 else None
         pre = ops.new_feat(x, B, H, W, mid) if grad_on else None
-        # operands that feed several GEMMs (fwd now, dgrad/wgrad later, every N tile) are split into bf16 hi/lo once
-        hn_s = ops.split_bf16(hn) if want_presplit(dim, mid, 3) else None
-        a = conv_forward(hn, dim, c1.weight, c1.bias, act=ACT_GELU, pre=pre, xs=hn_s)
+        if sp2:
+            a, a_s = conv_forward(hn, dim, c1.weight, c1.bias, act=ACT_GELU, pre=pre, xs=hn_s, split_out=True)
+        else:
+            a, a_s = conv_forward(hn, dim, c1.weight, c1.bias, act=ACT_GELU, pre=pre, xs=hn_s), None
         if m.has_res_conv:
             res = conv_forward(x, dim, m.res_conv.weight, m.res_conv.bias)
         else:
             res = x
-        a_s = ops.split_bf16(a) if want_presplit(mid, dim_out, 3) else None
         o = conv_forward(a, mid, c2.weight, c2.bias, res=res, xs=a_s)
         ctx.m = m
         ctx.has_t = tbias is not None
@@ -282,8 +294,10 @@ class ConvNextBlockFn(torch.autograd.Function):
             dx = ops.copy_feat(do)
         # conv2 -> (fused GELU') -> conv1
         do_s = ops.split_bf16(do) if a_s is not None else None
-        dpre = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=1, xs=a_s, dys=do_s)
-        dpre_s = ops.split_bf16(dpre) if hn_s is not None else None
+        if hn_s is not None:
+            dpre, dpre_s = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=1, xs=a_s, dys=do_s, split_dx=True)
+        else:
+            dpre, dpre_s = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=1, xs=a_s, dys=do_s), None
         dhn = conv_backward(hn, dim, dpre, c1.weight, c1.bias, xs=hn_s, dys=dpre_s)
         if m.has_norm:
             dh = ops.layernorm_bwd(dhn, h, m.net[0].g, m.net[0].b, mean, rstd)

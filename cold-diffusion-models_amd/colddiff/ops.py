@@ -133,18 +133,30 @@ def split_bf16(x):
     return hi, lo
 
 
+def split_planes_like(y, C):
+    """Empty (hi, lo) bf16 planes for a [.., C] feature map (pitch roundup8(C), padding zeroed)."""
+    ld = (C + 7) // 8 * 8
+    f = torch.zeros if ld != C else torch.empty
+    return (f(y.shape[:-1] + (ld,), device=y.device, dtype=torch.int16), f(y.shape[:-1] + (ld,), device=y.device, dtype=torch.int16))
+
+
 def conv_gemm_presplit(plan, xs, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None, pre=None, mul=None, act=0, mul_mode=0,
-                       accumulate=0):
-    """conv_gemm with the activation already split into bf16 hi/lo planes (xs) and (hi, lo) packed weights (wp)."""
+                       accumulate=0, split_out=False):
+    """conv_gemm with the activation already split into bf16 hi/lo planes (xs) and (hi, lo) packed weights (wp).
+    split_out: also return the output's own (hi, lo) planes, written by the same epilogue (fused cdf_split_bf16)."""
     hi, lo = xs
     B = hi.shape[0]
     if y is None:
         y = new_feat(hi, B, plan.OH, plan.OW, Cout)
+    ys = split_planes_like(y, Cout) if (split_out and Cout % 4 == 0) else None
     ldv = lambda t: 0 if t is None else ld_of(t)
     rt.lib().cdf_conv_gemm_bf16x(P(hi), P(lo), hi.shape[-1], P(zero_page(hi.device)), P(wp[0]), P(wp[1]), wp[0].shape[-1], P(y), ld_of(y),
                                  B, plan.H, plan.W, Cin, plan.OH, plan.OW, Cout, plan.QH, plan.QW, plan.os, plan.istride, plan.nphase,
                                  plan.desc, P(bias), P(sbias), 0 if sbias is None else sbias.stride(0), P(res), ldv(res), P(pre),
-                                 ldv(pre), P(mul), ldv(mul), act, mul_mode, accumulate, rt.stream(hi))
+                                 ldv(pre), P(mul), ldv(mul), act, mul_mode, accumulate, P(ys[0]) if ys else 0, P(ys[1]) if ys else 0,
+                                 ys[0].shape[-1] if ys else 0, rt.stream(hi))
+    if split_out:
+        return y, (ys if ys is not None else split_bf16(y))
     return y
 
 
@@ -255,13 +267,18 @@ def add_into(dst, src):
 # ---------------------------------------------------------------------------------------------------
 # norms / depthwise / attention primitives
 # ---------------------------------------------------------------------------------------------------
-def layernorm_fwd(x, g, b, eps, save):
+def layernorm_fwd(x, g, b, eps, save, split_out=False):
+    """split_out: also return the output's bf16 (hi, lo) planes for the conv that consumes it (fused cdf_split_bf16)."""
     B, H, W, C = x.shape
     M = B * H * W
     y = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
     mean = torch.empty((M,), device=x.device, dtype=torch.float32) if save else None
     rstd = torch.empty((M,), device=x.device, dtype=torch.float32) if save else None
-    rt.lib().cdf_layernorm_c_fwd(P(x), ld_of(x), P(y), C, P(g), P(b), P(mean), P(rstd), M, C, eps, rt.stream(x))
+    ys = split_planes_like(y, C) if split_out else None
+    rt.lib().cdf_layernorm_c_fwd(P(x), ld_of(x), P(y), C, P(g), P(b), P(mean), P(rstd), M, C, eps, P(ys[0]) if ys else 0,
+                                 P(ys[1]) if ys else 0, ys[0].shape[-1] if ys else 0, rt.stream(x))
+    if split_out:
+        return y, mean, rstd, ys
     return y, mean, rstd
 
 

@@ -42,6 +42,22 @@ static const float cdf_zero_page[64] = {0};
 static __device__ float cdf_zero_page[64];     // (not const: a constant-address-space pointer would turn the selected loads into flat loads)
 #endif
 
+// ---- bf16 split helpers ----------------------------------------------------------------------
+__device__ __forceinline__ unsigned cdf_f2bf(float x) {        // round-to-nearest-even bf16 (finite inputs)
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float cdf_bf2f(unsigned h) { return __uint_as_float(h << 16); }
+// x = hi + lo (+ O(2^-16 |x|)): the two bf16 planes the split-precision GEMMs multiply
+__device__ __forceinline__ void cdf_split_store4(unsigned short* hi, unsigned short* lo, const float* v) {
+    const unsigned h0 = cdf_f2bf(v[0]), h1 = cdf_f2bf(v[1]), h2 = cdf_f2bf(v[2]), h3 = cdf_f2bf(v[3]);
+    const unsigned l0 = cdf_f2bf(v[0] - cdf_bf2f(h0)), l1 = cdf_f2bf(v[1] - cdf_bf2f(h1));
+    const unsigned l2 = cdf_f2bf(v[2] - cdf_bf2f(h2)), l3 = cdf_f2bf(v[3] - cdf_bf2f(h3));
+    *(uint2*)hi = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+    *(uint2*)lo = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+}
+
 // ---- status codes (returned by every extern "C" entry point) -------------------------
 #define CDF_OK 0
 #define CDF_E_INVALID (-1)      // bad argument (shape, alignment, null pointer)

@@ -7,6 +7,7 @@
 // apart), after which every lane owns 4 consecutive channels of one pixel: float4 loads/stores of the output
 // and of every fused operand (bias, per-sample bias, pre-activation, activation-gradient source, residual),
 // BN/4 lanes = one contiguous pixel row.
+// Args::ys_hi / ys_lo / ld_ys (optional): the stored values again as bf16 hi / lo planes (operand split fused into the producer).
 // Args::vec (host-computed, cdf_epi_vec_ok) = all pitches % 4 == 0, Cout % 4 == 0, 16-byte-aligned pointers;
 // otherwise the same code runs with per-element accesses.
 #pragma once
@@ -100,5 +101,7 @@ __device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph
             for (int e = 0; e < 4; ++e) v[e] += u[e];
         }
         cdf_st4(dst, v, nval, vec);
+        if (a.ys_hi && vec)                                  // the consumer GEMMs' bf16 hi / lo planes of the same values
+            cdf_split_store4(a.ys_hi + opix * a.ld_ys + co, a.ys_lo + opix * a.ld_ys + co, v);
     }
 }

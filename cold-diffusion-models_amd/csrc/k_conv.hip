@@ -44,6 +44,9 @@ struct ConvArgs {
     int mul_mode;    // 0 none, 1 v*=gelu'(mul), 2 v*=silu'(mul), 3 v*=mul
     int accumulate;  // y += v
     int nphase, vec;
+    unsigned short* ys_hi;   // (unused by the fp32 kernels: always null)
+    unsigned short* ys_lo;
+    int ld_ys;
     long long x_bs, w_bs, y_bs;     // blockIdx.z = outer*batch2 + inner: outer batch strides (elements)
     long long x_bs2, w_bs2, y_bs2;  // inner batch strides (e.g. attention heads)
     int batch2;
@@ -562,6 +565,7 @@ extern "C" int cdf_conv_gemm(const float* x, int ldx, const float* w, int ldw, f
     a.x_bs = x_bs; a.w_bs = w_bs; a.y_bs = y_bs;
     a.x_bs2 = x_bs2; a.w_bs2 = w_bs2; a.y_bs2 = y_bs2; a.batch2 = batch2;
     a.vec = cdf_epi_vec_ok(Cout, y, ldy, bias, sbias, ld_sbias, res, ldr, pre, ldp, mul, ldm) && y_bs % 4 == 0 && y_bs2 % 4 == 0;
+    a.ys_hi = nullptr; a.ys_lo = nullptr; a.ld_ys = 0;
     batch *= batch2;
     // phase_desc: per phase [oy, ox, ntaps, (dy, dx, wi) * ntaps]
     const int* pd = phase_desc;

@@ -82,15 +82,12 @@ struct SpArgs {
     int ldx, ldk, ldy, ld_sbias, ldr, ldp, ldm;
     int B, H, W, Cin, OH, OW, Cout, QH, QW, os, is;
     int act, mul_mode, accumulate, nphase, vec;
+    unsigned short* ys_hi;         // nullable: bf16 hi / lo planes of the output (pitch ld_ys), written by the epilogue
+    unsigned short* ys_lo;
+    int ld_ys;
     SpPhase ph[4];
 };
 
-__device__ __forceinline__ unsigned cdf_f2bf(float x) {        // round-to-nearest-even bf16 (finite inputs)
-    unsigned u = __float_as_uint(x);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return u >> 16;
-}
-__device__ __forceinline__ float cdf_bf2f(unsigned h) { return __uint_as_float(h << 16); }
 
 // In-kernel split of an activation quad, kept to ~4 VALU ops per element (the kernel is VALU-, not
 // MFMA-bound): hi = x truncated to bf16 (the residual x - hi is exact in fp32 and lands in lo, so
@@ -490,6 +487,9 @@ struct SpxArgs {
     int ldx, ldk, ldy, ld_sbias, ldr, ldp, ldm;
     int B, H, W, Cin, OH, OW, Cout, QH, QW, os, is;
     int act, mul_mode, accumulate, nphase, vec;
+    unsigned short* ys_hi;         // nullable: bf16 hi / lo planes of the output (pitch ld_ys), written by the epilogue
+    unsigned short* ys_lo;
+    int ld_ys;
     SpPhase ph[4];
 };
 
@@ -1007,6 +1007,7 @@ extern "C" int cdf_conv_gemm_bf16(const float* x, int ldx, const void* w_hi, con
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.QH = QH; a.QW = QW; a.os = os; a.is = is;
     a.act = act; a.mul_mode = mul_mode; a.accumulate = accumulate; a.nphase = nphase;
     a.vec = cdf_epi_vec_ok(Cout, y, ldy, bias, sbias, ld_sbias, res, ldr, pre, ldp, mul, ldm);
+    a.ys_hi = nullptr; a.ys_lo = nullptr; a.ld_ys = 0;
     const int* pd = phase_desc;
     for (int p = 0; p < nphase; ++p) {
         a.ph[p].oy = pd[0]; a.ph[p].ox = pd[1]; a.ph[p].ntaps = pd[2];
@@ -1124,8 +1125,10 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
                                    int ldk, float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW,
                                    int os, int is, int nphase, const int* phase_desc, const float* bias, const float* sbias,
                                    int ld_sbias, const float* res, int ldr, float* pre, int ldp, const float* mul, int ldm, int act,
-                                   int mul_mode, int accumulate, void* stream) {
+                                   int mul_mode, int accumulate, void* y_hi, void* y_lo, int ld_ys, void* stream) {
     CDF_REQUIRE(x_hi && x_lo && zero && w_hi && w_lo && y, "cdf_conv_gemm_bf16x: null pointer");
+    CDF_REQUIRE((!y_hi && !y_lo) || (y_hi && y_lo && ld_ys % 4 == 0 && ld_ys >= Cout && Cout % 4 == 0 && ((((uintptr_t)y_hi) | ((uintptr_t)y_lo)) & 7) == 0),
+                "cdf_conv_gemm_bf16x: split output planes need Cout %% 4 == 0, ld_ys %% 4 == 0, 8-byte alignment");
     CDF_REQUIRE(((((uintptr_t)x_hi) | ((uintptr_t)x_lo) | ((uintptr_t)zero) | ((uintptr_t)w_hi) | ((uintptr_t)w_lo)) & 15) == 0, "cdf_conv_gemm_bf16x: operands must be 16B aligned");
     CDF_REQUIRE(ldx % 8 == 0 && Cin % 8 == 0 && ldx >= Cin && ldk % 32 == 0 && ldk >= Cin, "cdf_conv_gemm_bf16x: Cin and pitches must be multiples of 8 (ldk of 32)");
     CDF_REQUIRE(nphase >= 1 && nphase <= 4 && phase_desc && ldy >= Cout, "cdf_conv_gemm_bf16x: bad geometry");
@@ -1138,6 +1141,8 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.QH = QH; a.QW = QW; a.os = os; a.is = is;
     a.act = act; a.mul_mode = mul_mode; a.accumulate = accumulate; a.nphase = nphase;
     a.vec = cdf_epi_vec_ok(Cout, y, ldy, bias, sbias, ld_sbias, res, ldr, pre, ldp, mul, ldm);
+    a.ys_hi = (unsigned short*)y_hi; a.ys_lo = (unsigned short*)y_lo; a.ld_ys = ld_ys;
+    CDF_REQUIRE(!y_hi || a.vec, "cdf_conv_gemm_bf16x: split output planes need the vectorised epilogue (aligned pointers, pitches %% 4)");
     int rc = fill_phases(a.ph, nphase, phase_desc, "cdf_conv_gemm_bf16x");
     if (rc) return rc;
     // Tile choice: 64-wide N for Cout <= 64 (no half-empty MFMA columns); 64-row M tiles when 128-row tiles would

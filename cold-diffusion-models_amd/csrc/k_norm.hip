@@ -18,7 +18,8 @@
 template <int NV>
 __global__ void __launch_bounds__(256) layernorm_c_fwd_kernel(const float* x, int ldx, float* y, int ldy, const float* g,
                                                               const float* bta, float* mean_out, float* rstd_out,
-                                                              long long M, int C, int LP, float eps) {
+                                                              long long M, int C, int LP, float eps, unsigned short* ys_hi,
+                                                              unsigned short* ys_lo, int ld_ys) {
     constexpr int U = NV <= 2 ? 4 : 2;
     const int lane = threadIdx.x & 63, sub = lane / LP, li = lane - sub * LP;
     const int groups_per_wave = 64 / LP;
@@ -76,6 +77,10 @@ __global__ void __launch_bounds__(256) layernorm_c_fwd_kernel(const float* x, in
                         o.z = (v[u][j].z - mean) / sd * gg[j].z + bb[j].z;
                         o.w = (v[u][j].w - mean) / sd * gg[j].w + bb[j].w;
                         *(float4*)(y + m * ldy + c) = o;
+                        if (ys_hi) {                         // operand split of the following conv fused in
+                            const float ov[4] = {o.x, o.y, o.z, o.w};
+                            cdf_split_store4(ys_hi + m * ld_ys + c, ys_lo + m * ld_ys + c, ov);
+                        }
                     }
                 }
                 if (li == 0 && mean_out) {
@@ -391,13 +396,16 @@ extern "C" int cdf_layernorm_blocks(long long M, int C) {
 }
 
 extern "C" int cdf_layernorm_c_fwd(const float* x, int ldx, float* y, int ldy, const float* g, const float* b,
-                                   float* mean, float* rstd, long long M, int C, float eps, void* stream) {
+                                   float* mean, float* rstd, long long M, int C, float eps, void* y_hi, void* y_lo, int ld_ys,
+                                   void* stream) {
+    CDF_REQUIRE((!y_hi && !y_lo) || (y_hi && y_lo && ld_ys % 4 == 0 && ld_ys >= C && ((((uintptr_t)y_hi) | ((uintptr_t)y_lo)) & 7) == 0),
+                "cdf_layernorm_c_fwd: split output planes need ld_ys %% 4 == 0, ld_ys >= C, 8-byte alignment");
     CDF_REQUIRE(x && y && g && b && M > 0, "cdf_layernorm_c_fwd: null / empty");
     CDF_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && C <= 1024, "cdf_layernorm_c_fwd: C=%d must be a multiple of 4 and <= 1024", C);
     int LP, NV;
     CDF_REQUIRE(ln_geometry(C, &LP, &NV) == CDF_OK, "cdf_layernorm_c_fwd: unsupported C=%d", C);
     const int nb = cdf_layernorm_blocks(M, C);
-#define CDF_LN_FWD(N) CDF_LAUNCH((layernorm_c_fwd_kernel<N>), dim3(nb), dim3(256), 0, CDF_S, x, ldx, y, ldy, g, b, mean, rstd, M, C, LP, eps)
+#define CDF_LN_FWD(N) CDF_LAUNCH((layernorm_c_fwd_kernel<N>), dim3(nb), dim3(256), 0, CDF_S, x, ldx, y, ldy, g, b, mean, rstd, M, C, LP, eps, (unsigned short*)y_hi, (unsigned short*)y_lo, ld_ys)
     switch (NV) {
         case 1: CDF_LN_FWD(1); break;
         case 2: CDF_LN_FWD(2); break;

@@ -148,11 +148,13 @@ int cdf_conv_wgrad_bf16(const float* xa, int lda, const float* xb, int ldb, floa
  * then only copy and multiply.  `zero` = any 16-byte-aligned device buffer of >= 16 zero bytes (out-of-image
  * taps load from it).  Channel counts and pitches must be multiples of 8. */
 int cdf_split_bf16(const float* x, int ldx, void* hi, void* lo, int ldo, long long rows, int C, void* stream);
+/* cdf_conv_gemm_bf16x: y_hi / y_lo (nullable, pitch ld_ys) additionally receive the stored output split into bf16 hi / lo planes,
+ * i.e. cdf_split_bf16 fused into the producer (needs Cout % 4 == 0 and the aligned / pitched layout of the vector epilogue). */
 int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo, int ldk,
                         float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW, int os, int is,
                         int nphase, const int* phase_desc, const float* bias, const float* sbias, int ld_sbias, const float* res,
                         int ldr, float* pre, int ldp, const float* mul, int ldm, int act, int mul_mode, int accumulate,
-                        void* stream);
+                        void* y_hi, void* y_lo, int ld_ys, void* stream);
 /* Tuning / test hook: force the block tile of cdf_conv_gemm_bf16x (rows of pixels x output channels; bm 64, 128 or
  * 256 -- the latter with bn = 128 --, bn 64 or 128; 0 = automatic choice from the problem size).  Process-wide; results
  * do not depend on it. */
@@ -180,7 +182,7 @@ int cdf_colsum(const float* x, float* out, float* ws, int nseg, int rows_per_seg
  * backward also produces dg/db; part >= cdf_layernorm_blocks(M,C)*2*C floats of scratch. */
 int cdf_layernorm_blocks(long long M, int C);
 int cdf_layernorm_c_fwd(const float* x, int ldx, float* y, int ldy, const float* g, const float* b, float* mean,
-                        float* rstd, long long M, int C, float eps, void* stream);
+                        float* rstd, long long M, int C, float eps, void* y_hi, void* y_lo, int ld_ys, void* stream);
 int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, int ldx, const float* g, const float* mean,
                         const float* rstd, float* dx, int lddx, float* dg, float* db, float* part, long long M, int C,
                         int accumulate_dx, int accumulate_param, void* stream);

@@ -355,11 +355,19 @@ def test_layernorm_c(be, M, C):
     yref.backward(dy)
     xd, gd, bd = be.to(x), be.to(g), be.to(b)
     y, mo, ro = be.empty(M, C), be.empty(M), be.empty(M)
-    be.L.cdf_layernorm_c_fwd(P(xd), C, P(y), C, P(gd), P(bd), P(mo), P(ro), M, C, 1e-5, be.stream())
+    be.L.cdf_layernorm_c_fwd(P(xd), C, P(y), C, P(gd), P(bd), P(mo), P(ro), M, C, 1e-5, 0, 0, 0, be.stream())
     nb = be.L.cdf_layernorm_blocks(M, C)
     part, dx, dg, db = be.empty(nb * 2 * C), be.empty(M, C), be.zeros(C), be.zeros(C)
     be.L.cdf_layernorm_c_bwd(P(be.to(dy)), C, P(xd), C, P(gd), P(mo), P(ro), P(dx), C, P(dg), P(db), P(part), M, C, 0, 0, be.stream())
     assert err(y, yref) <= 5e-6 and err(dx, x.grad) <= 1e-5 and err(dg, g.grad) <= 2e-5 and err(db, b.grad) <= 2e-5
+    if C % 8 == 0:
+        # fused operand split: the bf16 hi / lo planes must equal cdf_split_bf16 of the stored output, bit for bit
+        y2 = be.empty(M, C)
+        yh = torch.zeros(M, C, dtype=torch.int16, device=be.device)
+        yl = torch.zeros_like(yh)
+        be.L.cdf_layernorm_c_fwd(P(xd), C, P(y2), C, P(gd), P(bd), 0, 0, M, C, 1e-5, P(yh), P(yl), C, be.stream())
+        rh, rl = _split(be, y2)
+        assert torch.equal(y2.cpu(), y.cpu()) and torch.equal(yh.cpu(), rh.cpu()) and torch.equal(yl.cpu(), rl.cpu())
 
 
 @pytest.mark.parametrize("B,HW,C,silu", [(2, 16, 32, 1), (3, 64, 64, 1), (1, 16, 128, 0), (2, 300, 96, 1)])
@@ -625,11 +633,22 @@ def _spx_case(be, B, Cin, Cout, H, k, s, p):
         y = be.zeros(B, pl.OH, pl.OW, r4(Co))
         be.L.cdf_conv_gemm_bf16x(P(xsplit[0]), P(xsplit[1]), xsplit[0].shape[-1], P(zero), P(wpair[0]), P(wpair[1]), wpair[0].shape[-1], P(y),
                                  y.shape[-1], B, pl.H, pl.W, Ci, pl.OH, pl.OW, Co, pl.QH, pl.QW, pl.os, pl.istride, pl.nphase, pl.desc,
-                                 P(bias_), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, be.stream())
+                                 P(bias_), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, be.stream())
         return y
 
     y = run(plan, xs, wf, Cin, Cout, be.to(bias))
     dx = run(pd, gs, wb, Cout, Cin, None)
+    if Cout % 4 == 0:
+        # the epilogue's fused operand split must equal cdf_split_bf16 of the stored output, bit for bit
+        ld8 = (Cout + 7) // 8 * 8
+        yh = torch.zeros(B, plan.OH, plan.OW, ld8, dtype=torch.int16, device=be.device)
+        yl = torch.zeros_like(yh)
+        y2 = be.zeros(B, plan.OH, plan.OW, r4(Cout))
+        be.L.cdf_conv_gemm_bf16x(P(xs[0]), P(xs[1]), xs[0].shape[-1], P(zero), P(wf[0]), P(wf[1]), wf[0].shape[-1], P(y2), y2.shape[-1], B,
+                                 plan.H, plan.W, Cin, plan.OH, plan.OW, Cout, plan.QH, plan.QW, plan.os, plan.istride, plan.nphase,
+                                 plan.desc, P(be.to(bias)), 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, P(yh), P(yl), ld8, be.stream())
+        rh, rl = _split(be, y2[..., :Cout].contiguous())
+        assert torch.equal(yh.cpu(), rh.cpu()) and torch.equal(yl.cpu(), rl.cpu())
     M = B * wg.QH * wg.QW
     ns, ldo = max(1, min(3, M // 32)), r4(Cout)
     ws, bsum = be.empty(ns, KK, Cin, ldo), be.empty(ns, ldo)

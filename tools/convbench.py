@@ -77,7 +77,7 @@ if os.environ.get("KB_SPX", "1") == "1":
         xs = split(x); gs = split(gy)
         p = cd.conv_fwd(H,H,k,k,1,k//2,k//2,k//2,k//2)
         fl = 2.0*B*H*H*Cin*Cout*k*k
-        ms = timeit(lambda: L.cdf_conv_gemm_bf16x(P(xs[0]),P(xs[1]),Cin,P(zero),P(hi),P(lo),ldk,P(y),y.shape[-1],B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,0,0,0,0,0,0,0,0,0,0,0,0,S()))
+        ms = timeit(lambda: L.cdf_conv_gemm_bf16x(P(xs[0]),P(xs[1]),Cin,P(zero),P(hi),P(lo),ldk,P(y),y.shape[-1],B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,S()))
         print(f"spx   {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv", flush=True)
         wg = cd.conv_wgrad(H,H,k,k,1,k//2,k//2,k//2,k//2); M=B*H*H
         tiles = ((Cin+127)//128)*((Cout+127)//128)*k*k

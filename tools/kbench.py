@@ -95,7 +95,7 @@ for (C, H) in [(64, 128), (256, 32), (1024, 16)]:
     x = torch.randn(M, C, device=dev)
     g, b_ = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     y, mo, ro = torch.empty_like(x), torch.empty(M, device=dev), torch.empty(M, device=dev)
-    ms = timeit(lambda: L.cdf_layernorm_c_fwd(P(x), C, P(y), C, P(g), P(b_), P(mo), P(ro), M, C, 1e-5, S()))
+    ms = timeit(lambda: L.cdf_layernorm_c_fwd(P(x), C, P(y), C, P(g), P(b_), P(mo), P(ro), M, C, 1e-5, 0, 0, 0, S()))
     rec(f"layernorm_fwd_M{M}_C{C}", ms, bytes_=8.0 * x.numel())
     nb = L.cdf_layernorm_blocks(M, C)
     part, dx, dg, db = torch.empty(nb * 2 * C, device=dev), torch.empty_like(x), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
