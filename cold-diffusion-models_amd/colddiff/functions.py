@@ -60,6 +60,7 @@ def want_presplit(Cin, Cout, k):
     return rt.precision == "bf16x3" and Cin % 8 == 0 and Cout % 8 == 0 and bool(_sp_suffix(Cin * k * k, Cout)) and bool(_sp_suffix(Cout * k * k, Cin))
 
 
+_AUTO_PRESPLIT = os.environ.get("CDF_AUTO_PRESPLIT", "1") != "0"
 _SP_KMIN = int(os.environ.get("CDF_SP_KMIN", "128"))     # tuning knob: smallest K routed to the bf16 matrix cores
 
 
@@ -218,16 +219,24 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, x, mod, Cin, kind, stride, pad):
-        y = conv_forward(x, Cin, mod.weight, mod.bias, kind, stride, pad)
+        k = mod.weight.shape[-1]
+        Cout = mod.weight.shape[0] if kind == "conv" else mod.weight.shape[1]
+        # 4x4 stride-2 down / transposed up-sampling convs: every input pixel feeds several taps and N tiles, and the
+        # same planes serve the weight gradient -> split once, use the LDS-DMA kernels (1x1 convs read x once: not worth it)
+        xs = ops.split_bf16(x) if (_AUTO_PRESPLIT and k > 1 and want_presplit(Cin, Cout, k)) else None
+        y = conv_forward(x, Cin, mod.weight, mod.bias, kind, stride, pad, xs=xs)
         ctx.mod, ctx.cfg = mod, (Cin, kind, stride, pad)
-        ctx.save_for_backward(x)
+        ctx.has_xs = xs is not None
+        ctx.save_for_backward(x, *(xs or (None, None)))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
+        x, x_hi, x_lo = ctx.saved_tensors
         Cin, kind, stride, pad = ctx.cfg
-        dx = conv_backward(x, Cin, dy, ctx.mod.weight, ctx.mod.bias, kind, stride, pad, need_dx=ctx.needs_input_grad[1])
+        xs = (x_hi, x_lo) if ctx.has_xs else None
+        dys = ops.split_bf16(dy) if xs is not None else None
+        dx = conv_backward(x, Cin, dy, ctx.mod.weight, ctx.mod.bias, kind, stride, pad, need_dx=ctx.needs_input_grad[1], xs=xs, dys=dys)
         _done(ctx.mod)
         return None, dx, None, None, None, None, None
 

@@ -256,3 +256,31 @@ def test_convnext_block_presplit_operands(mbe):
     for n, p_ in blk.named_parameters():
         r = sd[n].grad
         assert (p_.grad.cpu() - r).abs().max().item() <= tol * max(r.abs().max().item(), 1e-3), n
+
+
+@pytest.mark.parametrize("kind", ["conv", "convT"])
+def test_resampling_conv_presplit(mbe, kind):
+    """4x4 stride-2 down-sampling conv / transposed up-sampling conv (DEBLUR:125-130) on the pre-split LDS-DMA path:
+    forward, data gradient and weight gradient against torch."""
+    from colddiff import functions as F_
+    from colddiff.unet import anchor
+    assert F_.want_presplit(64, 64, 4)
+    torch.manual_seed(5)
+    mod = (torch.nn.Conv2d(64, 64, 4, 2, 1) if kind == "conv" else torch.nn.ConvTranspose2d(64, 64, 4, 2, 1))
+    ref = (torch.nn.Conv2d(64, 64, 4, 2, 1) if kind == "conv" else torch.nn.ConvTranspose2d(64, 64, 4, 2, 1))
+    ref.load_state_dict(mod.state_dict())
+    mod = mod.to(mbe.device)
+    x = torch.randn(2, 64, 12, 12)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    xd = mbe.to(x).requires_grad_(True)
+    xn = F_.ToNHWC.apply(xd)
+    y = F_.ToNCHW.apply(F_.ConvFn.apply(anchor(xn), xn, mod, 64, kind, 2, (1, 1, 1, 1)), 64, None)
+    y.backward(mbe.to(g))
+    tol = 1e-4
+    assert (y.detach().cpu() - yr.detach()).abs().max().item() <= tol * yr.abs().max().item()
+    assert (xd.grad.cpu() - xr.grad).abs().max().item() <= tol * xr.grad.abs().max().item()
+    for (n, p_), (_, r) in zip(mod.named_parameters(), ref.named_parameters()):
+        assert (p_.grad.cpu() - r.grad).abs().max().item() <= tol * max(r.grad.abs().max().item(), 1e-3), n
