@@ -60,6 +60,7 @@ def want_presplit(Cin, Cout, k):
     return rt.precision == "bf16x3" and Cin % 8 == 0 and Cout % 8 == 0 and bool(_sp_suffix(Cin * k * k, Cout)) and bool(_sp_suffix(Cout * k * k, Cin))
 
 
+_LINEAR_SMALL_M = 256      # batch sizes up to this use the skinny-linear kernels
 _AUTO_PRESPLIT = os.environ.get("CDF_AUTO_PRESPLIT", "1") != "0"
 _SP_KMIN = int(os.environ.get("CDF_SP_KMIN", "128"))     # tuning knob: smallest K routed to the bf16 matrix cores
 
@@ -186,11 +187,16 @@ class Linear(torch.autograd.Function):
         W, b = lin.weight, lin.bias
         N, K = W.shape
         B = x.shape[0]
+        ctx.lin = lin
+        ctx.save_for_backward(x)
+        if B <= _LINEAR_SMALL_M:                             # batch-rows-only GEMM: dedicated kernel (see k_misc.hip)
+            wp = ops.packed(W, "lin_fwd")                    # [1][K][r4(N)]
+            y = torch.empty((B, r4(N)), device=x.device, dtype=torch.float32)
+            rt.lib().cdf_linear_small(P(x), x.stride(0), P(wp), wp.shape[-1], P(b), P(y), r4(N), B, K, N, rt.stream(x))
+            return y
         plan = cd.conv_fwd(1, 1, 1, 1, 1, 0, 0, 0, 0)
         x4 = x.view(B, 1, 1, x.shape[1])
         y = ops.conv_gemm(plan, x4, K, ops.packed(W, "lin_fwd"), N, bias=b)
-        ctx.lin = lin
-        ctx.save_for_backward(x)
         return y.view(B, r4(N))
 
     @staticmethod
@@ -201,6 +207,17 @@ class Linear(torch.autograd.Function):
         N, K = W.shape
         B = x.shape[0]
         dy = dy.contiguous()
+        if B <= _LINEAR_SMALL_M:
+            L, S = rt.lib(), rt.stream(x)
+            L.cdf_linear_small_wgrad(P(dy), dy.stride(0), P(x), x.stride(0), P(ops.grad_of(W)), P(ops.grad_of(b)) if b is not None else 0,
+                                     B, N, K, S)
+            dx = None
+            if ctx.needs_input_grad[1]:
+                dx = torch.empty((B, r4(K)), device=x.device, dtype=torch.float32)
+                L.cdf_linear_small(P(dy), dy.stride(0), P(W), K, 0, P(dx), r4(K), B, N, K, S)
+                dx = dx[:, :x.shape[1]]
+            _done(lin)
+            return None, dx, None
         dy4, x4 = dy.view(B, 1, 1, dy.shape[1]), x.view(B, 1, 1, x.shape[1])
         wp = cd.conv_wgrad(1, 1, 1, 1, 1, 0, 0, 0, 0)
         ops.wgrad_into(ops.grad_of(W), wp, dy4, N, x4, K, 0, K, 1)          # dW[n][k] += dy[b][n] x[b][k]

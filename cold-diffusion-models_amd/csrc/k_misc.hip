@@ -144,11 +144,79 @@ __global__ void scale_kernel(float* x, long long n, float s) {
 }
 
 // ================================================================================================
+// ------------------------------------------------------------------------------------------------
+// Skinny linear layers (time-embedding MLPs: DEBLUR:96-103,142-144,160; MODEL2:44-48,238-245): M = batch rows only.
+// On the 128-row GEMM tiles these are one block walking K in 16-element steps behind a barrier each (~70 us for a
+// 32 x 512 x 64 product); here the rows are register accumulators and the contraction is split over 4 waves.
+//   out[m][j] = bias[j] + sum_i in[m][i] * Wm[i * ldw + j]
+// forward: i = k, j = n, Wm = the [K][N] packed weight;  data gradient: i = n, j = k, Wm = the PyTorch [N][K] weight.
+// grid = (ceil(J/64), ceil(M/32)); block 256 = 4 contraction slices x 64 output columns.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) linear_small_kernel(const float* in, int ldi, const float* Wm, int ldw, const float* bias,
+                                                           float* out, int ldo, int M, int I, int J) {
+    constexpr int MB = 32;
+    __shared__ float red[4][MB][64];
+    const int lane = threadIdx.x & 63, ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = blockIdx.x * 64 + lane, m0 = blockIdx.y * MB;
+    const int jc = j < J ? j : J - 1;
+    float acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[m] = 0.f;
+    const int per = (I + 3) / 4, i0 = ks * per, i1 = (i0 + per) < I ? (i0 + per) : I;
+    for (int i = i0; i < i1; ++i) {
+        const float w = Wm[(long long)i * ldw + jc];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int mm = (m0 + m) < M ? (m0 + m) : M - 1;   // wave-uniform row: the load is scalar
+            acc[m] = fmaf(in[(long long)mm * ldi + i], w, acc[m]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m) red[ks][m][lane] = acc[m];
+    __syncthreads();
+    const float b = (bias && j < J) ? bias[j] : 0.f;
+    for (int m = ks; m < MB; m += 4) {
+        if (m0 + m >= M || j >= ldo) continue;
+        const float v = (red[0][m][lane] + red[1][m][lane]) + (red[2][m][lane] + red[3][m][lane]) + b;
+        out[(long long)(m0 + m) * ldo + j] = j < J ? v : 0.f;     // columns J..ldo-1 are pitch padding
+    }
+}
+
+// dW[n][k] += sum_m dy[m][n] x[m][k];  db[n] += sum_m dy[m][n].  grid = (ceil(K/64), ceil(N/4)); wave = one n, lanes = k.
+__global__ void __launch_bounds__(256) linear_small_wgrad_kernel(const float* dy, int ldd, const float* x, int ldx, float* dW, float* db,
+                                                                 int M, int N, int K) {
+    const int lane = threadIdx.x & 63, n = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (n >= N) return;
+    const int k = blockIdx.x * 64 + lane, kc = k < K ? k : K - 1;
+    float acc = 0.f, bs = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float d = dy[(long long)m * ldd + n];          // wave-uniform
+        acc = fmaf(d, x[(long long)m * ldx + kc], acc);
+        bs += d;
+    }
+    if (k < K) dW[(long long)n * K + k] += acc;
+    if (db && blockIdx.x == 0 && lane == 0) db[n] += bs;
+}
+
 extern "C" int cdf_sinusoidal(const int64_t* t, const float* freq, float* out, int ldo, int B, int dim, void* stream) {
     CDF_REQUIRE(t && freq && out && B > 0 && dim >= 4 && (dim & 1) == 0 && ldo >= dim, "cdf_sinusoidal: bad args");
     CDF_LAUNCH(sinusoidal_kernel, dim3(ew_grid((long long)B * dim / 2)), dim3(256), 0, CDF_S, t, freq, out, ldo, B, dim);
     return cdf_check_launch("sinusoidal");
 }
+extern "C" int cdf_linear_small(const float* in, int ldi, const float* Wm, int ldw, const float* bias, float* out, int ldo, int M,
+                                int I, int J, void* stream) {
+    CDF_REQUIRE(in && Wm && out && M > 0 && I > 0 && J > 0 && ldi >= I && ldw >= J && ldo >= J, "cdf_linear_small: bad args");
+    CDF_LAUNCH(linear_small_kernel, dim3(cdf_cdiv(ldo, 64), cdf_cdiv(M, 32)), dim3(256), 0, CDF_S, in, ldi, Wm, ldw, bias, out, ldo, M, I, J);
+    return cdf_check_launch("linear_small");
+}
+
+extern "C" int cdf_linear_small_wgrad(const float* dy, int ldd, const float* x, int ldx, float* dW, float* db, int M, int N, int K,
+                                      void* stream) {
+    CDF_REQUIRE(dy && x && dW && M > 0 && N > 0 && K > 0 && ldd >= N && ldx >= K, "cdf_linear_small_wgrad: bad args");
+    CDF_LAUNCH(linear_small_wgrad_kernel, dim3(cdf_cdiv(K, 64), cdf_cdiv(N, 4)), dim3(256), 0, CDF_S, dy, ldd, x, ldx, dW, db, M, N, K);
+    return cdf_check_launch("linear_small_wgrad");
+}
+
 extern "C" int cdf_act_fwd(const float* x, int ldx, float* y, int ldy, long long rows, int C, int act, void* stream) {
     CDF_REQUIRE(x && y && rows > 0 && C > 0 && (act == 1 || act == 2), "cdf_act_fwd: bad args");
     CDF_LAUNCH(act_fwd_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, CDF_S, x, ldx, y, ldy, rows, C, act);

@@ -237,6 +237,13 @@ int cdf_softmax_rows_bwd(const float* p, const float* dp, float* ds, long long r
  * sinusoidal time embedding (DEBLUR:91-103, MODEL2:6-24): out[b] = (sin(t f_j) | cos(t f_j)),
  * freq[dim/2] = the init-time frequency table exp(-j ln(1e4)/(dim/2-1)) */
 int cdf_sinusoidal(const int64_t* t, const float* freq, float* out, int ldo, int B, int dim, void* stream);
+/* Skinny linear layers (M = batch rows; the time-embedding MLPs DEBLUR:96-103,142-144,160, MODEL2:44-48,238-245):
+ *   out[m][j] = bias[j] + sum_i in[m][i] * Wm[i*ldw + j]        (columns J..ldo-1 of out are zeroed)
+ * forward: Wm = the weight packed [K][N] (cdf_pack_weight), i = k, j = n; data gradient: Wm = the PyTorch [N][K]
+ * weight itself, i = n, j = k.  cdf_linear_small_wgrad ACCUMULATES dW[n][k] += sum_m dy[m][n] x[m][k], db[n] += sum_m dy[m][n]. */
+int cdf_linear_small(const float* in, int ldi, const float* Wm, int ldw, const float* bias, float* out, int ldo, int M, int I, int J,
+                     void* stream);
+int cdf_linear_small_wgrad(const float* dy, int ldd, const float* x, int ldx, float* dW, float* db, int M, int N, int K, void* stream);
 /* act 1 = exact GELU, 2 = SiLU on [rows, C] with pitches */
 int cdf_act_fwd(const float* x, int ldx, float* y, int ldy, long long rows, int C, int act, void* stream);
 int cdf_act_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, long long rows, int C, int act,

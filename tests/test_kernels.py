@@ -685,3 +685,29 @@ def test_conv_presplit_forced_tiles(be, tile):
 def test_conv_presplit_large(case):
     from conftest import Backend
     _spx_case(Backend("hip"), *case)
+
+
+@pytest.mark.parametrize("M,K,N", [(32, 64, 256), (5, 256, 40), (70, 48, 130)])
+def test_linear_small(be, M, K, N):
+    """Skinny linear layer kernels against torch: forward (packed [K][N] weight), data gradient (PyTorch [N][K] weight),
+    accumulating weight / bias gradients."""
+    torch.manual_seed(0)
+    x = torch.randn(M, K, requires_grad=True)
+    lin = torch.nn.Linear(K, N)
+    y = lin(x)
+    g = torch.randn(M, N)
+    y.backward(g)
+    Np = r4(N)
+    wp = be.empty(1, K, Np)
+    be.L.cdf_pack_weight(P(be.to(lin.weight.detach())), P(wp), 1, K, N, Np, 0, 1, K, be.stream())
+    xd, gd, Wd, bd = be.to(x.detach()), be.to(g), be.to(lin.weight.detach()), be.to(lin.bias.detach())
+    yo = be.empty(M, Np)
+    be.L.cdf_linear_small(P(xd), K, P(wp), Np, P(bd), P(yo), Np, M, K, N, be.stream())
+    assert err(yo[:, :N], y.detach()) <= 2e-5 and (yo[:, N:].cpu() == 0).all()
+    Kp = r4(K)
+    dx = be.empty(M, Kp)
+    be.L.cdf_linear_small(P(gd), N, P(Wd), K, 0, P(dx), Kp, M, N, K, be.stream())
+    assert err(dx[:, :K], x.grad) <= 2e-5
+    dW, db = be.to(torch.ones(N, K)), be.to(torch.ones(N))
+    be.L.cdf_linear_small_wgrad(P(gd), N, P(xd), K, P(dW), P(db), M, N, K, be.stream())
+    assert err(dW, lin.weight.grad + 1) <= 5e-5 and err(db, lin.bias.grad + 1) <= 5e-5
