@@ -316,8 +316,7 @@ class ConvNextBlockFn(torch.autograd.Function):
         dx = None
         if m.has_res_conv:
             dx = conv_backward(x, dim, do, m.res_conv.weight, m.res_conv.bias, need_dx=need_dx)
-        elif need_dx:
-            dx = ops.copy_feat(do)
+        # (without a res_conv the residual gradient is `do` itself: added by the depthwise data-gradient kernel below)
         # conv2 -> (fused GELU') -> conv1
         do_s = ops.split_bf16(do) if a_s is not None else None
         if hn_s is not None:
@@ -331,7 +330,10 @@ class ConvNextBlockFn(torch.autograd.Function):
             dh = dhn
         dtb = ops.dwconv7_wgrad(x, dh, m.ds_conv.weight, m.ds_conv.bias, ctx.has_t)
         if need_dx:
-            ops.dwconv7(dh, ops.packed(m.ds_conv.weight, "dw"), None, None, flip=1, y=dx, accumulate=1)
+            if m.has_res_conv:
+                ops.dwconv7(dh, ops.packed(m.ds_conv.weight, "dw"), None, None, flip=1, y=dx, accumulate=1)
+            else:
+                dx = ops.dwconv7(dh, ops.packed(m.ds_conv.weight, "dw"), None, None, flip=1, res=do)
         _done(m.ds_conv, m.net[0] if m.has_norm else None, c1, c2, m.res_conv if m.has_res_conv else None)
         return None, dx, dtb, None
 

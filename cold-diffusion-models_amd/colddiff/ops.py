@@ -296,12 +296,13 @@ def layernorm_bwd(dy, x, g_param, b_param, mean, rstd, dx=None):
     return dx
 
 
-def dwconv7(x, wp, bias, sbias, flip=0, y=None, accumulate=0):
+def dwconv7(x, wp, bias, sbias, flip=0, y=None, accumulate=0, res=None):
+    """y = dwconv(x) [+ bias + sbias] [+ old y] [+ res]"""
     B, H, W, Cp = x.shape
     if y is None:
         y = torch.empty((B, H, W, Cp), device=x.device, dtype=torch.float32)
     rt.lib().cdf_dwconv7(P(x), ld_of(x), P(wp), wp.shape[-1], P(bias), P(sbias), 0 if sbias is None else sbias.stride(0), P(y),
-                         ld_of(y), B, H, W, Cp, flip, accumulate, rt.stream(x))
+                         ld_of(y), B, H, W, Cp, flip, accumulate, P(res), 0 if res is None else ld_of(res), rt.stream(x))
     return y
 
 

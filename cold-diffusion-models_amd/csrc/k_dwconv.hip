@@ -34,7 +34,7 @@ __device__ __forceinline__ void f4_fma(float4& acc, const float4& a, const float
 template <int TBW, int TBH>
 __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx, const float* w, int ldw, const float* bias,
                                                          const float* sbias, int ld_sbias, float* y, int ldy, int B, int H,
-                                                         int W, int C4, int flip, int accumulate) {
+                                                         int W, int C4, int flip, int accumulate, const float* res, int ldr) {
     constexpr int HW_ = TBW + 6, HH_ = TBH + 6;              // halo extent
     constexpr int RP = HW_ * 8 + 4;                          // row pitch in float4 (pixels x 8 channel quads + 64 B)
     constexpr int TX = TBW / 4, TY = TBH / 2;                // thread tiles
@@ -136,6 +136,10 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx
             if (accumulate) {
                 const float4 old = *(const float4*)dst;
                 v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+            }
+            if (res) {                                       // fused residual (e.g. dx = dy + conv^T(dh))
+                const float4 r = *(const float4*)(res + (((long long)b * H + oy) * W + ox) * ldr + c);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
             }
             *(float4*)dst = v;
         }
@@ -274,7 +278,7 @@ __global__ void __launch_bounds__(1024) dwconv7_wgrad_final_kernel(const float* 
 
 template <int TBW, int TBH>
 static int launch_dwconv7(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias, int ld_sbias, float* y,
-                          int ldy, int B, int H, int W, int C4, int flip, int accumulate, hipStream_t s) {
+                          int ldy, int B, int H, int W, int C4, int flip, int accumulate, const float* res, int ldr, hipStream_t s) {
     constexpr size_t lds = ((size_t)(TBH + 6) * ((TBW + 6) * 8 + 4) + DW_TAPS * 8) * sizeof(float4);
 #ifndef CDF_EMU
     static bool attr_done = false;
@@ -285,20 +289,21 @@ static int launch_dwconv7(const float* x, int ldx, const float* w, int ldw, cons
 #endif
     const long long tiles = (long long)B * cdf_cdiv(H, TBH) * cdf_cdiv(W, TBW);
     CDF_LAUNCH((dwconv7_kernel<TBW, TBH>), dim3((unsigned)tiles, cdf_cdiv(C4, 8)), dim3(256), lds, s, x, ldx, w, ldw, bias, sbias, ld_sbias, y,
-               ldy, B, H, W, C4, flip, accumulate);
+               ldy, B, H, W, C4, flip, accumulate, res, ldr);
     return cdf_check_launch("dwconv7");
 }
 
 // ================================================================================================
 extern "C" int cdf_dwconv7(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias,
                            int ld_sbias, float* y, int ldy, int B, int H, int W, int C, int flip, int accumulate,
-                           void* stream) {
+                           const float* res, int ldr, void* stream) {
+    CDF_REQUIRE(!res || (ldr % 4 == 0 && (((uintptr_t)res) & 15) == 0), "cdf_dwconv7: residual must be 16B aligned with pitch %% 4 == 0");
     CDF_REQUIRE(x && w && y, "cdf_dwconv7: null pointer");
     const int Cp = (C + 3) & ~3;
     CDF_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldw % 4 == 0 && ldx >= Cp && ldy >= Cp && ldw >= Cp, "cdf_dwconv7: pitches must be multiples of 4 and >= roundup4(C)");
     CDF_REQUIRE(!bias || (C % 4 == 0), "cdf_dwconv7: bias with C %% 4 != 0 needs a padded bias (pass a padded vector and C rounded up)");
-    if (W <= 16) return launch_dwconv7<16, 16>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, CDF_S);
-    return launch_dwconv7<32, 8>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, CDF_S);
+    if (W <= 16) return launch_dwconv7<16, 16>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S);
+    return launch_dwconv7<32, 8>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S);
 }
 
 extern "C" int cdf_dwconv7_wgrad_nchunk(int H) {

@@ -154,22 +154,52 @@ __global__ void scale_kernel(float* x, long long n, float s) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) linear_small_kernel(const float* in, int ldi, const float* Wm, int ldw, const float* bias,
                                                            float* out, int ldo, int M, int I, int J) {
-    constexpr int MB = 32;
+    constexpr int MB = 32, IC = 128;                         // rows per block, contraction chunk staged in LDS
+    __shared__ __attribute__((aligned(16))) float xs[MB][IC];
     __shared__ float red[4][MB][64];
-    const int lane = threadIdx.x & 63, ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, ks = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = blockIdx.x * 64 + lane, m0 = blockIdx.y * MB;
     const int jc = j < J ? j : J - 1;
     float acc[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) acc[m] = 0.f;
-    const int per = (I + 3) / 4, i0 = ks * per, i1 = (i0 + per) < I ? (i0 + per) : I;
-    for (int i = i0; i < i1; ++i) {
-        const float w = Wm[(long long)i * ldw + jc];
+    for (int c0 = 0; c0 < I; c0 += IC) {
+        // stage in[m0 .. m0+31][c0 .. c0+127] (rows / columns past the end as zeros): element-wise, any pitch
+        // (all 16 loads of a thread in flight: unconditional, clamped address + select)
+        float stage[MB * IC / 256];
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int mm = (m0 + m) < M ? (m0 + m) : M - 1;   // wave-uniform row: the load is scalar
-            acc[m] = fmaf(in[(long long)mm * ldi + i], w, acc[m]);
+        for (int r = 0; r < MB * IC / 256; ++r) {
+            const int e = tid + 256 * r, m = e / IC, i = e - m * IC;
+            const bool ok = m0 + m < M && c0 + i < I;
+            const float v = in[(long long)(ok ? m0 + m : 0) * ldi + (ok ? c0 + i : 0)];
+            stage[r] = ok ? v : 0.f;
         }
+        // wave ks multiplies its quarter of the chunk: its 32 weight rows are fetched up front, in flight together with the
+        // staging loads (one round trip per chunk); the activations are then LDS broadcasts
+        float w[IC / 4];
+#pragma unroll
+        for (int u = 0; u < IC / 4; ++u) {
+            const int i = c0 + ks * (IC / 4) + u;
+            w[u] = Wm[(long long)(i < I ? i : I - 1) * ldw + jc];       // (xs is zero past I)
+        }
+#pragma unroll
+        for (int r = 0; r < MB * IC / 256; ++r) {
+            const int e = tid + 256 * r, m = e / IC, i = e - m * IC;
+            xs[m][i] = stage[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i4 = 0; i4 < IC / 4; i4 += 4) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const float4 xv = *(const float4*)&xs[m][ks * (IC / 4) + i4];
+                acc[m] = fmaf(xv.x, w[i4 + 0], acc[m]);
+                acc[m] = fmaf(xv.y, w[i4 + 1], acc[m]);
+                acc[m] = fmaf(xv.z, w[i4 + 2], acc[m]);
+                acc[m] = fmaf(xv.w, w[i4 + 3], acc[m]);
+            }
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int m = 0; m < MB; ++m) red[ks][m][lane] = acc[m];

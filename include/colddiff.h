@@ -202,7 +202,8 @@ int cdf_groupnorm_bwd(const float* dy, int lddy, const float* x, int ldx, const 
  * wgrad: dw in the parameter layout [C][1][7][7], dbias [C], dsb [B][ld_dsb] (time-bias gradient,
  * overwritten); ws >= B * cdf_dwconv7_wgrad_nchunk(H) * 50 * C floats. */
 int cdf_dwconv7(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias, int ld_sbias,
-                float* y, int ldy, int B, int H, int W, int C, int flip, int accumulate, void* stream);
+                float* y, int ldy, int B, int H, int W, int C, int flip, int accumulate,
+                const float* res, int ldr, void* stream);
 int cdf_dwconv7_wgrad_nchunk(int H);
 int cdf_dwconv7_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* dbias, float* dsb,
                       int ld_dsb, float* ws, int B, int H, int W, int C, int accumulate, void* stream);

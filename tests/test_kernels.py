@@ -402,8 +402,12 @@ def test_dwconv7(be, B, C, H):
     bp, sbp = torch.zeros(Cp), torch.zeros(B, Cp)
     bp[:C], sbp[:, :C] = bias.detach(), sb.detach()
     y, dx = be.empty(B, H, H, Cp), be.empty(B, H, H, Cp)
-    be.L.cdf_dwconv7(P(xn), Cp, P(wp), Cp, P(be.to(bp)), P(be.to(sbp)), Cp, P(y), Cp, B, H, H, Cp, 0, 0, be.stream())
-    be.L.cdf_dwconv7(P(dyn), Cp, P(wp), Cp, 0, 0, 0, P(dx), Cp, B, H, H, Cp, 1, 0, be.stream())
+    be.L.cdf_dwconv7(P(xn), Cp, P(wp), Cp, P(be.to(bp)), P(be.to(sbp)), Cp, P(y), Cp, B, H, H, Cp, 0, 0, 0, 0, be.stream())
+    rs = torch.randn(B, H, H, Cp)
+    be.L.cdf_dwconv7(P(dyn), Cp, P(wp), Cp, 0, 0, 0, P(dx), Cp, B, H, H, Cp, 1, 0, 0, 0, be.stream())
+    dxr = be.empty(B, H, H, Cp)
+    be.L.cdf_dwconv7(P(dyn), Cp, P(wp), Cp, 0, 0, 0, P(dxr), Cp, B, H, H, Cp, 1, 0, P(be.to(rs)), Cp, be.stream())     # fused residual
+    assert err(dxr[..., :C], dx[..., :C].cpu() + rs[..., :C]) <= 1e-6
     nch = be.L.cdf_dwconv7_wgrad_nchunk(H)
     ws, dw, dbias, dsb = be.empty(B * nch * 50 * C), be.zeros(C, 1, 7, 7), be.zeros(C), be.zeros(B, Cp)
     be.L.cdf_dwconv7_wgrad(P(xn), Cp, P(dyn), Cp, P(dw), P(dbias), P(dsb), Cp, P(ws), B, H, H, C, 0, be.stream())

@@ -81,7 +81,7 @@ for (C, H) in [(64, 128), (128, 64), (256, 32), (512, 16)]:
     x = torch.randn(B, H, H, C, device=dev)
     w = torch.randn(49, C, device=dev)
     y = torch.empty_like(x)
-    ms = timeit(lambda: L.cdf_dwconv7(P(x), C, P(w), C, 0, 0, 0, P(y), C, B, H, H, C, 0, 0, S()))
+    ms = timeit(lambda: L.cdf_dwconv7(P(x), C, P(w), C, 0, 0, 0, P(y), C, B, H, H, C, 0, 0, 0, 0, S()))
     rec(f"dwconv7_B{B}_C{C}@{H}", ms, bytes_=8.0 * x.numel())
     nch = L.cdf_dwconv7_wgrad_nchunk(H)
     ws = torch.empty(B * nch * 50 * C, device=dev)
