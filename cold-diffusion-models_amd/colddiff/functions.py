@@ -36,7 +36,7 @@ def _conv_plans(kind, H, W, k, stride, pad):
     return cd.convT_fwd(H, W, k, k, stride, pad[0]), cd.convT_dgrad(H, W, k, k, stride, pad[0]), cd.convT_wgrad(H, W, k, k, stride, pad[0])
 
 
-def conv_forward(x, Cin, weight, bias, kind="conv", stride=1, pad=None, xs=None, split_out=False, **epi):
+def conv_forward(x, Cin, weight, bias, kind="conv", stride=1, pad=None, xs=None, split_out=False, planes_only=False, **epi):
     """x [B,H,W,*] -> conv(x) with the weight in its PyTorch layout ([Cout,Cin,k,k] or [Cin,Cout,k,k]).
     xs: optional pre-split (hi, lo) bf16 planes of x (see want_presplit).
     split_out: return (y, (hi, lo) planes of y) -- fused into the epilogue on the pre-split path."""
@@ -49,7 +49,7 @@ def conv_forward(x, Cin, weight, bias, kind="conv", stride=1, pad=None, xs=None,
     sfx = _sp_suffix(Cin * k * k, Cout)
     wp = ops.packed(weight, ("conv_fwd" if kind == "conv" else "convT_fwd") + sfx)
     if xs is not None and sfx:
-        return ops.conv_gemm_presplit(plan, xs, Cin, wp, Cout, bias=bias, split_out=split_out, **epi)
+        return ops.conv_gemm_presplit(plan, xs, Cin, wp, Cout, bias=bias, split_out=split_out, planes_only=planes_only, **epi)
     y = ops.conv_gemm(plan, x, Cin, wp, Cout, bias=bias, **epi)
     return (y, ops.split_bf16(y)) if split_out else y
 
@@ -60,6 +60,7 @@ def want_presplit(Cin, Cout, k):
     return rt.precision == "bf16x3" and Cin % 8 == 0 and Cout % 8 == 0 and bool(_sp_suffix(Cin * k * k, Cout)) and bool(_sp_suffix(Cout * k * k, Cin))
 
 
+_LEAN = os.environ.get("CDF_LEAN", "1") != "0"    # skip fp32 copies of tensors only ever consumed as bf16 planes
 _LINEAR_SMALL_M = 256      # batch sizes up to this use the skinny-linear kernels
 _AUTO_PRESPLIT = os.environ.get("CDF_AUTO_PRESPLIT", "1") != "0"
 _SP_KMIN = int(os.environ.get("CDF_SP_KMIN", "128"))     # tuning knob: smallest K routed to the bf16 matrix cores
@@ -73,7 +74,7 @@ def _sp_suffix(K, N):
 
 
 def conv_backward(x, Cin, dy, weight, bias, kind="conv", stride=1, pad=None, need_dx=True, dx=None, dx_accumulate=0, mul=None,
-                  mul_mode=0, xs=None, dys=None, split_dx=False):
+                  mul_mode=0, xs=None, dys=None, split_dx=False, planes_only=False):
     """Gradients of conv_forward: returns dx (optionally fused with an activation-gradient multiply),
     accumulates into weight.grad / bias.grad."""
     k = weight.shape[-1]
@@ -99,7 +100,7 @@ def conv_backward(x, Cin, dy, weight, bias, kind="conv", stride=1, pad=None, nee
     wd = ops.packed(weight, ("conv_dgrad" if kind == "conv" else "convT_dgrad") + sfx)
     if dys is not None and sfx:
         return ops.conv_gemm_presplit(pd, dys, Cout, wd, Cin, y=dx, mul=mul, mul_mode=mul_mode, accumulate=dx_accumulate,
-                                      split_out=split_dx)
+                                      split_out=split_dx, planes_only=planes_only)
     g = ops.conv_gemm(pd, dy, Cout, wd, Cin, y=dx, mul=mul, mul_mode=mul_mode, accumulate=dx_accumulate)
     return (g, ops.split_bf16(g)) if split_dx else g
 
@@ -275,10 +276,14 @@ class ConvNextBlockFn(torch.autograd.Function):
         # operands that feed several GEMMs (fwd now, dgrad/wgrad later, every N tile) are split into bf16 hi/lo ONCE, by
         # the kernel that produces them (LayerNorm, the GELU epilogue of conv1, the GELU' epilogue of conv2's dgrad)
         sp1, sp2 = want_presplit(dim, mid, 3), want_presplit(mid, dim_out, 3)
+        # When every consumer of a tensor reads its bf16 planes (fwd / dgrad GEMMs always, the wgrad GEMM from 2048
+        # pixels up), its fp32 copy is not written at all: LN output, GELU output, conv2's data gradient.
+        lean = _LEAN and B * H * W >= 2048
         hn_s = None
         if m.has_norm:
             if sp1:
-                hn, mean, rstd, hn_s = ops.layernorm_fwd(h, m.net[0].g, m.net[0].b, m.net[0].eps, grad_on, split_out=True)
+                hn, mean, rstd, hn_s = ops.layernorm_fwd(h, m.net[0].g, m.net[0].b, m.net[0].eps, grad_on, split_out=True,
+                                                         planes_only=lean)
             else:
                 hn, mean, rstd = ops.layernorm_fwd(h, m.net[0].g, m.net[0].b, m.net[0].eps, grad_on)
         else:
@@ -286,7 +291,7 @@ class ConvNextBlockFn(torch.autograd.Function):
             hn_s = ops.split_bf16(hn) if sp1 else None
         pre = ops.new_feat(x, B, H, W, mid) if grad_on else None
         if sp2:
-            a, a_s = conv_forward(hn, dim, c1.weight, c1.bias, act=ACT_GELU, pre=pre, xs=hn_s, split_out=True)
+            a, a_s = conv_forward(hn, dim, c1.weight, c1.bias, act=ACT_GELU, pre=pre, xs=hn_s, split_out=True, planes_only=lean)
         else:
             a, a_s = conv_forward(hn, dim, c1.weight, c1.bias, act=ACT_GELU, pre=pre, xs=hn_s), None
         if m.has_res_conv:
@@ -320,7 +325,9 @@ class ConvNextBlockFn(torch.autograd.Function):
         # conv2 -> (fused GELU') -> conv1
         do_s = ops.split_bf16(do) if a_s is not None else None
         if hn_s is not None:
-            dpre, dpre_s = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=1, xs=a_s, dys=do_s, split_dx=True)
+            lean = _LEAN and a_s is not None and a.shape[0] * a.shape[1] * a.shape[2] >= 2048
+            dpre, dpre_s = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=1, xs=a_s, dys=do_s, split_dx=True,
+                                         planes_only=lean)
         else:
             dpre, dpre_s = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=1, xs=a_s, dys=do_s), None
         dhn = conv_backward(hn, dim, dpre, c1.weight, c1.bias, xs=hn_s, dys=dpre_s)

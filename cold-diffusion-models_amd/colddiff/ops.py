@@ -24,6 +24,13 @@ def ld_of(t):
     return t.stride(-2) if t.shape[-2] > 1 else t.shape[-1]
 
 
+def shape_only(B, H, W, C):
+    """A [B,H,W,r4(C)] tensor WITHOUT storage (meta device): stands for a feature map whose fp32 copy is not
+    materialised because every consumer reads its bf16 hi/lo planes.  Its data_ptr() is 0, so any kernel handed
+    it as data fails its null check instead of reading garbage."""
+    return torch.empty((B, H, W, r4(C)), device="meta", dtype=torch.float32)
+
+
 def new_feat(ref, B, H, W, C, zero=False):
     f = torch.zeros if (zero or C % 4) else torch.empty
     return f((B, H, W, r4(C)), device=ref.device, dtype=torch.float32)
@@ -133,22 +140,24 @@ def split_bf16(x):
     return hi, lo
 
 
-def split_planes_like(y, C):
-    """Empty (hi, lo) bf16 planes for a [.., C] feature map (pitch roundup8(C), padding zeroed)."""
+def split_planes_like(ref, B, H, W, C):
+    """Empty (hi, lo) bf16 planes for a [B,H,W,C] feature map (pitch roundup8(C), padding zeroed) on ref's device."""
     ld = (C + 7) // 8 * 8
     f = torch.zeros if ld != C else torch.empty
-    return (f(y.shape[:-1] + (ld,), device=y.device, dtype=torch.int16), f(y.shape[:-1] + (ld,), device=y.device, dtype=torch.int16))
+    return (f((B, H, W, ld), device=ref.device, dtype=torch.int16), f((B, H, W, ld), device=ref.device, dtype=torch.int16))
 
 
 def conv_gemm_presplit(plan, xs, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None, pre=None, mul=None, act=0, mul_mode=0,
-                       accumulate=0, split_out=False):
+                       accumulate=0, split_out=False, planes_only=False):
     """conv_gemm with the activation already split into bf16 hi/lo planes (xs) and (hi, lo) packed weights (wp).
-    split_out: also return the output's own (hi, lo) planes, written by the same epilogue (fused cdf_split_bf16)."""
+    split_out: also return the output's own (hi, lo) planes, written by the same epilogue (fused cdf_split_bf16).
+    planes_only (with split_out): do not materialise the fp32 output at all (a shape_only stand-in is returned)."""
     hi, lo = xs
     B = hi.shape[0]
+    planes_only = planes_only and split_out and Cout % 4 == 0 and y is None and not accumulate
+    ys = split_planes_like(hi, B, plan.OH, plan.OW, Cout) if (split_out and Cout % 4 == 0) else None
     if y is None:
-        y = new_feat(hi, B, plan.OH, plan.OW, Cout)
-    ys = split_planes_like(y, Cout) if (split_out and Cout % 4 == 0) else None
+        y = shape_only(B, plan.OH, plan.OW, Cout) if planes_only else new_feat(hi, B, plan.OH, plan.OW, Cout)
     ldv = lambda t: 0 if t is None else ld_of(t)
     rt.lib().cdf_conv_gemm_bf16x(P(hi), P(lo), hi.shape[-1], P(zero_page(hi.device)), P(wp[0]), P(wp[1]), wp[0].shape[-1], P(y), ld_of(y),
                                  B, plan.H, plan.W, Cin, plan.OH, plan.OW, Cout, plan.QH, plan.QW, plan.os, plan.istride, plan.nphase,
@@ -201,13 +210,15 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None, xa_s=No
     M = B * wplan.QH * wplan.QW
     ldo = r4(CB)
     if xa_s is not None and xb_s is not None and CA >= 64 and CB >= 64 and M >= 2048:
-        # both operands already split into bf16 hi/lo planes: copy + MFMA only (64-wide tiles for 64-channel sides)
+        # both operands already split into bf16 hi/lo planes: copy + MFMA only (64-wide tiles for 64-channel sides);
+        # xa / xb themselves may be shape-only stand-ins here
+        dev = xa_s[0].device
         tiles = (1 if CA <= 64 else (CA + 127) // 128) * (1 if CB <= 64 else (CB + 127) // 128) * wplan.ntaps
         ns = best_nsplit(tiles, 512, M // 512)
-        ws = torch.empty((ns, wplan.ntaps, CA, ldo), device=xa.device, dtype=torch.float32)
-        S = rt.stream(xa)
-        bsum = torch.empty((ns, ldo), device=xa.device, dtype=torch.float32) if gbias is not None else None
-        L.cdf_conv_wgrad_bf16x(P(xa_s[0]), P(xa_s[1]), xa_s[0].shape[-1], P(xb_s[0]), P(xb_s[1]), xb_s[0].shape[-1], P(zero_page(xa.device)),
+        ws = torch.empty((ns, wplan.ntaps, CA, ldo), device=dev, dtype=torch.float32)
+        S = rt.stream(xa_s[0])
+        bsum = torch.empty((ns, ldo), device=dev, dtype=torch.float32) if gbias is not None else None
+        L.cdf_conv_wgrad_bf16x(P(xa_s[0]), P(xa_s[1]), xa_s[0].shape[-1], P(xb_s[0]), P(xb_s[1]), xb_s[0].shape[-1], P(zero_page(dev)),
                                P(ws), ldo, B, wplan.QH, wplan.QW, wplan.HA, wplan.WA, wplan.sa, wplan.HB, wplan.WB, wplan.sb, CA, CB,
                                wplan.ntaps, wplan.desc, ns, P(bsum), S)
         L.cdf_unpack_reduce(P(ws), P(gparam), ns, wplan.ntaps, CA, CB, ldo, s_t, s_r, s_c, 1, S)
@@ -267,14 +278,16 @@ def add_into(dst, src):
 # ---------------------------------------------------------------------------------------------------
 # norms / depthwise / attention primitives
 # ---------------------------------------------------------------------------------------------------
-def layernorm_fwd(x, g, b, eps, save, split_out=False):
-    """split_out: also return the output's bf16 (hi, lo) planes for the conv that consumes it (fused cdf_split_bf16)."""
+def layernorm_fwd(x, g, b, eps, save, split_out=False, planes_only=False):
+    """split_out: also return the output's bf16 (hi, lo) planes for the conv that consumes it (fused cdf_split_bf16);
+    planes_only: do not materialise the fp32 output (a shape_only stand-in is returned)."""
     B, H, W, C = x.shape
     M = B * H * W
-    y = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+    planes_only = planes_only and split_out
+    y = shape_only(B, H, W, C) if planes_only else torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
     mean = torch.empty((M,), device=x.device, dtype=torch.float32) if save else None
     rstd = torch.empty((M,), device=x.device, dtype=torch.float32) if save else None
-    ys = split_planes_like(y, C) if split_out else None
+    ys = split_planes_like(x, B, H, W, C) if split_out else None
     rt.lib().cdf_layernorm_c_fwd(P(x), ld_of(x), P(y), C, P(g), P(b), P(mean), P(rstd), M, C, eps, P(ys[0]) if ys else 0,
                                  P(ys[1]) if ys else 0, ys[0].shape[-1] if ys else 0, rt.stream(x))
     if split_out:

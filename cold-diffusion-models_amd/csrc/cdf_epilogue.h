@@ -94,13 +94,15 @@ __device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += u[e];
         }
-        float* dst = Y + opix * a.ldy + co;
-        if (a.accumulate) {
-            cdf_ld4(u, dst, nval, vec);
+        if (Y) {                                             // (null: only the split planes below are wanted)
+            float* dst = Y + opix * a.ldy + co;
+            if (a.accumulate) {
+                cdf_ld4(u, dst, nval, vec);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += u[e];
+                for (int e = 0; e < 4; ++e) v[e] += u[e];
+            }
+            cdf_st4(dst, v, nval, vec);
         }
-        cdf_st4(dst, v, nval, vec);
         if (a.ys_hi && vec)                                  // the consumer GEMMs' bf16 hi / lo planes of the same values
             cdf_split_store4(a.ys_hi + opix * a.ld_ys + co, a.ys_lo + opix * a.ld_ys + co, v);
     }

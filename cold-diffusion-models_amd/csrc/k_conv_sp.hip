@@ -1126,12 +1126,12 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
                                    int os, int is, int nphase, const int* phase_desc, const float* bias, const float* sbias,
                                    int ld_sbias, const float* res, int ldr, float* pre, int ldp, const float* mul, int ldm, int act,
                                    int mul_mode, int accumulate, void* y_hi, void* y_lo, int ld_ys, void* stream) {
-    CDF_REQUIRE(x_hi && x_lo && zero && w_hi && w_lo && y, "cdf_conv_gemm_bf16x: null pointer");
+    CDF_REQUIRE(x_hi && x_lo && zero && w_hi && w_lo && (y || (y_hi && !accumulate)), "cdf_conv_gemm_bf16x: null pointer");
     CDF_REQUIRE((!y_hi && !y_lo) || (y_hi && y_lo && ld_ys % 4 == 0 && ld_ys >= Cout && Cout % 4 == 0 && ((((uintptr_t)y_hi) | ((uintptr_t)y_lo)) & 7) == 0),
                 "cdf_conv_gemm_bf16x: split output planes need Cout %% 4 == 0, ld_ys %% 4 == 0, 8-byte alignment");
     CDF_REQUIRE(((((uintptr_t)x_hi) | ((uintptr_t)x_lo) | ((uintptr_t)zero) | ((uintptr_t)w_hi) | ((uintptr_t)w_lo)) & 15) == 0, "cdf_conv_gemm_bf16x: operands must be 16B aligned");
     CDF_REQUIRE(ldx % 8 == 0 && Cin % 8 == 0 && ldx >= Cin && ldk % 32 == 0 && ldk >= Cin, "cdf_conv_gemm_bf16x: Cin and pitches must be multiples of 8 (ldk of 32)");
-    CDF_REQUIRE(nphase >= 1 && nphase <= 4 && phase_desc && ldy >= Cout, "cdf_conv_gemm_bf16x: bad geometry");
+    CDF_REQUIRE(nphase >= 1 && nphase <= 4 && phase_desc && (!y || ldy >= Cout), "cdf_conv_gemm_bf16x: bad geometry");
     CDF_REQUIRE(!mul_mode || mul, "cdf_conv_gemm_bf16x: mul_mode without mul tensor");
     SpxArgs a;
     a.x_hi = (const unsigned short*)x_hi; a.x_lo = (const unsigned short*)x_lo; a.zero = (const unsigned short*)zero;

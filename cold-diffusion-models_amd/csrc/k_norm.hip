@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) layernorm_c_fwd_kernel(const float* x, in
                         o.y = (v[u][j].y - mean) / sd * gg[j].y + bb[j].y;
                         o.z = (v[u][j].z - mean) / sd * gg[j].z + bb[j].z;
                         o.w = (v[u][j].w - mean) / sd * gg[j].w + bb[j].w;
-                        *(float4*)(y + m * ldy + c) = o;
+                        if (y) *(float4*)(y + m * ldy + c) = o;
                         if (ys_hi) {                         // operand split of the following conv fused in
                             const float ov[4] = {o.x, o.y, o.z, o.w};
                             cdf_split_store4(ys_hi + m * ld_ys + c, ys_lo + m * ld_ys + c, ov);
@@ -400,8 +400,8 @@ extern "C" int cdf_layernorm_c_fwd(const float* x, int ldx, float* y, int ldy, c
                                    void* stream) {
     CDF_REQUIRE((!y_hi && !y_lo) || (y_hi && y_lo && ld_ys % 4 == 0 && ld_ys >= C && ((((uintptr_t)y_hi) | ((uintptr_t)y_lo)) & 7) == 0),
                 "cdf_layernorm_c_fwd: split output planes need ld_ys %% 4 == 0, ld_ys >= C, 8-byte alignment");
-    CDF_REQUIRE(x && y && g && b && M > 0, "cdf_layernorm_c_fwd: null / empty");
-    CDF_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && C <= 1024, "cdf_layernorm_c_fwd: C=%d must be a multiple of 4 and <= 1024", C);
+    CDF_REQUIRE(x && (y || y_hi) && g && b && M > 0, "cdf_layernorm_c_fwd: null / empty");
+    CDF_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && (!y || ldy % 4 == 0) && C <= 1024, "cdf_layernorm_c_fwd: C=%d must be a multiple of 4 and <= 1024", C);
     int LP, NV;
     CDF_REQUIRE(ln_geometry(C, &LP, &NV) == CDF_OK, "cdf_layernorm_c_fwd: unsupported C=%d", C);
     const int nb = cdf_layernorm_blocks(M, C);

@@ -149,7 +149,8 @@ int cdf_conv_wgrad_bf16(const float* xa, int lda, const float* xb, int ldb, floa
  * taps load from it).  Channel counts and pitches must be multiples of 8. */
 int cdf_split_bf16(const float* x, int ldx, void* hi, void* lo, int ldo, long long rows, int C, void* stream);
 /* cdf_conv_gemm_bf16x: y_hi / y_lo (nullable, pitch ld_ys) additionally receive the stored output split into bf16 hi / lo planes,
- * i.e. cdf_split_bf16 fused into the producer (needs Cout % 4 == 0 and the aligned / pitched layout of the vector epilogue). */
+ * i.e. cdf_split_bf16 fused into the producer (needs Cout % 4 == 0 and the aligned / pitched layout of the vector epilogue).
+ * With the planes given, y itself may be NULL (no fp32 copy is written; not with accumulate).  Same for cdf_layernorm_c_fwd. */
 int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo, int ldk,
                         float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW, int os, int is,
                         int nphase, const int* phase_desc, const float* bias, const float* sbias, int ld_sbias, const float* res,
