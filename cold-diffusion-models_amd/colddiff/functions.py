@@ -429,8 +429,12 @@ class ResnetBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, x, tbias, m):
         cin, cout = m.in_channels, m.out_channels
+        # the 3x3 convs' operands are split into bf16 hi/lo planes once (forward, data gradient and weight gradient read them)
+        sp1 = _AUTO_PRESPLIT and want_presplit(cin, cout, 3)
+        sp2 = _AUTO_PRESPLIT and want_presplit(cout, cout, 3)
         h1, mean1, rstd1 = ops.groupnorm_fwd(x, m.norm1.weight, m.norm1.bias, GN_GROUPS, GN_EPS, True)
-        h2 = conv_forward(h1, cin, m.conv1.weight, m.conv1.bias, sbias=tbias)
+        h1_s = ops.split_bf16(h1) if sp1 else None
+        h2 = conv_forward(h1, cin, m.conv1.weight, m.conv1.bias, sbias=tbias, xs=h1_s)
         h3, mean2, rstd2 = ops.groupnorm_fwd(h2, m.norm2.weight, m.norm2.bias, GN_GROUPS, GN_EPS, True)
         p = m.dropout.p if m.training else 0.0
         seed = 0
@@ -442,29 +446,33 @@ class ResnetBlockFn(torch.autograd.Function):
             sc = conv_forward(x, cin, sc_mod.weight, sc_mod.bias)
         else:
             sc = x
-        o = conv_forward(h3, cout, m.conv2.weight, m.conv2.bias, res=sc)
+        h3_s = ops.split_bf16(h3) if sp2 else None
+        o = conv_forward(h3, cout, m.conv2.weight, m.conv2.bias, res=sc, xs=h3_s)
         ctx.m, ctx.drop = m, (p, seed)
-        ctx.save_for_backward(x, h1, h2, h3, mean1, rstd1, mean2, rstd2)
+        ctx.split = (sp1, sp2)
+        ctx.save_for_backward(x, h1, h2, h3, mean1, rstd1, mean2, rstd2, *(h1_s or (None, None)), *(h3_s or (None, None)))
         return o
 
     @staticmethod
     def backward(ctx, do):
-        x, h1, h2, h3, mean1, rstd1, mean2, rstd2 = ctx.saved_tensors
+        x, h1, h2, h3, mean1, rstd1, mean2, rstd2, h1_hi, h1_lo, h3_hi, h3_lo = ctx.saved_tensors
         m = ctx.m
         cin, cout = m.in_channels, m.out_channels
         p, seed = ctx.drop
+        h1_s = (h1_hi, h1_lo) if ctx.split[0] else None
+        h3_s = (h3_hi, h3_lo) if ctx.split[1] else None
         sc_mod = None
         if cin != cout:
             sc_mod = m.conv_shortcut if m.use_conv_shortcut else m.nin_shortcut
             dx = conv_backward(x, cin, do, sc_mod.weight, sc_mod.bias)
         else:
             dx = ops.copy_feat(do)
-        dh3 = conv_backward(h3, cout, do, m.conv2.weight, m.conv2.bias)
+        dh3 = conv_backward(h3, cout, do, m.conv2.weight, m.conv2.bias, xs=h3_s, dys=ops.split_bf16(do) if h3_s is not None else None)
         if p > 0:
             dh3 = ops.dropout(dh3, p, seed)
         dh2 = ops.groupnorm_bwd(dh3, h2, m.norm2.weight, m.norm2.bias, mean2, rstd2, GN_GROUPS, True)
         dtb = ops.colsum_new(dh2, cout, dh2.shape[0])
-        dh1 = conv_backward(h1, cin, dh2, m.conv1.weight, m.conv1.bias)
+        dh1 = conv_backward(h1, cin, dh2, m.conv1.weight, m.conv1.bias, xs=h1_s, dys=ops.split_bf16(dh2) if h1_s is not None else None)
         ops.groupnorm_bwd(dh1, x, m.norm1.weight, m.norm1.bias, mean1, rstd1, GN_GROUPS, True, dx=dx)
         _done(m.norm1, m.conv1, m.norm2, m.conv2, sc_mod)
         return None, dx, dtb, None

@@ -284,3 +284,31 @@ def test_resampling_conv_presplit(mbe, kind):
     assert (xd.grad.cpu() - xr.grad).abs().max().item() <= tol * xr.grad.abs().max().item()
     for (n, p_), (_, r) in zip(mod.named_parameters(), ref.named_parameters()):
         assert (p_.grad.cpu() - r.grad).abs().max().item() <= tol * max(r.grad.abs().max().item(), 1e-3), n
+
+
+def test_resnet_block_presplit_operands(mbe):
+    """CIFAR `Model` ResnetBlock (MODEL2:114-133) with its 3x3 convs on pre-split bf16 planes: forward and every
+    gradient against the oracle at the fp32 parity bound."""
+    from colddiff.model2 import ResnetBlock
+    from colddiff import functions as F_
+    from oracle import cold_oracle as O
+    assert F_.want_presplit(64, 128, 3) and F_.want_presplit(128, 128, 3)
+    torch.manual_seed(7)
+    blk = ResnetBlock(in_channels=64, out_channels=128, dropout=0.0, temb_channels=32)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    blk = blk.to(mbe.device)
+    x, temb, g = torch.randn(8, 64, 16, 16), torch.randn(8, 32), torch.randn(8, 128, 16, 16)
+    xr = x.clone().requires_grad_(True)
+    yr = O.resnet_block(sd, xr, temb)
+    yr.backward(g)
+    xd = mbe.to(x).requires_grad_(True)
+    xn = F_.ToNHWC.apply(xd)
+    sw = mbe.to(temb * torch.sigmoid(temb))
+    y = F_.ToNCHW.apply(blk(xn, sw), 128, None)
+    y.backward(mbe.to(g))
+    tol = 1e-4
+    assert (y.detach().cpu() - yr.detach()).abs().max().item() <= tol * yr.abs().max().item()
+    assert (xd.grad.cpu() - xr.grad).abs().max().item() <= tol * xr.grad.abs().max().item()
+    for n, p_ in blk.named_parameters():
+        r = sd[n].grad
+        assert (p_.grad.cpu() - r).abs().max().item() <= tol * max(r.abs().max().item(), 1e-3), n
