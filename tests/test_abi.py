@@ -34,3 +34,34 @@ def test_bad_arguments_return_status_not_abort():
     except _lib.CdfError as e:
         assert "null pointer" in str(e)
     assert lib._dll.cdf_blur_chain(0, 0, 0, 0, 0, 0, 1, 1, 8, 8, 4, 0, 0, 0, -1, 0, 0) == -1      # CDF_E_INVALID
+
+
+def test_hot_kernels_use_no_scratch():
+    """hipcc silently parks arrays of HIP vector structs and over-hoisted loads in scratch memory (each cost 1.3-2x
+    when it happened); the hot kernels must compile to zero scratch.  Needs hipcc (cross-compiles without a GPU)."""
+    import shutil
+    import pytest
+    hipcc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
+    if not shutil.which(hipcc):
+        pytest.skip("hipcc not available")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(repo, "cold-diffusion-models_amd", "csrc")
+    hot = {"k_conv_sp.hip": ("conv_igemm_spx_kernel", "conv_wgrad_spx_kernel", "conv_igemm_sp_kernel", "conv_wgrad_sp_kernel", "split_bf16_kernel"),
+           "k_conv.hip": ("conv_igemm_kernel", "unpack_reduce_kernel"),
+           "k_dwconv.hip": ("dwconv7_kernel", "dwconv7_wgrad_partial_kernel"),
+           "k_norm.hip": ("layernorm_c_fwd_kernel", "layernorm_c_bwd_kernel")}
+    for src, names in hot.items():
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", csrc, "-I", os.path.join(repo, "include"),
+                            "-c", os.path.join(csrc, src), "-o", os.devnull, "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        cur, seen = None, set()
+        for line in r.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                cur = m.group(1)
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+            if m and cur and any(n in cur for n in names):
+                seen.add(cur)
+                assert int(m.group(1)) == 0, (cur, line)
+        assert seen, "no resource-usage remarks parsed for " + src
