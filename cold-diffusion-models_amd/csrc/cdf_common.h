@@ -105,8 +105,13 @@ __device__ __forceinline__ float cdf_group_sum(float v, int width) {
 // as 0.5 x (1 + erf(x / sqrt 2)) like the reference (DEBLUR:133-135 -> F.gelu); the absolute error is <= 0.75e-7 |x|.
 __device__ __forceinline__ float cdf_erf_fast(float z, float& ez2) {
     const float az = fabsf(z);
+#ifdef CDF_EMU
     const float t = 1.0f / fmaf(0.3275911f, az, 1.0f);
     ez2 = expf(-az * az);
+#else
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));     // 1 ulp; the formula itself is 1.5e-7
+    ez2 = __expf(-az * az);                                                 // v_exp_f32 path, ~2 ulp
+#endif
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
