@@ -24,7 +24,17 @@ __global__ void linattn_kmax_kernel(const float* qkv, int ld, float* part, int n
     if (r1 > n) r1 = n;
     const float* kp = qkv + (long long)b * n * ld + HD + c;
     float m = -3.0e38f;
-    for (int r = r0 + rl; r < r1; r += 4) m = fmaxf(m, kp[(long long)r * ld]);
+    {
+        // 8 rows in flight per lane (one load per loop trip is a chain of memory round trips)
+        float t[8];
+        int r = r0 + rl;
+        for (; r + 28 < r1; r += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = kp[(long long)(r + 4 * u) * ld];
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])), fmaxf(fmaxf(t[4], t[5]), fmaxf(t[6], t[7]))));
+        }
+        for (; r < r1; r += 4) m = fmaxf(m, kp[(long long)r * ld]);
+    }
     red[rl][l] = m;
     __syncthreads();
     if (rl == 0) part[((long long)b * gridDim.y + blockIdx.y) * HD + c] = fmaxf(fmaxf(red[0][l], red[1][l]), fmaxf(red[2][l], red[3][l]));
@@ -46,6 +56,7 @@ __global__ void __launch_bounds__(256) linattn_ctx_kernel(const float* a_ptr, in
     if (EXPA) {
         if (threadIdx.x < LA_D) {
             float m = -3.0e38f;
+#pragma unroll 8
             for (int k = 0; k < nchunk_max; ++k) m = fmaxf(m, kmax_part[((long long)b * nchunk_max + k) * HD + h * LA_D + threadIdx.x]);
             smax[threadIdx.x] = m;
         }
@@ -61,17 +72,23 @@ __global__ void __launch_bounds__(256) linattn_ctx_kernel(const float* a_ptr, in
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float psum = 0.f;
-    // each wave takes row pairs r0 + 2*(wave + 4*j)
-    for (int r = r0 + 2 * wave; r < r1; r += 8) {
-        const int row = r + hh;
-        float av = 0.f, bv = 0.f;
-        if (row < r1) {
-            av = A[(long long)row * lda];
-            bv = Bp[(long long)row * ldb];
-            if (EXPA) av = expf(av - mx);
+    // each wave takes row pairs r0 + 2*(wave + 4*j); four pairs per trip with all 8 loads in flight, unconditional
+    // (clamped row + select: a load behind a divergent branch waits for everything before it)
+    for (int r = r0 + 2 * wave; r < r1; r += 32) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = r + 8 * u + hh;
+            const int rc = row < r1 ? row : r1 - 1;
+            const float ta = A[(long long)rc * lda], tb = Bp[(long long)rc * ldb];
+            av[u] = row < r1 ? (EXPA ? expf(ta - mx) : ta) : 0.f;
+            bv[u] = row < r1 ? tb : 0.f;
         }
-        psum += av;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            psum += av[u];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        }
     }
     psum += __shfl_xor(psum, 32);
 #pragma unroll
@@ -95,8 +112,10 @@ __global__ void linattn_ctx_final_kernel(const float* ctx_part, const float* sum
     if (threadIdx.x < LA_D) {
         const int c = h * LA_D + threadIdx.x;
         float s = 0.f;
+#pragma unroll 8
         for (int k = 0; k < nsplit; ++k) s += sum_part[((long long)b * nsplit + k) * HD + c];
         float m = -3.0e38f;
+#pragma unroll 8
         for (int k = 0; k < nchunk_max; ++k) m = fmaxf(m, kmax_part[((long long)b * nchunk_max + k) * HD + c]);
         ssum[threadIdx.x] = s;
         ksum[(long long)b * HD + c] = s;
@@ -105,6 +124,7 @@ __global__ void linattn_ctx_final_kernel(const float* ctx_part, const float* sum
     __syncthreads();
     for (int k = threadIdx.x; k < LA_D * LA_D; k += blockDim.x) {
         float s = 0.f;
+#pragma unroll 8
         for (int sp = 0; sp < nsplit; ++sp) s += ctx_part[((((long long)b * nsplit + sp) * heads + h) * LA_D) * LA_D + k];
         const float c = s / ssum[k / LA_D];
         ctx[(((long long)b * heads + h) * LA_D) * LA_D + k] = c;
@@ -120,6 +140,7 @@ __global__ void linattn_dctx_final_kernel(const float* part, int nsplit, const f
     const long long base = (((long long)b * heads + h) * LA_D) * LA_D;
     for (int k = threadIdx.x; k < LA_D * LA_D; k += blockDim.x) {
         float s = 0.f;
+#pragma unroll 8
         for (int sp = 0; sp < nsplit; ++sp) s += part[((((long long)b * nsplit + sp) * heads + h) * LA_D) * LA_D + k];
         s *= scale;
         dctx[base + k] = s;
