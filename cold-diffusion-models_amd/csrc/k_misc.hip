@@ -219,8 +219,22 @@ __global__ void __launch_bounds__(256) linear_small_wgrad_kernel(const float* dy
     if (n >= N) return;
     const int k = blockIdx.x * 64 + lane, kc = k < K ? k : K - 1;
     float acc = 0.f, bs = 0.f;
-    for (int m = 0; m < M; ++m) {
-        const float d = dy[(long long)m * ldd + n];          // wave-uniform
+    int m = 0;
+    for (; m + 8 <= M; m += 8) {                             // 8 row pairs in flight
+        float d[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            d[u] = dy[(long long)(m + u) * ldd + n];         // wave-uniform
+            xv[u] = x[(long long)(m + u) * ldx + kc];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc = fmaf(d[u], xv[u], acc);
+            bs += d[u];
+        }
+    }
+    for (; m < M; ++m) {
+        const float d = dy[(long long)m * ldd + n];
         acc = fmaf(d, x[(long long)m * ldx + kc], acc);
         bs += d;
     }

@@ -233,7 +233,18 @@ __global__ void groupnorm_partial_kernel(const float* x, int ldx, const float* d
     if (c < C) {
         const float* xp = x + (long long)b * HW * ldx + c;
         if (mode == 0) {
-            for (int r = r0 + rl; r < r1; r += 4) {
+            int r = r0 + rl;
+            for (; r + 12 < r1; r += 16) {                   // 4 rows in flight per lane
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = xp[(long long)(r + 4 * u) * ldx];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    p0 += v[u];
+                    p1 += v[u] * v[u];
+                }
+            }
+            for (; r < r1; r += 4) {
                 const float v = xp[(long long)r * ldx];
                 p0 += v;
                 p1 += v * v;
@@ -242,7 +253,24 @@ __global__ void groupnorm_partial_kernel(const float* x, int ldx, const float* d
             const int gi = c / (C / groups);
             const float mu = mean[b * groups + gi], rs = rstd[b * groups + gi], ga = gamma[c], be = beta[c];
             const float* dp = dy + (long long)b * HW * lddy + c;
-            for (int r = r0 + rl; r < r1; r += 4) {
+            int r = r0 + rl;
+            for (; r + 12 < r1; r += 16) {                   // 4 row pairs in flight per lane
+                float xv[4], dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    xv[u] = xp[(long long)(r + 4 * u) * ldx];
+                    dv[u] = dp[(long long)(r + 4 * u) * lddy];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float xh = (xv[u] - mu) * rs;
+                    float dz = dv[u];
+                    if (silu) dz *= cdf_silu_grad(xh * ga + be);
+                    p0 += dz;
+                    p1 += dz * xh;
+                }
+            }
+            for (; r < r1; r += 4) {
                 const float xh = (xp[(long long)r * ldx] - mu) * rs;
                 float dz = dp[(long long)r * lddy];
                 if (silu) dz *= cdf_silu_grad(xh * ga + be);
