@@ -62,6 +62,7 @@ def want_presplit(Cin, Cout, k):
 
 _LEAN = os.environ.get("CDF_LEAN", "1") != "0"    # skip fp32 copies of tensors only ever consumed as bf16 planes
 _LINEAR_SMALL_M = 256      # batch sizes up to this use the skinny-linear kernels
+_PRESPLIT_1X1 = os.environ.get("CDF_PRESPLIT_1X1", "0") != "0"
 _AUTO_PRESPLIT = os.environ.get("CDF_AUTO_PRESPLIT", "1") != "0"
 _SP_KMIN = int(os.environ.get("CDF_SP_KMIN", "128"))     # tuning knob: smallest K routed to the bf16 matrix cores
 
@@ -241,7 +242,7 @@ class ConvFn(torch.autograd.Function):
         Cout = mod.weight.shape[0] if kind == "conv" else mod.weight.shape[1]
         # 4x4 stride-2 down / transposed up-sampling convs: every input pixel feeds several taps and N tiles, and the
         # same planes serve the weight gradient -> split once, use the LDS-DMA kernels (1x1 convs read x once: not worth it)
-        xs = ops.split_bf16(x) if (_AUTO_PRESPLIT and k > 1 and want_presplit(Cin, Cout, k)) else None
+        xs = ops.split_bf16(x) if (_AUTO_PRESPLIT and (k > 1 or _PRESPLIT_1X1) and want_presplit(Cin, Cout, k)) else None
         y = conv_forward(x, Cin, mod.weight, mod.bias, kind, stride, pad, xs=xs)
         ctx.mod, ctx.cfg = mod, (Cin, kind, stride, pad)
         ctx.has_xs = xs is not None
@@ -409,7 +410,9 @@ class UpsampleConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, x, conv):
         up = ops.upsample2(x)
-        y = conv_forward(up, x.shape[-1], conv.weight, conv.bias)
+        C = x.shape[-1]
+        ctx.sp = _AUTO_PRESPLIT and want_presplit(C, conv.weight.shape[0], 3)
+        y = conv_forward(up, C, conv.weight, conv.bias, xs=ops.split_bf16(up) if ctx.sp else None)
         ctx.conv = conv
         ctx.save_for_backward(x)
         return y
@@ -418,7 +421,8 @@ class UpsampleConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         up = ops.upsample2(x)
-        dup = conv_backward(up, x.shape[-1], dy, ctx.conv.weight, ctx.conv.bias)
+        ups, dys = (ops.split_bf16(up), ops.split_bf16(dy)) if ctx.sp else (None, None)
+        dup = conv_backward(up, x.shape[-1], dy, ctx.conv.weight, ctx.conv.bias, xs=ups, dys=dys)
         _done(ctx.conv)
         return None, ops.upsample2_bwd(dup), None
 

@@ -312,40 +312,53 @@ __global__ void groupnorm_stats_kernel(const float* part, int nchunk, int C, int
     }
 }
 
-// backward finalize: per (b, c) sums A = sum dz, Bc = sum dz*xhat (chunk-reduced into ab[B][2][C]);
-// per (b, group): s1 = sum_c gamma*A / n, s2 = sum_c gamma*Bc / n ; dgamma[c] (+)= sum_b Bc, dbeta (+)= sum_b A
-__global__ void groupnorm_bwd_finalize_kernel(const float* part, int nchunk, int B, int C, int groups, int HW,
-                                              const float* gamma, float* s12 /*[B][groups][2]*/, float* dgamma,
-                                              float* dbeta, float* ab, int accumulate) {
-    // phase 1: chunk reduce -> ab   (grid-stride over B*2*C)
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;  // single block launch
-    for (int i = tid; i < B * 2 * C; i += blockDim.x * gridDim.x) {
-        const int b = i / (2 * C), j = i - b * 2 * C;
-        float s = 0.f;
-        for (int k = 0; k < nchunk; ++k) s += part[(((long long)b * nchunk + k) * 2) * C + j];
-        ab[i] = s;
+// backward finalize, three small multi-block kernels (one 1024-thread block doing all of it serially took ~95 us):
+//  (1) ab[b][2][C] = sum_chunk part           (A = sum dz, Bc = sum dz*xhat per sample and channel)
+//  (2) per (b, group): s1 = sum_c gamma*A / n, s2 = sum_c gamma*Bc / n
+//  (3) dgamma[c] (+)= sum_b Bc, dbeta[c] (+)= sum_b A      (16 batch lanes x 64 channels per block)
+__global__ void groupnorm_bwd_reduce_kernel(const float* part, int nchunk, int B, int C, float* ab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 2 * C) return;
+    const int b = i / (2 * C), j = i - b * 2 * C;
+    float s = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < nchunk; ++k) s += part[(((long long)b * nchunk + k) * 2) * C + j];
+    ab[i] = s;
+}
+__global__ void groupnorm_bwd_group_kernel(const float* ab, int B, int C, int groups, int HW, const float* gamma, float* s12) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * groups) return;
+    const int cg = C / groups, b = i / groups, gi = i - b * groups;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = gi * cg; c < (gi + 1) * cg; ++c) {
+        s1 += gamma[c] * ab[(long long)b * 2 * C + c];
+        s2 += gamma[c] * ab[(long long)b * 2 * C + C + c];
     }
-    __syncthreads();
-    const int cg = C / groups;
-    for (int i = tid; i < B * groups; i += blockDim.x * gridDim.x) {
-        const int b = i / groups, gi = i - b * groups;
-        float s1 = 0.f, s2 = 0.f;
-        for (int c = gi * cg; c < (gi + 1) * cg; ++c) {
-            s1 += gamma[c] * ab[(long long)b * 2 * C + c];
-            s2 += gamma[c] * ab[(long long)b * 2 * C + C + c];
-        }
-        const float n = (float)HW * (float)cg;
-        s12[2 * i] = s1 / n;
-        s12[2 * i + 1] = s2 / n;
-    }
-    for (int c = tid; c < C; c += blockDim.x * gridDim.x) {
-        float a = 0.f, bc = 0.f;
-        for (int b = 0; b < B; ++b) {
+    const float n = (float)HW * (float)cg;
+    s12[2 * i] = s1 / n;
+    s12[2 * i + 1] = s2 / n;
+}
+__global__ void __launch_bounds__(1024) groupnorm_bwd_param_kernel(const float* ab, int B, int C, float* dgamma, float* dbeta, int accumulate) {
+    __shared__ float red[2][16][64];
+    const int l = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + l;
+    float a = 0.f, bc = 0.f;
+    if (c < C)
+        for (int b = rl; b < B; b += 16) {
             a += ab[(long long)b * 2 * C + c];
             bc += ab[(long long)b * 2 * C + C + c];
         }
-        dgamma[c] = accumulate ? dgamma[c] + bc : bc;
-        dbeta[c] = accumulate ? dbeta[c] + a : a;
+    red[0][rl][l] = a;
+    red[1][rl][l] = bc;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            ta += red[0][r][l];
+            tb += red[1][r][l];
+        }
+        dgamma[c] = accumulate ? dgamma[c] + tb : tb;
+        dbeta[c] = accumulate ? dbeta[c] + ta : ta;
     }
 }
 
@@ -515,8 +528,9 @@ extern "C" int cdf_groupnorm_bwd(const float* dy, int lddy, const float* x, int 
     float* s12 = ab + (size_t)B * 2 * C;
     CDF_LAUNCH(groupnorm_partial_kernel, dim3(cdf_cdiv(C, 64), nchunk, B), dim3(256), 0, CDF_S, x, ldx, dy, lddy, gamma, beta, mean, rstd,
                part, HW, rpc, C, groups, 1, silu);
-    CDF_LAUNCH(groupnorm_bwd_finalize_kernel, dim3(1), dim3(1024), 0, CDF_S, (const float*)part, nchunk, B, C, groups, HW, gamma, s12,
-               dgamma, dbeta, ab, accumulate_param);
+    CDF_LAUNCH(groupnorm_bwd_reduce_kernel, dim3(cdf_cdiv(B * 2 * C, 256)), dim3(256), 0, CDF_S, (const float*)part, nchunk, B, C, ab);
+    CDF_LAUNCH(groupnorm_bwd_group_kernel, dim3(cdf_cdiv(B * groups, 256)), dim3(256), 0, CDF_S, (const float*)ab, B, C, groups, HW, gamma, s12);
+    CDF_LAUNCH(groupnorm_bwd_param_kernel, dim3(cdf_cdiv(C, 64)), dim3(1024), 0, CDF_S, (const float*)ab, B, C, dgamma, dbeta, accumulate_param);
     const long long n = (long long)B * HW * (C / 4);
     int grid = (int)((n + 255) / 256);
     if (grid > 4096) grid = 4096;
