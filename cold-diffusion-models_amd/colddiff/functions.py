@@ -48,6 +48,8 @@ def conv_forward(x, Cin, weight, bias, kind="conv", stride=1, pad=None, xs=None,
     Cout = weight.shape[0] if kind == "conv" else weight.shape[1]
     sfx = _sp_suffix(Cin * k * k, Cout)
     wp = ops.packed(weight, ("conv_fwd" if kind == "conv" else "convT_fwd") + sfx)
+    if xs is None and sfx and _ALWAYS_PRESPLIT and rt.precision == "bf16x3" and Cin % 8 == 0 and x.device.type != "meta":
+        xs = ops.split_bf16(x[..., :Cin] if x.shape[-1] != Cin else x)     # every bf16x3 GEMM goes through the LDS-DMA kernel
     if xs is not None and sfx:
         return ops.conv_gemm_presplit(plan, xs, Cin, wp, Cout, bias=bias, split_out=split_out, planes_only=planes_only, **epi)
     y = ops.conv_gemm(plan, x, Cin, wp, Cout, bias=bias, **epi)
@@ -62,6 +64,7 @@ def want_presplit(Cin, Cout, k):
 
 _LEAN = os.environ.get("CDF_LEAN", "1") != "0"    # skip fp32 copies of tensors only ever consumed as bf16 planes
 _LINEAR_SMALL_M = 256      # batch sizes up to this use the skinny-linear kernels
+_ALWAYS_PRESPLIT = os.environ.get("CDF_ALWAYS_PRESPLIT", "0") != "0"
 _PRESPLIT_1X1 = os.environ.get("CDF_PRESPLIT_1X1", "0") != "0"
 _AUTO_PRESPLIT = os.environ.get("CDF_AUTO_PRESPLIT", "1") != "0"
 _SP_KMIN = int(os.environ.get("CDF_SP_KMIN", "128"))     # tuning knob: smallest K routed to the bf16 matrix cores
@@ -99,6 +102,8 @@ def conv_backward(x, Cin, dy, weight, bias, kind="conv", stride=1, pad=None, nee
         return None
     sfx = _sp_suffix(Cout * KK, Cin)
     wd = ops.packed(weight, ("conv_dgrad" if kind == "conv" else "convT_dgrad") + sfx)
+    if dys is None and sfx and _ALWAYS_PRESPLIT and rt.precision == "bf16x3" and Cout % 8 == 0 and dy.device.type != "meta":
+        dys = ops.split_bf16(dy[..., :Cout] if dy.shape[-1] != Cout else dy)
     if dys is not None and sfx:
         return ops.conv_gemm_presplit(pd, dys, Cout, wd, Cin, y=dx, mul=mul, mul_mode=mul_mode, accumulate=dx_accumulate,
                                       split_out=split_dx, planes_only=planes_only)
