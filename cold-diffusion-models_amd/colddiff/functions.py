@@ -62,6 +62,7 @@ def want_presplit(Cin, Cout, k):
     return rt.precision == "bf16x3" and Cin % 8 == 0 and Cout % 8 == 0 and bool(_sp_suffix(Cin * k * k, Cout)) and bool(_sp_suffix(Cout * k * k, Cin))
 
 
+_CIN4 = os.environ.get("CDF_CIN4", "1") != "0"    # direct kernels for the <= 4-input-channel image-side convs
 _LEAN = os.environ.get("CDF_LEAN", "1") != "0"    # skip fp32 copies of tensors only ever consumed as bf16 planes
 _LINEAR_SMALL_M = 256      # batch sizes up to this use the skinny-linear kernels
 _ALWAYS_PRESPLIT = os.environ.get("CDF_ALWAYS_PRESPLIT", "0") != "0"
@@ -296,11 +297,21 @@ class ConvNextBlockFn(torch.autograd.Function):
             hn, mean, rstd = h, None, None
             hn_s = ops.split_bf16(hn) if sp1 else None
         pre = ops.new_feat(x, B, H, W, mid) if grad_on else None
-        if sp2:
+        # image-side block (dim <= 4 input channels): direct vector-ALU convolutions instead of K <= 36 GEMMs
+        ctx.cin4 = _CIN4 and ops.cin4_ok(hn, dim, c1.weight) and ops.cin4_ok(x, dim, c1.weight)
+        if ctx.cin4:
+            if sp2:
+                a, a_s = ops.conv_cin4_fwd(hn, c1.weight, c1.bias, act=ACT_GELU, pre=pre, split_out=True, planes_only=lean)
+            else:
+                a, a_s = ops.conv_cin4_fwd(hn, c1.weight, c1.bias, act=ACT_GELU, pre=pre), None
+        elif sp2:
             a, a_s = conv_forward(hn, dim, c1.weight, c1.bias, act=ACT_GELU, pre=pre, xs=hn_s, split_out=True, planes_only=lean)
         else:
             a, a_s = conv_forward(hn, dim, c1.weight, c1.bias, act=ACT_GELU, pre=pre, xs=hn_s), None
-        if m.has_res_conv:
+        ctx.res4 = bool(m.has_res_conv and _CIN4 and ops.cin4_ok(x, dim, m.res_conv.weight))
+        if ctx.res4:
+            res = ops.conv_cin4_fwd(x, m.res_conv.weight, m.res_conv.bias)
+        elif m.has_res_conv:
             res = conv_forward(x, dim, m.res_conv.weight, m.res_conv.bias)
         else:
             res = x
@@ -325,7 +336,9 @@ class ConvNextBlockFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[1]
         # residual branch
         dx = None
-        if m.has_res_conv:
+        if ctx.res4:
+            dx = ops.conv_cin4_bwd(x, do, m.res_conv.weight, m.res_conv.bias, need_dx)
+        elif m.has_res_conv:
             dx = conv_backward(x, dim, do, m.res_conv.weight, m.res_conv.bias, need_dx=need_dx)
         # (without a res_conv the residual gradient is `do` itself: added by the depthwise data-gradient kernel below)
         # conv2 -> (fused GELU') -> conv1
@@ -336,7 +349,14 @@ class ConvNextBlockFn(torch.autograd.Function):
                                          planes_only=lean)
         else:
             dpre, dpre_s = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=1, xs=a_s, dys=do_s), None
-        dhn = conv_backward(hn, dim, dpre, c1.weight, c1.bias, xs=hn_s, dys=dpre_s)
+        if ctx.cin4:
+            # weight / bias gradient by the direct kernel (reads dpre once); the data gradient re-reads dpre per tap from
+            # L2 either way and is faster on the MFMA gather-GEMM (229 vs 363 us)
+            ops.conv_cin4_bwd(hn, dpre, c1.weight, c1.bias, False)
+            pd = _conv_plans("conv", hn.shape[1], hn.shape[2], 3, 1, (1, 1, 1, 1))[1]
+            dhn = ops.conv_gemm(pd, dpre, mid, ops.packed(c1.weight, "conv_dgrad"), dim)
+        else:
+            dhn = conv_backward(hn, dim, dpre, c1.weight, c1.bias, xs=hn_s, dys=dpre_s)
         if m.has_norm:
             dh = ops.layernorm_bwd(dhn, h, m.net[0].g, m.net[0].b, mean, rstd)
         else:

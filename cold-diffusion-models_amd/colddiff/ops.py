@@ -87,6 +87,11 @@ def packed(param, kind):
         lo = torch.empty((KK, N, ldk), device=w.device, dtype=torch.int16)
         rt.lib().cdf_pack_weight_bf16(P(w), P(hi), P(lo), KK, N, K, ldk, 1, s_n, s_k, rt.stream(w))
         out = (hi, lo)
+    elif kind == "cin4":
+        # [k*k][4][r4(Cout)] for the direct <= 4-input-channel convolution kernels (rows >= Cin zero)
+        Co, Ci, KH, KW = w.shape
+        out = torch.empty((KH * KW, 4, r4(Co)), device=w.device, dtype=torch.float32)
+        rt.lib().cdf_pack_cin4(P(w), P(out), r4(Co), Co, Ci, KH, rt.stream(w))
     elif kind == "dw":
         C = w.shape[0]
         out = _pack(w, 49, 1, C, 1, 0, 49)
@@ -167,6 +172,50 @@ def conv_gemm_presplit(plan, xs, Cin, wp, Cout, y=None, bias=None, sbias=None, r
     if split_out:
         return y, (ys if ys is not None else split_bf16(y))
     return y
+
+
+def cin4_ok(x, Cin, weight, stride=1):
+    """The direct small-Cin kernels apply: <= 4 input channels held with pitch 4, k in {1, 3}, stride 1, Cout = 4 * 2^j <= 256."""
+    Cout, _, k, k2 = weight.shape
+    lp = Cout // 4
+    return (Cin <= 4 and x.dim() == 4 and x.shape[-1] == 4 and x.is_contiguous() and stride == 1 and k == k2 and k in (1, 3)
+            and Cout % 4 == 0 and 1 <= lp <= 64 and (lp & (lp - 1)) == 0)
+
+
+def conv_cin4_fwd(x, weight, bias, act=0, pre=None, split_out=False, planes_only=False):
+    """y = act(conv(x) + bias) for x [B,H,W,4]; optionally the pre-activation and the bf16 planes of y."""
+    B, H, W, _ = x.shape
+    Cout, _, k, _ = weight.shape
+    planes_only = planes_only and split_out
+    y = shape_only(B, H, W, Cout) if planes_only else torch.empty((B, H, W, Cout), device=x.device, dtype=torch.float32)
+    ys = split_planes_like(x, B, H, W, Cout) if split_out else None
+    wp = packed(weight, "cin4")
+    rt.lib().cdf_conv_cin4_fwd(P(x), P(wp), wp.shape[-1], P(bias), P(y), Cout, P(pre), 0 if pre is None else ld_of(pre),
+                               P(ys[0]) if ys else 0, P(ys[1]) if ys else 0, ys[0].shape[-1] if ys else 0, B, H, W, Cout, k, act, rt.stream(x))
+    return (y, ys) if split_out else y
+
+
+def conv_cin4_bwd(x, dy, weight, bias, need_dx, dx=None, dx_accumulate=0):
+    """Accumulates weight / bias gradients; returns dx [B,H,W,4] if need_dx."""
+    L, S = rt.lib(), rt.stream(x)
+    B, H, W, _ = x.shape
+    Cout, Cin, k, _ = weight.shape
+    KK = k * k
+    nch = L.cdf_conv_cin4_nchunk(B * H * W)
+    part = torch.empty((nch, KK * Cin, Cout), device=x.device, dtype=torch.float32)
+    bsum = torch.empty((nch, Cout), device=x.device, dtype=torch.float32) if bias is not None else None
+    L.cdf_conv_cin4_wgrad(P(x), P(dy), ld_of(dy), P(part), P(bsum), B, H, W, Cin, Cout, k, S)
+    L.cdf_unpack_reduce(P(part), P(grad_of(weight)), nch, KK, Cin, Cout, Cout, 1, KK, Cin * KK, 1, S)
+    if bias is not None:
+        L.cdf_unpack_reduce(P(bsum), P(grad_of(bias)), nch, 1, 1, Cout, Cout, 0, 0, 1, 1, S)
+    if not need_dx:
+        return None
+    if dx is None:
+        dx = torch.empty((B, H, W, 4), device=x.device, dtype=torch.float32)
+        dx_accumulate = 0
+    wp = packed(weight, "cin4")
+    L.cdf_conv_cin4_dgrad(P(dy), ld_of(dy), P(wp), wp.shape[-1], P(dx), B, H, W, Cout, k, dx_accumulate, S)
+    return dx
 
 
 def conv_gemm(plan, x, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None, pre=None, mul=None, act=0, mul_mode=0,

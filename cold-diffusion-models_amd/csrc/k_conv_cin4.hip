@@ -1,0 +1,278 @@
+// k_conv_cin4.hip — direct convolution for layers with at most 4 input channels (the image-side convs of the
+// UNets: ConvNeXt block 0 conv1 3->128 3x3 and res_conv 3->64 1x1, DEBLUR:145-165 with dim = channels).
+//
+// As GEMMs these are K = taps*Cin <= 36 against M = B*H*W = 524 288 pixels: the 128-row MFMA tiles spend their time
+// on padding, and the weight-gradient kernel re-reads the 128-channel gradient once per tap (2.4 GB).  The work is
+// only 27 FMAs per output element, so it runs on the vector ALUs at the speed of the one big tensor of each pass:
+//   forward   : x [M][4] (L1 broadcast) -> y / pre / bf16 planes [M][Cout], written once
+//   data grad : dy [M][Cout] read per tap (L2), dx [M][4] written
+//   weight grad: dy read ONCE, 27 x 4 register accumulators per lane, per-chunk partials + unpack_reduce
+// Layout: NHWC, input pitch exactly 4 floats (channel 3 is padding and must be zero or ignored: its weights are zero),
+// stride 1, odd k, "same" padding.  Weights arrive packed [taps][4][Cout] fp32 (cdf_pack_weight: T=taps, R=Cin<=4 ...).
+// All arithmetic fp32 FMA.
+#include "cdf_common.h"
+#include "colddiff.h"
+
+#define C4_MAX_TAPS 9
+
+struct Cin4Args {
+    const float* x;       // [B][H][W][4]
+    const float* w;       // [taps][4][ldw]  (rows c >= Cin are zero)
+    const float* bias;    // [Cout] nullable
+    float* y;             // nullable (planes only)
+    float* pre;           // nullable: pre-activation
+    unsigned short* ys_hi;
+    unsigned short* ys_lo;
+    int ldw, ldy, ldp, ld_ys;
+    int B, H, W, Cout, k, act;
+};
+
+// grid-stride over pixels; block 256 = (256 / LP) pixels x LP lanes, lane = 4 output channels
+template <int K>
+__global__ void __launch_bounds__(256) conv_cin4_fwd_kernel(Cin4Args a) {
+    constexpr int T = K * K, h = K / 2;
+    CDF_DYN_SMEM(smem);
+    float4* wl = (float4*)smem;                    // [T][4][LP]
+    const int LP = a.Cout / 4, PPB = 256 / LP;
+    for (int i = threadIdx.x; i < T * 4 * LP; i += 256) {
+        const int l = i % LP, tc = i / LP;
+        wl[i] = *(const float4*)(a.w + (long long)tc * a.ldw + l * 4);
+    }
+    __syncthreads();
+    const int l = threadIdx.x % LP, pl = threadIdx.x / LP;
+    if (pl >= PPB) return;
+    const int n = l * 4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) bv = *(const float4*)(a.bias + n);
+    const int M = a.B * a.H * a.W;                           // (< 2^31 pixels: 32-bit index math; 64-bit div/mod is ~100 instructions)
+    for (int m = blockIdx.x * PPB + pl; m < M; m += gridDim.x * PPB) {
+        const int px = m % a.W, py = (m / a.W) % a.H;
+        float4 xv[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int iy = py + t / K - h, ix = px + t % K - h;
+            const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            // pointer select against the zero page, no value select: "ok ? load : 0" becomes a branch around the load
+            xv[t] = *(const float4*)(ok ? a.x + (long long)(m + (t / K - h) * a.W + (t % K - h)) * 4 : cdf_zero_page);
+        }
+        float4 acc = bv;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const float4 w0 = wl[(t * 4 + 0) * LP + l], w1 = wl[(t * 4 + 1) * LP + l], w2 = wl[(t * 4 + 2) * LP + l], w3 = wl[(t * 4 + 3) * LP + l];
+            acc.x = fmaf(xv[t].x, w0.x, acc.x); acc.y = fmaf(xv[t].x, w0.y, acc.y); acc.z = fmaf(xv[t].x, w0.z, acc.z); acc.w = fmaf(xv[t].x, w0.w, acc.w);
+            acc.x = fmaf(xv[t].y, w1.x, acc.x); acc.y = fmaf(xv[t].y, w1.y, acc.y); acc.z = fmaf(xv[t].y, w1.z, acc.z); acc.w = fmaf(xv[t].y, w1.w, acc.w);
+            acc.x = fmaf(xv[t].z, w2.x, acc.x); acc.y = fmaf(xv[t].z, w2.y, acc.y); acc.z = fmaf(xv[t].z, w2.z, acc.z); acc.w = fmaf(xv[t].z, w2.w, acc.w);
+            acc.x = fmaf(xv[t].w, w3.x, acc.x); acc.y = fmaf(xv[t].w, w3.y, acc.y); acc.z = fmaf(xv[t].w, w3.z, acc.z); acc.w = fmaf(xv[t].w, w3.w, acc.w);
+        }
+        if (a.pre) *(float4*)(a.pre + (long long)m * a.ldp + n) = acc;
+        float v[4] = {acc.x, acc.y, acc.z, acc.w};
+        if (a.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = cdf_gelu(v[e]);
+        } else if (a.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = cdf_silu(v[e]);
+        }
+        if (a.y) *(float4*)(a.y + (long long)m * a.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (a.ys_hi) cdf_split_store4(a.ys_hi + (long long)m * a.ld_ys + n, a.ys_lo + (long long)m * a.ld_ys + n, v);
+    }
+}
+
+// dx[m][c] = sum_t sum_n dy[m - off(t)][n] * w[t][c][n]   (transposed taps);  block = (256/LP) pixels x LP lanes
+template <int K>
+__global__ void __launch_bounds__(256) conv_cin4_dgrad_kernel(const float* dy, int ldd, const float* w, int ldw, float* dx, int B, int H,
+                                                              int W, int Cout, int accumulate) {
+    constexpr int T = K * K, h = K / 2;
+    CDF_DYN_SMEM(smem);
+    float4* wl = (float4*)smem;                    // [T][4][LP]
+    const int LP = Cout / 4, PPB = 256 / LP;
+    for (int i = threadIdx.x; i < T * 4 * LP; i += 256) {
+        const int l = i % LP, tc = i / LP;
+        wl[i] = *(const float4*)(w + (long long)tc * ldw + l * 4);
+    }
+    __syncthreads();
+    const int l = threadIdx.x % LP, pl = threadIdx.x / LP;
+    const int n = l * 4;
+    const int M = B * H * W, mstep = gridDim.x * PPB;
+    // every lane of a pixel group runs the same trip count (the cross-lane sums below need all LP lanes)
+    for (int m0 = blockIdx.x * PPB; m0 < M; m0 += mstep) {
+        const int m = m0 + pl;
+        const bool live = pl < PPB && m < M;
+        const int mc = live ? m : 0;
+        const int px = mc % W, py = (mc / W) % H;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        float4 dv[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            // forward tap t reads x[m + off(t)]; its gradient flows from dy[m - off(t)]
+            const int oy = t / K - h, ox = t % K - h;
+            const int iy = py - oy, ix = px - ox;
+            const bool ok = live && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            dv[t] = *(const float4*)(ok ? dy + (long long)(mc - oy * W - ox) * ldd + n : cdf_zero_page);
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const float4 w0 = wl[(t * 4 + 0) * LP + l], w1 = wl[(t * 4 + 1) * LP + l], w2 = wl[(t * 4 + 2) * LP + l], w3 = wl[(t * 4 + 3) * LP + l];
+            s0 += (dv[t].x * w0.x + dv[t].y * w0.y) + (dv[t].z * w0.z + dv[t].w * w0.w);
+            s1 += (dv[t].x * w1.x + dv[t].y * w1.y) + (dv[t].z * w1.z + dv[t].w * w1.w);
+            s2 += (dv[t].x * w2.x + dv[t].y * w2.y) + (dv[t].z * w2.z + dv[t].w * w2.w);
+            s3 += (dv[t].x * w3.x + dv[t].y * w3.y) + (dv[t].z * w3.z + dv[t].w * w3.w);
+        }
+        s0 = cdf_group_sum(s0, LP); s1 = cdf_group_sum(s1, LP); s2 = cdf_group_sum(s2, LP); s3 = cdf_group_sum(s3, LP);
+        if (live && l == 0) {
+            float4 o = make_float4(s0, s1, s2, s3);
+            float* dst = dx + (long long)m * 4;
+            if (accumulate) {
+                const float4 old = *(const float4*)dst;
+                o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            }
+            *(float4*)dst = o;
+        }
+    }
+}
+
+// partial[chunk][t*Cin + c][n] = sum_{m in chunk} x[m + off(t)][c] * dy[m][n] (c < Cin);  bsum[chunk][n] = sum dy[m][n]
+// grid = nchunk; block = (256/LP) pixel lanes x LP channel lanes; 4*T float4 accumulators per thread
+template <int K>
+__global__ void __launch_bounds__(256) conv_cin4_wgrad_kernel(const float* x, const float* dy, int ldd, float* part, float* bsum, int B, int H,
+                                                              int W, int Cin, int Cout, long long m_per_chunk) {
+    constexpr int T = K * K, h = K / 2;
+    CDF_DYN_SMEM(smem);
+    float4* red = (float4*)smem;                   // [PPB][LP] reused per accumulator row
+    const int LP = Cout / 4, PPB = 256 / LP;
+    const int l = threadIdx.x % LP, pl = threadIdx.x / LP;
+    const int n = l * 4;
+    const int M = B * H * W;
+    const int m_lo = (int)(blockIdx.x * m_per_chunk);
+    int m_hi = m_lo + (int)m_per_chunk;
+    if (m_hi > M) m_hi = M;
+    float4 acc[T][4], bs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pl < PPB) {
+        for (int m = m_lo + pl; m < m_hi; m += PPB) {
+            const int px = m % W, py = (m / W) % H;
+            const float4 d = *(const float4*)(dy + (long long)m * ldd + n);
+            bs.x += d.x; bs.y += d.y; bs.z += d.z; bs.w += d.w;
+            float4 xv[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int iy = py + t / K - h, ix = px + t % K - h;
+                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                xv[t] = *(const float4*)(ok ? x + (long long)(m + (t / K - h) * W + (t % K - h)) * 4 : cdf_zero_page);
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                acc[t][0].x = fmaf(xv[t].x, d.x, acc[t][0].x); acc[t][0].y = fmaf(xv[t].x, d.y, acc[t][0].y); acc[t][0].z = fmaf(xv[t].x, d.z, acc[t][0].z); acc[t][0].w = fmaf(xv[t].x, d.w, acc[t][0].w);
+                acc[t][1].x = fmaf(xv[t].y, d.x, acc[t][1].x); acc[t][1].y = fmaf(xv[t].y, d.y, acc[t][1].y); acc[t][1].z = fmaf(xv[t].y, d.z, acc[t][1].z); acc[t][1].w = fmaf(xv[t].y, d.w, acc[t][1].w);
+                acc[t][2].x = fmaf(xv[t].z, d.x, acc[t][2].x); acc[t][2].y = fmaf(xv[t].z, d.y, acc[t][2].y); acc[t][2].z = fmaf(xv[t].z, d.z, acc[t][2].z); acc[t][2].w = fmaf(xv[t].z, d.w, acc[t][2].w);
+                acc[t][3].x = fmaf(xv[t].w, d.x, acc[t][3].x); acc[t][3].y = fmaf(xv[t].w, d.y, acc[t][3].y); acc[t][3].z = fmaf(xv[t].w, d.z, acc[t][3].z); acc[t][3].w = fmaf(xv[t].w, d.w, acc[t][3].w);
+            }
+        }
+    }
+    // fold the pixel lanes through LDS, one accumulator row at a time (static indices only: acc[] stays in registers)
+    float* prow = part + (long long)blockIdx.x * T * Cin * Cout;
+    auto fold = [&](const float4& v, float* dst) {
+        __syncthreads();
+        if (pl < PPB) red[pl * LP + l] = v;
+        __syncthreads();
+        if (pl == 0) {
+            float4 s = red[l];
+            for (int p = 1; p < PPB; ++p) {
+                const float4 r = red[p * LP + l];
+                s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
+            }
+            *(float4*)(dst + n) = s;
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < Cin) fold(acc[t][c], prow + (long long)(t * Cin + c) * Cout);       // (block-uniform)
+    if (bsum) fold(bs, bsum + (long long)blockIdx.x * Cout);
+}
+
+// dst[t][c][n] = c < Cin ? w[(n*Cin + c)*KK + t] : 0   (w in the PyTorch layout [Cout][Cin][k][k]); n >= Cout zero
+__global__ void pack_cin4_kernel(const float* w, float* dst, int ldw, int Cout, int Cin, int KK) {
+    const int n_all = KK * 4 * ldw;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += gridDim.x * blockDim.x) {
+        const int n = i % ldw, tc = i / ldw, c = tc & 3, t = tc >> 2;
+        dst[i] = (c < Cin && n < Cout) ? w[((long long)n * Cin + c) * KK + t] : 0.f;
+    }
+}
+
+extern "C" int cdf_pack_cin4(const float* w, float* dst, int ldw, int Cout, int Cin, int k, void* stream) {
+    CDF_REQUIRE(w && dst && Cin >= 1 && Cin <= 4 && ldw >= Cout && (k == 1 || k == 3), "cdf_pack_cin4: bad args");
+    const int n = k * k * 4 * ldw;
+    CDF_LAUNCH(pack_cin4_kernel, dim3(cdf_cdiv(n, 256)), dim3(256), 0, CDF_S, w, dst, ldw, Cout, Cin, k * k);
+    return cdf_check_launch("pack_cin4");
+}
+
+// ================================================================================================
+template <int K>
+static int launch_cin4_fwd(const Cin4Args& a, hipStream_t s) {
+    const int LP = a.Cout / 4, PPB = 256 / LP;
+    const long long M = (long long)a.B * a.H * a.W;
+    long long grid = (M + PPB - 1) / PPB;
+    if (grid > 4096) grid = 4096;
+    const size_t lds = (size_t)K * K * 4 * LP * sizeof(float4);
+    CDF_LAUNCH((conv_cin4_fwd_kernel<K>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    return cdf_check_launch("conv_cin4_fwd");
+}
+
+static int cin4_check(const char* who, int Cout, int k, int ldw) {
+    CDF_REQUIRE(Cout % 4 == 0 && Cout >= 4 && Cout <= 256 && 256 % (Cout / 4) == 0, "%s: Cout must be 4 * (a power of two <= 64), got %d", who, Cout);
+    CDF_REQUIRE(k == 1 || k == 3, "%s: kernel size 1 or 3", who);
+    CDF_REQUIRE(ldw % 4 == 0 && ldw >= Cout, "%s: bad weight pitch", who);
+    return CDF_OK;
+}
+
+extern "C" int cdf_conv_cin4_fwd(const float* x, const float* w, int ldw, const float* bias, float* y, int ldy, float* pre, int ldp,
+                                 void* y_hi, void* y_lo, int ld_ys, int B, int H, int W, int Cout, int k, int act, void* stream) {
+    CDF_REQUIRE(x && w && (y || y_hi), "cdf_conv_cin4_fwd: null pointer");
+    int rc = cin4_check("cdf_conv_cin4_fwd", Cout, k, ldw);
+    if (rc) return rc;
+    CDF_REQUIRE((!y || ldy % 4 == 0) && (!pre || ldp % 4 == 0) && (!y_hi || (y_lo && ld_ys % 4 == 0)), "cdf_conv_cin4_fwd: pitches must be multiples of 4");
+    Cin4Args a{x, w, bias, y, pre, (unsigned short*)y_hi, (unsigned short*)y_lo, ldw, ldy, ldp, ld_ys, B, H, W, Cout, k, act};
+    return k == 1 ? launch_cin4_fwd<1>(a, CDF_S) : launch_cin4_fwd<3>(a, CDF_S);
+}
+
+extern "C" int cdf_conv_cin4_dgrad(const float* dy, int ldd, const float* w, int ldw, float* dx, int B, int H, int W, int Cout, int k,
+                                   int accumulate, void* stream) {
+    CDF_REQUIRE(dy && w && dx && ldd % 4 == 0 && ldd >= Cout, "cdf_conv_cin4_dgrad: bad args");
+    int rc = cin4_check("cdf_conv_cin4_dgrad", Cout, k, ldw);
+    if (rc) return rc;
+    const int LP = Cout / 4, PPB = 256 / LP;
+    const long long M = (long long)B * H * W;
+    long long grid = (M + PPB - 1) / PPB;
+    if (grid > 4096) grid = 4096;
+    const size_t lds = (size_t)k * k * 4 * LP * sizeof(float4);
+    if (k == 1) CDF_LAUNCH((conv_cin4_dgrad_kernel<1>), dim3((unsigned)grid), dim3(256), lds, CDF_S, dy, ldd, w, ldw, dx, B, H, W, Cout, accumulate);
+    else CDF_LAUNCH((conv_cin4_dgrad_kernel<3>), dim3((unsigned)grid), dim3(256), lds, CDF_S, dy, ldd, w, ldw, dx, B, H, W, Cout, accumulate);
+    return cdf_check_launch("conv_cin4_dgrad");
+}
+
+extern "C" int cdf_conv_cin4_nchunk(long long M) {
+    long long n = M / 512;
+    if (n < 1) n = 1;
+    if (n > 1024) n = 1024;
+    return (int)n;
+}
+
+// part: nchunk * taps*Cin * Cout floats, bsum (nullable): nchunk * Cout floats; reduce with cdf_unpack_reduce
+extern "C" int cdf_conv_cin4_wgrad(const float* x, const float* dy, int ldd, float* part, float* bsum, int B, int H, int W, int Cin, int Cout,
+                                   int k, void* stream) {
+    CDF_REQUIRE(x && dy && part && ldd % 4 == 0 && ldd >= Cout && Cin >= 1 && Cin <= 4, "cdf_conv_cin4_wgrad: bad args");
+    int rc = cin4_check("cdf_conv_cin4_wgrad", Cout, k, Cout);
+    if (rc) return rc;
+    const long long M = (long long)B * H * W;
+    const int nchunk = cdf_conv_cin4_nchunk(M);
+    const long long mpc = (M + nchunk - 1) / nchunk;
+    const size_t lds = (size_t)256 * sizeof(float4);
+    if (k == 1) CDF_LAUNCH((conv_cin4_wgrad_kernel<1>), dim3(nchunk), dim3(256), lds, CDF_S, x, dy, ldd, part, bsum, B, H, W, Cin, Cout, mpc);
+    else CDF_LAUNCH((conv_cin4_wgrad_kernel<3>), dim3(nchunk), dim3(256), lds, CDF_S, x, dy, ldd, part, bsum, B, H, W, Cin, Cout, mpc);
+    return cdf_check_launch("conv_cin4_wgrad");
+}

@@ -239,6 +239,21 @@ int cdf_softmax_rows_bwd(const float* p, const float* dp, float* ds, long long r
  * sinusoidal time embedding (DEBLUR:91-103, MODEL2:6-24): out[b] = (sin(t f_j) | cos(t f_j)),
  * freq[dim/2] = the init-time frequency table exp(-j ln(1e4)/(dim/2-1)) */
 int cdf_sinusoidal(const int64_t* t, const float* freq, float* out, int ldo, int B, int dim, void* stream);
+/* Direct convolution for layers with <= 4 input channels (image-side convs: DEBLUR:145-165 with dim = channels):
+ * x is NHWC with pitch exactly 4 (channel padding zero), stride 1, k = 1 or 3, "same" padding; w = weights packed
+ * [k*k][4][ldw] fp32 (rows >= Cin zero).  Cout = 4 * (power of two <= 64).
+ *   fwd  : y (nullable) / pre (nullable pre-activation) / y_hi,y_lo (nullable bf16 planes) = act(conv(x) + bias)
+ *   dgrad: dx[M][4] (+)= sum_taps dy * w  (channel 3 of dx receives the zero-weight sum, i.e. 0)
+ *   wgrad: part[nchunk][k*k*Cin][Cout] and bsum[nchunk][Cout] partial sums, nchunk = cdf_conv_cin4_nchunk(B*H*W);
+ *          reduce with cdf_unpack_reduce (T = k*k, R = Cin).  cdf_pack_cin4 builds w from the PyTorch [Cout][Cin][k][k] weight. */
+int cdf_conv_cin4_fwd(const float* x, const float* w, int ldw, const float* bias, float* y, int ldy, float* pre, int ldp, void* y_hi,
+                      void* y_lo, int ld_ys, int B, int H, int W, int Cout, int k, int act, void* stream);
+int cdf_conv_cin4_dgrad(const float* dy, int ldd, const float* w, int ldw, float* dx, int B, int H, int W, int Cout, int k, int accumulate,
+                        void* stream);
+int cdf_conv_cin4_nchunk(long long M);
+int cdf_conv_cin4_wgrad(const float* x, const float* dy, int ldd, float* part, float* bsum, int B, int H, int W, int Cin, int Cout,
+                        int k, void* stream);
+int cdf_pack_cin4(const float* w, float* dst, int ldw, int Cout, int Cin, int k, void* stream);
 /* Skinny linear layers (M = batch rows; the time-embedding MLPs DEBLUR:96-103,142-144,160, MODEL2:44-48,238-245):
  *   out[m][j] = bias[j] + sum_i in[m][i] * Wm[i*ldw + j]        (columns J..ldo-1 of out are zeroed)
  * forward: Wm = the weight packed [K][N] (cdf_pack_weight), i = k, j = n; data gradient: Wm = the PyTorch [N][K]

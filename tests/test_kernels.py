@@ -715,3 +715,41 @@ def test_linear_small(be, M, K, N):
     dW, db = be.to(torch.ones(N, K)), be.to(torch.ones(N))
     be.L.cdf_linear_small_wgrad(P(gd), N, P(xd), K, P(dW), P(db), M, N, K, be.stream())
     assert err(dW, lin.weight.grad + 1) <= 5e-5 and err(db, lin.bias.grad + 1) <= 5e-5
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,act", [(2, 12, 3, 128, 3, 1), (1, 9, 3, 64, 1, 0), (3, 8, 1, 32, 3, 2), (1, 20, 4, 256, 3, 0)])
+def test_conv_cin4_direct(be, B, H, Cin, Cout, k, act):
+    """Direct convolution for <= 4 input channels (image-side convs, DEBLUR:145-165 with dim = channels): forward with fused
+    bias / activation / pre-activation / bf16 planes, data gradient, weight + bias gradient against torch."""
+    torch.manual_seed(0)
+    x = torch.randn(B, Cin, H, H, requires_grad=True)
+    conv = torch.nn.Conv2d(Cin, Cout, k, padding=k // 2)
+    pre_ref = conv(x)
+    yref = F.gelu(pre_ref) if act == 1 else (F.silu(pre_ref) if act == 2 else pre_ref)
+    g = torch.randn_like(pre_ref)
+    pre_ref.backward(g)                                      # gradients w.r.t. the pre-activation (the activation's own
+    KK = k * k                                               # derivative is fused elsewhere)
+    xn = torch.zeros(B, H, H, 4)
+    xn[..., :Cin] = x.detach().permute(0, 2, 3, 1)
+    xd, gd = be.to(xn), be.to(g.permute(0, 2, 3, 1).contiguous())
+    wp = be.empty(KK, 4, Cout)
+    be.L.cdf_pack_cin4(P(be.to(conv.weight.detach())), P(wp), Cout, Cout, Cin, k, be.stream())
+    y, pre = be.empty(B, H, H, Cout), be.empty(B, H, H, Cout)
+    yh = torch.zeros(B, H, H, Cout, dtype=torch.int16, device=be.device)
+    yl = torch.zeros_like(yh)
+    be.L.cdf_conv_cin4_fwd(P(xd), P(wp), Cout, P(be.to(conv.bias.detach())), P(y), Cout, P(pre), Cout, P(yh), P(yl), Cout, B, H, H, Cout, k, act,
+                           be.stream())
+    assert err(y.permute(0, 3, 1, 2), yref.detach()) <= 2e-5 and err(pre.permute(0, 3, 1, 2), pre_ref.detach()) <= 2e-5
+    rh, rl = _split(be, y)
+    assert torch.equal(yh.cpu(), rh.cpu()) and torch.equal(yl.cpu(), rl.cpu())
+    dx = be.empty(B, H, H, 4)
+    be.L.cdf_conv_cin4_dgrad(P(gd), Cout, P(wp), Cout, P(dx), B, H, H, Cout, k, 0, be.stream())
+    assert err(dx[..., :Cin].permute(0, 3, 1, 2), x.grad) <= 5e-5 * max(1.0, x.grad.abs().max().item())
+    nch = be.L.cdf_conv_cin4_nchunk(B * H * H)
+    part, bsum = be.empty(nch, KK * Cin, Cout), be.empty(nch, Cout)
+    be.L.cdf_conv_cin4_wgrad(P(xd), P(gd), Cout, P(part), P(bsum), B, H, H, Cin, Cout, k, be.stream())
+    dw, db = be.zeros(Cout, Cin, k, k), be.zeros(Cout)
+    be.L.cdf_unpack_reduce(P(part), P(dw), nch, KK, Cin, Cout, Cout, 1, KK, Cin * KK, 0, be.stream())
+    be.L.cdf_unpack_reduce(P(bsum), P(db), nch, 1, 1, Cout, Cout, 0, 0, 1, 0, be.stream())
+    assert err(dw, conv.weight.grad) <= 5e-5 * max(1.0, conv.weight.grad.abs().max().item())
+    assert err(db, conv.bias.grad) <= 5e-5 * max(1.0, conv.bias.grad.abs().max().item())
