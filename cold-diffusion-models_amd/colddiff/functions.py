@@ -68,12 +68,12 @@ _LINEAR_SMALL_M = 256      # batch sizes up to this use the skinny-linear kernel
 _ALWAYS_PRESPLIT = os.environ.get("CDF_ALWAYS_PRESPLIT", "0") != "0"
 _PRESPLIT_1X1 = os.environ.get("CDF_PRESPLIT_1X1", "0") != "0"
 _AUTO_PRESPLIT = os.environ.get("CDF_AUTO_PRESPLIT", "1") != "0"
-_SP_KMIN = int(os.environ.get("CDF_SP_KMIN", "128"))     # tuning knob: smallest K routed to the bf16 matrix cores
+_SP_KMIN = int(os.environ.get("CDF_SP_KMIN", "64"))     # tuning knob: smallest K routed to the bf16 matrix cores
 
 
 def _sp_suffix(K, N):
     """Route a dense conv to the split-precision bf16 MFMA kernel when enabled and the GEMM is deep and
-    wide enough (K = taps*Cin >= 128, N >= 64); the tiny first/last layers, K = 32 attention products and
+    wide enough (K = taps*Cin >= 64, N >= 64); the tiny first/last layers, K = 32 attention products and
     the time-embedding linears stay on the exact-fp32 kernel."""
     return "_sp" if (rt.precision != "f32" and K >= _SP_KMIN and N >= 64) else ""
 
