@@ -86,12 +86,13 @@ def convT_dgrad(H, W, KH, KW, stride, pad):
 
 
 class WgradPlan:
-    __slots__ = ("QH", "QW", "HA", "WA", "sa", "HB", "WB", "sb", "ntaps", "desc")
+    __slots__ = ("QH", "QW", "HA", "WA", "sa", "HB", "WB", "sb", "ntaps", "desc", "same_b")
 
     def __init__(self, QH, QW, HA, WA, sa, HB, WB, sb, taps):
         self.QH, self.QW, self.HA, self.WA, self.sa = QH, QW, HA, WA, sa
         self.HB, self.WB, self.sb = HB, WB, sb
         self.ntaps = len(taps)
+        self.same_b = len(taps) >= 2 and all(t[2:] == taps[0][2:] for t in taps)   # every tap reads B at one offset
         flat = []
         for t in taps:
             flat += list(t)

@@ -262,7 +262,8 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None, xa_s=No
         # both operands already split into bf16 hi/lo planes: copy + MFMA only (64-wide tiles for 64-channel sides);
         # xa / xb themselves may be shape-only stand-ins here
         dev = xa_s[0].device
-        tiles = (1 if CA <= 64 else (CA + 127) // 128) * (1 if CB <= 64 else (CB + 127) // 128) * wplan.ntaps
+        ntap_blocks = (wplan.ntaps + 1) // 2 if (CA <= 64 < CB and wplan.same_b) else wplan.ntaps    # two taps per tile there
+        tiles = (1 if CA <= 64 else (CA + 127) // 128) * (1 if CB <= 64 else (CB + 127) // 128) * ntap_blocks
         ns = best_nsplit(tiles, 512, M // 512)
         ws = torch.empty((ns, wplan.ntaps, CA, ldo), device=dev, dtype=torch.float32)
         S = rt.stream(xa_s[0])

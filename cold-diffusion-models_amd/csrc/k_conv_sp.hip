@@ -740,7 +740,10 @@ struct SpxWgradSlot {                  // one operand's share of a thread's load
     static constexpr int PITCH = T + 32;
 };
 
-template <int TA, int TB>
+// STACK2 (TA = 128 with CA <= 64): a 64-channel A operand would fill only half of the 128 MFMA rows, so the tile takes
+// TWO taps -- rows 0..63 = tap 2*blockIdx.y, rows 64..127 = tap 2*blockIdx.y + 1 (all-zero when past the last tap).  The B
+// rows are shared: valid when every tap reads B at the same offset (plain convolutions; checked by the host).
+template <int TA, int TB, bool STACK2 = false>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) {
     using SA = SpxWgradSlot<TA>;
     using SB = SpxWgradSlot<TB>;
@@ -754,16 +757,21 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_b = (a.CB + TB - 1) / TB;
     const int tile_a = blockIdx.x / tiles_b, tile_b = blockIdx.x - tile_a * tiles_b;
-    const int tap = blockIdx.y, split = blockIdx.z;
+    const int tap = STACK2 ? 2 * blockIdx.y : blockIdx.y, split = blockIdx.z;
     const int M = a.B * a.QH * a.QW;
     const int m_lo = split * a.m_per_split;
     int m_hi = m_lo + a.m_per_split;
     if (m_hi > M) m_hi = M;
     const int niter = m_hi > m_lo ? (m_hi - m_lo + BK - 1) / BK : 0;
-    const int day = a.day[tap], dax = a.dax[tap], dby = a.dby[tap], dbx = a.dbx[tap];
-
+    const int dby = a.dby[tap], dbx = a.dbx[tap];
     // load slots: operand X, pass p: pixel (tid / VPR) + PPP p of the chunk, 16-byte channel column (tid % VPR) * 8
-    const int ca = tile_a * TA + (tid % SA::VPR) * 8, cb = tile_b * TB + (tid % SB::VPR) * 8;
+    static_assert(!STACK2 || TA == 128, "tap stacking fills a 128-row A tile with two 64-channel taps");
+    const int a_half = STACK2 ? ((tid % SA::VPR) >> 3) : 0;                 // which of the two stacked taps this lane loads
+    const int tap_l = tap + a_half;
+    const bool tap_ok = tap_l < a.ntaps;
+    const int day = a.day[tap_ok ? tap_l : tap], dax = a.dax[tap_ok ? tap_l : tap];
+    const int ca = STACK2 ? ((tid % SA::VPR) & 7) * 8 : tile_a * TA + (tid % SA::VPR) * 8;
+    const int cb = tile_b * TB + (tid % SB::VPR) * 8;
     int qa[SA::PASS][3], qb[SB::PASS][3];
 #pragma unroll
     for (int p = 0; p < SA::PASS; ++p) {
@@ -811,7 +819,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
             // the other side holds (and the B rows stay intact for the fused bias gradient)
             const int m = m0 + tid / SA::VPR + SA::PPP * p;
             const unsigned ay = (unsigned)(qa[p][1] * a.sa + day), ax = (unsigned)(qa[p][0] * a.sa + dax);
-            const bool ok = m < m_hi && ay < (unsigned)a.HA && ax < (unsigned)a.WA && ca < a.CA;
+            const bool ok = m < m_hi && ay < (unsigned)a.HA && ax < (unsigned)a.WA && ca < a.CA && tap_ok;
             const unsigned pix = ((unsigned)qa[p][2] * (unsigned)a.HA + ay) * (unsigned)a.WA + ax;
             const size_t off = (size_t)pix * (unsigned)a.lda + (unsigned)ca;
             rah[p] = *(const u32x4_v*)(ok ? a.a_hi + off : a.zero);
@@ -951,8 +959,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
     const int c4 = (tid % TPR) * 4, col = tile_b * TB + c4;
     if (col < a.ldo) {
         for (int r = tid / TPR; r < TA; r += RPS) {
-            const int row = tile_a * TA + r;
-            if (row >= a.CA) break;
+            int row = tile_a * TA + r;
+            if (STACK2) {                          // tile row r = (stacked tap r >> 6, channel r & 63): the next tap's slab follows
+                if (tap + (r >> 6) >= a.ntaps || (r & 63) >= a.CA) continue;
+                row = (r >> 6) * a.CA + (r & 63);
+            } else if (row >= a.CA) break;
             float4 v = *(const float4*)(red + r * CP + c4);
             if (col + 3 >= a.CB) {                 // zero the pitch padding (ldo % 4 == 0 keeps the store in bounds)
                 if (col + 0 >= a.CB) v.x = 0.f;
@@ -1159,7 +1170,14 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
     return m64 ? launch_igemm_spx<64, 128, 2, 2, 2>(a, M, CDF_S) : launch_igemm_spx<128, 128, 2, 2, 2>(a, M, CDF_S);
 }
 
-template <int TA, int TB>
+static int g_wgrad_stack = 1;                  // tuning / test hook (cdf_conv_wgrad_bf16x_stack)
+
+extern "C" int cdf_conv_wgrad_bf16x_stack(int enable) {
+    g_wgrad_stack = enable ? 1 : 0;
+    return 0;
+}
+
+template <int TA, int TB, bool STACK2 = false>
 static int launch_wgrad_spx(const SpxWgradArgs& a, hipStream_t s) {
     constexpr size_t stage = (size_t)2 * 32 * ((TA + 32) + (TB + 32)) * sizeof(unsigned short);
     constexpr size_t epi = (size_t)TA * (TB + 8) * sizeof(float);
@@ -1167,12 +1185,12 @@ static int launch_wgrad_spx(const SpxWgradArgs& a, hipStream_t s) {
 #ifndef CDF_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_spx_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_spx_kernel<TA, TB, STACK2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
 #endif
-    const int tiles = cdf_cdiv(a.CA, TA) * cdf_cdiv(a.CB, TB);
-    CDF_LAUNCH((conv_wgrad_spx_kernel<TA, TB>), dim3(tiles, a.ntaps, a.nsplit), dim3(256), lds, s, a);
+    const int tiles = (STACK2 ? 1 : cdf_cdiv(a.CA, TA)) * cdf_cdiv(a.CB, TB);
+    CDF_LAUNCH((conv_wgrad_spx_kernel<TA, TB, STACK2>), dim3(tiles, STACK2 ? cdf_cdiv(a.ntaps, 2) : a.ntaps, a.nsplit), dim3(256), lds, s, a);
     return cdf_check_launch("conv_wgrad_spx");
 }
 
@@ -1199,7 +1217,12 @@ extern "C" int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda,
     }
     // thin layers get 64-wide tiles so that no half of a tile multiplies padding
     if (CA <= 64 && CB <= 64) return launch_wgrad_spx<64, 64>(a, CDF_S);
-    if (CA <= 64) return launch_wgrad_spx<64, 128>(a, CDF_S);
+    if (CA <= 64) {
+        bool same_b = ntaps >= 2;                  // two taps can share the B rows only if B is read at one offset
+        for (int t = 1; t < ntaps; ++t) same_b = same_b && a.dby[t] == a.dby[0] && a.dbx[t] == a.dbx[0];
+        if (same_b && g_wgrad_stack) return launch_wgrad_spx<128, 128, true>(a, CDF_S);
+        return launch_wgrad_spx<64, 128>(a, CDF_S);
+    }
     if (CB <= 64) return launch_wgrad_spx<128, 64>(a, CDF_S);
     return launch_wgrad_spx<128, 128>(a, CDF_S);
 }
