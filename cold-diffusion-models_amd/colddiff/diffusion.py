@@ -161,7 +161,12 @@ class DeblurDiffusion(nn.Module):
         img = self._collapse(img)
         if noise_level is not None:
             img = img + torch.randn_like(img) * noise_level
-        xt, direct_recons = img, None
+        xt = img
+        direct_recons, img = self._reverse_loop(batch_size, img, t)
+        return xt, direct_recons, img
+
+    def _reverse_loop(self, batch_size, img, t):
+        direct_recons = None
         while t:
             step = _full_step(batch_size, t - 1, img.device)
             x = self.denoise_fn(img, step)
@@ -171,7 +176,7 @@ class DeblurDiffusion(nn.Module):
                 x = self._reverse_step(img, x, t)
             img = x
             t = t - 1
-        return xt, direct_recons, img
+        return direct_recons, img
 
     def sample(self, batch_size=16, img=None, t=None):
         out = self._sample_impl(batch_size, img, t, None)
@@ -182,6 +187,108 @@ class DeblurDiffusion(nn.Module):
         return self._sample_impl(batch_size, img, t, noise_level)
 
     gen_sample_2 = gen_sample
+
+    def _chain(self, x, n, img=None, collapse=True):
+        """Kernels 0..n-1 on x (with img: the Alg.2 combination); `collapse=False` drops the discrete mean-collapse."""
+        saved, self.discrete = self.discrete, self.discrete and collapse
+        try:
+            return self._degrade(x, n, img=img)
+        finally:
+            self.discrete = saved
+
+    def _trajectory(self, img, lo, hi):
+        """[K_lo(img), K_{lo+1}(K_lo(img)), ...] for kernels lo..hi-1, one launch per step (any kernel size)."""
+        out = []
+        for i in range(lo, hi):
+            img = self._apply_one(i, img)
+            out.append(img)
+        return out
+
+    @torch.no_grad()
+    def forward_and_backward(self, batch_size=16, img=None, noise_level=0, t=None, times=None, eval=True):
+        """The whole forward trajectory and every x_t on the way back (DEBLUR:692-770)."""
+        if eval:
+            self.denoise_fn.eval()
+        if t is None:
+            t = self.num_timesteps
+        if times is None:
+            times = t
+        img = rt.check(img)
+        Forward = [img]
+        individual = self.blur_routine == 'Individual_Incremental'
+        if individual:
+            img = self._apply_one(t - 1, img)
+        else:
+            Forward += self._trajectory(img, 0, t)
+            img = Forward[-1]
+        Backward = []
+        if self.discrete:
+            img = self._collapse(img)
+            img = img + torch.randn_like(img) * noise_level
+        while times:
+            step = _full_step(batch_size, times - 1, img.device)
+            x = self.denoise_fn(img, step)
+            Backward.append(img)
+            if self.train_routine == 'Final':
+                if individual:
+                    if self.sampling_routine in ('default', 'x0_step_down') and times - 2 >= 0:
+                        x = self._apply_one(times - 2, img)           # reference quirk: blurs x_t (DEBLUR:731-733, 744-746)
+                elif self.sampling_routine == 'default':
+                    x = self._chain(x, times - 1, collapse=False)
+                elif self.sampling_routine == 'x0_step_down':
+                    x = self._chain(x, times, img=img)
+            img = x
+            times = times - 1
+        return Forward, Backward, img
+
+    @torch.no_grad()
+    def forward_and_backward_2(self, batch_size=16, img=None, noise_level=0, eval=True):
+        """One forward trajectory, then back twice from the same x_T: with D(x0_hat, t-1) (written `img - img + ...`
+        upstream) and with Algorithm 2 (DEBLUR:773-861)."""
+        if eval:
+            self.denoise_fn.eval()
+        T = self.num_timesteps
+        img = rt.check(img)
+        Forward = [img] + self._trajectory(img, 0, T)
+        img = Forward[-1]
+        if self.discrete:
+            img = self._collapse(img)
+            img = img + torch.randn_like(img) * noise_level
+        last_img = img
+        runs = []
+        for alg2 in (False, True):
+            img, times, back = last_img, T, []
+            while times:
+                step = _full_step(batch_size, times - 1, img.device)
+                x = self.denoise_fn(img, step)
+                back.append(img)
+                img = self._chain(x, times, img=img) if alg2 else self._chain(x, times - 1, collapse=False)
+                times = times - 1
+            runs.append((back, img))
+        return Forward, runs[0][0], runs[1][0], runs[0][1], runs[1][1]
+
+    @torch.no_grad()
+    def sample_from_blur(self, batch_size=16, img=None, t=None, times=None, eval=True, start=None):
+        """`sample` for an input that already carries kernels 0..start-1 (DEBLUR:864-925)."""
+        if eval:
+            self.denoise_fn.eval()
+        if t is None:
+            t = self.num_timesteps
+        if start is None:
+            start = 0
+        img = rt.check(img)
+        H, W = img.shape[2:]
+        k = self.gaussian_kernels[0].weight.shape[-1]
+        if t > start and self._uniform() and D.blur_fits_lds(H, W, k):
+            img = D.blur_chain(img, self._taps(img.device), k, self._pad_mode(), step_lo=start, step_hi=t - 1,
+                               taps1d=self._taps1d(img.device))
+        else:
+            for i in range(start, t):
+                img = self._apply_one(i, img)
+        img = self._collapse(img)
+        xt = img
+        direct_recons, img = self._reverse_loop(batch_size, img, t)
+        return xt, direct_recons, img
 
     @torch.no_grad()
     def opt(self, img, t=None):
@@ -329,6 +436,27 @@ class DenoiseDiffusion(nn.Module):
         return noise, direct_recons, img
 
     @torch.no_grad()
+    def forward_and_backward(self, batch_size=16, img=None, t=None, times=None, eval=True):
+        """Noising trajectory with ONE noise draw, then the fixed-noise way back (DENOISE:438-479)."""
+        self.denoise_fn.eval()
+        t = self.num_timesteps if t is None else t
+        ca, cb = self._tables()
+        img = rt.check(img)
+        Forward = [img]
+        noise = torch.randn_like(img)
+        for i in range(t):
+            n_img = D.noise_qsample(img, noise, ca, cb, _full_step(batch_size, i, img.device))
+            Forward.append(n_img)
+        Backward, img = [], n_img
+        while t:
+            step = _full_step(batch_size, t - 1, img.device)
+            x1_bar = self.denoise_fn(img, step)
+            Backward.append(img)
+            img = D.noise_step(img, x1_bar, noise, ca, cb, t, False)
+            t = t - 1
+        return Forward, Backward, img
+
+    @torch.no_grad()
     def all_sample(self, batch_size=16, img=None, t=None, times=None, eval=True):
         if eval:
             self.denoise_fn.eval()
@@ -450,26 +578,74 @@ class ResolutionDiffusion(nn.Module):
             t = t - 1
         return xt, direct_recons, img
 
+    def _reverse_update(self, img, x, times):
+        if self.train_routine == 'Final':
+            if self.sampling_routine == 'default':
+                return self._degrade(x, times - 1)
+            if self.sampling_routine == 'x0_step_down':
+                return self._degrade(x, times, img=img)
+        return x
+
     @torch.no_grad()
     def gen_sample(self, batch_size=16, img=None, t=None, times=None, noise_level=0):
+        """No forward process: `times` reverse updates from the given image (RESOL:460-505)."""
         if t is None:
             t = self.num_timesteps
+        if times is None:
+            times = t
         img = rt.check(img)
         img = img + torch.randn_like(img) * noise_level
         direct_recons = None
         xt = img
-        while t:
-            step = _full_step(batch_size, t - 1, img.device)
+        while times:
+            step = _full_step(batch_size, times - 1, img.device)
             x = self.denoise_fn(img, step)
             if direct_recons is None:
                 direct_recons = x
-            if self.sampling_routine == 'default':
-                x = self._degrade(x, t - 1)
-            elif self.sampling_routine == 'x0_step_down':
-                x = self._degrade(x, t, img=img)
-            img = x
-            t = t - 1
+            img = self._reverse_update(img, x, times)
+            times = times - 1
         return xt, direct_recons, img
+
+    @torch.no_grad()
+    def all_sample(self, batch_size=16, img=None, t=None, times=None):
+        """Every x0 estimate and every x_t of the reverse process (RESOL:508-556)."""
+        if t is None:
+            t = self.num_timesteps
+        if times is None:
+            times = t
+        img = self._degrade(rt.check(img), t)
+        X_0s, X_ts = [], []
+        while times:
+            step = _full_step(batch_size, times - 1, img.device)
+            x = self.denoise_fn(img, step)
+            X_0s.append(x)
+            X_ts.append(img)
+            img = self._reverse_update(img, x, times)
+            times = times - 1
+        return X_0s, X_ts
+
+    @torch.no_grad()
+    def forward_and_backward(self, batch_size=16, img=None, t=None, times=None, eval=True):
+        """The forward trajectory step by step, then every x_t on the way back (RESOL:559-617)."""
+        if eval:
+            self.denoise_fn.eval()
+        if t is None:
+            t = self.num_timesteps
+        if times is None:
+            times = t
+        img = rt.check(img)
+        Forward = [img]
+        for i in range(t):
+            img = self.transform_func(img, i)
+            Forward.append(img)
+        Backward = []
+        while times:
+            step = _full_step(batch_size, times - 1, img.device)
+            x = self.denoise_fn(img, step)
+            Backward.append(img)
+            img = self._reverse_update(img, x, times)
+            times = times - 1
+        return Forward, Backward, img
 
     @torch.no_grad()
     def opt(self, img, t=None):
@@ -488,16 +664,49 @@ class ResolutionDiffusion(nn.Module):
             out = torch.where((t == i).view(-1, 1, 1, 1), x, out)
         return out
 
+    def _final_loss(self, x_start, t):
+        x_blur = self.q_sample(x_start=x_start, t=t)
+        x_recon = self.denoise_fn(x_blur, t)
+        return D.loss(x_start, x_recon, self.loss_type)
+
+    @staticmethod
+    def _random_mean(x_start):
+        """x_start with every (sample, channel) mean replaced by a N(0,1) draw (RESOL:683-691)."""
+        new_mean = torch.randn_like(torch.mean(x_start, [2, 3]))
+        return x_start - torch.mean(x_start, [2, 3], keepdim=True) + new_mean[:, :, None, None]
+
     def p_losses(self, x_start, t):
-        if self.train_routine == 'Final':
+        """RESOL:655-760: 'Final' and its five alternatives."""
+        if self.loss_type not in ('l1', 'l2'):
+            raise NotImplementedError()
+        r = self.train_routine
+        if r == 'Final':
+            return self._final_loss(x_start, t)
+        if r == 'Final_small_noise':
+            return self._final_loss(x_start + 0.001 * torch.randn_like(x_start), t)
+        if r == 'Final_random_mean':
+            return self._final_loss(self._random_mean(x_start), t)
+        if r == 'Final_random_mean_and_actual':
+            loss1 = self._final_loss(x_start, t)
+            return loss1 + self._final_loss(self._random_mean(x_start), t)
+        if r == 'Gradient_norm':
+            # RESOL:738 calls LA.norm(gradient, dim=(1,2,3)), which torch.linalg.norm rejects, so the routine raises upstream;
+            # implemented with its evident intent, the 2-norm over all non-batch dims.
             x_blur = self.q_sample(x_start=x_start, t=t)
-            x_recon = self.denoise_fn(x_blur, t)
-            return D.loss(x_start, x_recon, self.loss_type)
-        if self.train_routine == 'Step':
+            grad_pred = self.denoise_fn(x_blur, t)
+            gradient = x_blur - x_start
+            norm = gradient.flatten(1).norm(dim=1).view(-1, 1, 1, 1)
+            return D.loss(gradient / (norm + 1e-5), grad_pred, self.loss_type)
+        if r == 'Step':
             x_blur = self.q_sample(x_start=x_start, t=t)
-            x_blur_sub = self.q_sample(x_start=x_start, t=t - 1)
+            # `all_blurs[t - 1, b]` with t = 0 indexes the stack from the END (RESOL:641-646): sample b gets step max(t - 1)
+            ts = t - 1
+            m = int(ts.max())
+            if m < 0:
+                raise RuntimeError("stack expects a non-empty TensorList")     # what torch.stack([]) raises upstream
+            x_blur_sub = self.q_sample(x_start=x_start, t=torch.where(ts < 0, ts + (m + 1), ts))
             return D.loss(x_blur_sub, self.denoise_fn(x_blur, t), self.loss_type)
-        raise NotImplementedError(self.train_routine)
+        raise UnboundLocalError("local variable 'loss' referenced before assignment")   # unknown routine upstream (RESOL:760)
 
     def forward(self, x, *args, **kwargs):
         b, c, h, w, device, img_size = *x.shape, x.device, self.image_size

@@ -319,6 +319,160 @@ def cold_sample(net, degrade_step, img, T, routine='x0_step_down', t=None):
     return xt, direct, img
 
 
+def _reverse_update(degrade_step, img, x, t, routine):
+    """One reverse update of Algorithm 1 ('default') / Algorithm 2 ('x0_step_down') from x = net(img, t-1)."""
+    if routine == 'default':
+        for i in range(t - 1):
+            x = degrade_step(x, i)
+        return x
+    if routine == 'x0_step_down':
+        x_times = x
+        for i in range(t):
+            x_times = degrade_step(x_times, i)
+        x_sub = x
+        for i in range(t - 1):
+            x_sub = degrade_step(x_sub, i)
+        return img - x_times + x_sub
+    return x
+
+
+def cold_sample_from(net, degrade_step, img, T, routine='x0_step_down', t=None, start=0):
+    """DEBLUR:864-925 (`sample_from_blur`): the input already carries steps 0..start-1; finish the forward
+    process with steps start..t-1, then sample as cold_sample does."""
+    t = T if t is None else t
+    for i in range(start, t):
+        img = degrade_step(img, i)
+    xt, direct = img, None
+    while t:
+        x = net(img, torch.full((img.shape[0],), t - 1, dtype=torch.long))
+        if direct is None:
+            direct = x
+        img = _reverse_update(degrade_step, img, x, t, routine)
+        t -= 1
+    return xt, direct, img
+
+
+def cold_all_sample(net, degrade_step, img, T, routine='x0_step_down', t=None, times=None):
+    """RESOL:508-556 / DEBLUR:610-689 (non-discrete, uniform kernels): every x0 estimate and every x_t."""
+    t = T if t is None else t
+    times = t if times is None else times
+    for i in range(t):
+        img = degrade_step(img, i)
+    X_0s, X_ts = [], []
+    while times:
+        x = net(img, torch.full((img.shape[0],), times - 1, dtype=torch.long))
+        X_0s.append(x)
+        X_ts.append(img)
+        img = _reverse_update(degrade_step, img, x, times, routine)
+        times -= 1
+    return X_0s, X_ts, img
+
+
+def cold_forward_and_backward(net, degrade_step, img, T, routine='x0_step_down', t=None, times=None):
+    """DEBLUR:692-770 (non-discrete, uniform kernels) / RESOL:559-617: the whole forward trajectory
+    [x0, D(x0,1), ...] and every x_t visited on the way back."""
+    t = T if t is None else t
+    times = t if times is None else times
+    Forward = [img]
+    for i in range(t):
+        img = degrade_step(img, i)
+        Forward.append(img)
+    Backward = []
+    while times:
+        x = net(img, torch.full((img.shape[0],), times - 1, dtype=torch.long))
+        Backward.append(img)
+        img = _reverse_update(degrade_step, img, x, times, routine)
+        times -= 1
+    return Forward, Backward, img
+
+
+def blur_forward_and_backward_2(net, degrade_step, img, T):
+    """DEBLUR:773-861 (non-discrete): one forward trajectory, then the way back twice from the same x_T --
+    with the `img - img + D(x, t-1)` update (Algorithm 1 written the long way) and with Algorithm 2."""
+    Forward = [img]
+    for i in range(T):
+        img = degrade_step(img, i)
+        Forward.append(img)
+    last = img
+    outs = []
+    for routine in ('default', 'x0_step_down'):
+        img, times, back = last, T, []
+        while times:
+            x = net(img, torch.full((img.shape[0],), times - 1, dtype=torch.long))
+            back.append(img)
+            if routine == 'default':
+                img = img - img + _reverse_update(degrade_step, img, x, times, 'default')
+            else:
+                img = _reverse_update(degrade_step, img, x, times, 'x0_step_down')
+            times -= 1
+        outs.append((back, img))
+    return Forward, outs[0][0], outs[1][0], outs[0][1], outs[1][1]
+
+
+def noise_forward_and_backward(net, img, noise, T, ca, cb, t=None):   # DENOISE:438-479 (`noise` = its randn_like draw)
+    t = T if t is None else t
+    B = img.shape[0]
+    Forward = [img]
+    for i in range(t):
+        n_img = noise_q_sample(img, noise, torch.full((B,), i, dtype=torch.long), ca, cb)
+        Forward.append(n_img)
+    Backward, img = [], n_img
+    while t:
+        step = torch.full((B,), t - 1, dtype=torch.long)
+        x1 = net(img, step)
+        Backward.append(img)
+        xt_bar = noise_q_sample(x1, noise, step, ca, cb)
+        xt_sub1 = x1
+        if t - 1 != 0:
+            xt_sub1 = noise_q_sample(x1, noise, torch.full((B,), t - 2, dtype=torch.long), ca, cb)
+        img = img - xt_bar + xt_sub1
+        t -= 1
+    return Forward, Backward, img
+
+
+def pixelate_q_sample_ref(x_start, t, sizes, mode):                   # RESOL:630-652, including its negative-index behaviour
+    """q_sample exactly as written: blur the batch to max(t), stack, pick `all_blurs[t[b], b]` -- so t[b] = -1
+    (train_routine 'Step' at t = 0, RESOL:752) selects the LAST stacked step, max(t), not "no degradation"."""
+    x, blurs = x_start, []
+    for i in range(int(t.max()) + 1):
+        x = pixelate_step(x, sizes[i], mode)
+        blurs.append(x)
+    allb = torch.stack(blurs)                                        # raises on an empty list like the reference
+    return torch.stack([allb[int(t[b]), b] for b in range(t.shape[0])])
+
+
+def pixelate_p_losses(net, x_start, t, sizes, mode, train_routine='Final', loss_type='l1', noise=None, new_mean=None):
+    """RESOL:655-760.  The reference's random draws are arguments: `noise` = randn_like(x_start)
+    ('Final_small_noise'), `new_mean` = randn_like(mean(x_start,[2,3])) ('Final_random_mean*')."""
+    q = lambda z, tt: pixelate_q_sample_ref(z, tt, sizes, mode)
+
+    def shift_mean(z):
+        nm = new_mean.unsqueeze(2).repeat(1, 1, z.shape[2]).unsqueeze(3).repeat(1, 1, 1, z.shape[3])
+        return z - torch.mean(z, [2, 3], keepdim=True) + nm
+    if train_routine == 'Final':
+        return loss_fn(x_start, net(q(x_start, t), t), loss_type)
+    if train_routine == 'Final_small_noise':
+        x_start = x_start + 0.001 * noise
+        return loss_fn(x_start, net(q(x_start, t), t), loss_type)
+    if train_routine == 'Final_random_mean':
+        x_start = shift_mean(x_start)
+        return loss_fn(x_start, net(q(x_start, t), t), loss_type)
+    if train_routine == 'Final_random_mean_and_actual':
+        loss1 = loss_fn(x_start, net(q(x_start, t), t), loss_type)
+        x_start = shift_mean(x_start)
+        return loss1 + loss_fn(x_start, net(q(x_start, t), t), loss_type)
+    if train_routine == 'Gradient_norm':
+        x_blur = q(x_start, t)
+        gradient = x_blur - x_start
+        # RESOL:738 calls LA.norm(gradient, dim=(1,2,3)), which torch.linalg.norm rejects (dim must have length 1 or 2):
+        # the routine raises upstream.  Restated with the evident intent, the 2-norm over all non-batch dims (parity unpinned).
+        norm = gradient.flatten(1).norm(dim=1).view(-1, 1, 1, 1)
+        return loss_fn(gradient / (norm + 1e-5), net(x_blur, t), loss_type)
+    if train_routine == 'Step':
+        return loss_fn(q(x_start, t - 1), net(q(x_start, t), t), loss_type)
+    raise NotImplementedError(train_routine)
+
+
 def noise_sample(net, img, T, ca, cb, fixed_noise, t=None):           # DENOISE:342-375 (est. noise) / 413-432 (fixed)
     t = T if t is None else t
     noise, direct = img, None

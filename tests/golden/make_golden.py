@@ -105,12 +105,89 @@ def diffusion_cases():
     return out
 
 
+def variant_cases(net_sd):
+    """Sampler variants (SURVEY §8 row C1 "and variants") and the resolution training routines (row A6)."""
+    import contextlib
+    import io
+    out = {}
+    g = torch.Generator().manual_seed(SEED + 1)
+    cpu = lambda L: [z.clone() for z in L]
+    quiet = lambda: contextlib.redirect_stdout(io.StringIO())       # the reference prints its loop counters
+    # ---- deblurring: forward_and_backward, forward_and_backward_2, sample_from_blur, all_sample ------------
+    ref = ref_shim.load("deblurring")
+    net = ref.Unet(dim=8, dim_mults=(1, 2), channels=3)
+    net.load_state_dict(net_sd)
+    for routine, ks, std in (("Incremental", 3, 0.4), ("Exponential_reflect", 5, 0.2)):
+        for sampling in ("default", "x0_step_down"):
+            T = 4
+            d = ref.GaussianDiffusion(net, image_size=16, device_of_kernel="cpu", channels=3, timesteps=T, kernel_std=std, kernel_size=ks,
+                                      blur_routine=routine, sampling_routine=sampling)
+            x = images(2, 3, 16, g)
+            with torch.no_grad(), quiet():
+                F1, B1, i1 = d.forward_and_backward(batch_size=2, img=x)
+                F2, Ba, Bb, ia, ib = d.forward_and_backward_2(batch_size=2, img=x)
+                half = x
+                for i in range(2):
+                    half = d.gaussian_kernels[i](half)
+                xt, direct, i3 = d.sample_from_blur(batch_size=2, img=half, start=2)
+                X0, Xt = d.all_sample(batch_size=2, img=x, times=3)
+            out[f"deblur/{routine}/{sampling}"] = dict(
+                T=T, ks=ks, std=std, x=x, fab=(cpu(F1), cpu(B1), i1), fab2=(cpu(F2), cpu(Ba), cpu(Bb), ia, ib), half=half,
+                from_blur=(xt, direct, i3), all_sample=(cpu(X0), cpu(Xt)),
+                kernels=[m.weight.detach().clone() for m in d.gaussian_kernels], modes=[m.padding_mode for m in d.gaussian_kernels])
+    # ---- denoising: forward_and_backward (its randn_like draw replayed from the same seed) -----------------
+    ref = ref_shim.load("denoising")
+    d = ref.GaussianDiffusion(net, image_size=16, channels=3, timesteps=5, sampling_routine="x0_step_down")
+    x = images(2, 3, 16, g)
+    torch.manual_seed(SEED + 2)
+    noise = torch.randn_like(x)
+    torch.manual_seed(SEED + 2)
+    with torch.no_grad(), quiet():
+        F1, B1, i1 = d.forward_and_backward(batch_size=2, img=x)
+    out["denoise/fab"] = dict(T=5, x=x, noise=noise, fab=(cpu(F1), cpu(B1), i1))
+    # ---- resolution: all_sample, forward_and_backward, gen_sample(times), train routines ------------------
+    ref = ref_shim.load("resolution")
+    for routine in ("Incremental_factor_2", "Incremental_area_factor_2"):
+        for sampling in ("default", "x0_step_down"):
+            T = 3
+            d = ref.GaussianDiffusion(net, image_size=16, device_of_kernel="cpu", channels=3, timesteps=T, resolution_routine=routine,
+                                      sampling_routine=sampling)
+            x = images(2, 3, 16, g)
+            with torch.no_grad(), quiet():
+                X0, Xt = d.all_sample(batch_size=2, img=x)
+                F1, B1, i1 = d.forward_and_backward(batch_size=2, img=x)
+                gs = d.gen_sample(batch_size=2, img=x, times=2)
+            out[f"resolution/{routine}/{sampling}"] = dict(T=T, x=x, all_sample=(cpu(X0), cpu(Xt)), fab=(cpu(F1), cpu(B1), i1), gen_times2=gs)
+    x, t = images(3, 3, 16, g), torch.tensor([1, 0, 2])
+    for tr in ("Final", "Final_small_noise", "Final_random_mean", "Final_random_mean_and_actual", "Step"):
+        for loss_type in ("l1", "l2"):
+            d = ref.GaussianDiffusion(net, image_size=16, device_of_kernel="cpu", channels=3, timesteps=3, loss_type=loss_type,
+                                      resolution_routine="Incremental_factor_2", train_routine=tr)
+            torch.manual_seed(SEED + 3)
+            noise, _ = torch.randn_like(x), torch.manual_seed(SEED + 3)
+            new_mean, _ = torch.randn_like(x.mean((2, 3))), torch.manual_seed(SEED + 3)
+            net.zero_grad()
+            loss = d.p_losses(x, t)
+            loss.backward()
+            out[f"resolution/train/{tr}/{loss_type}"] = dict(x=x, t=t, noise=noise, new_mean=new_mean, loss=loss.detach().clone(),
+                                                             grads=({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+                                                                    if loss_type == "l1" else None))
+    return out
+
+
 def main():
     assert ref_shim.available(), "needs /root/reference (build container)"
+    if "--variants" in sys.argv:                                      # only (re)write variants.pt
+        sd = torch.load(os.path.join(HERE, "diffusion.pt"), weights_only=False)["deblur/net_sd"]
+        torch.save(variant_cases(sd), os.path.join(HERE, "variants.pt"))
+        print("variants.pt", os.path.getsize(os.path.join(HERE, "variants.pt")) // 1024, "KiB")
+        return
     ref = ref_shim.load("deblurring")
     torch.save(unet_case(ref), os.path.join(HERE, "unet_dim8.pt"))
     torch.save(model_case(ref), os.path.join(HERE, "model_ch32.pt"))
-    torch.save(diffusion_cases(), os.path.join(HERE, "diffusion.pt"))
+    dc = diffusion_cases()
+    torch.save(dc, os.path.join(HERE, "diffusion.pt"))
+    torch.save(variant_cases(dc["deblur/net_sd"]), os.path.join(HERE, "variants.pt"))
     # torchgeometry boundary: values observed when the reference builds its kernels through the shim (SURVEY.md §8c)
     k = ref_shim.get_gaussian_kernel2d((11, 11), (7.0, 7.0))
     print("k=11 sigma=7 centre %.10f corner %.10f" % (k[5, 5].item(), k[0, 0].item()))

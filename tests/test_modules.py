@@ -141,6 +141,110 @@ def test_resolution_golden(mbe):
         assert (xt.cpu() - c["xt"]).abs().max() <= (0.0 if exact else 1e-5) and (img.cpu() - c["img"]).abs().max() <= 1e-4, key
 
 
+def _lists_close(a, b, tol):
+    assert len(a) == len(b)
+    for u, v in zip(a, b):
+        assert (u.cpu() - v).abs().max() <= tol
+
+
+def test_deblurring_sampler_variants_golden(mbe):
+    """forward_and_backward(_2), sample_from_blur, all_sample (DEBLUR:610-925) against the reference's own outputs."""
+    from deblurring_diffusion_pytorch import GaussianDiffusion
+    g = load("variants.pt")
+    net = _net(mbe, load("diffusion.pt")["deblur/net_sd"])
+    for key, c in g.items():
+        if not key.startswith("deblur/"):
+            continue
+        _, routine, sampling = key.split("/")
+        d = GaussianDiffusion(net, image_size=16, device_of_kernel="cuda", channels=3, timesteps=c["T"], kernel_std=c["std"],
+                              kernel_size=c["ks"], blur_routine=routine, sampling_routine=sampling).to(mbe.device)
+        x = mbe.to(c["x"])
+        F1, B1, i1 = d.forward_and_backward(batch_size=2, img=x)
+        _lists_close(F1, c["fab"][0], 2e-6), _lists_close(B1, c["fab"][1], 1e-4), _lists_close([i1], [c["fab"][2]], 1e-4)
+        F2, Ba, Bb, ia, ib = d.forward_and_backward_2(batch_size=2, img=x)
+        _lists_close(F2, c["fab2"][0], 2e-6), _lists_close(Ba, c["fab2"][1], 1e-4), _lists_close(Bb, c["fab2"][2], 1e-4)
+        _lists_close([ia, ib], list(c["fab2"][3:]), 1e-4)
+        _lists_close(list(d.sample_from_blur(batch_size=2, img=mbe.to(c["half"]), start=2)), list(c["from_blur"]), 1e-4)
+        X0, Xt = d.all_sample(batch_size=2, img=x, times=3)
+        _lists_close(X0, c["all_sample"][0], 1e-4), _lists_close(Xt, c["all_sample"][1], 1e-4)
+
+
+def test_denoising_forward_and_backward(mbe):
+    """DENOISE:438-479; its single randn_like draw is replayed from the same seed for the oracle."""
+    from denoising_diffusion_pytorch import GaussianDiffusion
+    sd = load("diffusion.pt")["deblur/net_sd"]
+    c = load("variants.pt")["denoise/fab"]
+    net = _net(mbe, sd)
+    d = GaussianDiffusion(net, image_size=16, channels=3, timesteps=c["T"], sampling_routine="x0_step_down").to(mbe.device)
+    x = mbe.to(c["x"])
+    torch.manual_seed(11)
+    noise = torch.randn_like(x)
+    torch.manual_seed(11)
+    F1, B1, i1 = d.forward_and_backward(batch_size=2, img=x)
+    ca, cb = O.cosine_tables(c["T"])
+    rF, rB, ri = O.noise_forward_and_backward(lambda im, st: O.unet_forward(sd, im, st), c["x"], noise.cpu(), c["T"], ca, cb)
+    _lists_close(F1, rF, 1e-6), _lists_close(B1, rB, 1e-4), _lists_close([i1], [ri], 1e-4)
+
+
+def test_resolution_sampler_variants_golden(mbe):
+    """all_sample, forward_and_backward, gen_sample(times=) (RESOL:460-617) against the reference's own outputs."""
+    from resolution_diffusion_pytorch import GaussianDiffusion
+    g = load("variants.pt")
+    net = _net(mbe, load("diffusion.pt")["deblur/net_sd"])
+    for key, c in g.items():
+        if not key.startswith("resolution/Incremental"):
+            continue
+        _, routine, sampling = key.split("/")
+        d = GaussianDiffusion(net, image_size=16, device_of_kernel="cuda", channels=3, timesteps=c["T"], resolution_routine=routine,
+                              sampling_routine=sampling)
+        x = mbe.to(c["x"])
+        X0, Xt = d.all_sample(batch_size=2, img=x)
+        _lists_close(X0, c["all_sample"][0], 1e-4), _lists_close(Xt, c["all_sample"][1], 1e-4)
+        F1, B1, i1 = d.forward_and_backward(batch_size=2, img=x)
+        _lists_close(F1, c["fab"][0], 0.0 if "_area" in routine else 1e-5)
+        _lists_close(B1, c["fab"][1], 1e-4), _lists_close([i1], [c["fab"][2]], 1e-4)
+        _lists_close(list(d.gen_sample(batch_size=2, img=x, times=2)), list(c["gen_times2"]), 1e-4)
+
+
+def test_resolution_train_routines(mbe):
+    """RESOL:655-760.  Deterministic routines against the reference's losses and gradients; the ones that draw random
+    numbers against the oracle fed with the same draw (replayed from the seed on the product's device)."""
+    from resolution_diffusion_pytorch import GaussianDiffusion
+    g = load("variants.pt")
+    sd = load("diffusion.pt")["deblur/net_sd"]
+    sizes = O.pixelate_sizes("Incremental_factor_2", 3, 16)
+    for tr in ("Final", "Step", "Final_small_noise", "Final_random_mean", "Final_random_mean_and_actual", "Gradient_norm"):
+        for loss_type in ("l1", "l2"):
+            c = g[f"resolution/train/{'Final' if tr == 'Gradient_norm' else tr}/{loss_type}"]
+            net = _net(mbe, sd)
+            d = GaussianDiffusion(net, image_size=16, device_of_kernel="cuda", channels=3, timesteps=3, loss_type=loss_type,
+                                  resolution_routine="Incremental_factor_2", train_routine=tr)
+            x, t = mbe.to(c["x"]), mbe.to(c["t"])
+            torch.manual_seed(5)
+            noise = torch.randn_like(x)
+            torch.manual_seed(5)
+            new_mean = torch.randn_like(torch.mean(x, [2, 3]))
+            torch.manual_seed(5)
+            loss = d.p_losses(x, t)
+            loss.backward()
+            if tr in ("Final", "Step"):
+                ref_loss, ref_grads = c["loss"], c["grads"]
+            else:
+                ps = {k: (v.clone().requires_grad_() if v.is_floating_point() else v) for k, v in sd.items()}
+                ref_loss = O.pixelate_p_losses(lambda im, st: O.unet_forward(ps, im, st), c["x"], c["t"], sizes, "bicubic", tr, loss_type,
+                                               noise=noise.cpu(), new_mean=new_mean.cpu())
+                ref_loss.backward()
+                ref_grads = {k: v.grad for k, v in ps.items() if v.is_floating_point() and v.grad is not None}
+                ref_loss = ref_loss.detach()
+            assert abs(loss.item() - ref_loss.item()) <= 1e-5 * max(1.0, abs(ref_loss.item())), (tr, loss_type)
+            if ref_grads is not None:
+                grad_check([(k, p) for k, p in net.named_parameters() if k in ref_grads], ref_grads)
+    d = GaussianDiffusion(net, image_size=16, device_of_kernel="cuda", channels=3, timesteps=3, resolution_routine="Incremental_factor_2",
+                          train_routine="Step")
+    with pytest.raises(RuntimeError):                     # every t = 0: the reference stacks an empty list (RESOL:641)
+        d.p_losses(x, torch.zeros_like(t))
+
+
 def test_defading_golden(mbe):
     from defading_diffusion_pytorch import GaussianDiffusion
     g = load("diffusion.pt")

@@ -81,6 +81,72 @@ def test_degradations_and_samplers_match_golden():
             assert (img - c["img"]).abs().max() <= 1e-6, key
 
 
+def _close_lists(a, b, tol=1e-6):
+    assert len(a) == len(b)
+    for u, v in zip(a, b):
+        assert (u - v).abs().max() <= tol
+
+
+def test_sampler_variants_match_golden():
+    """forward_and_backward(_2), sample_from_blur, all_sample, gen_sample(times) of the reference."""
+    g = load("variants.pt")
+    sd = load("diffusion.pt")["deblur/net_sd"]
+    net = lambda im, st: O.unet_forward(sd, im, st)
+    for key, c in g.items():
+        if key.startswith("deblur/"):
+            sampling = key.split("/")[2]
+            step = lambda z, i: O.blur_step(z, c["kernels"][i], c["modes"][i])
+            F1, B1, i1 = O.cold_forward_and_backward(net, step, c["x"], c["T"], sampling)
+            _close_lists(F1, c["fab"][0]), _close_lists(B1, c["fab"][1]), _close_lists([i1], [c["fab"][2]])
+            F2, Ba, Bb, ia, ib = O.blur_forward_and_backward_2(net, step, c["x"], c["T"])
+            _close_lists(F2, c["fab2"][0]), _close_lists(Ba, c["fab2"][1]), _close_lists(Bb, c["fab2"][2])
+            _close_lists([ia, ib], list(c["fab2"][3:]))
+            _close_lists(list(O.cold_sample_from(net, step, c["half"], c["T"], sampling, start=2)), list(c["from_blur"]))
+            X0, Xt, _ = O.cold_all_sample(net, step, c["x"], c["T"], sampling, times=3)
+            _close_lists(X0, c["all_sample"][0][:3]), _close_lists(Xt, c["all_sample"][1])
+        elif key == "denoise/fab":
+            ca, cb = O.cosine_tables(c["T"])
+            F1, B1, i1 = O.noise_forward_and_backward(net, c["x"], c["noise"], c["T"], ca, cb)
+            _close_lists(F1, c["fab"][0]), _close_lists(B1, c["fab"][1]), _close_lists([i1], [c["fab"][2]])
+        elif key.startswith("resolution/Incremental"):
+            _, routine, sampling = key.split("/")
+            mode = "area" if "_area" in routine else "bicubic"
+            sizes = O.pixelate_sizes(routine, c["T"], 16)
+            step = lambda z, i: O.pixelate_step(z, sizes[i], mode)
+            X0, Xt, _ = O.cold_all_sample(net, step, c["x"], c["T"], sampling)
+            _close_lists(X0, c["all_sample"][0]), _close_lists(Xt, c["all_sample"][1])
+            F1, B1, i1 = O.cold_forward_and_backward(net, step, c["x"], c["T"], sampling)
+            _close_lists(F1, c["fab"][0]), _close_lists(B1, c["fab"][1]), _close_lists([i1], [c["fab"][2]])
+            # gen_sample(times=2): no forward process, two reverse updates from the given image (RESOL:460-505)
+            img, direct = c["x"], None
+            for tt in (2, 1):
+                x = net(img, torch.full((2,), tt - 1, dtype=torch.long))
+                direct = x if direct is None else direct
+                img = O._reverse_update(step, img, x, tt, sampling)
+            _close_lists([c["x"], direct, img], list(c["gen_times2"]))
+
+
+def test_resolution_train_routines_match_golden():
+    """RESOL:655-760 incl. the `t - 1 = -1` indexing of 'Step' (SURVEY §8 row A6)."""
+    g = load("variants.pt")
+    sd0 = load("diffusion.pt")["deblur/net_sd"]
+    sizes = O.pixelate_sizes("Incremental_factor_2", 3, 16)
+    for key, c in g.items():
+        if not key.startswith("resolution/train/"):
+            continue
+        _, _, tr, loss_type = key.split("/")
+        ps = {k: (v.clone().requires_grad_() if v.is_floating_point() else v) for k, v in sd0.items()}
+        net = lambda im, st: O.unet_forward(ps, im, st)
+        loss = O.pixelate_p_losses(net, c["x"], c["t"], sizes, "bicubic", tr, loss_type, noise=c["noise"], new_mean=c["new_mean"])
+        assert (loss - c["loss"]).abs() <= 1e-6 * max(1.0, c["loss"].abs().item()), key
+        if c["grads"] is not None:
+            loss.backward()
+            for k, ref in c["grads"].items():
+                assert (ps[k].grad - ref).abs().max() <= 2e-6 * max(1.0, ref.abs().max().item()), (key, k)
+    with pytest.raises(RuntimeError):                                 # 'Step' with every t = 0: the reference stacks an empty list
+        O.pixelate_q_sample_ref(g["resolution/train/Step/l1"]["x"], torch.tensor([-1, -1, -1]), sizes, "bicubic")
+
+
 @pytest.mark.skipif(not ref_shim.available(), reason="reference tree only exists in the build container")
 def test_oracle_bit_exact_vs_live_reference():
     ref = ref_shim.load("deblurring")
