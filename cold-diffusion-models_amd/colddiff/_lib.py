@@ -111,4 +111,12 @@ def get():
     global _instance
     if _instance is None:
         _instance = Lib(LIB_PATH)
+        # tuning hooks of include/colddiff.h from the environment (results do not depend on them)
+        tile, waves = os.environ.get("COLDDIFF_SPX_TILE"), os.environ.get("COLDDIFF_SPX_WAVES")
+        if tile:
+            _instance.cdf_conv_gemm_bf16x_tile(*[int(v) for v in tile.split("x")])
+        if waves:
+            _instance.cdf_conv_gemm_bf16x_waves(int(waves))
+        if os.environ.get("COLDDIFF_SPX_MAX_BM"):
+            _instance.cdf_conv_gemm_bf16x_max_bm(int(os.environ["COLDDIFF_SPX_MAX_BM"]))
     return _instance

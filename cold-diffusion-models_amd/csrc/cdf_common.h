@@ -49,13 +49,33 @@ __device__ __forceinline__ unsigned cdf_f2bf(float x) {        // round-to-neare
     return u >> 16;
 }
 __device__ __forceinline__ float cdf_bf2f(unsigned h) { return __uint_as_float(h << 16); }
+// two floats -> packed bf16 pair (a in the low half), round to nearest even.  gfx950 has the conversion in hardware
+// (v_cvt_pk_bf16_f32: one instruction per pair instead of ~8 integer ops); the emulator build keeps the integer form.
+#ifndef CDF_HWCVT
+#define CDF_HWCVT 1
+#endif
+__device__ __forceinline__ unsigned cdf_pack2bf(float a, float b) {
+#if defined(CDF_EMU) || !CDF_HWCVT
+    return cdf_f2bf(a) | (cdf_f2bf(b) << 16);
+#else
+    typedef __bf16 bf16x2_cvt_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_cvt_t __attribute__((ext_vector_type(2)));
+    const f32x2_cvt_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_cvt_t));
+#endif
+}
 // x = hi + lo (+ O(2^-16 |x|)): the two bf16 planes the split-precision GEMMs multiply
+__device__ __forceinline__ void cdf_split4(float v0, float v1, float v2, float v3, uint2& hi, uint2& lo) {
+    hi.x = cdf_pack2bf(v0, v1);
+    hi.y = cdf_pack2bf(v2, v3);
+    lo.x = cdf_pack2bf(v0 - __uint_as_float(hi.x << 16), v1 - __uint_as_float(hi.x & 0xFFFF0000u));
+    lo.y = cdf_pack2bf(v2 - __uint_as_float(hi.y << 16), v3 - __uint_as_float(hi.y & 0xFFFF0000u));
+}
 __device__ __forceinline__ void cdf_split_store4(unsigned short* hi, unsigned short* lo, const float* v) {
-    const unsigned h0 = cdf_f2bf(v[0]), h1 = cdf_f2bf(v[1]), h2 = cdf_f2bf(v[2]), h3 = cdf_f2bf(v[3]);
-    const unsigned l0 = cdf_f2bf(v[0] - cdf_bf2f(h0)), l1 = cdf_f2bf(v[1] - cdf_bf2f(h1));
-    const unsigned l2 = cdf_f2bf(v[2] - cdf_bf2f(h2)), l3 = cdf_f2bf(v[3] - cdf_bf2f(h3));
-    *(uint2*)hi = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-    *(uint2*)lo = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+    uint2 h, l;
+    cdf_split4(v[0], v[1], v[2], v[3], h, l);
+    *(uint2*)hi = h;
+    *(uint2*)lo = l;
 }
 
 // ---- status codes (returned by every extern "C" entry point) -------------------------

@@ -93,7 +93,7 @@ struct SpArgs {
 // MFMA-bound): hi = x truncated to bf16 (the residual x - hi is exact in fp32 and lands in lo, so
 // truncating hi costs nothing), lo = (x - hi) truncated to bf16: x = hi + lo + O(2^-16 |x|).
 __device__ __forceinline__ unsigned cdf_pack_hi16(unsigned u0, unsigned u1) { return (u0 >> 16) | (u1 & 0xFFFF0000u); }
-__device__ __forceinline__ void cdf_split4(const float4& v, uint2& hi, uint2& lo) {
+__device__ __forceinline__ void cdf_split4_trunc(const float4& v, uint2& hi, uint2& lo) {
     const unsigned u0 = __float_as_uint(v.x), u1 = __float_as_uint(v.y), u2 = __float_as_uint(v.z), u3 = __float_as_uint(v.w);
     hi.x = cdf_pack_hi16(u0, u1);
     hi.y = cdf_pack_hi16(u2, u3);
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_sp_kernel(SpArgs a) {
             const float keep = ((a_ok >> p) & 1u) ? 1.0f : 0.0f;       // loaded values are finite: zeroing by multiplication
             const float4 v = make_float4(ra[p].x * keep, ra[p].y * keep, ra[p].z * keep, ra[p].w * keep);
             if (SPLIT > 1) {
-                cdf_split4(v, hi, lo);
+                cdf_split4_trunc(v, hi, lo);
             } else {      // plain bf16 operands: round to nearest even
                 hi.x = cdf_f2bf(v.x) | (cdf_f2bf(v.y) << 16);
                 hi.y = cdf_f2bf(v.z) | (cdf_f2bf(v.w) << 16);
@@ -367,10 +367,10 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_sp_kernel(SpWgradArgs a) {
         for (int p = 0; p < 4; ++p) {
             const int off = ((tid >> 5) + 8 * p) * BC + c4;
             uint2 hi, lo;
-            cdf_split4(ra[p], hi, lo);
+            cdf_split4_trunc(ra[p], hi, lo);
             *(uint2*)(st + off) = hi;
             *(uint2*)(st + PLANE + off) = lo;
-            cdf_split4(rb[p], hi, lo);
+            cdf_split4_trunc(rb[p], hi, lo);
             *(uint2*)(st + 2 * PLANE + off) = hi;
             *(uint2*)(st + 3 * PLANE + off) = lo;
         }
@@ -464,11 +464,10 @@ __global__ void split_bf16_kernel(const float* x, int ldx, unsigned short* hi, u
         const int c = (int)(i % C4) * 4;
         const long long r = i / C4;
         const float4 v = *(const float4*)(x + r * ldx + c);
-        const unsigned h0 = cdf_f2bf(v.x), h1 = cdf_f2bf(v.y), h2 = cdf_f2bf(v.z), h3 = cdf_f2bf(v.w);
-        const unsigned l0 = cdf_f2bf(v.x - cdf_bf2f(h0)), l1 = cdf_f2bf(v.y - cdf_bf2f(h1));
-        const unsigned l2 = cdf_f2bf(v.z - cdf_bf2f(h2)), l3 = cdf_f2bf(v.w - cdf_bf2f(h3));
-        *(uint2*)(hi + r * ldo + c) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-        *(uint2*)(lo + r * ldo + c) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+        uint2 h, l;
+        cdf_split4(v.x, v.y, v.z, v.w, h, l);
+        *(uint2*)(hi + r * ldo + c) = h;
+        *(uint2*)(lo + r * ldo + c) = l;
     }
 }
 
@@ -493,8 +492,8 @@ struct SpxArgs {
     SpPhase ph[4];
 };
 
-template <int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ void __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) conv_igemm_spx_kernel(SpxArgs a) {
+template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC = 512 / (64 * WM * WN)>
+__global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxArgs a) {
     // Block tile BM x BN, WM x WN waves of (BM/WM) x (BN/WN), BK = 32, NSTAGE LDS stages.  Two shapes of the template are
     // used: 4 waves (2 x 2) on a 64/128 x 64/128 tile with 2 stages, two blocks per CU; and 8 waves (4 x 2) on a
     // 256 x 128 tile with 3 stages, one block per CU -- the same 8 waves per CU, but the DMA of chunk it+2 is in flight
@@ -1105,6 +1104,20 @@ static int fill_phases(SpPhase* ph, int nphase, const int* pd, const char* who) 
 }
 
 static int g_spx_bm = 0, g_spx_bn = 0;     // 0 = automatic
+static int g_spx_waves = 0;                // 0 = automatic; 4 / 8 = waves of the 128 x 128 tile
+static int g_spx_max_bm = 0;               // 0 / 256 = no cap; 128 = the automatic choice never takes the 256-row tile
+
+extern "C" int cdf_conv_gemm_bf16x_max_bm(int bm) {
+    CDF_REQUIRE(bm == 0 || bm == 128 || bm == 256, "cdf_conv_gemm_bf16x_max_bm: 0, 128 or 256");
+    g_spx_max_bm = bm;
+    return 0;
+}
+
+extern "C" int cdf_conv_gemm_bf16x_waves(int waves) {
+    CDF_REQUIRE(waves == 0 || waves == 4 || waves == 8, "cdf_conv_gemm_bf16x_waves: 0 (auto), 4 or 8");
+    g_spx_waves = waves;
+    return 0;
+}
 
 extern "C" int cdf_conv_gemm_bf16x_tile(int bm, int bn) {
     CDF_REQUIRE((bm == 0 || bm == 64 || bm == 128 || bm == 256) && (bn == 0 || bn == 64 || bn == 128), "cdf_conv_gemm_bf16x_tile: bm is 0 (auto), 64, 128 or 256 (with bn = 128), bn 0, 64 or 128");
@@ -1113,7 +1126,7 @@ extern "C" int cdf_conv_gemm_bf16x_tile(int bm, int bn) {
     return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC = 512 / (64 * WM * WN)>
 static int launch_igemm_spx(const SpxArgs& a, int M, hipStream_t s) {
     constexpr size_t stages = (size_t)NSTAGE * 2 * (BM + BN) * 32 * sizeof(unsigned short) + (CDF_MAX_TAPS + 1) * sizeof(int);
     constexpr size_t epi = (size_t)BM * (BN + 8) * sizeof(float);
@@ -1123,12 +1136,12 @@ static int launch_igemm_spx(const SpxArgs& a, int M, hipStream_t s) {
 #ifndef CDF_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_spx_kernel<BM, BN, WM, WN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_spx_kernel<BM, BN, WM, WN, NSTAGE, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
 #endif
     const int tiles = cdf_cdiv(M, BM) * cdf_cdiv(a.Cout, BN);
-    CDF_LAUNCH((conv_igemm_spx_kernel<BM, BN, WM, WN, NSTAGE>), dim3(tiles, a.nphase), dim3(64 * WM * WN), lds, s, a);
+    CDF_LAUNCH((conv_igemm_spx_kernel<BM, BN, WM, WN, NSTAGE, OCC>), dim3(tiles, a.nphase), dim3(64 * WM * WN), lds, s, a);
     return cdf_check_launch("conv_igemm_spx");
 }
 
@@ -1163,11 +1176,14 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
     const bool n64 = g_spx_bn ? g_spx_bn == 64 : Cout <= 64;
     const long long tiles128 = (long long)cdf_cdiv(M, 128) * cdf_cdiv(Cout, n64 ? 64 : 128) * nphase;
     bool m64 = tiles128 < 384;
-    bool m256 = !n64 && tiles128 >= 1024;
+    bool m256 = !n64 && tiles128 >= 1024 && g_spx_max_bm != 128;
     if (g_spx_bm) { m64 = g_spx_bm == 64; m256 = g_spx_bm == 256 && !n64; }
     if (m256) return launch_igemm_spx<256, 128, 4, 2, 3>(a, M, CDF_S);
     if (n64) return m64 ? launch_igemm_spx<64, 64, 2, 2, 2>(a, M, CDF_S) : launch_igemm_spx<128, 64, 2, 2, 2>(a, M, CDF_S);
-    return m64 ? launch_igemm_spx<64, 128, 2, 2, 2>(a, M, CDF_S) : launch_igemm_spx<128, 128, 2, 2, 2>(a, M, CDF_S);
+    if (m64) return launch_igemm_spx<64, 128, 2, 2, 2>(a, M, CDF_S);
+    // 128 x 128 with 8 waves (4 x 2 of 32 x 64), still two blocks per CU: 16 waves per CU instead of 8
+    if (g_spx_waves == 8) return launch_igemm_spx<128, 128, 4, 2, 2, 2>(a, M, CDF_S);
+    return launch_igemm_spx<128, 128, 2, 2, 2>(a, M, CDF_S);
 }
 
 static int g_wgrad_stack = 1;                  // tuning / test hook (cdf_conv_wgrad_bf16x_stack)

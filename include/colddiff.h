@@ -160,6 +160,10 @@ int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void*
  * 256 -- the latter with bn = 128 --, bn 64 or 128; 0 = automatic choice from the problem size).  Process-wide; results
  * do not depend on it. */
 int cdf_conv_gemm_bf16x_tile(int bm, int bn);
+/* tuning / test hook: waves of the 128 x 128 tile of cdf_conv_gemm_bf16x: 0 (default: 4), 4 or 8 (4 x 2 waves of 32 x 64, two blocks per CU) */
+int cdf_conv_gemm_bf16x_waves(int waves);
+/* tuning / test hook: upper bound of the AUTOMATIC row-tile choice of cdf_conv_gemm_bf16x: 0 / 256 = none, 128 = never the 256 x 128 tile */
+int cdf_conv_gemm_bf16x_max_bm(int bm);
 /* Tuning / test hook: allow (1, default) or forbid (0) the two-taps-per-tile form of cdf_conv_wgrad_bf16x used when
  * CA <= 64 < CB.  Process-wide; results do not depend on it. */
 int cdf_conv_wgrad_bf16x_stack(int enable);

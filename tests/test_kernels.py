@@ -673,15 +673,17 @@ def test_conv_presplit(be, case):
     _spx_case(be, *case)
 
 
-@pytest.mark.parametrize("tile", [(256, 128), (128, 128), (128, 64), (64, 128), (64, 64)])
+@pytest.mark.parametrize("tile", [(256, 128, 0), (128, 128, 4), (128, 128, 8), (128, 64, 0), (64, 128, 0), (64, 64, 0)])
 def test_conv_presplit_forced_tiles(be, tile):
-    """Every block-tile instantiation of the pre-split GEMM on a shape with ragged M and N tiles (the automatic
-    choice would only ever pick the 64-row tiles at emulator-sized problems)."""
-    be.L.cdf_conv_gemm_bf16x_tile(*tile)
+    """Every block-tile instantiation of the pre-split GEMM (incl. the 8-wave form of the 128 x 128 tile) on a shape with
+    ragged M and N tiles (the automatic choice would only ever pick the 64-row tiles at emulator-sized problems)."""
+    be.L.cdf_conv_gemm_bf16x_tile(*tile[:2])
+    be.L.cdf_conv_gemm_bf16x_waves(tile[2])
     try:
         _spx_case(be, 3, 40, 72, 7, 3, 1, 1)
     finally:
         be.L.cdf_conv_gemm_bf16x_tile(0, 0)
+        be.L.cdf_conv_gemm_bf16x_waves(0)
 
 
 @pytest.mark.gpu

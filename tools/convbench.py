@@ -7,6 +7,8 @@ from colddiff import _lib, convdesc as cd
 L = _lib.get(); dev = torch.device("cuda:0")
 if os.environ.get('KB_TILE'):
     L.cdf_conv_gemm_bf16x_tile(*[int(v) for v in os.environ['KB_TILE'].split('x')])
+if os.environ.get('KB_WAVES'):
+    L.cdf_conv_gemm_bf16x_waves(int(os.environ['KB_WAVES']))
 
 S = lambda: torch.cuda.current_stream().cuda_stream
 P = lambda t: 0 if t is None else t.data_ptr()
@@ -21,7 +23,10 @@ def timeit(fn):
     return e0.elapsed_time(e1) / iters
 shapes = [(64,128,128,3),(128,64,128,3),(128,256,64,3),(256,128,64,3),(256,512,32,3),(512,256,32,3),(512,1024,16,3),(1024,512,16,3),(1024,2048,16,3),(64,384,128,1)]
 only = os.environ.get("KB_ONLY")
+if os.environ.get("KB_SHAPES"):
+    shapes = [tuple(int(v) for v in t.split("-")) for t in os.environ["KB_SHAPES"].split(",")]
 for (Cin,Cout,H,k) in shapes:
+    if os.environ.get("KB_F32", "1") != "1": break
     if only and only != f"{Cin}-{Cout}-{H}": continue
     x = torch.randn(B,H,H,r4(Cin),device=dev); w = torch.randn(k*k,Cin,r4(Cout),device=dev)*0.05; y = torch.empty(B,H,H,r4(Cout),device=dev)
     p = cd.conv_fwd(H,H,k,k,1,k//2,k//2,k//2,k//2)
@@ -79,6 +84,11 @@ if os.environ.get("KB_SPX", "1") == "1":
         fl = 2.0*B*H*H*Cin*Cout*k*k
         ms = timeit(lambda: L.cdf_conv_gemm_bf16x(P(xs[0]),P(xs[1]),Cin,P(zero),P(hi),P(lo),ldk,P(y),y.shape[-1],B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,S()))
         print(f"spx   {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv", flush=True)
+        if os.environ.get("KB_EPI", "1") == "1":      # the ConvNeXt conv1 form: bias + GELU, pre-activation kept, output as bf16 planes only
+            bias = torch.randn(Cout, device=dev); pre = torch.empty(B,H,H,Cout,device=dev)
+            yh = torch.empty(B,H,H,Cout,dtype=torch.int16,device=dev); yl = torch.empty_like(yh)
+            ms = timeit(lambda: L.cdf_conv_gemm_bf16x(P(xs[0]),P(xs[1]),Cin,P(zero),P(hi),P(lo),ldk,0,Cout,B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,P(bias),0,0,0,0,P(pre),Cout,0,0,1,0,0,P(yh),P(yl),Cout,S()))
+            print(f"spxG  {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv (bias+GELU, pre + planes out)", flush=True)
         wg = cd.conv_wgrad(H,H,k,k,1,k//2,k//2,k//2,k//2); M=B*H*H
         tiles = ((Cin+127)//128)*((Cout+127)//128)*k*k
         best, bc = 1, None
