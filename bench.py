@@ -269,6 +269,14 @@ def main():
                                "measured": "HIP events around every launch of %d further steps run right after the timed region "
                                            "(%.1f ms/step with the ~1000 event records per step, %.1f ms/step without)"
                                            % (args.steps, 1000 * elapsed_instr / args.steps, 1000 * elapsed / args.steps)}
+            # HBM traffic of that kernel group from the committed rocprofv3 --pmc passes over this same command
+            # (tools/pmc_traffic.py; bench.py cannot run the profiler on itself)
+            tpath = os.path.join(REPO, "profiles", "round1_pmc_traffic.json")
+            if os.path.exists(tpath) and dom == "conv_igemm_sp":
+                g = json.load(open(tpath)).get("conv_igemm_sp")
+                if g:
+                    out["roofline"]["traffic"] = round(g["hbm_bytes_per_launch"])
+                    out["roofline"]["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/round1_pmc_traffic.json)"
         out["gemm_kernels"] = kernels
         # whole-step view: 3 x F_fwd per image against the same MFMA peak
         step_tflops = 3 * UNET128_FWD_GFLOP * args.batch * args.accum * args.steps / elapsed / 1e3

@@ -273,9 +273,19 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int tiles_b = (a.CB + BNC - 1) / BNC;
-    const int tile_a = blockIdx.x / tiles_b, tile_b = blockIdx.x - tile_a * tiles_b;
-    const int tap = blockIdx.y;
-    const int batch = blockIdx.z / a.nsplit, split = blockIdx.z - batch * a.nsplit;
+    // XCD-aware block order (see cdf_wgrad_block in k_conv_sp.hip): the tiles and taps of one pixel range share an L2
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int v = cdf_xcd_swizzle(bx + gx * (by + gy * bz), gx * gy * (int)gridDim.z);
+        bx = v % gx;
+        const int t2 = v / gx;
+        by = t2 % gy;
+        bz = t2 / gy;
+    }
+    const int tile_a = bx / tiles_b, tile_b = bx - tile_a * tiles_b;
+    const int tap = by;
+    const int batch = bz / a.nsplit, split = bz - batch * a.nsplit;
     const float* XA = a.xa + (long long)batch * a.a_bs;
     const float* XB = a.xb + (long long)batch * a.b_bs;
     const int M = a.B * a.QH * a.QW;

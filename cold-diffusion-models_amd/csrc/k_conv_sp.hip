@@ -292,9 +292,26 @@ struct SpWgradArgs {
     int B, QH, QW;
     int HA, WA, sa, HB, WB, sb;
     int CA, CB;
-    int ntaps, nsplit, m_per_split;
+    int ntaps, nsplit, m_per_split, xcd_swizzle;
     signed char day[CDF_MAX_TAPS], dax[CDF_MAX_TAPS], dby[CDF_MAX_TAPS], dbx[CDF_MAX_TAPS];
 };
+
+// XCD-aware block order of the weight-gradient grids (tiles, taps, splits).  Workgroups go to the 8 XCDs round-robin in
+// dispatch order, so the taps of one pixel range (next to each other in dispatch order) would land on 8 different L2s
+// and each of them would fetch the same operand rows over the fabric: measured 4-6x the algorithmic bytes (rocprofv3
+// FETCH_SIZE).  Re-numbered so that every XCD works through a CONTIGUOUS range of (tile, tap, split) ids: all tiles and
+// taps of a pixel range run on one XCD at about the same time and share its L2.
+__device__ __forceinline__ void cdf_wgrad_block(int enable, int& bx, int& by, int& bz) {
+    bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (enable) {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int v = cdf_sp_swizzle(bx + gx * (by + gy * bz), gx * gy * (int)gridDim.z);
+        bx = v % gx;
+        const int t2 = v / gx;
+        by = t2 % gy;
+        bz = t2 / gy;
+    }
+}
 
 __global__ void __launch_bounds__(256, 2) conv_wgrad_sp_kernel(SpWgradArgs a) {
     constexpr int BC = 128, BK = 32;
@@ -306,8 +323,10 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_sp_kernel(SpWgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_b = (a.CB + BC - 1) / BC;
-    const int tile_a = blockIdx.x / tiles_b, tile_b = blockIdx.x - tile_a * tiles_b;
-    const int tap = blockIdx.y, split = blockIdx.z;
+    int bx, by, bz;
+    cdf_wgrad_block(a.xcd_swizzle, bx, by, bz);
+    const int tile_a = bx / tiles_b, tile_b = bx - tile_a * tiles_b;
+    const int tap = by, split = bz;
     const int M = a.B * a.QH * a.QW;
     const int m_lo = split * a.m_per_split;
     int m_hi = m_lo + a.m_per_split;
@@ -708,7 +727,7 @@ struct SpxWgradArgs {
     int B, QH, QW;
     int HA, WA, sa, HB, WB, sb;
     int CA, CB;
-    int ntaps, nsplit, m_per_split;
+    int ntaps, nsplit, m_per_split, xcd_swizzle;
     signed char day[CDF_MAX_TAPS], dax[CDF_MAX_TAPS], dby[CDF_MAX_TAPS], dbx[CDF_MAX_TAPS];
 };
 
@@ -755,8 +774,10 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_b = (a.CB + TB - 1) / TB;
-    const int tile_a = blockIdx.x / tiles_b, tile_b = blockIdx.x - tile_a * tiles_b;
-    const int tap = STACK2 ? 2 * blockIdx.y : blockIdx.y, split = blockIdx.z;
+    int bx, by, bz;
+    cdf_wgrad_block(a.xcd_swizzle, bx, by, bz);
+    const int tile_a = bx / tiles_b, tile_b = bx - tile_a * tiles_b;
+    const int tap = STACK2 ? 2 * by : by, split = bz;
     const int M = a.B * a.QH * a.QW;
     const int m_lo = split * a.m_per_split;
     int m_hi = m_lo + a.m_per_split;
@@ -1049,6 +1070,13 @@ extern "C" int cdf_conv_gemm_bf16(const float* x, int ldx, const void* w_hi, con
     return cdf_check_launch("conv_igemm_sp");
 }
 
+static int g_wgrad_swizzle = 1;                // tuning / test hook (cdf_conv_wgrad_bf16x_swizzle)
+
+extern "C" int cdf_conv_wgrad_bf16x_swizzle(int enable) {
+    g_wgrad_swizzle = enable ? 1 : 0;
+    return 0;
+}
+
 extern "C" int cdf_conv_wgrad_bf16(const float* xa, int lda, const float* xb, int ldb, float* ws, int ldo, int B, int QH, int QW,
                                    int HA, int WA, int sa, int HB, int WB, int sb, int CA, int CB, int ntaps, const int* tap_desc,
                                    int nsplit, float* bsum, void* stream) {
@@ -1058,7 +1086,7 @@ extern "C" int cdf_conv_wgrad_bf16(const float* xa, int lda, const float* xb, in
     SpWgradArgs a;
     a.xa = xa; a.xb = xb; a.out = ws; a.bsum = bsum; a.lda = lda; a.ldb = ldb; a.ldo = ldo;
     a.B = B; a.QH = QH; a.QW = QW; a.HA = HA; a.WA = WA; a.sa = sa; a.HB = HB; a.WB = WB; a.sb = sb;
-    a.CA = CA; a.CB = CB; a.ntaps = ntaps; a.nsplit = nsplit;
+    a.CA = CA; a.CB = CB; a.ntaps = ntaps; a.nsplit = nsplit; a.xcd_swizzle = g_wgrad_swizzle;
     const int M = B * QH * QW;
     a.m_per_split = cdf_cdiv(cdf_cdiv(M, nsplit), 32) * 32;
     for (int t = 0; t < ntaps; ++t) {
@@ -1222,7 +1250,7 @@ extern "C" int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda,
     a.b_lo = (const unsigned short*)b_lo; a.zero = (const unsigned short*)zero; a.out = ws; a.bsum = bsum;
     a.lda = lda; a.ldb = ldb; a.ldo = ldo;
     a.B = B; a.QH = QH; a.QW = QW; a.HA = HA; a.WA = WA; a.sa = sa; a.HB = HB; a.WB = WB; a.sb = sb;
-    a.CA = CA; a.CB = CB; a.ntaps = ntaps; a.nsplit = nsplit;
+    a.CA = CA; a.CB = CB; a.ntaps = ntaps; a.nsplit = nsplit; a.xcd_swizzle = g_wgrad_swizzle;
     const int M = B * QH * QW;
     a.m_per_split = cdf_cdiv(cdf_cdiv(M, nsplit), 32) * 32;
     for (int t = 0; t < ntaps; ++t) {

@@ -167,6 +167,9 @@ int cdf_conv_gemm_bf16x_max_bm(int bm);
 /* Tuning / test hook: allow (1, default) or forbid (0) the two-taps-per-tile form of cdf_conv_wgrad_bf16x used when
  * CA <= 64 < CB.  Process-wide; results do not depend on it. */
 int cdf_conv_wgrad_bf16x_stack(int enable);
+/* Tuning / test hook: XCD-aware block order of cdf_conv_wgrad_bf16x (1, default: the taps of a pixel range share one
+ * XCD's L2) or plain dispatch order (0).  Process-wide; results do not depend on it. */
+int cdf_conv_wgrad_bf16x_swizzle(int enable);
 int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, int ldb, const void* zero,
                          float* ws, int ldo, int B, int QH, int QW, int HA, int WA, int sa, int HB, int WB, int sb, int CA, int CB,
                          int ntaps, const int* tap_desc, int nsplit, float* bsum, void* stream);
