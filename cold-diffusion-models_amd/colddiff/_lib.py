@@ -119,6 +119,8 @@ def get():
             _instance.cdf_conv_gemm_bf16x_waves(int(waves))
         if os.environ.get("COLDDIFF_WGRAD_SWIZZLE"):
             _instance.cdf_conv_wgrad_bf16x_swizzle(int(os.environ["COLDDIFF_WGRAD_SWIZZLE"]))
+        if os.environ.get("COLDDIFF_SPX_TAPROT"):
+            _instance.cdf_conv_gemm_bf16x_taprot(int(os.environ["COLDDIFF_SPX_TAPROT"]))
         if os.environ.get("COLDDIFF_SPX_MAX_BM"):
             _instance.cdf_conv_gemm_bf16x_max_bm(int(os.environ["COLDDIFF_SPX_MAX_BM"]))
     return _instance

@@ -505,6 +505,7 @@ struct SpxArgs {
     int ldx, ldk, ldy, ld_sbias, ldr, ldp, ldm;
     int B, H, W, Cin, OH, OW, Cout, QH, QW, os, is;
     int act, mul_mode, accumulate, nphase, vec;
+    int taprot;                    // 1: a tile is one image row and the 9 taps are 3 row groups -> per-block row-group order (see kernel)
     unsigned short* ys_hi;         // nullable: bf16 hi / lo planes of the output (pitch ld_ys), written by the epilogue
     unsigned short* ys_lo;
     int ld_ys;
@@ -572,9 +573,25 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
     // Tap table -> LDS once, behind the stages (a dynamic index into the by-value kernel argument compiles to
     // per-iteration global byte loads in front of the tile loads).  CDF_MAX_TAPS + 1 entries: reading one past the
     // end is harmless.
+    // Row-group rotation (a.taprot: 3 x 3 taps as three groups of equal dy, tile = exactly one image row, so tile_m is the
+    // global row index).  Input row r is needed by the three tiles r - dy, each in its group dy.  In the table's order every
+    // tile would read it in a different third of its life and, with the ~64 co-resident tiles of an XCD streaming more than
+    // the 4 MB L2 per third, each of the three reads came over the fabric (measured 3.4x the algorithmic bytes).  Here tile j
+    // handles group dy in slot (j + dy) mod 3: the tiles of an XCD run in lockstep (same start, same work), so the three
+    // readers of a row now read it at the same time and the L2 fetches it once.
     int* tap_lds = (int*)(smem + NSTAGE * STAGE);
-    if (tid <= CDF_MAX_TAPS)
-        tap_lds[tid] = tid < ph.ntaps ? (ph.dy[tid] & 0xFF) | ((ph.dx[tid] & 0xFF) << 8) | ((ph.wi[tid] & 0xFF) << 16) : 0;
+    if (tid <= CDF_MAX_TAPS) {
+        int src = tid;
+        if (a.taprot && tid < 9) {
+            const int slot = tid / 3, kx = tid - 3 * slot;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const int r = (tile_m + (int)ph.dy[3 * g]) % 3;      // (tile_m + dy >= -1)
+                if ((r < 0 ? r + 3 : r) == slot) src = 3 * g + kx;
+            }
+        }
+        tap_lds[tid] = src < ph.ntaps ? (ph.dy[src] & 0xFF) | ((ph.dx[src] & 0xFF) << 8) | ((ph.wi[src] & 0xFF) << 16) : 0;
+    }
     CDF_LDS_BARRIER();
 
     // DMA source pointers of this lane, valid for the current tap and advanced by one K chunk per fetch.  The address
@@ -1134,6 +1151,12 @@ static int fill_phases(SpPhase* ph, int nphase, const int* pd, const char* who) 
 static int g_spx_bm = 0, g_spx_bn = 0;     // 0 = automatic
 static int g_spx_waves = 0;                // 0 = automatic; 4 / 8 = waves of the 128 x 128 tile
 static int g_spx_max_bm = 0;               // 0 / 256 = no cap; 128 = the automatic choice never takes the 256-row tile
+static int g_spx_taprot = 1;               // per-block row-group order of 3 x 3 taps when a tile is one image row
+
+extern "C" int cdf_conv_gemm_bf16x_taprot(int enable) {
+    g_spx_taprot = enable ? 1 : 0;
+    return 0;
+}
 
 extern "C" int cdf_conv_gemm_bf16x_max_bm(int bm) {
     CDF_REQUIRE(bm == 0 || bm == 128 || bm == 256, "cdf_conv_gemm_bf16x_max_bm: 0, 128 or 256");
@@ -1206,6 +1229,22 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
     bool m64 = tiles128 < 384;
     bool m256 = !n64 && tiles128 >= 1024 && g_spx_max_bm != 128;
     if (g_spx_bm) { m64 = g_spx_bm == 64; m256 = g_spx_bm == 256 && !n64; }
+    // 3 x 3, stride 1, three groups of equal dy covering three consecutive rows: candidates for the row-group rotation
+    bool rot_ok = g_spx_taprot && nphase == 1 && is == 1 && os == 1 && a.ph[0].ntaps == 9 && a.ph[0].oy == 0 && a.ph[0].ox == 0;
+    if (rot_ok) {
+        int seen = 0;
+        for (int g = 0; g < 3; ++g) {
+            const int dy = a.ph[0].dy[3 * g];
+            rot_ok = rot_ok && a.ph[0].dy[3 * g + 1] == dy && a.ph[0].dy[3 * g + 2] == dy && dy >= -1 && dy <= 1;
+            seen |= 1 << (dy + 1);
+        }
+        rot_ok = rot_ok && seen == 7;
+    }
+    // (measured at 128 x 128 images: 128 -> 64 channels 0.40 -> 0.37 ms with the rotation on its 128 x 64 tiles; for 64 -> 128
+    // the two-row 256 x 128 tile without rotation stays ahead of one-row tiles with it, 0.405 vs 0.414 ms, so the tile
+    // choice is not bent towards one-row tiles)
+    const int bm = m256 ? 256 : (m64 ? 64 : 128);
+    a.taprot = rot_ok && QW == bm;
     if (m256) return launch_igemm_spx<256, 128, 4, 2, 3>(a, M, CDF_S);
     if (n64) return m64 ? launch_igemm_spx<64, 64, 2, 2, 2>(a, M, CDF_S) : launch_igemm_spx<128, 64, 2, 2, 2>(a, M, CDF_S);
     if (m64) return launch_igemm_spx<64, 128, 2, 2, 2>(a, M, CDF_S);

@@ -164,6 +164,10 @@ int cdf_conv_gemm_bf16x_tile(int bm, int bn);
 int cdf_conv_gemm_bf16x_waves(int waves);
 /* tuning / test hook: upper bound of the AUTOMATIC row-tile choice of cdf_conv_gemm_bf16x: 0 / 256 = none, 128 = never the 256 x 128 tile */
 int cdf_conv_gemm_bf16x_max_bm(int bm);
+/* tuning / test hook: per-block row-group order of the 3 x 3 taps when a tile of cdf_conv_gemm_bf16x is exactly one image row
+ * (1, default: the three tiles that need an input row read it at the same time, one L2 fill instead of three) or the
+ * table's order (0).  Only the fp32 summation order depends on it. */
+int cdf_conv_gemm_bf16x_taprot(int enable);
 /* Tuning / test hook: allow (1, default) or forbid (0) the two-taps-per-tile form of cdf_conv_wgrad_bf16x used when
  * CA <= 64 < CB.  Process-wide; results do not depend on it. */
 int cdf_conv_wgrad_bf16x_stack(int enable);

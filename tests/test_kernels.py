@@ -590,7 +590,8 @@ def test_conv_gemm_bf16_large(split, case):
 # ---------------------------------------------------------------------------------------------
 SPX_CASES = [(2, 32, 40, 8, 3, 1, 1), (1, 64, 32, 8, 1, 1, 0), (1, 40, 136, 8, 3, 1, 1), (1, 32, 32, 8, 4, 2, 1),
              (1, 72, 24, 8, 3, 1, 1), (1, 136, 72, 6, 3, 1, 1)]   # wgrad tiles 64x64, 64x128, 128x64, 128x128
-SPX_CASES_GPU = [(4, 64, 128, 32, 3, 1, 1), (2, 128, 64, 32, 3, 1, 1), (2, 256, 512, 16, 3, 1, 1), (2, 64, 64, 32, 4, 2, 1)]
+SPX_CASES_GPU = [(4, 64, 128, 32, 3, 1, 1), (2, 128, 64, 32, 3, 1, 1), (2, 256, 512, 16, 3, 1, 1), (2, 64, 64, 32, 4, 2, 1),
+                 (4, 64, 128, 128, 3, 1, 1), (4, 128, 64, 128, 3, 1, 1)]   # the last two: one-row tiles, tap row groups rotated per tile
 
 
 def _split(be, t):
@@ -684,6 +685,16 @@ def test_conv_presplit_forced_tiles(be, tile):
     finally:
         be.L.cdf_conv_gemm_bf16x_tile(0, 0)
         be.L.cdf_conv_gemm_bf16x_waves(0)
+
+
+def test_conv_presplit_row_tiles(be):
+    """A tile that is exactly one image row (W = 64 with the 64-row tile): the 3 x 3 taps run in a per-tile row-group
+    order (cdf_conv_gemm_bf16x_taprot) -- every tap must still be taken exactly once, forward and data gradient."""
+    be.L.cdf_conv_gemm_bf16x_tile(64, 64)
+    try:
+        _spx_case(be, 1, 8, 16, 64, 3, 1, 1)
+    finally:
+        be.L.cdf_conv_gemm_bf16x_tile(0, 0)
 
 
 @pytest.mark.gpu
