@@ -457,16 +457,20 @@ __global__ void pack_weight_kernel(const float* src, float* dst, int T, int R, i
         dst[i] = c < C ? src[c * s_c + r * s_r + t * s_t] : 0.f;
     }
 }
-// block 256 = 4 slab lanes x 64 consecutive output elements (element index runs over [T][R][C], C fastest)
-__global__ void unpack_reduce_kernel(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc,
-                                     long long s_t, long long s_r, long long s_c, int accumulate) {
-    __shared__ float red[4][64];
+// block = SL slab lanes x 64 consecutive output elements (element index runs over [T][R][C], C fastest).  A lane adds
+// slabs rl, rl + SL, ... in four independent chains (four loads in flight per lane): with 4 lanes x 2 chains the ~230-slab
+// reductions of the 128 x 128-pixel layers were ~30 dependent round trips (80 us for 67 MB).  The summation tree is fixed
+// by (SL, nsplit): deterministic.
+template <int SL>
+__global__ void __launch_bounds__(64 * SL) unpack_reduce_kernel(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc,
+                                                                long long s_t, long long s_r, long long s_c, int accumulate) {
+    __shared__ float red[SL][64];
     const long long n = (long long)T * R * C;
     const long long slab = (long long)T * R * ldc;
     const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
     for (long long base = (long long)blockIdx.x * 64; base < n; base += (long long)gridDim.x * 64) {
         const long long i = base + l;
-        float s0 = 0.f, s1 = 0.f;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int c = 0, r = 0, t = 0;
         if (i < n) {
             c = (int)(i % C);
@@ -475,17 +479,23 @@ __global__ void unpack_reduce_kernel(const float* ws, float* g, int nsplit, int 
             t = (int)(tr / R);
             const float* p = ws + ((long long)t * R + r) * ldc + c;
             int z = rl;
-            for (; z + 4 < nsplit; z += 8) {          // two independent chains per lane
+            for (; z + 3 * SL < nsplit; z += 4 * SL) {
                 s0 += p[z * slab];
-                s1 += p[(z + 4) * slab];
+                s1 += p[(z + SL) * slab];
+                s2 += p[(z + 2 * SL) * slab];
+                s3 += p[(z + 3 * SL) * slab];
             }
             if (z < nsplit) s0 += p[z * slab];
+            if (z + SL < nsplit) s1 += p[(z + SL) * slab];
+            if (z + 2 * SL < nsplit) s2 += p[(z + 2 * SL) * slab];
         }
         __syncthreads();
-        red[rl][l] = s0 + s1;
+        red[rl][l] = (s0 + s1) + (s2 + s3);
         __syncthreads();
         if (rl == 0 && i < n) {
-            const float tot = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < SL; q += 4) tot += (red[q][l] + red[q + 1][l]) + (red[q + 2][l] + red[q + 3][l]);
             float* dst = g + c * s_c + r * s_r + t * s_t;
             *dst = accumulate ? *dst + tot : tot;
         }
@@ -677,7 +687,10 @@ extern "C" int cdf_pack_weight(const float* src, float* dst, int T, int R, int C
 extern "C" int cdf_unpack_reduce(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t,
                                  long long s_r, long long s_c, int accumulate, void* stream) {
     CDF_REQUIRE(ws && g && nsplit > 0 && T > 0 && R > 0 && C > 0 && ldc >= C, "cdf_unpack_reduce: bad args");
-    CDF_LAUNCH(unpack_reduce_kernel, dim3(ew_grid2((long long)T * R * C * 4)), dim3(256), 0, CDF_S, ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate);
+    if (nsplit >= 32)       // 16 slab lanes: every lane still has >= 2 slabs
+        CDF_LAUNCH(unpack_reduce_kernel<16>, dim3(ew_grid2((long long)T * R * C * 4)), dim3(1024), 0, CDF_S, ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate);
+    else
+        CDF_LAUNCH(unpack_reduce_kernel<4>, dim3(ew_grid2((long long)T * R * C * 4)), dim3(256), 0, CDF_S, ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate);
     return cdf_check_launch("unpack_reduce");
 }
 

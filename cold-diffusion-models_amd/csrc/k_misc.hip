@@ -152,9 +152,10 @@ __global__ void scale_kernel(float* x, long long n, float s) {
 // forward: i = k, j = n, Wm = the [K][N] packed weight;  data gradient: i = n, j = k, Wm = the PyTorch [N][K] weight.
 // grid = (ceil(J/64), ceil(M/32)); block 256 = 4 contraction slices x 64 output columns.
 // ------------------------------------------------------------------------------------------------
+template <int MB>                                            // rows per block: 32, or 8 when that leaves most CUs without a block
 __global__ void __launch_bounds__(256) linear_small_kernel(const float* in, int ldi, const float* Wm, int ldw, const float* bias,
                                                            float* out, int ldo, int M, int I, int J) {
-    constexpr int MB = 32, IC = 128;                         // rows per block, contraction chunk staged in LDS
+    constexpr int IC = 128;                                  // contraction chunk staged in LDS
     __shared__ __attribute__((aligned(16))) float xs[MB][IC];
     __shared__ float red[4][MB][64];
     const int tid = threadIdx.x, lane = tid & 63, ks = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -250,7 +251,11 @@ extern "C" int cdf_sinusoidal(const int64_t* t, const float* freq, float* out, i
 extern "C" int cdf_linear_small(const float* in, int ldi, const float* Wm, int ldw, const float* bias, float* out, int ldo, int M,
                                 int I, int J, void* stream) {
     CDF_REQUIRE(in && Wm && out && M > 0 && I > 0 && J > 0 && ldi >= I && ldw >= J && ldo >= J, "cdf_linear_small: bad args");
-    CDF_LAUNCH(linear_small_kernel, dim3(cdf_cdiv(ldo, 64), cdf_cdiv(M, 32)), dim3(256), 0, CDF_S, in, ldi, Wm, ldw, bias, out, ldo, M, I, J);
+    // the layers are latency bound (a few thousand FMAs per thread): with few 32-row blocks, 8-row blocks cut the serial part 4x
+    if ((long long)cdf_cdiv(ldo, 64) * cdf_cdiv(M, 32) < 128)
+        CDF_LAUNCH(linear_small_kernel<8>, dim3(cdf_cdiv(ldo, 64), cdf_cdiv(M, 8)), dim3(256), 0, CDF_S, in, ldi, Wm, ldw, bias, out, ldo, M, I, J);
+    else
+        CDF_LAUNCH(linear_small_kernel<32>, dim3(cdf_cdiv(ldo, 64), cdf_cdiv(M, 32)), dim3(256), 0, CDF_S, in, ldi, Wm, ldw, bias, out, ldo, M, I, J);
     return cdf_check_launch("linear_small");
 }
 

@@ -704,6 +704,22 @@ def test_conv_presplit_large(case):
     _spx_case(Backend("hip"), *case)
 
 
+@pytest.mark.parametrize("ns", [1, 3, 7, 31, 32, 37, 64, 70, 227])
+def test_unpack_reduce(be, ns):
+    """Slab reduction + scatter into the PyTorch weight layout, both lane counts (4 below 32 slabs, 16 from there) and every
+    tail length of the four-chain loop; accumulate on top of an existing gradient."""
+    torch.manual_seed(ns)
+    T, R, C, ldc = 9, 5, 13, 16
+    ws = torch.randn(ns, T, R, ldc)
+    g0 = torch.randn(C, R, T)
+    g = be.to(g0)
+    be.L.cdf_unpack_reduce(P(be.to(ws)), P(g), ns, T, R, C, ldc, 1, T, R * T, 1, be.stream())
+    ref = g0 + ws[..., :C].double().sum(0).permute(2, 1, 0).float()
+    assert err(g, ref) <= 2e-6 * math.sqrt(ns) * max(1.0, ref.abs().max().item())
+    be.L.cdf_unpack_reduce(P(be.to(ws)), P(g), ns, T, R, C, ldc, 1, T, R * T, 0, be.stream())
+    assert err(g, ref - g0) <= 2e-6 * math.sqrt(ns) * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("M,K,N", [(32, 64, 256), (5, 256, 40), (70, 48, 130)])
 def test_linear_small(be, M, K, N):
     """Skinny linear layer kernels against torch: forward (packed [K][N] weight), data gradient (PyTorch [N][K] weight),
