@@ -30,6 +30,10 @@
 #define CDF_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 // wait until at most N (a compile-time constant) of this wave's DMA / global loads are still outstanding
 #define CDF_WAIT_DMA_LEAVE(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+// nothing is scheduled across this point (compile-time only, no instruction)
+#define CDF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// s_waitcnt lgkmcnt(0) as a real instruction the compiler's wait-count bookkeeping sees (vmcnt / expcnt left at their maxima)
+#define CDF_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xC07F)
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 #endif

@@ -41,6 +41,11 @@ struct SpPhase {
     signed char dy[CDF_MAX_TAPS], dx[CDF_MAX_TAPS], wi[CDF_MAX_TAPS];
 };
 
+#ifndef CDF_SPX_PIPE
+#define CDF_SPX_PIPE 0   // 1: half-chunk software pipeline in conv_igemm_spx_kernel (fragment reads of the next half-chunk under the
+                         // current MFMAs, barrier between two MFMA groups).  Measured on MI355X: identical kernel and step times
+                         // (LDS latency after the barrier is not what idles the matrix pipe) at +36 VGPRs => off.
+#endif
 #ifndef CDF_ABLATE
 #define CDF_ABLATE 0     // tuning aid (tools/ablate.py): bit 0 no global loads in the K loop, bit 2 no epilogue stores,
 #endif                   // bit 3 no LDS stores in the K loop.  Always 0 in the product build.
@@ -675,6 +680,83 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
 
     const int half = lane >> 5, l31 = lane & 31;
     const int sw = (l31 >> 2) & 3;                           // read-side swizzle (tile row offsets are multiples of 32)
+    constexpr int PIECES = 2 * (SA + SB);                    // this wave's DMA instructions per chunk
+#if CDF_SPX_PIPE
+    // Software pipeline at HALF-chunk granularity (a chunk = two k16 steps).  Fragment set F[h] holds k-step h of a chunk:
+    //     top of step it : F[0] = chunk it, k-step 0 (read during the previous step)
+    //     read F[1] <- chunk it, k-step 1 ; MFMAs on F[0]              (F[1]'s LDS latency hides behind them)
+    //     wait: own DMA pieces of chunk it+1 landed ; barrier           (every wave has read ALL of chunk it: its stage is free,
+    //                                                                    and chunk it+1 is visible)
+    //     DMA chunk it+NSTAGE -> the stage of chunk it ; read F[0] <- chunk it+1, k-step 0 ; MFMAs on F[1]
+    // One barrier per chunk as before, but it sits BETWEEN two MFMA groups: the matrix pipe still has the first group in
+    // flight while the waves meet, and the group after the barrier has its operands in registers already.  Before, every
+    // barrier was followed by 8 ds_reads whose latency the two in-phase waves of a SIMD (one block per CU) waited out
+    // together.  NSTAGE chunks are in flight instead of NSTAGE - 1.  Same registers: the two sets are the old ah/al/bh/bl[2].
+    bf16x8_v ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+    auto read_half = [&](int buf, int ks) {
+        const unsigned short* sa = smem + buf * STAGE;
+        const unsigned short* sb = sa + 2 * PLANE_A;
+        const int kc = ((ks * 2 + half) ^ sw) * 8;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int off = (wm * (BM / WM) + i * 32 + l31) * RE + kc;
+            ah[ks][i] = *(const bf16x8_v*)(sa + off);
+            al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int off = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
+            bh[ks][j] = *(const bf16x8_v*)(sb + off);
+            bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + off);
+        }
+    };
+    // term-major: the three MFMAs on one accumulator tile are MT*NT instructions apart instead of back to back
+    // (same summation order per accumulator)
+    auto mfma_half = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = CDF_MFMA_BF16(al[ks][i], bh[ks][j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bl[ks][j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bh[ks][j], acc[i][j]);
+    };
+    if (niter > 0) {
+#pragma unroll
+        for (int d = 0; d < NSTAGE; ++d) fetch(d);           // chunks 0 .. NSTAGE-1 (past the end: the last one again, never read)
+    }
+    CDF_WAIT_DMA_LEAVE((NSTAGE - 1) * PIECES);               // chunk 0 has landed
+    CDF_LDS_BARRIER();
+    read_half(0, 0);
+    CDF_WAIT_LDS();                                          // (same bookkeeping reason as at the end of the loop body)
+    int buf = 0;
+    for (int it = 0; it < niter; ++it) {
+        // (the scheduling fences keep hipcc from sinking the fragment reads down to their first use, which is exactly the
+        // exposed LDS latency this loop exists to hide)
+        read_half(buf, 1);
+        CDF_SCHED_FENCE();
+        mfma_half(0);
+        CDF_SCHED_FENCE();                                   // (the MFMAs stay in front of the barrier: they cover F[1]'s latency and the wait)
+        CDF_WAIT_DMA_LEAVE((NSTAGE - 2) * PIECES);           // this wave's pieces of chunk it + 1 have landed ...
+        CDF_LDS_BARRIER();                                   // ... everybody's have, and chunk it is fully read (lgkmcnt(0) inside)
+        const int freed = buf;
+        buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+        read_half(buf, 0);                                   // (after the last chunk: a stale stage, never multiplied)
+        CDF_SCHED_FENCE();
+        mfma_half(1);
+        fetch(freed);                                        // chunk it + NSTAGE into the stage just freed: address arithmetic and
+                                                             // DMA issue interleave with the MFMAs above (no fence in between)
+        CDF_SCHED_FENCE();
+        CDF_WAIT_LDS();                                      // free (F[0] was requested 12 MFMAs ago), but it tells hipcc's wait-count
+                                                             // pass that nothing is pending at the loop head: without it the first MFMA
+                                                             // of the next trip waits for the F[1] reads issued just before it
+    }
+#else
     // chunk c lives in stage c % NSTAGE; NSTAGE - 1 chunks are in flight ahead of the one being multiplied
     int fbuf = 0;                                            // stage of the next fetch
     if (niter > 0) {
@@ -684,7 +766,7 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
             fbuf = fbuf + 1 == NSTAGE ? 0 : fbuf + 1;
         }
     }
-    CDF_WAIT_DMA_LEAVE((NSTAGE - 2) * 2 * (SA + SB));         // chunk 0 has landed; later ones may still be in flight
+    CDF_WAIT_DMA_LEAVE((NSTAGE - 2) * PIECES);               // chunk 0 has landed; later ones may still be in flight
     CDF_LDS_BARRIER();
     int buf = 0;
     for (int it = 0; it < niter; ++it) {
@@ -722,9 +804,10 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
                     acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bl[ks][j], acc[i][j]);
                     acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bh[ks][j], acc[i][j]);
                 }
-        CDF_WAIT_DMA_LEAVE((NSTAGE - 2) * 2 * (SA + SB));     // this wave's pieces of chunk it + 1 have landed ...
+        CDF_WAIT_DMA_LEAVE((NSTAGE - 2) * PIECES);           // this wave's pieces of chunk it + 1 have landed ...
         CDF_LDS_BARRIER();                                   // ... and so have everybody else's; chunk it is fully consumed
     }
+#endif
     CDF_WAIT_DMA_LEAVE(0);                                   // the tail fetches (never read) must not land in the epilogue tile
     CDF_LDS_BARRIER();
 

@@ -175,6 +175,8 @@ inline emu_s4 ds_read_tr16_b64(const unsigned short* p) {
 #define CDF_GLDS16(gptr, lds_base) memcpy((unsigned char*)(lds_base) + 16 * hipemu::lane_id(), (const void*)(gptr), 16)
 #define CDF_WAIT_DMA() ((void)0)
 #define CDF_WAIT_DMA_LEAVE(N) ((void)0)
+#define CDF_SCHED_FENCE() ((void)0)
+#define CDF_WAIT_LDS() ((void)0)
 
 static inline void __syncthreads() { hipemu::block_barrier(); }
 
