@@ -47,8 +47,8 @@ struct SpPhase {
                          // (LDS latency after the barrier is not what idles the matrix pipe) at +36 VGPRs => off.
 #endif
 #ifndef CDF_ABLATE
-#define CDF_ABLATE 0     // tuning aid (tools/ablate.py): bit 0 no global loads in the K loop, bit 2 no epilogue stores,
-#endif                   // bit 3 no LDS stores in the K loop.  Always 0 in the product build.
+#define CDF_ABLATE 0     // tuning aid (tools/ablate.py), pre-split GEMM: 1 no operand DMA in the K loop, 2 no MFMAs, 4 no epilogue
+#endif                   // stores, 8 no fragment LDS reads.  Always 0 in the product build (results are wrong otherwise).
 
 // Block tile BM x BN, WM x WN waves of (BM/WM) x (BN/WN): the whole tile goes through LDS in one pass (cdf_epilogue.h).
 constexpr int CDF_SP_CPITCH = 136;
@@ -635,6 +635,7 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
     auto fetch = [&](int buf) {
         unsigned short* st = smem + buf * STAGE;
         const bool cok = !ragged || (c0 + q8) < a.Cin;       // (false only in the ragged last chunk of a tap)
+#if !(CDF_ABLATE & 1)
 #pragma unroll
         for (int p = 0; p < SA; ++p) {
             unsigned short* seg = st + (wave * SA + p) * 16 * RE;
@@ -647,6 +648,9 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
             CDF_GLDS16(pb_hi[p], seg);                       // (weights are zero padded along K to the chunk size)
             CDF_GLDS16(pb_lo[p], seg + PLANE_B);
         }
+#else
+        (void)st; (void)cok;
+#endif
         const bool more = issued + 1 < niter;                // block-uniform
         issued += more ? 1 : 0;
         if (more) {
@@ -757,6 +761,10 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
                                                              // of the next trip waits for the F[1] reads issued just before it
     }
 #else
+#if CDF_ABLATE & 8
+    bf16x8_v abl_frag;
+    for (int e = 0; e < 8; ++e) abl_frag[e] = (short)(0x3f80 + lane + e);
+#endif
     // chunk c lives in stage c % NSTAGE; NSTAGE - 1 chunks are in flight ahead of the one being multiplied
     int fbuf = 0;                                            // stage of the next fetch
     if (niter > 0) {
@@ -784,16 +792,33 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int off = (wm * (BM / WM) + i * 32 + l31) * RE + kc;
+#if CDF_ABLATE & 8
+                ah[ks][i] = abl_frag; al[ks][i] = abl_frag; (void)off;
+#else
                 ah[ks][i] = *(const bf16x8_v*)(sa + off);
                 al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
+#endif
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int off = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
+#if CDF_ABLATE & 8
+                bh[ks][j] = abl_frag; bl[ks][j] = abl_frag; (void)off;
+#else
                 bh[ks][j] = *(const bf16x8_v*)(sb + off);
                 bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + off);
+#endif
             }
         }
+#if CDF_ABLATE & 2
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(ah[ks][i]), "v"(al[ks][i]));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(bh[ks][j]), "v"(bl[ks][j]));
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -804,11 +829,205 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
                     acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bl[ks][j], acc[i][j]);
                     acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bh[ks][j], acc[i][j]);
                 }
+#endif
         CDF_WAIT_DMA_LEAVE((NSTAGE - 2) * PIECES);           // this wave's pieces of chunk it + 1 have landed ...
         CDF_LDS_BARRIER();                                   // ... and so have everybody else's; chunk it is fully consumed
     }
 #endif
     CDF_WAIT_DMA_LEAVE(0);                                   // the tail fetches (never read) must not land in the epilogue tile
+    CDF_LDS_BARRIER();
+
+    cdf_sp_epilogue<BM, BN, WM, WN>(a, ph, acc, (float*)smem_raw, tile_m, tile_n, M, tid);
+}
+
+// ================================================================================================
+// 3 x 3 stride-1 convolutions with the INPUT TILE RESIDENT IN LDS ("halo" kernel).
+//
+// What bounds conv_igemm_spx_kernel is the operand DMA, not the matrix pipe (tools/ablate.py on MI355X, 512 -> 1024 at
+// 16 x 16: 0.233 ms; without the DMA 0.131; MFMAs + barriers alone 0.125): every 32-channel K step brings 32 KB into LDS
+// for 96 MFMAs, and only ~64 KB per CU are in flight against ~1.1 us of L2 / MALL latency.  Of those bytes half are the
+// A tile -- and the nine taps of a 3 x 3 conv fetch the SAME pixels nine times, shifted.  Here the K loop runs channel
+// chunk outermost, taps innermost: per 32-channel chunk the tile's pixels plus a one-pixel halo ((TH+2) x (W+2) rows of
+// 64 B, both planes) are fetched ONCE, double buffered, and all nine taps read their A fragments out of that image at
+// row offset dy (W+2) + dx.  Only the weights still stream per tap (3 stages).  DMA bytes per chunk, 128 x 128 tile:
+// 9 x 32 KB -> 144 KB + 24..50 KB.
+//
+// Tile = TH = 128 / W full image rows (W = 16, 32, 64 or 128: one tile never straddles two images), so the tile's
+// pixels are the contiguous range [128 tile_m, 128 tile_m + 128) of the flattened pixel index and the epilogue of the
+// generic kernel applies unchanged.  Halo rows outside the image come from the zero page.  8 waves (4 x 2 of 32 x 64).
+// Same XOR swizzle of the 16-byte column by (row >> 2) & 3 on both sides; a lane's 16 fragment rows are consecutive
+// halo rows except at an image-row wrap (+2), where a 2-way bank conflict can occur.
+// ================================================================================================
+// how many of the halo segments requested in steps t, t-1, ... t-(n-1) (tap index modulo 9) fall on steps with a request (t' < ta)
+constexpr int cdf_halo_parts(int t, int n, int ta) {
+    int c = 0;
+    for (int d = 0; d < n; ++d) c += ((t - d + 9) % 9) < ta ? 1 : 0;
+    return c;
+}
+
+template <int W, int BN, int NB>                                        // NB weight stages: NB - 1 tap steps requested ahead
+__global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
+    constexpr int BM = 128, WM = 4, WN = 2, NW = 8, BK = 32, RE = 32;
+    constexpr int TH = BM / W, HW2 = W + 2, HR = (TH + 2) * HW2;          // halo rows (pixels)
+    constexpr int NSEG = (HR + 15) / 16, HRP = NSEG * 16;                 // 16-row DMA segments
+    constexpr int TA = (NSEG + NW - 1) / NW;                              // tap steps in which a wave fetches one A segment
+    static_assert(NB >= 3 && NB <= 7 && TA <= 11 - NB && TA <= 12 - NB, "the next chunk's halo must be requested before the weights of its first tap");
+    constexpr int NT = BN / WN / 32;                                      // 32 x 32 MFMA tiles per wave along N (M: 1)
+    constexpr int SB = BN / 16 / NW;                                      // B segments per wave and plane (1 for BN = 128)
+    static_assert(SB * NW * 16 == BN || BN == 64, "B tile must split into 16-row segments");
+    constexpr int SBI = BN == 64 ? 1 : SB;                                // (BN = 64: waves 0..3 fetch a segment, 4..7 repeat them)
+    constexpr int PLANE_A = HRP * RE, ABUF = 2 * PLANE_A;                 // (unsigned short units)
+    constexpr int PLANE_B = BN * RE, BSTAGE = 2 * PLANE_B;
+    CDF_DYN_SMEM(smem_raw);
+    unsigned short* smem = (unsigned short*)smem_raw;
+    unsigned short* const abuf0 = smem;
+    unsigned short* const bst0 = smem + 2 * ABUF;
+    int* tap_lds = (int*)(bst0 + NB * BSTAGE);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int M = a.B * a.QH * a.QW;
+    const int tiles_n = (a.Cout + BN - 1) / BN, tiles_m = M / BM;
+    const int tile = cdf_sp_swizzle(blockIdx.x, tiles_m * tiles_n);
+    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+    const SpPhase& ph = a.ph[0];
+    const int tpi = a.H / TH;                                              // tiles per image
+    const int img = tile_m / tpi, y0 = (tile_m - img * tpi) * TH;
+
+    if (tid < 9) tap_lds[tid] = (ph.dy[tid] & 0xFF) | ((ph.dx[tid] & 0xFF) << 8) | ((ph.wi[tid] & 0xFF) << 16);
+
+    // ---- DMA sources.  A: segment g = wave + 8 q (q < TA; past NSEG the wave repeats segment g mod NSEG -- same bytes to
+    // the same place, so that every wave issues the same number of DMA instructions per step and one s_waitcnt count fits all)
+    const int srow = lane >> 2;
+    const int q8 = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+    const unsigned short* pa_hi[TA];
+    const unsigned short* pa_lo[TA];
+    int a_inc[TA], a_seg[TA];
+#pragma unroll
+    for (int q = 0; q < TA; ++q) {
+        int g = wave + NW * q;
+        if (g >= NSEG) g -= (g / NSEG) * NSEG;
+        a_seg[q] = g;
+        const int r = g * 16 + srow;
+        const int hy = r / HW2, hx = r - hy * HW2;
+        const int y = y0 - 1 + hy, x = hx - 1;
+        const bool ok = r < HR && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)W;
+        const size_t off = ((size_t)((img * a.H + y) * W + x)) * (unsigned)a.ldx + (unsigned)q8;
+        pa_hi[q] = ok ? a.x_hi + off : a.zero;
+        pa_lo[q] = ok ? a.x_lo + off : a.zero;
+        a_inc[q] = ok ? BK : 0;
+    }
+    int b_row[SBI];
+#pragma unroll
+    for (int p = 0; p < SBI; ++p) {
+        const int seg = BN == 64 ? (wave & 3) : wave * SB + p;
+        const int n = tile_n * BN + seg * 16 + srow;
+        b_row[p] = n < a.Cout ? n : a.Cout - 1;
+    }
+    const int nchunks = a.Cin / BK;
+    CDF_LDS_BARRIER();                                       // tap table visible
+
+    auto fetch_a = [&](int q, int buf) {                     // segment a_seg[q] of the chunk the pointers stand at -> halo buffer buf
+        unsigned short* seg = abuf0 + buf * ABUF + a_seg[q] * 16 * RE;
+        CDF_GLDS16(pa_hi[q], seg);
+        CDF_GLDS16(pa_lo[q], seg + PLANE_A);
+    };
+    auto advance_a = [&]() {
+#pragma unroll
+        for (int q = 0; q < TA; ++q) {
+            pa_hi[q] += a_inc[q];
+            pa_lo[q] += a_inc[q];
+        }
+    };
+    auto fetch_b = [&](int c, int t, int stage) {            // weights of (chunk c, tap t) -> stage (= step % 3 = t % 3)
+        if (c >= nchunks) c = nchunks - 1;                   // past the end: valid weights again, into an idle stage
+        const int wi = (tap_lds[t] >> 16) & 0xFF;
+        unsigned short* st = bst0 + stage * BSTAGE;
+#pragma unroll
+        for (int p = 0; p < SBI; ++p) {
+            const int seg = BN == 64 ? (wave & 3) : wave * SB + p;
+            const size_t woff = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)b_row[p]) * (unsigned)a.ldk + (unsigned)(c * BK + q8);
+            CDF_GLDS16(a.w_hi + woff, st + seg * 16 * RE);
+            CDF_GLDS16(a.w_lo + woff, st + PLANE_B + seg * 16 * RE);
+        }
+    };
+    constexpr int PB = 2 * SBI, PA = 2;                      // DMA instructions per wave: one B step, one A segment
+
+    f32x16_t acc[1][NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+    const int half = lane >> 5, l31 = lane & 31;
+    // this lane's A fragment row for tap (0, 0): pixel p = 32 wm + l31 of the tile
+    const int pix = wm * 32 + l31;
+    const int py = pix / W, px = pix - py * W;
+    const int row0 = (py + 1) * HW2 + px + 1;
+    const int swb = (l31 >> 2) & 3;                          // B rows: tile-local, multiples of 32 apart
+
+    // ---- prologue: halo of chunk 0, weights of steps 0 and 1
+#pragma unroll
+    for (int q = 0; q < TA; ++q) fetch_a(q, 0);
+    if (nchunks > 1) advance_a();                            // the pointers stand at the chunk requested next (the last one, at the end)
+#pragma unroll
+    for (int u = 0; u < NB - 1; ++u) fetch_b(u / 9, u % 9, u);  // weights of steps 0 .. NB-2 (NB - 1 <= 9: chunk 0 or 1)
+    CDF_WAIT_DMA_LEAVE((NB - 2) * PB);                       // the halo and the weights of step 0 have landed
+    CDF_LDS_BARRIER();
+    int rd = 0;                                              // weight stage of the current step
+
+    for (int c = 0; c < nchunks; ++c) {
+        const unsigned short* sa = abuf0 + (c & 1) * ABUF;
+        // (during the last chunk its own halo is requested again, into the idle buffer: every step issues the same
+        // number of DMA instructions, so the wait counts below are compile-time constants)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t < TA) fetch_a(t, (c + 1) & 1);
+            if (t == TA - 1 && c + 2 < nchunks) advance_a();
+            fetch_b(t + NB - 1 < 9 ? c : c + 1, (t + NB - 1) % 9, rd == 0 ? NB - 1 : rd - 1);   // step + NB-1 -> the stage read last step
+            const int tc = tap_lds[t];
+            const int dy = (int)(signed char)(tc & 0xFF), dx = (int)(signed char)((tc >> 8) & 0xFF);
+            const int row = row0 + dy * HW2 + dx;
+            const int swa = (row >> 2) & 3;
+            const unsigned short* sb = bst0 + rd * BSTAGE;
+            rd = rd + 1 == NB ? 0 : rd + 1;
+            bf16x8_v ah[2], al[2], bh[2][NT], bl[2][NT];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = row * RE + ((ks * 2 + half) ^ swa) * 8;
+                ah[ks] = *(const bf16x8_v*)(sa + off);
+                al[ks] = *(const bf16x8_v*)(sa + PLANE_A + off);
+                const int kc = ((ks * 2 + half) ^ swb) * 8;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int offb = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
+                    bh[ks][j] = *(const bf16x8_v*)(sb + offb);
+                    bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + offb);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[0][j] = CDF_MFMA_BF16(al[ks], bh[ks][j], acc[0][j]);
+                    acc[0][j] = CDF_MFMA_BF16(ah[ks], bl[ks][j], acc[0][j]);
+                    acc[0][j] = CDF_MFMA_BF16(ah[ks], bh[ks][j], acc[0][j]);
+                }
+            // the weights of step + 1 (requested NB - 2 steps ago) have landed -- and with them, in order, every halo segment
+            // requested before them; still in flight: the weight requests of the last NB - 2 steps and the halo segments
+            // requested in those steps (a compile-time count per tap index)
+            switch (cdf_halo_parts(t, NB - 2, TA)) {
+                case 0: CDF_WAIT_DMA_LEAVE((NB - 2) * PB); break;
+                case 1: CDF_WAIT_DMA_LEAVE((NB - 2) * PB + PA); break;
+                case 2: CDF_WAIT_DMA_LEAVE((NB - 2) * PB + 2 * PA); break;
+                case 3: CDF_WAIT_DMA_LEAVE((NB - 2) * PB + 3 * PA); break;
+                case 4: CDF_WAIT_DMA_LEAVE((NB - 2) * PB + 4 * PA); break;
+                default: CDF_WAIT_DMA_LEAVE((NB - 2) * PB + 5 * PA); break;
+            }
+            CDF_LDS_BARRIER();
+        }
+    }
+    CDF_WAIT_DMA_LEAVE(0);                                   // the tail requests (never read) must not land in the epilogue tile
     CDF_LDS_BARRIER();
 
     cdf_sp_epilogue<BM, BN, WM, WN>(a, ph, acc, (float*)smem_raw, tile_m, tile_n, M, tid);
@@ -1279,6 +1498,38 @@ static int launch_igemm_spx(const SpxArgs& a, int M, hipStream_t s) {
     return cdf_check_launch("conv_igemm_spx");
 }
 
+static int g_spx_halo = 7;                     // 3 x 3 stride-1 layers: input tile resident in LDS; bit mask over the image width
+                                               // 16 (1), 32 (2), 64 (4), 128 (8) (tuning / test hook; 128: measured slower than the
+                                               // generic kernel -- only 3 weight stages fit next to its 2 x 51 KB halo buffers)
+static long long g_spx_halo_min_tiles = 1;
+
+extern "C" int cdf_conv_gemm_bf16x_halo(int enable, int min_tiles) {
+    g_spx_halo = enable & 15;
+    g_spx_halo_min_tiles = min_tiles > 0 ? min_tiles : 1;
+    return 0;
+}
+
+template <int W, int BN>
+static int launch_igemm_halo(const SpxArgs& a, int M, hipStream_t s) {
+    // weight stages: as many as fit next to the two halo buffers (151.5 KB for BN = 128 at every width)
+    constexpr int NB = W >= 128 ? 3 : (W == 64 ? 5 : 6);
+    constexpr int TH = 128 / W, HR = (TH + 2) * (W + 2), HRP = (HR + 15) / 16 * 16;
+    constexpr size_t stages = (size_t)2 * 2 * HRP * 64 + (size_t)NB * 2 * BN * 64 + 16 * sizeof(int);
+    constexpr size_t epi = (size_t)128 * (BN + 8) * sizeof(float);
+    constexpr size_t lds = stages > epi ? stages : epi;
+    static_assert(lds <= 160 * 1024, "halo tile does not fit the LDS");
+#ifndef CDF_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_halo_kernel<W, BN, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+#endif
+    const int tiles = (M / 128) * cdf_cdiv(a.Cout, BN);
+    CDF_LAUNCH((conv_igemm_halo_kernel<W, BN, NB>), dim3(tiles), dim3(512), lds, s, a);
+    return cdf_check_launch("conv_igemm_halo");
+}
+
 extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo,
                                    int ldk, float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW,
                                    int os, int is, int nphase, const int* phase_desc, const float* bias, const float* sbias,
@@ -1313,21 +1564,37 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
     bool m256 = !n64 && tiles128 >= 1024 && g_spx_max_bm != 128;
     if (g_spx_bm) { m64 = g_spx_bm == 64; m256 = g_spx_bm == 256 && !n64; }
     // 3 x 3, stride 1, three groups of equal dy covering three consecutive rows: candidates for the row-group rotation
-    bool rot_ok = g_spx_taprot && nphase == 1 && is == 1 && os == 1 && a.ph[0].ntaps == 9 && a.ph[0].oy == 0 && a.ph[0].ox == 0;
-    if (rot_ok) {
+    bool is3x3 = nphase == 1 && is == 1 && os == 1 && a.ph[0].ntaps == 9 && a.ph[0].oy == 0 && a.ph[0].ox == 0;
+    if (is3x3) {
         int seen = 0;
         for (int g = 0; g < 3; ++g) {
             const int dy = a.ph[0].dy[3 * g];
-            rot_ok = rot_ok && a.ph[0].dy[3 * g + 1] == dy && a.ph[0].dy[3 * g + 2] == dy && dy >= -1 && dy <= 1;
+            is3x3 = is3x3 && a.ph[0].dy[3 * g + 1] == dy && a.ph[0].dy[3 * g + 2] == dy && dy >= -1 && dy <= 1;
             seen |= 1 << (dy + 1);
         }
-        rot_ok = rot_ok && seen == 7;
+        is3x3 = is3x3 && seen == 7;
     }
+    const bool rot_ok = g_spx_taprot && is3x3;
     // (measured at 128 x 128 images: 128 -> 64 channels 0.40 -> 0.37 ms with the rotation on its 128 x 64 tiles; for 64 -> 128
     // the two-row 256 x 128 tile without rotation stays ahead of one-row tiles with it, 0.405 vs 0.414 ms, so the tile
     // choice is not bent towards one-row tiles)
     const int bm = m256 ? 256 : (m64 ? 64 : 128);
     a.taprot = rot_ok && QW == bm;
+    // 3 x 3 stride-1 layers whose rows tile into 128-pixel strips: input tile resident in LDS (conv_igemm_halo_kernel)
+    if (g_spx_halo && is3x3 && !g_spx_bm && QW == W && QH == H && Cin % 32 == 0 && Cin >= 64 && M % 128 == 0) {
+        int dxs = 0;
+        for (int t = 0; t < 9; ++t) dxs |= 1 << (a.ph[0].dx[t] + 1);
+        const bool dx_ok = dxs == 7;                         // (is3x3: three groups of equal dy in {-1, 0, 1})
+        const long long tiles = (long long)(M / 128) * cdf_cdiv(Cout, n64 ? 64 : 128);
+        if (dx_ok && tiles >= g_spx_halo_min_tiles) {
+            a.taprot = 0;
+#define CDF_HALO_CASE(WW)                                                             \
+    if (W == WW && (g_spx_halo & (WW / 16 >= 8 ? 8 : WW / 16)) && H % (128 / WW) == 0) \
+        return n64 ? launch_igemm_halo<WW, 64>(a, M, CDF_S) : launch_igemm_halo<WW, 128>(a, M, CDF_S);
+            CDF_HALO_CASE(128) CDF_HALO_CASE(64) CDF_HALO_CASE(32) CDF_HALO_CASE(16)
+#undef CDF_HALO_CASE
+        }
+    }
     if (m256) return launch_igemm_spx<256, 128, 4, 2, 3>(a, M, CDF_S);
     if (n64) return m64 ? launch_igemm_spx<64, 64, 2, 2, 2>(a, M, CDF_S) : launch_igemm_spx<128, 64, 2, 2, 2>(a, M, CDF_S);
     if (m64) return launch_igemm_spx<64, 128, 2, 2, 2>(a, M, CDF_S);

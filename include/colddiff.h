@@ -168,6 +168,11 @@ int cdf_conv_gemm_bf16x_max_bm(int bm);
  * (1, default: the three tiles that need an input row read it at the same time, one L2 fill instead of three) or the
  * table's order (0).  Only the fp32 summation order depends on it. */
 int cdf_conv_gemm_bf16x_taprot(int enable);
+/* tuning / test hook: 3 x 3 stride-1 layers of cdf_conv_gemm_bf16x with the input tile (+ one-pixel halo) resident in LDS for
+ * all nine taps.  enable: bit mask over the image width 16 (1), 32 (2), 64 (4), 128 (8); default 7; 0 = always the generic
+ * gather kernel.  min_tiles: smallest tile count (128 pixels x BN) the LDS-resident form is used for.  Only the fp32
+ * summation order depends on it. */
+int cdf_conv_gemm_bf16x_halo(int enable, int min_tiles);
 /* Tuning / test hook: allow (1, default) or forbid (0) the two-taps-per-tile form of cdf_conv_wgrad_bf16x used when
  * CA <= 64 < CB.  Process-wide; results do not depend on it. */
 int cdf_conv_wgrad_bf16x_stack(int enable);

@@ -591,7 +591,7 @@ def test_conv_gemm_bf16_large(split, case):
 SPX_CASES = [(2, 32, 40, 8, 3, 1, 1), (1, 64, 32, 8, 1, 1, 0), (1, 40, 136, 8, 3, 1, 1), (1, 32, 32, 8, 4, 2, 1),
              (1, 72, 24, 8, 3, 1, 1), (1, 136, 72, 6, 3, 1, 1)]   # wgrad tiles 64x64, 64x128, 128x64, 128x128
 SPX_CASES_GPU = [(4, 64, 128, 32, 3, 1, 1), (2, 128, 64, 32, 3, 1, 1), (2, 256, 512, 16, 3, 1, 1), (2, 64, 64, 32, 4, 2, 1),
-                 (4, 64, 128, 128, 3, 1, 1), (4, 128, 64, 128, 3, 1, 1)]   # the last two: one-row tiles, tap row groups rotated per tile
+                 (4, 64, 128, 128, 3, 1, 1), (4, 128, 64, 128, 3, 1, 1), (2, 64, 96, 64, 3, 1, 1)]   # 128 / 64-wide images: LDS-resident input tiles
 
 
 def _split(be, t):
@@ -687,6 +687,20 @@ def test_conv_presplit_forced_tiles(be, tile):
         be.L.cdf_conv_gemm_bf16x_waves(0)
 
 
+@pytest.mark.parametrize("case", [(1, 64, 96, 16, 3, 1, 1), (2, 96, 40, 16, 3, 1, 1), (1, 64, 72, 32, 3, 1, 1)])
+def test_conv_presplit_halo(be, case):
+    """3 x 3 stride-1 layers with the input tile resident in LDS (conv_igemm_halo_kernel): 128-pixel strips of 16- and 32-wide
+    images, 128- and 64-wide N tiles, several channel chunks, forward taps and the mirrored taps of the data gradient; the
+    generic kernel must give the same numbers to rounding."""
+    be.L.cdf_conv_gemm_bf16x_halo(15, 1)
+    try:
+        _spx_case(be, *case)
+        be.L.cdf_conv_gemm_bf16x_halo(0, 1)
+        _spx_case(be, *case)
+    finally:
+        be.L.cdf_conv_gemm_bf16x_halo(7, 1)
+
+
 def test_conv_presplit_row_tiles(be):
     """A tile that is exactly one image row (W = 64 with the 64-row tile): the 3 x 3 taps run in a per-tile row-group
     order (cdf_conv_gemm_bf16x_taprot) -- every tap must still be taken exactly once, forward and data gradient."""
@@ -701,7 +715,13 @@ def test_conv_presplit_row_tiles(be):
 @pytest.mark.parametrize("case", SPX_CASES_GPU)
 def test_conv_presplit_large(case):
     from conftest import Backend
-    _spx_case(Backend("hip"), *case)
+    be = Backend("hip")
+    _spx_case(be, *case)
+    be.L.cdf_conv_gemm_bf16x_halo(15, 1)          # LDS-resident input tiles at every width (128 is off by default)
+    try:
+        _spx_case(be, *case)
+    finally:
+        be.L.cdf_conv_gemm_bf16x_halo(7, 1)
 
 
 @pytest.mark.parametrize("ns", [1, 3, 7, 31, 32, 37, 64, 70, 227])

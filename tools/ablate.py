@@ -13,8 +13,8 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "cold-diffusion-models_amd", "csrc")
 OUT = os.path.join(REPO, "tools", "_ablate")
-VARIANTS = [0, 4]
-SHAPES = [(64, 128, 128, 3, 32), (128, 64, 128, 3, 32), (256, 128, 64, 3, 32), (1024, 512, 16, 3, 32)]   # Cin, Cout, HW, k, B
+VARIANTS = [0, 1, 2, 4, 8, 9, 13, 7]
+SHAPES = [(64, 128, 128, 3, 32), (128, 64, 128, 3, 32), (128, 256, 64, 3, 32), (512, 1024, 16, 3, 32)]   # Cin, Cout, HW, k, B
 
 
 def build():
