@@ -41,6 +41,17 @@ struct SpPhase {
     signed char dy[CDF_MAX_TAPS], dx[CDF_MAX_TAPS], wi[CDF_MAX_TAPS];
 };
 
+#ifndef CDF_PROFILE
+#define CDF_PROFILE 0    // 1: s_memtime stamps around the phases of the pre-split GEMM's K step (tools/_ablate probes only)
+#endif
+#if CDF_PROFILE
+__device__ unsigned long long cdf_prof[64 * 8 * 6];
+extern "C" int cdf_debug_read_prof(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(cdf_prof), sizeof(cdf_prof)); }
+#endif
+#ifndef CDF_HALO_PIPE
+#define CDF_HALO_PIPE 0  // 1: conv_igemm_halo_kernel reads the fragments of tap step s+1 under the MFMAs of step s (needs >= 4 weight stages).
+                         // Measured on MI355X: 2-3 % SLOWER than the plain loop (twice the VGPRs, same matrix-pipe gaps) => off.
+#endif
 #ifndef CDF_SPX_PIPE
 #define CDF_SPX_PIPE 0   // 1: half-chunk software pipeline in conv_igemm_spx_kernel (fragment reads of the next half-chunk under the
                          // current MFMAs, barrier between two MFMA groups).  Measured on MI355X: identical kernel and step times
@@ -777,8 +788,18 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
     CDF_WAIT_DMA_LEAVE((NSTAGE - 2) * PIECES);               // chunk 0 has landed; later ones may still be in flight
     CDF_LDS_BARRIER();
     int buf = 0;
+#if CDF_PROFILE
+    unsigned long long pt_dma = 0, pt_mma = 0, pt_wait = 0, pt_bar = 0;
+    const unsigned long long pt_begin = __builtin_readcyclecounter();
+#endif
     for (int it = 0; it < niter; ++it) {
+#if CDF_PROFILE
+        const unsigned long long p0 = __builtin_readcyclecounter();
+#endif
         fetch(fbuf);                                         // chunk it + NSTAGE - 1
+#if CDF_PROFILE
+        const unsigned long long p1 = __builtin_readcyclecounter();
+#endif
         fbuf = fbuf + 1 == NSTAGE ? 0 : fbuf + 1;
         const unsigned short* sa = smem + buf * STAGE;
         const unsigned short* sb = sa + 2 * PLANE_A;
@@ -830,9 +851,26 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
                     acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bh[ks][j], acc[i][j]);
                 }
 #endif
+#if CDF_PROFILE
+        asm volatile("s_nop 0" ::"v"(acc[0][0][0]));          // (the last MFMA result is due: the matrix work of the step is done here)
+        const unsigned long long p2 = __builtin_readcyclecounter();
+#endif
         CDF_WAIT_DMA_LEAVE((NSTAGE - 2) * PIECES);           // this wave's pieces of chunk it + 1 have landed ...
+#if CDF_PROFILE
+        const unsigned long long p3 = __builtin_readcyclecounter();
+#endif
         CDF_LDS_BARRIER();                                   // ... and so have everybody else's; chunk it is fully consumed
+#if CDF_PROFILE
+        const unsigned long long p4 = __builtin_readcyclecounter();
+        pt_dma += p1 - p0; pt_mma += p2 - p1; pt_wait += p3 - p2; pt_bar += p4 - p3;
+#endif
     }
+#if CDF_PROFILE
+    if (lane == 0 && blockIdx.x < 64) {
+        unsigned long long* o = cdf_prof + (blockIdx.x * NW + wave) * 6;
+        o[0] = pt_dma; o[1] = pt_mma; o[2] = pt_wait; o[3] = pt_bar; o[4] = __builtin_readcyclecounter() - pt_begin; o[5] = niter;
+    }
+#endif
 #endif
     CDF_WAIT_DMA_LEAVE(0);                                   // the tail fetches (never read) must not land in the epilogue tile
     CDF_LDS_BARRIER();
@@ -882,7 +920,6 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
     unsigned short* smem = (unsigned short*)smem_raw;
     unsigned short* const abuf0 = smem;
     unsigned short* const bst0 = smem + 2 * ABUF;
-    int* tap_lds = (int*)(bst0 + NB * BSTAGE);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -894,7 +931,8 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
     const int tpi = a.H / TH;                                              // tiles per image
     const int img = tile_m / tpi, y0 = (tile_m - img * tpi) * TH;
 
-    if (tid < 9) tap_lds[tid] = (ph.dy[tid] & 0xFF) | ((ph.dx[tid] & 0xFF) << 8) | ((ph.wi[tid] & 0xFF) << 16);
+    // (tap indices are compile-time constants in the unrolled loops below: ph.dy[t] etc. are scalar kernel-argument loads
+    // hoisted out of the K loop -- an LDS tap table would put an lgkmcnt(0) wait between the fragment reads and the MFMAs)
 
     // ---- DMA sources.  A: segment g = wave + 8 q (q < TA; past NSEG the wave repeats segment g mod NSEG -- same bytes to
     // the same place, so that every wave issues the same number of DMA instructions per step and one s_waitcnt count fits all)
@@ -925,7 +963,6 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
         b_row[p] = n < a.Cout ? n : a.Cout - 1;
     }
     const int nchunks = a.Cin / BK;
-    CDF_LDS_BARRIER();                                       // tap table visible
 
     auto fetch_a = [&](int q, int buf) {                     // segment a_seg[q] of the chunk the pointers stand at -> halo buffer buf
         unsigned short* seg = abuf0 + buf * ABUF + a_seg[q] * 16 * RE;
@@ -941,7 +978,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
     };
     auto fetch_b = [&](int c, int t, int stage) {            // weights of (chunk c, tap t) -> stage (= step % 3 = t % 3)
         if (c >= nchunks) c = nchunks - 1;                   // past the end: valid weights again, into an idle stage
-        const int wi = (tap_lds[t] >> 16) & 0xFF;
+        const int wi = ph.wi[t];
         unsigned short* st = bst0 + stage * BSTAGE;
 #pragma unroll
         for (int p = 0; p < SBI; ++p) {
@@ -966,16 +1003,96 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
     const int row0 = (py + 1) * HW2 + px + 1;
     const int swb = (l31 >> 2) & 3;                          // B rows: tile-local, multiples of 32 apart
 
-    // ---- prologue: halo of chunk 0, weights of steps 0 and 1
+    // ---- prologue: halo of chunk 0, weights of steps 0 .. NB-2
 #pragma unroll
     for (int q = 0; q < TA; ++q) fetch_a(q, 0);
     if (nchunks > 1) advance_a();                            // the pointers stand at the chunk requested next (the last one, at the end)
 #pragma unroll
-    for (int u = 0; u < NB - 1; ++u) fetch_b(u / 9, u % 9, u);  // weights of steps 0 .. NB-2 (NB - 1 <= 9: chunk 0 or 1)
+    for (int u = 0; u < NB - 1; ++u) fetch_b(u / 9, u % 9, u);  // (NB - 1 <= 9: all in chunk 0)
+    int rd = 0;                                              // weight stage of the current step
+  if constexpr (CDF_HALO_PIPE != 0 && NB >= 4) {
+    // Software pipeline over whole tap steps: the fragments of step s+1 are read while the MFMAs of step s run, so the barrier
+    // at the end of a step has to make the data of step s+2 visible (hence a wave waits for ITS pieces of step s+2 before it);
+    // in-kernel timing of the unpipelined loop: 12 reads -> their latency -> 12 MFMAs -> barrier, the matrix pipe idle for the
+    // first and the last part of every step.  Two fragment sets; NB >= 4 weight stages.
+    CDF_WAIT_DMA_LEAVE((NB - 3) * PB);                       // halo 0 and the weights of steps 0 and 1 have landed
+    CDF_LDS_BARRIER();
+    bf16x8_v fa_h[2][2], fa_l[2][2], fb_h[2][2][NT], fb_l[2][2][NT];     // [set][k-step]
+    auto read_frags = [&](int set, const unsigned short* sa, int t, int stage) {
+        const int row = row0 + (int)ph.dy[t] * HW2 + (int)ph.dx[t];
+        const int swa = (row >> 2) & 3;
+        const unsigned short* sb = bst0 + stage * BSTAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = row * RE + ((ks * 2 + half) ^ swa) * 8;
+            fa_h[set][ks] = *(const bf16x8_v*)(sa + off);
+            fa_l[set][ks] = *(const bf16x8_v*)(sa + PLANE_A + off);
+            const int kc = ((ks * 2 + half) ^ swb) * 8;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int offb = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
+                fb_h[set][ks][j] = *(const bf16x8_v*)(sb + offb);
+                fb_l[set][ks][j] = *(const bf16x8_v*)(sb + PLANE_B + offb);
+            }
+        }
+    };
+    auto mfma_set = [&](int set) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[0][j] = CDF_MFMA_BF16(fa_l[set][ks], fb_h[set][ks][j], acc[0][j]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[0][j] = CDF_MFMA_BF16(fa_h[set][ks], fb_l[set][ks][j], acc[0][j]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[0][j] = CDF_MFMA_BF16(fa_h[set][ks], fb_h[set][ks][j], acc[0][j]);
+        }
+    };
+    read_frags(0, abuf0, 0, 0);
+    CDF_WAIT_LDS();
+    for (int c = 0; c < nchunks; ++c) {
+        const unsigned short* sa = abuf0 + (c & 1) * ABUF;
+        const unsigned short* sa_next = abuf0 + ((c + 1) & 1) * ABUF;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // fragments of step + 1 (past the last step: stale data, never multiplied) ...
+            const int rd1 = rd + 1 == NB ? 0 : rd + 1;
+            read_frags((t + 1) & 1, t + 1 < 9 ? sa : sa_next, (t + 1) % 9, rd1);
+            CDF_SCHED_FENCE();
+            // ... under the MFMAs of this step
+            mfma_set(t & 1);
+            // requests: one halo segment of the next chunk (first TA steps), the weights of step + NB-1 into the stage read a step ago
+            if (t < TA) fetch_a(t, (c + 1) & 1);
+            if (t == TA - 1 && c + 2 < nchunks) advance_a();
+            fetch_b(t + NB - 1 < 9 ? c : c + 1, (t + NB - 1) % 9, rd == 0 ? NB - 1 : rd - 1);
+            rd = rd1;
+            CDF_SCHED_FENCE();
+            // this wave's pieces of step + 2 (requested NB - 3 steps ago) have landed; still in flight: the requests since then
+            switch (cdf_halo_parts(t, NB - 3, TA)) {
+                case 0: CDF_WAIT_DMA_LEAVE((NB - 3) * PB); break;
+                case 1: CDF_WAIT_DMA_LEAVE((NB - 3) * PB + PA); break;
+                case 2: CDF_WAIT_DMA_LEAVE((NB - 3) * PB + 2 * PA); break;
+                default: CDF_WAIT_DMA_LEAVE((NB - 3) * PB + 3 * PA); break;
+            }
+            CDF_LDS_BARRIER();                               // (lgkmcnt(0) inside: the fragments of step + 1 are in registers)
+            CDF_WAIT_LDS();                                  // (no-op after the barrier's own wait; tells hipcc's wait-count pass so,
+                                                             // else it parks an lgkmcnt(0) between the next reads and the MFMAs)
+        }
+        // nine steps: the next chunk's first fragments sit in set 1 -- every chunk starts from set 0 (48 register moves per
+        // nine steps; indexing the sets by a runtime parity would put them in scratch)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            fa_h[0][ks] = fa_h[1][ks];
+            fa_l[0][ks] = fa_l[1][ks];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                fb_h[0][ks][j] = fb_h[1][ks][j];
+                fb_l[0][ks][j] = fb_l[1][ks][j];
+            }
+        }
+    }
+  } else {                                                 // (3 weight stages: W = 128 with BN = 128)
     CDF_WAIT_DMA_LEAVE((NB - 2) * PB);                       // the halo and the weights of step 0 have landed
     CDF_LDS_BARRIER();
-    int rd = 0;                                              // weight stage of the current step
-
     for (int c = 0; c < nchunks; ++c) {
         const unsigned short* sa = abuf0 + (c & 1) * ABUF;
         // (during the last chunk its own halo is requested again, into the idle buffer: every step issues the same
@@ -985,9 +1102,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
             if (t < TA) fetch_a(t, (c + 1) & 1);
             if (t == TA - 1 && c + 2 < nchunks) advance_a();
             fetch_b(t + NB - 1 < 9 ? c : c + 1, (t + NB - 1) % 9, rd == 0 ? NB - 1 : rd - 1);   // step + NB-1 -> the stage read last step
-            const int tc = tap_lds[t];
-            const int dy = (int)(signed char)(tc & 0xFF), dx = (int)(signed char)((tc >> 8) & 0xFF);
-            const int row = row0 + dy * HW2 + dx;
+            const int row = row0 + (int)ph.dy[t] * HW2 + (int)ph.dx[t];
             const int swa = (row >> 2) & 3;
             const unsigned short* sb = bst0 + rd * BSTAGE;
             rd = rd + 1 == NB ? 0 : rd + 1;
@@ -1027,6 +1142,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
             CDF_LDS_BARRIER();
         }
     }
+  }
     CDF_WAIT_DMA_LEAVE(0);                                   // the tail requests (never read) must not land in the epilogue tile
     CDF_LDS_BARRIER();
 
