@@ -1703,9 +1703,8 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
         const bool dx_ok = dxs == 7;                         // (is3x3: three groups of equal dy in {-1, 0, 1})
         const long long tiles = (long long)(M / 128) * cdf_cdiv(Cout, n64 ? 64 : 128);
         if (dx_ok && tiles >= g_spx_halo_min_tiles) {
-            a.taprot = 0;
 #define CDF_HALO_CASE(WW)                                                             \
-    if (W == WW && (g_spx_halo & (WW / 16 >= 8 ? 8 : WW / 16)) && H % (128 / WW) == 0) \
+    if (W == WW && (g_spx_halo & (WW / 16)) && H % (128 / WW) == 0)                    \
         return n64 ? launch_igemm_halo<WW, 64>(a, M, CDF_S) : launch_igemm_halo<WW, 128>(a, M, CDF_S);
             CDF_HALO_CASE(128) CDF_HALO_CASE(64) CDF_HALO_CASE(32) CDF_HALO_CASE(16)
 #undef CDF_HALO_CASE
