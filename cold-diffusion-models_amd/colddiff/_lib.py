@@ -59,7 +59,7 @@ def parse_header(path=HEADER):
 
 
 # int-returning entry points that are pure host-side queries (sizes / counts), not status codes
-_QUERY = re.compile(r"(_blocks|_nchunk|_nsplit|_abi_version|_is_device_build|_lds_bytes)$")
+_QUERY = re.compile(r"(_blocks|_nchunk|_nsplit|_abi_version|_is_device_build|_lds_bytes|_is_row3)$")
 
 
 class CdfError(RuntimeError):
@@ -117,6 +117,8 @@ def get():
             _instance.cdf_conv_gemm_bf16x_tile(*[int(v) for v in tile.split("x")])
         if waves:
             _instance.cdf_conv_gemm_bf16x_waves(int(waves))
+        if os.environ.get("COLDDIFF_WGRAD_ROW3"):
+            _instance.cdf_conv_wgrad_bf16x_row3(int(os.environ["COLDDIFF_WGRAD_ROW3"]))
         if os.environ.get("COLDDIFF_WGRAD_SWIZZLE"):
             _instance.cdf_conv_wgrad_bf16x_swizzle(int(os.environ["COLDDIFF_WGRAD_SWIZZLE"]))
         if os.environ.get("COLDDIFF_SPX_TAPROT"):

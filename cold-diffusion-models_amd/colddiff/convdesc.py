@@ -86,13 +86,16 @@ def convT_dgrad(H, W, KH, KW, stride, pad):
 
 
 class WgradPlan:
-    __slots__ = ("QH", "QW", "HA", "WA", "sa", "HB", "WB", "sb", "ntaps", "desc", "same_b")
+    __slots__ = ("QH", "QW", "HA", "WA", "sa", "HB", "WB", "sb", "ntaps", "desc", "same_b", "same3x3")
 
     def __init__(self, QH, QW, HA, WA, sa, HB, WB, sb, taps):
         self.QH, self.QW, self.HA, self.WA, self.sa = QH, QW, HA, WA, sa
         self.HB, self.WB, self.sb = HB, WB, sb
         self.ntaps = len(taps)
         self.same_b = len(taps) >= 2 and all(t[2:] == taps[0][2:] for t in taps)   # every tap reads B at one offset
+        # 3 x 3 stride-1 same-size convolution: A shifted by (-1..1, -1..1) in row-major tap order, B read in place
+        self.same3x3 = (len(taps) == 9 and sa == 1 and sb == 1 and (HA, WA, HB, WB) == (QH, QW, QH, QW) and
+                        [tuple(t) for t in taps] == [(dy, dx, 0, 0) for dy in (-1, 0, 1) for dx in (-1, 0, 1)])
         flat = []
         for t in taps:
             flat += list(t)

@@ -263,8 +263,11 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None, xa_s=No
         # xa / xb themselves may be shape-only stand-ins here
         dev = xa_s[0].device
         ntap_blocks = (wplan.ntaps + 1) // 2 if (CA <= 64 < CB and wplan.same_b) else wplan.ntaps    # two taps per tile there
+        slots = 512
+        if L.cdf_conv_wgrad_bf16x_is_row3(wplan.QH, wplan.QW, CA, CB, wplan.ntaps, 1 if wplan.same3x3 else 0):
+            ntap_blocks, slots = 3, 256                                # one block per row of taps, one 512-thread block per CU
         tiles = (1 if CA <= 64 else (CA + 127) // 128) * (1 if CB <= 64 else (CB + 127) // 128) * ntap_blocks
-        ns = best_nsplit(tiles, 512, M // 512)
+        ns = best_nsplit(tiles, slots, M // 512)
         ws = torch.empty((ns, wplan.ntaps, CA, ldo), device=dev, dtype=torch.float32)
         S = rt.stream(xa_s[0])
         bsum = torch.empty((ns, ldo), device=dev, dtype=torch.float32) if gbias is not None else None

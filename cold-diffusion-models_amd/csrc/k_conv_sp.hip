@@ -1431,6 +1431,213 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
     }
 }
 
+// ================================================================================================
+// Weight gradient of 3 x 3 stride-1 "same" convolutions, one block per ROW OF TAPS (dy fixed; dx = -1, 0, +1).
+//
+// conv_wgrad_spx_kernel gives every tap its own block, and each of the nine loads the same dY tile and a one-pixel-shifted
+// X tile: like the forward GEMM it is bound by the bytes its waves have to push through the vector-memory
+// path per MFMA.  Here a 32-pixel chunk (always inside one image row, or two rows of a 16-pixel-wide image) brings in dY ONCE
+// and X ONCE with a pixel of halo on either side ([34 or 36 px][TA]), and the three dx taps read their X fragments from that
+// tile at pixel offsets 0, 1, 2: a third of the loads (and of the per-chunk address arithmetic) per MFMA.  Pixel addresses are
+// linear in the chunk index (no per-tap decode); the row / image borders are a per-lane mask.  8 waves (32 x TB/WB tiles, three
+// accumulator sets), one block per CU; grid (tiles, 3 tap rows, splits) in the XCD-aware order of cdf_wgrad_block.
+// ================================================================================================
+template <int TA, int TB>
+__global__ void __launch_bounds__(512, 1) conv_wgrad_row3_kernel(SpxWgradArgs a) {
+    constexpr int BK = 32, NTHR = 512;
+    constexpr int WA_ = TA / 32, WB_ = 8 / WA_, TNW = TB / WB_, NT = TNW / 32;
+    static_assert(NT >= 1 && NT * 32 == TNW, "wave tile along B must be a multiple of 32 channels");
+    constexpr int NRAP = 36;                                   // halo rows: 34 (W >= 32) or 2 x 18 (W = 16)
+    constexpr int PITCH_A = TA + 32, PITCH_B = TB + 32;
+    constexpr int PLANE_A = NRAP * PITCH_A, PLANE_B = BK * PITCH_B;
+    constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;
+    constexpr int VPR_A = TA / 8, RPP_A = NTHR / VPR_A, PASS_A = (NRAP + RPP_A - 1) / RPP_A;
+    constexpr int VPR_B = TB / 8;                              // (512 / VPR_B >= 32 rows: one pass)
+    CDF_DYN_SMEM(smem_raw);
+    unsigned short* smem = (unsigned short*)smem_raw;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave / WB_, wb = wave % WB_;
+    const int tiles_b = (a.CB + TB - 1) / TB;
+    int bx, by, bz;
+    cdf_wgrad_block(a.xcd_swizzle, bx, by, bz);
+    const int tile_a = bx / tiles_b, tile_b = bx - tile_a * tiles_b;
+    const int grp = by, split = bz;                            // tap row: taps 3 grp .. 3 grp + 2 share day
+    const int W = a.QW, H = a.QH;
+    const int M = a.B * H * W;
+    const int m_lo = split * a.m_per_split;
+    int m_hi = m_lo + a.m_per_split;
+    if (m_hi > M) m_hi = M;
+    const int niter = m_hi > m_lo ? (m_hi - m_lo) / BK : 0;    // (M and m_per_split are multiples of 32)
+    const int dy = a.day[3 * grp];
+    const int cw = W < 32 ? W : 32, rps = cw + 2;              // chunk row width, halo rows per image row
+    const int nra = (32 / cw) * rps;
+
+    // ---- load slots.  A: halo row r = (sub-row, xr): pixel (y + sub + dy, x0 + xr - 1); B: chunk pixel pb
+    int a_r[PASS_A], a_sub[PASS_A], a_xr[PASS_A];
+    const int ca = tile_a * TA + (tid % VPR_A) * 8;
+#pragma unroll
+    for (int p = 0; p < PASS_A; ++p) {
+        a_r[p] = tid / VPR_A + RPP_A * p;
+        a_sub[p] = a_r[p] / rps;
+        a_xr[p] = a_r[p] - a_sub[p] * rps;
+    }
+    const int pb = tid / VPR_B;
+    const int cb = tile_b * TB + (tid % VPR_B) * 8;
+    const bool b_lane = pb < BK;
+    // chunk position (wave-uniform): x0 = first pixel's column, yc = its image row
+    int x0 = m_lo % W, yc = (m_lo / W) % H;
+    const bool do_bsum = a.bsum != nullptr && tile_a == 0 && grp == 0;
+    float bs_acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs_acc[e] = 0.f;
+
+    u32x4_v rah[PASS_A], ral[PASS_A], rbh, rbl;
+    auto load_global = [&](int it) {
+        const int m0 = m_lo + it * BK;
+#pragma unroll
+        for (int p = 0; p < PASS_A; ++p) {
+            const unsigned ax = (unsigned)(x0 + a_xr[p] - 1), ay = (unsigned)(yc + a_sub[p] + dy);
+            const bool ok = a_r[p] < nra && ax < (unsigned)W && ay < (unsigned)H && ca < a.CA;
+            const long long pix = (long long)m0 + (a_sub[p] + dy) * W + a_xr[p] - 1;
+            const size_t off = (size_t)(ok ? pix : 0) * (unsigned)a.lda + (unsigned)ca;
+            rah[p] = *(const u32x4_v*)(ok ? a.a_hi + off : a.zero);
+            ral[p] = *(const u32x4_v*)(ok ? a.a_lo + off : a.zero);
+        }
+        {
+            const bool ok = b_lane && cb < a.CB;
+            const size_t off = (size_t)(m0 + (b_lane ? pb : 0)) * (unsigned)a.ldb + (unsigned)cb;
+            rbh = *(const u32x4_v*)(ok ? a.b_hi + off : a.zero);
+            rbl = *(const u32x4_v*)(ok ? a.b_lo + off : a.zero);
+        }
+        // next chunk (uniform scalars, selects only): 32 pixels further -- inside the row, to the next row(s), to the next image
+        const int nx = x0 + (W < 32 ? 0 : 32);
+        const int wrap = nx >= W ? 1 : 0;
+        x0 = wrap ? 0 : nx;
+        yc += (W < 32 ? 32 / W : 0) + wrap;
+        yc = yc >= H ? yc - H : yc;
+    };
+    auto store_lds = [&](int buf) {
+        unsigned short* st = smem + buf * STAGE;
+#pragma unroll
+        for (int p = 0; p < PASS_A; ++p) {
+            if (a_r[p] < NRAP) {
+                const int so = a_r[p] * PITCH_A + (tid % VPR_A) * 8;
+                *(u32x4_v*)(st + so) = rah[p];
+                *(u32x4_v*)(st + PLANE_A + so) = ral[p];
+            }
+        }
+        if (b_lane) {
+            const int so = pb * PITCH_B + (tid % VPR_B) * 8;
+            *(u32x4_v*)(st + 2 * PLANE_A + so) = rbh;
+            *(u32x4_v*)(st + 2 * PLANE_A + PLANE_B + so) = rbl;
+            if (do_bsum) cdf_bf16x8_accum(bs_acc, rbh, rbl);
+        }
+    };
+
+    f32x16_t acc[3][NT];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int half = lane >> 5, l31 = lane & 31;
+    const int t16 = lane & 15, g16 = lane >> 4;
+    const int tr_row = (g16 >> 1) * 8 + (t16 >> 2), tr_col = (g16 & 1) * 16 + (t16 & 3) * 4;
+    const int trb = tr_row * PITCH_B + wb * TNW + tr_col;
+    // halo row of chunk pixel p for tap dx: p + 1 + dx (+ 2 from the second image row of a 16-wide chunk on)
+    int tra[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tra[i] = (tr_row + 1 + (int)a.dax[3 * grp + i]) * PITCH_A + wa * 32 + tr_col;
+    const int ks_skip = W < 32 ? 2 * PITCH_A : 0;              // k-step 1 = pixels 16..31 = the second row when W = 16
+
+    if (niter > 0) {
+        load_global(0);
+        store_lds(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < niter) load_global(it + 1);
+        const unsigned short* sa = smem + buf * STAGE;
+        const unsigned short* sb = sa + 2 * PLANE_A;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_v bh[NT], bl[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const unsigned short* q = sb + trb + ks * 16 * PITCH_B + j * 32;
+                const bf16x4_v h0 = cdf_lds_read_tr16(q), h1 = cdf_lds_read_tr16(q + 4 * PITCH_B);
+                const bf16x4_v l0 = cdf_lds_read_tr16(q + PLANE_B), l1 = cdf_lds_read_tr16(q + PLANE_B + 4 * PITCH_B);
+                bh[j] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                bl[j] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const unsigned short* q = sa + tra[i] + ks * (16 * PITCH_A + ks_skip);
+                const bf16x4_v h0 = cdf_lds_read_tr16(q), h1 = cdf_lds_read_tr16(q + 4 * PITCH_A);
+                const bf16x4_v l0 = cdf_lds_read_tr16(q + PLANE_A), l1 = cdf_lds_read_tr16(q + PLANE_A + 4 * PITCH_A);
+                const bf16x8_v ah = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8_v al = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = CDF_MFMA_BF16(al, bh[j], acc[i][j]);
+                    acc[i][j] = CDF_MFMA_BF16(ah, bl[j], acc[i][j]);
+                    acc[i][j] = CDF_MFMA_BF16(ah, bh[j], acc[i][j]);
+                }
+            }
+        }
+        if (it + 1 < niter) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* red = (float*)smem_raw;
+    if (do_bsum) {                                 // [32 px][TB] partial column sums -> one row
+        if (b_lane) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[pb * TB + (tid % VPR_B) * 8 + e] = bs_acc[e];
+        }
+        __syncthreads();
+        for (int c = tid; c < TB; c += NTHR) {
+            float t = 0.f;
+            for (int k = 0; k < BK; ++k) t += red[k * TB + c];
+            const int cc = tile_b * TB + c;
+            if (cc < a.ldo) a.bsum[(long long)split * a.ldo + cc] = cc < a.CB ? t : 0.f;
+        }
+        __syncthreads();
+    }
+    // accumulators of one tap -> LDS [TA][TB + 8] -> float4 rows of that tap's slab; three times
+    constexpr int CP = TB + 8, TPR = TB / 4, RPS = NTHR / TPR;
+    const int c4 = (tid % TPR) * 4, col = tile_b * TB + c4;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                red[(wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wb * TNW + j * 32 + l31] = acc[i][j][r];
+        __syncthreads();
+        float* O = a.out + ((long long)split * a.ntaps + 3 * grp + i) * a.CA * a.ldo;
+        if (col < a.ldo) {
+            for (int r = tid / TPR; r < TA; r += RPS) {
+                const int row = tile_a * TA + r;
+                if (row >= a.CA) break;
+                float4 v = *(const float4*)(red + r * CP + c4);
+                if (col + 3 >= a.CB) {             // zero the pitch padding (ldo % 4 == 0 keeps the store in bounds)
+                    if (col + 0 >= a.CB) v.x = 0.f;
+                    if (col + 1 >= a.CB) v.y = 0.f;
+                    if (col + 2 >= a.CB) v.z = 0.f;
+                    v.w = 0.f;
+                }
+                *(float4*)(O + (long long)row * a.ldo + col) = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // dst_hi/lo[t][r][c] (c < ldc, zero padded) = split(src[c*s_c + r*s_r + t*s_t])
 __global__ void pack_weight_bf16_kernel(const float* src, unsigned short* dst_hi, unsigned short* dst_lo, int T, int R, int C,
                                         int ldc, long long s_t, long long s_r, long long s_c) {
@@ -1742,6 +1949,37 @@ static int launch_wgrad_spx(const SpxWgradArgs& a, hipStream_t s) {
     return cdf_check_launch("conv_wgrad_spx");
 }
 
+static int g_wgrad_row3 = 1;                   // tuning / test hook (cdf_conv_wgrad_bf16x_row3)
+
+extern "C" int cdf_conv_wgrad_bf16x_row3(int enable) {
+    g_wgrad_row3 = enable ? 1 : 0;
+    return 0;
+}
+
+// 1 if cdf_conv_wgrad_bf16x takes the row-of-taps kernel for this geometry (the caller sizes the split count by it:
+// 3 tap blocks per tile and one block per CU instead of 9 (or 5) and two)
+extern "C" int cdf_conv_wgrad_bf16x_is_row3(int QH, int QW, int CA, int CB, int ntaps, int same_size_3x3) {
+    return g_wgrad_row3 && same_size_3x3 && ntaps == 9 && (QW == 16 || QW == 32 || QW == 64 || QW == 128) && (QH * QW) % 32 == 0 &&
+           (QW >= 32 || QH % (32 / QW) == 0) && !(CA <= 64 && CB <= 64);
+}
+
+template <int TA, int TB>
+static int launch_wgrad_row3(const SpxWgradArgs& a, hipStream_t s) {
+    constexpr size_t stage = (size_t)2 * (36 * (TA + 32) + 32 * (TB + 32)) * sizeof(unsigned short);
+    constexpr size_t epi = (size_t)TA * (TB + 8) * sizeof(float);
+    constexpr size_t lds = 2 * stage > epi ? 2 * stage : epi;
+#ifndef CDF_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_row3_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+#endif
+    const int tiles = cdf_cdiv(a.CA, TA) * cdf_cdiv(a.CB, TB);
+    CDF_LAUNCH((conv_wgrad_row3_kernel<TA, TB>), dim3(tiles, 3, a.nsplit), dim3(512), lds, s, a);
+    return cdf_check_launch("conv_wgrad_row3");
+}
+
 extern "C" int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, int ldb,
                                     const void* zero, float* ws, int ldo, int B, int QH, int QW, int HA, int WA, int sa, int HB, int WB,
                                     int sb, int CA, int CB, int ntaps, const int* tap_desc, int nsplit, float* bsum, void* stream) {
@@ -1762,6 +2000,25 @@ extern "C" int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda,
         a.dax[t] = (signed char)tap_desc[4 * t + 1];
         a.dby[t] = (signed char)tap_desc[4 * t + 2];
         a.dbx[t] = (signed char)tap_desc[4 * t + 3];
+    }
+    // 3 x 3 stride-1 "same" convolutions (X shifted per tap, dY read in place): one block per row of taps
+    if (g_wgrad_row3 && ntaps == 9 && sa == 1 && sb == 1 && HA == QH && WA == QW && HB == QH && WB == QW &&
+        (QW == 16 || QW == 32 || QW == 64 || QW == 128) && (QH * QW) % 32 == 0 && (QW >= 32 || QH % (32 / QW) == 0) && !(CA <= 64 && CB <= 64)) {
+        bool ok = true;
+        for (int g = 0; g < 3 && ok; ++g) {
+            int seen = 0;
+            for (int i = 0; i < 3; ++i) {
+                const int t = 3 * g + i;
+                ok = ok && a.day[t] == a.day[3 * g] && a.dby[t] == 0 && a.dbx[t] == 0 && a.dax[t] >= -1 && a.dax[t] <= 1 && a.day[t] >= -1 && a.day[t] <= 1;
+                seen |= 1 << (a.dax[t] + 1);
+            }
+            ok = ok && seen == 7;
+        }
+        if (ok) {
+            if (CA <= 64) return launch_wgrad_row3<64, 128>(a, CDF_S);
+            if (CB <= 64) return launch_wgrad_row3<128, 64>(a, CDF_S);
+            return launch_wgrad_row3<128, 128>(a, CDF_S);
+        }
     }
     // thin layers get 64-wide tiles so that no half of a tile multiplies padding
     if (CA <= 64 && CB <= 64) return launch_wgrad_spx<64, 64>(a, CDF_S);

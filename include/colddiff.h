@@ -179,6 +179,11 @@ int cdf_conv_wgrad_bf16x_stack(int enable);
 /* Tuning / test hook: XCD-aware block order of cdf_conv_wgrad_bf16x (1, default: the taps of a pixel range share one
  * XCD's L2) or plain dispatch order (0).  Process-wide; results do not depend on it. */
 int cdf_conv_wgrad_bf16x_swizzle(int enable);
+/* Tuning / test hook: weight gradients of 3 x 3 stride-1 same-size convolutions by one block per ROW of taps (1, default: dY and
+ * X with a pixel of halo are loaded once for the three dx taps) or one block per tap (0).  cdf_conv_wgrad_bf16x_is_row3 tells the
+ * caller whether a geometry takes that kernel (3 tap blocks per tile, one 512-thread block per CU) so that it can size nsplit. */
+int cdf_conv_wgrad_bf16x_row3(int enable);
+int cdf_conv_wgrad_bf16x_is_row3(int QH, int QW, int CA, int CB, int ntaps, int same_size_3x3);
 int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, int ldb, const void* zero,
                          float* ws, int ldo, int B, int QH, int QW, int HA, int WA, int sa, int HB, int WB, int sb, int CA, int CB,
                          int ntaps, const int* tap_desc, int nsplit, float* bsum, void* stream);

@@ -701,6 +701,19 @@ def test_conv_presplit_halo(be, case):
         be.L.cdf_conv_gemm_bf16x_halo(7, 1)
 
 
+@pytest.mark.parametrize("case", [(1, 136, 72, 16, 3, 1, 1), (2, 64, 136, 16, 3, 1, 1), (1, 136, 40, 32, 3, 1, 1)])
+def test_wgrad_presplit_row_of_taps(be, case):
+    """Weight gradient of 3 x 3 same-size convolutions by one block per row of taps (conv_wgrad_row3_kernel): 16-wide images
+    (a chunk spans two image rows) and 32-wide ones, the three tile shapes 128x128 / 64x128 / 128x64 with ragged channel tiles,
+    several splits; and the per-tap kernel on the same data."""
+    _spx_case(be, *case)
+    be.L.cdf_conv_wgrad_bf16x_row3(0)
+    try:
+        _spx_case(be, *case)
+    finally:
+        be.L.cdf_conv_wgrad_bf16x_row3(1)
+
+
 def test_conv_presplit_row_tiles(be):
     """A tile that is exactly one image row (W = 64 with the 64-row tile): the 3 x 3 taps run in a per-tile row-group
     order (cdf_conv_gemm_bf16x_taprot) -- every tap must still be taken exactly once, forward and data gradient."""

@@ -7,6 +7,8 @@ from colddiff import _lib, convdesc as cd
 L = _lib.get(); dev = torch.device("cuda:0")
 if os.environ.get('KB_TILE'):
     L.cdf_conv_gemm_bf16x_tile(*[int(v) for v in os.environ['KB_TILE'].split('x')])
+if os.environ.get('KB_ROW3'):
+    L.cdf_conv_wgrad_bf16x_row3(int(os.environ['KB_ROW3']))
 if os.environ.get('KB_WSWZ'):
     L.cdf_conv_wgrad_bf16x_swizzle(int(os.environ['KB_WSWZ']))
 if os.environ.get('KB_TAPROT'):
@@ -96,10 +98,12 @@ if os.environ.get("KB_SPX", "1") == "1":
             ms = timeit(lambda: L.cdf_conv_gemm_bf16x(P(xs[0]),P(xs[1]),Cin,P(zero),P(hi),P(lo),ldk,0,Cout,B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,P(bias),0,0,0,0,P(pre),Cout,0,0,1,0,0,P(yh),P(yl),Cout,S()))
             print(f"spxG  {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv (bias+GELU, pre + planes out)", flush=True)
         wg = cd.conv_wgrad(H,H,k,k,1,k//2,k//2,k//2,k//2); M=B*H*H
-        tiles = ((Cin+127)//128)*((Cout+127)//128)*k*k
+        row3 = L.cdf_conv_wgrad_bf16x_is_row3(H, H, Cin, Cout, k*k, 1 if k == 3 else 0)
+        tiles = ((Cin+127)//128)*((Cout+127)//128)*(3 if row3 else k*k)
+        slots = 256 if row3 else 512
         best, bc = 1, None
         for ns_ in range(1, min(M//512, 256)+1):
-            c_ = -(-tiles*ns_//512)/ns_
+            c_ = -(-tiles*ns_//slots)/ns_
             if bc is None or c_ < bc - 1e-9: best, bc = ns_, c_
         ns = best
         ws = torch.empty(ns,k*k,Cin,r4(Cout),device=dev)
