@@ -126,6 +126,8 @@ def get():
         if os.environ.get("COLDDIFF_SPX_HALO"):
             v = [int(x) for x in os.environ["COLDDIFF_SPX_HALO"].split(",")]
             _instance.cdf_conv_gemm_bf16x_halo(v[0], v[1] if len(v) > 1 else 1)
+        if os.environ.get("COLDDIFF_SPX_HALO_BM"):
+            _instance.cdf_conv_gemm_bf16x_halo_bm(int(os.environ["COLDDIFF_SPX_HALO_BM"]))
         if os.environ.get("COLDDIFF_SPX_MAX_BM"):
             _instance.cdf_conv_gemm_bf16x_max_bm(int(os.environ["COLDDIFF_SPX_MAX_BM"]))
     return _instance

@@ -903,9 +903,9 @@ constexpr int cdf_halo_parts(int t, int n, int ta) {
     return c;
 }
 
-template <int W, int BN, int NB>                                        // NB weight stages: NB - 1 tap steps requested ahead
+template <int W, int BN, int NB, int BM>                                // NB weight stages: NB - 1 tap steps requested ahead; BM = 128 or 256 pixels
 __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
-    constexpr int BM = 128, WM = 4, WN = 2, NW = 8, BK = 32, RE = 32;
+    constexpr int WM = 4, WN = 2, NW = 8, BK = 32, RE = 32, MT = BM / WM / 32;
     constexpr int TH = BM / W, HW2 = W + 2, HR = (TH + 2) * HW2;          // halo rows (pixels)
     constexpr int NSEG = (HR + 15) / 16, HRP = NSEG * 16;                 // 16-row DMA segments
     constexpr int TA = (NSEG + NW - 1) / NW;                              // tap steps in which a wave fetches one A segment
@@ -990,17 +990,23 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
     };
     constexpr int PB = 2 * SBI, PA = 2;                      // DMA instructions per wave: one B step, one A segment
 
-    f32x16_t acc[1][NT];
+    f32x16_t acc[MT][NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int half = lane >> 5, l31 = lane & 31;
-    // this lane's A fragment row for tap (0, 0): pixel p = 32 wm + l31 of the tile
-    const int pix = wm * 32 + l31;
-    const int py = pix / W, px = pix - py * W;
-    const int row0 = (py + 1) * HW2 + px + 1;
+    // this lane's A fragment rows for tap (0, 0): pixels p = (BM/4) wm + 32 i + l31 of the tile
+    int row0[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int pix = wm * (BM / WM) + i * 32 + l31;
+        const int py = pix / W, px = pix - py * W;
+        row0[i] = (py + 1) * HW2 + px + 1;
+    }
     const int swb = (l31 >> 2) & 3;                          // B rows: tile-local, multiples of 32 apart
 
     // ---- prologue: halo of chunk 0, weights of steps 0 .. NB-2
@@ -1010,7 +1016,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
 #pragma unroll
     for (int u = 0; u < NB - 1; ++u) fetch_b(u / 9, u % 9, u);  // (NB - 1 <= 9: all in chunk 0)
     int rd = 0;                                              // weight stage of the current step
-  if constexpr (CDF_HALO_PIPE != 0 && NB >= 4) {
+  if constexpr (CDF_HALO_PIPE != 0 && NB >= 4 && MT == 1) {
     // Software pipeline over whole tap steps: the fragments of step s+1 are read while the MFMAs of step s run, so the barrier
     // at the end of a step has to make the data of step s+2 visible (hence a wave waits for ITS pieces of step s+2 before it);
     // in-kernel timing of the unpipelined loop: 12 reads -> their latency -> 12 MFMAs -> barrier, the matrix pipe idle for the
@@ -1019,7 +1025,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
     CDF_LDS_BARRIER();
     bf16x8_v fa_h[2][2], fa_l[2][2], fb_h[2][2][NT], fb_l[2][2][NT];     // [set][k-step]
     auto read_frags = [&](int set, const unsigned short* sa, int t, int stage) {
-        const int row = row0 + (int)ph.dy[t] * HW2 + (int)ph.dx[t];
+        const int row = row0[0] + (int)ph.dy[t] * HW2 + (int)ph.dx[t];
         const int swa = (row >> 2) & 3;
         const unsigned short* sb = bst0 + stage * BSTAGE;
 #pragma unroll
@@ -1102,16 +1108,19 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
             if (t < TA) fetch_a(t, (c + 1) & 1);
             if (t == TA - 1 && c + 2 < nchunks) advance_a();
             fetch_b(t + NB - 1 < 9 ? c : c + 1, (t + NB - 1) % 9, rd == 0 ? NB - 1 : rd - 1);   // step + NB-1 -> the stage read last step
-            const int row = row0 + (int)ph.dy[t] * HW2 + (int)ph.dx[t];
-            const int swa = (row >> 2) & 3;
+            const int tapoff = (int)ph.dy[t] * HW2 + (int)ph.dx[t];
             const unsigned short* sb = bst0 + rd * BSTAGE;
             rd = rd + 1 == NB ? 0 : rd + 1;
-            bf16x8_v ah[2], al[2], bh[2][NT], bl[2][NT];
+            bf16x8_v ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const int off = row * RE + ((ks * 2 + half) ^ swa) * 8;
-                ah[ks] = *(const bf16x8_v*)(sa + off);
-                al[ks] = *(const bf16x8_v*)(sa + PLANE_A + off);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int row = row0[i] + tapoff;
+                    const int off = row * RE + ((ks * 2 + half) ^ ((row >> 2) & 3)) * 8;
+                    ah[ks][i] = *(const bf16x8_v*)(sa + off);
+                    al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
+                }
                 const int kc = ((ks * 2 + half) ^ swb) * 8;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
@@ -1123,11 +1132,13 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    acc[0][j] = CDF_MFMA_BF16(al[ks], bh[ks][j], acc[0][j]);
-                    acc[0][j] = CDF_MFMA_BF16(ah[ks], bl[ks][j], acc[0][j]);
-                    acc[0][j] = CDF_MFMA_BF16(ah[ks], bh[ks][j], acc[0][j]);
-                }
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        acc[i][j] = CDF_MFMA_BF16(al[ks][i], bh[ks][j], acc[i][j]);
+                        acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bl[ks][j], acc[i][j]);
+                        acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bh[ks][j], acc[i][j]);
+                    }
             // the weights of step + 1 (requested NB - 2 steps ago) have landed -- and with them, in order, every halo segment
             // requested before them; still in flight: the weight requests of the last NB - 2 steps and the halo segments
             // requested in those steps (a compile-time count per tap index)
@@ -1825,6 +1836,13 @@ static int g_spx_halo = 7;                     // 3 x 3 stride-1 layers: input t
                                                // 16 (1), 32 (2), 64 (4), 128 (8) (tuning / test hook; 128: measured slower than the
                                                // generic kernel -- only 3 weight stages fit next to its 2 x 51 KB halo buffers)
 static long long g_spx_halo_min_tiles = 1;
+static int g_spx_halo_bm = 0;                  // 0 = automatic, 128 / 256 = forced tile height of the halo kernel
+
+extern "C" int cdf_conv_gemm_bf16x_halo_bm(int bm) {
+    CDF_REQUIRE(bm == 0 || bm == 128 || bm == 256, "cdf_conv_gemm_bf16x_halo_bm: 0, 128 or 256");
+    g_spx_halo_bm = bm;
+    return 0;
+}
 
 extern "C" int cdf_conv_gemm_bf16x_halo(int enable, int min_tiles) {
     g_spx_halo = enable & 15;
@@ -1832,24 +1850,27 @@ extern "C" int cdf_conv_gemm_bf16x_halo(int enable, int min_tiles) {
     return 0;
 }
 
-template <int W, int BN>
+template <int W, int BN, int BM>
 static int launch_igemm_halo(const SpxArgs& a, int M, hipStream_t s) {
-    // weight stages: as many as fit next to the two halo buffers (151.5 KB for BN = 128 at every width)
-    constexpr int NB = W >= 128 ? 3 : (W == 64 ? 5 : 6);
-    constexpr int TH = 128 / W, HR = (TH + 2) * (W + 2), HRP = (HR + 15) / 16 * 16;
-    constexpr size_t stages = (size_t)2 * 2 * HRP * 64 + (size_t)NB * 2 * BN * 64 + 16 * sizeof(int);
-    constexpr size_t epi = (size_t)128 * (BN + 8) * sizeof(float);
+    // weight stages: as many as fit next to the two halo buffers
+    constexpr int TH = BM / W, HR = (TH + 2) * (W + 2), HRP = (HR + 15) / 16 * 16;
+    constexpr size_t abytes = (size_t)2 * 2 * HRP * 64, bstage = (size_t)2 * BN * 64;
+    constexpr int NBfit = (int)((160 * 1024 - 64 - abytes) / bstage);
+    constexpr int NB = NBfit > 6 ? 6 : NBfit;
+    static_assert(NB >= 3, "halo tile leaves no room for three weight stages");
+    constexpr size_t stages = abytes + (size_t)NB * bstage + 16 * sizeof(int);
+    constexpr size_t epi = (size_t)BM * (BN + 8) * sizeof(float);
     constexpr size_t lds = stages > epi ? stages : epi;
     static_assert(lds <= 160 * 1024, "halo tile does not fit the LDS");
 #ifndef CDF_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_halo_kernel<W, BN, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_halo_kernel<W, BN, NB, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
 #endif
-    const int tiles = (M / 128) * cdf_cdiv(a.Cout, BN);
-    CDF_LAUNCH((conv_igemm_halo_kernel<W, BN, NB>), dim3(tiles), dim3(512), lds, s, a);
+    const int tiles = (M / BM) * cdf_cdiv(a.Cout, BN);
+    CDF_LAUNCH((conv_igemm_halo_kernel<W, BN, NB, BM>), dim3(tiles), dim3(512), lds, s, a);
     return cdf_check_launch("conv_igemm_halo");
 }
 
@@ -1910,9 +1931,15 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
         const bool dx_ok = dxs == 7;                         // (is3x3: three groups of equal dy in {-1, 0, 1})
         const long long tiles = (long long)(M / 128) * cdf_cdiv(Cout, n64 ? 64 : 128);
         if (dx_ok && tiles >= g_spx_halo_min_tiles) {
-#define CDF_HALO_CASE(WW)                                                             \
-    if (W == WW && (g_spx_halo & (WW / 16)) && H % (128 / WW) == 0)                    \
-        return n64 ? launch_igemm_halo<WW, 64>(a, M, CDF_S) : launch_igemm_halo<WW, 128>(a, M, CDF_S);
+#define CDF_HALO_CASE(WW)                                                                                              \
+    if (W == WW && (g_spx_halo & (WW / 16)) && H % (128 / WW) == 0) {                                                  \
+        /* 256-pixel tiles (half the weight bytes per MFMA) when they still give every CU a tile and fit the LDS */     \
+        if (WW <= 64 && g_spx_halo_bm != 128 && H % (256 / WW) == 0 && M % 256 == 0 &&                                   \
+            (g_spx_halo_bm == 256 || (long long)(M / 256) * cdf_cdiv(Cout, n64 ? 64 : 128) >= 256))                     \
+            return n64 ? launch_igemm_halo<WW, 64, WW <= 64 ? 256 : 128>(a, M, CDF_S)                                   \
+                       : launch_igemm_halo<WW, 128, WW <= 64 ? 256 : 128>(a, M, CDF_S);                                 \
+        return n64 ? launch_igemm_halo<WW, 64, 128>(a, M, CDF_S) : launch_igemm_halo<WW, 128, 128>(a, M, CDF_S);        \
+    }
             CDF_HALO_CASE(128) CDF_HALO_CASE(64) CDF_HALO_CASE(32) CDF_HALO_CASE(16)
 #undef CDF_HALO_CASE
         }

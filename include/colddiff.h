@@ -173,6 +173,8 @@ int cdf_conv_gemm_bf16x_taprot(int enable);
  * gather kernel.  min_tiles: smallest tile count (128 pixels x BN) the LDS-resident form is used for.  Only the fp32
  * summation order depends on it. */
 int cdf_conv_gemm_bf16x_halo(int enable, int min_tiles);
+/* tuning / test hook: pixels per tile of the LDS-resident-input kernel: 0 = automatic (256 where every CU still gets a tile), 128, 256 */
+int cdf_conv_gemm_bf16x_halo_bm(int bm);
 /* Tuning / test hook: allow (1, default) or forbid (0) the two-taps-per-tile form of cdf_conv_wgrad_bf16x used when
  * CA <= 64 < CB.  Process-wide; results do not depend on it. */
 int cdf_conv_wgrad_bf16x_stack(int enable);

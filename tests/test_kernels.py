@@ -694,11 +694,14 @@ def test_conv_presplit_halo(be, case):
     generic kernel must give the same numbers to rounding."""
     be.L.cdf_conv_gemm_bf16x_halo(15, 1)
     try:
-        _spx_case(be, *case)
+        for bm in (128, 256):                         # both tile heights of the LDS-resident kernel
+            be.L.cdf_conv_gemm_bf16x_halo_bm(bm)
+            _spx_case(be, *case)
         be.L.cdf_conv_gemm_bf16x_halo(0, 1)
         _spx_case(be, *case)
     finally:
         be.L.cdf_conv_gemm_bf16x_halo(7, 1)
+        be.L.cdf_conv_gemm_bf16x_halo_bm(0)
 
 
 @pytest.mark.parametrize("case", [(1, 136, 72, 16, 3, 1, 1), (2, 64, 136, 16, 3, 1, 1), (1, 136, 40, 32, 3, 1, 1)])
@@ -730,11 +733,14 @@ def test_conv_presplit_large(case):
     from conftest import Backend
     be = Backend("hip")
     _spx_case(be, *case)
-    be.L.cdf_conv_gemm_bf16x_halo(15, 1)          # LDS-resident input tiles at every width (128 is off by default)
+    be.L.cdf_conv_gemm_bf16x_halo(15, 1)          # LDS-resident input tiles at every width (128 is off by default), both tile heights
     try:
-        _spx_case(be, *case)
+        for bm in (128, 256):
+            be.L.cdf_conv_gemm_bf16x_halo_bm(bm)
+            _spx_case(be, *case)
     finally:
         be.L.cdf_conv_gemm_bf16x_halo(7, 1)
+        be.L.cdf_conv_gemm_bf16x_halo_bm(0)
 
 
 @pytest.mark.parametrize("ns", [1, 3, 7, 31, 32, 37, 64, 70, 227])

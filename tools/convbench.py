@@ -15,6 +15,8 @@ if os.environ.get('KB_TAPROT'):
     L.cdf_conv_gemm_bf16x_taprot(int(os.environ['KB_TAPROT']))
 if os.environ.get('KB_HALO'):
     L.cdf_conv_gemm_bf16x_halo(*[int(v) for v in os.environ['KB_HALO'].split(',')])
+if os.environ.get('KB_HALO_BM'):
+    L.cdf_conv_gemm_bf16x_halo_bm(int(os.environ['KB_HALO_BM']))
 if os.environ.get('KB_WAVES'):
     L.cdf_conv_gemm_bf16x_waves(int(os.environ['KB_WAVES']))
 
