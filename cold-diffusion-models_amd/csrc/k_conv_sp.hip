@@ -1832,9 +1832,10 @@ static int launch_igemm_spx(const SpxArgs& a, int M, hipStream_t s) {
     return cdf_check_launch("conv_igemm_spx");
 }
 
-static int g_spx_halo = 7;                     // 3 x 3 stride-1 layers: input tile resident in LDS; bit mask over the image width
-                                               // 16 (1), 32 (2), 64 (4), 128 (8) (tuning / test hook; 128: measured slower than the
-                                               // generic kernel -- only 3 weight stages fit next to its 2 x 51 KB halo buffers)
+static int g_spx_halo = 15;                    // 3 x 3 stride-1 layers: input tile resident in LDS; bit mask over the image width
+                                               // 16 (1), 32 (2), 64 (4), 128 (8); 16: at width 128 also for 128-wide N tiles (measured
+                                               // level with the generic kernel there: only 3 weight stages fit next to 2 x 51 KB of halo;
+                                               // with 64-wide N tiles a 256-pixel tile fits and wins) (tuning / test hook)
 static long long g_spx_halo_min_tiles = 1;
 static int g_spx_halo_bm = 0;                  // 0 = automatic, 128 / 256 = forced tile height of the halo kernel
 
@@ -1845,7 +1846,7 @@ extern "C" int cdf_conv_gemm_bf16x_halo_bm(int bm) {
 }
 
 extern "C" int cdf_conv_gemm_bf16x_halo(int enable, int min_tiles) {
-    g_spx_halo = enable & 15;
+    g_spx_halo = enable & 31;
     g_spx_halo_min_tiles = min_tiles > 0 ? min_tiles : 1;
     return 0;
 }
@@ -1932,11 +1933,12 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
         const long long tiles = (long long)(M / 128) * cdf_cdiv(Cout, n64 ? 64 : 128);
         if (dx_ok && tiles >= g_spx_halo_min_tiles) {
 #define CDF_HALO_CASE(WW)                                                                                              \
-    if (W == WW && (g_spx_halo & (WW / 16)) && H % (128 / WW) == 0) {                                                  \
-        /* 256-pixel tiles (half the weight bytes per MFMA) when they still give every CU a tile and fit the LDS */     \
-        if (WW <= 64 && g_spx_halo_bm != 128 && H % (256 / WW) == 0 && M % 256 == 0 &&                                   \
+    if (W == WW && (g_spx_halo & (WW / 16)) && H % (128 / WW) == 0 && (WW < 128 || n64 || (g_spx_halo & 16))) {          \
+        /* 256-pixel tiles (half the weight bytes per MFMA) when they still give every CU a tile and fit the LDS      \
+           (at 128-pixel width only next to 64-wide weight stages) */                                                  \
+        if ((WW <= 64 || n64) && g_spx_halo_bm != 128 && H % (256 / WW) == 0 && M % 256 == 0 &&                          \
             (g_spx_halo_bm == 256 || (long long)(M / 256) * cdf_cdiv(Cout, n64 ? 64 : 128) >= 256))                     \
-            return n64 ? launch_igemm_halo<WW, 64, WW <= 64 ? 256 : 128>(a, M, CDF_S)                                   \
+            return n64 ? launch_igemm_halo<WW, 64, 256>(a, M, CDF_S)                                                    \
                        : launch_igemm_halo<WW, 128, WW <= 64 ? 256 : 128>(a, M, CDF_S);                                 \
         return n64 ? launch_igemm_halo<WW, 64, 128>(a, M, CDF_S) : launch_igemm_halo<WW, 128, 128>(a, M, CDF_S);        \
     }

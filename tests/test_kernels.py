@@ -692,7 +692,7 @@ def test_conv_presplit_halo(be, case):
     """3 x 3 stride-1 layers with the input tile resident in LDS (conv_igemm_halo_kernel): 128-pixel strips of 16- and 32-wide
     images, 128- and 64-wide N tiles, several channel chunks, forward taps and the mirrored taps of the data gradient; the
     generic kernel must give the same numbers to rounding."""
-    be.L.cdf_conv_gemm_bf16x_halo(15, 1)
+    be.L.cdf_conv_gemm_bf16x_halo(31, 1)
     try:
         for bm in (128, 256):                         # both tile heights of the LDS-resident kernel
             be.L.cdf_conv_gemm_bf16x_halo_bm(bm)
@@ -700,7 +700,7 @@ def test_conv_presplit_halo(be, case):
         be.L.cdf_conv_gemm_bf16x_halo(0, 1)
         _spx_case(be, *case)
     finally:
-        be.L.cdf_conv_gemm_bf16x_halo(7, 1)
+        be.L.cdf_conv_gemm_bf16x_halo(15, 1)
         be.L.cdf_conv_gemm_bf16x_halo_bm(0)
 
 
@@ -733,13 +733,13 @@ def test_conv_presplit_large(case):
     from conftest import Backend
     be = Backend("hip")
     _spx_case(be, *case)
-    be.L.cdf_conv_gemm_bf16x_halo(15, 1)          # LDS-resident input tiles at every width (128 is off by default), both tile heights
+    be.L.cdf_conv_gemm_bf16x_halo(31, 1)          # LDS-resident input tiles at every width (128 is off by default), both tile heights
     try:
         for bm in (128, 256):
             be.L.cdf_conv_gemm_bf16x_halo_bm(bm)
             _spx_case(be, *case)
     finally:
-        be.L.cdf_conv_gemm_bf16x_halo(7, 1)
+        be.L.cdf_conv_gemm_bf16x_halo(15, 1)
         be.L.cdf_conv_gemm_bf16x_halo_bm(0)
 
 
