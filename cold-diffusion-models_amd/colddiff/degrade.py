@@ -133,6 +133,24 @@ def noise_step(img, x1, noise, ca, cb, t, est_noise):
     return out
 
 
+def blend_qsample(x1, x2, alphas, one_minus, t):
+    """alphas[t[b]] * x1 + one_minus[t[b]] * x2 with per-pixel tables [T, 1, H, W] (or [T, H, W])."""
+    x1, x2 = _img(x1), _img(x2)
+    B, C, H, W = x1.shape
+    out = torch.empty_like(x1)
+    rt.lib().cdf_blend_qsample(P(x1), P(x2), P(alphas), P(one_minus), P(t), P(out), B, C, H * W, rt.stream(x1))
+    return out
+
+
+def blend_step(img, x1, x2, alphas, one_minus, t):
+    """img - q(x1, x2, t-1) + q(x1, x2, t-2) (x1 itself when t = 1) with the second image held fixed."""
+    img, x1, x2 = _img(img), _img(x1), _img(x2)
+    out = torch.empty_like(img)
+    rt.lib().cdf_blend_step(P(img), P(x1), P(x2), P(alphas), P(one_minus), int(t), P(out), img.shape[2] * img.shape[3], img.numel(),
+                            rt.stream(img))
+    return out
+
+
 class _Loss(torch.autograd.Function):
     """mean |x_start - x_recon| (l1) or mean squared error (l2); gradient flows to x_recon only."""
 

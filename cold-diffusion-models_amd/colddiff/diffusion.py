@@ -489,6 +489,168 @@ class DenoiseDiffusion(nn.Module):
 
 
 # ===================================================================================================
+# demixing: the cosine schedule blends an image of one dataset into an image of another
+# (demixing-diffusion-pytorch/demixing_diffusion_pytorch/demixing_diffusion_pytorch.py:309-502 = DEMIX)
+# ===================================================================================================
+class DemixDiffusion(DenoiseDiffusion):
+    """Same constructor, schedule, q_sample, p_losses, forward(x1, x2) and sample as the denoising class (the reference
+    files differ only in the methods below, DEMIX vs DENOISE diff); `x2` is an image instead of Gaussian noise."""
+
+    def gen_sample(self, batch_size=16, img=None, noise_level=0, t=None):
+        # always the fixed-x2 form, whatever sampling_routine says (DEMIX:384-413)
+        self.denoise_fn.eval()
+        t = self.num_timesteps if t is None else t
+        noise = rt.check(img)
+        img = noise + torch.randn_like(noise) * noise_level
+        direct_recons, img = self._reverse(batch_size, img, t, False, noise)
+        return noise, direct_recons, img
+
+    @torch.no_grad()
+    def forward_and_backward(self, batch_size=16, img1=None, img2=None, t=None, times=None, eval=True):
+        """img1 mixed step by step into img2, then back with img2 held fixed (DEMIX:416-458)."""
+        self.denoise_fn.eval()
+        t = self.num_timesteps if t is None else t
+        ca, cb = self._tables()
+        img, noise = rt.check(img1), rt.check(img2)
+        Forward = [img]
+        for i in range(t):
+            n_img = D.noise_qsample(img, noise, ca, cb, _full_step(batch_size, i, img.device))
+            Forward.append(n_img)
+        Backward, img = [], n_img
+        while t:
+            step = _full_step(batch_size, t - 1, img.device)
+            x1_bar = self.denoise_fn(img, step)
+            Backward.append(img)
+            img = D.noise_step(img, x1_bar, noise, ca, cb, t, False)
+            t = t - 1
+        return Forward, Backward, img
+
+    def all_sample(self, batch_size=16, img=None, t=None, times=None, eval=True):
+        X1_0s, _, X_ts = super().all_sample(batch_size=batch_size, img=img, t=t, times=times, eval=eval)
+        return X1_0s, X_ts                                            # (DEMIX:495)
+
+
+# ===================================================================================================
+# defading generation: per-pixel Gaussian-mask blend of an image into a second (solid-colour) image
+# (defading-generation-diffusion-pytorch/defading_diffusion_pytorch/defading_diffusion_pytorch.py:309-568 = DEFGEN)
+# ===================================================================================================
+def get_fade_kernel(dims, std):                                       # DEFGEN:309-314
+    k = D.gaussian_kernel2d(dims, std)
+    k = k / torch.max(k)
+    return (torch.ones_like(k) - k)[1:, 1:]
+
+
+def get_kernels_with_schedule(timesteps, size, kernel_std, initial_mask):             # DEFGEN:316-324
+    out, kers = [], torch.ones((1, size, size))
+    for i in range(timesteps):
+        kers = kers * get_fade_kernel((size + 1, size + 1), (kernel_std * (i + initial_mask), kernel_std * (i + initial_mask)))
+        out.append(kers)
+    return torch.stack(out)
+
+
+def get_reverse_kernels_with_schedule(timesteps, size, kernel_std, initial_mask):     # DEFGEN:327-337
+    out, kers = [], torch.ones((1, size, size))
+    for i in range(timesteps):
+        out.append(kers)
+        kers = kers * get_fade_kernel((size + 1, size + 1), (kernel_std * (i + initial_mask), kernel_std * (i + initial_mask)))
+    out.reverse()
+    return torch.stack(out)
+
+
+class DefadeGenDiffusion(nn.Module):
+    def __init__(self, denoise_fn, *, image_size, channels=3, timesteps=1000, loss_type='l1', train_routine='Final',
+                 sampling_routine='default', reverse=False, kernel_std=0.15, initial_mask=11):
+        super().__init__()
+        self.channels = channels
+        self.image_size = image_size
+        self.denoise_fn = denoise_fn
+        self.num_timesteps = int(timesteps)
+        self.loss_type = loss_type
+        self.reverse = reverse
+        if self.reverse:
+            one_minus_alphas = get_reverse_kernels_with_schedule(timesteps, image_size, kernel_std, initial_mask)
+            alphas = 1. - one_minus_alphas
+        else:
+            alphas = get_kernels_with_schedule(timesteps, image_size, kernel_std, initial_mask)
+            one_minus_alphas = 1. - alphas
+        self.register_buffer('alphas', alphas)                       # [T, 1, H, W]
+        self.register_buffer('one_minus_alphas', one_minus_alphas)
+        self.train_routine = train_routine
+        self.sampling_routine = sampling_routine
+
+    def q_sample(self, x_start, x_end, t):
+        return D.blend_qsample(rt.check(x_start), x_end, self.alphas, self.one_minus_alphas, t.contiguous())
+
+    def get_x2_bar_from_xt(self, x1_bar, xt, t):
+        return (xt - self.alphas[t] * x1_bar) / (self.one_minus_alphas[t] + 0.00000000000001)
+
+    @torch.no_grad()
+    def _reverse(self, batch_size, img, t, x2, collect=None):
+        direct_recons = None
+        while t:
+            step = _full_step(batch_size, t - 1, img.device)
+            x1_bar = self.denoise_fn(img, step)
+            if direct_recons is None:
+                direct_recons = x1_bar
+            if collect is not None:
+                collect(x1_bar, img)
+            img = D.blend_step(img, x1_bar, x2, self.alphas, self.one_minus_alphas, t)
+            t = t - 1
+        return direct_recons, img
+
+    def sample(self, batch_size=16, img=None, t=None):               # DEFGEN:386-419 (x2 = the start image)
+        self.denoise_fn.eval()
+        t = self.num_timesteps if t is None else t
+        xt = rt.check(img)
+        direct_recons, img = self._reverse(batch_size, xt, t, xt)
+        self.denoise_fn.train()
+        return xt, direct_recons, img
+
+    def gen_sample(self, batch_size=16, img=None, noise_level=0, t=None):    # DEFGEN:428-457
+        self.denoise_fn.eval()
+        t = self.num_timesteps if t is None else t
+        noise = rt.check(img)
+        img = noise + torch.randn_like(noise) * noise_level
+        direct_recons, img = self._reverse(batch_size, img, t, noise)
+        return noise, direct_recons, img
+
+    @torch.no_grad()
+    def forward_and_backward(self, batch_size=16, img1=None, img2=None, t=None, times=None, eval=True):   # DEFGEN:460-504
+        self.denoise_fn.eval()
+        t = self.num_timesteps if t is None else t
+        img1, img2 = rt.check(img1), rt.check(img2)
+        Forward = [img1]
+        for i in range(self.num_timesteps):                          # (the whole schedule, whatever t says: DEFGEN:475)
+            Forward.append(self.q_sample(img1, img2, _full_step(batch_size, i, img1.device)))
+        Backward = []
+        _, img = self._reverse(batch_size, img2, t, img2, collect=lambda x1, im: Backward.append(im))
+        return Forward, Backward, img
+
+    @torch.no_grad()
+    def all_sample(self, batch_size=16, img=None, t=None, times=None, eval=True):       # DEFGEN:507-541
+        if eval:
+            self.denoise_fn.eval()
+        t = self.num_timesteps if t is None else t
+        img = rt.check(img)
+        X1_0s, X_ts = [], []
+        self._reverse(batch_size, img, t, img, collect=lambda x1, im: (X1_0s.append(x1), X_ts.append(im)))
+        return X1_0s, X_ts
+
+    def p_losses(self, x_start, x_end, t):
+        if self.train_routine == 'Final':
+            x_mix = self.q_sample(x_start=x_start, x_end=x_end, t=t)
+            x_recon = self.denoise_fn(x_mix, t)
+            return D.loss(x_start, x_recon, self.loss_type)
+        raise NotImplementedError()
+
+    def forward(self, x1, x2, *args, **kwargs):
+        b, c, h, w, device, img_size = *x1.shape, x1.device, self.image_size
+        assert h == img_size and w == img_size, f'height and width of image must be {img_size}'
+        t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
+        return self.p_losses(x1, x2, t, *args, **kwargs)
+
+
+# ===================================================================================================
 # resolution (pixelation)
 # ===================================================================================================
 class ResolutionDiffusion(nn.Module):

@@ -139,18 +139,7 @@ class Trainer(object):
         self.pair_noise = hasattr(self.core, 'sqrt_alphas_cumprod')
         self.device = next(self.core.parameters()).device
 
-        if dataset == 'synthetic' or folder is None:
-            self.ds = None
-            self.dl = SyntheticImages(train_batch_size, self.core.channels, image_size, self.device)
-        else:
-            aug = dataset in self.AUG_DATASETS
-            print(dataset, "DA used" if aug else "")
-            self.ds = (Dataset_Aug1 if aug else Dataset)(folder, image_size)
-            sampler = None
-            if parallel.world_size() > 1:
-                sampler = data.distributed.DistributedSampler(self.ds, shuffle=shuffle)
-            self.dl = cycle(data.DataLoader(self.ds, batch_size=train_batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
-                                            pin_memory=True, num_workers=num_workers, drop_last=True))
+        self.ds, self.dl = self._make_loader(folder, dataset, shuffle, num_workers, seed=123457)
 
         # Adam(diffusion_model.parameters(), lr): one flat arena over every parameter of the model
         self.arena = flat.FlatArena(list(self.core.parameters()))
@@ -172,6 +161,20 @@ class Trainer(object):
         self.reset_parameters()
         if load_path is not None:
             self.load(load_path)
+
+    def _make_loader(self, folder, dataset, shuffle, num_workers, seed):
+        """(dataset, endless batch iterator): image folder as in the reference (DEBLUR:1094-1096), or synthetic images."""
+        if dataset == 'synthetic' or folder is None:
+            return None, SyntheticImages(self.batch_size, self.core.channels, self.image_size, self.device, seed=seed)
+        aug = dataset in self.AUG_DATASETS
+        print(dataset, "DA used" if aug else "")
+        ds = (Dataset_Aug1 if aug else Dataset)(folder, self.image_size)
+        sampler = None
+        if parallel.world_size() > 1:
+            sampler = data.distributed.DistributedSampler(ds, shuffle=shuffle)
+        dl = cycle(data.DataLoader(ds, batch_size=self.batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
+                                   pin_memory=True, num_workers=num_workers, drop_last=True))
+        return ds, dl
 
     # -- EMA / checkpoint --------------------------------------------------------------------------------
     def reset_parameters(self):
@@ -206,10 +209,14 @@ class Trainer(object):
             d = d[0]
         return d.to(self.device, non_blocking=True)
 
+    def _second(self, batch):
+        """The second argument of forward(x1, x2), None for the one-image packages; fresh Gaussian noise for the
+        denoising package (DENOISE:738-742)."""
+        return torch.randn_like(batch) if self.pair_noise else None
+
     def _loss(self, batch):
-        if self.pair_noise:
-            return self.core(batch, torch.randn_like(batch))
-        return self.core(batch)
+        x2 = self._second(batch)
+        return self.core(batch) if x2 is None else self.core(batch, x2)
 
     def train_step(self):
         """One optimizer step = gradient_accumulate_every micro-steps + Adam (+ EMA); returns the
@@ -248,8 +255,9 @@ class Trainer(object):
         milestone = self.step // self.save_and_sample_every
         if parallel.rank() == 0:                       # sampling and checkpointing stay on one GPU
             og_img = self._next_batch()
-            if self.pair_noise:
-                og_img = torch.randn_like(og_img)
+            x2 = self._second(og_img)
+            if x2 is not None:                         # the two-image packages sample from the second image (DENOISE:759-762, DEMIX:744)
+                og_img = x2
             if hasattr(self.ema_core, 'defade_fn'):
                 xt, direct_recons, all_images = self.ema_core.sample(batch_size=self.batch_size, faded_recon_sample=og_img)
             else:
@@ -263,3 +271,34 @@ class Trainer(object):
                 self.save(self.step)
         if parallel.world_size() > 1:
             torch.distributed.barrier()
+
+
+class DemixTrainer(Trainer):
+    """Trainer of demixing_diffusion_pytorch (DEMIX:596-775): two image folders; every micro-step mixes a batch of the
+    first into a batch of the second, and sampling starts from images of the second."""
+
+    def __init__(self, diffusion_model, folder1, folder2, *, dataset=None, shuffle=True, num_workers=8, **kw):
+        super().__init__(diffusion_model, folder1, dataset=dataset, shuffle=shuffle, num_workers=num_workers, **kw)
+        self.pair_noise = False
+        self.ds1, self.dl1 = self.ds, self.dl
+        self.ds2, self.dl2 = self._make_loader(folder2, dataset, shuffle, num_workers, seed=7654321)
+
+    def _second(self, batch):
+        d = next(self.dl2)
+        if isinstance(d, (list, tuple)):
+            d = d[0]
+        return d.to(self.device, non_blocking=True)
+
+
+class DefadeGenTrainer(Trainer):
+    """Trainer of the defading-generation package (DEFGEN:646-810): the second image is one uniform random colour per
+    sample and channel, rand(B, 3) - 0.5 spread over the image (DEFGEN:769-773)."""
+
+    def __init__(self, diffusion_model, folder, **kw):
+        super().__init__(diffusion_model, folder, **kw)
+        self.pair_noise = False
+
+    def _second(self, batch):
+        B, C, H, W = batch.shape
+        c = torch.rand((B, C), device=batch.device) - 0.5
+        return c[:, :, None, None].expand(B, C, H, W).contiguous()

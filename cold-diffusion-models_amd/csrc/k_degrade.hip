@@ -552,6 +552,44 @@ __global__ void noise_step_kernel(const float* img, const float* x1, const float
     }
 }
 
+// Per-pixel blend of two images by mask tables [T][H*W] (the "defading generation" forward process,
+// defading-generation-diffusion-pytorch/defading_diffusion_pytorch/defading_diffusion_pytorch.py:543-548):
+//   x_t[b,c,p] = alphas[t[b]][p] * x1[b,c,p] + one_minus_alphas[t[b]][p] * x2[b,c,p]
+__global__ void blend_qsample_kernel(const float* x1, const float* x2, const float* al, const float* om, const int64_t* t, float* out,
+                                     int C, long long HW, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i % HW;
+        const int b = (int)(i / (HW * C));
+        const long long k = (long long)t[b] * HW + p;
+        const float u = al[k] * x1[i];
+        const float v = om[k] * x2[i];
+        out[i] = u + v;
+    }
+}
+
+// One reverse step with a FIXED second image x2 (same file :386-419, :428-457):
+//   xt_bar = al[t-1] x1 + om[t-1] x2 ; xt_sub1 = (t-1 != 0) ? al[t-2] x1 + om[t-2] x2 : x1 ; out = img - xt_bar + xt_sub1
+__global__ void blend_step_kernel(const float* img, const float* x1, const float* x2, const float* al, const float* om, int t, float* out,
+                                  long long HW, long long n) {
+    const float* a1 = al + (long long)(t - 1) * HW;
+    const float* o1 = om + (long long)(t - 1) * HW;
+    const float* a2 = t - 1 != 0 ? al + (long long)(t - 2) * HW : a1;
+    const float* o2 = t - 1 != 0 ? om + (long long)(t - 2) * HW : o1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i % HW;
+        const float xa = x1[i], xb = x2[i];
+        const float u1 = a1[p] * xa, v1 = o1[p] * xb;
+        const float xt_bar = u1 + v1;
+        float xt_sub1 = xa;
+        if (t - 1 != 0) {
+            const float u2 = a2[p] * xa, v2 = o2[p] * xb;
+            xt_sub1 = u2 + v2;
+        }
+        const float d = img[i] - xt_bar;
+        out[i] = d + xt_sub1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // losses: mean|x-y| (l1) / mean (x-y)^2 (l2).  Two-stage deterministic reduction.
 // ------------------------------------------------------------------------------------------------
@@ -779,6 +817,21 @@ extern "C" int cdf_noise_step(const float* img, const float* x1, const float* no
     CDF_REQUIRE(est_noise || noise, "cdf_noise_step: fixed-noise mode needs the noise tensor");
     CDF_LAUNCH(noise_step_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, CDF_S, img, x1, noise, ca, cb, t, est_noise, out, n);
     return cdf_check_launch("noise_step");
+}
+
+extern "C" int cdf_blend_qsample(const float* x1, const float* x2, const float* alphas, const float* one_minus, const int64_t* t,
+                                 float* out, int B, int C, long long HW, void* stream) {
+    CDF_REQUIRE(x1 && x2 && alphas && one_minus && t && out && B > 0 && C > 0 && HW > 0, "cdf_blend_qsample: bad args");
+    const long long n = (long long)B * C * HW;
+    CDF_LAUNCH(blend_qsample_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, CDF_S, x1, x2, alphas, one_minus, t, out, C, HW, n);
+    return cdf_check_launch("blend_qsample");
+}
+
+extern "C" int cdf_blend_step(const float* img, const float* x1, const float* x2, const float* alphas, const float* one_minus, int t,
+                              float* out, long long HW, long long n, void* stream) {
+    CDF_REQUIRE(img && x1 && x2 && alphas && one_minus && out && t >= 1 && HW > 0 && n > 0, "cdf_blend_step: bad args");
+    CDF_LAUNCH(blend_step_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, CDF_S, img, x1, x2, alphas, one_minus, t, out, HW, n);
+    return cdf_check_launch("blend_step");
 }
 
 extern "C" int cdf_loss_fwd(const float* x, const float* y, float* out, float* partial /*>=1024 floats*/, long long n,

@@ -83,6 +83,14 @@ int cdf_noise_qsample(const float* x0, const float* eps, const float* ca, const 
 int cdf_noise_step(const float* img, const float* x1, const float* noise, const float* ca, const float* cb, int t,
                    int est_noise, float* out, long long n, void* stream);
 
+/* Per-pixel blend of two images by mask tables alphas / one_minus [T][H*W] ("defading generation":
+ * defading-generation-diffusion-pytorch/defading_diffusion_pytorch/defading_diffusion_pytorch.py:543-548 q_sample;
+ * :386-419 / :428-457 the reverse step with the second image held fixed).  NCHW images, t per sample / per call. */
+int cdf_blend_qsample(const float* x1, const float* x2, const float* alphas, const float* one_minus, const int64_t* t, float* out,
+                      int B, int C, long long HW, void* stream);
+int cdf_blend_step(const float* img, const float* x1, const float* x2, const float* alphas, const float* one_minus, int t, float* out,
+                   long long HW, long long n, void* stream);
+
 /* L1 / L2 training loss (deblurring_diffusion_pytorch.py:966-971): out[0] = mean|x-y| or
  * mean (x-y)^2; backward writes d loss / d y scaled by gout[0]. partial: >= 1024 floats. */
 int cdf_loss_fwd(const float* x, const float* y, float* out, float* partial, long long n, int l2, void* stream);

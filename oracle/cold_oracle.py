@@ -18,6 +18,8 @@ Every function cites the reference lines it follows (paths relative to /root/ref
   DENOISE = denoising-diffusion-pytorch/denoising_diffusion_pytorch/denoising_diffusion_pytorch.py
   RESOL   = resolution-diffusion-pytorch/resolution_diffusion_pytorch/resolution_diffusion_pytorch.py
   DEFADE  = defading-diffusion-pytorch/defading_diffusion_pytorch/defading_diffusion_gaussian.py
+  DEMIX   = demixing-diffusion-pytorch/demixing_diffusion_pytorch/demixing_diffusion_pytorch.py
+  DEFGEN  = defading-generation-diffusion-pytorch/defading_diffusion_pytorch/defading_diffusion_pytorch.py
 Networks are functions of a state_dict `sd` (the reference's parameter names), not nn.Modules.
 """
 import math
@@ -490,6 +492,53 @@ def noise_sample(net, img, T, ca, cb, fixed_noise, t=None):           # DENOISE:
         img = img - xt_bar + xt_sub1
         t -= 1
     return noise, direct, img
+
+
+# ---------------------------------------------------------------------------------------------------
+# the forward(x1, x2) packages of SURVEY section 8(f): demixing (= the cosine schedule above with an image as x2;
+# DEMIX:384-413 gen_sample is noise_sample(fixed_noise=True), DEMIX:416-458 is noise_forward_and_backward with noise = img2)
+# and defading generation (per-pixel mask tables)
+# ---------------------------------------------------------------------------------------------------
+def blend_tables(T, size, kernel_std, initial_mask, reverse=False):   # DEFGEN:309-337, 371-376 -> (alphas, one_minus) [T,1,H,W]
+    def fade(n, s):
+        k = gaussian_kernel2d((n, n), (s, s))
+        return (torch.ones_like(k) - k / torch.max(k))[1:, 1:]
+    tabs, kers = [], torch.ones((1, size, size))
+    for i in range(T):
+        if reverse:
+            tabs.append(kers)
+        kers = kers * fade(size + 1, kernel_std * (i + initial_mask))
+        if not reverse:
+            tabs.append(kers)
+    if reverse:
+        tabs.reverse()
+        one_minus = torch.stack(tabs)
+        return 1. - one_minus, one_minus
+    alphas = torch.stack(tabs)
+    return alphas, 1. - alphas
+
+
+def blend_q_sample(x_start, x_end, t, al, om):                        # DEFGEN:543-548 (extract = rows t[b] of the tables)
+    return al[t] * x_start + om[t] * x_end
+
+
+def blend_sample(net, img, x2, T, al, om, t=None, collect=None):      # DEFGEN:386-419 / 428-457 / 507-541: x2 held fixed
+    t = T if t is None else t
+    B, direct = img.shape[0], None
+    while t:
+        step = torch.full((B,), t - 1, dtype=torch.long)
+        x1 = net(img, step)
+        if direct is None:
+            direct = x1
+        if collect is not None:
+            collect(x1, img)
+        xt_bar = blend_q_sample(x1, x2, step, al, om)
+        xt_sub1 = x1
+        if t - 1 != 0:
+            xt_sub1 = blend_q_sample(x1, x2, torch.full((B,), t - 2, dtype=torch.long), al, om)
+        img = img - xt_bar + xt_sub1
+        t -= 1
+    return direct, img
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -28,6 +28,9 @@ PACKAGES = {
     "denoising": ("denoising-diffusion-pytorch", "denoising_diffusion_pytorch"),
     "resolution": ("resolution-diffusion-pytorch", "resolution_diffusion_pytorch"),
     "defading": ("defading-diffusion-pytorch", "defading_diffusion_pytorch"),
+    # the two forward(x1, x2) packages (the second shares its package NAME with "defading")
+    "demixing": ("demixing-diffusion-pytorch", "demixing_diffusion_pytorch"),
+    "defading_generation": ("defading-generation-diffusion-pytorch", "defading_diffusion_pytorch"),
 }
 
 
@@ -88,7 +91,7 @@ def install_stubs():
 
 
 def load(which):
-    """Import one reference package ('deblurring' | 'denoising' | 'resolution' | 'defading')."""
+    """Import one reference package ('deblurring' | 'denoising' | 'resolution' | 'defading' | 'demixing' | 'defading_generation')."""
     assert available(), "reference tree not present (this only works in the build container)"
     install_stubs()
     folder, pkg = PACKAGES[which]

@@ -175,8 +175,63 @@ def variant_cases(net_sd):
     return out
 
 
+def mixing_cases(net_sd):
+    """The forward(x1, x2) packages: demixing and defading generation."""
+    import contextlib
+    import io
+    out = {}
+    g = torch.Generator().manual_seed(SEED + 5)
+    cpu = lambda L: [z.clone() for z in L]
+    quiet = lambda: contextlib.redirect_stdout(io.StringIO())
+    # ---- demixing ------------------------------------------------------------------------------------------
+    ref = ref_shim.load("demixing")
+    net = ref.Unet(dim=8, dim_mults=(1, 2), channels=3)
+    net.load_state_dict(net_sd)
+    d = ref.GaussianDiffusion(net, image_size=16, channels=3, timesteps=5)
+    x1, x2, t = images(2, 3, 16, g), images(2, 3, 16, g), torch.tensor([4, 1])
+    with torch.no_grad(), quiet():
+        q = d.q_sample(x1, x2, t)
+        gen = d.gen_sample(batch_size=2, img=x2, noise_level=0)
+        smp = d.sample(batch_size=2, img=x2)
+        F1, B1, i1 = d.forward_and_backward(batch_size=2, img1=x1, img2=x2)
+        X0, Xt = d.all_sample(batch_size=2, img=x2)
+    net.zero_grad()
+    loss = d.p_losses(x1, x2, t)
+    loss.backward()
+    out["demix"] = dict(T=5, x1=x1, x2=x2, t=t, q=q, gen=gen, sample=smp, fab=(cpu(F1), cpu(B1), i1), all_sample=(cpu(X0), cpu(Xt)),
+                        loss=loss.detach().clone(), grads={k: p.grad.clone() for k, p in net.named_parameters()})
+    # ---- defading generation -----------------------------------------------------------------------------------
+    ref = ref_shim.load("defading_generation")
+    net = ref.Unet(dim=8, dim_mults=(1, 2), channels=3)
+    net.load_state_dict(net_sd)
+    for reverse in (False, True):
+        d = ref.GaussianDiffusion(net, image_size=16, channels=3, timesteps=5, reverse=reverse, kernel_std=0.3, initial_mask=2)
+        x1 = images(2, 3, 16, g)
+        x2 = (torch.rand((2, 3), generator=g) - 0.5)[:, :, None, None].expand(2, 3, 16, 16).contiguous()
+        t = torch.tensor([3, 0])
+        with torch.no_grad(), quiet():
+            q = d.q_sample(x1, x2, t)
+            smp = d.sample(batch_size=2, img=x2)
+            gen = d.gen_sample(batch_size=2, img=x2, noise_level=0)
+            F1, B1, i1 = d.forward_and_backward(batch_size=2, img1=x1, img2=x2)
+            X0, Xt = d.all_sample(batch_size=2, img=x2)
+        net.zero_grad()
+        loss = d.p_losses(x1, x2, t)
+        loss.backward()
+        out[f"defgen/{int(reverse)}"] = dict(T=5, kernel_std=0.3, initial_mask=2, x1=x1, x2=x2, t=t, alphas=d.alphas.clone(),
+                                             one_minus=d.one_minus_alphas.clone(), q=q, sample=smp, gen=gen, fab=(cpu(F1), cpu(B1), i1),
+                                             all_sample=(cpu(X0), cpu(Xt)), loss=loss.detach().clone(),
+                                             grads={k: p.grad.clone() for k, p in net.named_parameters()} if not reverse else None)
+    return out
+
+
 def main():
     assert ref_shim.available(), "needs /root/reference (build container)"
+    if "--mixing" in sys.argv:                                        # only (re)write mixing.pt
+        sd = torch.load(os.path.join(HERE, "diffusion.pt"), weights_only=False)["deblur/net_sd"]
+        torch.save(mixing_cases(sd), os.path.join(HERE, "mixing.pt"))
+        print("mixing.pt", os.path.getsize(os.path.join(HERE, "mixing.pt")) // 1024, "KiB")
+        return
     if "--variants" in sys.argv:                                      # only (re)write variants.pt
         sd = torch.load(os.path.join(HERE, "diffusion.pt"), weights_only=False)["deblur/net_sd"]
         torch.save(variant_cases(sd), os.path.join(HERE, "variants.pt"))
@@ -188,6 +243,7 @@ def main():
     dc = diffusion_cases()
     torch.save(dc, os.path.join(HERE, "diffusion.pt"))
     torch.save(variant_cases(dc["deblur/net_sd"]), os.path.join(HERE, "variants.pt"))
+    torch.save(mixing_cases(dc["deblur/net_sd"]), os.path.join(HERE, "mixing.pt"))
     # torchgeometry boundary: values observed when the reference builds its kernels through the shim
     k = ref_shim.get_gaussian_kernel2d((11, 11), (7.0, 7.0))
     print("k=11 sigma=7 centre %.10f corner %.10f" % (k[5, 5].item(), k[0, 0].item()))

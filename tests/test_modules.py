@@ -247,6 +247,87 @@ def test_resolution_train_routines(mbe):
         d.p_losses(x, torch.zeros_like(t))
 
 
+def test_demixing_golden(mbe):
+    """demixing_diffusion_pytorch: q_sample, sample, gen_sample, forward_and_backward, all_sample, loss + grads."""
+    from demixing_diffusion_pytorch import GaussianDiffusion
+    c = load("mixing.pt")["demix"]
+    net = _net(mbe, load("diffusion.pt")["deblur/net_sd"])
+    d = GaussianDiffusion(net, image_size=16, channels=3, timesteps=c["T"]).to(mbe.device)
+    x1, x2, t = mbe.to(c["x1"]), mbe.to(c["x2"]), mbe.to(c["t"])
+    with torch.no_grad():
+        assert torch.equal(d.q_sample(x1, x2, t).cpu(), c["q"])
+        _lists_close(list(d.gen_sample(batch_size=2, img=x2, noise_level=0)), list(c["gen"]), 1e-4)
+        _lists_close(list(d.sample(batch_size=2, img=x2)), list(c["sample"]), 1e-4)
+        F1, B1, i1 = d.forward_and_backward(batch_size=2, img1=x1, img2=x2)
+        _lists_close(F1, c["fab"][0], 1e-6), _lists_close(B1, c["fab"][1], 1e-4), _lists_close([i1], [c["fab"][2]], 1e-4)
+        X0, Xt = d.all_sample(batch_size=2, img=x2)
+        _lists_close(X0, c["all_sample"][0], 1e-4), _lists_close(Xt, c["all_sample"][1], 1e-4)
+    loss = d.p_losses(x1, x2, t)
+    loss.backward()
+    assert abs(loss.item() - c["loss"].item()) <= 1e-5
+    grad_check(net.named_parameters(), c["grads"])
+
+
+def test_defading_generation_golden(mbe):
+    """The defading-generation package (per-pixel mask blend into a solid colour)."""
+    import importlib
+    import sys
+    pkg_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cold-diffusion-models_amd", "defading_generation")
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "defading_diffusion_pytorch" or k.startswith("defading_diffusion_pytorch.")}
+    sys.path.insert(0, pkg_dir)
+    try:
+        GaussianDiffusion = importlib.import_module("defading_diffusion_pytorch").GaussianDiffusion
+    finally:
+        sys.path.remove(pkg_dir)
+        for k in [k for k in sys.modules if k == "defading_diffusion_pytorch" or k.startswith("defading_diffusion_pytorch.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    g = load("mixing.pt")
+    for key in ("defgen/0", "defgen/1"):
+        c = g[key]
+        net = _net(mbe, load("diffusion.pt")["deblur/net_sd"])
+        d = GaussianDiffusion(net, image_size=16, channels=3, timesteps=c["T"], reverse=key.endswith("1"), kernel_std=c["kernel_std"],
+                              initial_mask=c["initial_mask"]).to(mbe.device)
+        assert torch.equal(d.alphas.cpu(), c["alphas"]) and torch.equal(d.one_minus_alphas.cpu(), c["one_minus"])
+        x1, x2, t = mbe.to(c["x1"]), mbe.to(c["x2"]), mbe.to(c["t"])
+        with torch.no_grad():
+            assert torch.equal(d.q_sample(x1, x2, t).cpu(), c["q"])               # same two products and one sum per pixel
+            _lists_close(list(d.sample(batch_size=2, img=x2)), list(c["sample"]), 1e-4)
+            _lists_close(list(d.gen_sample(batch_size=2, img=x2, noise_level=0)), list(c["gen"]), 1e-4)
+            F1, B1, i1 = d.forward_and_backward(batch_size=2, img1=x1, img2=x2)
+            _lists_close(F1, c["fab"][0], 0.0), _lists_close(B1, c["fab"][1], 1e-4), _lists_close([i1], [c["fab"][2]], 1e-4)
+            X0, Xt = d.all_sample(batch_size=2, img=x2)
+            _lists_close(X0, c["all_sample"][0], 1e-4), _lists_close(Xt, c["all_sample"][1], 1e-4)
+        loss = d.p_losses(x1, x2, t)
+        loss.backward()
+        assert abs(loss.item() - c["loss"].item()) <= 1e-5
+        if c["grads"] is not None:
+            grad_check(net.named_parameters(), c["grads"])
+
+
+def test_two_image_trainers(mbe, tmp_path):
+    """Trainer variants of the forward(x1, x2) packages: demixing draws the second image from a second dataset (DEMIX:724-726),
+    defading generation from uniform random colours (DEFGEN:769-773); one optimizer step each on synthetic data."""
+    from demixing_diffusion_pytorch import GaussianDiffusion, Trainer, Unet
+    from colddiff.diffusion import DefadeGenDiffusion
+    from colddiff.trainer import DefadeGenTrainer
+    torch.manual_seed(0)
+    net = quiet(Unet, dim=8, dim_mults=(1, 2), channels=3).to(mbe.device)
+    d = GaussianDiffusion(net, image_size=16, channels=3, timesteps=4).to(mbe.device)
+    tr = quiet(Trainer, d, None, None, dataset='synthetic', image_size=16, train_batch_size=2, results_folder=str(tmp_path / "a"))
+    a, b = tr._next_batch(), tr._second(None)
+    assert a.shape == b.shape == (2, 3, 16, 16) and not torch.equal(a, b)           # two independent image streams
+    w0 = tr.arena.data.clone()
+    assert torch.isfinite(tr.train_step()).item() and not torch.equal(tr.arena.data, w0)
+    net2 = quiet(Unet, dim=8, dim_mults=(1, 2), channels=3).to(mbe.device)
+    d2 = DefadeGenDiffusion(net2, image_size=16, channels=3, timesteps=4, kernel_std=0.3, initial_mask=2).to(mbe.device)
+    tr2 = quiet(DefadeGenTrainer, d2, None, dataset='synthetic', image_size=16, train_batch_size=2, results_folder=str(tmp_path / "b"))
+    c = tr2._second(tr2._next_batch())
+    assert c.shape == (2, 3, 16, 16) and float(c.min()) >= -0.5 and float(c.max()) < 0.5
+    assert torch.equal(c, c[:, :, :1, :1].expand_as(c))                              # one colour per (sample, channel)
+    assert torch.isfinite(tr2.train_step()).item()
+
+
 def test_defading_golden(mbe):
     from defading_diffusion_pytorch import GaussianDiffusion
     g = load("diffusion.pt")

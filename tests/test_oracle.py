@@ -147,6 +147,40 @@ def test_resolution_train_routines_match_golden():
         O.pixelate_q_sample_ref(g["resolution/train/Step/l1"]["x"], torch.tensor([-1, -1, -1]), sizes, "bicubic")
 
 
+def test_mixing_packages_match_golden():
+    """demixing and defading generation: tables, q_sample, every sampler, loss + gradients."""
+    g = load("mixing.pt")
+    sd0 = load("diffusion.pt")["deblur/net_sd"]
+    net = lambda im, st: O.unet_forward(sd0, im, st)
+    c = g["demix"]
+    ca, cb = O.cosine_tables(c["T"])
+    assert torch.equal(O.noise_q_sample(c["x1"], c["x2"], c["t"], ca, cb), c["q"])
+    _close_lists(list(O.noise_sample(net, c["x2"], c["T"], ca, cb, True)), list(c["gen"]))
+    _close_lists(list(O.noise_sample(net, c["x2"], c["T"], ca, cb, False)), list(c["sample"]))
+    F1, B1, i1 = O.noise_forward_and_backward(net, c["x1"], c["x2"], c["T"], ca, cb)
+    _close_lists(F1, c["fab"][0]), _close_lists(B1, c["fab"][1]), _close_lists([i1], [c["fab"][2]])
+    for key in ("defgen/0", "defgen/1"):
+        c = g[key]
+        al, om = O.blend_tables(c["T"], 16, c["kernel_std"], c["initial_mask"], reverse=key.endswith("1"))
+        assert torch.equal(al, c["alphas"]) and torch.equal(om, c["one_minus"])
+        assert torch.equal(O.blend_q_sample(c["x1"], c["x2"], c["t"], al, om), c["q"])
+        direct, img = O.blend_sample(net, c["x2"], c["x2"], c["T"], al, om)
+        _close_lists([c["x2"], direct, img], list(c["sample"]))
+        _close_lists([c["x2"], direct, img], list(c["gen"]))            # noise_level = 0: the same walk
+        X0, Xt = [], []
+        O.blend_sample(net, c["x2"], c["x2"], c["T"], al, om, collect=lambda a, b: (X0.append(a), Xt.append(b)))
+        _close_lists(X0, c["all_sample"][0]), _close_lists(Xt, c["all_sample"][1])
+        F1 = [c["x1"]] + [O.blend_q_sample(c["x1"], c["x2"], torch.full((2,), i, dtype=torch.long), al, om) for i in range(c["T"])]
+        _close_lists(F1, c["fab"][0]), _close_lists(Xt, c["fab"][1]), _close_lists([img], [c["fab"][2]])
+        ps = {k: (v.clone().requires_grad_() if v.is_floating_point() else v) for k, v in sd0.items()}
+        loss = O.loss_fn(c["x1"], O.unet_forward(ps, O.blend_q_sample(c["x1"], c["x2"], c["t"], al, om), c["t"]))
+        assert (loss - c["loss"]).abs() <= 1e-6
+        if c["grads"] is not None:
+            loss.backward()
+            for k, ref in c["grads"].items():
+                assert (ps[k].grad - ref).abs().max() <= 2e-6 * max(1.0, ref.abs().max().item()), k
+
+
 @pytest.mark.skipif(not ref_shim.available(), reason="reference tree only exists in the build container")
 def test_oracle_bit_exact_vs_live_reference():
     ref = ref_shim.load("deblurring")
