@@ -114,6 +114,19 @@ def save_image(tensor, path, nrow=6):
     Image.fromarray(arr[:, :, 0] if C == 1 else arr).save(str(path))
 
 
+def _match_module_prefix(sd, target_keys):
+    """The authors' checkpoints are state_dicts of DataParallel-wrapped models (`module.` on every key: DEBLUR:1140-1157 with
+    celebA_128.py:102); the same file must load whether or not THIS model is wrapped (the reference's test scripts carry
+    remove_data_parallel / adjust_data_parallel helpers for that, e.g. DEBLUR:1026-1055)."""
+    has = len(sd) > 0 and all(k.startswith('module.') for k in sd)
+    want = all(k.startswith('module.') for k in target_keys)
+    if has and not want:
+        return {k[len('module.'):]: v for k, v in sd.items()}
+    if want and not has:
+        return {'module.' + k: v for k, v in sd.items()}
+    return sd
+
+
 class Trainer(object):
     AUG_DATASETS = ('mnist', 'cifar10', 'flower', 'celebA', 'AFHQ', 'train')
 
@@ -198,8 +211,8 @@ class Trainer(object):
         print("Loading : ", load_path)
         ckpt = torch.load(load_path, map_location=self.device)
         self.step = ckpt['step']
-        self.model.load_state_dict(ckpt['model'])
-        self.ema_model.load_state_dict(ckpt['ema'])
+        self.model.load_state_dict(_match_module_prefix(ckpt['model'], self.model.state_dict().keys()))
+        self.ema_model.load_state_dict(_match_module_prefix(ckpt['ema'], self.ema_model.state_dict().keys()))
         rt.bump_weights_epoch()
 
     # -- the hot loop (DEBLUR:1183-1235) -----------------------------------------------------------------

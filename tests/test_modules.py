@@ -387,6 +387,12 @@ def test_trainer_matches_oracle(mbe, tmp_path):
     prefix = "module." if mbe.kind == "hip" else ""
     assert ck["step"] == 3 and f"{prefix}denoise_fn.time_mlp.1.weight" in ck["model"] and f"{prefix}alphas_cumprod" in ck["ema"]
     tr.load(str(tmp_path / "res" / "model.pt"))
+    # the authors' checkpoints carry DataParallel's `module.` prefix (or not): both load into either kind of model
+    flip = (lambda sd: {k[len("module."):]: v for k, v in sd.items()}) if prefix else (lambda sd: {"module." + k: v for k, v in sd.items()})
+    torch.save({"step": 7, "model": flip(ck["model"]), "ema": flip(ck["ema"])}, str(tmp_path / "res" / "other.pt"))
+    before = {k: v.clone() for k, v in tr.model.state_dict().items()}
+    tr.load(str(tmp_path / "res" / "other.pt"))
+    assert tr.step == 7 and all(torch.equal(v, tr.model.state_dict()[k]) for k, v in before.items())
 
 
 def test_no_cpu_fallback():
