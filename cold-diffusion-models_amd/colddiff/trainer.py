@@ -178,7 +178,8 @@ class Trainer(object):
     def _make_loader(self, folder, dataset, shuffle, num_workers, seed):
         """(dataset, endless batch iterator): image folder as in the reference (DEBLUR:1094-1096), or synthetic images."""
         if dataset == 'synthetic' or folder is None:
-            return None, SyntheticImages(self.batch_size, self.core.channels, self.image_size, self.device, seed=seed)
+            # (every rank draws its own shard: the seed is offset by the rank)
+            return None, SyntheticImages(self.batch_size, self.core.channels, self.image_size, self.device, seed=seed + parallel.rank())
         aug = dataset in self.AUG_DATASETS
         print(dataset, "DA used" if aug else "")
         ds = (Dataset_Aug1 if aug else Dataset)(folder, self.image_size)
