@@ -1160,6 +1160,173 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
     cdf_sp_epilogue<BM, BN, WM, WN>(a, ph, acc, (float*)smem_raw, tile_m, tile_n, M, tid);
 }
 
+// ================================================================================================
+// 3 x 3 stride-1 convolutions, 256-pixel tiles with the input rows of ONE TAP ROW resident in LDS ("row-halo" kernel).
+//
+// The halo kernel above keeps (TH + 2) x (W + 2) pixels per channel chunk; at 128-pixel width two such buffers leave room
+// for the weight stages of a 128-wide N tile only with 128-pixel tiles, where it is no faster than the generic kernel.  This
+// variant shares the input across the three dx taps only: per (channel chunk, dy) it fetches the tile's TH rows shifted by
+// dy, with one pixel of halo left and right (TH x (W + 2) rows of 64 B, both planes, double buffered), and the three taps of
+// that row read their A fragments at pixel offsets -1, 0, +1.  A bytes per chunk 3 x 33 KB instead of 9 x 32 KB; with the
+// 256-pixel tile the weights cost half per MFMA: 141 bytes of DMA per MFMA against 250 (generic 256 x 128).  K loop:
+// chunk, dy group, dx; the rows of the next group are requested in the first step of a group, the weights 3 steps ahead
+// (4 stages).  8 waves (4 x 2 of 64 x 64).  Requires the taps in dy-major order (checked by the host).
+// NOT YET MEASURED ON HARDWARE (round 1 ran out of GPU time): off by default, bit 32 of cdf_conv_gemm_bf16x_halo.
+// ================================================================================================
+template <int W, int BN>
+__global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
+    constexpr int BM = 256, WM = 4, WN = 2, NW = 8, BK = 32, RE = 32, MT = BM / WM / 32, NB = 4;
+    constexpr int TH = BM / W, HW2 = W + 2, RH = TH * HW2;                 // rows of one (chunk, dy) image
+    constexpr int NSEG = (RH + 15) / 16, HRP = NSEG * 16;
+    constexpr int TAG = (NSEG + NW - 1) / NW;                              // segments per wave and group, all requested in its first step
+    constexpr int NT = BN / WN / 32;
+    constexpr int SB = BN / 16 / NW;
+    static_assert(SB * NW * 16 == BN || BN == 64, "B tile must split into 16-row segments");
+    constexpr int SBI = BN == 64 ? 1 : SB;
+    constexpr int PLANE_A = HRP * RE, ABUF = 2 * PLANE_A;
+    constexpr int PLANE_B = BN * RE, BSTAGE = 2 * PLANE_B;
+    CDF_DYN_SMEM(smem_raw);
+    unsigned short* smem = (unsigned short*)smem_raw;
+    unsigned short* const abuf0 = smem;
+    unsigned short* const bst0 = smem + 2 * ABUF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int M = a.B * a.QH * a.QW;
+    const int tiles_n = (a.Cout + BN - 1) / BN, tiles_m = M / BM;
+    const int tile = cdf_sp_swizzle(blockIdx.x, tiles_m * tiles_n);
+    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+    const SpPhase& ph = a.ph[0];
+    const int tpi = a.H / TH;
+    const int img = tile_m / tpi, y0 = (tile_m - img * tpi) * TH;
+
+    const int srow = lane >> 2;
+    const int q8 = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+    int a_seg[TAG], a_ry[TAG], a_x[TAG];
+#pragma unroll
+    for (int q = 0; q < TAG; ++q) {
+        int g = wave + NW * q;
+        if (g >= NSEG) g -= (g / NSEG) * NSEG;                 // (repeats: same bytes to the same place, equal DMA counts per wave)
+        a_seg[q] = g;
+        const int r = g * 16 + srow;
+        a_ry[q] = r < RH ? r / HW2 : -(1 << 20);               // rows past the image of the group: always outside
+        a_x[q] = r - (r / HW2) * HW2 - 1;
+    }
+    int b_row[SBI];
+#pragma unroll
+    for (int p = 0; p < SBI; ++p) {
+        const int seg = BN == 64 ? (wave & 3) : wave * SB + p;
+        const int n = tile_n * BN + seg * 16 + srow;
+        b_row[p] = n < a.Cout ? n : a.Cout - 1;
+    }
+    const int nchunks = a.Cin / BK;
+
+    auto fetch_a = [&](int c, int g, int buf) {              // rows of (chunk c, tap row g) -> buffer buf: all of this wave's segments
+        if (c >= nchunks) { c = nchunks - 1; g = 2; }        // past the end: the last group again, into the idle buffer
+        const int dy = ph.dy[3 * g];
+#pragma unroll
+        for (int q = 0; q < TAG; ++q) {
+            const int y = y0 + a_ry[q] + dy;
+            const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)a_x[q] < (unsigned)W;
+            const size_t off = ((size_t)((img * a.H + (ok ? y : 0)) * W + (ok ? a_x[q] : 0))) * (unsigned)a.ldx + (unsigned)(c * BK + q8);
+            unsigned short* seg = abuf0 + buf * ABUF + a_seg[q] * 16 * RE;
+            CDF_GLDS16(ok ? a.x_hi + off : a.zero, seg);
+            CDF_GLDS16(ok ? a.x_lo + off : a.zero, seg + PLANE_A);
+        }
+    };
+    auto fetch_b = [&](int c, int t, int stage) {
+        if (c >= nchunks) c = nchunks - 1;
+        const int wi = ph.wi[t];
+        unsigned short* st = bst0 + stage * BSTAGE;
+#pragma unroll
+        for (int p = 0; p < SBI; ++p) {
+            const int seg = BN == 64 ? (wave & 3) : wave * SB + p;
+            const size_t woff = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)b_row[p]) * (unsigned)a.ldk + (unsigned)(c * BK + q8);
+            CDF_GLDS16(a.w_hi + woff, st + seg * 16 * RE);
+            CDF_GLDS16(a.w_lo + woff, st + PLANE_B + seg * 16 * RE);
+        }
+    };
+    constexpr int PB = 2 * SBI, PAG = 2 * TAG;               // DMA instructions per wave: one weight step, one group of rows
+
+    f32x16_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int half = lane >> 5, l31 = lane & 31;
+    int row0[MT];                                            // this lane's A fragment rows for dx = 0
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int pix = wm * (BM / WM) + i * 32 + l31;
+        const int py = pix / W, px = pix - py * W;
+        row0[i] = py * HW2 + px + 1;
+    }
+    const int swb = (l31 >> 2) & 3;
+
+    // ---- prologue: rows of (chunk 0, tap row 0), weights of steps 0 .. 2
+    fetch_a(0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < NB - 1; ++u) fetch_b(0, u, u);
+    CDF_WAIT_DMA_LEAVE((NB - 2) * PB);
+    CDF_LDS_BARRIER();
+    int rd = 0, par = 0;                                     // weight stage / row buffer of the current step
+    for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int g = t / 3, i3 = t - 3 * g;
+            if (i3 == 0) fetch_a(g == 2 ? c + 1 : c, g == 2 ? 0 : g + 1, par ^ 1);      // the next tap row's input rows
+            fetch_b(t + NB - 1 < 9 ? c : c + 1, (t + NB - 1) % 9, rd == 0 ? NB - 1 : rd - 1);
+            const unsigned short* sa = abuf0 + par * ABUF;
+            const unsigned short* sb = bst0 + rd * BSTAGE;
+            rd = rd + 1 == NB ? 0 : rd + 1;
+            const int dx = ph.dx[t];
+            bf16x8_v ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int row = row0[i] + dx;
+                    const int off = row * RE + ((ks * 2 + half) ^ ((row >> 2) & 3)) * 8;
+                    ah[ks][i] = *(const bf16x8_v*)(sa + off);
+                    al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
+                }
+                const int kc = ((ks * 2 + half) ^ swb) * 8;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int offb = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
+                    bh[ks][j] = *(const bf16x8_v*)(sb + offb);
+                    bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + offb);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        acc[i][j] = CDF_MFMA_BF16(al[ks][i], bh[ks][j], acc[i][j]);
+                        acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bl[ks][j], acc[i][j]);
+                        acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bh[ks][j], acc[i][j]);
+                    }
+            // the weights of step + 1 (requested 2 steps ago, AFTER that step's row requests) have landed; still in flight: the
+            // requests of the last two steps -- two weight steps, plus one group of rows if one of them was a group's first step
+            if (i3 <= 1)
+                CDF_WAIT_DMA_LEAVE((NB - 2) * PB + PAG);
+            else
+                CDF_WAIT_DMA_LEAVE((NB - 2) * PB);
+            CDF_LDS_BARRIER();
+            if (i3 == 2) par ^= 1;
+        }
+    }
+    CDF_WAIT_DMA_LEAVE(0);
+    CDF_LDS_BARRIER();
+
+    cdf_sp_epilogue<BM, BN, WM, WN>(a, ph, acc, (float*)smem_raw, tile_m, tile_n, M, tid);
+}
+
 // weight gradient with both operands pre-split ([pixels][ld] bf16 hi / lo planes)
 struct SpxWgradArgs {
     const unsigned short* a_hi;
@@ -1846,7 +2013,7 @@ extern "C" int cdf_conv_gemm_bf16x_halo_bm(int bm) {
 }
 
 extern "C" int cdf_conv_gemm_bf16x_halo(int enable, int min_tiles) {
-    g_spx_halo = enable & 31;
+    g_spx_halo = enable & 63;
     g_spx_halo_min_tiles = min_tiles > 0 ? min_tiles : 1;
     return 0;
 }
@@ -1873,6 +2040,25 @@ static int launch_igemm_halo(const SpxArgs& a, int M, hipStream_t s) {
     const int tiles = (M / BM) * cdf_cdiv(a.Cout, BN);
     CDF_LAUNCH((conv_igemm_halo_kernel<W, BN, NB, BM>), dim3(tiles), dim3(512), lds, s, a);
     return cdf_check_launch("conv_igemm_halo");
+}
+
+template <int W, int BN>
+static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s) {
+    constexpr int TH = 256 / W, RH = TH * (W + 2), HRP = (RH + 15) / 16 * 16;
+    constexpr size_t stages = (size_t)2 * 2 * HRP * 64 + (size_t)4 * 2 * BN * 64;
+    constexpr size_t epi = (size_t)256 * (BN + 8) * sizeof(float);
+    constexpr size_t lds = stages > epi ? stages : epi;
+    static_assert(lds <= 160 * 1024, "row-halo tile does not fit the LDS");
+#ifndef CDF_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_kernel<W, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+#endif
+    const int tiles = (M / 256) * cdf_cdiv(a.Cout, BN);
+    CDF_LAUNCH((conv_igemm_rowhalo_kernel<W, BN>), dim3(tiles), dim3(512), lds, s, a);
+    return cdf_check_launch("conv_igemm_rowhalo");
 }
 
 extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo,
@@ -1931,6 +2117,14 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
         for (int t = 0; t < 9; ++t) dxs |= 1 << (a.ph[0].dx[t] + 1);
         const bool dx_ok = dxs == 7;                         // (is3x3: three groups of equal dy in {-1, 0, 1})
         const long long tiles = (long long)(M / 128) * cdf_cdiv(Cout, n64 ? 64 : 128);
+        // row-halo kernel (bit 32; not yet measured on hardware, off by default): 256-pixel tiles, input shared by the dx taps only
+        if (dx_ok && (g_spx_halo & 32) && M % 256 == 0) {
+#define CDF_ROWHALO_CASE(WW)                                                                                           \
+    if (W == WW && H % (256 / WW) == 0)                                                                                \
+        return n64 ? launch_igemm_rowhalo<WW, 64>(a, M, CDF_S) : launch_igemm_rowhalo<WW, 128>(a, M, CDF_S);
+            CDF_ROWHALO_CASE(128) CDF_ROWHALO_CASE(64) CDF_ROWHALO_CASE(32) CDF_ROWHALO_CASE(16)
+#undef CDF_ROWHALO_CASE
+        }
         if (dx_ok && tiles >= g_spx_halo_min_tiles) {
 #define CDF_HALO_CASE(WW)                                                                                              \
     if (W == WW && (g_spx_halo & (WW / 16)) && H % (128 / WW) == 0 && (WW < 128 || n64 || (g_spx_halo & 16))) {          \

@@ -717,6 +717,20 @@ def test_wgrad_presplit_row_of_taps(be, case):
         be.L.cdf_conv_wgrad_bf16x_row3(1)
 
 
+@pytest.mark.parametrize("case", [(1, 64, 96, 16, 3, 1, 1), (2, 96, 40, 16, 3, 1, 1), (1, 64, 72, 32, 3, 1, 1)])
+def test_conv_presplit_rowhalo_emu(case):
+    """Row-halo form of the 3 x 3 GEMM (256-pixel tiles, input shared by the dx taps of a row; bit 32 of the halo hook).
+    Simulator only: the kernel has not been measured on hardware yet and is off by default."""
+    from conftest import Backend
+    be = Backend("emu")
+    be.L.cdf_conv_gemm_bf16x_halo(32 | 15, 1)
+    try:
+        _spx_case(be, *case)
+    finally:
+        be.L.cdf_conv_gemm_bf16x_halo(15, 1)
+        be._keep.clear()
+
+
 def test_conv_presplit_row_tiles(be):
     """A tile that is exactly one image row (W = 64 with the 64-row tile): the 3 x 3 taps run in a per-tile row-group
     order (cdf_conv_gemm_bf16x_taprot) -- every tap must still be taken exactly once, forward and data gradient."""
