@@ -1171,7 +1171,9 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
 // 256-pixel tile the weights cost half per MFMA: 141 bytes of DMA per MFMA against 250 (generic 256 x 128).  K loop:
 // chunk, dy group, dx; the rows of the next group are requested in the first step of a group, the weights 3 steps ahead
 // (4 stages).  8 waves (4 x 2 of 64 x 64).  Requires the taps in dy-major order (checked by the host).
-// NOT YET MEASURED ON HARDWARE (round 1 ran out of GPU time): off by default, bit 32 of cdf_conv_gemm_bf16x_halo.
+// Measured (MI355X): 64 -> 128 channels at 128 x 128 pixels 0.325 -> 0.298 ms (with the GELU epilogue 0.406 -> 0.381) against the
+// generic 256 x 128 kernel; at 64 pixels the halo kernel's 256-pixel tile stays ahead (0.240 vs 0.252 ms).  Used for the > 64-channel
+// outputs at 128-pixel width (bits 32 / 64 of cdf_conv_gemm_bf16x_halo).
 // ================================================================================================
 template <int W, int BN>
 __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
@@ -1999,10 +2001,12 @@ static int launch_igemm_spx(const SpxArgs& a, int M, hipStream_t s) {
     return cdf_check_launch("conv_igemm_spx");
 }
 
-static int g_spx_halo = 15;                    // 3 x 3 stride-1 layers: input tile resident in LDS; bit mask over the image width
+static int g_spx_halo = 47;                    // 3 x 3 stride-1 layers: input tile resident in LDS; bit mask over the image width
                                                // 16 (1), 32 (2), 64 (4), 128 (8); 16: at width 128 also for 128-wide N tiles (measured
                                                // level with the generic kernel there: only 3 weight stages fit next to 2 x 51 KB of halo;
-                                               // with 64-wide N tiles a 256-pixel tile fits and wins) (tuning / test hook)
+                                               // with 64-wide N tiles a 256-pixel tile fits and wins); 32: the row-halo kernel for the
+                                               // > 64-channel outputs at width 128; 64: the row-halo kernel wherever it applies
+                                               // (tuning / test hook)
 static long long g_spx_halo_min_tiles = 1;
 static int g_spx_halo_bm = 0;                  // 0 = automatic, 128 / 256 = forced tile height of the halo kernel
 
@@ -2013,7 +2017,7 @@ extern "C" int cdf_conv_gemm_bf16x_halo_bm(int bm) {
 }
 
 extern "C" int cdf_conv_gemm_bf16x_halo(int enable, int min_tiles) {
-    g_spx_halo = enable & 63;
+    g_spx_halo = enable & 127;
     g_spx_halo_min_tiles = min_tiles > 0 ? min_tiles : 1;
     return 0;
 }
@@ -2117,8 +2121,10 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
         for (int t = 0; t < 9; ++t) dxs |= 1 << (a.ph[0].dx[t] + 1);
         const bool dx_ok = dxs == 7;                         // (is3x3: three groups of equal dy in {-1, 0, 1})
         const long long tiles = (long long)(M / 128) * cdf_cdiv(Cout, n64 ? 64 : 128);
-        // row-halo kernel (bit 32; not yet measured on hardware, off by default): 256-pixel tiles, input shared by the dx taps only
-        if (dx_ok && (g_spx_halo & 32) && M % 256 == 0) {
+        // row-halo kernel: 256-pixel tiles, input shared by the dx taps only.  Bit 32 (default): the > 64-channel outputs at
+        // 128-pixel width, where it beats the generic 256 x 128 kernel (64 -> 128: 0.325 -> 0.298 ms); bit 64: wherever it applies
+        // (at 64 pixels the halo kernel's 256-pixel tile stays ahead, 0.240 vs 0.252 ms)
+        if (dx_ok && M % 256 == 0 && ((g_spx_halo & 64) || ((g_spx_halo & 32) && W == 128 && !n64 && (long long)(M / 256) * cdf_cdiv(Cout, 128) >= 256))) {
 #define CDF_ROWHALO_CASE(WW)                                                                                           \
     if (W == WW && H % (256 / WW) == 0)                                                                                \
         return n64 ? launch_igemm_rowhalo<WW, 64>(a, M, CDF_S) : launch_igemm_rowhalo<WW, 128>(a, M, CDF_S);

@@ -178,8 +178,9 @@ int cdf_conv_gemm_bf16x_max_bm(int bm);
 int cdf_conv_gemm_bf16x_taprot(int enable);
 /* tuning / test hook: 3 x 3 stride-1 layers of cdf_conv_gemm_bf16x with the input tile (+ one-pixel halo) resident in LDS for
  * all nine taps.  enable: bit mask over the image width 16 (1), 32 (2), 64 (4), 128 (8), and 16 = at width 128 also for
- * layers with more than 64 output channels; 32 = the row-halo form (256-pixel tiles, input shared by the three dx taps of a row only;
- * not yet measured on hardware) wherever it applies; default 15; 0 = always the generic gather kernel.  min_tiles: smallest tile count (128 pixels x BN) the LDS-resident form is used for.  Only the fp32
+ * layers with more than 64 output channels; 32 = the row-halo form (256-pixel tiles, input shared by the three dx taps of a row only)
+ * for the > 64-channel outputs at width 128; 64 = the row-halo form wherever it applies; default 47; 0 = always the generic
+ * gather kernel.  min_tiles: smallest tile count (128 pixels x BN) the LDS-resident form is used for.  Only the fp32
  * summation order depends on it. */
 int cdf_conv_gemm_bf16x_halo(int enable, int min_tiles);
 /* tuning / test hook: pixels per tile of the LDS-resident-input kernel: 0 = automatic (256 where every CU still gets a tile), 128, 256 */

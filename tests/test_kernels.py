@@ -700,7 +700,7 @@ def test_conv_presplit_halo(be, case):
         be.L.cdf_conv_gemm_bf16x_halo(0, 1)
         _spx_case(be, *case)
     finally:
-        be.L.cdf_conv_gemm_bf16x_halo(15, 1)
+        be.L.cdf_conv_gemm_bf16x_halo(47, 1)
         be.L.cdf_conv_gemm_bf16x_halo_bm(0)
 
 
@@ -719,15 +719,15 @@ def test_wgrad_presplit_row_of_taps(be, case):
 
 @pytest.mark.parametrize("case", [(1, 64, 96, 16, 3, 1, 1), (2, 96, 40, 16, 3, 1, 1), (1, 64, 72, 32, 3, 1, 1)])
 def test_conv_presplit_rowhalo_emu(case):
-    """Row-halo form of the 3 x 3 GEMM (256-pixel tiles, input shared by the dx taps of a row; bit 32 of the halo hook).
-    Simulator only: the kernel has not been measured on hardware yet and is off by default."""
+    """Row-halo form of the 3 x 3 GEMM (256-pixel tiles, input shared by the dx taps of a row) forced at every width (bit 64 of
+    the halo hook; by default it serves the 128-pixel layers, which the GPU cases cover).  Simulator only, to keep the GPU suite short."""
     from conftest import Backend
     be = Backend("emu")
-    be.L.cdf_conv_gemm_bf16x_halo(32 | 15, 1)
+    be.L.cdf_conv_gemm_bf16x_halo(64 | 47, 1)
     try:
         _spx_case(be, *case)
     finally:
-        be.L.cdf_conv_gemm_bf16x_halo(15, 1)
+        be.L.cdf_conv_gemm_bf16x_halo(47, 1)
         be._keep.clear()
 
 
@@ -753,7 +753,7 @@ def test_conv_presplit_large(case):
             be.L.cdf_conv_gemm_bf16x_halo_bm(bm)
             _spx_case(be, *case)
     finally:
-        be.L.cdf_conv_gemm_bf16x_halo(15, 1)
+        be.L.cdf_conv_gemm_bf16x_halo(47, 1)
         be.L.cdf_conv_gemm_bf16x_halo_bm(0)
 
 
