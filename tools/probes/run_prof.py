@@ -1,6 +1,9 @@
-"""Phase timing of conv_igemm_spx_kernel (CDF_PROFILE build): s_memtime ticks per K step, wave 0..3 of the first blocks."""
+"""Phase timing of conv_igemm_spx_kernel: s_memtime ticks per K step, waves of the first 64 blocks.
+Needs the library built with -DCDF_PROFILE=1 at tools/_ablate/prof/lib_prof.so:
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DCDF_PROFILE=1 -Iinclude -Icold-diffusion-models_amd/csrc \
+        -shared cold-diffusion-models_amd/csrc/*.hip -o tools/_ablate/prof/lib_prof.so"""
 import ctypes, os, sys, torch
-REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(REPO, "cold-diffusion-models_amd"))
 os.environ["COLDDIFF_LIB"] = os.path.join(REPO, "tools/_ablate/prof/lib_prof.so")
 from colddiff import _lib, convdesc as cd
