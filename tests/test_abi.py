@@ -66,3 +66,38 @@ def test_hot_kernels_use_no_scratch():
                 seen.add(cur)
                 assert int(m.group(1)) == 0, (cur, line)
         assert seen, "no resource-usage remarks parsed for " + src
+
+
+def test_argument_checks_of_the_gemm_and_blend_entry_points():
+    """Contract of include/colddiff.h: a bad argument is a status + message, never an abort, never a launch (host-side checks:
+    they run without a GPU on the device build too)."""
+    import torch
+    lib = _lib.Lib(_lib.LIB_PATH)
+    buf = torch.zeros(4096)
+    p = buf.data_ptr()
+    desc = (ctypes.c_int * 8)(0, 0, 1, 0, 0, 0, 0, 0)
+
+    def expect(fn, args, text):
+        try:
+            fn(*args)
+        except _lib.CdfError as e:
+            assert text in str(e), str(e)
+        else:
+            raise AssertionError("expected CdfError containing %r" % text)
+
+    # pre-split GEMM: unaligned operand, channel count not a multiple of 8, split planes without the vectorised epilogue layout
+    gemm = [p, p, 8, p, p, p, 32, p, 8, 1, 4, 4, 8, 4, 4, 8, 4, 4, 1, 1, 1, desc, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]
+    bad = list(gemm); bad[0] = p + 2
+    expect(lib.cdf_conv_gemm_bf16x, bad, "16B aligned")
+    bad = list(gemm); bad[12] = 6
+    expect(lib.cdf_conv_gemm_bf16x, bad, "multiples of 8")
+    bad = list(gemm); bad[34], bad[35], bad[36] = p, p, 6
+    expect(lib.cdf_conv_gemm_bf16x, bad, "split output planes")
+    # weight gradient: tap count out of range
+    expect(lib.cdf_conv_wgrad_bf16x, [p, p, 8, p, p, 8, p, p, 8, 1, 4, 4, 4, 4, 1, 4, 4, 1, 8, 8, 0, desc, 1, 0, 0], "tap / split count")
+    # per-pixel blend: t = 0 is not a reverse step
+    expect(lib.cdf_blend_step, [p, p, p, p, p, 0, p, 16, 48, 0], "bad args")
+    expect(lib.cdf_blend_qsample, [p, p, p, p, 0, p, 1, 3, 16, 0], "bad args")
+    # tuning hooks validate their values too
+    expect(lib.cdf_conv_gemm_bf16x_tile, [96, 128], "bm is 0")
+    expect(lib.cdf_conv_gemm_bf16x_halo_bm, [192], "0, 128 or 256")
