@@ -305,6 +305,43 @@ def test_defading_generation_golden(mbe):
             grad_check(net.named_parameters(), c["grads"])
 
 
+def test_trainer_train_loop_with_milestone(tmp_path):
+    """(simulator only: host logic) Trainer.train() end to end (DEBLUR:1183-1235): optimizer steps, EMA, and at the milestone step the Algorithm-2 sample of
+    the EMA model, the four PNG grids and the checkpoint, for a one-image package (deblurring) and the defading one (whose
+    sampler takes `faded_recon_sample=`)."""
+    from deblurring_diffusion_pytorch import GaussianDiffusion, Trainer, Unet
+    import defading_diffusion_pytorch as DF
+    from colddiff import runtime
+    from emu_util import install_emu
+    install_emu()
+    mbe = MBE("emu")
+    torch.manual_seed(0)
+    try:
+        _train_loop_cases(mbe, tmp_path, GaussianDiffusion, Trainer, Unet, DF)
+    finally:
+        runtime._lib_override = None
+
+
+def _train_loop_cases(mbe, tmp_path, GaussianDiffusion, Trainer, Unet, DF):
+    for name, make in (("deblur", lambda net: GaussianDiffusion(net, image_size=16, device_of_kernel='cuda', channels=3, timesteps=3, kernel_std=0.5,
+                                                                  kernel_size=3, blur_routine='Incremental', sampling_routine='x0_step_down')),
+                       ("defade", lambda net: DF.GaussianDiffusion(net, image_size=16, device_of_kernel='cuda', channels=3, timesteps=3,
+                                                                   kernel_std=0.6, initial_mask=1, fade_routine='Incremental',
+                                                                   sampling_routine='x0_step_down'))):
+        net = quiet(Unet, dim=8, dim_mults=(1, 2), channels=3).to(mbe.device)
+        d = make(net).to(mbe.device)
+        res = tmp_path / name
+        tr = quiet(Trainer, d, None, dataset='synthetic', image_size=16, train_batch_size=2, train_num_steps=3, save_and_sample_every=2,
+                   results_folder=str(res))
+        tr.quiet = True
+        quiet(tr.train)
+        assert tr.step == 3
+        for f in ("sample-og-1.png", "sample-recon-1.png", "sample-direct_recons-1.png", "sample-xt-1.png", "model.pt"):
+            assert (res / f).exists(), (name, f)
+        ck = torch.load(str(res / "model.pt"), map_location="cpu", weights_only=False)
+        assert ck["step"] == 2 and set(ck) == {"step", "model", "ema"}
+
+
 def test_two_image_trainers(mbe, tmp_path):
     """Trainer variants of the forward(x1, x2) packages: demixing draws the second image from a second dataset (DEMIX:724-726),
     defading generation from uniform random colours (DEFGEN:769-773); one optimizer step each on synthetic data."""
