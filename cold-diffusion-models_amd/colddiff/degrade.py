@@ -16,8 +16,9 @@ PIX_MODES = {"area": 0, "bilinear": 1, "bicubic": 2}
 
 # -- torchgeometry.image.get_gaussian_kernel2d (0.1.x) restated: deblurring_diffusion_pytorch.py:348-349 ------
 def gaussian_1d(ksize, sigma):
-    vals = [math.exp(-(x - ksize // 2) ** 2 / float(2 * sigma ** 2)) for x in range(ksize)]
-    g = torch.stack([torch.tensor(v) for v in vals])
+    # torchgeometry 0.1.2 image/gaussian.py `gaussian()`: the exponent is rounded to fp32 by torch.tensor() and the
+    # exponential is evaluated IN fp32 (torch.exp), one tap at a time; then normalised in fp32.
+    g = torch.stack([torch.exp(torch.tensor(-(x - ksize // 2) ** 2 / float(2 * sigma ** 2))) for x in range(ksize)])
     return g / g.sum()
 
 

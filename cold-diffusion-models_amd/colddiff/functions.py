@@ -17,12 +17,21 @@ from . import runtime as rt
 from .runtime import P, r4
 
 
-def _done(*mods):
-    """Tell the data-parallel engine that the gradients of these modules' own parameters are final."""
+def _used(ctx, *mods):
+    """Forward side of _done: tell the data-parallel engine that this node's backward will write the gradients of these
+    modules' own parameters once more in this pass (a module may run several times per loss, e.g. RESOL's
+    'Final_random_mean_and_actual' calls the network twice: RESOL:702-716), and remember them on the node."""
+    ctx.owned = tuple(m for m in mods if m is not None)
+    if parallel._engine is not None and ctx.needs_input_grad[0]:      # anchor: True iff autograd is recording
+        for m in ctx.owned:
+            parallel.grads_used(list(m.parameters(recurse=False)))
+
+
+def _done(ctx):
+    """Tell the data-parallel engine that this node's contribution to the gradients of its modules' own parameters is enqueued."""
     if parallel._engine is not None:
-        for m in mods:
-            if m is not None:
-                parallel.grads_ready(list(m.parameters(recurse=False)))
+        for m in ctx.owned:
+            parallel.grads_ready(list(m.parameters(recurse=False)))
 
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
 
@@ -196,6 +205,7 @@ class Linear(torch.autograd.Function):
         N, K = W.shape
         B = x.shape[0]
         ctx.lin = lin
+        _used(ctx, lin)
         ctx.save_for_backward(x)
         if B <= _LINEAR_SMALL_M:                             # batch-rows-only GEMM: dedicated kernel (see k_misc.hip)
             wp = ops.packed(W, "lin_fwd")                    # [1][K][r4(N)]
@@ -224,7 +234,7 @@ class Linear(torch.autograd.Function):
                 dx = torch.empty((B, r4(K)), device=x.device, dtype=torch.float32)
                 L.cdf_linear_small(P(dy), dy.stride(0), P(W), K, 0, P(dx), r4(K), B, N, K, S)
                 dx = dx[:, :x.shape[1]]
-            _done(lin)
+            _done(ctx)
             return None, dx, None
         dy4, x4 = dy.view(B, 1, 1, dy.shape[1]), x.view(B, 1, 1, x.shape[1])
         wp = cd.conv_wgrad(1, 1, 1, 1, 1, 0, 0, 0, 0)
@@ -235,7 +245,7 @@ class Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             plan = cd.conv_fwd(1, 1, 1, 1, 1, 0, 0, 0, 0)
             dx = ops.conv_gemm(plan, dy4, N, W.detach().view(1, N, K), K).view(B, r4(K))[:, :x.shape[1]]
-        _done(lin)
+        _done(ctx)
         return None, dx, None
 
 
@@ -251,6 +261,7 @@ class ConvFn(torch.autograd.Function):
         xs = ops.split_bf16(x) if (_AUTO_PRESPLIT and (k > 1 or _PRESPLIT_1X1) and want_presplit(Cin, Cout, k)) else None
         y = conv_forward(x, Cin, mod.weight, mod.bias, kind, stride, pad, xs=xs)
         ctx.mod, ctx.cfg = mod, (Cin, kind, stride, pad)
+        _used(ctx, mod)
         ctx.has_xs = xs is not None
         ctx.save_for_backward(x, *(xs or (None, None)))
         return y
@@ -262,7 +273,7 @@ class ConvFn(torch.autograd.Function):
         xs = (x_hi, x_lo) if ctx.has_xs else None
         dys = ops.split_bf16(dy) if xs is not None else None
         dx = conv_backward(x, Cin, dy, ctx.mod.weight, ctx.mod.bias, kind, stride, pad, need_dx=ctx.needs_input_grad[1], xs=xs, dys=dys)
-        _done(ctx.mod)
+        _done(ctx)
         return None, dx, None, None, None, None, None
 
 
@@ -317,6 +328,7 @@ class ConvNextBlockFn(torch.autograd.Function):
             res = x
         o = conv_forward(a, mid, c2.weight, c2.bias, res=res, xs=a_s)
         ctx.m = m
+        _used(ctx, m.ds_conv, m.net[0] if m.has_norm else None, c1, c2, m.res_conv if m.has_res_conv else None)
         ctx.has_t = tbias is not None
         ctx.split = (hn_s is not None, a_s is not None)
         ctx.save_for_backward(x, h, hn if m.has_norm else None, mean, rstd, pre, a, *(hn_s or (None, None)), *(a_s or (None, None)))
@@ -367,7 +379,7 @@ class ConvNextBlockFn(torch.autograd.Function):
                 ops.dwconv7(dh, ops.packed(m.ds_conv.weight, "dw"), None, None, flip=1, y=dx, accumulate=1)
             else:
                 dx = ops.dwconv7(dh, ops.packed(m.ds_conv.weight, "dw"), None, None, flip=1, res=do)
-        _done(m.ds_conv, m.net[0] if m.has_norm else None, c1, c2, m.res_conv if m.has_res_conv else None)
+        _done(ctx)
         return None, dx, dtb, None
 
 
@@ -384,6 +396,7 @@ class LinAttnBlockFn(torch.autograd.Function):
         o, cx, cxs, kmax, ksum = ops.linattn_fwd(qkv, att.heads, att.scale)
         y = conv_forward(o, att.heads * 32, att.to_out.weight, att.to_out.bias, res=x)
         ctx.m = m
+        _used(ctx, norm, att.to_qkv, att.to_out)
         ctx.save_for_backward(x, xn, mean, rstd, qkv, o, cx, cxs, kmax, ksum)
         return y
 
@@ -397,7 +410,7 @@ class LinAttnBlockFn(torch.autograd.Function):
         dxn = conv_backward(xn, dim, dqkv, att.to_qkv.weight, None)
         dx = ops.copy_feat(dy)
         ops.layernorm_bwd(dxn, x, norm.g, norm.b, mean, rstd, dx=dx)
-        _done(norm, att.to_qkv, att.to_out)
+        _done(ctx)
         return None, dx, None
 
 
@@ -418,6 +431,7 @@ class GroupNormFn(torch.autograd.Function):
     def forward(ctx, anchor, x, norm, silu):
         y, mean, rstd = ops.groupnorm_fwd(x, norm.weight, norm.bias, GN_GROUPS, GN_EPS, silu)
         ctx.norm, ctx.silu = norm, silu
+        _used(ctx, norm)
         ctx.save_for_backward(x, mean, rstd)
         return y
 
@@ -425,7 +439,7 @@ class GroupNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, mean, rstd = ctx.saved_tensors
         dx = ops.groupnorm_bwd(dy, x, ctx.norm.weight, ctx.norm.bias, mean, rstd, GN_GROUPS, ctx.silu)
-        _done(ctx.norm)
+        _done(ctx)
         return None, dx, None, None
 
 
@@ -439,6 +453,7 @@ class UpsampleConvFn(torch.autograd.Function):
         ctx.sp = _AUTO_PRESPLIT and want_presplit(C, conv.weight.shape[0], 3)
         y = conv_forward(up, C, conv.weight, conv.bias, xs=ops.split_bf16(up) if ctx.sp else None)
         ctx.conv = conv
+        _used(ctx, conv)
         ctx.save_for_backward(x)
         return y
 
@@ -448,7 +463,7 @@ class UpsampleConvFn(torch.autograd.Function):
         up = ops.upsample2(x)
         ups, dys = (ops.split_bf16(up), ops.split_bf16(dy)) if ctx.sp else (None, None)
         dup = conv_backward(up, x.shape[-1], dy, ctx.conv.weight, ctx.conv.bias, xs=ups, dys=dys)
-        _done(ctx.conv)
+        _done(ctx)
         return None, ops.upsample2_bwd(dup), None
 
 
@@ -478,6 +493,7 @@ class ResnetBlockFn(torch.autograd.Function):
         h3_s = ops.split_bf16(h3) if sp2 else None
         o = conv_forward(h3, cout, m.conv2.weight, m.conv2.bias, res=sc, xs=h3_s)
         ctx.m, ctx.drop = m, (p, seed)
+        _used(ctx, m.norm1, m.conv1, m.norm2, m.conv2, sc_mod if cin != cout else None)
         ctx.split = (sp1, sp2)
         ctx.save_for_backward(x, h1, h2, h3, mean1, rstd1, mean2, rstd2, *(h1_s or (None, None)), *(h3_s or (None, None)))
         return o
@@ -503,7 +519,7 @@ class ResnetBlockFn(torch.autograd.Function):
         dtb = ops.colsum_new(dh2, cout, dh2.shape[0])
         dh1 = conv_backward(h1, cin, dh2, m.conv1.weight, m.conv1.bias, xs=h1_s, dys=ops.split_bf16(dh2) if h1_s is not None else None)
         ops.groupnorm_bwd(dh1, x, m.norm1.weight, m.norm1.bias, mean1, rstd1, GN_GROUPS, True, dx=dx)
-        _done(m.norm1, m.conv1, m.norm2, m.conv2, sc_mod)
+        _done(ctx)
         return None, dx, dtb, None
 
 
@@ -523,6 +539,7 @@ class AttnBlockFn(torch.autograd.Function):
         o = ops.bgemm_nn(pm, v, K=n).view(B, H, W, C)        # h_[b,i,c] = sum_j P[b,i,j] v[b,j,c]
         y = conv_forward(o, C, m.proj_out.weight, m.proj_out.bias, res=x)
         ctx.m = m
+        _used(ctx, m.norm, m.q, m.k, m.v, m.proj_out)
         ctx.save_for_backward(x, hn, mean, rstd, q, k, v, pm, o)
         return y
 
@@ -544,5 +561,5 @@ class AttnBlockFn(torch.autograd.Function):
         conv_backward(hn, C, dv.view(B, H, W, C), m.v.weight, m.v.bias, dx=dhn, dx_accumulate=1)
         dx = ops.copy_feat(dy)
         ops.groupnorm_bwd(dhn, x, m.norm.weight, m.norm.bias, mean, rstd, GN_GROUPS, False, dx=dx)
-        _done(m.norm, m.q, m.k, m.v, m.proj_out)
+        _done(ctx)
         return None, dx, None

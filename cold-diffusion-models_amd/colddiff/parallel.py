@@ -9,6 +9,7 @@ buckets on a side stream as soon as the blocks that own a bucket have finished t
 (so it overlaps with the rest of the backward pass), on the last accumulation micro-step only.
 Launch with `python -m torch.distributed.run --nproc-per-node N ...` (RANK / LOCAL_RANK / WORLD_SIZE).
 """
+import datetime
 import os
 
 import torch
@@ -32,6 +33,14 @@ def local_rank():
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def pin_device():
+    """One process per GPU: bind this process to `cuda:LOCAL_RANK` so that the `.cuda()` calls of an unmodified reference
+    script (e.g. deblurring-diffusion-pytorch/celebA_128.py:100-102) land on the rank's own GPU under
+    `python -m torch.distributed.run`.  Called at package import; a no-op without LOCAL_RANK or without a GPU."""
+    if "LOCAL_RANK" in os.environ and torch.cuda.is_available():
+        torch.cuda.set_device(local_rank() % max(1, torch.cuda.device_count()))
+
+
 def init_distributed(backend=None):
     """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
     if world_size() == 1 or dist.is_initialized():
@@ -41,45 +50,89 @@ def init_distributed(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if backend == "nccl":
-        torch.cuda.set_device(local_rank())
-    dist.init_process_group(backend=backend, rank=rank(), world_size=world_size())
+        pin_device()
+    # generous timeout: at a milestone rank 0 runs the full T-step sampler + image / checkpoint I/O while the others wait
+    dist.init_process_group(backend=backend, rank=rank(), world_size=world_size(), timeout=datetime.timedelta(hours=2))
+
+
+def decorrelate_rng():
+    """Every rank draws its own timesteps / noise / colours / dropout masks (under DataParallel each replica
+    draws its own t, DEBLUR:980).  Called by the Trainer AFTER the replicas' weights are equal."""
+    if world_size() > 1:
+        torch.manual_seed((torch.initial_seed() + 7919 * rank()) % (1 << 63))
+
+
+def make_buckets(sizes, per):
+    """Greedy runs of WHOLE tensors (arena order), a run is closed once it holds >= `per` elements: no tensor ever crosses
+    a bucket edge, so a bucket is final exactly when every tensor in it is.  Returns [(first_tensor, end_tensor)]."""
+    out, first, acc = [], 0, 0
+    for i, n in enumerate(sizes):
+        acc += n
+        if acc >= per:
+            out.append((first, i + 1))
+            first, acc = i + 1, 0
+    if first < len(sizes):
+        out.append((first, len(sizes)))
+    return out
 
 
 class GradSync:
-    """Bucketed, overlapped all-reduce of a FlatArena's gradient buffer."""
+    """Bucketed, overlapped sum-all-reduce of a FlatArena's gradient buffer.
+
+    * Buckets are runs of whole parameter tensors (`make_buckets`).
+    * Readiness is counted per USE: every autograd node announces in forward which parameters its backward will write
+      (`used`), and in backward that it has enqueued that contribution (`ready`); a bucket is final when every announced
+      use of every tensor in it has reported.  A module that runs twice per loss is therefore waited for twice, a parameter
+      the loss does not reach (the blur kernels, DEBLUR:355-359) is final from the start.
+    * Collectives are ISSUED in one fixed order on every rank (last bucket first = the order backward finishes them in),
+      whatever order readiness arrives in: RCCL requires identical call sequences on all ranks.
+    """
 
     def __init__(self, arena, bucket_bytes=BUCKET_BYTES):
         self.arena = arena
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.on_gpu = arena.grad.is_cuda
-        n = arena.numel
-        per = max(1, bucket_bytes // 4)
-        self.bounds = [(lo, min(lo + per, n)) for lo in range(0, n, per)]
+        sizes = [b - a for a, b in zip(arena.offsets, arena.offsets[1:] + [arena.numel])]        # padded slot sizes
+        self.groups = make_buckets(sizes, max(1, bucket_bytes // 4))
+        ends = arena.offsets[1:] + [arena.numel]
+        self.bounds = [(arena.offsets[i], ends[j - 1]) for i, j in self.groups]
         self.bucket_of = {}
-        self.count0 = [0] * len(self.bounds)
-        for p, o in zip(arena.params, arena.offsets):
-            b = min(o // per, len(self.bounds) - 1)
-            self.bucket_of[id(p)] = b
-            self.count0[b] += 1
+        for b, (i, j) in enumerate(self.groups):
+            for p in arena.params[i:j]:
+                self.bucket_of[id(p)] = b
+        self.order = list(range(len(self.bounds) - 1, -1, -1))
         self.comm_stream = torch.cuda.Stream() if self.on_gpu else None
         self.armed = False
+        self.uses = [0] * len(self.bounds)
         self.pending = None
-        self.launched = None
+        self.head = 0
         self.works = []
 
+    # -- forward side ---------------------------------------------------------------------------------
+    def begin(self):
+        """Start of a micro-step's forward pass."""
+        self.uses = [0] * len(self.bounds)
+
+    def used(self, params):
+        for p in params:
+            b = self.bucket_of.get(id(p))
+            if b is not None:
+                self.uses[b] += 1
+
+    # -- backward side --------------------------------------------------------------------------------
     def arm(self):
-        """Call before the backward pass of the LAST accumulation micro-step."""
+        """Call after the forward and before the backward pass of the LAST accumulation micro-step."""
         if self.world == 1:
             return
         self.armed = True
-        self.pending = list(self.count0)
-        self.launched = [False] * len(self.bounds)
+        self.pending = list(self.uses)
+        self.head = 0
         self.works = []
+        self._drain()
 
     def _launch(self, b):
         lo, hi = self.bounds[b]
         buf = self.arena.grad[lo:hi]
-        self.launched[b] = True
         if self.on_gpu:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -89,25 +142,27 @@ class GradSync:
         else:
             self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
 
+    def _drain(self, force=False):
+        while self.head < len(self.order) and (force or self.pending[self.order[self.head]] == 0):
+            self._launch(self.order[self.head])
+            self.head += 1
+
     def ready(self, params):
-        """The gradients of `params` are final (their backward kernels are enqueued)."""
+        """One announced use of each of `params` has its backward kernels enqueued."""
         if not self.armed:
             return
         for p in params:
             b = self.bucket_of.get(id(p))
-            if b is None:
-                continue
-            self.pending[b] -= 1
-            if self.pending[b] == 0 and not self.launched[b]:
-                self._launch(b)
+            if b is not None:
+                self.pending[b] -= 1
+                assert self.pending[b] >= 0, "a backward node reported gradients it never announced in forward"
+        self._drain()
 
     def finish(self):
         """After backward returned: reduce whatever is left and make the compute stream wait."""
         if not self.armed:
             return
-        for b in range(len(self.bounds)):
-            if not self.launched[b]:
-                self._launch(b)
+        self._drain(force=True)        # (uses whose backward never ran, e.g. a detached branch: final now that backward is over)
         for w in self.works:
             w.wait()
         if self.on_gpu:
@@ -118,6 +173,11 @@ class GradSync:
 def set_engine(e):
     global _engine
     _engine = e
+
+
+def grads_used(params):
+    if _engine is not None:
+        _engine.used(params)
 
 
 def grads_ready(params):

@@ -22,10 +22,16 @@ from . import flat, parallel
 from . import runtime as rt
 
 
-def cycle(dl):
+def cycle(dl, sampler=None):
+    """Endless iterator over a DataLoader (DEBLUR:52-55); a DistributedSampler is re-seeded on every wrap-around so that the
+    ranks' shards are re-shuffled each epoch."""
+    epoch = 0
     while True:
+        if sampler is not None and hasattr(sampler, 'set_epoch'):
+            sampler.set_epoch(epoch)
         for d in dl:
             yield d
+        epoch += 1
 
 
 def unwrap(model):
@@ -171,6 +177,8 @@ class Trainer(object):
             parallel.set_engine(self.sync)
             # every rank starts from rank 0's weights (the reference replicates GPU 0's module)
             torch.distributed.broadcast(self.arena.data, src=0)
+            rt.bump_weights_epoch()
+            parallel.decorrelate_rng()     # weights are equal now: from here on every rank draws its own t / noise / masks
         self.reset_parameters()
         if load_path is not None:
             self.load(load_path)
@@ -187,7 +195,7 @@ class Trainer(object):
         if parallel.world_size() > 1:
             sampler = data.distributed.DistributedSampler(ds, shuffle=shuffle)
         dl = cycle(data.DataLoader(ds, batch_size=self.batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
-                                   pin_memory=True, num_workers=num_workers, drop_last=True))
+                                   pin_memory=self.device.type == 'cuda', num_workers=num_workers, drop_last=True), sampler)
         return ds, dl
 
     # -- EMA / checkpoint --------------------------------------------------------------------------------
@@ -228,6 +236,13 @@ class Trainer(object):
         denoising package (DENOISE:738-742)."""
         return torch.randn_like(batch) if self.pair_noise else None
 
+    def _sample_source(self):
+        """The images a milestone samples from: a data batch, or for the two-image packages the second image
+        (fresh noise drawn like a batch: DENOISE:759-762)."""
+        og_img = self._next_batch()
+        x2 = self._second(og_img)
+        return og_img if x2 is None else x2
+
     def _loss(self, batch):
         x2 = self._second(batch)
         return self.core(batch) if x2 is None else self.core(batch, x2)
@@ -239,6 +254,8 @@ class Trainer(object):
         scale = 1.0 / (acc * parallel.world_size())
         total = None
         for i in range(acc):
+            if self.sync is not None:
+                self.sync.begin()
             loss = torch.mean(self._loss(self._next_batch()))
             if self.sync is not None and i == acc - 1:
                 self.sync.arm()
@@ -268,10 +285,7 @@ class Trainer(object):
     def _milestone(self, acc_loss):
         milestone = self.step // self.save_and_sample_every
         if parallel.rank() == 0:                       # sampling and checkpointing stay on one GPU
-            og_img = self._next_batch()
-            x2 = self._second(og_img)
-            if x2 is not None:                         # the two-image packages sample from the second image (DENOISE:759-762, DEMIX:744)
-                og_img = x2
+            og_img = self._sample_source()
             if hasattr(self.ema_core, 'defade_fn'):
                 xt, direct_recons, all_images = self.ema_core.sample(batch_size=self.batch_size, faded_recon_sample=og_img)
             else:
@@ -297,11 +311,14 @@ class DemixTrainer(Trainer):
         self.ds1, self.dl1 = self.ds, self.dl
         self.ds2, self.dl2 = self._make_loader(folder2, dataset, shuffle, num_workers, seed=7654321)
 
-    def _second(self, batch):
+    def _second(self, batch=None):
         d = next(self.dl2)
         if isinstance(d, (list, tuple)):
             d = d[0]
         return d.to(self.device, non_blocking=True)
+
+    def _sample_source(self):
+        return self._second()          # DEMIX:744 draws from the second loader only
 
 
 class DefadeGenTrainer(Trainer):

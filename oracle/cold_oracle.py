@@ -179,7 +179,7 @@ def model_forward(sd, x, t, *, num_res_blocks, num_resolutions):     # MODEL2:28
 def gaussian_kernel2d(ksize, sigma):
     """torchgeometry.image.get_gaussian_kernel2d (0.1.x, image/gaussian.py) — see module docstring."""
     def g1(k, s):
-        v = torch.stack([torch.tensor(math.exp(-(x - k // 2) ** 2 / float(2 * s ** 2))) for x in range(k)])
+        v = torch.stack([torch.exp(torch.tensor(-(x - k // 2) ** 2 / float(2 * s ** 2))) for x in range(k)])
         return v / v.sum()
     return torch.matmul(g1(ksize[0], sigma[0]).unsqueeze(-1), g1(ksize[1], sigma[1]).unsqueeze(-1).t())
 

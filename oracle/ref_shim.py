@@ -39,8 +39,8 @@ def available():
 
 
 def gaussian_1d(ksize, sigma):
-    vals = [math.exp(-(x - ksize // 2) ** 2 / float(2 * sigma ** 2)) for x in range(ksize)]
-    g = torch.stack([torch.tensor(v) for v in vals])   # fp32, one rounding per tap
+    # torchgeometry 0.1.2 image/gaussian.py:9-17: fp32 exponent, fp32 torch.exp, per tap
+    g = torch.stack([torch.exp(torch.tensor(-(x - ksize // 2) ** 2 / float(2 * sigma ** 2))) for x in range(ksize)])
     return g / g.sum()
 
 

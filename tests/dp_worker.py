@@ -1,4 +1,10 @@
-"""Worker for tests/test_dp.py: one rank of a 2-process gloo data-parallel run on the CPU simulator."""
+"""Worker for tests/test_dp.py: one rank of a multi-process gloo data-parallel run on the CPU simulator.
+
+argv: out_path nsteps bucket_bytes mode
+  mode 'once'  : loss = L1(x, f(q(x, e, t), t))                         (the denoising package's p_losses)
+  mode 'twice' : the network runs TWICE per loss (as RESOL:702-716 'Final_random_mean_and_actual' does):
+                 loss = L1(x, f(q(x,e,t), t)) + L1(x, f(q(x,-e,t), t))
+"""
 import contextlib
 import io
 import os
@@ -16,7 +22,10 @@ install_emu()
 from colddiff import parallel  # noqa: E402
 from denoising_diffusion_pytorch import GaussianDiffusion, Trainer, Unet  # noqa: E402
 
-out_path, nsteps = sys.argv[1], int(sys.argv[2])
+out_path, nsteps, bucket_bytes, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+if bucket_bytes > 0:
+    parallel.BUCKET_BYTES = bucket_bytes
+    parallel.GradSync.__init__.__defaults__ = (bucket_bytes,)
 parallel.init_distributed("gloo")
 rank, world = parallel.rank(), parallel.world_size()
 torch.manual_seed(0)
@@ -29,14 +38,55 @@ if rank == 1:      # ranks must converge to rank 0's weights through the initial
 diff = GaussianDiffusion(net, image_size=8, channels=3, timesteps=10)
 tr = Trainer(diff, None, image_size=8, train_batch_size=2, train_lr=1e-3, train_num_steps=nsteps, gradient_accumulate_every=2,
              dataset="synthetic", results_folder=os.path.join(os.path.dirname(out_path), f"res{rank}"))
+# the per-rank RNG streams must differ after construction (every rank draws its own t / noise)
+seeds = [None] * world
+torch.distributed.all_gather_object(seeds, torch.initial_seed())
+assert len(set(seeds)) == world, seeds
+# no tensor may cross a bucket edge; record how many buckets were used and when each was launched
+sync = tr.sync
+edges = {lo for lo, _ in sync.bounds} | {hi for _, hi in sync.bounds}
+for p, o in zip(tr.arena.params, tr.arena.offsets):
+    assert not any(o < e < o + p.numel() for e in edges), "a parameter straddles a bucket edge"
+launch_log = []
+orig_launch = sync._launch
+
+
+def logged_launch(b):
+    # at launch time every announced use of the bucket must have reported (or backward is over)
+    launch_log.append((b, sync.pending[b]))
+    orig_launch(b)
+
+
+sync._launch = logged_launch
+early = []                      # buckets already issued when backward returns (= overlapped with the backward pass)
+orig_finish = sync.finish
+
+
+def logged_finish():
+    early.append(len(launch_log) - len(early) * len(sync.bounds))      # every step issues each bucket exactly once
+    orig_finish()
+
+
+sync.finish = logged_finish
 g = torch.Generator().manual_seed(1)
 # all ranks generate the full schedule and take their own shard: batches[step][rank][micro]
 batches = [[[(torch.rand(2, 3, 8, 8, generator=g) * 2 - 1, torch.randn(2, 3, 8, 8, generator=g), torch.randint(0, 10, (2,), generator=g))
              for _ in range(2)] for _ in range(world)] for _ in range(nsteps)]
+
+
+def loss_of(x, e, t):
+    if mode == "once":
+        return tr.core.p_losses(x, e, t)
+    return tr.core.p_losses(x, e, t) + tr.core.p_losses(x, -e, t)
+
+
 for s in range(nsteps):
     it = iter(batches[s][rank])
-    tr._loss = lambda batch, it=it: tr.core.p_losses(*next(it))
+    tr._loss = lambda batch, it=it: loss_of(*next(it))
     tr.train_step()
     tr.step += 1
-torch.save({k: v.clone() for k, v in net.state_dict().items()}, out_path + f".rank{rank}")
+assert all(pend == 0 for _, pend in launch_log), launch_log
+assert [b for b, _ in launch_log[:len(sync.bounds)]] == sync.order          # same issue order on every rank
+torch.save({"sd": {k: v.clone() for k, v in net.state_dict().items()}, "buckets": len(sync.bounds),
+            "max_uses": max(sync.uses), "early": min(early)}, out_path + f".rank{rank}")
 torch.distributed.barrier()

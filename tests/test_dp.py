@@ -1,11 +1,15 @@
 """Data-parallel path: 2 ranks (gloo, CPU simulator kernels) with bucketed gradient all-reduce must
 reproduce a single process that sees the global batch (same per-sample t / noise), and leave every
-rank with identical weights."""
+rank with identical weights — for every bucket size (many buckets, buckets smaller than a tensor),
+and for a loss that runs the network twice."""
+import contextlib
+import io
 import os
 import socket
 import subprocess
 import sys
 
+import pytest
 import torch
 
 from oracle import cold_oracle as O
@@ -21,19 +25,35 @@ def _free_port():
     return p
 
 
-def test_two_rank_training_matches_global_batch(tmp_path):
+def test_buckets_are_whole_tensors():
+    from colddiff.parallel import make_buckets
+    sizes = [4, 100, 8, 8, 300, 4, 4, 4, 52]
+    for per in (1, 16, 64, 128, 1 << 20):
+        b = make_buckets(sizes, per)
+        assert b[0][0] == 0 and b[-1][1] == len(sizes)
+        assert all(x[1] == y[0] for x, y in zip(b, b[1:]))                     # contiguous, cover everything
+        for i, j in b[:-1]:
+            assert sum(sizes[i:j]) >= per and sum(sizes[i:j - 1]) < per         # closed as soon as it is big enough
+
+
+@pytest.mark.parametrize("bucket_bytes,mode,min_buckets", [(512, "once", 8), (1024, "once", 8), (4096, "once", 8), (0, "once", 1),
+                                                            (1024, "twice", 8), (0, "twice", 1)])
+def test_two_rank_training_matches_global_batch(tmp_path, bucket_bytes, mode, min_buckets):
     out, nsteps = str(tmp_path / "w.pt"), 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(HERE, "dp_worker.py"), out, str(nsteps)]
+           "--master-port", str(_free_port()), os.path.join(HERE, "dp_worker.py"), out, str(nsteps), str(bucket_bytes), mode]
     env = dict(os.environ, OMP_NUM_THREADS="2")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    w0, w1 = torch.load(out + ".rank0"), torch.load(out + ".rank1")
+    r0, r1 = torch.load(out + ".rank0"), torch.load(out + ".rank1")
+    w0, w1 = r0["sd"], r1["sd"]
+    assert r0["buckets"] >= min_buckets, r0["buckets"]
+    assert r0["max_uses"] >= (2 if mode == "twice" else 1)
+    if r0["buckets"] >= 8:
+        assert r0["early"] >= r0["buckets"] // 2, r0        # most buckets are issued DURING backward, not after it
     for k in w0:
-        assert torch.equal(w0[k], w1[k]), k                      # replicas stay in lock-step
+        assert torch.equal(w0[k], w1[k]), k                      # replicas stay in lock-step, bit for bit
     # single-process oracle over the global batch: 2 ranks x 2 micro-steps = accumulate 4
-    import contextlib
-    import io
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "cold-diffusion-models_amd"))
     from colddiff.unet import Unet
     torch.manual_seed(0)
@@ -43,7 +63,12 @@ def test_two_rank_training_matches_global_batch(tmp_path):
     batches = [[[(torch.rand(2, 3, 8, 8, generator=g) * 2 - 1, torch.randn(2, 3, 8, 8, generator=g), torch.randint(0, 10, (2,), generator=g))
                  for _ in range(2)] for _ in range(2)] for _ in range(nsteps)]
     ca, cb = O.cosine_tables(10)
-    otr = O.OracleTrainer(sd0, lambda p, x, e, t: O.loss_fn(x, O.unet_forward(p, O.noise_q_sample(x, e, t, ca, cb), t)), lr=1e-3, accumulate=4)
+
+    def one(p, x, e, t):
+        return O.loss_fn(x, O.unet_forward(p, O.noise_q_sample(x, e, t, ca, cb), t))
+
+    loss = one if mode == "once" else (lambda p, x, e, t: one(p, x, e, t) + one(p, x, -e, t))
+    otr = O.OracleTrainer(sd0, loss, lr=1e-3, accumulate=4)
     for s in range(nsteps):
         otr.train_step([b for rank_b in batches[s] for b in rank_b])
     for k in sd0:

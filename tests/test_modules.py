@@ -391,6 +391,69 @@ def test_defading_golden(mbe):
     assert torch.equal(q, O.fade_q_sample(x, t, d.fade_kernels.cpu(), rx, ry, discrete=True))
 
 
+def test_extras_golden_discrete_individual_and_random_fades(mbe):
+    """Reference-generated vectors (tests/golden/make_golden.py: extra_cases) for the branches that round 1 only compared with the
+    oracle: deblurring `discrete=True` (DEBLUR:413-415, 441-444, 937-940, 954-958), blur_routine 'Individual_Incremental'
+    (DEBLUR:380-383, 402-403, 427-428), defading 'Constant' / 'Random_Incremental' (+discrete) with the reference's own seeded crop
+    offsets replayed (DEFADE:359-368, 501-516)."""
+    from deblurring_diffusion_pytorch import GaussianDiffusion
+    g = load("extras.pt")
+    net = _net(mbe, load("diffusion.pt")["deblur/net_sd"])
+    for key, c in g.items():
+        if not key.startswith("deblur/"):
+            continue
+        _, routine, sampling = key.split("/")
+        d = GaussianDiffusion(net, image_size=16, device_of_kernel="cuda", channels=3, timesteps=c["T"], kernel_std=c["std"],
+                              kernel_size=c["ks"], blur_routine=routine, sampling_routine=sampling, discrete=c["discrete"]).to(mbe.device)
+        for m, w in zip(d.gaussian_kernels, c["kernels"]):
+            assert torch.equal(m.weight.detach().cpu(), w), key
+        with torch.no_grad():
+            if routine != "Individual_Incremental":          # (its kernel sizes differ per step: q_sample's conv stack is still uniform upstream)
+                q = d.q_sample(mbe.to(c["x"]), mbe.to(c["t"])).cpu()
+                if c["discrete"]:
+                    # int() truncation to 8-bit levels: a 1-ulp difference before the floor may move a pixel by one level
+                    lv = ((q - c["q"]).abs() * 127.5).round()
+                    assert lv.max() <= 1 and (lv > 0).float().mean() <= 2e-3, (key, lv.max(), (lv > 0).float().mean())
+                else:
+                    assert (q - c["q"]).abs().max() <= 2e-6, key
+            xt, direct, img = quiet(d.sample, batch_size=3, img=mbe.to(c["x"]))
+        assert (xt.cpu() - c["xt"]).abs().max() <= 2e-6, key
+        assert (direct.cpu() - c["direct"]).abs().max() <= 1e-4 and (img.cpu() - c["img"]).abs().max() <= 1e-4, key
+    from defading_diffusion_pytorch import GaussianDiffusion as Defade
+    for key, c in g.items():
+        if not key.startswith("defade/"):
+            continue
+        _, routine, discrete, sampling = key.split("/")
+        d = Defade(net, image_size=16, device_of_kernel="cuda", channels=3, timesteps=c["T"], kernel_std=0.5, initial_mask=1,
+                   fade_routine=routine, sampling_routine=sampling, discrete=bool(int(discrete)))
+        assert torch.equal(d.fade_kernels, c["masks"]), key
+        if "Random" in routine:                               # the reference's draws (CPU generator) replayed on any device
+            d._offsets = lambda b, dev, c=c: (c["rand_x"].to(dev), c["rand_y"].to(dev))
+        with torch.no_grad():
+            assert torch.equal(d.q_sample(mbe.to(c["x"]), mbe.to(c["t"])).cpu(), c["q"]), key          # bit-exact (products + truncation)
+            xt, direct, img = d.sample(batch_size=3, faded_recon_sample=mbe.to(c["x"]))
+        assert torch.equal(xt.cpu(), c["xt"]), key
+        assert (direct.cpu() - c["direct"]).abs().max() <= 1e-4 and (img.cpu() - c["img"]).abs().max() <= 1e-4, key
+
+
+def test_gaussian_taps_follow_torchgeometry_fp32_exp():
+    """torchgeometry 0.1.2 image/gaussian.py evaluates exp IN fp32 on the fp32-rounded exponent (torch.exp(torch.tensor(.))), tap by
+    tap.  Independent restatement with numpy float32 scalars + the SURVEY 8(c) probe values; fp64-exp-then-round (round 1) differs
+    in 2-8 taps per kernel for sigma = 0.35 / 0.84 / 7."""
+    import numpy as np
+    from colddiff import degrade as D
+    for k, s in ((11, 7.0), (11, 0.35), (11, 0.84), (15, 1.0), (5, 0.2), (3, 0.4)):
+        e = np.array([np.exp(np.float32(-(x - k // 2) ** 2 / float(2 * s ** 2))) for x in range(k)], dtype=np.float32)
+        g1 = torch.from_numpy(e) / torch.from_numpy(e).sum()
+        ref = torch.matmul(g1.unsqueeze(-1), g1.unsqueeze(-1).t())
+        got = D.gaussian_kernel2d((k, k), (s, s))
+        assert got.dtype == torch.float32 and (got - ref).abs().max() <= 4e-7 * ref.max(), (k, s)       # numpy vs torch fp32 exp: a few ulp apart at most
+        assert torch.equal(got, O.gaussian_kernel2d((k, k), (s, s)))
+    k = D.gaussian_kernel2d((11, 11), (7.0, 7.0))
+    assert abs(k[5, 5].item() - 0.0100549823) < 1e-9 and abs(k[0, 0].item() - 0.0060367407) < 1e-9
+    assert abs(D.gaussian_kernel2d((15, 15), (1.0, 1.0))[7, 7].item() - 0.1591549516) < 2e-8
+
+
 def test_trainer_matches_oracle(mbe, tmp_path):
     """3 optimizer steps (2 micro-steps each, fused Adam over the flat arena, EMA copy phase) and the
     checkpoint round trip, against the oracle's torch.optim.Adam loop."""
