@@ -267,6 +267,16 @@ def extra_cases(net_sd):
                 xt, direct, img = d.sample(batch_size=3, faded_recon_sample=x)
             out[f"defade/{routine}/{int(discrete)}/{sampling}"] = dict(T=T, x=x, t=t, q=xq, xt=xt, direct=direct, img=img, masks=d.fade_kernels.clone(),
                                                                       rand_x=offs["q"][0], rand_y=offs["q"][1])
+    ref = ref_shim.load("resolution")                                   # the *_with_blur routines (RESOL:354-385, 399-404)
+    for routine in ("Incremental_bicubic_with_blur", "Incremental_area_with_blur"):
+        T = 3
+        d = ref.GaussianDiffusion(net, image_size=16, device_of_kernel="cpu", channels=3, timesteps=T, resolution_routine=routine,
+                                  sampling_routine="x0_step_down")
+        x, t = images(3, 3, 16, g), torch.tensor([0, 2, 1])
+        with torch.no_grad(), quiet():
+            xq = d.q_sample(x, t)
+            xt, direct, img = d.sample(batch_size=3, img=x)
+        out[f"resolution/{routine}"] = dict(T=T, x=x, t=t, q=xq, xt=xt, img=img)
     return out
 
 

@@ -434,6 +434,16 @@ def test_extras_golden_discrete_individual_and_random_fades(mbe):
             xt, direct, img = d.sample(batch_size=3, faded_recon_sample=mbe.to(c["x"]))
         assert torch.equal(xt.cpu(), c["xt"]), key
         assert (direct.cpu() - c["direct"]).abs().max() <= 1e-4 and (img.cpu() - c["img"]).abs().max() <= 1e-4, key
+    from resolution_diffusion_pytorch import GaussianDiffusion as Resol
+    for key, c in g.items():
+        if not key.startswith("resolution/"):
+            continue
+        d = Resol(net, image_size=16, device_of_kernel="cuda", channels=3, timesteps=c["T"], resolution_routine=key.split("/")[1],
+                  sampling_routine="x0_step_down")
+        with torch.no_grad():
+            assert (d.q_sample(mbe.to(c["x"]), mbe.to(c["t"])).cpu() - c["q"]).abs().max() <= 1e-5, key
+            xt, _, img = quiet(d.sample, batch_size=3, img=mbe.to(c["x"]))
+        assert (xt.cpu() - c["xt"]).abs().max() <= 1e-5 and (img.cpu() - c["img"]).abs().max() <= 1e-4, key
 
 
 def test_gaussian_taps_follow_torchgeometry_fp32_exp():
