@@ -33,8 +33,33 @@ def log(msg):
 
 _T0 = time.perf_counter()
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E
 UNET128_FWD_GFLOP = 67.41          # SURVEY.md §8(d), per image
+UNET128_ACT_TRAIN_MB = {"f32": 1098.0, "bf16": 549.0}   # A_train = 2.5 x A_fwd, layer-boundary bytes per image
+UNET128_PARAMS = 56615708
 TIMESTEPS = 200
+
+
+def step_roofline(batch, accum, ms_per_step, mfma_per_product, act="f32"):
+    """SURVEY.md 8(d): bytes_step = B (A_train + D_bytes) accum + 3 W accum + 28 P (+ 1.2 P amortised EMA);
+    flops_step = B (F_train + D_flops) accum; t_roof = max(bytes / BW_HBM, flops x mfma_per_product / PEAK_MFMA[bf16])."""
+    P = UNET128_PARAMS
+    W = 4.0 * P
+    d_bytes = 3 * 3 * 128 * 128 * 4.0                       # noise q_sample: read x, read noise, write x_t (fp32)
+    bytes_step = batch * (UNET128_ACT_TRAIN_MB[act] * 1e6 + d_bytes) * accum + 3 * W * accum + 28.0 * P + 1.2 * P
+    flops_step = batch * accum * (3 * UNET128_FWD_GFLOP * 1e9 + 3 * 3 * 128 * 128)
+    t = ms_per_step * 1e-3
+    t_hbm = bytes_step / (PEAK_HBM_GBS * 1e9)
+    t_mfma = flops_step * mfma_per_product / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+    return {"bytes_step": round(bytes_step), "flops_step": round(flops_step), "hbm_gbs": round(bytes_step / t / 1e9, 1),
+            "hbm_frac_of_peak": round(bytes_step / t / 1e9 / PEAK_HBM_GBS, 4),
+            "algorithmic_tflops": round(flops_step / t / 1e12, 2), "mfma_per_product": mfma_per_product,
+            "mfma_issue_frac_of_bf16_peak": round(flops_step * mfma_per_product / t / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+            "t_roof_ms": round(1000 * max(t_hbm, t_mfma), 3), "t_roof_over_t": round(max(t_hbm, t_mfma) / t, 4),
+            "bound": "mfma" if t_mfma >= t_hbm else "hbm",
+            "formula": "SURVEY 8(d): bytes = B(A_train+D)accum + 3W accum + 28P + 1.2P; flops = 3 x 67.41 GF/img; "
+                       "t_roof = max(bytes/8 TB/s, flops x mfma_per_product / 2.5 PF)"}
 
 
 def build_workload(args, device):
@@ -163,17 +188,125 @@ def cpu_baseline(args):
         return out
 
     t0 = time.perf_counter()
-    tr.train_step(batches())                     # warm-up
+    tr.train_step(batches())                     # warm-up 1
     warm = time.perf_counter() - t0
-    log(f"cpu baseline warm-up step: {warm:.1f}s on {ncores} threads")
-    n = 2 if warm < 12 else 1                    # keep the whole leg within ~30 s
+    log(f"cpu baseline first warm-up step: {warm:.1f}s on {ncores} threads")
+    nwarm, n = (3, 5) if warm < 4.5 else ((2, 3) if warm < 9 else (1, 1))     # 3 warm-up + 5 timed; bounded to ~35 s on a slow host
+    for _ in range(nwarm - 1):
+        tr.train_step(batches())
     t0 = time.perf_counter()
     for _ in range(n):
         tr.train_step(batches())
     dt = (time.perf_counter() - t0) / n
     return {"value": round(Bc * args.accum / dt, 3), "unit": "img/s", "cores": ncores, "kind": "port",
-            "sample": f"oracle/cold_oracle.py (PyTorch CPU fp32) optimizer step, {args.accum} micro-steps x {Bc} images at 128x128, "
-                      f"{n} timed steps after 1 warm-up"}
+            "sample": f"oracle/cold_oracle.py = bit-exact port of the reference's PyTorch CPU path (tests/test_oracle.py pins it to the live "
+                      f"reference; /root/reference does not exist on the GPU box): same optimizer step, {args.accum} micro-steps x {Bc} images "
+                      f"at 128x128, {n} timed steps after {nwarm} warm-up, {ncores} threads"}
+
+
+def selfcheck(diffusion, device):
+    """The benchmarked weights on a 2-image sub-batch: micro-step loss on the HIP path vs the CPU oracle."""
+    from oracle import cold_oracle as O
+    g = torch.Generator().manual_seed(99)
+    x = torch.randint(0, 256, (2, 3, 128, 128), generator=g).float() / 255 * 2 - 1
+    e = torch.randn(2, 3, 128, 128, generator=g)
+    t = torch.tensor([17, 183])
+    with torch.no_grad():
+        lh = float(diffusion.p_losses(x.to(device), e.to(device), t.to(device)))
+        sd = {k: v.detach().cpu() for k, v in diffusion.denoise_fn.state_dict().items()}
+        ca, cb = O.cosine_tables(TIMESTEPS)
+        lo = float(O.loss_fn(x, O.unet_forward(sd, O.noise_q_sample(x, e, t, ca, cb), t)))
+    return {"microstep_loss_hip": lh, "microstep_loss_oracle": lo, "abs_diff": abs(lh - lo), "images": 2,
+            "note": "p_losses (q_sample -> UNet -> L1) of the benchmarked weights on a 2-image sub-batch, HIP path vs oracle/cold_oracle.py"}
+
+
+def timed_train(trainer, steps, warmup):
+    for _ in range(warmup):
+        trainer.train_step()
+        trainer.step += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.train_step()
+        trainer.step += 1
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def secondary_workloads(device):
+    """BASELINE configs 2 and 4 on the same engine (secondary keys; the judged line stays config 3)."""
+    import contextlib
+    import io
+    from colddiff.trainer import Trainer
+    out = {}
+    quiet = lambda: contextlib.redirect_stdout(io.StringIO())
+    res = os.path.join(REPO, "gpurun_out", "bench_results")
+    # ---- config 4: CelebA-128 deblurring, Exponential_reflect T=200 k=15 std=0.01 (celebA_128.py) ------------------------
+    from deblurring_diffusion_pytorch import GaussianDiffusion, Model, Unet
+    torch.manual_seed(123457)
+    with quiet():
+        net = Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=3).to(device)
+        d = GaussianDiffusion(net, image_size=128, device_of_kernel='cuda', channels=3, timesteps=200, loss_type='l1', kernel_std=0.01,
+                              kernel_size=15, blur_routine='Exponential_reflect', train_routine='Final', sampling_routine='x0_step_down').to(device)
+        tr = Trainer(d, None, image_size=128, train_batch_size=32, train_lr=2e-5, train_num_steps=10 ** 9, gradient_accumulate_every=2,
+                     dataset='synthetic', results_folder=res)
+    tr.quiet = True
+    dt = timed_train(tr, 5, 2)
+    out["cfg4_celeba128_deblur_train"] = {"img_per_s": round(64 / dt, 1), "ms_per_step": round(1000 * dt, 2),
+                                          "workload": "Unet(64,(1,2,4,8)) @128x128, blur Exponential_reflect T=200 k=15 std=0.01, 2 x 32 img + Adam"}
+    with torch.no_grad():
+        x = tr._next_batch()[:16]
+        with quiet():
+            d.sample(batch_size=16, img=x, t=2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with quiet():
+            d.sample(batch_size=16, img=x)
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t0
+    out["cfg4_celeba128_deblur_sample"] = {"ms_per_img": round(1000 * dts / 16, 2), "batch": 16,
+                                           "workload": "Algorithm 2 (x0_step_down), T=200: 200 UNet calls + D(x0,t), D(x0,t-1) blur chains (T(T+1)/2 steps each) per image"}
+    del tr, d, net
+    torch.cuda.empty_cache()
+    # ---- config 2: CIFAR-10 deblurring, Model(ch=128,(1,2,2,2)), Special_6_routine T=50, batch 128 (cifar10_train.py) -----
+    torch.manual_seed(123457)
+    with quiet():
+        net = Model(resolution=32, in_channels=3, out_ch=3, ch=128, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,), dropout=0.1).to(device)
+        d = GaussianDiffusion(net, image_size=32, device_of_kernel='cuda', channels=3, timesteps=50, loss_type='l1', kernel_std=0.1, kernel_size=11,
+                              blur_routine='Special_6_routine', train_routine='Final', sampling_routine='x0_step_down').to(device)
+        tr = Trainer(d, None, image_size=32, train_batch_size=128, train_lr=2e-5, train_num_steps=10 ** 9, gradient_accumulate_every=2,
+                     dataset='synthetic', results_folder=res)
+    tr.quiet = True
+    dt = timed_train(tr, 10, 3)
+    out["cfg2_cifar10_deblur_train"] = {"img_per_s": round(256 / dt, 1), "ms_per_step": round(1000 * dt, 2),
+                                        "workload": "Model(ch=128,(1,2,2,2),attn@16,dropout 0.1) @32x32, blur Special_6_routine T=50, 2 x 128 img + Adam"}
+    del tr, d, net
+    torch.cuda.empty_cache()
+    return out
+
+
+def bandwidth_classes():
+    """HBM GB/s of the bandwidth-bound kernel classes: bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (tools/pmc_traffic.py) divided by the average launch duration of the committed rocprofv3 --kernel-trace of the same command
+    (bench.py cannot run the profiler on itself)."""
+    tp, kp = os.path.join(REPO, "profiles", "round2_pmc_traffic.json"), os.path.join(REPO, "profiles", "round2_kernel_trace.json")
+    if not (os.path.exists(tp) and os.path.exists(kp)):
+        return None
+    traffic, trace = json.load(open(tp))["kernels"], json.load(open(kp))
+    classes = {"depthwise 7x7": ("dwconv7_kernel", "dwconv7_wgrad_partial_kernel"), "channel LayerNorm": ("layernorm_c_fwd_kernel", "layernorm_c_bwd_kernel"),
+               "Adam": ("adam_kernel",), "operand split": ("split_bf16_kernel",), "split-K reduction": ("unpack_reduce_kernel",),
+               "linear attention": ("linattn_",)}
+    out = {}
+    for name, prefixes in classes.items():
+        b = t = 0.0
+        for k, v in traffic.items():
+            if k.startswith(prefixes) and k in trace:
+                b += v["hbm_bytes_per_launch"] * trace[k]["calls"]
+                t += trace[k]["total_ms"] * 1e-3
+        if t > 0:
+            out[name] = {"hbm_gbs": round(b / t / 1e9, 1), "frac_of_peak": round(b / t / 1e9 / PEAK_HBM_GBS, 3)}
+    out["source"] = "profiles/round2_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per launch) / profiles/round2_kernel_trace.json (avg duration)"
+    return out
 
 
 def main():
@@ -186,6 +319,7 @@ def main():
     ap.add_argument("--sample-batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sample", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the bf16-mode line, the config 2 / 4 secondary workloads and the self-check")
     args = ap.parse_args()
 
     from colddiff import parallel, runtime
@@ -271,17 +405,24 @@ def main():
                                            % (args.steps, 1000 * elapsed_instr / args.steps, 1000 * elapsed / args.steps)}
             # HBM traffic of that kernel group from the committed rocprofv3 --pmc passes over this same command
             # (tools/pmc_traffic.py; bench.py cannot run the profiler on itself)
-            tpath = os.path.join(REPO, "profiles", "round1_pmc_traffic.json")
+            tpath = os.path.join(REPO, "profiles", "round2_pmc_traffic.json")
+            if not os.path.exists(tpath):
+                tpath = os.path.join(REPO, "profiles", "round1_pmc_traffic.json")
             if os.path.exists(tpath) and dom == "conv_igemm_sp":
                 g = json.load(open(tpath)).get("conv_igemm_sp")
                 if g:
                     out["roofline"]["traffic"] = round(g["hbm_bytes_per_launch"])
-                    out["roofline"]["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/round1_pmc_traffic.json)"
+                    out["roofline"]["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, %s)" % os.path.relpath(tpath, REPO)
         out["gemm_kernels"] = kernels
-        # whole-step view: 3 x F_fwd per image against the same MFMA peak
+        # whole-step view: layer-boundary bytes and 3 x F_fwd flops per image against the HBM / MFMA roofs
+        npp = {"bf16x3": 3, "bf16": 1}.get(runtime.precision, 16)      # MFMAs per algorithmic product (f32: the 16x slower fp32 MFMA)
+        out["step_roofline"] = step_roofline(args.batch, args.accum, 1000 * elapsed / args.steps, npp)
         step_tflops = 3 * UNET128_FWD_GFLOP * args.batch * args.accum * args.steps / elapsed / 1e3
         out["step_algorithmic_tflops"] = round(step_tflops, 2)
         out["step_frac_of_f32_mfma_peak"] = round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)
+        bw = bandwidth_classes()
+        if bw:
+            out["hbm_bound_kernel_classes"] = bw
         if world == 1 and not args.no_sample:
             with torch.no_grad():
                 noise = torch.randn(args.sample_batch, 3, 128, 128, device=device)
@@ -293,6 +434,28 @@ def main():
                 out["sample_ms_per_img_200step"] = round(1000 * (time.perf_counter() - ts) / args.sample_batch, 2)
                 log(f"200-step gen_sample of {args.sample_batch} images: {time.perf_counter() - ts:.2f}s")
                 out["sample_batch"] = args.sample_batch
+        if world == 1 and not args.no_secondary:
+            out["selfcheck"] = selfcheck(diffusion, device)
+            log("self-check: loss hip %.6f oracle %.6f" % (out["selfcheck"]["microstep_loss_hip"], out["selfcheck"]["microstep_loss_oracle"]))
+            if runtime.precision == "bf16x3":
+                # second, LABELLED line: the same step with single-pass bf16 GEMM operands (BASELINE config 3 names bf16).  Not parity
+                # grade (tolerance below); reported beside the parity-grade `value`, never instead of it.
+                runtime.set_precision("bf16")
+                runtime.bump_weights_epoch()
+                dtb = timed_train(trainer, args.steps, args.warmup)
+                runtime.set_precision("bf16x3")
+                runtime.bump_weights_epoch()
+                out["bf16_mode"] = {"value": round(args.batch * args.accum / dtb, 2), "unit": "img/s", "ms_per_step": round(1000 * dtb, 3),
+                                    "dtype": "bf16 GEMM operands (one MFMA per product), fp32 accumulate / master weights / norms / softmax / "
+                                             "degradation / optimizer; bf16 planes are the only stored form of LN and GELU outputs",
+                                    "tolerance_vs_fp32_oracle": "UNet output max-abs <= 1e-2 (measured 2.5e-3 on a 64x64 dim-64 net), gradients ~2e-2 "
+                                                                "relative (tests/test_gpu_parity2.py::test_other_precision_modes_module_level)",
+                                    "step_roofline": step_roofline(args.batch, args.accum, 1000 * dtb, 1)}
+                log(f"bf16 mode: {out['bf16_mode']['value']} img/s")
+            del trainer
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary_workloads(device)
+            log("secondary workloads done")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

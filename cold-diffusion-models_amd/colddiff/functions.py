@@ -57,7 +57,7 @@ def conv_forward(x, Cin, weight, bias, kind="conv", stride=1, pad=None, xs=None,
     Cout = weight.shape[0] if kind == "conv" else weight.shape[1]
     sfx = _sp_suffix(Cin * k * k, Cout)
     wp = ops.packed(weight, ("conv_fwd" if kind == "conv" else "convT_fwd") + sfx)
-    if xs is None and sfx and _ALWAYS_PRESPLIT and rt.precision == "bf16x3" and Cin % 8 == 0 and x.device.type != "meta":
+    if xs is None and sfx and _ALWAYS_PRESPLIT and rt.precision != "f32" and Cin % 8 == 0 and x.device.type != "meta":
         xs = ops.split_bf16(x[..., :Cin] if x.shape[-1] != Cin else x)     # every bf16x3 GEMM goes through the LDS-DMA kernel
     if xs is not None and sfx:
         return ops.conv_gemm_presplit(plan, xs, Cin, wp, Cout, bias=bias, split_out=split_out, planes_only=planes_only, **epi)
@@ -66,9 +66,9 @@ def conv_forward(x, Cin, weight, bias, kind="conv", stride=1, pad=None, xs=None,
 
 
 def want_presplit(Cin, Cout, k):
-    """True when a conv's operands should be split once up front (bf16x3 mode, GEMM routed to the
+    """True when a conv's operands should be handed over as bf16 planes produced once up front (bf16x3 / bf16 modes, GEMM routed to the
     split-precision kernels, channel counts vector-friendly)."""
-    return rt.precision == "bf16x3" and Cin % 8 == 0 and Cout % 8 == 0 and bool(_sp_suffix(Cin * k * k, Cout)) and bool(_sp_suffix(Cout * k * k, Cin))
+    return rt.precision != "f32" and Cin % 8 == 0 and Cout % 8 == 0 and bool(_sp_suffix(Cin * k * k, Cout)) and bool(_sp_suffix(Cout * k * k, Cin))
 
 
 _CIN4 = os.environ.get("CDF_CIN4", "1") != "0"    # direct kernels for the <= 4-input-channel image-side convs
@@ -112,7 +112,7 @@ def conv_backward(x, Cin, dy, weight, bias, kind="conv", stride=1, pad=None, nee
         return None
     sfx = _sp_suffix(Cout * KK, Cin)
     wd = ops.packed(weight, ("conv_dgrad" if kind == "conv" else "convT_dgrad") + sfx)
-    if dys is None and sfx and _ALWAYS_PRESPLIT and rt.precision == "bf16x3" and Cout % 8 == 0 and dy.device.type != "meta":
+    if dys is None and sfx and _ALWAYS_PRESPLIT and rt.precision != "f32" and Cout % 8 == 0 and dy.device.type != "meta":
         dys = ops.split_bf16(dy[..., :Cout] if dy.shape[-1] != Cout else dy)
     if dys is not None and sfx:
         return ops.conv_gemm_presplit(pd, dys, Cout, wd, Cin, y=dx, mul=mul, mul_mode=mul_mode, accumulate=dx_accumulate,

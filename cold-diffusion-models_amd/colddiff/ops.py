@@ -58,7 +58,7 @@ def packed(param, kind):
            dw        [49][C]                                          (weight [C,1,7,7])
            lin_fwd   [1][K][N]                                        (weight [N,K])
     """
-    key = (param.data_ptr(), param._version, rt.weights_epoch, kind)
+    key = (param.data_ptr(), param._version, rt.weights_epoch, kind, rt.precision)
     slot = (id(param), kind)
     hit = _pack_cache.get(slot)
     if hit is not None and hit[0] == key and hit[2]() is param:   # the weakref guards against id()/address reuse by a new tensor
@@ -86,7 +86,7 @@ def packed(param, kind):
         N, K, s_n, s_k = geo
         ldk = (K + 31) // 32 * 32
         hi = torch.empty((KK, N, ldk), device=w.device, dtype=torch.int16)
-        lo = torch.empty((KK, N, ldk), device=w.device, dtype=torch.int16)
+        lo = torch.empty((KK, N, ldk), device=w.device, dtype=torch.int16) if rt.precision == "bf16x3" else None    # bf16 mode: hi plane only
         rt.lib().cdf_pack_weight_bf16(P(w), P(hi), P(lo), KK, N, K, ldk, 1, s_n, s_k, rt.stream(w))
         out = (hi, lo)
     elif kind == "cin4":
@@ -137,12 +137,13 @@ def zero_page(device):
 
 
 def split_bf16(x):
-    """fp32 feature map [.., C] (any pixel pitch) -> (hi, lo) bf16 planes, contiguous, pitch roundup8(C)."""
+    """fp32 feature map [.., C] (any pixel pitch) -> (hi, lo) bf16 planes, contiguous, pitch roundup8(C).
+    In "bf16" mode the operands are single bf16 values: lo is None and is never written or read."""
     C = x.shape[-1]
     ld = (C + 7) // 8 * 8
     f = torch.zeros if ld != C else torch.empty
     hi = f(x.shape[:-1] + (ld,), device=x.device, dtype=torch.int16)
-    lo = f(x.shape[:-1] + (ld,), device=x.device, dtype=torch.int16)
+    lo = f(x.shape[:-1] + (ld,), device=x.device, dtype=torch.int16) if rt.precision == "bf16x3" else None
     rt.lib().cdf_split_bf16(P(x), ld_of(x), P(hi), P(lo), ld, x.numel() // C, C, rt.stream(x))
     return hi, lo
 
@@ -151,7 +152,8 @@ def split_planes_like(ref, B, H, W, C):
     """Empty (hi, lo) bf16 planes for a [B,H,W,C] feature map (pitch roundup8(C), padding zeroed) on ref's device."""
     ld = (C + 7) // 8 * 8
     f = torch.zeros if ld != C else torch.empty
-    return (f((B, H, W, ld), device=ref.device, dtype=torch.int16), f((B, H, W, ld), device=ref.device, dtype=torch.int16))
+    return (f((B, H, W, ld), device=ref.device, dtype=torch.int16),
+            f((B, H, W, ld), device=ref.device, dtype=torch.int16) if rt.precision == "bf16x3" else None)
 
 
 def conv_gemm_presplit(plan, xs, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None, pre=None, mul=None, act=0, mul_mode=0,

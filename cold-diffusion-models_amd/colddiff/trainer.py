@@ -139,7 +139,7 @@ class Trainer(object):
     def __init__(self, diffusion_model, folder, *, ema_decay=0.995, image_size=128, train_batch_size=32, train_lr=2e-5,
                  train_num_steps=100000, gradient_accumulate_every=2, fp16=False, step_start_ema=2000, update_ema_every=10,
                  save_and_sample_every=1000, results_folder='./results', load_path=None, dataset=None, shuffle=True,
-                 num_workers=8):
+                 num_workers=8, device_data=None):
         super().__init__()
         assert not fp16, "apex fp16 is not supported (every reference script passes fp16=False)"
         self.model = diffusion_model
@@ -157,6 +157,11 @@ class Trainer(object):
         # the denoising package feeds (image, fresh Gaussian noise) pairs (DENOISE:738-742)
         self.pair_noise = hasattr(self.core, 'sqrt_alphas_cumprod')
         self.device = next(self.core.parameters()).device
+        # device_data: keep the (1.12x-resized, uint8) image folder in HBM and crop / mirror / convert per batch in one kernel instead
+        # of PIL DataLoader workers.  None = automatic: on for a HIP device unless COLDDIFF_DEVICE_DATA=0.
+        if device_data is None:
+            device_data = self.device.type == 'cuda' and os.environ.get("COLDDIFF_DEVICE_DATA", "1") != "0"
+        self.device_data = bool(device_data)
 
         self.ds, self.dl = self._make_loader(folder, dataset, shuffle, num_workers, seed=123457)
 
@@ -190,6 +195,10 @@ class Trainer(object):
             return None, SyntheticImages(self.batch_size, self.core.channels, self.image_size, self.device, seed=seed + parallel.rank())
         aug = dataset in self.AUG_DATASETS
         print(dataset, "DA used" if aug else "")
+        if self.device_data:
+            cache = DeviceImageCache(folder, self.image_size, self.device)
+            return cache, DeviceLoader(cache, self.batch_size, augment=aug, shuffle=shuffle, seed=seed, rank=parallel.rank(),
+                                       world=parallel.world_size())
         ds = (Dataset_Aug1 if aug else Dataset)(folder, self.image_size)
         sampler = None
         if parallel.world_size() > 1:
@@ -333,3 +342,106 @@ class DefadeGenTrainer(Trainer):
         B, C, H, W = batch.shape
         c = torch.rand((B, C), device=batch.device) - 0.5
         return c[:, :, None, None].expand(B, C, H, W).contiguous()
+
+
+# -- device-side input pipeline -----------------------------------------------------------------------
+class DeviceImageCache:
+    """The image folder of `Dataset_Aug1` / `Dataset` (DEBLUR:983-1026) decoded ONCE and kept in HBM as uint8, already resized to
+    S = int(1.12 image_size) -- the deterministic `transforms.Resize((S, S))` of the reference's chain, done with the same PIL call
+    (bilinear, PIL's reducing filter) on the host at cache-build time by a thread pool.  What is random per sample (crop offset,
+    mirror) or pure arithmetic (ToTensor, t*2-1) runs per batch in ONE kernel (cdf_augment_batch): the training loop never waits for
+    host image workers (the reference spawns 8-16 PIL processes, DEBLUR:1095, 1107, 1114).
+    CelebA (202 599 images) at S = 143: 12.4 GB of the MI355X's 288 GB."""
+
+    def __init__(self, folder, image_size, device, exts=('jpg', 'jpeg', 'png'), decode_threads=None, paths=None):
+        import numpy as np
+        from concurrent.futures import ThreadPoolExecutor
+        from PIL import Image
+        self.image_size = image_size
+        self.S = int(image_size * 1.12)
+        self.paths = list(paths) if paths is not None else [p for ext in exts for p in Path(f'{folder}').glob(f'**/*.{ext}')]
+        assert len(self.paths) > 0, f"no images under {folder}"
+        S = self.S
+
+        def load(p):
+            img = Image.open(p)
+            arr = np.asarray(img.resize((S, S), Image.BILINEAR))      # == transforms.Resize((S, S)) on a PIL image
+            return arr[:, :, None] if arr.ndim == 2 else arr
+
+        first = load(self.paths[0])
+        self.channels = first.shape[2]
+        n = len(self.paths)
+        host = torch.empty((n, S, S, self.channels), dtype=torch.uint8, pin_memory=torch.device(device).type == 'cuda')
+        hv = host.numpy()
+        hv[0] = first
+
+        def fill(i):
+            a = load(self.paths[i])
+            assert a.shape == first.shape, f"{self.paths[i]}: {a.shape} vs {first.shape} (mixed image modes in one folder)"
+            hv[i] = a
+
+        with ThreadPoolExecutor(max_workers=decode_threads or min(32, os.cpu_count() or 1)) as ex:   # PIL releases the GIL while decoding / resizing
+            list(ex.map(fill, range(1, n)))
+        self.data = host.to(device, non_blocking=True)
+
+    def __len__(self):
+        return len(self.paths)
+
+    def batch(self, idx, oy, ox, flip):
+        """[B, C, H, H] fp32 batch: images idx (int64 [B]) cropped at (oy, ox), mirrored where flip != 0 (int32 [B] each, on the device)."""
+        rt.check(self.data)
+        B, H = idx.numel(), self.image_size
+        out = torch.empty((B, self.channels, H, H), device=self.data.device, dtype=torch.float32)
+        rt.lib().cdf_augment_batch(rt.P(self.data), len(self.paths), self.S, self.channels, rt.P(idx), rt.P(oy), rt.P(ox), rt.P(flip), rt.P(out),
+                                   B, H, H, rt.stream(self.data))
+        return out
+
+
+class DeviceLoader:
+    """Endless batch iterator over a DeviceImageCache with the sampling semantics of the reference's loader: `shuffle=True`
+    permutes the indices every epoch, `drop_last=True`, batch_size images per step (DEBLUR:1095-1096); with several ranks every
+    rank takes the DistributedSampler slice perm[rank::world] of the SAME epoch permutation (seed + epoch on a CPU generator).
+    augment: RandomCrop(image_size) + RandomHorizontalFlip() (Dataset_Aug1), else CenterCrop (Dataset)."""
+
+    def __init__(self, cache, batch_size, augment, shuffle=True, seed=123457, rank=0, world=1):
+        self.cache, self.batch_size, self.augment, self.shuffle = cache, batch_size, augment, shuffle
+        self.seed, self.rank, self.world = seed, rank, world
+        self.epoch, self.pos, self.order = 0, 0, None
+        dev = cache.data.device
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(seed + 7919 * rank)
+        n = len(cache) // world if world > 1 else len(cache)
+        assert n >= batch_size, f"{len(cache)} images over {world} ranks: fewer than one batch of {batch_size}"
+        c = (cache.S - cache.image_size) // 2
+        self._center = torch.full((batch_size,), c, dtype=torch.int32, device=dev)
+        self._noflip = torch.zeros((batch_size,), dtype=torch.int32, device=dev)
+
+    def _new_epoch(self):
+        n = len(self.cache)
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            perm = torch.randperm(n, generator=g)
+        else:
+            perm = torch.arange(n)
+        if self.world > 1:
+            perm = perm[:n - n % self.world][self.rank::self.world]
+        self.order = perm.to(self.cache.data.device)
+        self.pos = 0
+        self.epoch += 1
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        B = self.batch_size
+        if self.order is None or self.pos + B > self.order.numel():       # drop_last
+            self._new_epoch()
+        idx = self.order[self.pos:self.pos + B].contiguous()
+        self.pos += B
+        if not self.augment:
+            return self.cache.batch(idx, self._center, self._center, self._noflip)
+        dev, span = self.cache.data.device, self.cache.S - self.cache.image_size + 1
+        oy = torch.randint(0, span, (B,), generator=self.gen, device=dev, dtype=torch.int32)      # RandomCrop: i (top), then j (left)
+        ox = torch.randint(0, span, (B,), generator=self.gen, device=dev, dtype=torch.int32)
+        flip = (torch.rand((B,), generator=self.gen, device=dev) < 0.5).to(torch.int32)          # RandomHorizontalFlip(p = 0.5)
+        return self.cache.batch(idx, oy, ox, flip)

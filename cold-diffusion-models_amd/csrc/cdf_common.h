@@ -79,7 +79,7 @@ __device__ __forceinline__ void cdf_split_store4(unsigned short* hi, unsigned sh
     uint2 h, l;
     cdf_split4(v[0], v[1], v[2], v[3], h, l);
     *(uint2*)hi = h;
-    *(uint2*)lo = l;
+    if (lo) *(uint2*)lo = l;          // lo == nullptr: hi-only planes (single-pass bf16 operands)
 }
 
 // ---- status codes (returned by every extern "C" entry point) -------------------------

@@ -104,6 +104,6 @@ __device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph
             cdf_st4(dst, v, nval, vec);
         }
         if (a.ys_hi && vec)                                  // the consumer GEMMs' bf16 hi / lo planes of the same values
-            cdf_split_store4(a.ys_hi + opix * a.ld_ys + co, a.ys_lo + opix * a.ld_ys + co, v);
+            cdf_split_store4(a.ys_hi + opix * a.ld_ys + co, a.ys_lo ? a.ys_lo + opix * a.ld_ys + co : nullptr, v);
     }
 }

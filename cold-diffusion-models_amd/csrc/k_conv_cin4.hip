@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) conv_cin4_fwd_kernel(Cin4Args a) {
             for (int e = 0; e < 4; ++e) v[e] = cdf_silu(v[e]);
         }
         if (a.y) *(float4*)(a.y + (long long)m * a.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
-        if (a.ys_hi) cdf_split_store4(a.ys_hi + (long long)m * a.ld_ys + n, a.ys_lo + (long long)m * a.ld_ys + n, v);
+        if (a.ys_hi) cdf_split_store4(a.ys_hi + (long long)m * a.ld_ys + n, a.ys_lo ? a.ys_lo + (long long)m * a.ld_ys + n : nullptr, v);
     }
 }
 
@@ -235,7 +235,7 @@ extern "C" int cdf_conv_cin4_fwd(const float* x, const float* w, int ldw, const 
     CDF_REQUIRE(x && w && (y || y_hi), "cdf_conv_cin4_fwd: null pointer");
     int rc = cin4_check("cdf_conv_cin4_fwd", Cout, k, ldw);
     if (rc) return rc;
-    CDF_REQUIRE((!y || ldy % 4 == 0) && (!pre || ldp % 4 == 0) && (!y_hi || (y_lo && ld_ys % 4 == 0)), "cdf_conv_cin4_fwd: pitches must be multiples of 4");
+    CDF_REQUIRE((!y || ldy % 4 == 0) && (!pre || ldp % 4 == 0) && (!y_hi || ld_ys % 4 == 0), "cdf_conv_cin4_fwd: pitches must be multiples of 4");
     Cin4Args a{x, w, bias, y, pre, (unsigned short*)y_hi, (unsigned short*)y_lo, ldw, ldy, ldp, ld_ys, B, H, W, Cout, k, act};
     return k == 1 ? launch_cin4_fwd<1>(a, CDF_S) : launch_cin4_fwd<3>(a, CDF_S);
 }

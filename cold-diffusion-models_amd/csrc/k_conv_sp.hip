@@ -16,6 +16,7 @@
 #include "cdf_common.h"
 #include "cdf_epilogue.h"
 #include "colddiff.h"
+#include <atomic>
 
 #define CDF_MAX_TAPS 16
 
@@ -126,6 +127,50 @@ __device__ __forceinline__ int cdf_sp_swizzle(int bid, int nblk) {
     const int xcd = bid & 7, idx = bid >> 3;
     const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
+}
+
+// One algorithmic product a * b on the matrix cores.  NS = 3: split precision, al*bh + ah*bl + ah*bh (x = hi + lo bf16 terms,
+// fp32 accumulate); NS = 1: single-pass bf16 operands (the hi planes only; al / bl are never read and their loads fold away).
+template <int NS>
+__device__ __forceinline__ void cdf_mma_sp(f32x16_t& acc, const bf16x8_v& ah, const bf16x8_v& al, const bf16x8_v& bh, const bf16x8_v& bl) {
+    if constexpr (NS == 3) {
+        acc = CDF_MFMA_BF16(al, bh, acc);
+        acc = CDF_MFMA_BF16(ah, bl, acc);
+    }
+    acc = CDF_MFMA_BF16(ah, bh, acc);
+}
+
+// All products of one K chunk (two k16 steps) of a wave tile, TERM-MAJOR: consecutive MFMAs go to different accumulators
+// (al*bh for every tile, then ah*bl, then ah*bh), so no instruction waits for the result of the one just issued; the
+// summation order per accumulator is the same as in cdf_mma_sp.
+#ifndef CDF_TERM_MAJOR
+#define CDF_TERM_MAJOR 1
+#endif
+template <int NS, int MT, int NT>
+__device__ __forceinline__ void cdf_mma_tile(f32x16_t (&acc)[MT][NT], const bf16x8_v (&ah)[2][MT], const bf16x8_v (&al)[2][MT],
+                                             const bf16x8_v (&bh)[2][NT], const bf16x8_v (&bl)[2][NT]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        if constexpr (NS == 3 && CDF_TERM_MAJOR) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = CDF_MFMA_BF16(al[ks][i], bh[ks][j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bl[ks][j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bh[ks][j], acc[i][j]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) cdf_mma_sp<NS>(acc[i][j], ah[ks][i], al[ks][i], bh[ks][j], bl[ks][j]);
+        }
+    }
 }
 
 // 256 threads = 4 waves (2x2), block tile 128x128, wave tile 64x64 = 2x2 MFMA 32x32 tiles.
@@ -502,7 +547,7 @@ __global__ void split_bf16_kernel(const float* x, int ldx, unsigned short* hi, u
         uint2 h, l;
         cdf_split4(v.x, v.y, v.z, v.w, h, l);
         *(uint2*)(hi + r * ldo + c) = h;
-        *(uint2*)(lo + r * ldo + c) = l;
+        if (lo) *(uint2*)(lo + r * ldo + c) = l;
     }
 }
 
@@ -522,13 +567,14 @@ struct SpxArgs {
     int B, H, W, Cin, OH, OW, Cout, QH, QW, os, is;
     int act, mul_mode, accumulate, nphase, vec;
     int taprot;                    // 1: a tile is one image row and the 9 taps are 3 row groups -> per-block row-group order (see kernel)
+    int dephase;                   // 1: the two waves of a SIMD run half a K step apart (one reads fragments / issues DMA while the other multiplies)
     unsigned short* ys_hi;         // nullable: bf16 hi / lo planes of the output (pitch ld_ys), written by the epilogue
     unsigned short* ys_lo;
     int ld_ys;
     SpPhase ph[4];
 };
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC = 512 / (64 * WM * WN)>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC = 512 / (64 * WM * WN), int NS = 3>
 __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxArgs a) {
     // Block tile BM x BN, WM x WN waves of (BM/WM) x (BN/WN), BK = 32, NSTAGE LDS stages.  Two shapes of the template are
     // used: 4 waves (2 x 2) on a 64/128 x 64/128 tile with 2 stages, two blocks per CU; and 8 waves (4 x 2) on a
@@ -651,13 +697,13 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
         for (int p = 0; p < SA; ++p) {
             unsigned short* seg = st + (wave * SA + p) * 16 * RE;
             CDF_GLDS16(cok ? pa_hi[p] : a.zero, seg);
-            CDF_GLDS16(cok ? pa_lo[p] : a.zero, seg + PLANE_A);
+            if constexpr (NS == 3) CDF_GLDS16(cok ? pa_lo[p] : a.zero, seg + PLANE_A);
         }
 #pragma unroll
         for (int p = 0; p < SB; ++p) {
             unsigned short* seg = st + 2 * PLANE_A + (wave * SB + p) * 16 * RE;
             CDF_GLDS16(pb_hi[p], seg);                       // (weights are zero padded along K to the chunk size)
-            CDF_GLDS16(pb_lo[p], seg + PLANE_B);
+            if constexpr (NS == 3) CDF_GLDS16(pb_lo[p], seg + PLANE_B);
         }
 #else
         (void)st; (void)cok;
@@ -695,7 +741,7 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
 
     const int half = lane >> 5, l31 = lane & 31;
     const int sw = (l31 >> 2) & 3;                           // read-side swizzle (tile row offsets are multiples of 32)
-    constexpr int PIECES = 2 * (SA + SB);                    // this wave's DMA instructions per chunk
+    constexpr int PIECES = (NS == 3 ? 2 : 1) * (SA + SB);    // this wave's DMA instructions per chunk
 #if CDF_SPX_PIPE
     // Software pipeline at HALF-chunk granularity (a chunk = two k16 steps).  Fragment set F[h] holds k-step h of a chunk:
     //     top of step it : F[0] = chunk it, k-step 0 (read during the previous step)
@@ -788,11 +834,74 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
     CDF_WAIT_DMA_LEAVE((NSTAGE - 2) * PIECES);               // chunk 0 has landed; later ones may still be in flight
     CDF_LDS_BARRIER();
     int buf = 0;
+    bf16x8_v ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+    // De-phased waves (a.dephase, 8-wave tiles: waves 4..7 share their SIMDs with waves 0..3): a late wave multiplies the
+    // fragments it read in the PREVIOUS step first, then issues its DMA and reads this step's fragments -- while one wave of a
+    // SIMD is stalled issuing global_load_lds / reading LDS the other one feeds the matrix pipe (see conv_igemm_halo_kernel).
+    const bool late = a.dephase != 0 && NW == 8 && wave >= 4;    // (wave-uniform)
+    if (late) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ah[ks][i][e] = 0; al[ks][i][e] = 0; }
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { bh[ks][j][e] = 0; bl[ks][j][e] = 0; }
+        }
+    }
+    auto read_frags = [&](const unsigned short* sa, const unsigned short* sb) {
+        // all fragment reads of the chunk are issued up front: the second k-step's LDS latency hides behind the first
+        // k-step's MFMAs (the registers are there -- LDS, not VGPRs, limits the residency)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int kc = ((ks * 2 + half) ^ sw) * 8;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int off = (wm * (BM / WM) + i * 32 + l31) * RE + kc;
+#if CDF_ABLATE & 8
+                ah[ks][i] = abl_frag; al[ks][i] = abl_frag; (void)off;
+#else
+                ah[ks][i] = *(const bf16x8_v*)(sa + off);
+                if constexpr (NS == 3) al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
+#endif
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int off = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
+#if CDF_ABLATE & 8
+                bh[ks][j] = abl_frag; bl[ks][j] = abl_frag; (void)off;
+#else
+                bh[ks][j] = *(const bf16x8_v*)(sb + off);
+                if constexpr (NS == 3) bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + off);
+#endif
+            }
+        }
+    };
+    auto mma_frags = [&]() {
+#if CDF_ABLATE & 2
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(ah[ks][i]), "v"(al[ks][i]));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(bh[ks][j]), "v"(bl[ks][j]));
+        }
+#else
+        cdf_mma_tile<NS, MT, NT>(acc, ah, al, bh, bl);
+#endif
+    };
 #if CDF_PROFILE
     unsigned long long pt_dma = 0, pt_mma = 0, pt_wait = 0, pt_bar = 0;
     const unsigned long long pt_begin = __builtin_readcyclecounter();
 #endif
     for (int it = 0; it < niter; ++it) {
+        if (late) {
+            mma_frags();
+            CDF_SCHED_FENCE();
+        }
 #if CDF_PROFILE
         const unsigned long long p0 = __builtin_readcyclecounter();
 #endif
@@ -804,53 +913,8 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
         const unsigned short* sa = smem + buf * STAGE;
         const unsigned short* sb = sa + 2 * PLANE_A;
         buf = buf + 1 == NSTAGE ? 0 : buf + 1;
-        // all fragment reads of the chunk are issued up front: the second k-step's LDS latency hides behind the first
-        // k-step's MFMAs (the registers are there -- LDS, not VGPRs, limits the residency)
-        bf16x8_v ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int kc = ((ks * 2 + half) ^ sw) * 8;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int off = (wm * (BM / WM) + i * 32 + l31) * RE + kc;
-#if CDF_ABLATE & 8
-                ah[ks][i] = abl_frag; al[ks][i] = abl_frag; (void)off;
-#else
-                ah[ks][i] = *(const bf16x8_v*)(sa + off);
-                al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
-#endif
-            }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int off = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
-#if CDF_ABLATE & 8
-                bh[ks][j] = abl_frag; bl[ks][j] = abl_frag; (void)off;
-#else
-                bh[ks][j] = *(const bf16x8_v*)(sb + off);
-                bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + off);
-#endif
-            }
-        }
-#if CDF_ABLATE & 2
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(ah[ks][i]), "v"(al[ks][i]));
-#pragma unroll
-            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(bh[ks][j]), "v"(bl[ks][j]));
-        }
-#else
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = CDF_MFMA_BF16(al[ks][i], bh[ks][j], acc[i][j]);
-                    acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bl[ks][j], acc[i][j]);
-                    acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bh[ks][j], acc[i][j]);
-                }
-#endif
+        read_frags(sa, sb);
+        if (!late) mma_frags();
 #if CDF_PROFILE
         asm volatile("s_nop 0" ::"v"(acc[0][0][0]));          // (the last MFMA result is due: the matrix work of the step is done here)
         const unsigned long long p2 = __builtin_readcyclecounter();
@@ -865,6 +929,7 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
         pt_dma += p1 - p0; pt_mma += p2 - p1; pt_wait += p3 - p2; pt_bar += p4 - p3;
 #endif
     }
+    if (late) mma_frags();                                   // the fragments of the last chunk
 #if CDF_PROFILE
     if (lane == 0 && blockIdx.x < 64) {
         unsigned long long* o = cdf_prof + (blockIdx.x * NW + wave) * 6;
@@ -903,7 +968,7 @@ constexpr int cdf_halo_parts(int t, int n, int ta) {
     return c;
 }
 
-template <int W, int BN, int NB, int BM>                                // NB weight stages: NB - 1 tap steps requested ahead; BM = 128 or 256 pixels
+template <int W, int BN, int NB, int BM, int NS = 3>                    // NB weight stages: NB - 1 tap steps requested ahead; BM = 128 or 256 pixels
 __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
     constexpr int WM = 4, WN = 2, NW = 8, BK = 32, RE = 32, MT = BM / WM / 32;
     constexpr int TH = BM / W, HW2 = W + 2, HR = (TH + 2) * HW2;          // halo rows (pixels)
@@ -967,7 +1032,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
     auto fetch_a = [&](int q, int buf) {                     // segment a_seg[q] of the chunk the pointers stand at -> halo buffer buf
         unsigned short* seg = abuf0 + buf * ABUF + a_seg[q] * 16 * RE;
         CDF_GLDS16(pa_hi[q], seg);
-        CDF_GLDS16(pa_lo[q], seg + PLANE_A);
+        if constexpr (NS == 3) CDF_GLDS16(pa_lo[q], seg + PLANE_A);
     };
     auto advance_a = [&]() {
 #pragma unroll
@@ -985,10 +1050,11 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
             const int seg = BN == 64 ? (wave & 3) : wave * SB + p;
             const size_t woff = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)b_row[p]) * (unsigned)a.ldk + (unsigned)(c * BK + q8);
             CDF_GLDS16(a.w_hi + woff, st + seg * 16 * RE);
-            CDF_GLDS16(a.w_lo + woff, st + PLANE_B + seg * 16 * RE);
+            if constexpr (NS == 3) CDF_GLDS16(a.w_lo + woff, st + PLANE_B + seg * 16 * RE);
         }
     };
-    constexpr int PB = 2 * SBI, PA = 2;                      // DMA instructions per wave: one B step, one A segment
+    constexpr int NPL = NS == 3 ? 2 : 1;                     // operand planes in flight (hi [, lo])
+    constexpr int PB = NPL * SBI, PA = NPL;                  // DMA instructions per wave: one B step, one A segment
 
     f32x16_t acc[MT][NT];
 #pragma unroll
@@ -1099,6 +1165,22 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
   } else {                                                 // (3 weight stages: W = 128 with BN = 128)
     CDF_WAIT_DMA_LEAVE((NB - 2) * PB);                       // the halo and the weights of step 0 have landed
     CDF_LDS_BARRIER();
+    bf16x8_v ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+    const bool late = a.dephase != 0 && wave >= NW / 2;      // (wave-uniform)
+    if (late) {                                              // first step of a late wave: multiplies zeros
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ah[ks][i][e] = 0; al[ks][i][e] = 0; }
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { bh[ks][j][e] = 0; bl[ks][j][e] = 0; }
+        }
+    }
+    auto mma_frags = [&]() { cdf_mma_tile<NS, MT, NT>(acc, ah, al, bh, bl); };
     for (int c = 0; c < nchunks; ++c) {
         const unsigned short* sa = abuf0 + (c & 1) * ABUF;
         // (during the last chunk its own halo is requested again, into the idle buffer: every step issues the same
@@ -1111,34 +1193,35 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
             const int tapoff = (int)ph.dy[t] * HW2 + (int)ph.dx[t];
             const unsigned short* sb = bst0 + rd * BSTAGE;
             rd = rd + 1 == NB ? 0 : rd + 1;
-            bf16x8_v ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+            auto read_frags = [&]() {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+                for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int row = row0[i] + tapoff;
-                    const int off = row * RE + ((ks * 2 + half) ^ ((row >> 2) & 3)) * 8;
-                    ah[ks][i] = *(const bf16x8_v*)(sa + off);
-                    al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
-                }
-                const int kc = ((ks * 2 + half) ^ swb) * 8;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int offb = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
-                    bh[ks][j] = *(const bf16x8_v*)(sb + offb);
-                    bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + offb);
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
+                    for (int i = 0; i < MT; ++i) {
+                        const int row = row0[i] + tapoff;
+                        const int off = row * RE + ((ks * 2 + half) ^ ((row >> 2) & 3)) * 8;
+                        ah[ks][i] = *(const bf16x8_v*)(sa + off);
+                        if constexpr (NS == 3) al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
+                    }
+                    const int kc = ((ks * 2 + half) ^ swb) * 8;
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        acc[i][j] = CDF_MFMA_BF16(al[ks][i], bh[ks][j], acc[i][j]);
-                        acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bl[ks][j], acc[i][j]);
-                        acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bh[ks][j], acc[i][j]);
+                        const int offb = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
+                        bh[ks][j] = *(const bf16x8_v*)(sb + offb);
+                        if constexpr (NS == 3) bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + offb);
                     }
+                }
+            };
+            // De-phased waves (a.dephase): the block's waves 4..7 share their SIMDs with waves 0..3 and the step barrier keeps all
+            // eight in lockstep, so fragment reads (LDS) and MFMAs (matrix pipe) of a SIMD's two waves used to happen one after the
+            // other, never together.  Waves 4..7 therefore multiply the fragments they read in the PREVIOUS step first and read this
+            // step's fragments afterwards: while one wave of a SIMD multiplies, the other one reads.
+            if (late) {
+                mma_frags();
+                CDF_SCHED_FENCE();                           // (the reads overwrite the fragments just multiplied: hoisting them doubles the live set)
+            }
+            read_frags();
+            if (!late) mma_frags();
             // the weights of step + 1 (requested NB - 2 steps ago) have landed -- and with them, in order, every halo segment
             // requested before them; still in flight: the weight requests of the last NB - 2 steps and the halo segments
             // requested in those steps (a compile-time count per tap index)
@@ -1153,6 +1236,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
             CDF_LDS_BARRIER();
         }
     }
+    if (late) mma_frags();                                   // the fragments of the last step
   }
     CDF_WAIT_DMA_LEAVE(0);                                   // the tail requests (never read) must not land in the epilogue tile
     CDF_LDS_BARRIER();
@@ -1175,7 +1259,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
 // generic 256 x 128 kernel; at 64 pixels the halo kernel's 256-pixel tile stays ahead (0.240 vs 0.252 ms).  Used for the > 64-channel
 // outputs at 128-pixel width (bits 32 / 64 of cdf_conv_gemm_bf16x_halo).
 // ================================================================================================
-template <int W, int BN>
+template <int W, int BN, int NS = 3>
 __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
     constexpr int BM = 256, WM = 4, WN = 2, NW = 8, BK = 32, RE = 32, MT = BM / WM / 32, NB = 4;
     constexpr int TH = BM / W, HW2 = W + 2, RH = TH * HW2;                 // rows of one (chunk, dy) image
@@ -1233,7 +1317,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
             const size_t off = ((size_t)((img * a.H + (ok ? y : 0)) * W + (ok ? a_x[q] : 0))) * (unsigned)a.ldx + (unsigned)(c * BK + q8);
             unsigned short* seg = abuf0 + buf * ABUF + a_seg[q] * 16 * RE;
             CDF_GLDS16(ok ? a.x_hi + off : a.zero, seg);
-            CDF_GLDS16(ok ? a.x_lo + off : a.zero, seg + PLANE_A);
+            if constexpr (NS == 3) CDF_GLDS16(ok ? a.x_lo + off : a.zero, seg + PLANE_A);
         }
     };
     auto fetch_b = [&](int c, int t, int stage) {
@@ -1245,10 +1329,11 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
             const int seg = BN == 64 ? (wave & 3) : wave * SB + p;
             const size_t woff = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)b_row[p]) * (unsigned)a.ldk + (unsigned)(c * BK + q8);
             CDF_GLDS16(a.w_hi + woff, st + seg * 16 * RE);
-            CDF_GLDS16(a.w_lo + woff, st + PLANE_B + seg * 16 * RE);
+            if constexpr (NS == 3) CDF_GLDS16(a.w_lo + woff, st + PLANE_B + seg * 16 * RE);
         }
     };
-    constexpr int PB = 2 * SBI, PAG = 2 * TAG;               // DMA instructions per wave: one weight step, one group of rows
+    constexpr int NPL = NS == 3 ? 2 : 1;
+    constexpr int PB = NPL * SBI, PAG = NPL * TAG;           // DMA instructions per wave: one weight step, one group of rows
 
     f32x16_t acc[MT][NT];
 #pragma unroll
@@ -1274,6 +1359,22 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
     for (int u = 0; u < NB - 1; ++u) fetch_b(0, u, u);
     CDF_WAIT_DMA_LEAVE((NB - 2) * PB);
     CDF_LDS_BARRIER();
+    bf16x8_v ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+    const bool late = a.dephase != 0 && wave >= NW / 2;      // (wave-uniform)
+    if (late) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ah[ks][i][e] = 0; al[ks][i][e] = 0; }
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { bh[ks][j][e] = 0; bl[ks][j][e] = 0; }
+        }
+    }
+    auto mma_frags = [&]() { cdf_mma_tile<NS, MT, NT>(acc, ah, al, bh, bl); };
     int rd = 0, par = 0;                                     // weight stage / row buffer of the current step
     for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
@@ -1285,34 +1386,31 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
             const unsigned short* sb = bst0 + rd * BSTAGE;
             rd = rd + 1 == NB ? 0 : rd + 1;
             const int dx = ph.dx[t];
-            bf16x8_v ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+            auto read_frags = [&]() {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+                for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int row = row0[i] + dx;
-                    const int off = row * RE + ((ks * 2 + half) ^ ((row >> 2) & 3)) * 8;
-                    ah[ks][i] = *(const bf16x8_v*)(sa + off);
-                    al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
-                }
-                const int kc = ((ks * 2 + half) ^ swb) * 8;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int offb = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
-                    bh[ks][j] = *(const bf16x8_v*)(sb + offb);
-                    bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + offb);
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
+                    for (int i = 0; i < MT; ++i) {
+                        const int row = row0[i] + dx;
+                        const int off = row * RE + ((ks * 2 + half) ^ ((row >> 2) & 3)) * 8;
+                        ah[ks][i] = *(const bf16x8_v*)(sa + off);
+                        if constexpr (NS == 3) al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
+                    }
+                    const int kc = ((ks * 2 + half) ^ swb) * 8;
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        acc[i][j] = CDF_MFMA_BF16(al[ks][i], bh[ks][j], acc[i][j]);
-                        acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bl[ks][j], acc[i][j]);
-                        acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bh[ks][j], acc[i][j]);
+                        const int offb = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
+                        bh[ks][j] = *(const bf16x8_v*)(sb + offb);
+                        if constexpr (NS == 3) bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + offb);
                     }
+                }
+            };
+            if (late) {                                      // de-phased waves: see conv_igemm_halo_kernel
+                mma_frags();
+                CDF_SCHED_FENCE();                           // (the reads overwrite the fragments just multiplied: hoisting them doubles the live set)
+            }
+            read_frags();
+            if (!late) mma_frags();
             // the weights of step + 1 (requested 2 steps ago, AFTER that step's row requests) have landed; still in flight: the
             // requests of the last two steps -- two weight steps, plus one group of rows if one of them was a group's first step
             if (i3 <= 1)
@@ -1323,6 +1421,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
             if (i3 == 2) par ^= 1;
         }
     }
+    if (late) mma_frags();
     CDF_WAIT_DMA_LEAVE(0);
     CDF_LDS_BARRIER();
 
@@ -1346,11 +1445,17 @@ struct SpxWgradArgs {
     signed char day[CDF_MAX_TAPS], dax[CDF_MAX_TAPS], dby[CDF_MAX_TAPS], dbx[CDF_MAX_TAPS];
 };
 
+template <int NS>
 __device__ __forceinline__ void cdf_bf16x8_accum(float* acc8, const u32x4_v& h, const u32x4_v& l) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        acc8[2 * e] += __uint_as_float(h[e] << 16) + __uint_as_float(l[e] << 16);
-        acc8[2 * e + 1] += __uint_as_float(h[e] & 0xFFFF0000u) + __uint_as_float(l[e] & 0xFFFF0000u);
+        if constexpr (NS == 3) {
+            acc8[2 * e] += __uint_as_float(h[e] << 16) + __uint_as_float(l[e] << 16);
+            acc8[2 * e + 1] += __uint_as_float(h[e] & 0xFFFF0000u) + __uint_as_float(l[e] & 0xFFFF0000u);
+        } else {
+            acc8[2 * e] += __uint_as_float(h[e] << 16);
+            acc8[2 * e + 1] += __uint_as_float(h[e] & 0xFFFF0000u);
+        }
     }
 }
 
@@ -1376,7 +1481,7 @@ struct SpxWgradSlot {                  // one operand's share of a thread's load
 // STACK2 (TA = 128 with CA <= 64): a 64-channel A operand would fill only half of the 128 MFMA rows, so the tile takes
 // TWO taps -- rows 0..63 = tap 2*blockIdx.y, rows 64..127 = tap 2*blockIdx.y + 1 (all-zero when past the last tap).  The B
 // rows are shared: valid when every tap reads B at the same offset (plain convolutions; checked by the host).
-template <int TA, int TB, bool STACK2 = false>
+template <int TA, int TB, bool STACK2 = false, int NS = 3>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) {
     using SA = SpxWgradSlot<TA>;
     using SB = SpxWgradSlot<TB>;
@@ -1458,7 +1563,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
             const unsigned pix = ((unsigned)qa[p][2] * (unsigned)a.HA + ay) * (unsigned)a.WA + ax;
             const size_t off = (size_t)pix * (unsigned)a.lda + (unsigned)ca;
             rah[p] = *(const u32x4_v*)(ok ? a.a_hi + off : a.zero);
-            ral[p] = *(const u32x4_v*)(ok ? a.a_lo + off : a.zero);
+            if constexpr (NS == 3) ral[p] = *(const u32x4_v*)(ok ? a.a_lo + off : a.zero);
             advance(qa[p]);
         }
 #pragma unroll
@@ -1469,7 +1574,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
             const unsigned pix = ((unsigned)qb[p][2] * (unsigned)a.HB + by) * (unsigned)a.WB + bx;
             const size_t off = (size_t)pix * (unsigned)a.ldb + (unsigned)cb;
             rbh[p] = *(const u32x4_v*)(ok ? a.b_hi + off : a.zero);
-            rbl[p] = *(const u32x4_v*)(ok ? a.b_lo + off : a.zero);
+            if constexpr (NS == 3) rbl[p] = *(const u32x4_v*)(ok ? a.b_lo + off : a.zero);
             advance(qb[p]);
         }
     };
@@ -1479,14 +1584,14 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
         for (int p = 0; p < SA::PASS; ++p) {
             const int so = (tid / SA::VPR + SA::PPP * p) * SA::PITCH + (tid % SA::VPR) * 8;
             *(u32x4_v*)(st + so) = rah[p];
-            *(u32x4_v*)(st + PLANE_A + so) = ral[p];
+            if constexpr (NS == 3) *(u32x4_v*)(st + PLANE_A + so) = ral[p];
         }
 #pragma unroll
         for (int p = 0; p < SB::PASS; ++p) {
             const int so = (tid / SB::VPR + SB::PPP * p) * SB::PITCH + (tid % SB::VPR) * 8;
             *(u32x4_v*)(st + 2 * PLANE_A + so) = rbh[p];
-            *(u32x4_v*)(st + 2 * PLANE_A + PLANE_B + so) = rbl[p];
-            if (do_bsum) cdf_bf16x8_accum(bs_acc[p], rbh[p], rbl[p]);     // here the loads have landed anyway
+            if constexpr (NS == 3) *(u32x4_v*)(st + 2 * PLANE_A + PLANE_B + so) = rbl[p];
+            if (do_bsum) cdf_bf16x8_accum<NS>(bs_acc[p], rbh[p], rbl[p]);     // here the loads have landed anyway
         }
     };
 
@@ -1522,9 +1627,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
 #if CDF_WGRAD_TR
                 const unsigned short* pa = sa + tra + ks * 16 * SA::PITCH + i * 32;
                 const bf16x4_v h0 = cdf_lds_read_tr16(pa), h1 = cdf_lds_read_tr16(pa + 4 * SA::PITCH);
-                const bf16x4_v l0 = cdf_lds_read_tr16(pa + PLANE_A), l1 = cdf_lds_read_tr16(pa + PLANE_A + 4 * SA::PITCH);
                 ah[i] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-                al[i] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                if constexpr (NS == 3) {
+                    const bf16x4_v l0 = cdf_lds_read_tr16(pa + PLANE_A), l1 = cdf_lds_read_tr16(pa + PLANE_A + 4 * SA::PITCH);
+                    al[i] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
 #else
                 const unsigned short* pa = sa + (ks * 16 + half * 8) * SA::PITCH + wm * (TA / 2) + i * 32 + l31;
 #pragma unroll
@@ -1539,9 +1646,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
 #if CDF_WGRAD_TR
                 const unsigned short* pb = sb + trb + ks * 16 * SB::PITCH + j * 32;
                 const bf16x4_v h0 = cdf_lds_read_tr16(pb), h1 = cdf_lds_read_tr16(pb + 4 * SB::PITCH);
-                const bf16x4_v l0 = cdf_lds_read_tr16(pb + PLANE_B), l1 = cdf_lds_read_tr16(pb + PLANE_B + 4 * SB::PITCH);
                 bh[j] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-                bl[j] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                if constexpr (NS == 3) {
+                    const bf16x4_v l0 = cdf_lds_read_tr16(pb + PLANE_B), l1 = cdf_lds_read_tr16(pb + PLANE_B + 4 * SB::PITCH);
+                    bl[j] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
 #else
                 const unsigned short* pb = sb + (ks * 16 + half * 8) * SB::PITCH + wn * (TB / 2) + j * 32 + l31;
 #pragma unroll
@@ -1555,9 +1664,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = CDF_MFMA_BF16(al[i], bh[j], acc[i][j]);
-                    acc[i][j] = CDF_MFMA_BF16(ah[i], bl[j], acc[i][j]);
-                    acc[i][j] = CDF_MFMA_BF16(ah[i], bh[j], acc[i][j]);
+                    cdf_mma_sp<NS>(acc[i][j], ah[i], al[i], bh[j], bl[j]);
                 }
         }
         if (it + 1 < niter) store_lds(buf ^ 1);
@@ -1622,7 +1729,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
 // linear in the chunk index (no per-tap decode); the row / image borders are a per-lane mask.  8 waves (32 x TB/WB tiles, three
 // accumulator sets), one block per CU; grid (tiles, 3 tap rows, splits) in the XCD-aware order of cdf_wgrad_block.
 // ================================================================================================
-template <int TA, int TB>
+template <int TA, int TB, int NS = 3>
 __global__ void __launch_bounds__(512, 1) conv_wgrad_row3_kernel(SpxWgradArgs a) {
     constexpr int BK = 32, NTHR = 512;
     constexpr int WA_ = TA / 32, WB_ = 8 / WA_, TNW = TB / WB_, NT = TNW / 32;
@@ -1682,13 +1789,13 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_row3_kernel(SpxWgradArgs a)
             const long long pix = (long long)m0 + (a_sub[p] + dy) * W + a_xr[p] - 1;
             const size_t off = (size_t)(ok ? pix : 0) * (unsigned)a.lda + (unsigned)ca;
             rah[p] = *(const u32x4_v*)(ok ? a.a_hi + off : a.zero);
-            ral[p] = *(const u32x4_v*)(ok ? a.a_lo + off : a.zero);
+            if constexpr (NS == 3) ral[p] = *(const u32x4_v*)(ok ? a.a_lo + off : a.zero);
         }
         {
             const bool ok = b_lane && cb < a.CB;
             const size_t off = (size_t)(m0 + (b_lane ? pb : 0)) * (unsigned)a.ldb + (unsigned)cb;
             rbh = *(const u32x4_v*)(ok ? a.b_hi + off : a.zero);
-            rbl = *(const u32x4_v*)(ok ? a.b_lo + off : a.zero);
+            if constexpr (NS == 3) rbl = *(const u32x4_v*)(ok ? a.b_lo + off : a.zero);
         }
         // next chunk (uniform scalars, selects only): 32 pixels further -- inside the row, to the next row(s), to the next image
         const int nx = x0 + (W < 32 ? 0 : 32);
@@ -1704,14 +1811,14 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_row3_kernel(SpxWgradArgs a)
             if (a_r[p] < NRAP) {
                 const int so = a_r[p] * PITCH_A + (tid % VPR_A) * 8;
                 *(u32x4_v*)(st + so) = rah[p];
-                *(u32x4_v*)(st + PLANE_A + so) = ral[p];
+                if constexpr (NS == 3) *(u32x4_v*)(st + PLANE_A + so) = ral[p];
             }
         }
         if (b_lane) {
             const int so = pb * PITCH_B + (tid % VPR_B) * 8;
             *(u32x4_v*)(st + 2 * PLANE_A + so) = rbh;
-            *(u32x4_v*)(st + 2 * PLANE_A + PLANE_B + so) = rbl;
-            if (do_bsum) cdf_bf16x8_accum(bs_acc, rbh, rbl);
+            if constexpr (NS == 3) *(u32x4_v*)(st + 2 * PLANE_A + PLANE_B + so) = rbl;
+            if (do_bsum) cdf_bf16x8_accum<NS>(bs_acc, rbh, rbl);
         }
     };
 
@@ -1750,22 +1857,25 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_row3_kernel(SpxWgradArgs a)
             for (int j = 0; j < NT; ++j) {
                 const unsigned short* q = sb + trb + ks * 16 * PITCH_B + j * 32;
                 const bf16x4_v h0 = cdf_lds_read_tr16(q), h1 = cdf_lds_read_tr16(q + 4 * PITCH_B);
-                const bf16x4_v l0 = cdf_lds_read_tr16(q + PLANE_B), l1 = cdf_lds_read_tr16(q + PLANE_B + 4 * PITCH_B);
                 bh[j] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-                bl[j] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                if constexpr (NS == 3) {
+                    const bf16x4_v l0 = cdf_lds_read_tr16(q + PLANE_B), l1 = cdf_lds_read_tr16(q + PLANE_B + 4 * PITCH_B);
+                    bl[j] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const unsigned short* q = sa + tra[i] + ks * (16 * PITCH_A + ks_skip);
                 const bf16x4_v h0 = cdf_lds_read_tr16(q), h1 = cdf_lds_read_tr16(q + 4 * PITCH_A);
-                const bf16x4_v l0 = cdf_lds_read_tr16(q + PLANE_A), l1 = cdf_lds_read_tr16(q + PLANE_A + 4 * PITCH_A);
                 const bf16x8_v ah = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-                const bf16x8_v al = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                bf16x8_v al;
+                if constexpr (NS == 3) {
+                    const bf16x4_v l0 = cdf_lds_read_tr16(q + PLANE_A), l1 = cdf_lds_read_tr16(q + PLANE_A + 4 * PITCH_A);
+                    al = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = CDF_MFMA_BF16(al, bh[j], acc[i][j]);
-                    acc[i][j] = CDF_MFMA_BF16(ah, bl[j], acc[i][j]);
-                    acc[i][j] = CDF_MFMA_BF16(ah, bh[j], acc[i][j]);
+                    cdf_mma_sp<NS>(acc[i][j], ah, al, bh[j], bl[j]);
                 }
             }
         }
@@ -1829,14 +1939,14 @@ __global__ void pack_weight_bf16_kernel(const float* src, unsigned short* dst_hi
         const float v = c < C ? src[c * s_c + r * s_r + t * s_t] : 0.f;
         const unsigned h = cdf_f2bf(v);
         dst_hi[i] = (unsigned short)h;
-        dst_lo[i] = (unsigned short)cdf_f2bf(v - cdf_bf2f(h));
+        if (dst_lo) dst_lo[i] = (unsigned short)cdf_f2bf(v - cdf_bf2f(h));
     }
 }
 
 // ================================================================================================
 extern "C" int cdf_pack_weight_bf16(const float* src, void* dst_hi, void* dst_lo, int T, int R, int C, int ldc, long long s_t,
                                     long long s_r, long long s_c, void* stream) {
-    CDF_REQUIRE(src && dst_hi && dst_lo && T > 0 && R > 0 && C > 0 && ldc >= C && ldc % 32 == 0, "cdf_pack_weight_bf16: bad args (ldc must be a multiple of 32)");
+    CDF_REQUIRE(src && dst_hi && T > 0 && R > 0 && C > 0 && ldc >= C && ldc % 32 == 0, "cdf_pack_weight_bf16: bad args (ldc must be a multiple of 32)");
     long long g = ((long long)T * R * ldc + 255) / 256;
     if (g > 4096) g = 4096;
     CDF_LAUNCH(pack_weight_bf16_kernel, dim3((int)g), dim3(256), 0, CDF_S, src, (unsigned short*)dst_hi, (unsigned short*)dst_lo, T, R, C, ldc, s_t, s_r, s_c);
@@ -1892,7 +2002,7 @@ extern "C" int cdf_conv_gemm_bf16(const float* x, int ldx, const void* w_hi, con
     return cdf_check_launch("conv_igemm_sp");
 }
 
-static int g_wgrad_swizzle = 1;                // tuning / test hook (cdf_conv_wgrad_bf16x_swizzle)
+static std::atomic<int> g_wgrad_swizzle{1};                // tuning / test hook (cdf_conv_wgrad_bf16x_swizzle)
 
 extern "C" int cdf_conv_wgrad_bf16x_swizzle(int enable) {
     g_wgrad_swizzle = enable ? 1 : 0;
@@ -1932,7 +2042,7 @@ extern "C" int cdf_conv_wgrad_bf16(const float* xa, int lda, const float* xb, in
 
 // ---- pre-split operand entry points ---------------------------------------------------------------------
 extern "C" int cdf_split_bf16(const float* x, int ldx, void* hi, void* lo, int ldo, long long rows, int C, void* stream) {
-    CDF_REQUIRE(x && hi && lo && rows > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldo % 8 == 0 && ldo >= C, "cdf_split_bf16: bad args (C %% 4, ldo %% 8)");
+    CDF_REQUIRE(x && hi && rows > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldo % 8 == 0 && ldo >= C, "cdf_split_bf16: bad args (C %% 4, ldo %% 8)");
     long long g = (rows * (C / 4) + 255) / 256;
     if (g > 8192) g = 8192;
     CDF_LAUNCH(split_bf16_kernel, dim3((int)g), dim3(256), 0, CDF_S, x, ldx, (unsigned short*)hi, (unsigned short*)lo, ldo, rows, C / 4);
@@ -1953,10 +2063,17 @@ static int fill_phases(SpPhase* ph, int nphase, const int* pd, const char* who) 
     return CDF_OK;
 }
 
-static int g_spx_bm = 0, g_spx_bn = 0;     // 0 = automatic
-static int g_spx_waves = 0;                // 0 = automatic; 4 / 8 = waves of the 128 x 128 tile
-static int g_spx_max_bm = 0;               // 0 / 256 = no cap; 128 = the automatic choice never takes the 256-row tile
-static int g_spx_taprot = 1;               // per-block row-group order of 3 x 3 taps when a tile is one image row
+static std::atomic<int> g_spx_bm{0}, g_spx_bn{0};     // 0 = automatic
+static std::atomic<int> g_spx_waves{0};                // 0 = automatic; 4 / 8 = waves of the 128 x 128 tile
+static std::atomic<int> g_spx_max_bm{0};               // 0 / 256 = no cap; 128 = the automatic choice never takes the 256-row tile
+static std::atomic<int> g_spx_taprot{1};               // per-block row-group order of 3 x 3 taps when a tile is one image row
+
+static std::atomic<int> g_spx_dephase{1};              // the two waves of a SIMD run half a K step apart in the 8-wave tiles (tuning / test hook)
+
+extern "C" int cdf_conv_gemm_bf16x_dephase(int enable) {
+    g_spx_dephase = enable ? 1 : 0;
+    return 0;
+}
 
 extern "C" int cdf_conv_gemm_bf16x_taprot(int enable) {
     g_spx_taprot = enable ? 1 : 0;
@@ -1982,7 +2099,7 @@ extern "C" int cdf_conv_gemm_bf16x_tile(int bm, int bn) {
     return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC = 512 / (64 * WM * WN)>
+template <int NS, int BM, int BN, int WM, int WN, int NSTAGE, int OCC = 512 / (64 * WM * WN)>
 static int launch_igemm_spx(const SpxArgs& a, int M, hipStream_t s) {
     constexpr size_t stages = (size_t)NSTAGE * 2 * (BM + BN) * 32 * sizeof(unsigned short) + (CDF_MAX_TAPS + 1) * sizeof(int);
     constexpr size_t epi = (size_t)BM * (BN + 8) * sizeof(float);
@@ -1992,23 +2109,23 @@ static int launch_igemm_spx(const SpxArgs& a, int M, hipStream_t s) {
 #ifndef CDF_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_spx_kernel<BM, BN, WM, WN, NSTAGE, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_spx_kernel<BM, BN, WM, WN, NSTAGE, OCC, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
 #endif
     const int tiles = cdf_cdiv(M, BM) * cdf_cdiv(a.Cout, BN);
-    CDF_LAUNCH((conv_igemm_spx_kernel<BM, BN, WM, WN, NSTAGE, OCC>), dim3(tiles, a.nphase), dim3(64 * WM * WN), lds, s, a);
+    CDF_LAUNCH((conv_igemm_spx_kernel<BM, BN, WM, WN, NSTAGE, OCC, NS>), dim3(tiles, a.nphase), dim3(64 * WM * WN), lds, s, a);
     return cdf_check_launch("conv_igemm_spx");
 }
 
-static int g_spx_halo = 47;                    // 3 x 3 stride-1 layers: input tile resident in LDS; bit mask over the image width
+static std::atomic<int> g_spx_halo{47};                    // 3 x 3 stride-1 layers: input tile resident in LDS; bit mask over the image width
                                                // 16 (1), 32 (2), 64 (4), 128 (8); 16: at width 128 also for 128-wide N tiles (measured
                                                // level with the generic kernel there: only 3 weight stages fit next to 2 x 51 KB of halo;
                                                // with 64-wide N tiles a 256-pixel tile fits and wins); 32: the row-halo kernel for the
                                                // > 64-channel outputs at width 128; 64: the row-halo kernel wherever it applies
                                                // (tuning / test hook)
-static long long g_spx_halo_min_tiles = 1;
-static int g_spx_halo_bm = 0;                  // 0 = automatic, 128 / 256 = forced tile height of the halo kernel
+static std::atomic<long long> g_spx_halo_min_tiles{1};
+static std::atomic<int> g_spx_halo_bm{0};                  // 0 = automatic, 128 / 256 = forced tile height of the halo kernel
 
 extern "C" int cdf_conv_gemm_bf16x_halo_bm(int bm) {
     CDF_REQUIRE(bm == 0 || bm == 128 || bm == 256, "cdf_conv_gemm_bf16x_halo_bm: 0, 128 or 256");
@@ -2022,7 +2139,7 @@ extern "C" int cdf_conv_gemm_bf16x_halo(int enable, int min_tiles) {
     return 0;
 }
 
-template <int W, int BN, int BM>
+template <int NS, int W, int BN, int BM>
 static int launch_igemm_halo(const SpxArgs& a, int M, hipStream_t s) {
     // weight stages: as many as fit next to the two halo buffers
     constexpr int TH = BM / W, HR = (TH + 2) * (W + 2), HRP = (HR + 15) / 16 * 16;
@@ -2037,16 +2154,16 @@ static int launch_igemm_halo(const SpxArgs& a, int M, hipStream_t s) {
 #ifndef CDF_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_halo_kernel<W, BN, NB, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_halo_kernel<W, BN, NB, BM, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
 #endif
     const int tiles = (M / BM) * cdf_cdiv(a.Cout, BN);
-    CDF_LAUNCH((conv_igemm_halo_kernel<W, BN, NB, BM>), dim3(tiles), dim3(512), lds, s, a);
+    CDF_LAUNCH((conv_igemm_halo_kernel<W, BN, NB, BM, NS>), dim3(tiles), dim3(512), lds, s, a);
     return cdf_check_launch("conv_igemm_halo");
 }
 
-template <int W, int BN>
+template <int NS, int W, int BN>
 static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s) {
     constexpr int TH = 256 / W, RH = TH * (W + 2), HRP = (RH + 15) / 16 * 16;
     constexpr size_t stages = (size_t)2 * 2 * HRP * 64 + (size_t)4 * 2 * BN * 64;
@@ -2056,39 +2173,17 @@ static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s) {
 #ifndef CDF_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_kernel<W, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_kernel<W, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
 #endif
     const int tiles = (M / 256) * cdf_cdiv(a.Cout, BN);
-    CDF_LAUNCH((conv_igemm_rowhalo_kernel<W, BN>), dim3(tiles), dim3(512), lds, s, a);
+    CDF_LAUNCH((conv_igemm_rowhalo_kernel<W, BN, NS>), dim3(tiles), dim3(512), lds, s, a);
     return cdf_check_launch("conv_igemm_rowhalo");
 }
 
-extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo,
-                                   int ldk, float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW,
-                                   int os, int is, int nphase, const int* phase_desc, const float* bias, const float* sbias,
-                                   int ld_sbias, const float* res, int ldr, float* pre, int ldp, const float* mul, int ldm, int act,
-                                   int mul_mode, int accumulate, void* y_hi, void* y_lo, int ld_ys, void* stream) {
-    CDF_REQUIRE(x_hi && x_lo && zero && w_hi && w_lo && (y || (y_hi && !accumulate)), "cdf_conv_gemm_bf16x: null pointer");
-    CDF_REQUIRE((!y_hi && !y_lo) || (y_hi && y_lo && ld_ys % 4 == 0 && ld_ys >= Cout && Cout % 4 == 0 && ((((uintptr_t)y_hi) | ((uintptr_t)y_lo)) & 7) == 0),
-                "cdf_conv_gemm_bf16x: split output planes need Cout %% 4 == 0, ld_ys %% 4 == 0, 8-byte alignment");
-    CDF_REQUIRE(((((uintptr_t)x_hi) | ((uintptr_t)x_lo) | ((uintptr_t)zero) | ((uintptr_t)w_hi) | ((uintptr_t)w_lo)) & 15) == 0, "cdf_conv_gemm_bf16x: operands must be 16B aligned");
-    CDF_REQUIRE(ldx % 8 == 0 && Cin % 8 == 0 && ldx >= Cin && ldk % 32 == 0 && ldk >= Cin, "cdf_conv_gemm_bf16x: Cin and pitches must be multiples of 8 (ldk of 32)");
-    CDF_REQUIRE(nphase >= 1 && nphase <= 4 && phase_desc && (!y || ldy >= Cout), "cdf_conv_gemm_bf16x: bad geometry");
-    CDF_REQUIRE(!mul_mode || mul, "cdf_conv_gemm_bf16x: mul_mode without mul tensor");
-    SpxArgs a;
-    a.x_hi = (const unsigned short*)x_hi; a.x_lo = (const unsigned short*)x_lo; a.zero = (const unsigned short*)zero;
-    a.w_hi = (const unsigned short*)w_hi; a.w_lo = (const unsigned short*)w_lo; a.y = y;
-    a.bias = bias; a.sbias = sbias; a.res = res; a.pre = pre; a.mul = mul;
-    a.ldx = ldx; a.ldk = ldk; a.ldy = ldy; a.ld_sbias = ld_sbias; a.ldr = ldr; a.ldp = ldp; a.ldm = ldm;
-    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.QH = QH; a.QW = QW; a.os = os; a.is = is;
-    a.act = act; a.mul_mode = mul_mode; a.accumulate = accumulate; a.nphase = nphase;
-    a.vec = cdf_epi_vec_ok(Cout, y, ldy, bias, sbias, ld_sbias, res, ldr, pre, ldp, mul, ldm);
-    a.ys_hi = (unsigned short*)y_hi; a.ys_lo = (unsigned short*)y_lo; a.ld_ys = ld_ys;
-    CDF_REQUIRE(!y_hi || a.vec, "cdf_conv_gemm_bf16x: split output planes need the vectorised epilogue (aligned pointers, pitches %% 4)");
-    int rc = fill_phases(a.ph, nphase, phase_desc, "cdf_conv_gemm_bf16x");
-    if (rc) return rc;
+template <int NS>
+static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cout, int QH, int QW, int os, int is, int nphase, hipStream_t s) {
     // Tile choice: 64-wide N for Cout <= 64 (no half-empty MFMA columns); 64-row M tiles when 128-row tiles would
     // leave most of the 256 CUs x 2 resident blocks idle (deep, small-image layers: M = 8192 at 16 x 16); the 8-wave
     // 256 x 128 tile (3 stages, one block per CU) when it still gives every CU at least ~2 tiles.
@@ -2115,6 +2210,7 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
     // choice is not bent towards one-row tiles)
     const int bm = m256 ? 256 : (m64 ? 64 : 128);
     a.taprot = rot_ok && QW == bm;
+    a.dephase = g_spx_dephase;
     // 3 x 3 stride-1 layers whose rows tile into 128-pixel strips: input tile resident in LDS (conv_igemm_halo_kernel)
     if (g_spx_halo && is3x3 && !g_spx_bm && QW == W && QH == H && Cin % 32 == 0 && Cin >= 64 && M % 128 == 0) {
         int dxs = 0;
@@ -2127,7 +2223,7 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
         if (dx_ok && M % 256 == 0 && ((g_spx_halo & 64) || ((g_spx_halo & 32) && W == 128 && !n64 && (long long)(M / 256) * cdf_cdiv(Cout, 128) >= 256))) {
 #define CDF_ROWHALO_CASE(WW)                                                                                           \
     if (W == WW && H % (256 / WW) == 0)                                                                                \
-        return n64 ? launch_igemm_rowhalo<WW, 64>(a, M, CDF_S) : launch_igemm_rowhalo<WW, 128>(a, M, CDF_S);
+        return n64 ? launch_igemm_rowhalo<NS, WW, 64>(a, M, s) : launch_igemm_rowhalo<NS, WW, 128>(a, M, s);
             CDF_ROWHALO_CASE(128) CDF_ROWHALO_CASE(64) CDF_ROWHALO_CASE(32) CDF_ROWHALO_CASE(16)
 #undef CDF_ROWHALO_CASE
         }
@@ -2138,30 +2234,59 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
            (at 128-pixel width only next to 64-wide weight stages) */                                                  \
         if ((WW <= 64 || n64) && g_spx_halo_bm != 128 && H % (256 / WW) == 0 && M % 256 == 0 &&                          \
             (g_spx_halo_bm == 256 || (long long)(M / 256) * cdf_cdiv(Cout, n64 ? 64 : 128) >= 256))                     \
-            return n64 ? launch_igemm_halo<WW, 64, 256>(a, M, CDF_S)                                                    \
-                       : launch_igemm_halo<WW, 128, WW <= 64 ? 256 : 128>(a, M, CDF_S);                                 \
-        return n64 ? launch_igemm_halo<WW, 64, 128>(a, M, CDF_S) : launch_igemm_halo<WW, 128, 128>(a, M, CDF_S);        \
+            return n64 ? launch_igemm_halo<NS, WW, 64, 256>(a, M, s)                                                    \
+                       : launch_igemm_halo<NS, WW, 128, WW <= 64 ? 256 : 128>(a, M, s);                                 \
+        return n64 ? launch_igemm_halo<NS, WW, 64, 128>(a, M, s) : launch_igemm_halo<NS, WW, 128, 128>(a, M, s);        \
     }
             CDF_HALO_CASE(128) CDF_HALO_CASE(64) CDF_HALO_CASE(32) CDF_HALO_CASE(16)
 #undef CDF_HALO_CASE
         }
     }
-    if (m256) return launch_igemm_spx<256, 128, 4, 2, 3>(a, M, CDF_S);
-    if (n64) return m64 ? launch_igemm_spx<64, 64, 2, 2, 2>(a, M, CDF_S) : launch_igemm_spx<128, 64, 2, 2, 2>(a, M, CDF_S);
-    if (m64) return launch_igemm_spx<64, 128, 2, 2, 2>(a, M, CDF_S);
+    if (m256) return launch_igemm_spx<NS, 256, 128, 4, 2, 3>(a, M, s);
+    if (n64) return m64 ? launch_igemm_spx<NS, 64, 64, 2, 2, 2>(a, M, s) : launch_igemm_spx<NS, 128, 64, 2, 2, 2>(a, M, s);
+    if (m64) return launch_igemm_spx<NS, 64, 128, 2, 2, 2>(a, M, s);
     // 128 x 128 with 8 waves (4 x 2 of 32 x 64), still two blocks per CU: 16 waves per CU instead of 8
-    if (g_spx_waves == 8) return launch_igemm_spx<128, 128, 4, 2, 2, 2>(a, M, CDF_S);
-    return launch_igemm_spx<128, 128, 2, 2, 2>(a, M, CDF_S);
+    if (g_spx_waves == 8) return launch_igemm_spx<NS, 128, 128, 4, 2, 2, 2>(a, M, s);
+    return launch_igemm_spx<NS, 128, 128, 2, 2, 2>(a, M, s);
 }
 
-static int g_wgrad_stack = 1;                  // tuning / test hook (cdf_conv_wgrad_bf16x_stack)
+extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo,
+                                   int ldk, float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW,
+                                   int os, int is, int nphase, const int* phase_desc, const float* bias, const float* sbias,
+                                   int ld_sbias, const float* res, int ldr, float* pre, int ldp, const float* mul, int ldm, int act,
+                                   int mul_mode, int accumulate, void* y_hi, void* y_lo, int ld_ys, void* stream) {
+    CDF_REQUIRE(x_hi && zero && w_hi && (y || (y_hi && !accumulate)), "cdf_conv_gemm_bf16x: null pointer");
+    CDF_REQUIRE((x_lo != nullptr) == (w_lo != nullptr), "cdf_conv_gemm_bf16x: pass both lo planes (split precision, 3 MFMAs per product) or neither (single-pass bf16)");
+    CDF_REQUIRE((!y_hi && !y_lo) || (y_hi && ld_ys % 4 == 0 && ld_ys >= Cout && Cout % 4 == 0 && ((((uintptr_t)y_hi) | ((uintptr_t)y_lo)) & 7) == 0),
+                "cdf_conv_gemm_bf16x: output planes need Cout %% 4 == 0, ld_ys %% 4 == 0, 8-byte alignment (y_lo optional: hi-only planes)");
+    CDF_REQUIRE(((((uintptr_t)x_hi) | ((uintptr_t)x_lo) | ((uintptr_t)zero) | ((uintptr_t)w_hi) | ((uintptr_t)w_lo)) & 15) == 0, "cdf_conv_gemm_bf16x: operands must be 16B aligned");
+    CDF_REQUIRE(ldx % 8 == 0 && Cin % 8 == 0 && ldx >= Cin && ldk % 32 == 0 && ldk >= Cin, "cdf_conv_gemm_bf16x: Cin and pitches must be multiples of 8 (ldk of 32)");
+    CDF_REQUIRE(nphase >= 1 && nphase <= 4 && phase_desc && (!y || ldy >= Cout), "cdf_conv_gemm_bf16x: bad geometry");
+    CDF_REQUIRE(!mul_mode || mul, "cdf_conv_gemm_bf16x: mul_mode without mul tensor");
+    SpxArgs a;
+    a.x_hi = (const unsigned short*)x_hi; a.x_lo = (const unsigned short*)x_lo; a.zero = (const unsigned short*)zero;
+    a.w_hi = (const unsigned short*)w_hi; a.w_lo = (const unsigned short*)w_lo; a.y = y;
+    a.bias = bias; a.sbias = sbias; a.res = res; a.pre = pre; a.mul = mul;
+    a.ldx = ldx; a.ldk = ldk; a.ldy = ldy; a.ld_sbias = ld_sbias; a.ldr = ldr; a.ldp = ldp; a.ldm = ldm;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.QH = QH; a.QW = QW; a.os = os; a.is = is;
+    a.act = act; a.mul_mode = mul_mode; a.accumulate = accumulate; a.nphase = nphase;
+    a.vec = cdf_epi_vec_ok(Cout, y, ldy, bias, sbias, ld_sbias, res, ldr, pre, ldp, mul, ldm);
+    a.ys_hi = (unsigned short*)y_hi; a.ys_lo = (unsigned short*)y_lo; a.ld_ys = ld_ys;
+    CDF_REQUIRE(!y_hi || a.vec, "cdf_conv_gemm_bf16x: split output planes need the vectorised epilogue (aligned pointers, pitches %% 4)");
+    int rc = fill_phases(a.ph, nphase, phase_desc, "cdf_conv_gemm_bf16x");
+    if (rc) return rc;
+    return x_lo ? dispatch_gemm_bf16x<3>(a, B, H, W, Cin, Cout, QH, QW, os, is, nphase, CDF_S)
+                : dispatch_gemm_bf16x<1>(a, B, H, W, Cin, Cout, QH, QW, os, is, nphase, CDF_S);
+}
+
+static std::atomic<int> g_wgrad_stack{1};                  // tuning / test hook (cdf_conv_wgrad_bf16x_stack)
 
 extern "C" int cdf_conv_wgrad_bf16x_stack(int enable) {
     g_wgrad_stack = enable ? 1 : 0;
     return 0;
 }
 
-template <int TA, int TB, bool STACK2 = false>
+template <int NS, int TA, int TB, bool STACK2 = false>
 static int launch_wgrad_spx(const SpxWgradArgs& a, hipStream_t s) {
     constexpr size_t stage = (size_t)2 * 32 * ((TA + 32) + (TB + 32)) * sizeof(unsigned short);
     constexpr size_t epi = (size_t)TA * (TB + 8) * sizeof(float);
@@ -2169,16 +2294,16 @@ static int launch_wgrad_spx(const SpxWgradArgs& a, hipStream_t s) {
 #ifndef CDF_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_spx_kernel<TA, TB, STACK2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_spx_kernel<TA, TB, STACK2, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
 #endif
     const int tiles = (STACK2 ? 1 : cdf_cdiv(a.CA, TA)) * cdf_cdiv(a.CB, TB);
-    CDF_LAUNCH((conv_wgrad_spx_kernel<TA, TB, STACK2>), dim3(tiles, STACK2 ? cdf_cdiv(a.ntaps, 2) : a.ntaps, a.nsplit), dim3(256), lds, s, a);
+    CDF_LAUNCH((conv_wgrad_spx_kernel<TA, TB, STACK2, NS>), dim3(tiles, STACK2 ? cdf_cdiv(a.ntaps, 2) : a.ntaps, a.nsplit), dim3(256), lds, s, a);
     return cdf_check_launch("conv_wgrad_spx");
 }
 
-static int g_wgrad_row3 = 1;                   // tuning / test hook (cdf_conv_wgrad_bf16x_row3)
+static std::atomic<int> g_wgrad_row3{1};                   // tuning / test hook (cdf_conv_wgrad_bf16x_row3)
 
 extern "C" int cdf_conv_wgrad_bf16x_row3(int enable) {
     g_wgrad_row3 = enable ? 1 : 0;
@@ -2192,7 +2317,7 @@ extern "C" int cdf_conv_wgrad_bf16x_is_row3(int QH, int QW, int CA, int CB, int 
            (QW >= 32 || QH % (32 / QW) == 0) && !(CA <= 64 && CB <= 64);
 }
 
-template <int TA, int TB>
+template <int NS, int TA, int TB>
 static int launch_wgrad_row3(const SpxWgradArgs& a, hipStream_t s) {
     constexpr size_t stage = (size_t)2 * (36 * (TA + 32) + 32 * (TB + 32)) * sizeof(unsigned short);
     constexpr size_t epi = (size_t)TA * (TB + 8) * sizeof(float);
@@ -2200,19 +2325,53 @@ static int launch_wgrad_row3(const SpxWgradArgs& a, hipStream_t s) {
 #ifndef CDF_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_row3_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_row3_kernel<TA, TB, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
 #endif
     const int tiles = cdf_cdiv(a.CA, TA) * cdf_cdiv(a.CB, TB);
-    CDF_LAUNCH((conv_wgrad_row3_kernel<TA, TB>), dim3(tiles, 3, a.nsplit), dim3(512), lds, s, a);
+    CDF_LAUNCH((conv_wgrad_row3_kernel<TA, TB, NS>), dim3(tiles, 3, a.nsplit), dim3(512), lds, s, a);
     return cdf_check_launch("conv_wgrad_row3");
+}
+
+template <int NS>
+static int dispatch_wgrad_bf16x(SpxWgradArgs& a, int QH, int QW, int HA, int WA, int sa, int HB, int WB, int sb, int CA, int CB, int ntaps, hipStream_t s) {
+    // 3 x 3 stride-1 "same" convolutions (X shifted per tap, dY read in place): one block per row of taps
+    if (g_wgrad_row3 && ntaps == 9 && sa == 1 && sb == 1 && HA == QH && WA == QW && HB == QH && WB == QW &&
+        (QW == 16 || QW == 32 || QW == 64 || QW == 128) && (QH * QW) % 32 == 0 && (QW >= 32 || QH % (32 / QW) == 0) && !(CA <= 64 && CB <= 64)) {
+        bool ok = true;
+        for (int g = 0; g < 3 && ok; ++g) {
+            int seen = 0;
+            for (int i = 0; i < 3; ++i) {
+                const int t = 3 * g + i;
+                ok = ok && a.day[t] == a.day[3 * g] && a.dby[t] == 0 && a.dbx[t] == 0 && a.dax[t] >= -1 && a.dax[t] <= 1 && a.day[t] >= -1 && a.day[t] <= 1;
+                seen |= 1 << (a.dax[t] + 1);
+            }
+            ok = ok && seen == 7;
+        }
+        if (ok) {
+            if (CA <= 64) return launch_wgrad_row3<NS, 64, 128>(a, s);
+            if (CB <= 64) return launch_wgrad_row3<NS, 128, 64>(a, s);
+            return launch_wgrad_row3<NS, 128, 128>(a, s);
+        }
+    }
+    // thin layers get 64-wide tiles so that no half of a tile multiplies padding
+    if (CA <= 64 && CB <= 64) return launch_wgrad_spx<NS, 64, 64>(a, s);
+    if (CA <= 64) {
+        bool same_b = ntaps >= 2;                  // two taps can share the B rows only if B is read at one offset
+        for (int t = 1; t < ntaps; ++t) same_b = same_b && a.dby[t] == a.dby[0] && a.dbx[t] == a.dbx[0];
+        if (same_b && g_wgrad_stack) return launch_wgrad_spx<NS, 128, 128, true>(a, s);
+        return launch_wgrad_spx<NS, 64, 128>(a, s);
+    }
+    if (CB <= 64) return launch_wgrad_spx<NS, 128, 64>(a, s);
+    return launch_wgrad_spx<NS, 128, 128>(a, s);
 }
 
 extern "C" int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, int ldb,
                                     const void* zero, float* ws, int ldo, int B, int QH, int QW, int HA, int WA, int sa, int HB, int WB,
                                     int sb, int CA, int CB, int ntaps, const int* tap_desc, int nsplit, float* bsum, void* stream) {
-    CDF_REQUIRE(a_hi && a_lo && b_hi && b_lo && zero && ws, "cdf_conv_wgrad_bf16x: null pointer");
+    CDF_REQUIRE(a_hi && b_hi && zero && ws, "cdf_conv_wgrad_bf16x: null pointer");
+    CDF_REQUIRE((a_lo != nullptr) == (b_lo != nullptr), "cdf_conv_wgrad_bf16x: pass both lo planes (split precision) or neither (single-pass bf16)");
     CDF_REQUIRE(((((uintptr_t)a_hi) | ((uintptr_t)a_lo) | ((uintptr_t)b_hi) | ((uintptr_t)b_lo) | ((uintptr_t)zero)) & 15) == 0, "cdf_conv_wgrad_bf16x: operands must be 16B aligned");
     CDF_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && CA % 8 == 0 && CB % 8 == 0 && lda >= CA && ldb >= CB && ldo % 4 == 0 && ldo >= CB, "cdf_conv_wgrad_bf16x: channels / pitches must be multiples of 8");
     CDF_REQUIRE(ntaps >= 1 && ntaps <= CDF_MAX_TAPS && tap_desc && nsplit >= 1, "cdf_conv_wgrad_bf16x: bad tap / split count");
@@ -2230,33 +2389,6 @@ extern "C" int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda,
         a.dby[t] = (signed char)tap_desc[4 * t + 2];
         a.dbx[t] = (signed char)tap_desc[4 * t + 3];
     }
-    // 3 x 3 stride-1 "same" convolutions (X shifted per tap, dY read in place): one block per row of taps
-    if (g_wgrad_row3 && ntaps == 9 && sa == 1 && sb == 1 && HA == QH && WA == QW && HB == QH && WB == QW &&
-        (QW == 16 || QW == 32 || QW == 64 || QW == 128) && (QH * QW) % 32 == 0 && (QW >= 32 || QH % (32 / QW) == 0) && !(CA <= 64 && CB <= 64)) {
-        bool ok = true;
-        for (int g = 0; g < 3 && ok; ++g) {
-            int seen = 0;
-            for (int i = 0; i < 3; ++i) {
-                const int t = 3 * g + i;
-                ok = ok && a.day[t] == a.day[3 * g] && a.dby[t] == 0 && a.dbx[t] == 0 && a.dax[t] >= -1 && a.dax[t] <= 1 && a.day[t] >= -1 && a.day[t] <= 1;
-                seen |= 1 << (a.dax[t] + 1);
-            }
-            ok = ok && seen == 7;
-        }
-        if (ok) {
-            if (CA <= 64) return launch_wgrad_row3<64, 128>(a, CDF_S);
-            if (CB <= 64) return launch_wgrad_row3<128, 64>(a, CDF_S);
-            return launch_wgrad_row3<128, 128>(a, CDF_S);
-        }
-    }
-    // thin layers get 64-wide tiles so that no half of a tile multiplies padding
-    if (CA <= 64 && CB <= 64) return launch_wgrad_spx<64, 64>(a, CDF_S);
-    if (CA <= 64) {
-        bool same_b = ntaps >= 2;                  // two taps can share the B rows only if B is read at one offset
-        for (int t = 1; t < ntaps; ++t) same_b = same_b && a.dby[t] == a.dby[0] && a.dbx[t] == a.dbx[0];
-        if (same_b && g_wgrad_stack) return launch_wgrad_spx<128, 128, true>(a, CDF_S);
-        return launch_wgrad_spx<64, 128>(a, CDF_S);
-    }
-    if (CB <= 64) return launch_wgrad_spx<128, 64>(a, CDF_S);
-    return launch_wgrad_spx<128, 128>(a, CDF_S);
+    return a_lo ? dispatch_wgrad_bf16x<3>(a, QH, QW, HA, WA, sa, HB, WB, sb, CA, CB, ntaps, CDF_S)
+                : dispatch_wgrad_bf16x<1>(a, QH, QW, HA, WA, sa, HB, WB, sb, CA, CB, ntaps, CDF_S);
 }

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) layernorm_c_fwd_kernel(const float* x, in
                         if (y) *(float4*)(y + m * ldy + c) = o;
                         if (ys_hi) {                         // operand split of the following conv fused in
                             const float ov[4] = {o.x, o.y, o.z, o.w};
-                            cdf_split_store4(ys_hi + m * ld_ys + c, ys_lo + m * ld_ys + c, ov);
+                            cdf_split_store4(ys_hi + m * ld_ys + c, ys_lo ? ys_lo + m * ld_ys + c : nullptr, ov);
                         }
                     }
                 }
@@ -439,7 +439,7 @@ extern "C" int cdf_layernorm_blocks(long long M, int C) {
 extern "C" int cdf_layernorm_c_fwd(const float* x, int ldx, float* y, int ldy, const float* g, const float* b,
                                    float* mean, float* rstd, long long M, int C, float eps, void* y_hi, void* y_lo, int ld_ys,
                                    void* stream) {
-    CDF_REQUIRE((!y_hi && !y_lo) || (y_hi && y_lo && ld_ys % 4 == 0 && ld_ys >= C && ((((uintptr_t)y_hi) | ((uintptr_t)y_lo)) & 7) == 0),
+    CDF_REQUIRE((!y_hi && !y_lo) || (y_hi && ld_ys % 4 == 0 && ld_ys >= C && ((((uintptr_t)y_hi) | ((uintptr_t)y_lo)) & 7) == 0),
                 "cdf_layernorm_c_fwd: split output planes need ld_ys %% 4 == 0, ld_ys >= C, 8-byte alignment");
     CDF_REQUIRE(x && (y || y_hi) && g && b && M > 0, "cdf_layernorm_c_fwd: null / empty");
     CDF_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && (!y || ldy % 4 == 0) && C <= 1024, "cdf_layernorm_c_fwd: C=%d must be a multiple of 4 and <= 1024", C);

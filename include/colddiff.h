@@ -153,7 +153,9 @@ int cdf_conv_wgrad_bf16(const float* xa, int lda, const float* xb, int ldb, floa
                         float* bsum, void* stream);
 /* Pre-split operand variants: an activation that feeds several GEMMs (forward, data gradient, weight
  * gradient, every N tile) is split ONCE into bf16 hi / lo planes [rows][ld] by cdf_split_bf16; the GEMMs
- * then only copy and multiply.  `zero` = any 16-byte-aligned device buffer of >= 16 zero bytes (out-of-image
+ * then only copy and multiply.  Every lo pointer is OPTIONAL: with x_lo == w_lo == NULL (a_lo == b_lo == NULL for the weight
+ * gradient) the operands are single bf16 values and each product is ONE MFMA ("bf16" arithmetic mode, fp32 accumulate) instead of
+ * the three of split precision; producers given lo == NULL / y_lo == NULL write the hi plane only.  `zero` = any 16-byte-aligned device buffer of >= 16 zero bytes (out-of-image
  * taps load from it).  Channel counts and pitches must be multiples of 8. */
 int cdf_split_bf16(const float* x, int ldx, void* hi, void* lo, int ldo, long long rows, int C, void* stream);
 /* cdf_conv_gemm_bf16x: y_hi / y_lo (nullable, pitch ld_ys) additionally receive the stored output split into bf16 hi / lo planes,
@@ -164,8 +166,14 @@ int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void*
                         int nphase, const int* phase_desc, const float* bias, const float* sbias, int ld_sbias, const float* res,
                         int ldr, float* pre, int ldp, const float* mul, int ldm, int act, int mul_mode, int accumulate,
                         void* y_hi, void* y_lo, int ld_ys, void* stream);
-/* Tuning / test hook: force the block tile of cdf_conv_gemm_bf16x (rows of pixels x output channels; bm 64, 128 or
- * 256 -- the latter with bn = 128 --, bn 64 or 128; 0 = automatic choice from the problem size).  Process-wide; results
+/* RE-ENTRANCY.  Every compute entry point is a pure function of its arguments: no mutable process-wide state is read on the product
+ * path.  The `tuning / test hook` setters below each store one std::atomic word that later launches read once (autograd runs the
+ * backward launches on its own thread, so the knobs have to be process-wide to be usable at all); they only choose between kernels
+ * that compute the same sums, and the Python package never calls them -- tests, tools/convbench.py and tools/ablate.py do (or the
+ * COLDDIFF_SPX_* / COLDDIFF_WGRAD_* environment variables read once when the library is loaded).  The only other statics are one-time
+ * hipFuncSetAttribute(MaxDynamicSharedMemorySize) latches (idempotent).
+ * Tuning / test hook: force the block tile of cdf_conv_gemm_bf16x (rows of pixels x output channels; bm 64, 128 or
+ * 256 -- the latter with bn = 128 --, bn 64 or 128; 0 = automatic choice from the problem size).  Process-wide (an atomic word each); results
  * do not depend on it. */
 int cdf_conv_gemm_bf16x_tile(int bm, int bn);
 /* tuning / test hook: waves of the 128 x 128 tile of cdf_conv_gemm_bf16x: 0 (default: 4), 4 or 8 (4 x 2 waves of 32 x 64, two blocks per CU) */
@@ -176,6 +184,10 @@ int cdf_conv_gemm_bf16x_max_bm(int bm);
  * (1, default: the three tiles that need an input row read it at the same time, one L2 fill instead of three) or the
  * table's order (0).  Only the fp32 summation order depends on it. */
 int cdf_conv_gemm_bf16x_taprot(int enable);
+/* tuning / test hook: de-phased waves in the 8-wave tiles of cdf_conv_gemm_bf16x (1, default): waves 4..7 of a block share their
+ * SIMDs with waves 0..3; they multiply the fragments read in the previous K step first and read / request afterwards, so that one
+ * wave of a SIMD feeds the matrix pipe while the other one reads LDS or issues global_load_lds.  Only the schedule depends on it. */
+int cdf_conv_gemm_bf16x_dephase(int enable);
 /* tuning / test hook: 3 x 3 stride-1 layers of cdf_conv_gemm_bf16x with the input tile (+ one-pixel halo) resident in LDS for
  * all nine taps.  enable: bit mask over the image width 16 (1), 32 (2), 64 (4), 128 (8), and 16 = at width 128 also for
  * layers with more than 64 output channels; 32 = the row-halo form (256-pixel tiles, input shared by the three dx taps of a row only)
@@ -186,10 +198,10 @@ int cdf_conv_gemm_bf16x_halo(int enable, int min_tiles);
 /* tuning / test hook: pixels per tile of the LDS-resident-input kernel: 0 = automatic (256 where every CU still gets a tile), 128, 256 */
 int cdf_conv_gemm_bf16x_halo_bm(int bm);
 /* Tuning / test hook: allow (1, default) or forbid (0) the two-taps-per-tile form of cdf_conv_wgrad_bf16x used when
- * CA <= 64 < CB.  Process-wide; results do not depend on it. */
+ * CA <= 64 < CB.  Process-wide (an atomic word each); results do not depend on it. */
 int cdf_conv_wgrad_bf16x_stack(int enable);
 /* Tuning / test hook: XCD-aware block order of cdf_conv_wgrad_bf16x (1, default: the taps of a pixel range share one
- * XCD's L2) or plain dispatch order (0).  Process-wide; results do not depend on it. */
+ * XCD's L2) or plain dispatch order (0).  Process-wide (an atomic word each); results do not depend on it. */
 int cdf_conv_wgrad_bf16x_swizzle(int enable);
 /* Tuning / test hook: weight gradients of 3 x 3 stride-1 same-size convolutions by one block per ROW of taps (1, default: dY and
  * X with a pixel of halo are loaded once for the three dx taps) or one block per tap (0).  cdf_conv_wgrad_bf16x_is_row3 tells the
@@ -199,6 +211,15 @@ int cdf_conv_wgrad_bf16x_is_row3(int QH, int QW, int CA, int CB, int ntaps, int 
 int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, int ldb, const void* zero,
                          float* ws, int ldo, int B, int QH, int QW, int HA, int WA, int sa, int HB, int WB, int sb, int CA, int CB,
                          int ntaps, const int* tap_desc, int nsplit, float* bsum, void* stream);
+
+/* Device-side input pipeline (replaces Dataset_Aug1 / Dataset + DataLoader, deblurring_diffusion_pytorch.py:983-1026, 1094-1096).
+ * cache: [N][S][S][C] uint8 (NHWC) images already resized to S = int(1.12 image_size) (the deterministic Resize of the reference's
+ * transform chain, applied once when the cache is built).  out[b][c][y][x] (NCHW fp32, [B][C][H][W]) =
+ * float(cache[idx[b]][oy[b] + y][ox[b] + (flip[b] ? W-1-x : x)][c]) / 255 * 2 - 1  -- RandomCrop / CenterCrop, RandomHorizontalFlip,
+ * ToTensor and Lambda(t * 2 - 1) with their exact arithmetic.  idx: int64 [B] (device), oy / ox / flip: int32 [B] (device);
+ * offsets must satisfy oy + H <= S, ox + W <= S (not checked on the device). */
+int cdf_augment_batch(const void* cache, long long N, int S, int C, const long long* idx, const int* oy, const int* ox,
+                      const int* flip, float* out, int B, int H, int W, void* stream);
 
 /* parameter layout <-> GEMM layout: dst[t][r][c] = src[c*s_c + r*s_r + t*s_t] (c >= C zero-filled up to ldc);
  * g[c*s_c + r*s_r + t*s_t] (+)= sum_z ws[z][t][r][c] */

@@ -92,7 +92,7 @@ def test_argument_checks_of_the_gemm_and_blend_entry_points():
     bad = list(gemm); bad[12] = 6
     expect(lib.cdf_conv_gemm_bf16x, bad, "multiples of 8")
     bad = list(gemm); bad[34], bad[35], bad[36] = p, p, 6
-    expect(lib.cdf_conv_gemm_bf16x, bad, "split output planes")
+    expect(lib.cdf_conv_gemm_bf16x, bad, "output planes need")
     # weight gradient: tap count out of range
     expect(lib.cdf_conv_wgrad_bf16x, [p, p, 8, p, p, 8, p, p, 8, 1, 4, 4, 4, 4, 1, 4, 4, 1, 8, 8, 0, desc, 1, 0, 0], "tap / split count")
     # per-pixel blend: t = 0 is not a reverse step

@@ -594,19 +594,23 @@ SPX_CASES_GPU = [(4, 64, 128, 32, 3, 1, 1), (2, 128, 64, 32, 3, 1, 1), (2, 256, 
                  (4, 64, 128, 128, 3, 1, 1), (4, 128, 64, 128, 3, 1, 1), (2, 64, 96, 64, 3, 1, 1)]   # 128 / 64-wide images: LDS-resident input tiles
 
 
-def _split(be, t):
-    """fp32 NHWC [.., C] -> (hi, lo) bf16 planes with pitch roundup8(C)."""
+def _split(be, t, single=False):
+    """fp32 NHWC [.., C] -> (hi, lo) bf16 planes with pitch roundup8(C); single: hi only (lo = None, single-pass bf16 operands)."""
     C = t.shape[-1]
     ld = (C + 7) // 8 * 8
     rows = t.numel() // C
     hi = torch.zeros(t.shape[:-1] + (ld,), dtype=torch.int16, device=be.device)
-    lo = torch.zeros_like(hi)
+    lo = None if single else torch.zeros_like(hi)
     be.L.cdf_split_bf16(P(t), C, P(hi), P(lo), ld, rows, C, be.stream())
     be._keep += [hi, lo]
     return hi, lo
 
 
+SPX_SINGLE = False      # module switch: run _spx_case with hi-only planes (the "bf16" arithmetic mode: NS = 1 kernel instantiations)
+
+
 def _spx_case(be, B, Cin, Cout, H, k, s, p):
+    single = SPX_SINGLE
     torch.manual_seed(0)
     x = torch.randn(B, Cin, H, H, requires_grad=True)
     w = (torch.randn(Cout, Cin, k, k) * (1.0 / math.sqrt(Cin * k * k))).requires_grad_()
@@ -614,6 +618,17 @@ def _spx_case(be, B, Cin, Cout, H, k, s, p):
     yref = F.conv2d(x, w, bias, stride=s, padding=p)
     gy = torch.randn_like(yref)
     yref.backward(gy)
+    if single:
+        # reference of the single-pass mode: the SAME fp32 arithmetic on operands rounded to bf16 (round to nearest even), so the
+        # tolerances below stay at accumulation-order level
+        bf = lambda t: t.detach().bfloat16().float()
+        xq, wq, gq = bf(x).requires_grad_(), bf(w).requires_grad_(), bf(gy)
+        yref = F.conv2d(xq, wq, bias, stride=s, padding=p)
+        yref.backward(gq)
+        dx_ref, dw_ref, db_ref = xq.grad, wq.grad, gq.sum((0, 2, 3))
+    else:
+        dx_ref, dw_ref, db_ref = x.grad, w.grad, gy.sum((0, 2, 3))
+    yref = yref.detach()
     KK = k * k
     zero = be.zeros(16)
     wd_ = be.to(w)
@@ -621,7 +636,7 @@ def _spx_case(be, B, Cin, Cout, H, k, s, p):
     def pack_sp(N, K, s_n, s_k):
         ldk = (K + 31) // 32 * 32
         hi = torch.empty(KK, N, ldk, dtype=torch.int16, device=be.device)
-        lo = torch.empty(KK, N, ldk, dtype=torch.int16, device=be.device)
+        lo = None if single else torch.empty(KK, N, ldk, dtype=torch.int16, device=be.device)
         be.L.cdf_pack_weight_bf16(P(wd_), P(hi), P(lo), KK, N, K, ldk, 1, s_n, s_k, be.stream())
         be._keep += [hi, lo]
         return hi, lo
@@ -632,7 +647,7 @@ def _spx_case(be, B, Cin, Cout, H, k, s, p):
     xn[...] = x.detach().permute(0, 2, 3, 1)
     gyn = torch.zeros(B, plan.OH, plan.OW, Cout)
     gyn[...] = gy.permute(0, 2, 3, 1)
-    xs, gs = _split(be, be.to(xn)), _split(be, be.to(gyn))
+    xs, gs = _split(be, be.to(xn), single), _split(be, be.to(gyn), single)
 
     def run(pl, xsplit, wpair, Ci, Co, bias_):
         y = be.zeros(B, pl.OH, pl.OW, r4(Co))
@@ -647,13 +662,13 @@ def _spx_case(be, B, Cin, Cout, H, k, s, p):
         # the epilogue's fused operand split must equal cdf_split_bf16 of the stored output, bit for bit
         ld8 = (Cout + 7) // 8 * 8
         yh = torch.zeros(B, plan.OH, plan.OW, ld8, dtype=torch.int16, device=be.device)
-        yl = torch.zeros_like(yh)
+        yl = None if single else torch.zeros_like(yh)
         y2 = be.zeros(B, plan.OH, plan.OW, r4(Cout))
         be.L.cdf_conv_gemm_bf16x(P(xs[0]), P(xs[1]), xs[0].shape[-1], P(zero), P(wf[0]), P(wf[1]), wf[0].shape[-1], P(y2), y2.shape[-1], B,
                                  plan.H, plan.W, Cin, plan.OH, plan.OW, Cout, plan.QH, plan.QW, plan.os, plan.istride, plan.nphase,
                                  plan.desc, P(be.to(bias)), 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, P(yh), P(yl), ld8, be.stream())
-        rh, rl = _split(be, y2[..., :Cout].contiguous())
-        assert torch.equal(yh.cpu(), rh.cpu()) and torch.equal(yl.cpu(), rl.cpu())
+        rh, rl = _split(be, y2[..., :Cout].contiguous(), single)
+        assert torch.equal(yh.cpu(), rh.cpu()) and (single or torch.equal(yl.cpu(), rl.cpu()))
     M = B * wg.QH * wg.QW
     ns, ldo = max(1, min(3, M // 32)), r4(Cout)
     ws, bsum = be.empty(ns, KK, Cin, ldo), be.empty(ns, ldo)
@@ -664,9 +679,9 @@ def _spx_case(be, B, Cin, Cout, H, k, s, p):
     be.L.cdf_unpack_reduce(P(bsum), P(db), ns, 1, 1, Cout, ldo, 0, 0, 1, 0, be.stream())
     tol = lambda ref: 3e-5 * max(1.0, ref.abs().max().item())
     assert err(y[..., :Cout].permute(0, 3, 1, 2), yref) <= tol(yref)
-    assert err(dx[..., :Cin].permute(0, 3, 1, 2), x.grad) <= tol(x.grad)
-    assert err(dw, w.grad) <= 3e-5 * max(1.0, w.grad.abs().max().item()) * math.sqrt(M / 16)
-    assert err(db, gy.sum((0, 2, 3))) <= 3e-5 * max(1.0, gy.sum((0, 2, 3)).abs().max().item()) * math.sqrt(M)
+    assert err(dx[..., :Cin].permute(0, 3, 1, 2), dx_ref) <= tol(dx_ref)
+    assert err(dw, dw_ref) <= 3e-5 * max(1.0, dw_ref.abs().max().item()) * math.sqrt(M / 16)
+    assert err(db, db_ref) <= 3e-5 * max(1.0, db_ref.abs().max().item()) * math.sqrt(M)
 
 
 @pytest.mark.parametrize("case", SPX_CASES)
@@ -835,3 +850,37 @@ def test_conv_cin4_direct(be, B, H, Cin, Cout, k, act):
     be.L.cdf_unpack_reduce(P(bsum), P(db), nch, 1, 1, Cout, Cout, 0, 0, 1, 0, be.stream())
     assert err(dw, conv.weight.grad) <= 5e-5 * max(1.0, conv.weight.grad.abs().max().item())
     assert err(db, conv.bias.grad) <= 5e-5 * max(1.0, conv.bias.grad.abs().max().item())
+
+
+@pytest.fixture
+def single_pass():
+    """Run the pre-split cases with hi-only planes: the NS = 1 instantiations ("bf16" mode: one MFMA per product)."""
+    global SPX_SINGLE
+    SPX_SINGLE = True
+    yield
+    SPX_SINGLE = False
+
+
+@pytest.mark.parametrize("case", SPX_CASES)
+def test_conv_presplit_single_pass(be, single_pass, case):
+    _spx_case(be, *case)
+
+
+@pytest.mark.parametrize("case", [(1, 64, 96, 16, 3, 1, 1), (2, 96, 40, 16, 3, 1, 1)])
+def test_conv_presplit_halo_single_pass(be, single_pass, case):
+    test_conv_presplit_halo(be, case)
+
+
+@pytest.mark.parametrize("case", [(1, 136, 72, 16, 3, 1, 1), (2, 64, 136, 16, 3, 1, 1)])
+def test_wgrad_presplit_row_of_taps_single_pass(be, single_pass, case):
+    test_wgrad_presplit_row_of_taps(be, case)
+
+
+def test_conv_presplit_rowhalo_emu_single_pass(single_pass):
+    test_conv_presplit_rowhalo_emu((2, 96, 40, 16, 3, 1, 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", SPX_CASES_GPU)
+def test_conv_presplit_large_single_pass(single_pass, case):
+    test_conv_presplit_large(case)

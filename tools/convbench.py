@@ -17,6 +17,9 @@ if os.environ.get('KB_HALO'):
     L.cdf_conv_gemm_bf16x_halo(*[int(v) for v in os.environ['KB_HALO'].split(',')])
 if os.environ.get('KB_HALO_BM'):
     L.cdf_conv_gemm_bf16x_halo_bm(int(os.environ['KB_HALO_BM']))
+if os.environ.get('KB_DEPHASE'):
+    L.cdf_conv_gemm_bf16x_dephase(int(os.environ['KB_DEPHASE']))
+SINGLE = os.environ.get('KB_SINGLE', '0') == '1'      # hi-only planes: single-pass bf16 (NS = 1 kernels)
 if os.environ.get('KB_WAVES'):
     L.cdf_conv_gemm_bf16x_waves(int(os.environ['KB_WAVES']))
 
@@ -78,14 +81,14 @@ if os.environ.get("KB_SPW", "1") == "1":
 if os.environ.get("KB_SPX", "1") == "1":
     zero = torch.zeros(64, device=dev)
     def split(t):
-        C = t.shape[-1]; hi = torch.empty(t.shape, dtype=torch.int16, device=dev); lo = torch.empty_like(hi)
+        C = t.shape[-1]; hi = torch.empty(t.shape, dtype=torch.int16, device=dev); lo = None if SINGLE else torch.empty_like(hi)
         L.cdf_split_bf16(P(t), C, P(hi), P(lo), C, t.numel()//C, C, S()); return hi, lo
     for (Cin,Cout,H,k) in shapes:
         if only and only != f"{Cin}-{Cout}-{H}": continue
         if Cin % 8 or Cout % 8: continue
         x = torch.randn(B,H,H,Cin,device=dev); y = torch.empty(B,H,H,r4(Cout),device=dev); gy = torch.randn(B,H,H,Cout,device=dev)
         ldk = (Cin+31)//32*32
-        hi = torch.zeros(k*k,Cout,ldk,dtype=torch.int16,device=dev); lo = torch.zeros_like(hi)
+        hi = torch.zeros(k*k,Cout,ldk,dtype=torch.int16,device=dev); lo = None if SINGLE else torch.zeros_like(hi)
         w = torch.randn(Cout,Cin,k,k,device=dev)*0.05
         L.cdf_pack_weight_bf16(P(w),P(hi),P(lo),k*k,Cout,Cin,ldk,1,Cin*k*k,k*k,S())
         ms = timeit(lambda: split(x)); print(f"split {Cin:5d} ch @{H:3d}: {ms:8.3f} ms {8.0*x.numel()/ms/1e6:7.1f} GB/s", flush=True)
@@ -96,7 +99,7 @@ if os.environ.get("KB_SPX", "1") == "1":
         print(f"spx   {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv", flush=True)
         if os.environ.get("KB_EPI", "1") == "1":      # the ConvNeXt conv1 form: bias + GELU, pre-activation kept, output as bf16 planes only
             bias = torch.randn(Cout, device=dev); pre = torch.empty(B,H,H,Cout,device=dev)
-            yh = torch.empty(B,H,H,Cout,dtype=torch.int16,device=dev); yl = torch.empty_like(yh)
+            yh = torch.empty(B,H,H,Cout,dtype=torch.int16,device=dev); yl = None if SINGLE else torch.empty_like(yh)
             ms = timeit(lambda: L.cdf_conv_gemm_bf16x(P(xs[0]),P(xs[1]),Cin,P(zero),P(hi),P(lo),ldk,0,Cout,B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,P(bias),0,0,0,0,P(pre),Cout,0,0,1,0,0,P(yh),P(yl),Cout,S()))
             print(f"spxG  {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv (bias+GELU, pre + planes out)", flush=True)
         wg = cd.conv_wgrad(H,H,k,k,1,k//2,k//2,k//2,k//2); M=B*H*H

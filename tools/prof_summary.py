@@ -1,15 +1,20 @@
 """Summarise a rocprofv3 rocpd sqlite database (kernel trace) into a per-kernel table:
-   python tools/prof_summary.py gpurun_out/prof/x_results.db [out.md]"""
+   python tools/prof_summary.py gpurun_out/prof/x_results.db [out.md [out.json]]
+out.json: {kernel family (same key as tools/pmc_traffic.py): {calls, total_ms, avg_us}} -- read by bench.py's per-class HBM figures."""
+import json
 import os
 import re
 import sqlite3
 import sys
 
 
+def family(name):
+    name = re.sub(r"^void\s+", "", name)
+    return re.sub(r"\(.*$", "", name)
+
+
 def short(name):
-    name = re.sub(r"\(.*$", "", name)
-    name = re.sub(r"^void ", "", name)
-    return name[:90]
+    return family(name)[:90]
 
 
 def main():
@@ -23,8 +28,11 @@ def main():
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
     rows = db.execute(f"select {name_col}, start, end from kernels").fetchall()
-    agg = {}
+    agg, fam = {}, {}
     for n, s, e in rows:
+        f = fam.setdefault(family(n), [0, 0.0])
+        f[0] += 1
+        f[1] += (e - s) / 1e6
         k = short(n)
         a = agg.setdefault(k, [0, 0.0, 1e30, 0.0])
         d = (e - s) / 1e3
@@ -41,6 +49,9 @@ def main():
     print(txt)
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(txt + "\n")
+    if len(sys.argv) > 3:
+        json.dump({k: {"calls": v[0], "total_ms": round(v[1], 4), "avg_us": round(1e3 * v[1] / v[0], 2)} for k, v in fam.items()},
+                  open(sys.argv[3], "w"), indent=1)
 
 
 if __name__ == "__main__":
