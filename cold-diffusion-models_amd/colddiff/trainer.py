@@ -19,6 +19,7 @@ import torch
 from torch.utils import data
 
 from . import flat, parallel
+from .evaluate import EvalMixin
 from . import runtime as rt
 
 
@@ -133,7 +134,7 @@ def _match_module_prefix(sd, target_keys):
     return sd
 
 
-class Trainer(object):
+class Trainer(EvalMixin):
     AUG_DATASETS = ('mnist', 'cifar10', 'flower', 'celebA', 'AFHQ', 'train')
 
     def __init__(self, diffusion_model, folder, *, ema_decay=0.995, image_size=128, train_batch_size=32, train_lr=2e-5,
@@ -194,6 +195,7 @@ class Trainer(object):
             # (every rank draws its own shard: the seed is offset by the rank)
             return None, SyntheticImages(self.batch_size, self.core.channels, self.image_size, self.device, seed=seed + parallel.rank())
         aug = dataset in self.AUG_DATASETS
+        self.ds_augment = aug
         print(dataset, "DA used" if aug else "")
         if self.device_data:
             cache = DeviceImageCache(folder, self.image_size, self.device)

@@ -221,6 +221,14 @@ int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda, const void
 int cdf_augment_batch(const void* cache, long long N, int S, int C, const long long* idx, const int* oy, const int* ox,
                       const int* flip, float* out, int B, int H, int W, void* stream);
 
+/* Metric step after sampling (deblurring_diffusion_pytorch.py:1677-1702): SSIM as pytorch_msssim.ssim computes it (11-tap Gaussian
+ * window sigma 1.5 given by the caller as 11 HOST floats, "valid" filtering along H then W, C1 = (0.01 L)^2, C2 = (0.03 L)^2).
+ * x, y: [planes][H][W] fp32 (planes = B * C); partial[plane][tile] (cdf_ssim_tiles(H, W) tiles of 32 x 32 valid positions per plane)
+ * receives the SUM of the SSIM map over the tile; the caller divides the per-plane sums by (H-10)(W-10) and averages. */
+int cdf_ssim_tiles(int H, int W);
+int cdf_ssim_partial(const float* x, const float* y, float* partial, int planes, int H, int W, const float* window11, float C1,
+                     float C2, void* stream);
+
 /* parameter layout <-> GEMM layout: dst[t][r][c] = src[c*s_c + r*s_r + t*s_t] (c >= C zero-filled up to ldc);
  * g[c*s_c + r*s_r + t*s_t] (+)= sum_z ws[z][t][r][c] */
 int cdf_pack_weight(const float* src, float* dst, int T, int R, int C, int ldc, long long s_t, long long s_r,
