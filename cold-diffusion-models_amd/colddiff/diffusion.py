@@ -361,6 +361,20 @@ class DeblurDiffusion(nn.Module):
         t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
         return self.p_losses(x, t, *args, **kwargs)
 
+    # -- forward() in two phases, for the Trainer's degradation prefetch: the blur chain of micro-batch i+1 (up to T sequential
+    # steps on B*C planes: 96 of 256 CUs at B = 32) does not depend on the network and runs on a side stream under the
+    # forward / backward of micro-batch i.  prepare() + loss_prepared() == forward(): same draws, same kernels.
+    def prepare(self, x):
+        b, c, h, w, device, img_size = *x.shape, x.device, self.image_size
+        assert h == img_size and w == img_size, f'height and width of image must be {img_size}'
+        assert self.train_routine == 'Final'
+        t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
+        return x, t, self.q_sample(x_start=x, t=t)
+
+    def loss_prepared(self, prep):
+        x_start, t, x_blur = prep
+        return D.loss(x_start, self.denoise_fn(x_blur, t), self.loss_type)
+
 
 # ===================================================================================================
 # denoising ("hot" Gaussian-noise baseline with cold-style samplers)

@@ -254,6 +254,29 @@ class Trainer(EvalMixin):
         x2 = self._second(og_img)
         return og_img if x2 is None else x2
 
+    # -- degradation prefetch (deblurring: q_sample is up to T sequential blur steps on B*C planes, independent of the network) ----
+    _pending = None
+    _side = None
+
+    def _can_prefetch(self):
+        """Only for the plain loop on a HIP device: not when a test / subclass replaced _loss, not for two-image packages."""
+        return (self.device.type == 'cuda' and hasattr(self.core, 'prepare') and '_loss' not in self.__dict__
+                and type(self)._loss is Trainer._loss and not self.pair_noise and rt._lib_override is None
+                and getattr(self.core, 'train_routine', None) == 'Final' and os.environ.get("COLDDIFF_PREFETCH", "1") != "0")
+
+    def _launch_prepare(self):
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+            self._side.wait_stream(main)                     # once: model / kernel-stack tensors created on the main stream are complete
+        with torch.cuda.stream(self._side):
+            prep = self.core.prepare(self._next_batch())
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        for t in prep:
+            t.record_stream(main)                            # produced on the side stream, consumed (and freed) on the main stream
+        return prep, ev
+
     def _loss(self, batch):
         x2 = self._second(batch)
         return self.core(batch) if x2 is None else self.core(batch, x2)
@@ -264,10 +287,19 @@ class Trainer(EvalMixin):
         acc = self.gradient_accumulate_every
         scale = 1.0 / (acc * parallel.world_size())
         total = None
+        prefetch = self._can_prefetch()
         for i in range(acc):
             if self.sync is not None:
                 self.sync.begin()
-            loss = torch.mean(self._loss(self._next_batch()))
+            if prefetch:
+                if self._pending is None:
+                    self._pending = self._launch_prepare()
+                prep, ev = self._pending
+                torch.cuda.current_stream().wait_event(ev)
+                self._pending = self._launch_prepare()       # micro-batch i+1 is degraded under the forward / backward of micro-batch i
+                loss = torch.mean(self.core.loss_prepared(prep))
+            else:
+                loss = torch.mean(self._loss(self._next_batch()))
             if self.sync is not None and i == acc - 1:
                 self.sync.arm()
             (loss * scale).backward()

@@ -235,3 +235,26 @@ def test_gradsync_single_rank_rccl():
     finally:
         parallel.set_engine(None)
         dist.destroy_process_group()
+
+
+def test_degradation_prefetch_is_bit_identical(monkeypatch):
+    """Trainer's side-stream prefetch of q_sample (deblurring) must not change a single bit of the training trajectory."""
+    from deblurring_diffusion_pytorch import GaussianDiffusion, Trainer, Unet
+    out = []
+    for pf in ("0", "1"):
+        monkeypatch.setenv("COLDDIFF_PREFETCH", pf)
+        torch.manual_seed(3)
+        net = quiet(Unet, dim=16, dim_mults=(1, 2), channels=3).to(DEV)
+        d = GaussianDiffusion(net, image_size=32, device_of_kernel="cuda", channels=3, timesteps=20, kernel_size=5, kernel_std=0.3,
+                              blur_routine="Exponential_reflect").to(DEV)
+        tr = Trainer(d, None, image_size=32, train_batch_size=8, train_lr=1e-3, train_num_steps=4, gradient_accumulate_every=2,
+                     dataset="synthetic", results_folder="/tmp/cdf_prefetch_res")
+        assert tr._can_prefetch() == (pf == "1")
+        torch.manual_seed(5)
+        losses = []
+        for _ in range(4):
+            losses.append(tr.train_step())
+            tr.step += 1
+        torch.cuda.synchronize()
+        out.append((tr.arena.data.clone(), torch.stack(losses).cpu()))
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][0], out[1][0])
