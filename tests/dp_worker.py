@@ -1,6 +1,6 @@
 """Worker for tests/test_dp.py: one rank of a multi-process gloo data-parallel run on the CPU simulator.
 
-argv: out_path nsteps bucket_bytes mode
+argv: out_path nsteps bucket_bytes mode [hip]        ("hip": both ranks on cuda:0 with the product library, gloo moving CUDA tensors)
   mode 'once'  : loss = L1(x, f(q(x, e, t), t))                         (the denoising package's p_losses)
   mode 'twice' : the network runs TWICE per loss (as RESOL:702-716 'Final_random_mean_and_actual' does):
                  loss = L1(x, f(q(x,e,t), t)) + L1(x, f(q(x,-e,t), t))
@@ -18,7 +18,9 @@ for p in (os.path.join(REPO, "cold-diffusion-models_amd"), HERE, REPO):
 import torch  # noqa: E402
 from emu_util import install_emu  # noqa: E402
 
-install_emu()
+ON_HIP = len(sys.argv) > 5 and sys.argv[5] == "hip"
+if not ON_HIP:
+    install_emu()
 from colddiff import parallel  # noqa: E402
 from denoising_diffusion_pytorch import GaussianDiffusion, Trainer, Unet  # noqa: E402
 
@@ -35,7 +37,11 @@ if rank == 1:      # ranks must converge to rank 0's weights through the initial
     with torch.no_grad():
         for p in net.parameters():
             p.add_(1.0)
+if ON_HIP:
+    net = net.to("cuda:0")
 diff = GaussianDiffusion(net, image_size=8, channels=3, timesteps=10)
+if ON_HIP:
+    diff = diff.to("cuda:0")
 tr = Trainer(diff, None, image_size=8, train_batch_size=2, train_lr=1e-3, train_num_steps=nsteps, gradient_accumulate_every=2,
              dataset="synthetic", results_folder=os.path.join(os.path.dirname(out_path), f"res{rank}"))
 # the per-rank RNG streams must differ after construction (every rank draws its own t / noise)
@@ -75,6 +81,8 @@ batches = [[[(torch.rand(2, 3, 8, 8, generator=g) * 2 - 1, torch.randn(2, 3, 8, 
 
 
 def loss_of(x, e, t):
+    if ON_HIP:
+        x, e, t = x.to("cuda:0"), e.to("cuda:0"), t.to("cuda:0")
     if mode == "once":
         return tr.core.p_losses(x, e, t)
     return tr.core.p_losses(x, e, t) + tr.core.p_losses(x, -e, t)
@@ -87,6 +95,8 @@ for s in range(nsteps):
     tr.step += 1
 assert all(pend == 0 for _, pend in launch_log), launch_log
 assert [b for b, _ in launch_log[:len(sync.bounds)]] == sync.order          # same issue order on every rank
-torch.save({"sd": {k: v.clone() for k, v in net.state_dict().items()}, "buckets": len(sync.bounds),
+if ON_HIP:
+    torch.cuda.synchronize()
+torch.save({"sd": {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, "buckets": len(sync.bounds),
             "max_uses": max(sync.uses), "early": min(early)}, out_path + f".rank{rank}")
 torch.distributed.barrier()

@@ -39,9 +39,22 @@ def test_buckets_are_whole_tensors():
 @pytest.mark.parametrize("bucket_bytes,mode,min_buckets", [(512, "once", 8), (1024, "once", 8), (4096, "once", 8), (0, "once", 1),
                                                             (1024, "twice", 8), (0, "twice", 1)])
 def test_two_rank_training_matches_global_batch(tmp_path, bucket_bytes, mode, min_buckets):
+    _two_rank_case(tmp_path, bucket_bytes, mode, min_buckets, hip=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bucket_bytes,mode,min_buckets", [(1024, "twice", 8), (0, "once", 1)])
+def test_two_rank_training_on_the_gpu(tmp_path, bucket_bytes, mode, min_buckets):
+    """The same two-rank run with the product library: both ranks on cuda:0, gloo carrying the CUDA gradient buckets (RCCL refuses two
+    ranks on one device).  Exercises on hardware what the CPU run cannot: the side comm stream, the events between the backward
+    kernels and each bucket's all-reduce, and the compute stream's wait before Adam."""
+    _two_rank_case(tmp_path, bucket_bytes, mode, min_buckets, hip=True)
+
+
+def _two_rank_case(tmp_path, bucket_bytes, mode, min_buckets, hip):
     out, nsteps = str(tmp_path / "w.pt"), 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(HERE, "dp_worker.py"), out, str(nsteps), str(bucket_bytes), mode]
+           "--master-port", str(_free_port()), os.path.join(HERE, "dp_worker.py"), out, str(nsteps), str(bucket_bytes), mode] + (["hip"] if hip else [])
     env = dict(os.environ, OMP_NUM_THREADS="2")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
