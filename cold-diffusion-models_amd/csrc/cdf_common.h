@@ -105,6 +105,17 @@ int cdf_check_launch(const char* what);
 
 static inline int cdf_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// XCD-aware work order.  Workgroups are handed to the 8 XCDs (each with its own 4 MB L2) round-robin in dispatch order, so
+// work items that are neighbours in memory -- adjacent image tiles with a shared halo, the taps of one pixel range -- land on 8
+// different L2s and each fetches the shared bytes from HBM again.  Re-numbered so that every XCD walks a CONTIGUOUS range of
+// work ids: bid -> the bid-th item of XCD (bid & 7)'s range.
+__device__ __forceinline__ int cdf_xcd_order(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
 // ---- device helpers ---------------------------------------------------------------------
 __device__ __forceinline__ float cdf_wave_sum(float v) {
 #pragma unroll

@@ -45,12 +45,17 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx
 
     const int tid = threadIdx.x;
     const int tiles_w = (W + TBW - 1) / TBW, tiles_h = (H + TBH - 1) / TBH;
-    int t = blockIdx.x;
+    // XCD-aware tile order: the (TBW+6) x (TBH+6) halo is 2.1x the tile, i.e. half of what a block reads is shared with its
+    // neighbours.  In dispatch order the neighbours sit on other XCDs and every L2 fetched the shared rows from HBM again
+    // (rocprofv3 FETCH_SIZE: 2.3x the tensor); an XCD now walks a contiguous run of tiles of one channel group (its 64 resident
+    // blocks = one 128 x 128 image).
+    const int vid = cdf_xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    int t = vid % (int)gridDim.x;
     const int bx = t % tiles_w;
     t /= tiles_w;
     const int by = t % tiles_h, b = t / tiles_h;
     const int X0 = bx * TBW, Y0 = by * TBH;
-    const int cq0 = blockIdx.y * 8;
+    const int cq0 = (vid / (int)gridDim.x) * 8;
 
     for (int i = tid; i < DW_TAPS * 8; i += 256) {
         const int tp = i >> 3, l = i & 7;
@@ -158,11 +163,16 @@ __global__ void __launch_bounds__(256) dwconv7_wgrad_partial_kernel(const float*
     constexpr int TW = 8;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: branches on it are uniform
     const int l16 = lane & 15, slot = lane >> 4;
-    const int c = blockIdx.x * 64 + l16 * 4, b = blockIdx.z;
+    // XCD-aware chunk order: a chunk of rows_per_chunk (= 4 at 128 rows) image rows reads 6 halo rows of x besides its own, shared
+    // with the chunks above and below; consecutive chunks of an image now run on one XCD and find them in its L2 (FETCH_SIZE was
+    // 2.5x the two tensors).
+    const int vid = cdf_xcd_order(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+    const int bid_c = vid % (int)gridDim.x, bid_chunk = (vid / (int)gridDim.x) % (int)gridDim.y, b = vid / (int)(gridDim.x * gridDim.y);
+    const int c = bid_c * 64 + l16 * 4;
     const int C4r = (C + 3) & ~3;
     const bool cv = c < C4r;
     const int cc = cv ? c : 0;
-    const int y0 = blockIdx.y * rows_per_chunk;
+    const int y0 = bid_chunk * rows_per_chunk;
     int y1 = y0 + rows_per_chunk;
     if (y1 > H) y1 = H;
     const int strips_w = (W + TW - 1) / TW, nstrips = (y1 - y0) * strips_w;
@@ -210,7 +220,7 @@ __global__ void __launch_bounds__(256) dwconv7_wgrad_partial_kernel(const float*
         v.x += __shfl_xor(v.x, 16); v.y += __shfl_xor(v.y, 16); v.z += __shfl_xor(v.z, 16); v.w += __shfl_xor(v.w, 16);
         v.x += __shfl_xor(v.x, 32); v.y += __shfl_xor(v.y, 32); v.z += __shfl_xor(v.z, 32); v.w += __shfl_xor(v.w, 32);
     };
-    float* dst = part + (((long long)b * gridDim.y + blockIdx.y) * (DW_TAPS + 1)) * C;
+    float* dst = part + (((long long)b * gridDim.y + bid_chunk) * (DW_TAPS + 1)) * C;
     auto put = [&](int tap, const float4& v) {
         if (slot != 0 || !cv) return;
         float* p = dst + (long long)tap * C + c;
