@@ -133,11 +133,16 @@ __device__ __forceinline__ int cdf_sp_swizzle(int bid, int nblk) {
 // fp32 accumulate); NS = 1: single-pass bf16 operands (the hi planes only; al / bl are never read and their loads fold away).
 template <int NS>
 __device__ __forceinline__ void cdf_mma_sp(f32x16_t& acc, const bf16x8_v& ah, const bf16x8_v& al, const bf16x8_v& bh, const bf16x8_v& bl) {
+#if CDF_ABLATE & 2
+    asm volatile("" ::"v"(ah), "v"(al), "v"(bh), "v"(bl));
+    (void)acc;
+#else
     if constexpr (NS == 3) {
         acc = CDF_MFMA_BF16(al, bh, acc);
         acc = CDF_MFMA_BF16(ah, bl, acc);
     }
     acc = CDF_MFMA_BF16(ah, bh, acc);
+#endif
 }
 
 // All products of one K chunk (two k16 steps) of a wave tile, TERM-MAJOR: consecutive MFMAs go to different accumulators
@@ -151,7 +156,7 @@ __device__ __forceinline__ void cdf_mma_tile(f32x16_t (&acc)[MT][NT], const bf16
                                              const bf16x8_v (&bh)[2][NT], const bf16x8_v (&bl)[2][NT]) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        if constexpr (NS == 3 && CDF_TERM_MAJOR) {
+        if constexpr (NS == 3 && CDF_TERM_MAJOR && !(CDF_ABLATE & 2)) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -550,6 +555,12 @@ __global__ void split_bf16_kernel(const float* x, int ldx, unsigned short* hi, u
         if (lo) *(uint2*)(lo + r * ldo + c) = l;
     }
 }
+
+#if CDF_ABLATE & 1
+#define CDF_GLDS16_K(g, l) ((void)(g), (void)(l))       // tuning aid: no operand DMA inside the K loops of the LDS-resident-input kernels
+#else
+#define CDF_GLDS16_K(g, l) CDF_GLDS16(g, l)
+#endif
 
 struct SpxArgs {
     const unsigned short* x_hi;
@@ -1031,8 +1042,8 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
 
     auto fetch_a = [&](int q, int buf) {                     // segment a_seg[q] of the chunk the pointers stand at -> halo buffer buf
         unsigned short* seg = abuf0 + buf * ABUF + a_seg[q] * 16 * RE;
-        CDF_GLDS16(pa_hi[q], seg);
-        if constexpr (NS == 3) CDF_GLDS16(pa_lo[q], seg + PLANE_A);
+        CDF_GLDS16_K(pa_hi[q], seg);
+        if constexpr (NS == 3) CDF_GLDS16_K(pa_lo[q], seg + PLANE_A);
     };
     auto advance_a = [&]() {
 #pragma unroll
@@ -1049,8 +1060,8 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
         for (int p = 0; p < SBI; ++p) {
             const int seg = BN == 64 ? (wave & 3) : wave * SB + p;
             const size_t woff = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)b_row[p]) * (unsigned)a.ldk + (unsigned)(c * BK + q8);
-            CDF_GLDS16(a.w_hi + woff, st + seg * 16 * RE);
-            if constexpr (NS == 3) CDF_GLDS16(a.w_lo + woff, st + PLANE_B + seg * 16 * RE);
+            CDF_GLDS16_K(a.w_hi + woff, st + seg * 16 * RE);
+            if constexpr (NS == 3) CDF_GLDS16_K(a.w_lo + woff, st + PLANE_B + seg * 16 * RE);
         }
     };
     constexpr int NPL = NS == 3 ? 2 : 1;                     // operand planes in flight (hi [, lo])
@@ -1316,8 +1327,8 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
             const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)a_x[q] < (unsigned)W;
             const size_t off = ((size_t)((img * a.H + (ok ? y : 0)) * W + (ok ? a_x[q] : 0))) * (unsigned)a.ldx + (unsigned)(c * BK + q8);
             unsigned short* seg = abuf0 + buf * ABUF + a_seg[q] * 16 * RE;
-            CDF_GLDS16(ok ? a.x_hi + off : a.zero, seg);
-            if constexpr (NS == 3) CDF_GLDS16(ok ? a.x_lo + off : a.zero, seg + PLANE_A);
+            CDF_GLDS16_K(ok ? a.x_hi + off : a.zero, seg);
+            if constexpr (NS == 3) CDF_GLDS16_K(ok ? a.x_lo + off : a.zero, seg + PLANE_A);
         }
     };
     auto fetch_b = [&](int c, int t, int stage) {
@@ -1328,8 +1339,8 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
         for (int p = 0; p < SBI; ++p) {
             const int seg = BN == 64 ? (wave & 3) : wave * SB + p;
             const size_t woff = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)b_row[p]) * (unsigned)a.ldk + (unsigned)(c * BK + q8);
-            CDF_GLDS16(a.w_hi + woff, st + seg * 16 * RE);
-            if constexpr (NS == 3) CDF_GLDS16(a.w_lo + woff, st + PLANE_B + seg * 16 * RE);
+            CDF_GLDS16_K(a.w_hi + woff, st + seg * 16 * RE);
+            if constexpr (NS == 3) CDF_GLDS16_K(a.w_lo + woff, st + PLANE_B + seg * 16 * RE);
         }
     };
     constexpr int NPL = NS == 3 ? 2 : 1;
