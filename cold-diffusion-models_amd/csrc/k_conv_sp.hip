@@ -48,6 +48,14 @@ struct SpPhase {
 #if CDF_PROFILE
 __device__ unsigned long long cdf_prof[64 * 8 * 6];
 extern "C" int cdf_debug_read_prof(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(cdf_prof), sizeof(cdf_prof)); }
+// first 256 blocks of conv_igemm_rowhalo_kernel (thread 0): 100 MHz ticks in [prologue until the first data landed, K loop,
+// epilogue until its stores are acknowledged], tiles (tools/probes/run_prof_tile.py)
+__device__ unsigned long long cdf_prof_tile[256 * 4];
+extern "C" int cdf_debug_read_prof_tile(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(cdf_prof_tile), sizeof(cdf_prof_tile)); }
+#define CDF_PROF_T() wall_clock64()
+#endif
+#if !CDF_PROFILE
+#define CDF_PROF_T() 0ull
 #endif
 #ifndef CDF_HALO_PIPE
 #define CDF_HALO_PIPE 0  // 1: conv_igemm_halo_kernel reads the fragments of tap step s+1 under the MFMAs of step s (needs >= 4 weight stages).
@@ -1291,6 +1299,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int M = a.B * a.QH * a.QW;
     const int tiles_n = (a.Cout + BN - 1) / BN, tiles_m = M / BM;
+    const unsigned long long pt0 = CDF_PROF_T();             // (profile builds only)
     const int tile = cdf_sp_swizzle(blockIdx.x, tiles_m * tiles_n);
     const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
     const SpPhase& ph = a.ph[0];
@@ -1370,6 +1379,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
     for (int u = 0; u < NB - 1; ++u) fetch_b(0, u, u);
     CDF_WAIT_DMA_LEAVE((NB - 2) * PB);
     CDF_LDS_BARRIER();
+    const unsigned long long pt1 = CDF_PROF_T();
     bf16x8_v ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
     const bool late = a.dephase != 0 && wave >= NW / 2;      // (wave-uniform)
     if (late) {
@@ -1435,8 +1445,18 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
     if (late) mma_frags();
     CDF_WAIT_DMA_LEAVE(0);
     CDF_LDS_BARRIER();
+    const unsigned long long pt2 = CDF_PROF_T();
 
     cdf_sp_epilogue<BM, BN, WM, WN>(a, ph, acc, (float*)smem_raw, tile_m, tile_n, M, tid);
+#if CDF_PROFILE
+    CDF_WAIT_DMA_LEAVE(0);                                   // (count the epilogue until its stores are acknowledged)
+    if (tid == 0 && blockIdx.x < 256) {
+        unsigned long long* o = cdf_prof_tile + blockIdx.x * 4;
+        o[0] = pt1 - pt0; o[1] = pt2 - pt1; o[2] = CDF_PROF_T() - pt2; o[3] = 1;
+    }
+#else
+    (void)pt0; (void)pt1; (void)pt2;
+#endif
 }
 
 // weight gradient with both operands pre-split ([pixels][ld] bf16 hi / lo planes)
