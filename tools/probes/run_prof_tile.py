@@ -37,3 +37,11 @@ for persist in (0,):
         us = [sum(r[i] for r in rows) / n / 100.0 for i in range(3)]
         print(f"persist {persist} {Cin}->{Cout}@{H}: kernel {e0.elapsed_time(e1)*1e3:.0f} us; per tile (avg over {len(rows)} blocks, {n} tiles): "
               f"prologue {us[0]:.2f} us  K loop {us[1]:.2f} us  epilogue+store ack {us[2]:.2f} us", flush=True)
+        b6 = (ctypes.c_ulonglong * (64 * 8 * 6))()
+        raw.cdf_debug_read_prof(b6)
+        for grp, name in ((range(0, 4), "waves 0-3 (early)"), (range(4, 8), "waves 4-7 (late)")):
+            rw = [[b6[(b * 8 + wv) * 6 + i] for i in range(6)] for b in range(64) for wv in grp]
+            rw = [r for r in rw if r[5] > 0]
+            if rw:
+                a5 = [sum(r[i] / r[5] for r in rw) / len(rw) for i in range(5)]
+                print(f"    {name}: shader clocks per K step: DMA issue {a5[0]:.0f}  fragment reads {a5[1]:.0f}  MFMAs {a5[2]:.0f}  DMA wait {a5[3]:.0f}  barrier {a5[4]:.0f}  (sum {sum(a5):.0f})", flush=True)
