@@ -1397,12 +1397,21 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
     }
     auto mma_frags = [&]() { cdf_mma_tile<NS, MT, NT>(acc, ah, al, bh, bl); };
     int rd = 0, par = 0;                                     // weight stage / row buffer of the current step
+#if CDF_PROFILE
+    unsigned long long qt[6] = {0, 0, 0, 0, 0, 0};            // shader clocks in: DMA issue, fragment reads (until landed), MFMAs, DMA wait, barrier; steps
+#endif
     for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int g = t / 3, i3 = t - 3 * g;
+#if CDF_PROFILE
+            const unsigned long long q0 = __builtin_readcyclecounter();
+#endif
             if (i3 == 0) fetch_a(g == 2 ? c + 1 : c, g == 2 ? 0 : g + 1, par ^ 1);      // the next tap row's input rows
             fetch_b(t + NB - 1 < 9 ? c : c + 1, (t + NB - 1) % 9, rd == 0 ? NB - 1 : rd - 1);
+#if CDF_PROFILE
+            const unsigned long long q1 = __builtin_readcyclecounter();
+#endif
             const unsigned short* sa = abuf0 + par * ABUF;
             const unsigned short* sb = bst0 + rd * BSTAGE;
             rd = rd + 1 == NB ? 0 : rd + 1;
@@ -1431,14 +1440,30 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
                 CDF_SCHED_FENCE();                           // (the reads overwrite the fragments just multiplied: hoisting them doubles the live set)
             }
             read_frags();
+#if CDF_PROFILE
+            CDF_WAIT_LDS();
+            const unsigned long long q2 = __builtin_readcyclecounter();
+#endif
             if (!late) mma_frags();
+#if CDF_PROFILE
+            asm volatile("s_nop 0" ::"v"(acc[0][0][0]));          // (the last MFMA result is due here)
+            const unsigned long long q3 = __builtin_readcyclecounter();
+#endif
             // the weights of step + 1 (requested 2 steps ago, AFTER that step's row requests) have landed; still in flight: the
             // requests of the last two steps -- two weight steps, plus one group of rows if one of them was a group's first step
             if (i3 <= 1)
                 CDF_WAIT_DMA_LEAVE((NB - 2) * PB + PAG);
             else
                 CDF_WAIT_DMA_LEAVE((NB - 2) * PB);
+#if CDF_PROFILE
+            const unsigned long long q4 = __builtin_readcyclecounter();
+#endif
             CDF_LDS_BARRIER();
+#if CDF_PROFILE
+            // (late waves multiply between q1 and q2: their "fragment reads" column contains their MFMAs)
+            const unsigned long long q5 = __builtin_readcyclecounter();
+            qt[0] += q1 - q0; qt[1] += q2 - q1; qt[2] += q3 - q2; qt[3] += q4 - q3; qt[4] += q5 - q4; ++qt[5];
+#endif
             if (i3 == 2) par ^= 1;
         }
     }
@@ -1453,6 +1478,10 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
     if (tid == 0 && blockIdx.x < 256) {
         unsigned long long* o = cdf_prof_tile + blockIdx.x * 4;
         o[0] = pt1 - pt0; o[1] = pt2 - pt1; o[2] = CDF_PROF_T() - pt2; o[3] = 1;
+    }
+    if (lane == 0 && blockIdx.x < 64) {
+        unsigned long long* o = cdf_prof + (blockIdx.x * NW + wave) * 6;
+        for (int i = 0; i < 6; ++i) o[i] = qt[i];
     }
 #else
     (void)pt0; (void)pt1; (void)pt2;
