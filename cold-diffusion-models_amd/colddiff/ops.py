@@ -209,9 +209,10 @@ def conv_cin4_bwd(x, dy, weight, bias, need_dx, dx=None, dx_accumulate=0):
     part = torch.empty((nch, KK * Cin, Cout), device=x.device, dtype=torch.float32)
     bsum = torch.empty((nch, Cout), device=x.device, dtype=torch.float32) if bias is not None else None
     L.cdf_conv_cin4_wgrad(P(x), P(dy), ld_of(dy), P(part), P(bsum), B, H, W, Cin, Cout, k, S)
-    L.cdf_unpack_reduce(P(part), P(grad_of(weight)), nch, KK, Cin, Cout, Cout, 1, KK, Cin * KK, 1, S)
     if bias is not None:
-        L.cdf_unpack_reduce(P(bsum), P(grad_of(bias)), nch, 1, 1, Cout, Cout, 0, 0, 1, 1, S)
+        L.cdf_unpack_reduce_bias(P(part), P(grad_of(weight)), nch, KK, Cin, Cout, Cout, 1, KK, Cin * KK, P(bsum), P(grad_of(bias)), Cout, 1, S)
+    else:
+        L.cdf_unpack_reduce(P(part), P(grad_of(weight)), nch, KK, Cin, Cout, Cout, 1, KK, Cin * KK, 1, S)
     if not need_dx:
         return None
     if dx is None:
@@ -278,9 +279,7 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None, xa_s=No
         L.cdf_conv_wgrad_bf16x(P(xa_s[0]), P(xa_s[1]), xa_s[0].shape[-1], P(xb_s[0]), P(xb_s[1]), xb_s[0].shape[-1], P(zero_page(dev)),
                                P(ws), ldo, B, wplan.QH, wplan.QW, wplan.HA, wplan.WA, wplan.sa, wplan.HB, wplan.WB, wplan.sb, CA, CB,
                                wplan.ntaps, wplan.desc, ns, P(bsum), S)
-        L.cdf_unpack_reduce(P(ws), P(gparam), ns, wplan.ntaps, CA, CB, ldo, s_t, s_r, s_c, 1, S)
-        if gbias is not None:
-            L.cdf_unpack_reduce(P(bsum), P(gbias), ns, 1, 1, CB, ldo, 0, 0, 1, 1, S)
+        _reduce_slabs(L, ws, gparam, ns, wplan.ntaps, CA, CB, ldo, s_t, s_r, s_c, bsum, gbias, S)
         return
     if rt.precision != "f32" and CA >= 128 and CB >= 128 and M >= 2048:   # full 128x128 tiles only; thinner layers are faster on the fp32 kernel
         # split-precision bf16 MFMA kernel: 128x128 tiles, resident twice per CU (512 slots)
@@ -291,9 +290,7 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None, xa_s=No
         bsum = torch.empty((ns, ldo), device=xa.device, dtype=torch.float32) if gbias is not None else None
         L.cdf_conv_wgrad_bf16(P(xa), ld_of(xa), P(xb), ld_of(xb), P(ws), ldo, B, wplan.QH, wplan.QW, wplan.HA, wplan.WA, wplan.sa,
                               wplan.HB, wplan.WB, wplan.sb, CA, CB, wplan.ntaps, wplan.desc, ns, P(bsum), S)
-        L.cdf_unpack_reduce(P(ws), P(gparam), ns, wplan.ntaps, CA, CB, ldo, s_t, s_r, s_c, 1, S)
-        if gbias is not None:
-            L.cdf_unpack_reduce(P(bsum), P(gbias), ns, 1, 1, CB, ldo, 0, 0, 1, 1, S)
+        _reduce_slabs(L, ws, gparam, ns, wplan.ntaps, CA, CB, ldo, s_t, s_r, s_c, bsum, gbias, S)
         return
     tiles_f32 = (1 if CA <= 64 else (CA + 127) // 128) * (1 if CB <= 64 else (CB + 127) // 128) * wplan.ntaps
     ns = best_nsplit(tiles_f32, 1024, max(1, M // 256))
@@ -302,9 +299,15 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None, xa_s=No
     bsum = torch.empty((ns, ldo), device=xa.device, dtype=torch.float32) if gbias is not None else None
     L.cdf_conv_wgrad(P(xa), ld_of(xa), P(xb), ld_of(xb), P(ws), ldo, B, wplan.QH, wplan.QW, wplan.HA, wplan.WA, wplan.sa,
                      wplan.HB, wplan.WB, wplan.sb, CA, CB, wplan.ntaps, wplan.desc, ns, 1, 0, 0, 0, P(bsum), S)
-    L.cdf_unpack_reduce(P(ws), P(gparam), ns, wplan.ntaps, CA, CB, ldo, s_t, s_r, s_c, 1, S)
+    _reduce_slabs(L, ws, gparam, ns, wplan.ntaps, CA, CB, ldo, s_t, s_r, s_c, bsum, gbias, S)
+
+
+def _reduce_slabs(L, ws, gparam, ns, ntaps, CA, CB, ldo, s_t, s_r, s_c, bsum, gbias, S):
+    """gparam += sum over the split-K slabs (and gbias += sum over the bias partials, in the same launch)."""
     if gbias is not None:
-        L.cdf_unpack_reduce(P(bsum), P(gbias), ns, 1, 1, CB, ldo, 0, 0, 1, 1, S)
+        L.cdf_unpack_reduce_bias(P(ws), P(gparam), ns, ntaps, CA, CB, ldo, s_t, s_r, s_c, P(bsum), P(gbias), ldo, 1, S)
+    else:
+        L.cdf_unpack_reduce(P(ws), P(gparam), ns, ntaps, CA, CB, ldo, s_t, s_r, s_c, 1, S)
 
 
 def colsum_into(gvec, x, C, nseg=1):

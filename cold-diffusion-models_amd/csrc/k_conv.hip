@@ -461,10 +461,16 @@ __global__ void pack_weight_kernel(const float* src, float* dst, int T, int R, i
 // slabs rl, rl + SL, ... in four independent chains (four loads in flight per lane): with 4 lanes x 2 chains the ~230-slab
 // reductions of the 128 x 128-pixel layers were ~30 dependent round trips (80 us for 67 MB).  The summation tree is fixed
 // by (SL, nsplit): deterministic.
+// (bws / gb / bC / bld: optional second reduction folded into the same launch -- the bias-gradient partials [nsplit][bld] that the
+// weight-gradient kernels produce next to their slabs: gb[c] (+)= sum_z bws[z][c].  The LAST blockIdx.y row of the grid does it.)
 template <int SL>
 __global__ void __launch_bounds__(64 * SL) unpack_reduce_kernel(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc,
-                                                                long long s_t, long long s_r, long long s_c, int accumulate) {
+                                                                long long s_t, long long s_r, long long s_c, int accumulate,
+                                                                const float* bws, float* gb, int bC, int bld) {
     __shared__ float red[SL][64];
+    if (bws != nullptr && blockIdx.y == 1) {                 // the fused bias reduction: one 1 x 1 x bC "tensor" with unit strides
+        ws = bws; g = gb; T = 1; R = 1; C = bC; ldc = bld; s_t = 0; s_r = 0; s_c = 1;
+    }
     const long long n = (long long)T * R * C;
     const long long slab = (long long)T * R * ldc;
     const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -684,14 +690,27 @@ extern "C" int cdf_pack_weight(const float* src, float* dst, int T, int R, int C
     return cdf_check_launch("pack_weight");
 }
 
+static int launch_unpack_reduce(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t, long long s_r,
+                                long long s_c, int accumulate, const float* bws, float* gb, int bC, int bld, hipStream_t s) {
+    const dim3 grid(ew_grid2((long long)T * R * C * 4), bws ? 2 : 1);
+    if (nsplit >= 32)       // 16 slab lanes: every lane still has >= 2 slabs
+        CDF_LAUNCH(unpack_reduce_kernel<16>, grid, dim3(1024), 0, s, ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld);
+    else
+        CDF_LAUNCH(unpack_reduce_kernel<4>, grid, dim3(256), 0, s, ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld);
+    return cdf_check_launch("unpack_reduce");
+}
+
 extern "C" int cdf_unpack_reduce(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t,
                                  long long s_r, long long s_c, int accumulate, void* stream) {
     CDF_REQUIRE(ws && g && nsplit > 0 && T > 0 && R > 0 && C > 0 && ldc >= C, "cdf_unpack_reduce: bad args");
-    if (nsplit >= 32)       // 16 slab lanes: every lane still has >= 2 slabs
-        CDF_LAUNCH(unpack_reduce_kernel<16>, dim3(ew_grid2((long long)T * R * C * 4)), dim3(1024), 0, CDF_S, ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate);
-    else
-        CDF_LAUNCH(unpack_reduce_kernel<4>, dim3(ew_grid2((long long)T * R * C * 4)), dim3(256), 0, CDF_S, ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate);
-    return cdf_check_launch("unpack_reduce");
+    return launch_unpack_reduce(ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate, nullptr, nullptr, 0, 0, CDF_S);
+}
+
+extern "C" int cdf_unpack_reduce_bias(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t,
+                                      long long s_r, long long s_c, const float* bias_ws, float* gbias, int bias_ld, int accumulate,
+                                      void* stream) {
+    CDF_REQUIRE(ws && g && bias_ws && gbias && nsplit > 0 && T > 0 && R > 0 && C > 0 && ldc >= C && bias_ld >= C, "cdf_unpack_reduce_bias: bad args");
+    return launch_unpack_reduce(ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate, bias_ws, gbias, C, bias_ld, CDF_S);
 }
 
 extern "C" int cdf_colsum_nchunk(int rows_per_seg) {

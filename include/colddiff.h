@@ -235,6 +235,10 @@ int cdf_pack_weight(const float* src, float* dst, int T, int R, int C, int ldc, 
                     long long s_c, void* stream);
 int cdf_unpack_reduce(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t,
                       long long s_r, long long s_c, int accumulate, void* stream);
+/* the same with the bias-gradient reduction of the same weight-gradient launch folded in (one launch instead of two):
+ * gbias[c] (+)= sum_z bias_ws[z * bias_ld + c], c < C (the `bsum` partials of cdf_conv_wgrad*). */
+int cdf_unpack_reduce_bias(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t, long long s_r,
+                           long long s_c, const float* bias_ws, float* gbias, int bias_ld, int accumulate, void* stream);
 
 /* out[seg][c] (+)= sum over the rows of segment seg of x[r*ld + c]  (bias / time-bias gradients);
  * ws >= nseg * cdf_colsum_nchunk(rows_per_seg) * C floats */
