@@ -327,8 +327,10 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
     if world > 1:
-        parallel.init_distributed("nccl")
-    device = torch.device("cuda", parallel.local_rank())
+        # RCCL over xGMI; COLDDIFF_DIST_BACKEND=gloo exists only so that the multi-rank code path can be exercised with several ranks on
+        # ONE GPU (RCCL refuses two ranks per device)
+        parallel.init_distributed(os.environ.get("COLDDIFF_DIST_BACKEND", "nccl"))
+    device = torch.device("cuda", parallel.local_rank() % torch.cuda.device_count())
     torch.cuda.set_device(device)
 
     log(f"building workload on {device} (world {world})")
