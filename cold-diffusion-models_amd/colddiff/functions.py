@@ -72,6 +72,7 @@ def want_presplit(Cin, Cout, k):
 
 
 _CIN4 = os.environ.get("CDF_CIN4", "1") != "0"    # direct kernels for the <= 4-input-channel image-side convs
+_ATTN_FUSED = os.environ.get("CDF_ATTN_FUSED", "1") != "0"   # to_out folded into the linear-attention product (ops.linattn_project)
 _LEAN = os.environ.get("CDF_LEAN", "1") != "0"    # skip fp32 copies of tensors only ever consumed as bf16 planes
 _LINEAR_SMALL_M = 256      # batch sizes up to this use the skinny-linear kernels
 _ALWAYS_PRESPLIT = os.environ.get("CDF_ALWAYS_PRESPLIT", "0") != "0"
@@ -393,10 +394,17 @@ class LinAttnBlockFn(torch.autograd.Function):
         grad_on = ctx.needs_input_grad[0]   # anchor: True iff autograd is recording
         xn, mean, rstd = ops.layernorm_fwd(x, norm.g, norm.b, norm.eps, grad_on)
         qkv = conv_forward(xn, dim, att.to_qkv.weight, None)
-        o, cx, cxs, kmax, ksum = ops.linattn_fwd(qkv, att.heads, att.scale)
-        y = conv_forward(o, att.heads * 32, att.to_out.weight, att.to_out.bias, res=x)
         ctx.m = m
         _used(ctx, norm, att.to_qkv, att.to_out)
+        ctx.fused = _ATTN_FUSED and dim % 4 == 0
+        if ctx.fused:
+            # output projection folded into the attention product: the attention output is never materialised (ops.linattn_project)
+            cx, cxs, kmax, ksum = ops.linattn_context(qkv, att.heads, att.scale)
+            y, Mb = ops.linattn_project(qkv, cxs, att.to_out.weight, att.to_out.bias, x, att.heads)
+            ctx.save_for_backward(x, xn, mean, rstd, qkv, Mb, cx, cxs, kmax, ksum)
+            return y
+        o, cx, cxs, kmax, ksum = ops.linattn_fwd(qkv, att.heads, att.scale)
+        y = conv_forward(o, att.heads * 32, att.to_out.weight, att.to_out.bias, res=x)
         ctx.save_for_backward(x, xn, mean, rstd, qkv, o, cx, cxs, kmax, ksum)
         return y
 
@@ -405,8 +413,15 @@ class LinAttnBlockFn(torch.autograd.Function):
         x, xn, mean, rstd, qkv, o, cx, cxs, kmax, ksum = ctx.saved_tensors
         norm, att = ctx.m.fn.norm, ctx.m.fn.fn
         dim, HD = x.shape[-1], att.heads * 32
-        do = conv_backward(o, HD, dy, att.to_out.weight, att.to_out.bias)
-        dqkv = ops.linattn_bwd(qkv, do, cx, cxs, kmax, ksum, att.heads, att.scale)
+        if ctx.fused:
+            B, H, W, _ = qkv.shape
+            dqkv = torch.empty((B, H, W, 3 * HD), device=qkv.device, dtype=torch.float32)
+            dy = dy.contiguous()
+            dctx, rvec = ops.linattn_project_bwd(qkv, dy, o, cx, cxs, att.to_out.weight, att.to_out.bias, dqkv, att.heads, att.scale)   # (o = Mb here)
+            ops.linattn_bwd_core(qkv, dctx, rvec, kmax, ksum, dqkv, att.heads)
+        else:
+            do = conv_backward(o, HD, dy, att.to_out.weight, att.to_out.bias)
+            dqkv = ops.linattn_bwd(qkv, do, cx, cxs, kmax, ksum, att.heads, att.scale)
         dxn = conv_backward(xn, dim, dqkv, att.to_qkv.weight, None)
         dx = ops.copy_feat(dy)
         ops.layernorm_bwd(dxn, x, norm.g, norm.b, mean, rstd, dx=dx)

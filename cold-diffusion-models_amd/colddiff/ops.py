@@ -438,6 +438,110 @@ def linattn_bwd(qkv, dout, ctx, ctxs, kmax, ksum, heads, scale):
     return dqkv
 
 
+# -- linear attention with the output projection folded in (round 2) ---------------------------------------------------
+# Residual(PreNorm(LinearAttention)) ends in  y = to_out(q . blockdiag_h(scale ctx_h)) + b + x.  Both maps are linear in q, so
+# y[n] = q[n] . M_b + b + x[n]  with  M_b = blockdiag(scale ctx_b) . W_out^T  ([HD x dim], ONE small matrix per image).  The
+# attention output o ([B,n,HD], 268 MB per micro-batch at 128 x 128) is never written or read, the K = 32 per-head products
+# (1.3 TB/s: 32-deep GEMMs are all epilogue) and the separate to_out convolution become one K = 128 batched GEMM, and in the
+# backward pass d_o disappears the same way:  dq = dy . M_b^T,  dM_b = q^T dy  (one pass over q and dy instead of the two passes
+# (o, dy) for dW_out and (q, d_o) for dctx),  d(scale ctx_h) = dM_b[h] . W_h^T,  dW_h = sum_b (scale ctx_bh)^T dM_b[h].
+def _headsplit_plan(heads):
+    return cd.WgradPlan(1, 32, heads, 32, 1, heads, 32, 1, [(h, 0, h, 0) for h in range(heads)])
+
+
+_HEADSPLIT = {}
+
+
+def linattn_project(qkv, ctxs, w_out, b_out, res, heads):
+    """y = q . M_b + b_out + res,  M_b = blockdiag(ctxs[b]) . W_out^T.  Returns (y, Mb)."""
+    L, S = rt.lib(), rt.stream(qkv)
+    B, H, W, _ = qkv.shape
+    n, HD, dim = H * W, heads * 32, w_out.shape[0]
+    wp = packed(w_out, "conv_fwd")                            # [1][HD][r4(dim)]: row h*32 + e = W_out[:, h*32 + e]
+    ldw = wp.shape[-1]
+    Mb = torch.empty((B, HD, ldw), device=qkv.device, dtype=torch.float32)
+    # M_b[h*32 + d][c] = sum_e ctxs[b,h][d][e] W_out[c][h*32 + e]: B x heads GEMMs of 32 x 32 x dim
+    L.cdf_conv_gemm(P(ctxs), 32, P(wp), ldw, P(Mb), ldw, 1, 1, 32, 32, 1, 32, dim, 1, 32, 1, 1, 1, _one_tap(32).desc,
+                    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, B, heads * 1024, 0, HD * ldw, heads, 1024, 32 * ldw, 32 * ldw, S)
+    y = new_feat(qkv, B, H, W, dim)
+    ldq, ldy = ld_of(qkv), ld_of(y)
+    # y[b] = q[b] . M_b (+ bias + residual): one GEMM per image, K = HD
+    L.cdf_conv_gemm(P(qkv), ldq, P(Mb), ldw, P(y), ldy, 1, 1, n, HD, 1, n, dim, 1, n, 1, 1, 1, _one_tap(n).desc,
+                    P(b_out), 0, 0, P(res), 0 if res is None else ld_of(res), 0, 0, 0, 0, 0, 0, 0, 0, B, n * ldq, HD * ldw, n * ldy, 1, 0, 0, 0, S)
+    return y, Mb
+
+
+def linattn_project_bwd(qkv, dy, Mb, ctx, ctxs, w_out, b_out, dqkv, heads, scale):
+    """Backward of linattn_project: writes dq into dqkv[..., :HD], accumulates the to_out weight / bias gradients, returns
+    (dctx, rvec) -- the gradient w.r.t. the (unscaled) context and rvec[b, h*32+d] = sum_e dctx*ctx for the softmax backward."""
+    L, S = rt.lib(), rt.stream(qkv)
+    B, H, W, _ = qkv.shape
+    n, HD, dim = H * W, heads * 32, w_out.shape[0]
+    ldw, ldq, lddy, lddq = Mb.shape[-1], ld_of(qkv), ld_of(dy), ld_of(dqkv)
+    dev = qkv.device
+    # dq[b] = dy[b] . M_b^T  (b_trans: M_b is a plain [HD][ldw >= dim] matrix)
+    L.cdf_conv_gemm(P(dy), lddy, P(Mb), ldw, P(dqkv), lddq, 1, 1, n, dim, 1, n, HD, 1, n, 1, 1, 1, _one_tap(n).desc,
+                    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, B, n * lddy, HD * ldw, n * lddq, 1, 0, 0, 0, S)
+    # dM_b = q[b]^T dy[b]: per-image weight-gradient GEMM over the n pixels, split-K slabs laid out [split][b] and summed in one pass
+    wplan = cd.conv_wgrad(1, n, 1, 1, 1, 0, 0, 0, 0)
+    tiles = ((HD + 127) // 128) * (1 if dim <= 64 else (dim + 127) // 128) * B
+    ns = best_nsplit(tiles, 1024, max(1, n // 256))
+    ws = torch.empty((ns, B, HD, ldw), device=dev, dtype=torch.float32)
+    bsum = torch.empty((B * ns, ldw), device=dev, dtype=torch.float32) if b_out is not None else None    # column sums of dy as it streams by
+    L.cdf_conv_wgrad(P(qkv), ldq, P(dy), lddy, P(ws), ldw, 1, 1, n, 1, n, 1, 1, n, 1, HD, dim, 1, wplan.desc, ns, B, n * ldq, n * lddy, -1, P(bsum), S)
+    dMb = torch.empty((B, HD, ldw), device=dev, dtype=torch.float32)
+    L.cdf_unpack_reduce(P(ws), P(dMb), ns, B, HD, dim, ldw, HD * ldw, ldw, 1, 0, S)
+    if b_out is not None:
+        L.cdf_unpack_reduce(P(bsum), P(grad_of(b_out)), B * ns, 1, 1, dim, ldw, 0, 0, 1, 1, S)
+    # d(ctxs)[b,h][d][e] = sum_c dM_b[h*32 + d][c] W_out[c][h*32 + e]; dctx = scale * that; rvec = rowwise <dctx, ctx>
+    wp = packed(w_out, "conv_fwd")
+    raw = torch.empty((B, heads, 32, 32), device=dev, dtype=torch.float32)
+    L.cdf_conv_gemm(P(dMb), ldw, P(wp), ldw, P(raw), 32, 1, 1, 32, dim, 1, 32, 32, 1, 32, 1, 1, 1, _one_tap(32).desc,
+                    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, B, HD * ldw, 0, heads * 1024, heads, 32 * ldw, 32 * ldw, 1024, S)
+    dctx = torch.empty_like(raw)
+    rvec = torch.empty((B, HD), device=dev, dtype=torch.float32)
+    L.cdf_linattn_dctx_finish(P(raw), P(ctx), P(dctx), P(rvec), B * heads * 32, scale, S)
+    # dW_out[c][h*32 + e] += sum_{b,d} ctxs[b,h][d][e] dM_b[h*32 + d][c]: a weight-gradient GEMM whose "taps" are the heads
+    hp = _HEADSPLIT.get(heads)
+    if hp is None:
+        hp = _HEADSPLIT[heads] = _headsplit_plan(heads)
+    nsw = max(1, min(16, (B * 32) // 64))                      # B * 32 contraction rows: a few blocks each instead of one long serial loop
+    wsw = torch.empty((nsw, heads, 32, ldw), device=dev, dtype=torch.float32)
+    L.cdf_conv_wgrad(P(ctxs), 32, P(dMb), ldw, P(wsw), ldw, B, 1, 32, heads, 32, 1, heads, 32, 1, 32, dim, heads, hp.desc, nsw, 1, 0, 0, 0, 0, S)
+    L.cdf_unpack_reduce(P(wsw), P(grad_of(w_out)), nsw, heads, 32, dim, ldw, 32, 1, HD, 1, S)
+    return dctx, rvec
+
+
+def linattn_bwd_core(qkv, dctx, rvec, kmax, ksum, dqkv, heads):
+    """The softmax / v part of the attention backward given dctx and rvec (dq is already in dqkv)."""
+    L = rt.lib()
+    B, H, W, _ = qkv.shape
+    n, HD = H * W, heads * 32
+    dev, S = qkv.device, rt.stream(qkv)
+    pn = torch.empty((B, H, W, HD), device=dev, dtype=torch.float32)
+    dp = torch.empty((B, H, W, HD), device=dev, dtype=torch.float32)
+    L.cdf_linattn_softk(P(qkv), ld_of(qkv), P(kmax), P(ksum), P(pn), HD, B, n, heads, S)
+    _head_gemm(qkv, 2 * HD, dctx, dp, 0, B, n, heads, True)        # dP[n,d] = sum_e v[n,e] dctx[d,e]
+    _head_gemm(pn, 0, dctx, dqkv, 2 * HD, B, n, heads, False)      # dv[n,e] = sum_d P[n,d] dctx[d,e]
+    L.cdf_linattn_dk(P(pn), HD, P(dp), HD, P(rvec), P(dqkv) + 4 * HD, 3 * HD, B, n, heads, S)
+    return dqkv
+
+
+def linattn_context(qkv, heads, scale):
+    """(ctx, ctxs = scale * ctx, kmax, ksum) of LinearAttention (no output product)."""
+    L = rt.lib()
+    B, H, W, _ = qkv.shape
+    n, HD = H * W, heads * 32
+    dev = qkv.device
+    ctx = torch.empty((B, heads, 32, 32), device=dev, dtype=torch.float32)
+    ctxs = torch.empty_like(ctx)
+    kmax = torch.empty((B, HD), device=dev, dtype=torch.float32)
+    ksum = torch.empty((B, HD), device=dev, dtype=torch.float32)
+    ws = torch.empty((L.cdf_linattn_ws_floats(B, n, heads),), device=dev, dtype=torch.float32)
+    L.cdf_linattn_context(P(qkv), ld_of(qkv), P(ctx), P(ctxs), P(kmax), P(ksum), P(ws), B, n, heads, scale, rt.stream(qkv))
+    return ctx, ctxs, kmax, ksum
+
+
 def nchw_to_nhwc(x):
     B, C, H, W = x.shape
     y = new_feat(x, B, H, W, C)

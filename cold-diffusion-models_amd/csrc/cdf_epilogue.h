@@ -42,9 +42,11 @@ __device__ __forceinline__ void cdf_st4(float* p, const float* v, int n, bool ve
 
 // One pass over RP transposed rows held in cs ([RP][BN + 8]); rowmap(p) = row of pass-row p inside the block tile.
 // NTHR threads (default 256).  Contains no barrier (callers sync around it).
+// pix_off (batched launches whose per-batch outputs are whole rows of ONE output tensor): added to the output pixel index, so
+// that Y, pre, mul and res are all addressed from their own, un-offset bases.
 template <int BN, int RP, int NTHR = 256, class Args, class Phase, class RowMap>
 __device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph, float* Y, const float* cs, int m_base, int n_base, int M,
-                                                  int tid, RowMap rowmap) {
+                                                  int tid, RowMap rowmap, long long pix_off = 0) {
     constexpr int CP = BN + 8, TPR = BN / 4, RPS = NTHR / TPR;
     const int c4 = (tid % TPR) * 4, co = n_base + c4;
     if (co >= a.Cout) return;
@@ -68,6 +70,7 @@ __device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph
             b = t2 / a.QH;
             opix = ((long long)b * a.OH + qy * a.os + ph.oy) * a.OW + qx * a.os + ph.ox;
         }
+        opix += pix_off;
         const float4 t = *(const float4*)(cs + p * CP + c4);
         float v[4] = {t.x + bv[0], t.y + bv[1], t.z + bv[2], t.w + bv[3]};
         float u[4];

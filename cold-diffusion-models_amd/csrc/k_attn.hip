@@ -284,6 +284,26 @@ extern "C" int cdf_linattn_dk(const float* pn, int ldp, const float* dp, int ldd
     return cdf_check_launch("linattn_dk");
 }
 
+// dctx = scale * raw ; rvec[row] = sum_e dctx[row][e] * ctx[row][e]  (rows of LA_D = 32 entries; one 32-lane group per row)
+__global__ void linattn_dctx_finish_kernel(const float* raw, const float* ctx, float* dctx, float* rvec, long long rows, float scale) {
+    const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int e = threadIdx.x & 31;
+    float p = 0.f;
+    if (row < rows) {
+        const float d = scale * raw[row * LA_D + e];
+        dctx[row * LA_D + e] = d;
+        p = d * ctx[row * LA_D + e];
+    }
+    p = cdf_group_sum(p, 32);
+    if (row < rows && e == 0) rvec[row] = p;
+}
+
+extern "C" int cdf_linattn_dctx_finish(const float* raw, const float* ctx, float* dctx, float* rvec, long long rows, float scale, void* stream) {
+    CDF_REQUIRE(raw && ctx && dctx && rvec && rows > 0, "cdf_linattn_dctx_finish: bad args");
+    CDF_LAUNCH(linattn_dctx_finish_kernel, dim3(cdf_cdiv(rows * 32, 256)), dim3(256), 0, CDF_S, raw, ctx, dctx, rvec, rows, scale);
+    return cdf_check_launch("linattn_dctx_finish");
+}
+
 extern "C" int cdf_softmax_rows_fwd(const float* s, float* p, long long rows, int n, int ld, float scale, void* stream) {
     CDF_REQUIRE(s && p && rows > 0 && n > 0 && ld >= n, "cdf_softmax_rows_fwd: bad args");
     long long g = (rows + 3) / 4;

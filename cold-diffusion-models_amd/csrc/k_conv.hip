@@ -49,6 +49,8 @@ struct ConvArgs {
     int ld_ys;
     long long x_bs, w_bs, y_bs;     // blockIdx.z = outer*batch2 + inner: outer batch strides (elements)
     long long x_bs2, w_bs2, y_bs2;  // inner batch strides (e.g. attention heads)
+    int epi_follow;                 // batched launch whose y offsets are whole rows (y_bs % ldy == 0, y_bs2 % ldy == 0) and that has epilogue
+                                    // operands: pre / mul / res are addressed like y (row offset added to the pixel index), not from row 0
     int batch2;
     ConvPhase ph[4];
 };
@@ -87,6 +89,11 @@ __global__ void __launch_bounds__(256, 4) conv_igemm_kernel(ConvArgs a) {
     const float* X = a.x + (long long)zo * a.x_bs + (long long)zi * a.x_bs2;
     const float* Wt = a.w + (long long)zo * a.w_bs + (long long)zi * a.w_bs2;
     float* Y = a.y + (long long)zo * a.y_bs + (long long)zi * a.y_bs2;
+    long long pix_off = 0;
+    if (a.epi_follow) {
+        pix_off = ((long long)zo * a.y_bs + (long long)zi * a.y_bs2) / a.ldy;
+        Y = a.y;
+    }
 
     // ---- A-operand row bookkeeping ----------------------------------------------------------
     const int a_col = (tid & 3) * 4;
@@ -236,7 +243,7 @@ __global__ void __launch_bounds__(256, 4) conv_igemm_kernel(ConvArgs a) {
                 smem[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * WN + j * 32 + l31] = acc[i][j][r];
         __syncthreads();
         cdf_epilogue_rows<BN, EPI_ROWS>(a, ph, Y, smem, tile_m * BM, tile_n * BN, M, tid,
-                                        [i](int p) { return (p >> 5) * WM + i * 32 + (p & 31); });
+                                        [i](int p) { return (p >> 5) * WM + i * 32 + (p & 31); }, pix_off);
     }
 }
 
@@ -256,6 +263,7 @@ struct WgradArgs {
     int ntaps;
     int nsplit, m_per_split;
     long long a_bs, b_bs, o_bs;  // batch strides (blockIdx.z / nsplit)
+    int nbatch;
     float* bsum;                 // nullable: [nsplit][ldo] column sums of XB (bias gradient), written by tile_a == 0, tap == 0
     signed char day[CDF_MAX_TAPS], dax[CDF_MAX_TAPS], dby[CDF_MAX_TAPS], dbx[CDF_MAX_TAPS];
 };
@@ -427,7 +435,10 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(WgradArgs a) {
             if (cb < a.ldo) a.bsum[(long long)(batch * a.nsplit + split) * a.ldo + cb] = cb < a.CB ? t : 0.f;
         }
     }
-    float* O = a.out + (long long)batch * a.o_bs + ((long long)split * a.ntaps + tap) * a.CA * a.ldo;
+    // o_bs >= 0: [batch (stride o_bs)][split][tap][CA][ldo];  o_bs < 0: [split][batch][tap][CA][ldo] -- the per-batch results stay
+    // separate and ONE cdf_unpack_reduce(T = nbatch * ntaps) sums the splits of all of them
+    float* O = a.o_bs >= 0 ? a.out + (long long)batch * a.o_bs + ((long long)split * a.ntaps + tap) * a.CA * a.ldo
+                           : a.out + (((long long)split * a.nbatch + batch) * a.ntaps + tap) * a.CA * a.ldo;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -602,6 +613,12 @@ extern "C" int cdf_conv_gemm(const float* x, int ldx, const float* w, int ldw, f
     a.x_bs = x_bs; a.w_bs = w_bs; a.y_bs = y_bs;
     a.x_bs2 = x_bs2; a.w_bs2 = w_bs2; a.y_bs2 = y_bs2; a.batch2 = batch2;
     a.vec = cdf_epi_vec_ok(Cout, y, ldy, bias, sbias, ld_sbias, res, ldr, pre, ldp, mul, ldm) && y_bs % 4 == 0 && y_bs2 % 4 == 0;
+    a.epi_follow = 0;
+    if ((long long)batch * batch2 > 1 && (res || pre || mul)) {
+        CDF_REQUIRE(y_bs % ldy == 0 && y_bs2 % ldy == 0 && !sbias, "cdf_conv_gemm: batched launches with pre / mul / res operands need per-batch outputs that are whole rows "
+                    "of y (y_bs and y_bs2 multiples of ldy) and no per-sample bias");
+        a.epi_follow = 1;
+    }
     a.ys_hi = nullptr; a.ys_lo = nullptr; a.ld_ys = 0;
     batch *= batch2;
     // phase_desc: per phase [oy, ox, ntaps, (dy, dx, wi) * ntaps]
@@ -659,7 +676,7 @@ extern "C" int cdf_conv_wgrad(const float* xa, int lda, const float* xb, int ldb
     a.CA = CA; a.CB = CB; a.ntaps = ntaps; a.nsplit = nsplit;
     const int M = B * QH * QW;
     a.m_per_split = cdf_cdiv(cdf_cdiv(M, nsplit), 16) * 16;
-    a.a_bs = a_bs; a.b_bs = b_bs; a.o_bs = o_bs; a.bsum = bsum;
+    a.a_bs = a_bs; a.b_bs = b_bs; a.o_bs = o_bs; a.bsum = bsum; a.nbatch = batch;
     for (int t = 0; t < ntaps; ++t) {
         a.day[t] = (signed char)tap_desc[4 * t + 0];
         a.dax[t] = (signed char)tap_desc[4 * t + 1];

@@ -123,7 +123,8 @@ int cdf_conv_gemm(const float* x, int ldx, const float* w, int ldw, float* y, in
 
 /* cdf_conv_wgrad: ws[z][tap][ca][cb] = sum_{m in split z} XA[pixA(m,tap)][ca] * XB[pixB(m,tap)][cb]
  *   m = (b,qy,qx); pixA = (qy*sa+day, qx*sa+dax) in HAxWA, pixB likewise; tap_desc = (day,dax,dby,dbx) x ntaps.
- *   ws holds nsplit (x batch) slabs of [ntaps][CA][ldo]; cdf_unpack_reduce sums the slabs into the
+ *   ws holds nsplit (x batch) slabs of [ntaps][CA][ldo] -- [batch (stride o_bs)][split][tap], or with o_bs < 0 [split][batch][tap], so that
+ *   one cdf_unpack_reduce(T = batch * ntaps) reduces the splits of every batch entry; cdf_unpack_reduce sums the slabs into the
  *   parameter-gradient tensor in its PyTorch layout.  bsum (nullable, [nsplit*batch][ldo]) receives the
  *   per-split column sums of XB's rows as they stream through (the bias gradient when XB = dY with
  *   sb = 1 and a zero tap offset, so that every row is visited exactly once); reduce it with
@@ -298,6 +299,9 @@ int cdf_linattn_softk(const float* qkv, int ld, const float* kmax, const float* 
                       int heads, void* stream);
 int cdf_linattn_dk(const float* pn, int ldp, const float* dp, int lddp, const float* rvec, float* dk, int lddk, int B,
                    int n, int heads, void* stream);
+/* cdf_linattn_dctx_finish: dctx[i] = scale * raw[i]; rvec[row] = sum_e dctx[row][e] * ctx[row][e] over rows of 32 (rows = B * heads * 32):
+ * the tail of the fused attention backward, where raw = d(scale * ctx) comes out of a batched GEMM (see colddiff/ops.py linattn_bwd). */
+int cdf_linattn_dctx_finish(const float* raw, const float* ctx, float* dctx, float* rvec, long long rows, float scale, void* stream);
 /* AttnBlock (Model2.py:164-188) row softmax of the score matrix: p = softmax(scale*s) per row;
  * ds = scale * p * (dp - sum(dp*p)) */
 int cdf_softmax_rows_fwd(const float* s, float* p, long long rows, int n, int ld, float scale, void* stream);
