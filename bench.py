@@ -35,6 +35,13 @@ _T0 = time.perf_counter()
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E
+MEASURED_MFMA_CEILING_TFLOPS = 1820.0   # tools/probes/mfma_power.hip on this part: v_mfma_f32_32x32x16_bf16, registers only, RANDOM bf16 operands
+                                        # (zeros / small constants: 2490) -- profiles/round2_mfma_power.md
+
+
+def npp_of(precision):
+    """MFMAs per algorithmic product of the dense-conv GEMMs in an arithmetic mode."""
+    return {"bf16x3": 3, "bf16": 1}.get(precision, 1)
 UNET128_FWD_GFLOP = 67.41          # SURVEY.md §8(d), per image
 UNET128_ACT_TRAIN_MB = {"f32": 1098.0, "bf16": 549.0}   # SURVEY.md §8(d): A_train = 2.5 x A_fwd, layer-boundary bytes per image
 UNET128_PARAMS = 56615708
@@ -401,6 +408,11 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": dom, "arithmetic": d["arithmetic"], "achieved": d["achieved"], "peak": d["peak"],
                                "unit": "TFLOP/s", "frac": d["frac"], "traffic": None, "launches_per_step": d["launches_per_step"],
                                "avg_launch_ms": d["avg_launch_ms"], "algorithmic_gflop_per_step": d["algorithmic_gflop_per_step"],
+                               # the data-sheet peak above is what `frac` is taken against; the same instruction sustains 1.82 PF on random bf16
+                               # operands with nothing else running (profiles/round2_mfma_power.md): MFMA issue rate against that ceiling
+                               "mfma_issue_tflops": round(d["achieved"] * npp_of(runtime.precision), 1),
+                               "measured_mfma_ceiling_random_operands_tflops": MEASURED_MFMA_CEILING_TFLOPS,
+                               "mfma_issue_frac_of_measured_ceiling": round(d["achieved"] * npp_of(runtime.precision) / MEASURED_MFMA_CEILING_TFLOPS, 4),
                                "share_of_step": d["share_of_step"],
                                "measured": "HIP events around every launch of %d further steps run right after the timed region "
                                            "(%.1f ms/step with the ~1000 event records per step, %.1f ms/step without)"
