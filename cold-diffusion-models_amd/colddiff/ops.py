@@ -41,7 +41,9 @@ def new_feat(ref, B, H, W, C, zero=False):
 # ---------------------------------------------------------------------------------------------------
 # packed-weight cache
 # ---------------------------------------------------------------------------------------------------
-_pack_cache = {}
+_pack_cache = {}          # (id(param), kind) -> [key, out, weakref, geom, last_used_epoch]
+_pack_tables = {}         # device -> (signature, device table tensor, nentries, nblocks): the cdf_pack_many descriptor table
+_PACK_ALL = __import__("os").environ.get("CDF_PACK_ALL", "1") != "0"
 
 
 def _pack(src, T, R, C, s_t, s_r, s_c):
@@ -50,59 +52,127 @@ def _pack(src, T, R, C, s_t, s_r, s_c):
     return dst
 
 
+def _pack_geom(w, kind):
+    """(T, R, C, ldc, s_t, s_r, s_c, bf16) of dst[t][r][c] = src[c*s_c + r*s_r + t*s_t] for a GEMM layout of parameter w, or None."""
+    if kind in ("conv_fwd", "conv_dgrad"):
+        Co, Ci, KH, KW = w.shape
+        KK = KH * KW
+        return (KK, Ci, Co, r4(Co), 1, KK, Ci * KK, False) if kind == "conv_fwd" else (KK, Co, Ci, r4(Ci), 1, Ci * KK, KK, False)
+    if kind in ("convT_fwd", "convT_dgrad"):
+        Ci, Co, KH, KW = w.shape
+        KK = KH * KW
+        return (KK, Ci, Co, r4(Co), 1, Co * KK, KK, False) if kind == "convT_fwd" else (KK, Co, Ci, r4(Ci), 1, KK, Co * KK, False)
+    if kind in ("conv_fwd_sp", "conv_dgrad_sp", "convT_fwd_sp", "convT_dgrad_sp"):
+        # bf16 hi/lo planes [KK][N][ldk] (K contiguous) for the split-precision kernels
+        if kind.startswith("convT"):
+            Ci, Co, KH, KW = w.shape
+            KK = KH * KW
+            # (N, K, s_n, s_k): fwd: N=Cout (stride KK), K=Cin (stride Co*KK); dgrad: N=Cin (stride Co*KK), K=Cout (stride KK)
+            N, K, s_n, s_k = (Co, Ci, KK, Co * KK) if kind == "convT_fwd_sp" else (Ci, Co, Co * KK, KK)
+        else:
+            Co, Ci, KH, KW = w.shape
+            KK = KH * KW
+            N, K, s_n, s_k = (Co, Ci, Ci * KK, KK) if kind == "conv_fwd_sp" else (Ci, Co, KK, Ci * KK)
+        return (KK, N, K, (K + 31) // 32 * 32, 1, s_n, s_k, True)
+    if kind == "dw":
+        return (49, 1, w.shape[0], r4(w.shape[0]), 1, 0, 49, False)
+    if kind == "lin_fwd":
+        N, K = w.shape
+        return (1, K, N, r4(N), 0, 1, K, False)
+    return None
+
+
+def _pack_one(w, kind, geom, out=None):
+    """Pack one layout (own launch); reuses `out` when its buffers fit."""
+    if kind == "cin4":
+        # [k*k][4][r4(Cout)] for the direct <= 4-input-channel convolution kernels (rows >= Cin zero)
+        Co, Ci, KH, KW = w.shape
+        out = torch.empty((KH * KW, 4, r4(Co)), device=w.device, dtype=torch.float32)
+        rt.lib().cdf_pack_cin4(P(w), P(out), r4(Co), Co, Ci, KH, rt.stream(w))
+        return out
+    if geom is None:
+        raise ValueError(kind)
+    T, R, C, ldc, s_t, s_r, s_c, bf16 = geom
+    if bf16:
+        want_lo = rt.precision == "bf16x3"                   # bf16 mode: hi plane only
+        if out is None or (out[1] is not None) != want_lo:
+            out = (torch.empty((T, R, ldc), device=w.device, dtype=torch.int16),
+                   torch.empty((T, R, ldc), device=w.device, dtype=torch.int16) if want_lo else None)
+        rt.lib().cdf_pack_weight_bf16(P(w), P(out[0]), P(out[1]), T, R, C, ldc, s_t, s_r, s_c, rt.stream(w))
+        return out
+    if out is None:
+        out = torch.empty((T, R, ldc), device=w.device, dtype=torch.float32)
+    rt.lib().cdf_pack_weight(P(w), P(out), T, R, C, ldc, s_t, s_r, s_c, rt.stream(w))
+    return out
+
+
+def _repack_all(device, epoch_used):
+    """The weights changed (optimizer step): rewrite, IN PLACE and in ONE launch, every cached layout on `device` that the previous
+    weights epoch used.  Returns the number of layouts refreshed."""
+    import struct
+    L = rt.lib()
+    ents = []
+    for slot, ent in list(_pack_cache.items()):
+        key, out, ref, geom, used = ent
+        p = ref()
+        if p is None or geom is None or used != epoch_used or key[2] != epoch_used or p.device != device:
+            continue
+        if key[0] != p.data_ptr() or key[1] != p._version or key[4] != rt.precision:
+            continue                                         # re-homed / rewritten through torch / other arithmetic mode: individual path
+        ents.append((slot, ent, p))
+    if len(ents) < 2:
+        return 0
+    recs, first, sig = [], 0, []
+    for slot, ent, p in ents:
+        T, R, C, ldc, s_t, s_r, s_c, bf16 = ent[3]
+        out = ent[1]
+        d0, d1 = (P(out[0]), P(out[1])) if bf16 else (P(out), 0)
+        recs.append(struct.pack("<QQQqqqiiiiii", p.data_ptr(), d0, d1, s_t, s_r, s_c, T, R, C, ldc, 1 if bf16 else 0, first))
+        sig.append((p.data_ptr(), d0, d1))
+        first += (T * R * ldc + 1023) // 1024
+    sig = tuple(sig)
+    tab = _pack_tables.get(device)
+    if tab is None or tab[0] != sig:
+        blob = b"".join(recs)
+        assert len(blob) == len(recs) * L.cdf_pack_entry_bytes()
+        t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+        tab = _pack_tables[device] = (sig, t, len(recs), first)
+    L.cdf_pack_many(P(tab[1]), tab[2], tab[3], rt.stream(tab[1]))
+    for slot, ent, p in ents:
+        k = ent[0]
+        ent[0] = (k[0], k[1], rt.weights_epoch, k[3], k[4])
+    return len(ents)
+
+
 def packed(param, kind):
     """GEMM-layout copy of a parameter, cached until the parameter changes.
 
     kinds: conv_fwd  [KK][Cin][Cout]   conv_dgrad  [KK][Cout][Cin]   (weight [Cout,Cin,KH,KW])
            convT_fwd [KK][Cin][Cout]   convT_dgrad [KK][Cout][Cin]   (weight [Cin,Cout,KH,KW])
+           *_sp      bf16 hi [/ lo] planes [KK][N][ldk] for the split-precision / bf16 kernels
            dw        [49][C]                                          (weight [C,1,7,7])
            lin_fwd   [1][K][N]                                        (weight [N,K])
+    When only the weights epoch moved (an optimizer step rewrote the arena), the first request re-packs EVERY layout the previous
+    epoch used in one cdf_pack_many launch, in place.
     """
     key = (param.data_ptr(), param._version, rt.weights_epoch, kind, rt.precision)
     slot = (id(param), kind)
     hit = _pack_cache.get(slot)
-    if hit is not None and hit[0] == key and hit[2]() is param:   # the weakref guards against id()/address reuse by a new tensor
-        return hit[1]
+    if hit is not None and hit[2]() is param:                # the weakref guards against id()/address reuse by a new tensor
+        if hit[0] == key:
+            hit[4] = rt.weights_epoch
+            return hit[1]
+        k = hit[0]
+        if (_PACK_ALL and hit[3] is not None and k[0] == key[0] and k[1] == key[1] and k[4] == key[4] and param.device.type != "meta"
+                and hit[4] == k[2]):
+            if _repack_all(param.device, k[2]) and hit[0] == key:
+                hit[4] = rt.weights_epoch
+                return hit[1]
     w = param.detach()
-    if kind in ("conv_fwd", "conv_dgrad"):
-        Co, Ci, KH, KW = w.shape
-        KK = KH * KW
-        out = _pack(w, KK, Ci, Co, 1, KK, Ci * KK) if kind == "conv_fwd" else _pack(w, KK, Co, Ci, 1, Ci * KK, KK)
-    elif kind in ("convT_fwd", "convT_dgrad"):
-        Ci, Co, KH, KW = w.shape
-        KK = KH * KW
-        out = _pack(w, KK, Ci, Co, 1, Co * KK, KK) if kind == "convT_fwd" else _pack(w, KK, Co, Ci, 1, KK, Co * KK)
-    elif kind in ("conv_fwd_sp", "conv_dgrad_sp", "convT_fwd_sp", "convT_dgrad_sp"):
-        # bf16 hi/lo planes [KK][N][ldk] (K contiguous) for the split-precision kernel
-        if kind.startswith("convT"):
-            Ci, Co, KH, KW = w.shape
-            KK = KH * KW
-            geo = (Co, Ci, Ci * 0 + KK, Co * KK) if kind == "convT_fwd_sp" else (Ci, Co, Co * KK, KK)
-            # (N, K, s_n, s_k): fwd: N=Cout (stride KK), K=Cin (stride Co*KK); dgrad: N=Cin (stride Co*KK), K=Cout (stride KK)
-        else:
-            Co, Ci, KH, KW = w.shape
-            KK = KH * KW
-            geo = (Co, Ci, Ci * KK, KK) if kind == "conv_fwd_sp" else (Ci, Co, KK, Ci * KK)
-        N, K, s_n, s_k = geo
-        ldk = (K + 31) // 32 * 32
-        hi = torch.empty((KK, N, ldk), device=w.device, dtype=torch.int16)
-        lo = torch.empty((KK, N, ldk), device=w.device, dtype=torch.int16) if rt.precision == "bf16x3" else None    # bf16 mode: hi plane only
-        rt.lib().cdf_pack_weight_bf16(P(w), P(hi), P(lo), KK, N, K, ldk, 1, s_n, s_k, rt.stream(w))
-        out = (hi, lo)
-    elif kind == "cin4":
-        # [k*k][4][r4(Cout)] for the direct <= 4-input-channel convolution kernels (rows >= Cin zero)
-        Co, Ci, KH, KW = w.shape
-        out = torch.empty((KH * KW, 4, r4(Co)), device=w.device, dtype=torch.float32)
-        rt.lib().cdf_pack_cin4(P(w), P(out), r4(Co), Co, Ci, KH, rt.stream(w))
-    elif kind == "dw":
-        C = w.shape[0]
-        out = _pack(w, 49, 1, C, 1, 0, 49)
-    elif kind == "lin_fwd":
-        N, K = w.shape
-        out = _pack(w, 1, K, N, 0, 1, K)
-    else:
-        raise ValueError(kind)
-    _pack_cache[slot] = (key, out, weakref.ref(param, lambda _r, slot=slot: _pack_cache.pop(slot, None)))
+    geom = _pack_geom(w, kind) if kind != "cin4" else None
+    reuse = hit[1] if (hit is not None and hit[2]() is param and hit[3] == geom and geom is not None) else None
+    out = _pack_one(w, kind, geom, reuse)
+    _pack_cache[slot] = [key, out, weakref.ref(param, lambda _r, slot=slot: _pack_cache.pop(slot, None)), geom, rt.weights_epoch]
     return out
 
 

@@ -700,6 +700,55 @@ static inline int ew_grid2(long long n) {
     return g < 1 ? 1 : (int)g;
 }
 
+// Every cached GEMM layout of a model in ONE launch (the weights change once per optimizer step; one launch per layout was ~160
+// launches of 2-60 us per step).  Entry e: dst[t][r][c] = (c < C) ? src[c*s_c + r*s_r + t*s_t] : 0 over [T][R][ldc], written as fp32
+// (kind 0) or as bf16 hi [/ lo] planes (kind 1; lo == NULL: hi only).  Block b works on entry `e` with first_block[e] <= b <
+// first_block[e+1], elements (b - first_block[e]) * 1024 ... + 1023 of it.
+struct CdfPackEntry {
+    const float* src;
+    void* dst0;
+    void* dst1;
+    long long s_t, s_r, s_c;
+    int T, R, C, ldc, kind, first_block;
+};
+
+__global__ void __launch_bounds__(256) pack_many_kernel(const CdfPackEntry* tab, int nentries) {
+    int lo = 0, hi = nentries - 1;                          // (wave-uniform binary search over <= a few hundred entries)
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].first_block <= b) lo = mid; else hi = mid - 1;
+    }
+    const CdfPackEntry e = tab[lo];
+    const long long n = (long long)e.T * e.R * e.ldc;
+    const long long i0 = (long long)(b - e.first_block) * 1024 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = i0 + 256 * k;
+        if (i >= n) break;
+        const int c = (int)(i % e.ldc);
+        const long long tr = i / e.ldc;
+        const int r = (int)(tr % e.R), t = (int)(tr / e.R);
+        const float v = c < e.C ? e.src[c * e.s_c + r * e.s_r + t * e.s_t] : 0.f;
+        if (e.kind == 0) {
+            ((float*)e.dst0)[i] = v;
+        } else {
+            const unsigned h = cdf_f2bf(v);
+            ((unsigned short*)e.dst0)[i] = (unsigned short)h;
+            if (e.dst1) ((unsigned short*)e.dst1)[i] = (unsigned short)cdf_f2bf(v - cdf_bf2f(h));
+        }
+    }
+}
+
+extern "C" int cdf_pack_entry_bytes(void) { return (int)sizeof(CdfPackEntry); }
+
+// table: nentries CdfPackEntry records in DEVICE memory (first_block ascending, entry e spanning ceil(T R ldc / 1024) blocks)
+extern "C" int cdf_pack_many(const void* table, int nentries, int nblocks, void* stream) {
+    CDF_REQUIRE(table && nentries > 0 && nblocks > 0, "cdf_pack_many: bad args");
+    CDF_LAUNCH(pack_many_kernel, dim3(nblocks), dim3(256), 0, CDF_S, (const CdfPackEntry*)table, nentries);
+    return cdf_check_launch("pack_many");
+}
+
 extern "C" int cdf_pack_weight(const float* src, float* dst, int T, int R, int C, int ldc, long long s_t,
                                long long s_r, long long s_c, void* stream) {
     CDF_REQUIRE(src && dst && T > 0 && R > 0 && C > 0 && ldc >= C && ldc % 4 == 0, "cdf_pack_weight: bad args");
@@ -707,8 +756,72 @@ extern "C" int cdf_pack_weight(const float* src, float* dst, int T, int R, int C
     return cdf_check_launch("pack_weight");
 }
 
+// The same reduction with 16-byte loads: a lane owns 4 consecutive c (C % 4 == 0, ldc % 4 == 0, 16-byte-aligned slabs) -- four times the
+// bytes in flight per lane (the scalar form ran at ~2.5 TB/s: 2 x the time the slab bytes need); identical summation tree per element.
+template <int SL>
+__global__ void __launch_bounds__(64 * SL) unpack_reduce4_kernel(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc,
+                                                                 long long s_t, long long s_r, long long s_c, int accumulate,
+                                                                 const float* bws, float* gb, int bC, int bld) {
+    __shared__ float4 red[SL][64];
+    if (bws != nullptr && blockIdx.y == 1) {
+        ws = bws; g = gb; T = 1; R = 1; C = bC; ldc = bld; s_t = 0; s_r = 0; s_c = 1;
+    }
+    const int C4 = C >> 2;
+    const long long n4 = (long long)T * R * C4;
+    const long long slab = (long long)T * R * ldc;
+    const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    auto add4 = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    for (long long base = (long long)blockIdx.x * 64; base < n4; base += (long long)gridDim.x * 64) {
+        const long long i = base + l;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+        int c = 0, r = 0, t = 0;
+        if (i < n4) {
+            c = (int)(i % C4) * 4;
+            const long long tr = i / C4;
+            r = (int)(tr % R);
+            t = (int)(tr / R);
+            const float* p = ws + ((long long)t * R + r) * ldc + c;
+            int z = rl;
+            for (; z + 3 * SL < nsplit; z += 4 * SL) {
+                const float4 v0 = *(const float4*)(p + z * slab), v1 = *(const float4*)(p + (z + SL) * slab);
+                const float4 v2 = *(const float4*)(p + (z + 2 * SL) * slab), v3 = *(const float4*)(p + (z + 3 * SL) * slab);
+                add4(s0, v0); add4(s1, v1); add4(s2, v2); add4(s3, v3);
+            }
+            if (z < nsplit) add4(s0, *(const float4*)(p + z * slab));
+            if (z + SL < nsplit) add4(s1, *(const float4*)(p + (z + SL) * slab));
+            if (z + 2 * SL < nsplit) add4(s2, *(const float4*)(p + (z + 2 * SL) * slab));
+        }
+        __syncthreads();
+        red[rl][l] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+        __syncthreads();
+        if (rl == 0 && i < n4) {
+            float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < SL; q += 4) {
+                tot.x += (red[q][l].x + red[q + 1][l].x) + (red[q + 2][l].x + red[q + 3][l].x);
+                tot.y += (red[q][l].y + red[q + 1][l].y) + (red[q + 2][l].y + red[q + 3][l].y);
+                tot.z += (red[q][l].z + red[q + 1][l].z) + (red[q + 2][l].z + red[q + 3][l].z);
+                tot.w += (red[q][l].w + red[q + 1][l].w) + (red[q + 2][l].w + red[q + 3][l].w);
+            }
+            float* dst = g + c * s_c + r * s_r + t * s_t;
+            const float v[4] = {tot.x, tot.y, tot.z, tot.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e * s_c] = accumulate ? dst[e * s_c] + v[e] : v[e];
+        }
+    }
+}
+
 static int launch_unpack_reduce(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t, long long s_r,
                                 long long s_c, int accumulate, const float* bws, float* gb, int bC, int bld, hipStream_t s) {
+    const bool v4 = C % 4 == 0 && ldc % 4 == 0 && (((uintptr_t)ws) & 15) == 0 && (!bws || (bC % 4 == 0 && bld % 4 == 0 && (((uintptr_t)bws) & 15) == 0));
+    if (v4) {
+        const dim3 grid(ew_grid2((long long)T * R * C), bws ? 2 : 1);
+        if (nsplit >= 32)
+            CDF_LAUNCH(unpack_reduce4_kernel<16>, grid, dim3(1024), 0, s, ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld);
+        else
+            CDF_LAUNCH(unpack_reduce4_kernel<4>, grid, dim3(256), 0, s, ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld);
+        return cdf_check_launch("unpack_reduce");
+    }
     const dim3 grid(ew_grid2((long long)T * R * C * 4), bws ? 2 : 1);
     if (nsplit >= 32)       // 16 slab lanes: every lane still has >= 2 slabs
         CDF_LAUNCH(unpack_reduce_kernel<16>, grid, dim3(1024), 0, s, ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld);

@@ -234,6 +234,12 @@ int cdf_ssim_partial(const float* x, const float* y, float* partial, int planes,
  * g[c*s_c + r*s_r + t*s_t] (+)= sum_z ws[z][t][r][c] */
 int cdf_pack_weight(const float* src, float* dst, int T, int R, int C, int ldc, long long s_t, long long s_r,
                     long long s_c, void* stream);
+/* cdf_pack_many: every cached layout in one launch.  table = nentries records in device memory, each
+ *   { const float* src; void* dst0; void* dst1; long long s_t, s_r, s_c; int T, R, C, ldc, kind, first_block; }   (cdf_pack_entry_bytes() bytes)
+ * kind 0: cdf_pack_weight into dst0 (fp32); kind 1: cdf_pack_weight_bf16 into dst0 (hi) / dst1 (lo, nullable).  first_block ascending; entry e
+ * owns ceil(T*R*ldc / 1024) consecutive blocks; nblocks = their total. */
+int cdf_pack_entry_bytes(void);
+int cdf_pack_many(const void* table, int nentries, int nblocks, void* stream);
 int cdf_unpack_reduce(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t,
                       long long s_r, long long s_c, int accumulate, void* stream);
 /* the same with the bias-gradient reduction of the same weight-gradient launch folded in (one launch instead of two):

@@ -777,15 +777,22 @@ def test_unpack_reduce(be, ns):
     """Slab reduction + scatter into the PyTorch weight layout, both lane counts (4 below 32 slabs, 16 from there) and every
     tail length of the four-chain loop; accumulate on top of an existing gradient."""
     torch.manual_seed(ns)
-    T, R, C, ldc = 9, 5, 13, 16
-    ws = torch.randn(ns, T, R, ldc)
-    g0 = torch.randn(C, R, T)
-    g = be.to(g0)
-    be.L.cdf_unpack_reduce(P(be.to(ws)), P(g), ns, T, R, C, ldc, 1, T, R * T, 1, be.stream())
-    ref = g0 + ws[..., :C].double().sum(0).permute(2, 1, 0).float()
-    assert err(g, ref) <= 2e-6 * math.sqrt(ns) * max(1.0, ref.abs().max().item())
-    be.L.cdf_unpack_reduce(P(be.to(ws)), P(g), ns, T, R, C, ldc, 1, T, R * T, 0, be.stream())
-    assert err(g, ref - g0) <= 2e-6 * math.sqrt(ns) * max(1.0, ref.abs().max().item())
+    for C in (13, 12):                                   # 13: scalar loads; 12 (C % 4 == 0): the 16-byte-load form
+        T, R, ldc = 9, 5, 16
+        ws = torch.randn(ns, T, R, ldc)
+        g0 = torch.randn(C, R, T)
+        g = be.to(g0)
+        be.L.cdf_unpack_reduce(P(be.to(ws)), P(g), ns, T, R, C, ldc, 1, T, R * T, 1, be.stream())
+        ref = g0 + ws[..., :C].double().sum(0).permute(2, 1, 0).float()
+        assert err(g, ref) <= 2e-6 * math.sqrt(ns) * max(1.0, ref.abs().max().item())
+        be.L.cdf_unpack_reduce(P(be.to(ws)), P(g), ns, T, R, C, ldc, 1, T, R * T, 0, be.stream())
+        assert err(g, ref - g0) <= 2e-6 * math.sqrt(ns) * max(1.0, ref.abs().max().item())
+        # with the bias-partial reduction folded into the same launch
+        bws, gb0 = torch.randn(ns, ldc), torch.randn(C)
+        g, gb = be.to(g0), be.to(gb0)
+        be.L.cdf_unpack_reduce_bias(P(be.to(ws)), P(g), ns, T, R, C, ldc, 1, T, R * T, P(be.to(bws)), P(gb), ldc, 1, be.stream())
+        assert err(g, ref) <= 2e-6 * math.sqrt(ns) * max(1.0, ref.abs().max().item())
+        assert err(gb, gb0 + bws[:, :C].double().sum(0).float()) <= 2e-6 * math.sqrt(ns) * 4
 
 
 @pytest.mark.parametrize("M,K,N", [(32, 64, 256), (5, 256, 40), (70, 48, 130)])
