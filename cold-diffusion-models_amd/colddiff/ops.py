@@ -588,6 +588,10 @@ def linattn_bwd_core(qkv, dctx, rvec, kmax, ksum, dqkv, heads):
     B, H, W, _ = qkv.shape
     n, HD = H * W, heads * 32
     dev, S = qkv.device, rt.stream(qkv)
+    if _ATTN_KV_FUSED and heads <= 4:
+        # one pass: P recomputed from k, dP and dv on the fp32 matrix cores, dk / dv written straight into dqkv (k_attn.hip)
+        L.cdf_linattn_bwd_kv(P(qkv), ld_of(qkv), P(dctx), P(rvec), P(kmax), P(ksum), P(dqkv), ld_of(dqkv), B, n, heads, S)
+        return dqkv
     pn = torch.empty((B, H, W, HD), device=dev, dtype=torch.float32)
     dp = torch.empty((B, H, W, HD), device=dev, dtype=torch.float32)
     L.cdf_linattn_softk(P(qkv), ld_of(qkv), P(kmax), P(ksum), P(pn), HD, B, n, heads, S)
@@ -595,6 +599,9 @@ def linattn_bwd_core(qkv, dctx, rvec, kmax, ksum, dqkv, heads):
     _head_gemm(pn, 0, dctx, dqkv, 2 * HD, B, n, heads, False)      # dv[n,e] = sum_d P[n,d] dctx[d,e]
     L.cdf_linattn_dk(P(pn), HD, P(dp), HD, P(rvec), P(dqkv) + 4 * HD, 3 * HD, B, n, heads, S)
     return dqkv
+
+
+_ATTN_KV_FUSED = __import__("os").environ.get("CDF_ATTN_KV_FUSED", "1") != "0"
 
 
 def linattn_context(qkv, heads, scale):

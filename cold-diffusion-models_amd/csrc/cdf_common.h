@@ -37,6 +37,13 @@
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 #endif
+// Order the LDS accesses of ONE wave against each other (a wave's LDS operations execute in order on the hardware: only the compiler
+// must not move them; the fiber simulator really has to let the other lanes catch up).
+#ifdef CDF_EMU
+#define CDF_WAVE_SYNC() hipemu::wave_barrier()
+#else
+#define CDF_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
 
 // 256 zero bytes: out-of-range operand elements are loaded from here, so that loads never sit behind a branch.
 // (one copy per translation unit; the contents never change)

@@ -284,6 +284,114 @@ extern "C" int cdf_linattn_dk(const float* pn, int ldp, const float* dp, int ldd
     return cdf_check_launch("linattn_dk");
 }
 
+// ---- fused k / v backward -------------------------------------------------------------------------------------------------
+// Given dctx [B,heads,32,32] (gradient of the softmax-weighted context) and rvec, per pixel n and head h:
+//   P[d]  = exp(k[n,d] - kmax[d]) / ksum[d]                        (softmax over n, recomputed)
+//   dP[d] = sum_e v[n,e] dctx[d,e]          dk[n,d] = P[d] (dP[d] - rvec[d])
+//   dv[e] = sum_d P[d] dctx[d,e]
+// Upstream of this kernel these were four launches (cdf_linattn_softk, two K = 32 GEMMs, cdf_linattn_dk) that wrote and re-read
+// three [B,n,HD] intermediates (P, dP, and P again): 4.6 KB of HBM traffic per pixel against the 2 KB this kernel needs (read k, v;
+// write dk, dv).  One wave = one head: a 32-pixel tile of k and v goes global -> registers (float4, lanes along channels: full
+// 128-byte rows) -> LDS, the two 32 x 32 x 32 products run on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, A fragments from
+// the LDS tiles with lanes along pixels, the dctx fragments live in registers for the whole tile loop), and the results go
+// back through an LDS tile so that they leave as float4 rows.  grid = (ceil(n / (32 TILES)), B), block = 64 heads threads.
+#define LA_TP 36                                             // LDS row pitch (floats): 16-byte aligned rows
+#define LA_TILES 8                                           // 32-pixel tiles per wave
+
+__global__ void __launch_bounds__(256) linattn_bwd_kv_kernel(const float* qkv, int ld, const float* dctx, const float* rvec, const float* kmax,
+                                                            const float* ksum, float* dqkv, int lddq, int n, int heads) {
+    CDF_DYN_SMEM(smem_raw);
+    const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, b = blockIdx.y;
+    const int HD = heads * LA_D;
+    float* sp = (float*)smem_raw + (size_t)h * 3 * LA_D * LA_TP;          // this wave's P tile
+    float* sv = sp + LA_D * LA_TP;                                         // V tile
+    float* so = sv + LA_D * LA_TP;                                         // output staging
+    const int i = lane & 31, hh = lane >> 5;                               // MFMA lane geometry
+    const int lr = lane >> 3, lc = (lane & 7) * 4;                          // load / store geometry: pixel row lr + 8 q, channels lc .. lc+3
+    // dctx fragments: B1[s] = dctx[d = i][e = 2s + hh] (dP = V dctx^T), B2[s] = dctx[d = 2s + hh][e = i] (dv = P dctx)
+    const float* dc = dctx + ((size_t)b * heads + h) * LA_D * LA_D;
+    float B1[16], B2[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        B1[s] = dc[i * LA_D + 2 * s + hh];
+        B2[s] = dc[(2 * s + hh) * LA_D + i];
+    }
+    const float rv = rvec[(size_t)b * HD + h * LA_D + i];
+    const float4 km = *(const float4*)(kmax + (size_t)b * HD + h * LA_D + lc);
+    const float4 ks = *(const float4*)(ksum + (size_t)b * HD + h * LA_D + lc);
+    const float4 ri = make_float4(1.0f / ks.x, 1.0f / ks.y, 1.0f / ks.z, 1.0f / ks.w);
+    const float* kbase = qkv + (size_t)b * n * ld + HD + h * LA_D + lc;
+    const float* vbase = kbase + HD;
+    float* dkbase = dqkv + (size_t)b * n * lddq + HD + h * LA_D + lc;
+    float* dvbase = dkbase + HD;
+    const int p_begin = blockIdx.x * (LA_D * LA_TILES);
+    for (int t = 0; t < LA_TILES; ++t) {
+        const int p0 = p_begin + t * LA_D;
+        if (p0 >= n) break;                                                // (block-uniform)
+        // ---- k, v tile -> P, V in LDS (rows past n: zeros)
+        float4 kq[4], vq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = p0 + lr + 8 * q;
+            const int pc = p < n ? p : n - 1;
+            kq[q] = *(const float4*)(kbase + (size_t)pc * ld);
+            vq[q] = *(const float4*)(vbase + (size_t)pc * ld);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool ok = p0 + lr + 8 * q < n;
+            float4 pn = make_float4(expf(kq[q].x - km.x) * ri.x, expf(kq[q].y - km.y) * ri.y, expf(kq[q].z - km.z) * ri.z, expf(kq[q].w - km.w) * ri.w);
+            if (!ok) { pn = make_float4(0.f, 0.f, 0.f, 0.f); vq[q] = pn; }
+            *(float4*)(sp + (lr + 8 * q) * LA_TP + lc) = pn;
+            *(float4*)(sv + (lr + 8 * q) * LA_TP + lc) = vq[q];
+        }
+        CDF_WAVE_SYNC();                                   // (one wave owns these tiles: LDS operations of a wave are in order)
+        // ---- dP = V dctx^T ; dk = P (dP - rvec)
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[i * LA_TP + 2 * s + hh], B1[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int px = (r & 3) + 8 * (r >> 2) + 4 * hh;                // accumulator row of this lane's column d = i
+            so[px * LA_TP + i] = sp[px * LA_TP + i] * (acc[r] - rv);
+        }
+        CDF_WAVE_SYNC();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = p0 + lr + 8 * q;
+            if (p < n) *(float4*)(dkbase + (size_t)p * lddq) = *(const float4*)(so + (lr + 8 * q) * LA_TP + lc);
+        }
+        CDF_WAVE_SYNC();
+        // ---- dv = P dctx
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sp[i * LA_TP + 2 * s + hh], B2[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) so[((r & 3) + 8 * (r >> 2) + 4 * hh) * LA_TP + i] = acc[r];
+        CDF_WAVE_SYNC();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = p0 + lr + 8 * q;
+            if (p < n) *(float4*)(dvbase + (size_t)p * lddq) = *(const float4*)(so + (lr + 8 * q) * LA_TP + lc);
+        }
+        CDF_WAVE_SYNC();                                   // the tiles are rewritten by the next trip
+    }
+}
+
+extern "C" int cdf_linattn_bwd_kv(const float* qkv, int ld, const float* dctx, const float* rvec, const float* kmax, const float* ksum,
+                                  float* dqkv, int lddq, int B, int n, int heads, void* stream) {
+    CDF_REQUIRE(qkv && dctx && rvec && kmax && ksum && dqkv && B > 0 && n > 0, "cdf_linattn_bwd_kv: null pointer");
+    CDF_REQUIRE(heads >= 1 && heads <= 4 && ld % 4 == 0 && lddq % 4 == 0 && ld >= 3 * heads * LA_D && lddq >= 3 * heads * LA_D &&
+                ((((uintptr_t)qkv) | ((uintptr_t)dqkv) | ((uintptr_t)kmax) | ((uintptr_t)ksum)) & 15) == 0,
+                "cdf_linattn_bwd_kv: up to 4 heads; pitches must be multiples of 4, pointers 16-byte aligned");
+    const size_t lds = (size_t)heads * 3 * LA_D * LA_TP * sizeof(float);
+    CDF_LAUNCH(linattn_bwd_kv_kernel, dim3(cdf_cdiv(n, LA_D * LA_TILES), B), dim3(64 * heads), lds, CDF_S, qkv, ld, dctx, rvec, kmax, ksum, dqkv, lddq, n, heads);
+    return cdf_check_launch("linattn_bwd_kv");
+}
+
 // dctx = scale * raw ; rvec[row] = sum_e dctx[row][e] * ctx[row][e]  (rows of LA_D = 32 entries; one 32-lane group per row)
 __global__ void linattn_dctx_finish_kernel(const float* raw, const float* ctx, float* dctx, float* rvec, long long rows, float scale) {
     const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;

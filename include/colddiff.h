@@ -305,6 +305,11 @@ int cdf_linattn_softk(const float* qkv, int ld, const float* kmax, const float* 
                       int heads, void* stream);
 int cdf_linattn_dk(const float* pn, int ldp, const float* dp, int lddp, const float* rvec, float* dk, int lddk, int B,
                    int n, int heads, void* stream);
+/* cdf_linattn_bwd_kv: the k / v part of the attention backward in one pass (replaces cdf_linattn_softk + two K = 32 products +
+ * cdf_linattn_dk): dk[n,d] = P[n,d] (sum_e v[n,e] dctx[d,e] - rvec[d]),  dv[n,e] = sum_d P[n,d] dctx[d,e],  P = softmax_n(k) recomputed
+ * from kmax / ksum; written into the k and v column blocks of dqkv ([B,n,3 HD], pitch lddq).  heads <= 4. */
+int cdf_linattn_bwd_kv(const float* qkv, int ld, const float* dctx, const float* rvec, const float* kmax, const float* ksum, float* dqkv,
+                       int lddq, int B, int n, int heads, void* stream);
 /* cdf_linattn_dctx_finish: dctx[i] = scale * raw[i]; rvec[row] = sum_e dctx[row][e] * ctx[row][e] over rows of 32 (rows = B * heads * 32):
  * the tail of the fused attention backward, where raw = d(scale * ctx) comes out of a batched GEMM (see colddiff/ops.py linattn_bwd). */
 int cdf_linattn_dctx_finish(const float* raw, const float* ctx, float* dctx, float* rvec, long long rows, float scale, void* stream);

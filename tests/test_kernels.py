@@ -891,3 +891,30 @@ def test_conv_presplit_rowhalo_emu_single_pass(single_pass):
 @pytest.mark.parametrize("case", SPX_CASES_GPU)
 def test_conv_presplit_large_single_pass(single_pass, case):
     test_conv_presplit_large(case)
+
+
+@pytest.mark.parametrize("B,n,heads", [(1, 32, 4), (2, 70, 4), (1, 300, 2)])
+def test_linattn_bwd_kv_fused(be, B, n, heads):
+    """The one-pass k / v backward of linear attention (P recomputed, dP and dv on the fp32 matrix cores) against torch:
+    ragged pixel counts (not a multiple of the 32-pixel tile), 2 and 4 heads."""
+    torch.manual_seed(n)
+    HD = heads * 32
+    qkv = torch.randn(B, n, 3 * HD)
+    k, v = qkv[..., HD:2 * HD], qkv[..., 2 * HD:]
+    kmax = k.max(1).values                                              # [B, HD]
+    ksum = torch.exp(k - kmax[:, None]).sum(1)
+    Pn = torch.exp(k - kmax[:, None]) / ksum[:, None]                   # softmax over n
+    dctx = torch.randn(B, heads, 32, 32) * 0.3
+    ctx = torch.randn(B, heads, 32, 32)
+    rvec = (dctx * ctx).sum(-1).reshape(B, HD)
+    Ph, vh = Pn.view(B, n, heads, 32), v.reshape(B, n, heads, 32)
+    dP = torch.einsum("bnhe,bhde->bnhd", vh, dctx)
+    dk_ref = (Ph * (dP - rvec.view(B, 1, heads, 32))).reshape(B, n, HD)
+    dv_ref = torch.einsum("bnhd,bhde->bnhe", Ph, dctx).reshape(B, n, HD)
+    dqkv = be.zeros(B, n, 3 * HD)
+    be.L.cdf_linattn_bwd_kv(P(be.to(qkv)), 3 * HD, P(be.to(dctx)), P(be.to(rvec)), P(be.to(kmax)), P(be.to(ksum)), P(dqkv), 3 * HD, B, n, heads,
+                            be.stream())
+    out = dqkv.cpu()
+    assert (out[..., :HD] == 0).all()                                   # the q block is not this kernel's
+    assert err(out[..., HD:2 * HD], dk_ref) <= 2e-5 * max(1.0, dk_ref.abs().max().item())
+    assert err(out[..., 2 * HD:], dv_ref) <= 2e-5 * max(1.0, dv_ref.abs().max().item())
