@@ -756,72 +756,8 @@ extern "C" int cdf_pack_weight(const float* src, float* dst, int T, int R, int C
     return cdf_check_launch("pack_weight");
 }
 
-// The same reduction with 16-byte loads: a lane owns 4 consecutive c (C % 4 == 0, ldc % 4 == 0, 16-byte-aligned slabs) -- four times the
-// bytes in flight per lane (the scalar form ran at ~2.5 TB/s: 2 x the time the slab bytes need); identical summation tree per element.
-template <int SL>
-__global__ void __launch_bounds__(64 * SL) unpack_reduce4_kernel(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc,
-                                                                 long long s_t, long long s_r, long long s_c, int accumulate,
-                                                                 const float* bws, float* gb, int bC, int bld) {
-    __shared__ float4 red[SL][64];
-    if (bws != nullptr && blockIdx.y == 1) {
-        ws = bws; g = gb; T = 1; R = 1; C = bC; ldc = bld; s_t = 0; s_r = 0; s_c = 1;
-    }
-    const int C4 = C >> 2;
-    const long long n4 = (long long)T * R * C4;
-    const long long slab = (long long)T * R * ldc;
-    const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    auto add4 = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
-    for (long long base = (long long)blockIdx.x * 64; base < n4; base += (long long)gridDim.x * 64) {
-        const long long i = base + l;
-        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
-        int c = 0, r = 0, t = 0;
-        if (i < n4) {
-            c = (int)(i % C4) * 4;
-            const long long tr = i / C4;
-            r = (int)(tr % R);
-            t = (int)(tr / R);
-            const float* p = ws + ((long long)t * R + r) * ldc + c;
-            int z = rl;
-            for (; z + 3 * SL < nsplit; z += 4 * SL) {
-                const float4 v0 = *(const float4*)(p + z * slab), v1 = *(const float4*)(p + (z + SL) * slab);
-                const float4 v2 = *(const float4*)(p + (z + 2 * SL) * slab), v3 = *(const float4*)(p + (z + 3 * SL) * slab);
-                add4(s0, v0); add4(s1, v1); add4(s2, v2); add4(s3, v3);
-            }
-            if (z < nsplit) add4(s0, *(const float4*)(p + z * slab));
-            if (z + SL < nsplit) add4(s1, *(const float4*)(p + (z + SL) * slab));
-            if (z + 2 * SL < nsplit) add4(s2, *(const float4*)(p + (z + 2 * SL) * slab));
-        }
-        __syncthreads();
-        red[rl][l] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
-        __syncthreads();
-        if (rl == 0 && i < n4) {
-            float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int q = 0; q < SL; q += 4) {
-                tot.x += (red[q][l].x + red[q + 1][l].x) + (red[q + 2][l].x + red[q + 3][l].x);
-                tot.y += (red[q][l].y + red[q + 1][l].y) + (red[q + 2][l].y + red[q + 3][l].y);
-                tot.z += (red[q][l].z + red[q + 1][l].z) + (red[q + 2][l].z + red[q + 3][l].z);
-                tot.w += (red[q][l].w + red[q + 1][l].w) + (red[q + 2][l].w + red[q + 3][l].w);
-            }
-            float* dst = g + c * s_c + r * s_r + t * s_t;
-            const float v[4] = {tot.x, tot.y, tot.z, tot.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dst[e * s_c] = accumulate ? dst[e * s_c] + v[e] : v[e];
-        }
-    }
-}
-
 static int launch_unpack_reduce(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t, long long s_r,
                                 long long s_c, int accumulate, const float* bws, float* gb, int bC, int bld, hipStream_t s) {
-    const bool v4 = C % 4 == 0 && ldc % 4 == 0 && (((uintptr_t)ws) & 15) == 0 && (!bws || (bC % 4 == 0 && bld % 4 == 0 && (((uintptr_t)bws) & 15) == 0));
-    if (v4) {
-        const dim3 grid(ew_grid2((long long)T * R * C), bws ? 2 : 1);
-        if (nsplit >= 32)
-            CDF_LAUNCH(unpack_reduce4_kernel<16>, grid, dim3(1024), 0, s, ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld);
-        else
-            CDF_LAUNCH(unpack_reduce4_kernel<4>, grid, dim3(256), 0, s, ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld);
-        return cdf_check_launch("unpack_reduce");
-    }
     const dim3 grid(ew_grid2((long long)T * R * C * 4), bws ? 2 : 1);
     if (nsplit >= 32)       // 16 slab lanes: every lane still has >= 2 slabs
         CDF_LAUNCH(unpack_reduce_kernel<16>, grid, dim3(1024), 0, s, ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld);
