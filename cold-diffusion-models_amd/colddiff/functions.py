@@ -145,6 +145,38 @@ class ToNCHW(torch.autograd.Function):
         return ops.nchw_to_nhwc(dy), None, (dy if ctx.has_add else None)
 
 
+class CatBuf:
+    """The buffer of a skip concatenation torch.cat((x, h), dim=1) (DEBLUR:274), allocated when the SKIP half is produced on the down
+    path: the attention block writes h straight into channels [Cx, Cx + Ch) and, on the up path, the producer of x (mid_block2 or the
+    transposed-conv upsampler) writes into channels [0, Cx) -- every kernel takes a pixel pitch, so neither half is ever copied
+    (the round-1 `Concat` node spent two cdf_axpby passes per stage on it).  Not a tensor: autograd does not look inside."""
+
+    def __init__(self, ref, B, H, W, Cx, Ch):
+        self.Cx, self.Ch = Cx, Ch
+        self.buf = torch.empty((B, H, W, Cx + Ch), device=ref.device, dtype=torch.float32)
+
+    def first(self):
+        return self.buf[..., :self.Cx]
+
+    def second(self):
+        return self.buf[..., self.Cx:]
+
+
+class Join(torch.autograd.Function):
+    """The two halves already sit side by side in one CatBuf: hand out the whole buffer; the backward hands out channel-slice views."""
+
+    @staticmethod
+    def forward(ctx, a, b, cat):
+        assert a.data_ptr() == cat.buf.data_ptr() and b.data_ptr() == cat.buf.data_ptr() + 4 * cat.Cx and a.shape[-1] == cat.Cx and \
+            b.shape[-1] == cat.Ch and ops.ld_of(a) == cat.Cx + cat.Ch and ops.ld_of(b) == cat.Cx + cat.Ch, "Join: the halves are not the two slices of this CatBuf"
+        ctx.Ca = cat.Cx
+        return cat.buf.view(cat.buf.shape)              # (a fresh tensor object over the same storage)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d[..., :ctx.Ca], d[..., ctx.Ca:], None
+
+
 class Concat(torch.autograd.Function):
     """torch.cat((a, b), dim=channel) on NHWC maps; the backward hands out channel-slice views."""
 
@@ -254,13 +286,13 @@ class ConvFn(torch.autograd.Function):
     """A single dense convolution module (Down/Upsample, final 1x1, conv_in/out ...)."""
 
     @staticmethod
-    def forward(ctx, anchor, x, mod, Cin, kind, stride, pad):
+    def forward(ctx, anchor, x, mod, Cin, kind, stride, pad, dest=None):
         k = mod.weight.shape[-1]
         Cout = mod.weight.shape[0] if kind == "conv" else mod.weight.shape[1]
         # 4x4 stride-2 down / transposed up-sampling convs: every input pixel feeds several taps and N tiles, and the
         # same planes serve the weight gradient -> split once, use the LDS-DMA kernels (1x1 convs read x once: not worth it)
         xs = ops.split_bf16(x) if (_AUTO_PRESPLIT and (k > 1 or _PRESPLIT_1X1) and want_presplit(Cin, Cout, k)) else None
-        y = conv_forward(x, Cin, mod.weight, mod.bias, kind, stride, pad, xs=xs)
+        y = conv_forward(x, Cin, mod.weight, mod.bias, kind, stride, pad, xs=xs, **({"y": dest.first()} if dest is not None else {}))
         ctx.mod, ctx.cfg = mod, (Cin, kind, stride, pad)
         _used(ctx, mod)
         ctx.has_xs = xs is not None
@@ -275,7 +307,7 @@ class ConvFn(torch.autograd.Function):
         dys = ops.split_bf16(dy) if xs is not None else None
         dx = conv_backward(x, Cin, dy, ctx.mod.weight, ctx.mod.bias, kind, stride, pad, need_dx=ctx.needs_input_grad[1], xs=xs, dys=dys)
         _done(ctx)
-        return None, dx, None, None, None, None, None
+        return None, dx, None, None, None, None, None, None
 
 
 class ConvNextBlockFn(torch.autograd.Function):
@@ -283,7 +315,7 @@ class ConvNextBlockFn(torch.autograd.Function):
     h = ds_conv(x) + b + mlp(t); hn = LayerNorm(h); a = GELU(conv3x3(hn)); o = conv3x3(a) + res_conv(x)."""
 
     @staticmethod
-    def forward(ctx, anchor, x, tbias, m):
+    def forward(ctx, anchor, x, tbias, m, dest=None):
         dim, dim_out = m.dim, m.dim_out
         Cp = x.shape[-1]
         grad_on = ctx.needs_input_grad[0]   # anchor: True iff autograd is recording
@@ -327,7 +359,7 @@ class ConvNextBlockFn(torch.autograd.Function):
             res = conv_forward(x, dim, m.res_conv.weight, m.res_conv.bias)
         else:
             res = x
-        o = conv_forward(a, mid, c2.weight, c2.bias, res=res, xs=a_s)
+        o = conv_forward(a, mid, c2.weight, c2.bias, res=res, xs=a_s, **({"y": dest.first()} if dest is not None else {}))
         ctx.m = m
         _used(ctx, m.ds_conv, m.net[0] if m.has_norm else None, c1, c2, m.res_conv if m.has_res_conv else None)
         ctx.has_t = tbias is not None
@@ -381,17 +413,18 @@ class ConvNextBlockFn(torch.autograd.Function):
             else:
                 dx = ops.dwconv7(dh, ops.packed(m.ds_conv.weight, "dw"), None, None, flip=1, res=do)
         _done(ctx)
-        return None, dx, dtb, None
+        return None, dx, dtb, None, None
 
 
 class LinAttnBlockFn(torch.autograd.Function):
     """Residual(PreNorm(dim, LinearAttention(dim))) (deblurring_diffusion_pytorch.py:83-89,123-131,167-187)."""
 
     @staticmethod
-    def forward(ctx, anchor, x, m):
+    def forward(ctx, anchor, x, m, dest=None):
         norm, att = m.fn.norm, m.fn.fn
         dim = x.shape[-1]
         grad_on = ctx.needs_input_grad[0]   # anchor: True iff autograd is recording
+        ydst = {"y": dest.second()} if dest is not None else {}      # skip tensor: produced in place in its concat buffer (CatBuf)
         xn, mean, rstd = ops.layernorm_fwd(x, norm.g, norm.b, norm.eps, grad_on)
         qkv = conv_forward(xn, dim, att.to_qkv.weight, None)
         ctx.m = m
@@ -400,11 +433,11 @@ class LinAttnBlockFn(torch.autograd.Function):
         if ctx.fused:
             # output projection folded into the attention product: the attention output is never materialised (ops.linattn_project)
             cx, cxs, kmax, ksum = ops.linattn_context(qkv, att.heads, att.scale)
-            y, Mb = ops.linattn_project(qkv, cxs, att.to_out.weight, att.to_out.bias, x, att.heads)
+            y, Mb = ops.linattn_project(qkv, cxs, att.to_out.weight, att.to_out.bias, x, att.heads, **ydst)
             ctx.save_for_backward(x, xn, mean, rstd, qkv, Mb, cx, cxs, kmax, ksum)
             return y
         o, cx, cxs, kmax, ksum = ops.linattn_fwd(qkv, att.heads, att.scale)
-        y = conv_forward(o, att.heads * 32, att.to_out.weight, att.to_out.bias, res=x)
+        y = conv_forward(o, att.heads * 32, att.to_out.weight, att.to_out.bias, res=x, **ydst)
         ctx.save_for_backward(x, xn, mean, rstd, qkv, o, cx, cxs, kmax, ksum)
         return y
 
@@ -416,7 +449,6 @@ class LinAttnBlockFn(torch.autograd.Function):
         if ctx.fused:
             B, H, W, _ = qkv.shape
             dqkv = torch.empty((B, H, W, 3 * HD), device=qkv.device, dtype=torch.float32)
-            dy = dy.contiguous()
             dctx, rvec = ops.linattn_project_bwd(qkv, dy, o, cx, cxs, att.to_out.weight, att.to_out.bias, dqkv, att.heads, att.scale)   # (o = Mb here)
             ops.linattn_bwd_core(qkv, dctx, rvec, kmax, ksum, dqkv, att.heads)
         else:
@@ -426,7 +458,7 @@ class LinAttnBlockFn(torch.autograd.Function):
         dx = ops.copy_feat(dy)
         ops.layernorm_bwd(dxn, x, norm.g, norm.b, mean, rstd, dx=dx)
         _done(ctx)
-        return None, dx, None
+        return None, dx, None, None
 
 
 # ===================================================================================================

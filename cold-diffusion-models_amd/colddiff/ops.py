@@ -522,8 +522,9 @@ def _headsplit_plan(heads):
 _HEADSPLIT = {}
 
 
-def linattn_project(qkv, ctxs, w_out, b_out, res, heads):
-    """y = q . M_b + b_out + res,  M_b = blockdiag(ctxs[b]) . W_out^T.  Returns (y, Mb)."""
+def linattn_project(qkv, ctxs, w_out, b_out, res, heads, y=None):
+    """y = q . M_b + b_out + res,  M_b = blockdiag(ctxs[b]) . W_out^T.  Returns (y, Mb).  y: optional destination (a channel slice of a
+    wider buffer is fine)."""
     L, S = rt.lib(), rt.stream(qkv)
     B, H, W, _ = qkv.shape
     n, HD, dim = H * W, heads * 32, w_out.shape[0]
@@ -533,7 +534,8 @@ def linattn_project(qkv, ctxs, w_out, b_out, res, heads):
     # M_b[h*32 + d][c] = sum_e ctxs[b,h][d][e] W_out[c][h*32 + e]: B x heads GEMMs of 32 x 32 x dim
     L.cdf_conv_gemm(P(ctxs), 32, P(wp), ldw, P(Mb), ldw, 1, 1, 32, 32, 1, 32, dim, 1, 32, 1, 1, 1, _one_tap(32).desc,
                     0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, B, heads * 1024, 0, HD * ldw, heads, 1024, 32 * ldw, 32 * ldw, S)
-    y = new_feat(qkv, B, H, W, dim)
+    if y is None:
+        y = new_feat(qkv, B, H, W, dim)
     ldq, ldy = ld_of(qkv), ld_of(y)
     # y[b] = q[b] . M_b (+ bias + residual): one GEMM per image, K = HD
     L.cdf_conv_gemm(P(qkv), ldq, P(Mb), ldw, P(y), ldy, 1, 1, n, HD, 1, n, dim, 1, n, 1, 1, 1, _one_tap(n).desc,

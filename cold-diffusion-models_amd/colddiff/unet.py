@@ -40,6 +40,9 @@ class _Anchor(nn.Module):
         return a
 
 
+_CONCAT_FREE = __import__("os").environ.get("CDF_CONCAT_FREE", "1") != "0"
+
+
 def anchor(t):
     return _Anchor.get(t.device)
 
@@ -49,8 +52,8 @@ class Residual(nn.Module):
         super().__init__()
         self.fn = fn
 
-    def forward(self, x):           # only Residual(PreNorm(LinearAttention)) occurs in the model
-        return F_.LinAttnBlockFn.apply(anchor(x), x, self)
+    def forward(self, x, dest=None):    # only Residual(PreNorm(LinearAttention)) occurs in the model
+        return F_.LinAttnBlockFn.apply(anchor(x), x, self, dest)
 
 
 class SinusoidalPosEmb(nn.Module):
@@ -102,13 +105,14 @@ class ConvNextBlock(nn.Module):
         self.has_norm = norm
         self.has_res_conv = dim != dim_out
 
-    def forward(self, x, gelu_t=None):
-        """x: NHWC feature map; gelu_t: GELU(time embedding) [B, time_dim] (shared by all blocks)."""
+    def forward(self, x, gelu_t=None, dest=None):
+        """x: NHWC feature map; gelu_t: GELU(time embedding) [B, time_dim] (shared by all blocks); dest: CatBuf whose first half
+        receives the output."""
         tb = None
         if exists(self.mlp):
             assert exists(gelu_t), "time emb must be passed in"
             tb = F_.Linear.apply(anchor(x), gelu_t, self.mlp[1])
-        return F_.ConvNextBlockFn.apply(anchor(x), x, tb, self)
+        return F_.ConvNextBlockFn.apply(anchor(x), x, tb, self, dest)
 
 
 class LinearAttention(nn.Module):
@@ -196,26 +200,35 @@ class Unet(nn.Module):
         a = anchor(x)
         gt = self._time(time, x)
         x = F_.ToNHWC.apply(x.float())
+        # Skip connections without copies (DEBLUR:266, 274): the skip tensor of every level an up stage consumes is produced INSIDE its
+        # concat buffer (second half), and the producer of the tensor it is concatenated with writes the first half (F_.CatBuf).
+        nskip = len(self.ups)                                  # (the first level's skip is appended upstream but never consumed)
         h = []
-        for convnext, convnext2, attn, downsample in self.downs:
+        for lvl, (convnext, convnext2, attn, downsample) in enumerate(self.downs):
             x = convnext(x, gt)
             x = convnext2(x, gt)
-            x = attn(x)
-            h.append(x)
+            cat = None
+            if _CONCAT_FREE and lvl >= len(self.downs) - nskip:
+                B_, H_, W_, C_ = x.shape
+                cat = F_.CatBuf(x, B_, H_, W_, C_, C_)
+            x = attn(x, cat)
+            h.append((x, cat))
             if not isinstance(downsample, nn.Identity):
                 x = F_.ConvFn.apply(a, x, downsample, x.shape[-1], "conv", 2, (1, 1, 1, 1))
 
         x = self.mid_block1(x, gt)
         x = self.mid_attn(x)
-        x = self.mid_block2(x, gt)
+        x = self.mid_block2(x, gt, h[-1][1])                   # (its output is the first half of the deepest concat)
 
-        for convnext, convnext2, attn, upsample in self.ups:
-            x = F_.Concat.apply(x, h.pop())
+        for j, (convnext, convnext2, attn, upsample) in enumerate(self.ups):
+            skip, cat = h.pop()
+            x = F_.Join.apply(x, skip, cat) if cat is not None else F_.Concat.apply(x, skip)
             x = convnext(x, gt)
             x = convnext2(x, gt)
             x = attn(x)
             if not isinstance(upsample, nn.Identity):
-                x = F_.ConvFn.apply(a, x, upsample, x.shape[-1], "convT", 2, (1, 1, 1, 1))
+                nxt = h[-1][1] if j + 1 < len(self.ups) else None      # the next stage's concat buffer takes the upsampled map
+                x = F_.ConvFn.apply(a, x, upsample, x.shape[-1], "convT", 2, (1, 1, 1, 1), nxt)
 
         x = self.final_conv[0](x)
         x = F_.ConvFn.apply(a, x, self.final_conv[1], x.shape[-1], "conv", 1, (0, 0, 0, 0))
