@@ -448,6 +448,15 @@ def main():
                 out["sample_ms_per_img_200step"] = round(1000 * (time.perf_counter() - ts) / args.sample_batch, 2)
                 log(f"200-step gen_sample of {args.sample_batch} images: {time.perf_counter() - ts:.2f}s")
                 out["sample_batch"] = args.sample_batch
+                if not args.no_secondary:
+                    # the same sampler at a batch that fills the deep 16 x 16 layers (at 16 images half of their tiles' CUs idle)
+                    noise64 = torch.randn(64, 3, 128, 128, device=device)
+                    torch.cuda.synchronize()
+                    ts = time.perf_counter()
+                    trainer.ema_core.gen_sample(batch_size=64, img=noise64)
+                    torch.cuda.synchronize()
+                    out["sample_ms_per_img_200step_batch64"] = round(1000 * (time.perf_counter() - ts) / 64, 2)
+                    del noise64
         if world == 1 and not args.no_secondary:
             out["selfcheck"] = selfcheck(diffusion, device)
             log("self-check: loss hip %.6f oracle %.6f" % (out["selfcheck"]["microstep_loss_hip"], out["selfcheck"]["microstep_loss_oracle"]))
@@ -457,6 +466,16 @@ def main():
                 runtime.set_precision("bf16")
                 runtime.bump_weights_epoch()
                 dtb = timed_train(trainer, args.steps, args.warmup)
+                sample_bf16 = None
+                if not args.no_sample:
+                    with torch.no_grad():
+                        noise = torch.randn(args.sample_batch, 3, 128, 128, device=device)
+                        trainer.ema_core.gen_sample(batch_size=args.sample_batch, img=noise, t=2)
+                        torch.cuda.synchronize()
+                        ts = time.perf_counter()
+                        trainer.ema_core.gen_sample(batch_size=args.sample_batch, img=noise)
+                        torch.cuda.synchronize()
+                        sample_bf16 = round(1000 * (time.perf_counter() - ts) / args.sample_batch, 2)
                 runtime.set_precision("bf16x3")
                 runtime.bump_weights_epoch()
                 out["bf16_mode"] = {"value": round(args.batch * args.accum / dtb, 2), "unit": "img/s", "ms_per_step": round(1000 * dtb, 3),
@@ -464,6 +483,7 @@ def main():
                                              "degradation / optimizer; bf16 planes are the only stored form of LN and GELU outputs",
                                     "tolerance_vs_fp32_oracle": "UNet output max-abs <= 1e-2 (measured 2.5e-3 on a 64x64 dim-64 net), gradients ~2e-2 "
                                                                 "relative (tests/test_gpu_parity2.py::test_other_precision_modes_module_level)",
+                                    "sample_ms_per_img_200step": sample_bf16, "sample_batch": args.sample_batch,
                                     "step_roofline": step_roofline(args.batch, args.accum, 1000 * dtb, 1)}
                 log(f"bf16 mode: {out['bf16_mode']['value']} img/s")
             del trainer
