@@ -51,10 +51,17 @@ def test_hot_kernels_use_no_scratch():
            "k_conv.hip": ("conv_igemm_kernel", "unpack_reduce_kernel"),
            "k_dwconv.hip": ("dwconv7_kernel", "dwconv7_wgrad_partial_kernel"),
            "k_norm.hip": ("layernorm_c_fwd_kernel", "layernorm_c_bwd_kernel")}
+    from concurrent.futures import ThreadPoolExecutor
+
+    def compile_one(src):
+        return subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", csrc, "-I", os.path.join(repo, "include"),
+                               "-c", os.path.join(csrc, src), "-o", os.devnull, "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage"],
+                              capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        results = dict(zip(hot, ex.map(compile_one, hot)))
     for src, names in hot.items():
-        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", csrc, "-I", os.path.join(repo, "include"),
-                            "-c", os.path.join(csrc, src), "-o", os.devnull, "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage"],
-                           capture_output=True, text=True)
+        r = results[src]
         assert r.returncode == 0, r.stderr[-2000:]
         cur, seen = None, set()
         for line in r.stderr.splitlines():

@@ -37,7 +37,7 @@ def test_buckets_are_whole_tensors():
 
 
 @pytest.mark.parametrize("bucket_bytes,mode,min_buckets", [(512, "once", 8), (1024, "once", 8), (4096, "once", 8), (0, "once", 1),
-                                                            (1024, "twice", 8), (0, "twice", 1)])
+                                                            (1024, "twice", 8)])
 def test_two_rank_training_matches_global_batch(tmp_path, bucket_bytes, mode, min_buckets):
     _two_rank_case(tmp_path, bucket_bytes, mode, min_buckets, hip=False)
 
