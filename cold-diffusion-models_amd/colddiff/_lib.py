@@ -117,6 +117,8 @@ def get():
             _instance.cdf_conv_gemm_bf16x_tile(*[int(v) for v in tile.split("x")])
         if waves:
             _instance.cdf_conv_gemm_bf16x_waves(int(waves))
+        if os.environ.get("COLDDIFF_UNPACK_TILED"):
+            _instance.cdf_unpack_reduce_tiled(int(os.environ["COLDDIFF_UNPACK_TILED"]))
         if os.environ.get("COLDDIFF_WGRAD_ROW3"):
             _instance.cdf_conv_wgrad_bf16x_row3(int(os.environ["COLDDIFF_WGRAD_ROW3"]))
         if os.environ.get("COLDDIFF_WGRAD_SWIZZLE"):

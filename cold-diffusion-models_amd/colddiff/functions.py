@@ -416,6 +416,24 @@ class ConvNextBlockFn(torch.autograd.Function):
         return None, dx, dtb, None, None
 
 
+def kv_forward(xn, dim, w_qkv):
+    """kv = xn . Wkv^T ([B,H,W,2 HD]): the k | v rows of to_qkv as a 1x1 convolution of their own (ops.linattn_fold)."""
+    N2 = w_qkv.shape[0] // 3 * 2
+    plan = _conv_plans("conv", xn.shape[1], xn.shape[2], 1, 1, (0, 0, 0, 0))[0]
+    return ops.conv_gemm(plan, xn, dim, ops.packed(w_qkv, "kv_fwd" + _sp_suffix(dim, N2)), N2)
+
+
+def kv_backward(xn, dim, dkv, w_qkv, dxn):
+    """dxn += dkv . Wkv;  rows HD .. 3 HD of to_qkv.weight.grad += dkv^T xn."""
+    HD = w_qkv.shape[0] // 3
+    _, pd, pw = _conv_plans("conv", xn.shape[1], xn.shape[2], 1, 1, (0, 0, 0, 0))
+    ops.wgrad_into(ops.grad_of(w_qkv)[HD:], pw, xn, dim, dkv, 2 * HD, 1, 1, dim)
+    return ops.conv_gemm(pd, dkv, 2 * HD, ops.packed(w_qkv, "kv_dgrad" + _sp_suffix(2 * HD, dim)), dim, y=dxn, accumulate=1)
+
+
+_ATTN_QFOLD = os.environ.get("CDF_ATTN_QFOLD", "1") != "0"   # q projection folded into the attention product too (dim <= heads*32)
+
+
 class LinAttnBlockFn(torch.autograd.Function):
     """Residual(PreNorm(dim, LinearAttention(dim))) (deblurring_diffusion_pytorch.py:83-89,123-131,167-187)."""
 
@@ -426,10 +444,18 @@ class LinAttnBlockFn(torch.autograd.Function):
         grad_on = ctx.needs_input_grad[0]   # anchor: True iff autograd is recording
         ydst = {"y": dest.second()} if dest is not None else {}      # skip tensor: produced in place in its concat buffer (CatBuf)
         xn, mean, rstd = ops.layernorm_fwd(x, norm.g, norm.b, norm.eps, grad_on)
-        qkv = conv_forward(xn, dim, att.to_qkv.weight, None)
         ctx.m = m
         _used(ctx, norm, att.to_qkv, att.to_out)
         ctx.fused = _ATTN_FUSED and dim % 4 == 0
+        ctx.qfold = ctx.fused and _ATTN_QFOLD and dim <= att.heads * 32 and att.heads <= 4
+        if ctx.qfold:
+            # q folded in as well: only k | v are projected, y = xn . N_b + b + x (ops.linattn_fold)
+            kv = kv_forward(xn, dim, att.to_qkv.weight)
+            cx, cxs, kmax, ksum = ops.linattn_context(kv, att.heads, att.scale, koff=0)
+            y, Mb, Nb = ops.linattn_fold(xn, cxs, att.to_qkv.weight, att.to_out.weight, att.to_out.bias, x, att.heads, **ydst)
+            ctx.save_for_backward(x, xn, mean, rstd, kv, Mb, cx, cxs, kmax, ksum, Nb)
+            return y
+        qkv = conv_forward(xn, dim, att.to_qkv.weight, None)
         if ctx.fused:
             # output projection folded into the attention product: the attention output is never materialised (ops.linattn_project)
             cx, cxs, kmax, ksum = ops.linattn_context(qkv, att.heads, att.scale)
@@ -443,8 +469,19 @@ class LinAttnBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, xn, mean, rstd, qkv, o, cx, cxs, kmax, ksum = ctx.saved_tensors
         norm, att = ctx.m.fn.norm, ctx.m.fn.fn
+        if ctx.qfold:
+            x, xn, mean, rstd, kv, Mb, cx, cxs, kmax, ksum, Nb = ctx.saved_tensors
+            dim = x.shape[-1]
+            dxn, dctx, rvec = ops.linattn_fold_bwd(xn, dy, Mb, Nb, cx, cxs, att.to_qkv.weight, att.to_out.weight, att.to_out.bias,
+                                                   att.heads, att.scale)
+            dkv = torch.empty(kv.shape, device=kv.device, dtype=torch.float32)
+            ops.linattn_bwd_core(kv, dctx, rvec, kmax, ksum, dkv, att.heads, koff=0)
+            kv_backward(xn, dim, dkv, att.to_qkv.weight, dxn)
+            dx = ops.layernorm_bwd(dxn, x, norm.g, norm.b, mean, rstd, add=dy)     # + the residual branch, same pass
+            _done(ctx)
+            return None, dx, None, None
+        x, xn, mean, rstd, qkv, o, cx, cxs, kmax, ksum = ctx.saved_tensors
         dim, HD = x.shape[-1], att.heads * 32
         if ctx.fused:
             B, H, W, _ = qkv.shape
@@ -455,8 +492,7 @@ class LinAttnBlockFn(torch.autograd.Function):
             do = conv_backward(o, HD, dy, att.to_out.weight, att.to_out.bias)
             dqkv = ops.linattn_bwd(qkv, do, cx, cxs, kmax, ksum, att.heads, att.scale)
         dxn = conv_backward(xn, dim, dqkv, att.to_qkv.weight, None)
-        dx = ops.copy_feat(dy)
-        ops.layernorm_bwd(dxn, x, norm.g, norm.b, mean, rstd, dx=dx)
+        dx = ops.layernorm_bwd(dxn, x, norm.g, norm.b, mean, rstd, add=dy)
         _done(ctx)
         return None, dx, None, None
 

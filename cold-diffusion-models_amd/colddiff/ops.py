@@ -53,7 +53,26 @@ def _pack(src, T, R, C, s_t, s_r, s_c):
 
 
 def _pack_geom(w, kind):
-    """(T, R, C, ldc, s_t, s_r, s_c, bf16) of dst[t][r][c] = src[c*s_c + r*s_r + t*s_t] for a GEMM layout of parameter w, or None."""
+    """(T, R, C, ldc, s_t, s_r, s_c, bf16, off) of dst[t][r][c] = src[off + c*s_c + r*s_r + t*s_t] for a GEMM layout of parameter w, or None."""
+    g = _pack_geom0(w, kind)
+    return g if (g is None or len(g) == 9) else g + (0,)
+
+
+def _pack_geom0(w, kind):
+    if kind.startswith("kv_"):
+        # the k | v rows of a LinearAttention to_qkv weight [3 HD, Ci, 1, 1] as a conv of its own (rows HD .. 3 HD)
+        Co3, Ci = w.shape[0], w.shape[1]
+        HD = Co3 // 3
+        N2, off = 2 * HD, HD * Ci
+        if kind == "kv_fwd":
+            return (1, Ci, N2, r4(N2), 1, 1, Ci, False, off)
+        if kind == "kv_dgrad":
+            return (1, N2, Ci, r4(Ci), 1, Ci, 1, False, off)
+        if kind == "kv_fwd_sp":
+            return (1, N2, Ci, (Ci + 31) // 32 * 32, 1, Ci, 1, True, off)
+        if kind == "kv_dgrad_sp":
+            return (1, Ci, N2, (N2 + 31) // 32 * 32, 1, 1, Ci, True, off)
+        return None
     if kind in ("conv_fwd", "conv_dgrad"):
         Co, Ci, KH, KW = w.shape
         KK = KH * KW
@@ -92,17 +111,18 @@ def _pack_one(w, kind, geom, out=None):
         return out
     if geom is None:
         raise ValueError(kind)
-    T, R, C, ldc, s_t, s_r, s_c, bf16 = geom
+    T, R, C, ldc, s_t, s_r, s_c, bf16, off = geom
+    src = P(w) + 4 * off
     if bf16:
         want_lo = rt.precision == "bf16x3"                   # bf16 mode: hi plane only
         if out is None or (out[1] is not None) != want_lo:
             out = (torch.empty((T, R, ldc), device=w.device, dtype=torch.int16),
                    torch.empty((T, R, ldc), device=w.device, dtype=torch.int16) if want_lo else None)
-        rt.lib().cdf_pack_weight_bf16(P(w), P(out[0]), P(out[1]), T, R, C, ldc, s_t, s_r, s_c, rt.stream(w))
+        rt.lib().cdf_pack_weight_bf16(src, P(out[0]), P(out[1]), T, R, C, ldc, s_t, s_r, s_c, rt.stream(w))
         return out
     if out is None:
         out = torch.empty((T, R, ldc), device=w.device, dtype=torch.float32)
-    rt.lib().cdf_pack_weight(P(w), P(out), T, R, C, ldc, s_t, s_r, s_c, rt.stream(w))
+    rt.lib().cdf_pack_weight(src, P(out), T, R, C, ldc, s_t, s_r, s_c, rt.stream(w))
     return out
 
 
@@ -124,11 +144,11 @@ def _repack_all(device, epoch_used):
         return 0
     recs, first, sig = [], 0, []
     for slot, ent, p in ents:
-        T, R, C, ldc, s_t, s_r, s_c, bf16 = ent[3]
+        T, R, C, ldc, s_t, s_r, s_c, bf16, off = ent[3]
         out = ent[1]
         d0, d1 = (P(out[0]), P(out[1])) if bf16 else (P(out), 0)
-        recs.append(struct.pack("<QQQqqqiiiiii", p.data_ptr(), d0, d1, s_t, s_r, s_c, T, R, C, ldc, 1 if bf16 else 0, first))
-        sig.append((p.data_ptr(), d0, d1))
+        recs.append(struct.pack("<QQQqqqiiiiii", p.data_ptr() + 4 * off, d0, d1, s_t, s_r, s_c, T, R, C, ldc, 1 if bf16 else 0, first))
+        sig.append((p.data_ptr() + 4 * off, d0, d1))
         first += (T * R * ldc + 1023) // 1024
     sig = tuple(sig)
     tab = _pack_tables.get(device)
@@ -150,6 +170,7 @@ def packed(param, kind):
     kinds: conv_fwd  [KK][Cin][Cout]   conv_dgrad  [KK][Cout][Cin]   (weight [Cout,Cin,KH,KW])
            convT_fwd [KK][Cin][Cout]   convT_dgrad [KK][Cout][Cin]   (weight [Cin,Cout,KH,KW])
            *_sp      bf16 hi [/ lo] planes [KK][N][ldk] for the split-precision / bf16 kernels
+           kv_*      the same four layouts of rows HD .. 3 HD of a to_qkv weight [3 HD, C, 1, 1] (the k | v projection alone)
            dw        [49][C]                                          (weight [C,1,7,7])
            lin_fwd   [1][K][N]                                        (weight [N,K])
     When only the weights epoch moved (an optimizer step rewrote the arena), the first request re-packs EVERY layout the previous
@@ -425,17 +446,19 @@ def layernorm_fwd(x, g, b, eps, save, split_out=False, planes_only=False):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, g_param, b_param, mean, rstd, dx=None):
-    """returns dx (accumulating into `dx` if given); accumulates g/b gradients into the params."""
+def layernorm_bwd(dy, x, g_param, b_param, mean, rstd, dx=None, add=None):
+    """returns dx (accumulating into `dx` if given; add: a second tensor added in the same pass -- the residual gradient of
+    Residual(PreNorm(..)) --, into a new dx); accumulates g/b gradients into the params."""
     L = rt.lib()
     B, H, W, C = x.shape
     M = B * H * W
     acc = 1 if dx is not None else 0
+    assert not (acc and add is not None)
     if dx is None:
         dx = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
     part = torch.empty((L.cdf_layernorm_blocks(M, C) * 2 * C,), device=x.device, dtype=torch.float32)
-    L.cdf_layernorm_c_bwd(P(dy), ld_of(dy), P(x), ld_of(x), P(g_param), P(mean), P(rstd), P(dx), ld_of(dx), P(grad_of(g_param)),
-                          P(grad_of(b_param)), P(part), M, C, acc, 1, rt.stream(x))
+    L.cdf_layernorm_c_bwd(P(dy), ld_of(dy), P(x), ld_of(x), P(g_param), P(mean), P(rstd), P(dx), ld_of(dx), P(add),
+                          0 if add is None else ld_of(add), P(grad_of(g_param)), P(grad_of(b_param)), P(part), M, C, acc, 1, rt.stream(x))
     return dx
 
 
@@ -483,7 +506,7 @@ def linattn_fwd(qkv, heads, scale):
     kmax = torch.empty((B, HD), device=dev, dtype=torch.float32)
     ksum = torch.empty((B, HD), device=dev, dtype=torch.float32)
     ws = torch.empty((L.cdf_linattn_ws_floats(B, n, heads),), device=dev, dtype=torch.float32)
-    L.cdf_linattn_context(P(qkv), ld_of(qkv), P(ctx), P(ctxs), P(kmax), P(ksum), P(ws), B, n, heads, scale, rt.stream(qkv))
+    L.cdf_linattn_context(P(qkv), ld_of(qkv), HD, P(ctx), P(ctxs), P(kmax), P(ksum), P(ws), B, n, heads, scale, rt.stream(qkv))
     _head_gemm(qkv, 0, ctxs, out, 0, B, n, heads, False)          # out = q . (scale*ctx)
     return out, ctx, ctxs, kmax, ksum
 
@@ -565,6 +588,14 @@ def linattn_project_bwd(qkv, dy, Mb, ctx, ctxs, w_out, b_out, dqkv, heads, scale
     L.cdf_unpack_reduce(P(ws), P(dMb), ns, B, HD, dim, ldw, HD * ldw, ldw, 1, 0, S)
     if b_out is not None:
         L.cdf_unpack_reduce(P(bsum), P(grad_of(b_out)), B * ns, 1, 1, dim, ldw, 0, 0, 1, 1, S)
+    return _linattn_out_bwd(dMb, ctx, ctxs, w_out, heads, scale)
+
+
+def _linattn_out_bwd(dMb, ctx, ctxs, w_out, heads, scale):
+    """From dM_b ([B][HD][ldw]): (dctx, rvec), and the to_out weight gradient accumulated."""
+    L, S = rt.lib(), rt.stream(dMb)
+    B, HD, ldw = dMb.shape
+    dim, dev = w_out.shape[0], dMb.device
     # d(ctxs)[b,h][d][e] = sum_c dM_b[h*32 + d][c] W_out[c][h*32 + e]; dctx = scale * that; rvec = rowwise <dctx, ctx>
     wp = packed(w_out, "conv_fwd")
     raw = torch.empty((B, heads, 32, 32), device=dev, dtype=torch.float32)
@@ -584,16 +615,84 @@ def linattn_project_bwd(qkv, dy, Mb, ctx, ctxs, w_out, b_out, dqkv, heads, scale
     return dctx, rvec
 
 
-def linattn_bwd_core(qkv, dctx, rvec, kmax, ksum, dqkv, heads):
-    """The softmax / v part of the attention backward given dctx and rvec (dq is already in dqkv)."""
+# -- ... and with the q projection folded in as well (round 2) ------------------------------------------------------------------
+# q = xn . Wq^T is linear too (to_qkv has no bias, q is used as it is), so y[n] = xn[n] . N_b + b + x[n] with
+# N_b = Wq^T . M_b ([dim x dim] per image).  Where dim <= heads*32 (the 128- and 64-pixel levels of the CelebA net) that is fewer
+# FLOPs than q . M_b AND q never exists: to_qkv shrinks to the k | v projection (256 instead of 384 output channels: a third less
+# written, re-read by the context pass, the data gradient and the weight gradient), the batched GEMMs stream xn / dy (dim channels)
+# instead of q / dq (128), and Wq's gradient is dWq = sum_b M_b . dN_b^T with dN_b = xn_b^T dy_b.
+def linattn_fold(xn, ctxs, w_qkv, w_out, b_out, res, heads, y=None):
+    """y = xn . N_b + b_out + res.  Returns (y, Mb, Nb)."""
+    L, S = rt.lib(), rt.stream(xn)
+    B, H, W, _ = xn.shape
+    n, HD, dim = H * W, heads * 32, w_out.shape[0]
+    wp = packed(w_out, "conv_fwd")                            # [1][HD][r4(dim)]
+    ldw = wp.shape[-1]
+    Mb = torch.empty((B, HD, ldw), device=xn.device, dtype=torch.float32)
+    L.cdf_conv_gemm(P(ctxs), 32, P(wp), ldw, P(Mb), ldw, 1, 1, 32, 32, 1, 32, dim, 1, 32, 1, 1, 1, _one_tap(32).desc,
+                    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, B, heads * 1024, 0, HD * ldw, heads, 1024, 32 * ldw, 32 * ldw, S)
+    wq = packed(w_qkv, "conv_fwd")                            # [1][dim][r4(3 HD)]: row i, columns 0 .. HD-1 = Wq[:, i]
+    Nb = torch.empty((B, dim, ldw), device=xn.device, dtype=torch.float32)
+    L.cdf_conv_gemm(P(wq), wq.shape[-1], P(Mb), ldw, P(Nb), ldw, 1, 1, dim, HD, 1, dim, dim, 1, dim, 1, 1, 1, _one_tap(dim).desc,
+                    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, B, 0, HD * ldw, dim * ldw, 1, 0, 0, 0, S)
+    if y is None:
+        y = new_feat(xn, B, H, W, dim)
+    ldx, ldy = ld_of(xn), ld_of(y)
+    L.cdf_conv_gemm(P(xn), ldx, P(Nb), ldw, P(y), ldy, 1, 1, n, dim, 1, n, dim, 1, n, 1, 1, 1, _one_tap(n).desc,
+                    P(b_out), 0, 0, P(res), 0 if res is None else ld_of(res), 0, 0, 0, 0, 0, 0, 0, 0, B, n * ldx, dim * ldw, n * ldy, 1, 0, 0, 0, S)
+    return y, Mb, Nb
+
+
+def linattn_fold_bwd(xn, dy, Mb, Nb, ctx, ctxs, w_qkv, w_out, b_out, heads, scale):
+    """Backward of linattn_fold w.r.t. everything but k | v: returns (dxn, dctx, rvec) with dxn = dy . N_b^T (the q path's share of the
+    LayerNorm-output gradient); accumulates the gradients of Wq (rows 0 .. HD-1 of to_qkv), to_out.weight and to_out.bias."""
+    L, S = rt.lib(), rt.stream(xn)
+    B, H, W, _ = xn.shape
+    n, HD, dim = H * W, heads * 32, w_out.shape[0]
+    ldw, ldx, lddy = Mb.shape[-1], ld_of(xn), ld_of(dy)
+    dev = xn.device
+    dxn = new_feat(xn, B, H, W, dim)
+    L.cdf_conv_gemm(P(dy), lddy, P(Nb), ldw, P(dxn), ld_of(dxn), 1, 1, n, dim, 1, n, dim, 1, n, 1, 1, 1, _one_tap(n).desc,
+                    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, B, n * lddy, dim * ldw, n * ld_of(dxn), 1, 0, 0, 0, S)
+    # dN_b = xn[b]^T dy[b] (split-K slabs [split][b], summed in one pass); the bias gradient = column sums of dy as it streams by
+    wplan = cd.conv_wgrad(1, n, 1, 1, 1, 0, 0, 0, 0)
+    t1 = 1 if dim <= 64 else (dim + 127) // 128
+    ns = best_nsplit(t1 * t1 * B, 1024, max(1, n // 256))
+    ws = torch.empty((ns, B, dim, ldw), device=dev, dtype=torch.float32)
+    bsum = torch.empty((B * ns, ldw), device=dev, dtype=torch.float32) if b_out is not None else None
+    L.cdf_conv_wgrad(P(xn), ldx, P(dy), lddy, P(ws), ldw, 1, 1, n, 1, n, 1, 1, n, 1, dim, dim, 1, wplan.desc, ns, B, n * ldx, n * lddy, -1, P(bsum), S)
+    dNb = torch.empty((B, dim, ldw), device=dev, dtype=torch.float32)
+    L.cdf_unpack_reduce(P(ws), P(dNb), ns, B, dim, dim, ldw, dim * ldw, ldw, 1, 0, S)
+    if b_out is not None:
+        L.cdf_unpack_reduce(P(bsum), P(grad_of(b_out)), B * ns, 1, 1, dim, ldw, 0, 0, 1, 1, S)
+    # dM_b = Wq . dN_b  (Wq = rows 0 .. HD-1 of the to_qkv weight, a plain [HD][dim] matrix in place)
+    wq_rows = w_qkv.detach()
+    dMb = torch.empty((B, HD, ldw), device=dev, dtype=torch.float32)
+    L.cdf_conv_gemm(P(wq_rows), dim, P(dNb), ldw, P(dMb), ldw, 1, 1, HD, dim, 1, HD, dim, 1, HD, 1, 1, 1, _one_tap(HD).desc,
+                    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, B, 0, dim * ldw, HD * ldw, 1, 0, 0, 0, S)
+    # dWq[hd][i] += sum_b sum_c M_b[hd][c] dN_b[i][c]
+    T = torch.empty((B, HD, ldw), device=dev, dtype=torch.float32)
+    L.cdf_conv_gemm(P(Mb), ldw, P(dNb), ldw, P(T), ldw, 1, 1, HD, dim, 1, HD, dim, 1, HD, 1, 1, 1, _one_tap(HD).desc,
+                    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, B, HD * ldw, dim * ldw, HD * ldw, 1, 0, 0, 0, S)
+    L.cdf_unpack_reduce(P(T), P(grad_of(w_qkv)), B, 1, HD, dim, ldw, 0, dim, 1, 1, S)
+    dctx, rvec = _linattn_out_bwd(dMb, ctx, ctxs, w_out, heads, scale)
+    return dxn, dctx, rvec
+
+
+def linattn_bwd_core(qkv, dctx, rvec, kmax, ksum, dqkv, heads, koff=None):
+    """The softmax / v part of the attention backward given dctx and rvec (dq is already in dqkv).  koff: channel offset of k | v in
+    qkv's rows and of dk | dv in dqkv's (default heads*32; 0: both are (k|v) tensors, fused kernel only)."""
     L = rt.lib()
     B, H, W, _ = qkv.shape
     n, HD = H * W, heads * 32
     dev, S = qkv.device, rt.stream(qkv)
-    if _ATTN_KV_FUSED and heads <= 4:
+    koff = HD if koff is None else koff
+    if (_ATTN_KV_FUSED or koff != HD) and heads <= 4:
         # one pass: P recomputed from k, dP and dv on the fp32 matrix cores, dk / dv written straight into dqkv (k_attn.hip)
-        L.cdf_linattn_bwd_kv(P(qkv), ld_of(qkv), P(dctx), P(rvec), P(kmax), P(ksum), P(dqkv), ld_of(dqkv), B, n, heads, S)
+        L.cdf_linattn_bwd_kv(P(qkv), ld_of(qkv), koff, P(dctx), P(rvec), P(kmax), P(ksum), P(dqkv), ld_of(dqkv), koff, B, n, heads, S)
         return dqkv
+    if koff != HD:
+        raise ValueError("the (k|v)-only attention backward needs the fused kernel (heads <= 4)")
     pn = torch.empty((B, H, W, HD), device=dev, dtype=torch.float32)
     dp = torch.empty((B, H, W, HD), device=dev, dtype=torch.float32)
     L.cdf_linattn_softk(P(qkv), ld_of(qkv), P(kmax), P(ksum), P(pn), HD, B, n, heads, S)
@@ -606,18 +705,20 @@ def linattn_bwd_core(qkv, dctx, rvec, kmax, ksum, dqkv, heads):
 _ATTN_KV_FUSED = __import__("os").environ.get("CDF_ATTN_KV_FUSED", "1") != "0"
 
 
-def linattn_context(qkv, heads, scale):
-    """(ctx, ctxs = scale * ctx, kmax, ksum) of LinearAttention (no output product)."""
+def linattn_context(qkv, heads, scale, koff=None):
+    """(ctx, ctxs = scale * ctx, kmax, ksum) of LinearAttention (no output product).  koff: channel offset of k in qkv's rows
+    (default heads*32: the (q|k|v) tensor; 0 for a (k|v) tensor)."""
     L = rt.lib()
     B, H, W, _ = qkv.shape
     n, HD = H * W, heads * 32
+    koff = HD if koff is None else koff
     dev = qkv.device
     ctx = torch.empty((B, heads, 32, 32), device=dev, dtype=torch.float32)
     ctxs = torch.empty_like(ctx)
     kmax = torch.empty((B, HD), device=dev, dtype=torch.float32)
     ksum = torch.empty((B, HD), device=dev, dtype=torch.float32)
     ws = torch.empty((L.cdf_linattn_ws_floats(B, n, heads),), device=dev, dtype=torch.float32)
-    L.cdf_linattn_context(P(qkv), ld_of(qkv), P(ctx), P(ctxs), P(kmax), P(ksum), P(ws), B, n, heads, scale, rt.stream(qkv))
+    L.cdf_linattn_context(P(qkv), ld_of(qkv), koff, P(ctx), P(ctxs), P(kmax), P(ksum), P(ws), B, n, heads, scale, rt.stream(qkv))
     return ctx, ctxs, kmax, ksum
 
 

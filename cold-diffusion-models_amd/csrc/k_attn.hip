@@ -16,13 +16,13 @@
 
 // ---- pass 1: per (b, chunk, channel) max of k ---------------------------------------------------
 // grid = (HD/64, nchunk, B); block 256 = 4 row lanes x 64 channels ; part [B][nchunk][HD]
-__global__ void linattn_kmax_kernel(const float* qkv, int ld, float* part, int n, int rows_per_chunk, int HD) {
+__global__ void linattn_kmax_kernel(const float* qkv, int ld, float* part, int n, int rows_per_chunk, int HD, int koff) {
     __shared__ float red[4][64];
     const int l = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + l, b = blockIdx.z;
     const int r0 = blockIdx.y * rows_per_chunk;
     int r1 = r0 + rows_per_chunk;
     if (r1 > n) r1 = n;
-    const float* kp = qkv + (long long)b * n * ld + HD + c;
+    const float* kp = qkv + (long long)b * n * ld + koff + c;
     float m = -3.0e38f;
     {
         // 8 rows in flight per lane (one load per loop trip is a chain of memory round trips)
@@ -234,17 +234,18 @@ extern "C" size_t cdf_linattn_ws_floats(int B, int n, int heads) {
 
 // Context pass: ctx[b,h,d,e] = sum_n softmax_n(k)[d,n] v[e,n]; ctxs = scale*ctx; kmax/ksum [B,HD] saved.
 // The output  out[n, h*32+e] = sum_d q[n, h*32+d] ctxs[h,d,e]  is a K=32 GEMM per (b, head): cdf_conv_gemm.
-extern "C" int cdf_linattn_context(const float* qkv, int ld, float* ctx, float* ctxs, float* kmax, float* ksum, float* ws,
+extern "C" int cdf_linattn_context(const float* qkv, int ld, int koff, float* ctx, float* ctxs, float* kmax, float* ksum, float* ws,
                                    int B, int n, int heads, float scale, void* stream) {
     CDF_REQUIRE(qkv && ctx && ctxs && kmax && ksum && ws, "cdf_linattn_context: null pointer");
     const int HD = heads * LA_D;
-    CDF_REQUIRE(HD % 64 == 0 && ld % 4 == 0 && ld >= 3 * HD, "cdf_linattn_context: heads=%d unsupported / bad pitch", heads);
+    CDF_REQUIRE(HD % 64 == 0 && ld % 4 == 0 && koff >= 0 && koff % 4 == 0 && ld >= koff + 2 * HD,
+                "cdf_linattn_context: heads=%d unsupported / bad pitch or k offset", heads);
     const int ns = cdf_linattn_nsplit(n), rps = cdf_cdiv(cdf_cdiv(n, ns), 2) * 2;
     float* kmax_part = ws;
     float* ctx_part = kmax_part + (size_t)B * ns * HD;
     float* sum_part = ctx_part + (size_t)B * ns * heads * LA_D * LA_D;
-    CDF_LAUNCH(linattn_kmax_kernel, dim3(HD / 64, ns, B), dim3(256), 0, CDF_S, qkv, ld, kmax_part, n, rps, HD);
-    CDF_LAUNCH((linattn_ctx_kernel<true>), dim3(heads, ns, B), dim3(256), 0, CDF_S, qkv + HD, ld, qkv + 2 * HD, ld, (const float*)kmax_part, ns, ctx_part, sum_part, n, rps, HD);
+    CDF_LAUNCH(linattn_kmax_kernel, dim3(HD / 64, ns, B), dim3(256), 0, CDF_S, qkv, ld, kmax_part, n, rps, HD, koff);
+    CDF_LAUNCH((linattn_ctx_kernel<true>), dim3(heads, ns, B), dim3(256), 0, CDF_S, qkv + koff, ld, qkv + koff + HD, ld, (const float*)kmax_part, ns, ctx_part, sum_part, n, rps, HD);
     CDF_LAUNCH(linattn_ctx_final_kernel, dim3(heads, B), dim3(256), 0, CDF_S, (const float*)ctx_part, (const float*)sum_part, (const float*)kmax_part, ns, ns, HD, ctx, ctxs, scale, kmax, ksum);
     return cdf_check_launch("linattn_context");
 }
@@ -299,7 +300,7 @@ extern "C" int cdf_linattn_dk(const float* pn, int ldp, const float* dp, int ldd
 #define LA_TILES 8                                           // 32-pixel tiles per wave
 
 __global__ void __launch_bounds__(256) linattn_bwd_kv_kernel(const float* qkv, int ld, const float* dctx, const float* rvec, const float* kmax,
-                                                            const float* ksum, float* dqkv, int lddq, int n, int heads) {
+                                                            const float* ksum, float* dqkv, int lddq, int n, int heads, int koff, int dkoff) {
     CDF_DYN_SMEM(smem_raw);
     const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, b = blockIdx.y;
     const int HD = heads * LA_D;
@@ -320,9 +321,9 @@ __global__ void __launch_bounds__(256) linattn_bwd_kv_kernel(const float* qkv, i
     const float4 km = *(const float4*)(kmax + (size_t)b * HD + h * LA_D + lc);
     const float4 ks = *(const float4*)(ksum + (size_t)b * HD + h * LA_D + lc);
     const float4 ri = make_float4(1.0f / ks.x, 1.0f / ks.y, 1.0f / ks.z, 1.0f / ks.w);
-    const float* kbase = qkv + (size_t)b * n * ld + HD + h * LA_D + lc;
+    const float* kbase = qkv + (size_t)b * n * ld + koff + h * LA_D + lc;
     const float* vbase = kbase + HD;
-    float* dkbase = dqkv + (size_t)b * n * lddq + HD + h * LA_D + lc;
+    float* dkbase = dqkv + (size_t)b * n * lddq + dkoff + h * LA_D + lc;
     float* dvbase = dkbase + HD;
     const int p_begin = blockIdx.x * (LA_D * LA_TILES);
     for (int t = 0; t < LA_TILES; ++t) {
@@ -381,14 +382,15 @@ __global__ void __launch_bounds__(256) linattn_bwd_kv_kernel(const float* qkv, i
     }
 }
 
-extern "C" int cdf_linattn_bwd_kv(const float* qkv, int ld, const float* dctx, const float* rvec, const float* kmax, const float* ksum,
-                                  float* dqkv, int lddq, int B, int n, int heads, void* stream) {
+extern "C" int cdf_linattn_bwd_kv(const float* qkv, int ld, int koff, const float* dctx, const float* rvec, const float* kmax, const float* ksum,
+                                  float* dqkv, int lddq, int dkoff, int B, int n, int heads, void* stream) {
     CDF_REQUIRE(qkv && dctx && rvec && kmax && ksum && dqkv && B > 0 && n > 0, "cdf_linattn_bwd_kv: null pointer");
-    CDF_REQUIRE(heads >= 1 && heads <= 4 && ld % 4 == 0 && lddq % 4 == 0 && ld >= 3 * heads * LA_D && lddq >= 3 * heads * LA_D &&
+    CDF_REQUIRE(heads >= 1 && heads <= 4 && ld % 4 == 0 && lddq % 4 == 0 && koff >= 0 && dkoff >= 0 && koff % 4 == 0 && dkoff % 4 == 0 &&
+                ld >= koff + 2 * heads * LA_D && lddq >= dkoff + 2 * heads * LA_D &&
                 ((((uintptr_t)qkv) | ((uintptr_t)dqkv) | ((uintptr_t)kmax) | ((uintptr_t)ksum)) & 15) == 0,
-                "cdf_linattn_bwd_kv: up to 4 heads; pitches must be multiples of 4, pointers 16-byte aligned");
+                "cdf_linattn_bwd_kv: up to 4 heads; pitches / channel offsets must be multiples of 4 and hold k | v, pointers 16-byte aligned");
     const size_t lds = (size_t)heads * 3 * LA_D * LA_TP * sizeof(float);
-    CDF_LAUNCH(linattn_bwd_kv_kernel, dim3(cdf_cdiv(n, LA_D * LA_TILES), B), dim3(64 * heads), lds, CDF_S, qkv, ld, dctx, rvec, kmax, ksum, dqkv, lddq, n, heads);
+    CDF_LAUNCH(linattn_bwd_kv_kernel, dim3(cdf_cdiv(n, LA_D * LA_TILES), B), dim3(64 * heads), lds, CDF_S, qkv, ld, dctx, rvec, kmax, ksum, dqkv, lddq, n, heads, koff, dkoff);
     return cdf_check_launch("linattn_bwd_kv");
 }
 

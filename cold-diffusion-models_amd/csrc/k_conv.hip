@@ -18,6 +18,7 @@
 // (register prefetch of step i+1 while step i is on the matrix pipe, one barrier per step).
 // The MFMA k index is free as long as A and B agree, so lane half h owns k = 8h..8h+7 of the
 // chunk: its A fragment is two ds_read_b128 (row stride 20 floats -> conflict-free).
+#include <atomic>
 #include "cdf_common.h"
 #include "cdf_epilogue.h"
 #include "colddiff.h"
@@ -519,6 +520,68 @@ __global__ void __launch_bounds__(64 * SL) unpack_reduce_kernel(const float* ws,
     }
 }
 
+// Transposing form of the slab reduction for parameter layouts whose fast index is NOT the slab's (conv weights [Cout][Cin][kh][kw]:
+// s_c = Cin kh kw).  The kernel above hands 64 consecutive c to a block: every result is a lone 4-byte read-modify-write
+// s_c floats from its neighbours -- a 32-byte sector moved each way per 4 useful bytes, neighbours in (r, t) landing on other XCDs.
+// Here a block owns a tile of 32 c x RJ r x T taps (J = RJ T <= 36 values per c): 32 c-lanes x 8 slab-lanes, every lane J independent
+// loads per slab (128-byte rows over c), the 8 slab-lanes are folded through LDS in a fixed order (deterministic) and the tile leaves
+// as runs of J consecutive floats per c (144 B for 3 x 3, the whole [c][t] block for transposed-conv weights).
+template <int T_, int RJ>
+__device__ __forceinline__ void unpack_tile_body(const float* ws, float* g, int nsplit, int R, int C, int ldc, long long s_t, long long s_r,
+                                                 long long s_c, int accumulate, int tile, float* red) {
+    constexpr int J = T_ * RJ;
+    const int cl = threadIdx.x & 31, zg = threadIdx.x >> 5;
+    const int tiles_c = (C + 31) >> 5;
+    const int tr = tile / tiles_c, tc = tile - tr * tiles_c;
+    const int c0 = tc * 32, r0 = tr * RJ;
+    const long long slab = (long long)T_ * R * ldc;
+    const int cc = c0 + cl < C ? c0 + cl : C - 1;
+    int roff[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int r = r0 + j / T_, t = j % T_;
+        roff[j] = (t * R + (r < R ? r : R - 1)) * ldc + cc;
+    }
+    float acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[j] = 0.f;
+    for (int z = zg; z < nsplit; z += 8) {
+        const float* p = ws + (long long)z * slab;
+        float v[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) v[j] = p[roff[j]];
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[j] += v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) red[(zg * J + j) * 33 + cl] = acc[j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * J; e += 256) {
+        const int c_l = e / J, j = e - c_l * J;
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q += 4)
+            tot += (red[(q * J + j) * 33 + c_l] + red[((q + 1) * J + j) * 33 + c_l]) + (red[((q + 2) * J + j) * 33 + c_l] + red[((q + 3) * J + j) * 33 + c_l]);
+        const int c = c0 + c_l, r = r0 + j / T_, t = j % T_;
+        if (c < C && r < R) {
+            float* dst = g + c * s_c + r * s_r + t * s_t;
+            *dst = accumulate ? *dst + tot : tot;
+        }
+    }
+}
+
+template <int T_, int RJ>
+__global__ void __launch_bounds__(256) unpack_reduce_tiled_kernel(const float* ws, float* g, int nsplit, int R, int C, int ldc, long long s_t,
+                                                                   long long s_r, long long s_c, int accumulate, const float* bws, float* gb,
+                                                                   int bC, int bld) {
+    __shared__ float red[8 * T_ * RJ * 33 > 8 * 33 ? 8 * T_ * RJ * 33 : 8 * 33];
+    if (blockIdx.y == 1) {                                   // the fused bias reduction: a [1][1][bC] tensor, unit strides
+        if ((int)blockIdx.x < (bC + 31) / 32) unpack_tile_body<1, 1>(bws, gb, nsplit, 1, bC, bld, 0, 0, 1, accumulate, blockIdx.x, red);
+        return;
+    }
+    unpack_tile_body<T_, RJ>(ws, g, nsplit, R, C, ldc, s_t, s_r, s_c, accumulate, blockIdx.x, red);
+}
+
 // column sums of a row-major matrix with pitch, two deterministic stages:
 //   stage 1: part[(seg*nchunk + chunk)][c] = sum_{r in chunk of segment} x[r*ld + c]
 //   stage 2: out[seg][c] (+)= sum_chunk part
@@ -756,8 +819,28 @@ extern "C" int cdf_pack_weight(const float* src, float* dst, int T, int R, int C
     return cdf_check_launch("pack_weight");
 }
 
+static std::atomic<int> g_unpack_tiled{1};
+extern "C" int cdf_unpack_reduce_tiled(int on) {             // tuning / test hook (process-wide): the transposing tiled reduction
+    g_unpack_tiled.store(on ? 1 : 0);
+    return 0;
+}
+
 static int launch_unpack_reduce(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t, long long s_r,
                                 long long s_c, int accumulate, const float* bws, float* gb, int bC, int bld, hipStream_t s) {
+    if (s_c != 1 && C >= 32 && (T == 1 || T == 9 || T == 16) && g_unpack_tiled.load()) {
+        const int RJ = T == 9 ? 4 : (T == 16 ? 2 : 32);
+        const long long tiles = (long long)((C + 31) / 32) * ((R + RJ - 1) / RJ);
+        if (tiles < (1 << 30) && (!bws || (bC + 31) / 32 <= tiles)) {
+            const dim3 tg((unsigned)tiles, bws ? 2 : 1);
+            if (T == 9)
+                CDF_LAUNCH((unpack_reduce_tiled_kernel<9, 4>), tg, dim3(256), 0, s, ws, g, nsplit, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld);
+            else if (T == 16)
+                CDF_LAUNCH((unpack_reduce_tiled_kernel<16, 2>), tg, dim3(256), 0, s, ws, g, nsplit, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld);
+            else
+                CDF_LAUNCH((unpack_reduce_tiled_kernel<1, 32>), tg, dim3(256), 0, s, ws, g, nsplit, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld);
+            return cdf_check_launch("unpack_reduce_tiled");
+        }
+    }
     const dim3 grid(ew_grid2((long long)T * R * C * 4), bws ? 2 : 1);
     if (nsplit >= 32)       // 16 slab lanes: every lane still has >= 2 slabs
         CDF_LAUNCH(unpack_reduce_kernel<16>, grid, dim3(1024), 0, s, ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld);

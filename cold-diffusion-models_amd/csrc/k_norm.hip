@@ -97,8 +97,9 @@ template <int NV>
 __global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const float* dy, int lddy, const float* x, int ldx,
                                                               const float* g, const float* mean_in, const float* rstd_in,
                                                               float* dx, int lddx, float* part, long long M, int C,
-                                                              int LP, int accumulate_dx) {
+                                                              int LP, const float* add, int ldadd) {
     constexpr int U = NV <= 2 ? 2 : 1;
+    const bool accumulate_dx = add != nullptr;               // dx = grad + add (add == dx: accumulate in place)
     CDF_DYN_SMEM(smem);
     float* sred = (float*)smem;  // [G][2][C]
     const int lane = threadIdx.x & 63, sub = lane / LP, li = lane - sub * LP;
@@ -133,7 +134,7 @@ __global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const float* dy, i
                 const float4 tx = *(const float4*)(x + mc * ldx + cc), td = *(const float4*)(dy + mc * lddy + cc);
                 xv[u][j] = ok ? tx : make_float4(mean[u], mean[u], mean[u], mean[u]);      // => xhat = 0
                 dv[u][j] = ok ? td : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (accumulate_dx) old[u][j] = *(const float4*)(dx + mc * lddx + cc);      // block-uniform branch
+                if (accumulate_dx) old[u][j] = *(const float4*)(add + mc * ldadd + cc);    // block-uniform branch
             }
         }
 #pragma unroll
@@ -459,11 +460,13 @@ extern "C" int cdf_layernorm_c_fwd(const float* x, int ldx, float* y, int ldy, c
 
 // part: >= cdf_layernorm_blocks(M, C) * 2 * C floats
 extern "C" int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, int ldx, const float* g,
-                                   const float* mean, const float* rstd, float* dx, int lddx, float* dg, float* db,
-                                   float* part, long long M, int C, int accumulate_dx, int accumulate_param,
+                                   const float* mean, const float* rstd, float* dx, int lddx, const float* add, int ldadd,
+                                   float* dg, float* db, float* part, long long M, int C, int accumulate_dx, int accumulate_param,
                                    void* stream) {
     CDF_REQUIRE(dy && x && g && mean && rstd && dx && dg && db && part && M > 0, "cdf_layernorm_c_bwd: null / empty");
     CDF_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && C <= 1024, "cdf_layernorm_c_bwd: bad C / pitch");
+    CDF_REQUIRE(!(add && accumulate_dx) && (!add || (ldadd % 4 == 0 && (((uintptr_t)add) & 15) == 0)), "cdf_layernorm_c_bwd: add and accumulate_dx exclude each other; add must be 16-byte aligned with a pitch % 4 == 0");
+    if (accumulate_dx) { add = dx; ldadd = lddx; }
     int LP, NV;
     CDF_REQUIRE(ln_geometry(C, &LP, &NV) == CDF_OK, "cdf_layernorm_c_bwd: unsupported C=%d", C);
     const int nb = cdf_layernorm_blocks(M, C);
@@ -479,7 +482,7 @@ extern "C" int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, in
         attr_done = true;
     }
 #endif
-#define CDF_LN_BWD(N) CDF_LAUNCH((layernorm_c_bwd_kernel<N>), dim3(nb), dim3(256), lds, CDF_S, dy, lddy, x, ldx, g, mean, rstd, dx, lddx, part, M, C, LP, accumulate_dx)
+#define CDF_LN_BWD(N) CDF_LAUNCH((layernorm_c_bwd_kernel<N>), dim3(nb), dim3(256), lds, CDF_S, dy, lddy, x, ldx, g, mean, rstd, dx, lddx, part, M, C, LP, add, ldadd)
     switch (NV) {
         case 1: CDF_LN_BWD(1); break;
         case 2: CDF_LN_BWD(2); break;

@@ -246,6 +246,10 @@ int cdf_unpack_reduce(const float* ws, float* g, int nsplit, int T, int R, int C
  * gbias[c] (+)= sum_z bias_ws[z * bias_ld + c], c < C (the `bsum` partials of cdf_conv_wgrad*). */
 int cdf_unpack_reduce_bias(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t, long long s_r,
                            long long s_c, const float* bias_ws, float* gbias, int bias_ld, int accumulate, void* stream);
+/* tuning / test hook (process-wide, see RE-ENTRANCY): 1 (default) = parameter layouts whose fast index is not the slab's (s_c != 1, T in
+ * {1, 9, 16}) are reduced by the LDS-tiled transposing kernel (contiguous runs per output channel instead of lone 4-byte
+ * read-modify-writes); 0 = always the element-wise kernel.  Same sums either way up to fp32 summation order. */
+int cdf_unpack_reduce_tiled(int on);
 
 /* out[seg][c] (+)= sum over the rows of segment seg of x[r*ld + c]  (bias / time-bias gradients);
  * ws >= nseg * cdf_colsum_nchunk(rows_per_seg) * C floats */
@@ -260,9 +264,11 @@ int cdf_colsum(const float* x, float* out, float* ws, int nseg, int rows_per_seg
 int cdf_layernorm_blocks(long long M, int C);
 int cdf_layernorm_c_fwd(const float* x, int ldx, float* y, int ldy, const float* g, const float* b, float* mean,
                         float* rstd, long long M, int C, float eps, void* y_hi, void* y_lo, int ld_ys, void* stream);
+/* add (nullable, pitch ldadd): dx = grad + add -- the residual branch of Residual(PreNorm(..)) added in the same pass instead of a
+ * copy + accumulate; accumulate_dx = 1 is the same with add = dx (the two exclude each other). */
 int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, int ldx, const float* g, const float* mean,
-                        const float* rstd, float* dx, int lddx, float* dg, float* db, float* part, long long M, int C,
-                        int accumulate_dx, int accumulate_param, void* stream);
+                        const float* rstd, float* dx, int lddx, const float* add, int ldadd, float* dg, float* db, float* part,
+                        long long M, int C, int accumulate_dx, int accumulate_param, void* stream);
 /* GroupNorm(groups) [+ SiLU] (Model2.py:27-33): statistics per (sample, group) over C/groups channels
  * and all HW pixels; mean/rstd [B][groups].  fwd ws >= B*nchunk*2*C floats;
  * bwd ws >= B*nchunk*2*C + B*2*C + B*groups*2 floats, nchunk = cdf_groupnorm_nchunk(HW). */
@@ -297,7 +303,9 @@ int cdf_dwconv7_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
  * ws >= cdf_linattn_ws_floats(B,n,heads) floats. */
 int cdf_linattn_nsplit(int n);
 size_t cdf_linattn_ws_floats(int B, int n, int heads);
-int cdf_linattn_context(const float* qkv, int ld, float* ctx, float* ctxs, float* kmax, float* ksum, float* ws, int B,
+/* koff: channel offset of k inside a row (v follows at koff + heads*32): heads*32 for the reference's (q|k|v) tensor, 0 for a (k|v)
+ * tensor (the q-free form of colddiff/ops.py linattn_fold: q never exists when dim <= heads*32). */
+int cdf_linattn_context(const float* qkv, int ld, int koff, float* ctx, float* ctxs, float* kmax, float* ksum, float* ws, int B,
                         int n, int heads, float scale, void* stream);
 int cdf_linattn_dcontext(const float* qkv, int ld, const float* dout, int lddo, const float* ctx, float* dctx,
                          float* rvec, float* ws, int B, int n, int heads, float scale, void* stream);
@@ -307,9 +315,10 @@ int cdf_linattn_dk(const float* pn, int ldp, const float* dp, int lddp, const fl
                    int n, int heads, void* stream);
 /* cdf_linattn_bwd_kv: the k / v part of the attention backward in one pass (replaces cdf_linattn_softk + two K = 32 products +
  * cdf_linattn_dk): dk[n,d] = P[n,d] (sum_e v[n,e] dctx[d,e] - rvec[d]),  dv[n,e] = sum_d P[n,d] dctx[d,e],  P = softmax_n(k) recomputed
- * from kmax / ksum; written into the k and v column blocks of dqkv ([B,n,3 HD], pitch lddq).  heads <= 4. */
-int cdf_linattn_bwd_kv(const float* qkv, int ld, const float* dctx, const float* rvec, const float* kmax, const float* ksum, float* dqkv,
-                       int lddq, int B, int n, int heads, void* stream);
+ * from kmax / ksum; k | v are read at channel offset koff of qkv's rows, dk | dv written at channel offset dkoff of dqkv's rows
+ * (pitch lddq).  heads <= 4. */
+int cdf_linattn_bwd_kv(const float* qkv, int ld, int koff, const float* dctx, const float* rvec, const float* kmax, const float* ksum,
+                       float* dqkv, int lddq, int dkoff, int B, int n, int heads, void* stream);
 /* cdf_linattn_dctx_finish: dctx[i] = scale * raw[i]; rvec[row] = sum_e dctx[row][e] * ctx[row][e] over rows of 32 (rows = B * heads * 32):
  * the tail of the fused attention backward, where raw = d(scale * ctx) comes out of a batched GEMM (see colddiff/ops.py linattn_bwd). */
 int cdf_linattn_dctx_finish(const float* raw, const float* ctx, float* dctx, float* rvec, long long rows, float scale, void* stream);

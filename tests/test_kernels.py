@@ -358,8 +358,16 @@ def test_layernorm_c(be, M, C):
     be.L.cdf_layernorm_c_fwd(P(xd), C, P(y), C, P(gd), P(bd), P(mo), P(ro), M, C, 1e-5, 0, 0, 0, be.stream())
     nb = be.L.cdf_layernorm_blocks(M, C)
     part, dx, dg, db = be.empty(nb * 2 * C), be.empty(M, C), be.zeros(C), be.zeros(C)
-    be.L.cdf_layernorm_c_bwd(P(be.to(dy)), C, P(xd), C, P(gd), P(mo), P(ro), P(dx), C, P(dg), P(db), P(part), M, C, 0, 0, be.stream())
+    be.L.cdf_layernorm_c_bwd(P(be.to(dy)), C, P(xd), C, P(gd), P(mo), P(ro), P(dx), C, 0, 0, P(dg), P(db), P(part), M, C, 0, 0, be.stream())
     assert err(y, yref) <= 5e-6 and err(dx, x.grad) <= 1e-5 and err(dg, g.grad) <= 2e-5 and err(db, b.grad) <= 2e-5
+    # dx = grad + add (the residual branch, a pitched second tensor) and the in-place accumulate form
+    addt = torch.randn(M, C + 4)
+    addd, dx2 = be.to(addt), be.empty(M, C)
+    be.L.cdf_layernorm_c_bwd(P(be.to(dy)), C, P(xd), C, P(gd), P(mo), P(ro), P(dx2), C, P(addd), C + 4, P(dg), P(db), P(part), M, C, 0, 0, be.stream())
+    assert err(dx2, x.grad + addt[:, :C]) <= 1e-5
+    dx3 = be.to(addt[:, :C].contiguous())
+    be.L.cdf_layernorm_c_bwd(P(be.to(dy)), C, P(xd), C, P(gd), P(mo), P(ro), P(dx3), C, 0, 0, P(dg), P(db), P(part), M, C, 1, 0, be.stream())
+    assert torch.equal(dx3.cpu(), dx2.cpu())
     if C % 8 == 0:
         # fused operand split: the bf16 hi / lo planes must equal cdf_split_bf16 of the stored output, bit for bit
         y2 = be.empty(M, C)
@@ -795,6 +803,40 @@ def test_unpack_reduce(be, ns):
         assert err(gb, gb0 + bws[:, :C].double().sum(0).float()) <= 2e-6 * math.sqrt(ns) * 4
 
 
+@pytest.mark.parametrize("T,R,C,conv_t", [(9, 10, 70, False), (9, 3, 128, False), (16, 5, 33, False), (16, 7, 64, True), (1, 45, 100, False)])
+@pytest.mark.parametrize("ns", [1, 5, 19])
+def test_unpack_reduce_tiled(be, T, R, C, conv_t, ns):
+    """The LDS-tiled transposing form of the slab reduction (conv weights: the slab's fast index c is the layout's slowest): ragged
+    tiles in c and r, 3x3 / 4x4 / 1x1 tap counts, transposed-conv strides, fused bias row, accumulate on and off -- against the
+    element-wise kernel's contract and against that kernel itself (hook off)."""
+    torch.manual_seed(ns + T)
+    ldc = (C + 3) // 4 * 4
+    ws = torch.randn(ns, T, R, ldc)
+    if conv_t:                                           # weight [R = Cin][C = Cout][T]: s_r = C T, s_c = T
+        g0, s_r, s_c = torch.randn(R, C, T), C * T, T
+        ref_add = ws[..., :C].double().sum(0).permute(1, 2, 0).float()
+    else:                                                # weight [C = Cout][R = Cin][T]
+        g0, s_r, s_c = torch.randn(C, R, T), T, R * T
+        ref_add = ws[..., :C].double().sum(0).permute(2, 1, 0).float()
+    bws, gb0 = torch.randn(ns, ldc), torch.randn(C)
+    tol = 2e-6 * math.sqrt(ns) * max(1.0, (g0 + ref_add).abs().max().item())
+    outs = []
+    try:
+        for tiled in (1, 0):
+            be.L.cdf_unpack_reduce_tiled(tiled)
+            g, gb = be.to(g0), be.to(gb0)
+            be.L.cdf_unpack_reduce_bias(P(be.to(ws)), P(g), ns, T, R, C, ldc, 1, s_r, s_c, P(be.to(bws)), P(gb), ldc, 1, be.stream())
+            assert err(g, g0 + ref_add) <= tol
+            assert err(gb, gb0 + bws[:, :C].double().sum(0).float()) <= 2e-6 * math.sqrt(ns) * 4
+            g2 = be.to(g0)
+            be.L.cdf_unpack_reduce(P(be.to(ws)), P(g2), ns, T, R, C, ldc, 1, s_r, s_c, 0, be.stream())
+            assert err(g2, ref_add) <= tol
+            outs.append(g2.detach().cpu().clone())
+    finally:
+        be.L.cdf_unpack_reduce_tiled(1)
+    assert (outs[0] - outs[1]).abs().max().item() <= tol
+
+
 @pytest.mark.parametrize("M,K,N", [(32, 64, 256), (5, 256, 40), (70, 48, 130)])
 def test_linear_small(be, M, K, N):
     """Skinny linear layer kernels against torch: forward (packed [K][N] weight), data gradient (PyTorch [N][K] weight),
@@ -912,7 +954,7 @@ def test_linattn_bwd_kv_fused(be, B, n, heads):
     dk_ref = (Ph * (dP - rvec.view(B, 1, heads, 32))).reshape(B, n, HD)
     dv_ref = torch.einsum("bnhd,bhde->bnhe", Ph, dctx).reshape(B, n, HD)
     dqkv = be.zeros(B, n, 3 * HD)
-    be.L.cdf_linattn_bwd_kv(P(be.to(qkv)), 3 * HD, P(be.to(dctx)), P(be.to(rvec)), P(be.to(kmax)), P(be.to(ksum)), P(dqkv), 3 * HD, B, n, heads,
+    be.L.cdf_linattn_bwd_kv(P(be.to(qkv)), 3 * HD, HD, P(be.to(dctx)), P(be.to(rvec)), P(be.to(kmax)), P(be.to(ksum)), P(dqkv), 3 * HD, HD, B, n, heads,
                             be.stream())
     out = dqkv.cpu()
     assert (out[..., :HD] == 0).all()                                   # the q block is not this kernel's

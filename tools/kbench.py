@@ -99,7 +99,7 @@ for (C, H) in [(64, 128), (256, 32), (1024, 16)]:
     rec(f"layernorm_fwd_M{M}_C{C}", ms, bytes_=8.0 * x.numel())
     nb = L.cdf_layernorm_blocks(M, C)
     part, dx, dg, db = torch.empty(nb * 2 * C, device=dev), torch.empty_like(x), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
-    ms = timeit(lambda: L.cdf_layernorm_c_bwd(P(y), C, P(x), C, P(g), P(mo), P(ro), P(dx), C, P(dg), P(db), P(part), M, C, 0, 0, S()))
+    ms = timeit(lambda: L.cdf_layernorm_c_bwd(P(y), C, P(x), C, P(g), P(mo), P(ro), P(dx), C, 0, 0, P(dg), P(db), P(part), M, C, 0, 0, S()))
     rec(f"layernorm_bwd_M{M}_C{C}", ms, bytes_=12.0 * x.numel())
 
 # linear attention
