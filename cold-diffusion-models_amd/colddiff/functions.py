@@ -72,6 +72,7 @@ def want_presplit(Cin, Cout, k):
 
 
 _CIN4 = os.environ.get("CDF_CIN4", "1") != "0"    # direct kernels for the <= 4-input-channel image-side convs
+_CIN_DGRAD2 = os.environ.get("CDF_CIN_DGRAD2", "1") != "0"   # their 3x3 data gradient in two stages (ops.conv_cin_dgrad2)
 _ATTN_FUSED = os.environ.get("CDF_ATTN_FUSED", "1") != "0"   # to_out folded into the linear-attention product (ops.linattn_project)
 _LEAN = os.environ.get("CDF_LEAN", "1") != "0"    # skip fp32 copies of tensors only ever consumed as bf16 planes
 _LINEAR_SMALL_M = 256      # batch sizes up to this use the skinny-linear kernels
@@ -395,11 +396,15 @@ class ConvNextBlockFn(torch.autograd.Function):
         else:
             dpre, dpre_s = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=1, xs=a_s, dys=do_s), None
         if ctx.cin4:
-            # weight / bias gradient by the direct kernel (reads dpre once); the data gradient re-reads dpre per tap from
-            # L2 either way and is faster on the MFMA gather-GEMM (229 vs 363 us)
+            # weight / bias gradient by the direct kernel (reads dpre once); the data gradient in two stages (sum over the mid
+            # channels per pixel as a 1x1 GEMM, then the nine shifted 3-vectors: ops.conv_cin_dgrad2) instead of a K = 9 mid
+            # gather-GEMM with 3 useful output columns (0.4 ms at 128 x 128)
             ops.conv_cin4_bwd(hn, dpre, c1.weight, c1.bias, False)
-            pd = _conv_plans("conv", hn.shape[1], hn.shape[2], 3, 1, (1, 1, 1, 1))[1]
-            dhn = ops.conv_gemm(pd, dpre, mid, ops.packed(c1.weight, "conv_dgrad"), dim)
+            if _CIN_DGRAD2 and c1.weight.shape[-1] == 3:
+                dhn = ops.conv_cin_dgrad2(dpre, mid, c1.weight)
+            else:
+                pd = _conv_plans("conv", hn.shape[1], hn.shape[2], 3, 1, (1, 1, 1, 1))[1]
+                dhn = ops.conv_gemm(pd, dpre, mid, ops.packed(c1.weight, "conv_dgrad"), dim)
         else:
             dhn = conv_backward(hn, dim, dpre, c1.weight, c1.bias, xs=hn_s, dys=dpre_s)
         if m.has_norm:

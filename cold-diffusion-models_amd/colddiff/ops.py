@@ -93,6 +93,10 @@ def _pack_geom0(w, kind):
             KK = KH * KW
             N, K, s_n, s_k = (Co, Ci, Ci * KK, KK) if kind == "conv_fwd_sp" else (Ci, Co, KK, Ci * KK)
         return (KK, N, K, (K + 31) // 32 * 32, 1, s_n, s_k, True)
+    if kind == "cin_z":
+        # [1][Cout][9 Cin]: the 3x3 weight as the [K = Cout][N = Cin 9] matrix of the two-stage small-Cin data gradient (conv_cin_dgrad2)
+        Co, Ci, KH, KW = w.shape
+        return (1, Co, Ci * KH * KW, r4(Ci * KH * KW), 0, Ci * KH * KW, 1, False)
     if kind == "dw":
         return (49, 1, w.shape[0], r4(w.shape[0]), 1, 0, 49, False)
     if kind == "lin_fwd":
@@ -311,6 +315,19 @@ def conv_cin4_bwd(x, dy, weight, bias, need_dx, dx=None, dx_accumulate=0):
         dx_accumulate = 0
     wp = packed(weight, "cin4")
     L.cdf_conv_cin4_dgrad(P(dy), ld_of(dy), P(wp), wp.shape[-1], P(dx), B, H, W, Cout, k, dx_accumulate, S)
+    return dx
+
+
+def conv_cin_dgrad2(dy, Cout, weight):
+    """Data gradient of a 3x3 'same' conv with <= 4 input channels in two stages (k_conv_cin4.hip: tapsum3_kernel): the sum over
+    the Cout channels first, per pixel, as a 1x1 GEMM onto the 9 Cin (c, ky, kx) columns (dy is read ONCE instead of nine times
+    through a K = 9 Cout gather-GEMM with 3 useful output columns), then the nine shifted 3-vectors are added.  Returns dx [B,H,W,4]."""
+    B, H, W, _ = dy.shape
+    Cin = weight.shape[1]
+    plan = cd.conv_fwd(H, W, 1, 1, 1, 0, 0, 0, 0)
+    z = conv_gemm(plan, dy, Cout, packed(weight, "cin_z"), 9 * Cin)
+    dx = torch.empty((B, H, W, 4), device=dy.device, dtype=torch.float32)
+    rt.lib().cdf_conv_cin4_tapsum3(P(z), ld_of(z), P(dx), B, H, W, Cin, 0, rt.stream(dy))
     return dx
 
 

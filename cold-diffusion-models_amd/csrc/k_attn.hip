@@ -9,6 +9,7 @@
 // and v are each read once per pass; O(n d^2) work, HBM-bound.
 //
 // AttnBlock softmax (Model2.py:164-188): row softmax of the [n, n] score matrix with scale C^-0.5.
+#include <atomic>
 #include "cdf_common.h"
 #include "colddiff.h"
 
@@ -100,6 +101,122 @@ __global__ void __launch_bounds__(256) linattn_ctx_kernel(const float* a_ptr, in
     if (sum_part && threadIdx.x < LA_D)
         sum_part[((long long)b * gridDim.y + split) * HD + h * LA_D + threadIdx.x] =
             (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+}
+
+// ---- one-pass context partials (round 2) -----------------------------------------------------------
+// The two passes above read k twice (column max, then exp(k - max)^T v with 4-byte loads per lane).  Here a block owns 256 rows of
+// one (image, head): the k and v tiles [256][32] come in ONCE as float4 rows (eight loads in flight per thread and tensor), the
+// column max is the TILE's own (m_loc), P~ = exp(k - m_loc) and v go to LDS ([row][32] unpadded: the MFMA fragment reads put rows
+// 2s / 2s+1 on banks 0-31 / 32-63) and the 32 x 32 context partial runs on the fp32 matrix cores from there.  The finalize kernel
+// rescales every partial by exp(m_loc - max_splits m_loc) -- the usual online-softmax identity; kmax / ksum come out as before.
+// grid = (heads, ceil(n / 256), B), block 256.
+__global__ void __launch_bounds__(256) linattn_ctx1p_kernel(const float* kv, int ld, int koff, float* max_part, float* ctx_part,
+                                                           float* sum_part, int n, int HD) {
+    CDF_DYN_SMEM(smem_raw);
+    float* sp = (float*)smem_raw;                 // [256][32] P~
+    float* sv = sp + 256 * LA_D;                  // [256][32] v
+    float* red = sv + 256 * LA_D;                 // [32 row groups][32] column reductions
+    float* scol = red + 32 * LA_D;                // [32] the tile's column maxima
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, split = blockIdx.y, b = blockIdx.z, heads = gridDim.x, nsplit = gridDim.y;
+    const int rg = tid >> 3, c4 = (tid & 7) * 4;
+    const int r0 = split * 256;
+    const float* kb = kv + (size_t)b * n * ld + koff + h * LA_D + c4;
+    const float* vb = kb + HD;
+    float4 kq[8], vq[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = r0 + rg + 32 * q;
+        const int rc = r < n ? r : n - 1;
+        kq[q] = *(const float4*)(kb + (size_t)rc * ld);
+        vq[q] = *(const float4*)(vb + (size_t)rc * ld);
+    }
+    float4 m4 = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (r0 + rg + 32 * q < n) {
+            m4.x = fmaxf(m4.x, kq[q].x); m4.y = fmaxf(m4.y, kq[q].y); m4.z = fmaxf(m4.z, kq[q].z); m4.w = fmaxf(m4.w, kq[q].w);
+        }
+    *(float4*)(red + rg * LA_D + c4) = m4;
+    __syncthreads();
+    if (tid < LA_D) {
+        float m = -3.0e38f;
+#pragma unroll 8
+        for (int g = 0; g < 32; ++g) m = fmaxf(m, red[g * LA_D + tid]);
+        scol[tid] = m;
+    }
+    __syncthreads();
+    const float4 mx = *(const float4*)(scol + c4);
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const bool ok = r0 + rg + 32 * q < n;
+        float4 p = make_float4(expf(kq[q].x - mx.x), expf(kq[q].y - mx.y), expf(kq[q].z - mx.z), expf(kq[q].w - mx.w));
+        if (!ok) { p = make_float4(0.f, 0.f, 0.f, 0.f); vq[q] = p; }
+        s4.x += p.x; s4.y += p.y; s4.z += p.z; s4.w += p.w;
+        *(float4*)(sp + (rg + 32 * q) * LA_D + c4) = p;
+        *(float4*)(sv + (rg + 32 * q) * LA_D + c4) = vq[q];
+    }
+    *(float4*)(red + rg * LA_D + c4) = s4;
+    __syncthreads();
+    const size_t pb = ((size_t)b * nsplit + split);
+    if (tid < LA_D) {
+        float sum = 0.f;
+#pragma unroll 8
+        for (int g = 0; g < 32; ++g) sum += red[g * LA_D + tid];
+        sum_part[pb * HD + h * LA_D + tid] = sum;
+        max_part[pb * HD + h * LA_D + tid] = scol[tid];
+    }
+    // ctx_part[d][e] = sum_rows P~[row][d] v[row][e]: wave w takes rows 64 w .. 64 w + 63
+    const int i = lane & 31, hh = lane >> 5;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* ap = sp + (wave * 64 + hh) * LA_D + i;
+    const float* bp = sv + (wave * 64 + hh) * LA_D + i;
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s * LA_D], bp[2 * s * LA_D], acc, 0, 0, 0);
+    __syncthreads();                              // every wave is done reading sp / sv (and the sums in red)
+    float* rw = sp + wave * (LA_D * LA_D);            // (the four accumulator tiles reuse the P~ tile)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rw[((r & 3) + 8 * (r >> 2) + 4 * hh) * LA_D + i] = acc[r];
+    __syncthreads();
+    float* dst = ctx_part + (pb * heads + h) * (LA_D * LA_D);
+    for (int k = tid; k < LA_D * LA_D; k += 256)
+        dst[k] = (sp[k] + sp[LA_D * LA_D + k]) + (sp[2 * LA_D * LA_D + k] + sp[3 * LA_D * LA_D + k]);
+}
+
+// finalize of the one-pass form: m = max_s m_s; w_s = exp(m_s - m); ksum = sum_s w_s sum_s; ctx = sum_s w_s ctx_s / ksum
+__global__ void linattn_ctx1p_final_kernel(const float* ctx_part, const float* sum_part, const float* max_part, int nsplit, int HD,
+                                           float* ctx, float* ctxs, float scale, float* kmax, float* ksum) {
+    CDF_DYN_SMEM(wsm_raw);
+    float* wsm = (float*)wsm_raw;                 // [nsplit][32] weights, then [32] 1 / ksum
+    const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
+    float* inv = wsm + (size_t)nsplit * LA_D;
+    if (threadIdx.x < LA_D) {
+        const int c = h * LA_D + threadIdx.x;
+        float m = -3.0e38f;
+        for (int k = 0; k < nsplit; ++k) m = fmaxf(m, max_part[((size_t)b * nsplit + k) * HD + c]);
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) {
+            const float w = expf(max_part[((size_t)b * nsplit + k) * HD + c] - m);
+            wsm[k * LA_D + threadIdx.x] = w;
+            s += w * sum_part[((size_t)b * nsplit + k) * HD + c];
+        }
+        inv[threadIdx.x] = 1.0f / s;
+        ksum[(size_t)b * HD + c] = s;
+        kmax[(size_t)b * HD + c] = m;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < LA_D * LA_D; k += blockDim.x) {
+        const int d = k / LA_D;
+        float s = 0.f;
+#pragma unroll 4
+        for (int sp = 0; sp < nsplit; ++sp) s += wsm[sp * LA_D + d] * ctx_part[((((size_t)b * nsplit + sp) * heads + h) * LA_D) * LA_D + k];
+        const float c = s * inv[d];
+        ctx[(((size_t)b * heads + h) * LA_D) * LA_D + k] = c;
+        ctxs[(((size_t)b * heads + h) * LA_D) * LA_D + k] = c * scale;
+    }
 }
 
 // ---- finalize (forward): kmax, ksum, ctx = sum_split part / ksum ---------------------------------
@@ -219,11 +336,16 @@ __global__ void softmax_rows_bwd_kernel(const float* p, const float* dp, float* 
 // ================================================================================================
 // C ABI
 // ================================================================================================
-extern "C" int cdf_linattn_nsplit(int n) {
-    int s = n / 256;
+extern "C" int cdf_linattn_nsplit(int n) {       // 256 rows per split (the one-pass context kernel holds a split's k, v tile in LDS)
+    int s = (n + 255) / 256;
     if (s < 1) s = 1;
-    if (s > 64) s = 64;
     return s;
+}
+
+static std::atomic<int> g_linattn_onepass{1};
+extern "C" int cdf_linattn_onepass(int on) {      // tuning / test hook (process-wide): one-pass context (online softmax) vs max pass + context pass
+    g_linattn_onepass.store(on ? 1 : 0);
+    return 0;
 }
 
 // ws >= B*nsplit*HD (kmax partials) + B*nsplit*heads*1024 (ctx partials) + B*nsplit*HD (sum partials) floats
@@ -244,6 +366,20 @@ extern "C" int cdf_linattn_context(const float* qkv, int ld, int koff, float* ct
     float* kmax_part = ws;
     float* ctx_part = kmax_part + (size_t)B * ns * HD;
     float* sum_part = ctx_part + (size_t)B * ns * heads * LA_D * LA_D;
+    if (g_linattn_onepass.load() && ns <= 1024) {
+        const size_t lds = ((size_t)2 * 256 * LA_D + 32 * LA_D + LA_D) * sizeof(float);
+#ifndef CDF_EMU
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)linattn_ctx1p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done = true;
+        }
+#endif
+        CDF_LAUNCH(linattn_ctx1p_kernel, dim3(heads, ns, B), dim3(256), lds, CDF_S, qkv, ld, koff, kmax_part, ctx_part, sum_part, n, HD);
+        CDF_LAUNCH(linattn_ctx1p_final_kernel, dim3(heads, B), dim3(256), (size_t)(ns + 1) * LA_D * sizeof(float), CDF_S, (const float*)ctx_part,
+                   (const float*)sum_part, (const float*)kmax_part, ns, HD, ctx, ctxs, scale, kmax, ksum);
+        return cdf_check_launch("linattn_context");
+    }
     CDF_LAUNCH(linattn_kmax_kernel, dim3(HD / 64, ns, B), dim3(256), 0, CDF_S, qkv, ld, kmax_part, n, rps, HD, koff);
     CDF_LAUNCH((linattn_ctx_kernel<true>), dim3(heads, ns, B), dim3(256), 0, CDF_S, qkv + koff, ld, qkv + koff + HD, ld, (const float*)kmax_part, ns, ctx_part, sum_part, n, rps, HD);
     CDF_LAUNCH(linattn_ctx_final_kernel, dim3(heads, B), dim3(256), 0, CDF_S, (const float*)ctx_part, (const float*)sum_part, (const float*)kmax_part, ns, ns, HD, ctx, ctxs, scale, kmax, ksum);

@@ -556,18 +556,33 @@ __device__ __forceinline__ void unpack_tile_body(const float* ws, float* g, int 
 #pragma unroll
     for (int j = 0; j < J; ++j) red[(zg * J + j) * 33 + cl] = acc[j];
     __syncthreads();
-    for (int e = threadIdx.x; e < 32 * J; e += 256) {
-        const int c_l = e / J, j = e - c_l * J;
-        float tot = 0.f;
+    // all of a thread's read-modify-writes in flight together (unconditional loads from a clamped address, predicated stores)
+    constexpr int NE = (32 * J + 255) / 256;
+    float tot[NE], old[NE];
+    float* dst[NE];
+    bool ok[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        const int ee = e < 32 * J ? e : 0;
+        const int c_l = ee / J, j = ee - c_l * J;
+        tot[k] = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; q += 4)
-            tot += (red[(q * J + j) * 33 + c_l] + red[((q + 1) * J + j) * 33 + c_l]) + (red[((q + 2) * J + j) * 33 + c_l] + red[((q + 3) * J + j) * 33 + c_l]);
+            tot[k] += (red[(q * J + j) * 33 + c_l] + red[((q + 1) * J + j) * 33 + c_l]) + (red[((q + 2) * J + j) * 33 + c_l] + red[((q + 3) * J + j) * 33 + c_l]);
         const int c = c0 + c_l, r = r0 + j / T_, t = j % T_;
-        if (c < C && r < R) {
-            float* dst = g + c * s_c + r * s_r + t * s_t;
-            *dst = accumulate ? *dst + tot : tot;
-        }
+        ok[k] = e < 32 * J && c < C && r < R;
+        dst[k] = ok[k] ? g + c * s_c + r * s_r + t * s_t : g;
     }
+    if (accumulate) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) old[k] = *dst[k];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) tot[k] += old[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NE; ++k)
+        if (ok[k]) *dst[k] = tot[k];
 }
 
 template <int T_, int RJ>

@@ -255,6 +255,50 @@ extern "C" int cdf_conv_cin4_dgrad(const float* dy, int ldd, const float* w, int
     return cdf_check_launch("conv_cin4_dgrad");
 }
 
+// ---- data gradient of a 3 x 3 conv with <= 4 input channels, second stage --------------------------------------------------
+// dx[p][c] = sum_{ky,kx} sum_co dy[p - (ky-1, kx-1)][co] W[co][c][ky][kx].  As an implicit GEMM that is K = 9 Cout deep with 3 useful
+// output columns (0.4 ms at 128 x 128 x 128 channels: the 128-wide dy rows are gathered nine times).  Instead the sum over co runs
+// FIRST, per pixel, for all 27 (c, ky, kx) at once: z[q][c*9 + ky*3 + kx] = sum_co dy[q][co] W[co][c][ky][kx] is a plain 1 x 1 GEMM
+// whose weight matrix [Cout][Cin 9] IS the parameter in its PyTorch layout (dy read once), and this kernel adds the nine shifted
+// 3-vectors: dx[p][c] = sum_{ky,kx} z[p - (ky-1, kx-1)][c*9 + ky*3 + kx] (zero outside the image).  z is 28 floats per pixel.
+__global__ void __launch_bounds__(256) tapsum3_kernel(const float* z, int ldz, float* dx, int B, int H, int W, int Cin, int accumulate) {
+    const long long M = (long long)B * H * W;
+    for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(m % W);
+        const long long t2 = m / W;
+        const int y = (int)(t2 % H);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int qy = y - (ky - 1), qx = x - (kx - 1);
+                const bool ok = qy >= 0 && qy < H && qx >= 0 && qx < W;
+                const long long q = ok ? m - (long long)(ky - 1) * W - (kx - 1) : m;       // clamped: loads stay unconditional
+                const float* zp = z + q * ldz + ky * 3 + kx;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = zp[(c < Cin ? c : 0) * 9];
+                    acc[c] += (ok && c < Cin) ? v : 0.f;
+                }
+            }
+        float4* o = (float4*)(dx + m * 4);
+        float4 r = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (accumulate) { const float4 old = *o; r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
+        *o = r;
+    }
+}
+
+extern "C" int cdf_conv_cin4_tapsum3(const float* z, int ldz, float* dx, int B, int H, int W, int Cin, int accumulate, void* stream) {
+    CDF_REQUIRE(z && dx && B > 0 && H > 0 && W > 0 && Cin >= 1 && Cin <= 4 && ldz >= 9 * Cin && (((uintptr_t)dx) & 15) == 0,
+                "cdf_conv_cin4_tapsum3: 1..4 input channels, z rows hold 9 Cin values, dx is [B,H,W,4] and 16-byte aligned");
+    const long long M = (long long)B * H * W;
+    long long grid = (M + 255) / 256;
+    if (grid > 16384) grid = 16384;
+    CDF_LAUNCH(tapsum3_kernel, dim3((unsigned)grid), dim3(256), 0, CDF_S, z, ldz, dx, B, H, W, Cin, accumulate);
+    return cdf_check_launch("conv_cin4_tapsum3");
+}
+
 extern "C" int cdf_conv_cin4_nchunk(long long M) {
     long long n = M / 512;
     if (n < 1) n = 1;

@@ -302,6 +302,9 @@ int cdf_dwconv7_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
  *   dk = P * (dP - rvec)                                  (cdf_linattn_dk)
  * ws >= cdf_linattn_ws_floats(B,n,heads) floats. */
 int cdf_linattn_nsplit(int n);
+/* tuning / test hook (process-wide, see RE-ENTRANCY): 1 (default) = cdf_linattn_context reads k and v ONCE (per-tile maxima, partials
+ * rescaled in the finalize kernel: online softmax); 0 = column-max pass + context pass.  Same results up to fp32 rounding. */
+int cdf_linattn_onepass(int on);
 size_t cdf_linattn_ws_floats(int B, int n, int heads);
 /* koff: channel offset of k inside a row (v follows at koff + heads*32): heads*32 for the reference's (q|k|v) tensor, 0 for a (k|v)
  * tensor (the q-free form of colddiff/ops.py linattn_fold: q never exists when dim <= heads*32). */
@@ -343,6 +346,10 @@ int cdf_conv_cin4_fwd(const float* x, const float* w, int ldw, const float* bias
                       void* y_lo, int ld_ys, int B, int H, int W, int Cout, int k, int act, void* stream);
 int cdf_conv_cin4_dgrad(const float* dy, int ldd, const float* w, int ldw, float* dx, int B, int H, int W, int Cout, int k, int accumulate,
                         void* stream);
+/* Second stage of the two-stage 3x3 data gradient (first stage: the 1x1 GEMM z[q][c*9 + ky*3 + kx] = sum_co dy[q][co] W[co][c][ky][kx],
+ * whose [Cout][9 Cin] weight matrix is the parameter in its PyTorch layout):  dx[p][c] (+)= sum_{ky,kx} z[p - (ky-1, kx-1)][c*9 + ky*3 + kx],
+ * zero outside the image; dx is [B,H,W,4] (channels >= Cin zero), z rows have pitch ldz >= 9 Cin. */
+int cdf_conv_cin4_tapsum3(const float* z, int ldz, float* dx, int B, int H, int W, int Cin, int accumulate, void* stream);
 int cdf_conv_cin4_nchunk(long long M);
 int cdf_conv_cin4_wgrad(const float* x, const float* dy, int ldd, float* part, float* bsum, int B, int H, int W, int Cin, int Cout,
                         int k, void* stream);

@@ -449,6 +449,39 @@ def test_linear_attention(be, B, n):
     assert err(out, outr) <= 2e-6 and err(ctx, ctxr) <= 2e-6 and err(dqkv, qkv.grad) <= 5e-6
 
 
+@pytest.mark.parametrize("B,n,heads,koff", [(2, 700, 4, 128), (1, 256, 2, 0), (3, 1030, 4, 0), (1, 37, 4, 128)])
+def test_linattn_context_one_pass(be, B, n, heads, koff):
+    """cdf_linattn_context, one-pass (per-tile maxima + rescaled partials) and two-pass forms, (q|k|v) and (k|v) row layouts, ragged
+    last tile, and k columns whose maxima differ by ~60 between tiles (the rescaling weights span e^-60 .. 1)."""
+    torch.manual_seed(n)
+    HD, scale = heads * 32, 32 ** -0.5
+    ld = koff + 2 * HD
+    t = torch.randn(B, n, ld)
+    t[:, :, koff:koff + HD] += torch.linspace(-30, 30, n).view(1, n, 1) * (torch.arange(HD) % 3 - 1).float().view(1, 1, HD)
+    k, v = t[..., koff:koff + HD].double(), t[..., koff + HD:].double()
+    kmax_ref = k.max(1).values
+    e = torch.exp(k - kmax_ref[:, None])
+    ksum_ref = e.sum(1)
+    Pn = (e / ksum_ref[:, None]).view(B, n, heads, 32)
+    ctx_ref = torch.einsum("bnhd,bnhe->bhde", Pn, v.view(B, n, heads, 32)).float()
+    td = be.to(t)
+    res = []
+    try:
+        for onepass in (1, 0):
+            be.L.cdf_linattn_onepass(onepass)
+            ctx, ctxs, kmax, ksum = be.empty(B, heads, 32, 32), be.empty(B, heads, 32, 32), be.empty(B, HD), be.empty(B, HD)
+            ws = be.empty(be.L.cdf_linattn_ws_floats(B, n, heads))
+            be.L.cdf_linattn_context(P(td), ld, koff, P(ctx), P(ctxs), P(kmax), P(ksum), P(ws), B, n, heads, scale, be.stream())
+            assert torch.equal(kmax.cpu(), kmax_ref.float())
+            assert err(ksum, ksum_ref.float()) <= 1e-5 * ksum_ref.max().item()
+            assert err(ctx, ctx_ref) <= 1e-5 * max(1.0, ctx_ref.abs().max().item())
+            assert err(ctxs, ctx_ref * scale) <= 1e-5 * max(1.0, ctx_ref.abs().max().item())
+            res.append(ctx.cpu().clone())
+    finally:
+        be.L.cdf_linattn_onepass(1)
+    assert (res[0] - res[1]).abs().max().item() <= 1e-5 * max(1.0, ctx_ref.abs().max().item())
+
+
 def test_small_ops(be):
     torch.manual_seed(0)
     L, S = be.L, be.stream()
@@ -891,6 +924,17 @@ def test_conv_cin4_direct(be, B, H, Cin, Cout, k, act):
     dx = be.empty(B, H, H, 4)
     be.L.cdf_conv_cin4_dgrad(P(gd), Cout, P(wp), Cout, P(dx), B, H, H, Cout, k, 0, be.stream())
     assert err(dx[..., :Cin].permute(0, 3, 1, 2), x.grad) <= 5e-5 * max(1.0, x.grad.abs().max().item())
+    if k == 3:
+        # the two-stage form: z = dY . W[Cout][9 Cin] per pixel (torch here; cdf_conv_gemm in the package), then the tap sum
+        ldz = (9 * Cin + 3) // 4 * 4
+        z = torch.zeros(B, H, H, ldz)
+        z[..., :9 * Cin] = g.permute(0, 2, 3, 1).reshape(-1, Cout) .matmul(conv.weight.detach().reshape(Cout, 9 * Cin)).reshape(B, H, H, 9 * Cin)
+        dx2 = be.to(torch.full((B, H, H, 4), 7.0))
+        be.L.cdf_conv_cin4_tapsum3(P(be.to(z)), ldz, P(dx2), B, H, H, Cin, 0, be.stream())
+        assert err(dx2[..., :Cin].permute(0, 3, 1, 2), x.grad) <= 5e-5 * max(1.0, x.grad.abs().max().item())
+        assert dx2[..., Cin:].abs().max().item() == 0.0 if Cin < 4 else True
+        be.L.cdf_conv_cin4_tapsum3(P(be.to(z)), ldz, P(dx2), B, H, H, Cin, 1, be.stream())
+        assert err(dx2[..., :Cin].permute(0, 3, 1, 2), 2 * x.grad) <= 1e-4 * max(1.0, x.grad.abs().max().item())
     nch = be.L.cdf_conv_cin4_nchunk(B * H * H)
     part, bsum = be.empty(nch, KK * Cin, Cout), be.empty(nch, Cout)
     be.L.cdf_conv_cin4_wgrad(P(xd), P(gd), Cout, P(part), P(bsum), B, H, H, Cin, Cout, k, be.stream())
