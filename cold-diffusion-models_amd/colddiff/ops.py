@@ -153,7 +153,7 @@ def _repack_all(device, epoch_used):
         d0, d1 = (P(out[0]), P(out[1])) if bf16 else (P(out), 0)
         recs.append(struct.pack("<QQQqqqiiiiii", p.data_ptr() + 4 * off, d0, d1, s_t, s_r, s_c, T, R, C, ldc, 1 if bf16 else 0, first))
         sig.append((p.data_ptr() + 4 * off, d0, d1))
-        first += (T * R * ldc + 1023) // 1024
+        first += L.cdf_pack_blocks(T, R, ldc, s_t)
     sig = tuple(sig)
     tab = _pack_tables.get(device)
     if tab is None or tab[0] != sig:
@@ -351,11 +351,11 @@ def conv_gemm(plan, x, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None, p
     return y
 
 
-def best_nsplit(tiles, slots, max_ns):
+def best_nsplit(tiles, slots, max_ns, cap=256):
     """Split-K factor: time ~ ceil(tiles*ns / slots) / ns (equal-length block rounds per unit of work).
     The SMALLEST ns within 3 % of the optimum wins: every split costs a partial-sum slab that is written and
     read back by the reduction (at 128x128 pixels ns = 227 instead of 56 meant 4x the slab traffic for 1 %)."""
-    hi = max(1, min(max_ns, 256))
+    hi = max(1, min(max_ns, cap))
     cost = [-(-tiles * ns // slots) / ns for ns in range(1, hi + 1)]
     best = min(cost)
     for ns, c in enumerate(cost, 1):
@@ -401,7 +401,9 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None, xa_s=No
         _reduce_slabs(L, ws, gparam, ns, wplan.ntaps, CA, CB, ldo, s_t, s_r, s_c, bsum, gbias, S)
         return
     tiles_f32 = (1 if CA <= 64 else (CA + 127) // 128) * (1 if CB <= 64 else (CB + 127) // 128) * wplan.ntaps
-    ns = best_nsplit(tiles_f32, 1024, max(1, M // 256))
+    # (one or two output tiles -- 64 -> 3, the 64-channel k|v projection: a block keeps ONE 4 KB chunk in flight, so the bandwidth
+    #  comes from filling all 1024 block slots: up to 1024 splits there, the slabs stay a few percent of the operand bytes)
+    ns = best_nsplit(tiles_f32, 1024, max(1, M // 256), cap=1024 if tiles_f32 <= 2 else 256)
     ws = torch.empty((ns, wplan.ntaps, CA, ldo), device=xa.device, dtype=torch.float32)
     S = rt.stream(xa)
     bsum = torch.empty((ns, ldo), device=xa.device, dtype=torch.float32) if gbias is not None else None

@@ -187,36 +187,64 @@ __global__ void __launch_bounds__(256) linattn_ctx1p_kernel(const float* kv, int
 }
 
 // finalize of the one-pass form: m = max_s m_s; w_s = exp(m_s - m); ksum = sum_s w_s sum_s; ctx = sum_s w_s ctx_s / ksum
-__global__ void linattn_ctx1p_final_kernel(const float* ctx_part, const float* sum_part, const float* max_part, int nsplit, int HD,
-                                           float* ctx, float* ctxs, float scale, float* kmax, float* ksum) {
+// grid = (heads, B), block 1024 = one thread per context element; the statistics phase runs as 32 channels x 32 split lanes.
+__global__ void __launch_bounds__(1024) linattn_ctx1p_final_kernel(const float* ctx_part, const float* sum_part, const float* max_part,
+                                                                   int nsplit, int HD, float* ctx, float* ctxs, float scale, float* kmax,
+                                                                   float* ksum) {
     CDF_DYN_SMEM(wsm_raw);
-    float* wsm = (float*)wsm_raw;                 // [nsplit][32] weights, then [32] 1 / ksum
+    float* wsm = (float*)wsm_raw;                 // [nsplit][32] weights
+    __shared__ float sred[32][33];
+    __shared__ float smx[LA_D], sinv[LA_D];
     const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
-    float* inv = wsm + (size_t)nsplit * LA_D;
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = h * LA_D + cl;
+    const float* mp = max_part + (size_t)b * nsplit * HD + c;
+    const float* sp = sum_part + (size_t)b * nsplit * HD + c;
+    float m = -3.0e38f;
+    for (int k = sl; k < nsplit; k += 32) m = fmaxf(m, mp[(size_t)k * HD]);
+    sred[sl][cl] = m;
+    __syncthreads();
     if (threadIdx.x < LA_D) {
-        const int c = h * LA_D + threadIdx.x;
-        float m = -3.0e38f;
-        for (int k = 0; k < nsplit; ++k) m = fmaxf(m, max_part[((size_t)b * nsplit + k) * HD + c]);
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) {
-            const float w = expf(max_part[((size_t)b * nsplit + k) * HD + c] - m);
-            wsm[k * LA_D + threadIdx.x] = w;
-            s += w * sum_part[((size_t)b * nsplit + k) * HD + c];
-        }
-        inv[threadIdx.x] = 1.0f / s;
-        ksum[(size_t)b * HD + c] = s;
-        kmax[(size_t)b * HD + c] = m;
+        float mm = -3.0e38f;
+#pragma unroll 8
+        for (int g = 0; g < 32; ++g) mm = fmaxf(mm, sred[g][threadIdx.x]);
+        smx[threadIdx.x] = mm;
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < LA_D * LA_D; k += blockDim.x) {
-        const int d = k / LA_D;
-        float s = 0.f;
-#pragma unroll 4
-        for (int sp = 0; sp < nsplit; ++sp) s += wsm[sp * LA_D + d] * ctx_part[((((size_t)b * nsplit + sp) * heads + h) * LA_D) * LA_D + k];
-        const float c = s * inv[d];
-        ctx[(((size_t)b * heads + h) * LA_D) * LA_D + k] = c;
-        ctxs[(((size_t)b * heads + h) * LA_D) * LA_D + k] = c * scale;
+    m = smx[cl];
+    float s = 0.f;
+    for (int k = sl; k < nsplit; k += 32) {
+        const float w = expf(mp[(size_t)k * HD] - m);
+        wsm[k * LA_D + cl] = w;
+        s += w * sp[(size_t)k * HD];
     }
+    sred[sl][cl] = s;
+    __syncthreads();
+    if (threadIdx.x < LA_D) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int g = 0; g < 32; ++g) t += sred[g][threadIdx.x];
+        sinv[threadIdx.x] = 1.0f / t;
+        ksum[(size_t)b * HD + h * LA_D + threadIdx.x] = t;
+        kmax[(size_t)b * HD + h * LA_D + threadIdx.x] = smx[threadIdx.x];
+    }
+    __syncthreads();
+    const int k = threadIdx.x, d = k >> 5;        // element [d][e] of the 32 x 32 context
+    const float* cp = ctx_part + (((size_t)b * nsplit) * heads + h) * (LA_D * LA_D) + k;
+    const size_t cstride = (size_t)heads * LA_D * LA_D;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int q = 0;
+    for (; q + 3 < nsplit; q += 4) {
+        const float v0 = cp[(size_t)q * cstride], v1 = cp[(size_t)(q + 1) * cstride], v2 = cp[(size_t)(q + 2) * cstride], v3 = cp[(size_t)(q + 3) * cstride];
+        a0 += wsm[q * LA_D + d] * v0;
+        a1 += wsm[(q + 1) * LA_D + d] * v1;
+        a2 += wsm[(q + 2) * LA_D + d] * v2;
+        a3 += wsm[(q + 3) * LA_D + d] * v3;
+    }
+    for (; q < nsplit; ++q) a0 += wsm[q * LA_D + d] * cp[(size_t)q * cstride];
+    const float r = ((a0 + a1) + (a2 + a3)) * sinv[d];
+    ctx[(((size_t)b * heads + h) * LA_D) * LA_D + k] = r;
+    ctxs[(((size_t)b * heads + h) * LA_D) * LA_D + k] = r * scale;
 }
 
 // ---- finalize (forward): kmax, ksum, ctx = sum_split part / ksum ---------------------------------
@@ -376,7 +404,7 @@ extern "C" int cdf_linattn_context(const float* qkv, int ld, int koff, float* ct
         }
 #endif
         CDF_LAUNCH(linattn_ctx1p_kernel, dim3(heads, ns, B), dim3(256), lds, CDF_S, qkv, ld, koff, kmax_part, ctx_part, sum_part, n, HD);
-        CDF_LAUNCH(linattn_ctx1p_final_kernel, dim3(heads, B), dim3(256), (size_t)(ns + 1) * LA_D * sizeof(float), CDF_S, (const float*)ctx_part,
+        CDF_LAUNCH(linattn_ctx1p_final_kernel, dim3(heads, B), dim3(1024), (size_t)ns * LA_D * sizeof(float), CDF_S, (const float*)ctx_part,
                    (const float*)sum_part, (const float*)kmax_part, ns, HD, ctx, ctxs, scale, kmax, ksum);
         return cdf_check_launch("linattn_context");
     }

@@ -261,41 +261,52 @@ extern "C" int cdf_conv_cin4_dgrad(const float* dy, int ldd, const float* w, int
 // FIRST, per pixel, for all 27 (c, ky, kx) at once: z[q][c*9 + ky*3 + kx] = sum_co dy[q][co] W[co][c][ky][kx] is a plain 1 x 1 GEMM
 // whose weight matrix [Cout][Cin 9] IS the parameter in its PyTorch layout (dy read once), and this kernel adds the nine shifted
 // 3-vectors: dx[p][c] = sum_{ky,kx} z[p - (ky-1, kx-1)][c*9 + ky*3 + kx] (zero outside the image).  z is 28 floats per pixel.
-__global__ void __launch_bounds__(256) tapsum3_kernel(const float* z, int ldz, float* dx, int B, int H, int W, int Cin, int accumulate) {
-    const long long M = (long long)B * H * W;
-    for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long long)gridDim.x * blockDim.x) {
-        const int x = (int)(m % W);
-        const long long t2 = m / W;
-        const int y = (int)(t2 % H);
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int qy = y - (ky - 1), qx = x - (kx - 1);
-                const bool ok = qy >= 0 && qy < H && qx >= 0 && qx < W;
-                const long long q = ok ? m - (long long)(ky - 1) * W - (kx - 1) : m;       // clamped: loads stay unconditional
-                const float* zp = z + q * ldz + ky * 3 + kx;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float v = zp[(c < Cin ? c : 0) * 9];
-                    acc[c] += (ok && c < Cin) ? v : 0.f;
-                }
-            }
-        float4* o = (float4*)(dx + m * 4);
-        float4 r = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        if (accumulate) { const float4 old = *o; r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
-        *o = r;
+// One block = a 16 x 16 pixel tile of one image: the 18 x 18 halo of z rows (ldz floats each, contiguous per image row) comes in as
+// float4s, the nine shifted 3-vectors are gathered from LDS (per-lane 4-byte global gathers 112 B apart took 0.21 ms; this 0.02).
+#define TS_T 16
+__global__ void __launch_bounds__(256) tapsum3_kernel(const float* z, int ldz, float* dx, int H, int W, int Cin, int accumulate, int tiles_x,
+                                                      int tiles_y) {
+    CDF_DYN_SMEM(smem_raw);
+    float* sz = (float*)smem_raw;                         // [(TS_T+2)^2][ldz]
+    const int tile = blockIdx.x, tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, b = t2 / tiles_y;
+    const int y0 = ty * TS_T - 1, x0 = tx * TS_T - 1;     // halo origin
+    const int v4 = ldz / 4, nvec = (TS_T + 2) * (TS_T + 2) * v4;
+    const float* zb = z + (size_t)b * H * W * ldz;
+    for (int i = threadIdx.x; i < nvec; i += 256) {
+        const int p = i / v4, k = i - p * v4;
+        const int py = y0 + p / (TS_T + 2), px = x0 + p % (TS_T + 2);
+        const bool ok = py >= 0 && py < H && px >= 0 && px < W;
+        const float4 v = *(const float4*)(zb + ((size_t)(ok ? py : 0) * W + (ok ? px : 0)) * ldz + k * 4);
+        *(float4*)(sz + (size_t)p * ldz + k * 4) = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    __syncthreads();
+    const int ly = threadIdx.x / TS_T, lx = threadIdx.x % TS_T;
+    const int y = ty * TS_T + ly, x = tx * TS_T + lx;
+    if (y >= H || x >= W) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            // source pixel (y - (ky-1), x - (kx-1)) = halo cell (ly + 2 - ky, lx + 2 - kx)
+            const float* zp = sz + (size_t)((ly + 2 - ky) * (TS_T + 2) + (lx + 2 - kx)) * ldz + ky * 3 + kx;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < Cin) acc[c] += zp[c * 9];
+        }
+    float4* o = (float4*)(dx + (((size_t)b * H + y) * W + x) * 4);
+    float4 r = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (accumulate) { const float4 old = *o; r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
+    *o = r;
 }
 
 extern "C" int cdf_conv_cin4_tapsum3(const float* z, int ldz, float* dx, int B, int H, int W, int Cin, int accumulate, void* stream) {
-    CDF_REQUIRE(z && dx && B > 0 && H > 0 && W > 0 && Cin >= 1 && Cin <= 4 && ldz >= 9 * Cin && (((uintptr_t)dx) & 15) == 0,
-                "cdf_conv_cin4_tapsum3: 1..4 input channels, z rows hold 9 Cin values, dx is [B,H,W,4] and 16-byte aligned");
-    const long long M = (long long)B * H * W;
-    long long grid = (M + 255) / 256;
-    if (grid > 16384) grid = 16384;
-    CDF_LAUNCH(tapsum3_kernel, dim3((unsigned)grid), dim3(256), 0, CDF_S, z, ldz, dx, B, H, W, Cin, accumulate);
+    CDF_REQUIRE(z && dx && B > 0 && H > 0 && W > 0 && Cin >= 1 && Cin <= 4 && ldz >= 9 * Cin && ldz % 4 == 0 && ldz <= 64 &&
+                ((((uintptr_t)dx) | ((uintptr_t)z)) & 15) == 0,
+                "cdf_conv_cin4_tapsum3: 1..4 input channels, z rows hold 9 Cin values with a pitch % 4 == 0, dx is [B,H,W,4], both 16-byte aligned");
+    const int tiles_x = cdf_cdiv(W, TS_T), tiles_y = cdf_cdiv(H, TS_T);
+    const size_t lds = (size_t)(TS_T + 2) * (TS_T + 2) * ldz * sizeof(float);
+    CDF_LAUNCH(tapsum3_kernel, dim3((unsigned)(tiles_x * tiles_y * B)), dim3(256), lds, CDF_S, z, ldz, dx, H, W, Cin, accumulate, tiles_x, tiles_y);
     return cdf_check_launch("conv_cin4_tapsum3");
 }
 

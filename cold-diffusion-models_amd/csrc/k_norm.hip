@@ -197,12 +197,24 @@ __global__ void __launch_bounds__(1024) norm_param_reduce_kernel(const float* pa
     const int l = threadIdx.x & 63, rl = threadIdx.x >> 6, i = blockIdx.x * 64 + l;
     float s0 = 0.f, s1 = 0.f;
     if (i < 2 * C) {
+        // eight independent loads in flight (1024 partials = 64 per lane: with two in flight the 32 dependent round trips were
+        // 11 of the kernel's 12 us); the summation tree is fixed by nblocks: deterministic
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f, t5 = 0.f, t6 = 0.f, t7 = 0.f;
+        const float* p = part + i;
+        const size_t st = (size_t)2 * C;
         int b = rl;
-        for (; b + 16 < nblocks; b += 32) {                  // two independent loads in flight
-            s0 += part[(size_t)b * 2 * C + i];
-            s1 += part[(size_t)(b + 16) * 2 * C + i];
+        for (; b + 112 < nblocks; b += 128) {
+            const float v0 = p[(size_t)b * st], v1 = p[(size_t)(b + 16) * st], v2 = p[(size_t)(b + 32) * st], v3 = p[(size_t)(b + 48) * st];
+            const float v4 = p[(size_t)(b + 64) * st], v5 = p[(size_t)(b + 80) * st], v6 = p[(size_t)(b + 96) * st], v7 = p[(size_t)(b + 112) * st];
+            t0 += v0; t1 += v1; t2 += v2; t3 += v3; t4 += v4; t5 += v5; t6 += v6; t7 += v7;
         }
-        if (b < nblocks) s0 += part[(size_t)b * 2 * C + i];
+        for (; b + 16 < nblocks; b += 32) {
+            s0 += p[(size_t)b * st];
+            s1 += p[(size_t)(b + 16) * st];
+        }
+        if (b < nblocks) s0 += p[(size_t)b * st];
+        s0 += (t0 + t1) + (t2 + t3);
+        s1 += (t4 + t5) + (t6 + t7);
     }
     red[rl][l] = s0 + s1;
     __syncthreads();

@@ -237,8 +237,10 @@ int cdf_pack_weight(const float* src, float* dst, int T, int R, int C, int ldc, 
 /* cdf_pack_many: every cached layout in one launch.  table = nentries records in device memory, each
  *   { const float* src; void* dst0; void* dst1; long long s_t, s_r, s_c; int T, R, C, ldc, kind, first_block; }   (cdf_pack_entry_bytes() bytes)
  * kind 0: cdf_pack_weight into dst0 (fp32); kind 1: cdf_pack_weight_bf16 into dst0 (hi) / dst1 (lo, nullable).  first_block ascending; entry e
- * owns ceil(T*R*ldc / 1024) consecutive blocks; nblocks = their total. */
+ * owns cdf_pack_blocks(T, R, ldc, s_t) consecutive blocks (ceil(T*R*ldc / 1024), or ceil(R*ldc / 1024) when the taps are contiguous in
+ * the source -- s_t == 1, 1 < T <= 16 -- and a thread moves all T taps of an (r, c) pair); nblocks = their total. */
 int cdf_pack_entry_bytes(void);
+int cdf_pack_blocks(int T, int R, int ldc, long long s_t);
 int cdf_pack_many(const void* table, int nentries, int nblocks, void* stream);
 int cdf_unpack_reduce(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t,
                       long long s_r, long long s_c, int accumulate, void* stream);
@@ -348,7 +350,7 @@ int cdf_conv_cin4_dgrad(const float* dy, int ldd, const float* w, int ldw, float
                         void* stream);
 /* Second stage of the two-stage 3x3 data gradient (first stage: the 1x1 GEMM z[q][c*9 + ky*3 + kx] = sum_co dy[q][co] W[co][c][ky][kx],
  * whose [Cout][9 Cin] weight matrix is the parameter in its PyTorch layout):  dx[p][c] (+)= sum_{ky,kx} z[p - (ky-1, kx-1)][c*9 + ky*3 + kx],
- * zero outside the image; dx is [B,H,W,4] (channels >= Cin zero), z rows have pitch ldz >= 9 Cin. */
+ * zero outside the image; dx is [B,H,W,4] (channels >= Cin zero), z rows have pitch ldz >= 9 Cin (ldz % 4 == 0, <= 64). */
 int cdf_conv_cin4_tapsum3(const float* z, int ldz, float* dx, int B, int H, int W, int Cin, int accumulate, void* stream);
 int cdf_conv_cin4_nchunk(long long M);
 int cdf_conv_cin4_wgrad(const float* x, const float* dy, int ldd, float* part, float* bsum, int B, int H, int W, int Cin, int Cout,

@@ -482,6 +482,59 @@ def test_linattn_context_one_pass(be, B, n, heads, koff):
     assert (res[0] - res[1]).abs().max().item() <= 1e-5 * max(1.0, ctx_ref.abs().max().item())
 
 
+def test_pack_many_matches_single_packs(be):
+    """cdf_pack_many (one launch, device-resident descriptor table) against cdf_pack_weight / cdf_pack_weight_bf16 entry by entry: 3x3 and
+    4x4 conv weights in forward and data-gradient layouts (taps contiguous in the source: the all-taps-per-thread path), a transposed-conv
+    weight, a 1x1 conv and a linear layer (element-wise path), ragged channel counts, fp32 and bf16 hi / lo planes, hi only."""
+    import struct
+    torch.manual_seed(0)
+    ents = []          # (src tensor, T, R, C, ldc, s_t, s_r, s_c, bf16, want_lo)
+    def conv(Co, Ci, k, bf16, want_lo=True):
+        w = torch.randn(Co, Ci, k, k)
+        KK = k * k
+        r32 = lambda v: (v + 31) // 32 * 32
+        r4_ = lambda v: (v + 3) // 4 * 4
+        if bf16:
+            ents.append((w, KK, Co, Ci, r32(Ci), 1, Ci * KK, KK, True, want_lo))          # conv_fwd_sp
+            ents.append((w, KK, Ci, Co, r32(Co), 1, KK, Ci * KK, True, want_lo))          # conv_dgrad_sp
+        else:
+            ents.append((w, KK, Ci, Co, r4_(Co), 1, KK, Ci * KK, False, False))           # conv_fwd
+            ents.append((w, KK, Co, Ci, r4_(Ci), 1, Ci * KK, KK, False, False))           # conv_dgrad
+    conv(40, 24, 3, True)
+    conv(33, 70, 3, False)
+    conv(64, 32, 4, True, want_lo=False)
+    conv(48, 20, 1, True)
+    wl = torch.randn(50, 36)
+    ents.append((wl, 1, 36, 50, 52, 0, 1, 36, False, False))                              # lin_fwd
+    L, S = be.L, be.stream()
+    recs, first, outs, refs = [], 0, [], []
+    keep = []
+    for (w, T, R, C, ldc, s_t, s_r, s_c, bf16, want_lo) in ents:
+        wd = be.to(w)
+        keep.append(wd)
+        if bf16:
+            d0 = torch.full((T, R, ldc), -1, dtype=torch.int16, device=be.device)
+            d1 = torch.full((T, R, ldc), -1, dtype=torch.int16, device=be.device) if want_lo else None
+            r0, r1 = torch.zeros_like(d0), (torch.zeros_like(d0) if want_lo else None)
+            L.cdf_pack_weight_bf16(P(wd), P(r0), P(r1), T, R, C, ldc, s_t, s_r, s_c, S)
+            outs.append((d0, d1)); refs.append((r0, r1))
+        else:
+            d0, d1 = be.empty(T, R, ldc), None
+            r0 = be.empty(T, R, ldc)
+            L.cdf_pack_weight(P(wd), P(r0), T, R, C, ldc, s_t, s_r, s_c, S)
+            outs.append((d0, None)); refs.append((r0, None))
+        recs.append(struct.pack("<QQQqqqiiiiii", P(wd), P(d0), P(d1), s_t, s_r, s_c, T, R, C, ldc, 1 if bf16 else 0, first))
+        first += L.cdf_pack_blocks(T, R, ldc, s_t)
+    blob = b"".join(recs)
+    assert len(blob) == len(recs) * L.cdf_pack_entry_bytes()
+    tab = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(be.device)
+    L.cdf_pack_many(P(tab), len(recs), first, S)
+    for (d0, d1), (r0, r1) in zip(outs, refs):
+        assert torch.equal(d0.cpu(), r0.cpu())
+        if d1 is not None:
+            assert torch.equal(d1.cpu(), r1.cpu())
+
+
 def test_small_ops(be):
     torch.manual_seed(0)
     L, S = be.L, be.stream()
