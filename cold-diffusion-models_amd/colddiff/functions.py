@@ -73,7 +73,7 @@ def want_presplit(Cin, Cout, k):
 
 _CIN4 = os.environ.get("CDF_CIN4", "1") != "0"    # direct kernels for the <= 4-input-channel image-side convs
 _CIN_DGRAD2 = os.environ.get("CDF_CIN_DGRAD2", "1") != "0"   # their 3x3 data gradient in two stages (ops.conv_cin_dgrad2)
-_ATTN_FUSED = os.environ.get("CDF_ATTN_FUSED", "1") != "0"   # to_out folded into the linear-attention product (ops.linattn_project)
+_ATTN_FUSED = int(os.environ.get("CDF_ATTN_FUSED", "1"))    # to_out folded into the linear-attention product (ops.linattn_project): 0 never, 1 where dim <= heads*32, 2 always
 _LEAN = os.environ.get("CDF_LEAN", "1") != "0"    # skip fp32 copies of tensors only ever consumed as bf16 planes
 _LINEAR_SMALL_M = 256      # batch sizes up to this use the skinny-linear kernels
 _ALWAYS_PRESPLIT = os.environ.get("CDF_ALWAYS_PRESPLIT", "0") != "0"
@@ -451,7 +451,10 @@ class LinAttnBlockFn(torch.autograd.Function):
         xn, mean, rstd = ops.layernorm_fwd(x, norm.g, norm.b, norm.eps, grad_on)
         ctx.m = m
         _used(ctx, norm, att.to_qkv, att.to_out)
-        ctx.fused = _ATTN_FUSED and dim % 4 == 0
+        # to_out folded into the attention product where that shrinks the batched GEMMs (dim <= heads*32: the 128- and 64-pixel
+        # levels of the CelebA net); above, the per-image [HD x dim] GEMMs over a few hundred pixels are latency-bound and the
+        # plain form (K = 32 head products + a dense to_out GEMM over all images) is faster (16 x 16: 1.75 vs 2.2 ms per 12 passes)
+        ctx.fused = dim % 4 == 0 and (_ATTN_FUSED == 2 or (_ATTN_FUSED == 1 and dim <= att.heads * 32))
         ctx.qfold = ctx.fused and _ATTN_QFOLD and dim <= att.heads * 32 and att.heads <= 4
         if ctx.qfold:
             # q folded in as well: only k | v are projected, y = xn . N_b + b + x (ops.linattn_fold)

@@ -27,10 +27,13 @@ struct Cin4Args {
     int B, H, W, Cout, k, act;
 };
 
-// grid-stride over pixels; block 256 = (256 / LP) pixels x LP lanes, lane = 4 output channels
-template <int K>
+// grid-stride over groups of PX consecutive pixels of an image row (PX = 4 when W % 4 == 0, else 1); block 256 = (256 / LP) groups x
+// LP lanes, lane = 4 output channels.  A lane reads its 4 T weight vectors from LDS ONCE per group: with one pixel per trip the 36
+// ds_read_b128 per pixel were the bound (9.4 GB of LDS reads per launch at 128 x 128 x 32 images: 0.2 ms for a 0.11 ms store stream),
+// and the K x (PX + K - 1) input window replaces PX K^2 separate (L1-broadcast) loads and their border selects.
+template <int K, int PX>
 __global__ void __launch_bounds__(256) conv_cin4_fwd_kernel(Cin4Args a) {
-    constexpr int T = K * K, h = K / 2;
+    constexpr int T = K * K, h = K / 2, WC = PX + K - 1;
     CDF_DYN_SMEM(smem);
     float4* wl = (float4*)smem;                    // [T][4][LP]
     const int LP = a.Cout / 4, PPB = 256 / LP;
@@ -44,37 +47,54 @@ __global__ void __launch_bounds__(256) conv_cin4_fwd_kernel(Cin4Args a) {
     const int n = l * 4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bias) bv = *(const float4*)(a.bias + n);
-    const int M = a.B * a.H * a.W;                           // (< 2^31 pixels: 32-bit index math; 64-bit div/mod is ~100 instructions)
-    for (int m = blockIdx.x * PPB + pl; m < M; m += gridDim.x * PPB) {
+    const int MG = a.B * a.H * a.W / PX;                     // (< 2^31 pixels: 32-bit index math; 64-bit div/mod is ~100 instructions)
+    for (int g = blockIdx.x * PPB + pl; g < MG; g += gridDim.x * PPB) {
+        const int m = g * PX;
         const int px = m % a.W, py = (m / a.W) % a.H;
-        float4 xv[T];
+        float4 acc[PX];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int iy = py + t / K - h, ix = px + t % K - h;
-            const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            // pointer select against the zero page, no value select: "ok ? load : 0" becomes a branch around the load
-            xv[t] = *(const float4*)(ok ? a.x + (long long)(m + (t / K - h) * a.W + (t % K - h)) * 4 : cdf_zero_page);
+        for (int p = 0; p < PX; ++p) acc[p] = bv;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int iy = py + ky - h;
+            const bool rok = iy >= 0 && iy < a.H;
+            float4 xw[WC];
+#pragma unroll
+            for (int c = 0; c < WC; ++c) {
+                const int ix = px + c - h;
+                const bool ok = rok && ix >= 0 && ix < a.W;
+                // pointer select against the zero page, no value select: "ok ? load : 0" becomes a branch around the load
+                xw[c] = *(const float4*)(ok ? a.x + (long long)(m + (ky - h) * a.W + (c - h)) * 4 : cdf_zero_page);
+            }
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int t = ky * K + kx;
+                const float4 w0 = wl[(t * 4 + 0) * LP + l], w1 = wl[(t * 4 + 1) * LP + l], w2 = wl[(t * 4 + 2) * LP + l], w3 = wl[(t * 4 + 3) * LP + l];
+#pragma unroll
+                for (int p = 0; p < PX; ++p) {
+                    const float4 xv = xw[p + kx];
+                    acc[p].x = fmaf(xv.x, w0.x, acc[p].x); acc[p].y = fmaf(xv.x, w0.y, acc[p].y); acc[p].z = fmaf(xv.x, w0.z, acc[p].z); acc[p].w = fmaf(xv.x, w0.w, acc[p].w);
+                    acc[p].x = fmaf(xv.y, w1.x, acc[p].x); acc[p].y = fmaf(xv.y, w1.y, acc[p].y); acc[p].z = fmaf(xv.y, w1.z, acc[p].z); acc[p].w = fmaf(xv.y, w1.w, acc[p].w);
+                    acc[p].x = fmaf(xv.z, w2.x, acc[p].x); acc[p].y = fmaf(xv.z, w2.y, acc[p].y); acc[p].z = fmaf(xv.z, w2.z, acc[p].z); acc[p].w = fmaf(xv.z, w2.w, acc[p].w);
+                    acc[p].x = fmaf(xv.w, w3.x, acc[p].x); acc[p].y = fmaf(xv.w, w3.y, acc[p].y); acc[p].z = fmaf(xv.w, w3.z, acc[p].z); acc[p].w = fmaf(xv.w, w3.w, acc[p].w);
+                }
+            }
         }
-        float4 acc = bv;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const float4 w0 = wl[(t * 4 + 0) * LP + l], w1 = wl[(t * 4 + 1) * LP + l], w2 = wl[(t * 4 + 2) * LP + l], w3 = wl[(t * 4 + 3) * LP + l];
-            acc.x = fmaf(xv[t].x, w0.x, acc.x); acc.y = fmaf(xv[t].x, w0.y, acc.y); acc.z = fmaf(xv[t].x, w0.z, acc.z); acc.w = fmaf(xv[t].x, w0.w, acc.w);
-            acc.x = fmaf(xv[t].y, w1.x, acc.x); acc.y = fmaf(xv[t].y, w1.y, acc.y); acc.z = fmaf(xv[t].y, w1.z, acc.z); acc.w = fmaf(xv[t].y, w1.w, acc.w);
-            acc.x = fmaf(xv[t].z, w2.x, acc.x); acc.y = fmaf(xv[t].z, w2.y, acc.y); acc.z = fmaf(xv[t].z, w2.z, acc.z); acc.w = fmaf(xv[t].z, w2.w, acc.w);
-            acc.x = fmaf(xv[t].w, w3.x, acc.x); acc.y = fmaf(xv[t].w, w3.y, acc.y); acc.z = fmaf(xv[t].w, w3.z, acc.z); acc.w = fmaf(xv[t].w, w3.w, acc.w);
+        for (int p = 0; p < PX; ++p) {
+            const long long mp = m + p;
+            if (a.pre) *(float4*)(a.pre + mp * a.ldp + n) = acc[p];
+            float v[4] = {acc[p].x, acc[p].y, acc[p].z, acc[p].w};
+            if (a.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = cdf_gelu(v[e]);
+            } else if (a.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = cdf_silu(v[e]);
+            }
+            if (a.y) *(float4*)(a.y + mp * a.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+            if (a.ys_hi) cdf_split_store4(a.ys_hi + mp * a.ld_ys + n, a.ys_lo ? a.ys_lo + mp * a.ld_ys + n : nullptr, v);
         }
-        if (a.pre) *(float4*)(a.pre + (long long)m * a.ldp + n) = acc;
-        float v[4] = {acc.x, acc.y, acc.z, acc.w};
-        if (a.act == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = cdf_gelu(v[e]);
-        } else if (a.act == 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = cdf_silu(v[e]);
-        }
-        if (a.y) *(float4*)(a.y + (long long)m * a.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
-        if (a.ys_hi) cdf_split_store4(a.ys_hi + (long long)m * a.ld_ys + n, a.ys_lo ? a.ys_lo + (long long)m * a.ld_ys + n : nullptr, v);
     }
 }
 
@@ -132,18 +152,20 @@ __global__ void __launch_bounds__(256) conv_cin4_dgrad_kernel(const float* dy, i
 }
 
 // partial[chunk][t*Cin + c][n] = sum_{m in chunk} x[m + off(t)][c] * dy[m][n] (c < Cin);  bsum[chunk][n] = sum dy[m][n]
-// grid = nchunk; block = (256/LP) pixel lanes x LP channel lanes; 4*T float4 accumulators per thread
-template <int K>
+// grid = nchunk; block = (256/LP) pixel-group lanes x LP channel lanes; 4*T float4 accumulators per thread.  Groups of PX consecutive
+// pixels of a row per trip (PX = 4 when W % 4 == 0): one pixel decode and one K x (PX + K - 1) window per group instead of per pixel
+// (the integer divisions and the nine border selects outnumbered the 144 FMAs of a pixel).
+template <int K, int PX>
 __global__ void __launch_bounds__(256) conv_cin4_wgrad_kernel(const float* x, const float* dy, int ldd, float* part, float* bsum, int B, int H,
                                                               int W, int Cin, int Cout, long long m_per_chunk) {
-    constexpr int T = K * K, h = K / 2;
+    constexpr int T = K * K, h = K / 2, WC = PX + K - 1;
     CDF_DYN_SMEM(smem);
     float4* red = (float4*)smem;                   // [PPB][LP] reused per accumulator row
     const int LP = Cout / 4, PPB = 256 / LP;
     const int l = threadIdx.x % LP, pl = threadIdx.x / LP;
     const int n = l * 4;
     const int M = B * H * W;
-    const int m_lo = (int)(blockIdx.x * m_per_chunk);
+    const int m_lo = (int)(blockIdx.x * m_per_chunk);        // (a multiple of PX)
     int m_hi = m_lo + (int)m_per_chunk;
     if (m_hi > M) m_hi = M;
     float4 acc[T][4], bs = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -152,23 +174,37 @@ __global__ void __launch_bounds__(256) conv_cin4_wgrad_kernel(const float* x, co
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[t][c] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (pl < PPB) {
-        for (int m = m_lo + pl; m < m_hi; m += PPB) {
+        for (int m = m_lo + pl * PX; m < m_hi; m += PPB * PX) {
             const int px = m % W, py = (m / W) % H;
-            const float4 d = *(const float4*)(dy + (long long)m * ldd + n);
-            bs.x += d.x; bs.y += d.y; bs.z += d.z; bs.w += d.w;
-            float4 xv[T];
+            float4 d[PX];
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const int iy = py + t / K - h, ix = px + t % K - h;
-                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                xv[t] = *(const float4*)(ok ? x + (long long)(m + (t / K - h) * W + (t % K - h)) * 4 : cdf_zero_page);
+            for (int p = 0; p < PX; ++p) {
+                d[p] = *(const float4*)(dy + (long long)(m + p) * ldd + n);
+                bs.x += d[p].x; bs.y += d[p].y; bs.z += d[p].z; bs.w += d[p].w;
             }
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                acc[t][0].x = fmaf(xv[t].x, d.x, acc[t][0].x); acc[t][0].y = fmaf(xv[t].x, d.y, acc[t][0].y); acc[t][0].z = fmaf(xv[t].x, d.z, acc[t][0].z); acc[t][0].w = fmaf(xv[t].x, d.w, acc[t][0].w);
-                acc[t][1].x = fmaf(xv[t].y, d.x, acc[t][1].x); acc[t][1].y = fmaf(xv[t].y, d.y, acc[t][1].y); acc[t][1].z = fmaf(xv[t].y, d.z, acc[t][1].z); acc[t][1].w = fmaf(xv[t].y, d.w, acc[t][1].w);
-                acc[t][2].x = fmaf(xv[t].z, d.x, acc[t][2].x); acc[t][2].y = fmaf(xv[t].z, d.y, acc[t][2].y); acc[t][2].z = fmaf(xv[t].z, d.z, acc[t][2].z); acc[t][2].w = fmaf(xv[t].z, d.w, acc[t][2].w);
-                acc[t][3].x = fmaf(xv[t].w, d.x, acc[t][3].x); acc[t][3].y = fmaf(xv[t].w, d.y, acc[t][3].y); acc[t][3].z = fmaf(xv[t].w, d.z, acc[t][3].z); acc[t][3].w = fmaf(xv[t].w, d.w, acc[t][3].w);
+            for (int ky = 0; ky < K; ++ky) {
+                const int iy = py + ky - h;
+                const bool rok = iy >= 0 && iy < H;
+                float4 xw[WC];
+#pragma unroll
+                for (int c = 0; c < WC; ++c) {
+                    const int ix = px + c - h;
+                    const bool ok = rok && ix >= 0 && ix < W;
+                    xw[c] = *(const float4*)(ok ? x + (long long)(m + (ky - h) * W + (c - h)) * 4 : cdf_zero_page);
+                }
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const int t = ky * K + kx;
+#pragma unroll
+                    for (int p = 0; p < PX; ++p) {
+                        const float4 xv = xw[p + kx], dd = d[p];
+                        acc[t][0].x = fmaf(xv.x, dd.x, acc[t][0].x); acc[t][0].y = fmaf(xv.x, dd.y, acc[t][0].y); acc[t][0].z = fmaf(xv.x, dd.z, acc[t][0].z); acc[t][0].w = fmaf(xv.x, dd.w, acc[t][0].w);
+                        acc[t][1].x = fmaf(xv.y, dd.x, acc[t][1].x); acc[t][1].y = fmaf(xv.y, dd.y, acc[t][1].y); acc[t][1].z = fmaf(xv.y, dd.z, acc[t][1].z); acc[t][1].w = fmaf(xv.y, dd.w, acc[t][1].w);
+                        acc[t][2].x = fmaf(xv.z, dd.x, acc[t][2].x); acc[t][2].y = fmaf(xv.z, dd.y, acc[t][2].y); acc[t][2].z = fmaf(xv.z, dd.z, acc[t][2].z); acc[t][2].w = fmaf(xv.z, dd.w, acc[t][2].w);
+                        acc[t][3].x = fmaf(xv.w, dd.x, acc[t][3].x); acc[t][3].y = fmaf(xv.w, dd.y, acc[t][3].y); acc[t][3].z = fmaf(xv.w, dd.z, acc[t][3].z); acc[t][3].w = fmaf(xv.w, dd.w, acc[t][3].w);
+                    }
+                }
             }
         }
     }
@@ -215,11 +251,13 @@ extern "C" int cdf_pack_cin4(const float* w, float* dst, int ldw, int Cout, int 
 template <int K>
 static int launch_cin4_fwd(const Cin4Args& a, hipStream_t s) {
     const int LP = a.Cout / 4, PPB = 256 / LP;
-    const long long M = (long long)a.B * a.H * a.W;
-    long long grid = (M + PPB - 1) / PPB;
+    const int PX = a.W % 4 == 0 ? 4 : 1;
+    const long long MG = (long long)a.B * a.H * a.W / PX;
+    long long grid = (MG + PPB - 1) / PPB;
     if (grid > 4096) grid = 4096;
     const size_t lds = (size_t)K * K * 4 * LP * sizeof(float4);
-    CDF_LAUNCH((conv_cin4_fwd_kernel<K>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    if (PX == 4) CDF_LAUNCH((conv_cin4_fwd_kernel<K, 4>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    else CDF_LAUNCH((conv_cin4_fwd_kernel<K, 1>), dim3((unsigned)grid), dim3(256), lds, s, a);
     return cdf_check_launch("conv_cin4_fwd");
 }
 
@@ -325,9 +363,12 @@ extern "C" int cdf_conv_cin4_wgrad(const float* x, const float* dy, int ldd, flo
     if (rc) return rc;
     const long long M = (long long)B * H * W;
     const int nchunk = cdf_conv_cin4_nchunk(M);
-    const long long mpc = (M + nchunk - 1) / nchunk;
+    const int PX = W % 4 == 0 ? 4 : 1;
+    const long long mpc = ((M + nchunk - 1) / nchunk + PX - 1) / PX * PX;                  // chunk edges on group edges
     const size_t lds = (size_t)256 * sizeof(float4);
-    if (k == 1) CDF_LAUNCH((conv_cin4_wgrad_kernel<1>), dim3(nchunk), dim3(256), lds, CDF_S, x, dy, ldd, part, bsum, B, H, W, Cin, Cout, mpc);
-    else CDF_LAUNCH((conv_cin4_wgrad_kernel<3>), dim3(nchunk), dim3(256), lds, CDF_S, x, dy, ldd, part, bsum, B, H, W, Cin, Cout, mpc);
+    if (k == 1 && PX == 4) CDF_LAUNCH((conv_cin4_wgrad_kernel<1, 4>), dim3(nchunk), dim3(256), lds, CDF_S, x, dy, ldd, part, bsum, B, H, W, Cin, Cout, mpc);
+    else if (k == 1) CDF_LAUNCH((conv_cin4_wgrad_kernel<1, 1>), dim3(nchunk), dim3(256), lds, CDF_S, x, dy, ldd, part, bsum, B, H, W, Cin, Cout, mpc);
+    else if (PX == 4) CDF_LAUNCH((conv_cin4_wgrad_kernel<3, 4>), dim3(nchunk), dim3(256), lds, CDF_S, x, dy, ldd, part, bsum, B, H, W, Cin, Cout, mpc);
+    else CDF_LAUNCH((conv_cin4_wgrad_kernel<3, 1>), dim3(nchunk), dim3(256), lds, CDF_S, x, dy, ldd, part, bsum, B, H, W, Cin, Cout, mpc);
     return cdf_check_launch("conv_cin4_wgrad");
 }

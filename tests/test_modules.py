@@ -70,6 +70,58 @@ def test_unet_golden(mbe):
     grad_check(net.named_parameters(), g["grads"])
 
 
+@pytest.mark.parametrize("dim,H", [(16, 12), (160, 8)])
+def test_linear_attention_block_all_forms(mbe, dim, H):
+    """Residual(PreNorm(LinearAttention)) in its three arithmetic forms -- plain (per-head products + to_out conv), to_out folded into a
+    per-image matrix, q folded in as well (k|v-only projection; only where dim <= heads*32) -- against a torch restatement of
+    deblurring_diffusion_pytorch.py:83-89,111-131,167-187: output and every gradient."""
+    from colddiff import functions as F_, unet as D
+    from einops import rearrange
+    torch.manual_seed(dim)
+    blk = D.Residual(D.PreNorm(dim, D.LinearAttention(dim)))
+    with torch.no_grad():
+        blk.fn.norm.g.add_(0.3 * torch.randn_like(blk.fn.norm.g))
+        blk.fn.norm.b.add_(0.3 * torch.randn_like(blk.fn.norm.b))
+    B = 2
+    x0 = torch.randn(B, dim, H, H)
+    gy = torch.randn(B, dim, H, H)
+    # torch reference
+    xr = x0.clone().requires_grad_(True)
+    n, att = blk.fn.norm, blk.fn.fn
+    var, mean = torch.var(xr, dim=1, unbiased=False, keepdim=True), torch.mean(xr, dim=1, keepdim=True)
+    xn = (xr - mean) / (var + n.eps).sqrt() * n.g.detach() + n.b.detach()
+    wq, wo, bo = att.to_qkv.weight.detach().clone().requires_grad_(True), att.to_out.weight.detach().clone().requires_grad_(True), \
+        att.to_out.bias.detach().clone().requires_grad_(True)
+    qkv = torch.nn.functional.conv2d(xn, wq).chunk(3, dim=1)
+    q, k, v = [rearrange(t_, "b (h c) x y -> b h c (x y)", h=att.heads) for t_ in qkv]
+    q = q * att.scale
+    k = k.softmax(dim=-1)
+    cx = torch.einsum("b h d n, b h e n -> b h d e", k, v)
+    out = rearrange(torch.einsum("b h d e, b h d n -> b h e n", cx, q), "b h c (x y) -> b (h c) x y", x=H, y=H)
+    yr = torch.nn.functional.conv2d(out, wo, bo) + xr
+    yr.backward(gy)
+    ref = {"x": xr.grad, "wq": wq.grad, "wo": wo.grad, "bo": bo.grad}
+    blk = blk.to(mbe.device)
+    saved = (F_._ATTN_FUSED, F_._ATTN_QFOLD)
+    forms = [(0, False), (2, False)] + ([(2, True)] if dim <= att.heads * 32 else [])
+    try:
+        for fused, qfold in forms:
+            F_._ATTN_FUSED, F_._ATTN_QFOLD = fused, qfold
+            for p in blk.parameters():
+                p.grad = None
+            xd = mbe.to(x0.permute(0, 2, 3, 1).contiguous()).requires_grad_(True)
+            y = blk(xd)
+            y.backward(mbe.to(gy.permute(0, 2, 3, 1).contiguous()))
+            tag = (dim, fused, qfold)
+            assert (y.detach().cpu().permute(0, 3, 1, 2) - yr.detach()).abs().max() <= 1e-4, tag
+            got = {"x": xd.grad.cpu().permute(0, 3, 1, 2), "wq": att.to_qkv.weight.grad.cpu(), "wo": att.to_out.weight.grad.cpu(),
+                   "bo": att.to_out.bias.grad.cpu()}
+            for kname, r in ref.items():
+                assert (got[kname] - r).abs().max() <= 1e-3 * max(1.0, r.abs().max().item()), (tag, kname)
+    finally:
+        F_._ATTN_FUSED, F_._ATTN_QFOLD = saved
+
+
 def test_model_golden(mbe):
     from deblurring_diffusion_pytorch import Model
     g = load("model_ch32.pt")
