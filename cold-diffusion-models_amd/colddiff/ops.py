@@ -44,6 +44,7 @@ def new_feat(ref, B, H, W, C, zero=False):
 _pack_cache = {}          # (id(param), kind) -> [key, out, weakref, geom, last_used_epoch]
 _pack_tables = {}         # device -> (signature, device table tensor, nentries, nblocks): the cdf_pack_many descriptor table
 _PACK_ALL = __import__("os").environ.get("CDF_PACK_ALL", "1") != "0"
+_ATTN_KV_FUSED = __import__("os").environ.get("CDF_ATTN_KV_FUSED", "1") != "0"    # one-kernel k / v attention backward (k_attn.hip)
 
 
 def _pack(src, T, R, C, s_t, s_r, s_c):
@@ -540,6 +541,10 @@ def linattn_bwd(qkv, dout, ctx, ctxs, kmax, ksum, heads, scale):
     rvec = torch.empty((B, HD), device=dev, dtype=torch.float32)
     ws = torch.empty((L.cdf_linattn_ws_floats(B, n, heads),), device=dev, dtype=torch.float32)
     L.cdf_linattn_dcontext(P(qkv), ld_of(qkv), P(dout), ld_of(dout), P(ctx), P(dctx), P(rvec), P(ws), B, n, heads, scale, S)
+    if _ATTN_KV_FUSED and heads <= 4:
+        _head_gemm(dout, 0, ctxs, dqkv, 0, B, n, heads, True)      # dq[n,d] = sum_e dout[n,e] ctxs[d,e]
+        L.cdf_linattn_bwd_kv(P(qkv), ld_of(qkv), HD, P(dctx), P(rvec), P(kmax), P(ksum), P(dqkv), ld_of(dqkv), HD, B, n, heads, S)
+        return dqkv
     pn = torch.empty((B, H, W, HD), device=dev, dtype=torch.float32)
     dp = torch.empty((B, H, W, HD), device=dev, dtype=torch.float32)
     L.cdf_linattn_softk(P(qkv), ld_of(qkv), P(kmax), P(ksum), P(pn), HD, B, n, heads, S)
@@ -719,9 +724,6 @@ def linattn_bwd_core(qkv, dctx, rvec, kmax, ksum, dqkv, heads, koff=None):
     _head_gemm(pn, 0, dctx, dqkv, 2 * HD, B, n, heads, False)      # dv[n,e] = sum_d P[n,d] dctx[d,e]
     L.cdf_linattn_dk(P(pn), HD, P(dp), HD, P(rvec), P(dqkv) + 4 * HD, 3 * HD, B, n, heads, S)
     return dqkv
-
-
-_ATTN_KV_FUSED = __import__("os").environ.get("CDF_ATTN_KV_FUSED", "1") != "0"
 
 
 def linattn_context(qkv, heads, scale, koff=None):

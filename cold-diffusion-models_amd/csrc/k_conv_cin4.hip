@@ -27,10 +27,10 @@ struct Cin4Args {
     int B, H, W, Cout, k, act;
 };
 
-// grid-stride over groups of PX consecutive pixels of an image row (PX = 4 when W % 4 == 0, else 1); block 256 = (256 / LP) groups x
-// LP lanes, lane = 4 output channels.  A lane reads its 4 T weight vectors from LDS ONCE per group: with one pixel per trip the 36
-// ds_read_b128 per pixel were the bound (9.4 GB of LDS reads per launch at 128 x 128 x 32 images: 0.2 ms for a 0.11 ms store stream),
-// and the K x (PX + K - 1) input window replaces PX K^2 separate (L1-broadcast) loads and their border selects.
+// grid-stride over groups of PX consecutive pixels of an image row; block 256 = (256 / LP) groups x LP lanes, lane = 4 output channels.
+// (hipcc keeps the 4 T weight vectors of a lane in registers across the loop.  PX = 4 -- one K x (PX + K - 1) input window per group --
+// was measured at 128 x 128: 0.200 ms either way, the 144 FMAs + GELU + operand split per pixel and lane are the bound, and it needs every
+// VGPR; the launcher uses PX = 1.)
 template <int K, int PX>
 __global__ void __launch_bounds__(256) conv_cin4_fwd_kernel(Cin4Args a) {
     constexpr int T = K * K, h = K / 2, WC = PX + K - 1;
@@ -251,13 +251,11 @@ extern "C" int cdf_pack_cin4(const float* w, float* dst, int ldw, int Cout, int 
 template <int K>
 static int launch_cin4_fwd(const Cin4Args& a, hipStream_t s) {
     const int LP = a.Cout / 4, PPB = 256 / LP;
-    const int PX = a.W % 4 == 0 ? 4 : 1;
-    const long long MG = (long long)a.B * a.H * a.W / PX;
+    const long long MG = (long long)a.B * a.H * a.W;
     long long grid = (MG + PPB - 1) / PPB;
     if (grid > 4096) grid = 4096;
     const size_t lds = (size_t)K * K * 4 * LP * sizeof(float4);
-    if (PX == 4) CDF_LAUNCH((conv_cin4_fwd_kernel<K, 4>), dim3((unsigned)grid), dim3(256), lds, s, a);
-    else CDF_LAUNCH((conv_cin4_fwd_kernel<K, 1>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    CDF_LAUNCH((conv_cin4_fwd_kernel<K, 1>), dim3((unsigned)grid), dim3(256), lds, s, a);
     return cdf_check_launch("conv_cin4_fwd");
 }
 
