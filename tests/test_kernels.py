@@ -602,7 +602,7 @@ def test_adam_ema_match_torch(be):
 # split-precision bf16 MFMA conv (bf16x3: fp32-grade parity; bf16: plain)
 # ---------------------------------------------------------------------------------------------
 SP_CASES = [(2, 32, 40, 8, 3, 1, 1, False), (1, 64, 32, 8, 1, 1, 0, False), (1, 36, 130, 8, 3, 1, 1, False), (1, 32, 32, 8, 4, 2, 1, False),
-            (1, 32, 32, 4, 4, 2, 1, True)]
+            (1, 32, 32, 4, 4, 2, 1, True), (1, 96, 160, 8, 1, 1, 0, False)]      # (last: 3 and 5 K steps -- both parities of the two-step lookahead)
 SP_CASES_GPU = [(4, 64, 128, 32, 3, 1, 1, False), (2, 128, 64, 32, 3, 1, 1, False), (2, 64, 64, 32, 4, 2, 1, False),
                 (2, 64, 64, 16, 4, 2, 1, True), (2, 256, 512, 16, 3, 1, 1, False), (3, 64, 384, 32, 1, 1, 0, False)]
 
