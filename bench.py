@@ -301,7 +301,7 @@ def bandwidth_classes():
         return None
     traffic, trace = json.load(open(tp))["kernels"], json.load(open(kp))
     classes = {"depthwise 7x7": ("dwconv7_kernel", "dwconv7_wgrad_partial_kernel"), "channel LayerNorm": ("layernorm_c_fwd_kernel", "layernorm_c_bwd_kernel"),
-               "Adam": ("adam_kernel",), "operand split": ("split_bf16_kernel",), "split-K reduction": ("unpack_reduce_kernel",),
+               "Adam": ("adam_kernel",), "operand split": ("split_bf16_kernel",), "split-K reduction": ("unpack_reduce_",),
                "linear attention": ("linattn_",)}
     out = {}
     for name, prefixes in classes.items():

@@ -528,11 +528,22 @@ __global__ void __launch_bounds__(64 * SL) unpack_reduce_kernel(const float* ws,
 // as runs of J consecutive floats per c (144 B for 3 x 3, the whole [c][t] block for transposed-conv weights).
 template <int T_, int RJ>
 __device__ __forceinline__ void unpack_tile_body(const float* ws, float* g, int nsplit, int R, int C, int ldc, long long s_t, long long s_r,
-                                                 long long s_c, int accumulate, int tile, float* red) {
+                                                 long long s_c, int accumulate, int tile, float* red, int order) {
     constexpr int J = T_ * RJ;
     const int cl = threadIdx.x & 31, zg = threadIdx.x >> 5;
     const int tiles_c = (C + 31) >> 5;
-    const int tr = tile / tiles_c, tc = tile - tr * tiles_c;
+    int tr, tc;
+    if (order == 2) {
+        // r tiles fastest inside XCD-contiguous runs: the J-float runs of neighbouring r tiles continue each other in the parameter
+        // (same c), so the partial 64-byte lines at their edges meet in ONE L2 instead of being merged in memory
+        const int tiles_r = (R + RJ - 1) / RJ;
+        const int vt = cdf_xcd_order(tile, tiles_c * tiles_r);
+        tc = vt / tiles_r;
+        tr = vt - tc * tiles_r;
+    } else {
+        tr = tile / tiles_c;
+        tc = tile - tr * tiles_c;
+    }
     const int c0 = tc * 32, r0 = tr * RJ;
     const long long slab = (long long)T_ * R * ldc;
     const int cc = c0 + cl < C ? c0 + cl : C - 1;
@@ -588,13 +599,13 @@ __device__ __forceinline__ void unpack_tile_body(const float* ws, float* g, int 
 template <int T_, int RJ>
 __global__ void __launch_bounds__(256) unpack_reduce_tiled_kernel(const float* ws, float* g, int nsplit, int R, int C, int ldc, long long s_t,
                                                                    long long s_r, long long s_c, int accumulate, const float* bws, float* gb,
-                                                                   int bC, int bld) {
+                                                                   int bC, int bld, int order) {
     __shared__ float red[8 * T_ * RJ * 33 > 8 * 33 ? 8 * T_ * RJ * 33 : 8 * 33];
     if (blockIdx.y == 1) {                                   // the fused bias reduction: a [1][1][bC] tensor, unit strides
-        if ((int)blockIdx.x < (bC + 31) / 32) unpack_tile_body<1, 1>(bws, gb, nsplit, 1, bC, bld, 0, 0, 1, accumulate, blockIdx.x, red);
+        if ((int)blockIdx.x < (bC + 31) / 32) unpack_tile_body<1, 1>(bws, gb, nsplit, 1, bC, bld, 0, 0, 1, accumulate, blockIdx.x, red, 1);
         return;
     }
-    unpack_tile_body<T_, RJ>(ws, g, nsplit, R, C, ldc, s_t, s_r, s_c, accumulate, blockIdx.x, red);
+    unpack_tile_body<T_, RJ>(ws, g, nsplit, R, C, ldc, s_t, s_r, s_c, accumulate, blockIdx.x, red, order);
 }
 
 // column sums of a row-major matrix with pitch, two deterministic stages:
@@ -873,24 +884,26 @@ extern "C" int cdf_pack_weight(const float* src, float* dst, int T, int R, int C
 }
 
 static std::atomic<int> g_unpack_tiled{1};
-extern "C" int cdf_unpack_reduce_tiled(int on) {             // tuning / test hook (process-wide): the transposing tiled reduction
-    g_unpack_tiled.store(on ? 1 : 0);
+extern "C" int cdf_unpack_reduce_tiled(int on) {             // tuning / test hook (process-wide): the transposing tiled reduction (0 off, 1 c tiles fastest, 2 r tiles fastest per XCD)
+    g_unpack_tiled.store(on < 0 ? 0 : (on > 2 ? 2 : on));
     return 0;
 }
 
 static int launch_unpack_reduce(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t, long long s_r,
                                 long long s_c, int accumulate, const float* bws, float* gb, int bC, int bld, hipStream_t s) {
-    if (s_c != 1 && C >= 32 && (T == 1 || T == 9 || T == 16) && g_unpack_tiled.load()) {
+    int tiled_mode = g_unpack_tiled.load();
+    if (tiled_mode == 2 && s_r >= s_c) tiled_mode = 1;       // (transposed-conv weights: the runs of neighbouring C tiles continue each other)
+    if (s_c != 1 && C >= 32 && (T == 1 || T == 9 || T == 16) && tiled_mode) {
         const int RJ = T == 9 ? 4 : (T == 16 ? 2 : 32);
         const long long tiles = (long long)((C + 31) / 32) * ((R + RJ - 1) / RJ);
         if (tiles < (1 << 30) && (!bws || (bC + 31) / 32 <= tiles)) {
             const dim3 tg((unsigned)tiles, bws ? 2 : 1);
             if (T == 9)
-                CDF_LAUNCH((unpack_reduce_tiled_kernel<9, 4>), tg, dim3(256), 0, s, ws, g, nsplit, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld);
+                CDF_LAUNCH((unpack_reduce_tiled_kernel<9, 4>), tg, dim3(256), 0, s, ws, g, nsplit, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld, tiled_mode);
             else if (T == 16)
-                CDF_LAUNCH((unpack_reduce_tiled_kernel<16, 2>), tg, dim3(256), 0, s, ws, g, nsplit, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld);
+                CDF_LAUNCH((unpack_reduce_tiled_kernel<16, 2>), tg, dim3(256), 0, s, ws, g, nsplit, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld, tiled_mode);
             else
-                CDF_LAUNCH((unpack_reduce_tiled_kernel<1, 32>), tg, dim3(256), 0, s, ws, g, nsplit, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld);
+                CDF_LAUNCH((unpack_reduce_tiled_kernel<1, 32>), tg, dim3(256), 0, s, ws, g, nsplit, R, C, ldc, s_t, s_r, s_c, accumulate, bws, gb, bC, bld, tiled_mode);
             return cdf_check_launch("unpack_reduce_tiled");
         }
     }

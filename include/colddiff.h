@@ -248,9 +248,10 @@ int cdf_unpack_reduce(const float* ws, float* g, int nsplit, int T, int R, int C
  * gbias[c] (+)= sum_z bias_ws[z * bias_ld + c], c < C (the `bsum` partials of cdf_conv_wgrad*). */
 int cdf_unpack_reduce_bias(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t, long long s_r,
                            long long s_c, const float* bias_ws, float* gbias, int bias_ld, int accumulate, void* stream);
-/* tuning / test hook (process-wide, see RE-ENTRANCY): 1 (default) = parameter layouts whose fast index is not the slab's (s_c != 1, T in
+/* tuning / test hook (process-wide, see RE-ENTRANCY): 1 / 2 (default 1) = parameter layouts whose fast index is not the slab's (s_c != 1, T in
  * {1, 9, 16}) are reduced by the LDS-tiled transposing kernel (contiguous runs per output channel instead of lone 4-byte
- * read-modify-writes); 0 = always the element-wise kernel.  Same sums either way up to fp32 summation order. */
+ * read-modify-writes; 2: tiles whose runs continue each other share an XCD -- measured: no difference); 0 = always the element-wise kernel.  Same sums either way up
+ * to fp32 summation order. */
 int cdf_unpack_reduce_tiled(int on);
 
 /* out[seg][c] (+)= sum over the rows of segment seg of x[r*ld + c]  (bias / time-bias gradients);

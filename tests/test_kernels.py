@@ -908,7 +908,7 @@ def test_unpack_reduce_tiled(be, T, R, C, conv_t, ns):
     tol = 2e-6 * math.sqrt(ns) * max(1.0, (g0 + ref_add).abs().max().item())
     outs = []
     try:
-        for tiled in (1, 0):
+        for tiled in (2, 1, 0):
             be.L.cdf_unpack_reduce_tiled(tiled)
             g, gb = be.to(g0), be.to(gb0)
             be.L.cdf_unpack_reduce_bias(P(be.to(ws)), P(g), ns, T, R, C, ldc, 1, s_r, s_c, P(be.to(bws)), P(gb), ldc, 1, be.stream())
@@ -920,7 +920,7 @@ def test_unpack_reduce_tiled(be, T, R, C, conv_t, ns):
             outs.append(g2.detach().cpu().clone())
     finally:
         be.L.cdf_unpack_reduce_tiled(1)
-    assert (outs[0] - outs[1]).abs().max().item() <= tol
+    assert (outs[0] - outs[2]).abs().max().item() <= tol and torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("M,K,N", [(32, 64, 256), (5, 256, 40), (70, 48, 130)])
