@@ -1,11 +1,16 @@
+# Round artifacts on the GPU box (run through gpurun from the repo root): kernel traces of the train step in both arithmetic modes
+# and the two PMC passes.  Copy the summaries from gpurun_out/ into profiles/ afterwards (profiles/round2_*), then run bench.py
+# (its hbm_bound_kernel_classes figures read profiles/round2_pmc_traffic.json and profiles/round2_kernel_trace.json).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out; mkdir -p $O
-timeout 400 python bench.py > $O/bench_final.json 2> $O/bench_err.log; tail -c 600 $O/bench_final.json | head -c 300; echo
-B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sample"
-rm -rf /tmp/prof_kt /tmp/pmcF /tmp/pmcW
-timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- $B > $O/prof_v23.log 2>&1
-python tools/prof_summary.py /tmp/prof_kt > $O/prof_v23_summary.md 2>&1; head -12 $O/prof_v23_summary.md
+O=gpurun_out/final; mkdir -p $O
+B="python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-sample --no-secondary"
+rm -rf /tmp/prof_kt /tmp/prof_bf /tmp/pmcF /tmp/pmcW
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- $B > $O/trace_x3.log 2>&1
+python tools/prof_summary.py /tmp/prof_kt $O/kernel_trace_x3.md $O/kernel_trace.json > /dev/null 2>&1; head -8 $O/kernel_trace_x3.md; tail -1 $O/kernel_trace_x3.md
+COLDDIFF_PRECISION=bf16 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_bf -- $B > $O/trace_bf16.log 2>&1
+python tools/prof_summary.py /tmp/prof_bf $O/kernel_trace_bf16.md > /dev/null 2>&1; tail -1 $O/kernel_trace_bf16.md
 export CDF_BENCH_NOTIMER=1
-timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmcF -- $B > $O/pmcF.log 2>&1; tail -2 $O/pmcF.log
-timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmcW -- $B > $O/pmcW.log 2>&1; tail -2 $O/pmcW.log
-python tools/pmc_traffic.py /tmp/pmcF /tmp/pmcW $O/pmc_traffic.json $O/pmc_traffic.md; head -14 $O/pmc_traffic.md; tail -4 $O/pmc_traffic.md
+B2="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sample --no-secondary"
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmcF -- $B2 > $O/pmcF.log 2>&1; tail -1 $O/pmcF.log | cut -c1-200
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmcW -- $B2 > $O/pmcW.log 2>&1; tail -1 $O/pmcW.log | cut -c1-200
+python tools/pmc_traffic.py /tmp/pmcF /tmp/pmcW $O/pmc_traffic.json $O/pmc_traffic.md; head -6 $O/pmc_traffic.md; tail -3 $O/pmc_traffic.md
