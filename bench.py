@@ -162,6 +162,20 @@ class GemmTimer:
                          "frac": round(tf / self.PEAK[kind], 4), "launches_per_step": len(recs) // max(1, steps),
                          "avg_launch_ms": round(ms / len(recs), 4), "algorithmic_gflop_per_step": round(fl / max(1, steps) / 1e9, 1),
                          "share_of_step": round(ms / (1000 * elapsed_s), 3)}
+            if kind == "conv_igemm_sp":
+                # the group mixes two regimes: the pre-split 3x3 / 4x4 GEMMs (matrix-core-bound) and the in-kernel-split 1x1 attention
+                # projections (K = 64 ... 512 against 256 ... 1536 output channels: HBM-bound streams) -- same figures per entry point
+                sub = {}
+                for entry, label in (("cdf_conv_gemm_bf16x", "pre_split_3x3_4x4"), ("cdf_conv_gemm_bf16", "in_kernel_split_1x1_attention")):
+                    rs = [r for r in recs if r[3][0] == entry]
+                    if not rs:
+                        continue
+                    m = sum(e0.elapsed_time(e1) for e0, e1, *_ in rs)
+                    f = sum(r[2] for r in rs)
+                    t = f / (m * 1e-3) / 1e12 if m > 0 else 0.0
+                    sub[label] = {"achieved": round(t, 2), "frac": round(t / self.PEAK[kind], 4), "launches_per_step": len(rs) // max(1, steps),
+                                  "algorithmic_gflop_per_step": round(f / max(1, steps) / 1e9, 1), "share_of_step": round(m / (1000 * elapsed_s), 3)}
+                out[kind]["by_entry_point"] = sub
         return out
 
 
