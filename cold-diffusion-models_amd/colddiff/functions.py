@@ -437,6 +437,7 @@ def kv_backward(xn, dim, dkv, w_qkv, dxn):
 
 
 _ATTN_QFOLD = os.environ.get("CDF_ATTN_QFOLD", "1") != "0"   # q projection folded into the attention product too (dim <= heads*32)
+_ATTN_KVCTX = os.environ.get("CDF_ATTN_KVCTX", "1") != "0"   # ... with the k|v projection and the context in one kernel (ops.linattn_kvctx)
 
 
 class LinAttnBlockFn(torch.autograd.Function):
@@ -458,8 +459,11 @@ class LinAttnBlockFn(torch.autograd.Function):
         ctx.qfold = ctx.fused and _ATTN_QFOLD and dim <= att.heads * 32 and att.heads <= 4
         if ctx.qfold:
             # q folded in as well: only k | v are projected, y = xn . N_b + b + x (ops.linattn_fold)
-            kv = kv_forward(xn, dim, att.to_qkv.weight)
-            cx, cxs, kmax, ksum = ops.linattn_context(kv, att.heads, att.scale, koff=0)
+            if _ATTN_KVCTX and ops.linattn_kvctx_ok(xn, dim, att.heads):
+                kv, cx, cxs, kmax, ksum = ops.linattn_kvctx(xn, dim, att.to_qkv.weight, att.heads, att.scale)    # one pass: k | v never re-read
+            else:
+                kv = kv_forward(xn, dim, att.to_qkv.weight)
+                cx, cxs, kmax, ksum = ops.linattn_context(kv, att.heads, att.scale, koff=0)
             y, Mb, Nb = ops.linattn_fold(xn, cxs, att.to_qkv.weight, att.to_out.weight, att.to_out.bias, x, att.heads, **ydst)
             ctx.save_for_backward(x, xn, mean, rstd, kv, Mb, cx, cxs, kmax, ksum, Nb)
             return y

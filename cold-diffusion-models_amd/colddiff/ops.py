@@ -667,6 +667,32 @@ def linattn_fold(xn, ctxs, w_qkv, w_out, b_out, res, heads, y=None):
     return y, Mb, Nb
 
 
+def linattn_kvctx_ok(xn, dim, heads):
+    """The fused k|v projection + context kernel applies (bf16 matrix-core modes, 4 heads, whole 128-pixel tiles, K a multiple of 32)."""
+    B, H, W, _ = xn.shape
+    return rt.precision != "f32" and heads == 4 and (H * W) % 128 == 0 and dim % 32 == 0 and 64 <= dim <= 512 and xn.device.type != "meta"
+
+
+def linattn_kvctx(xn, dim, w_qkv, heads, scale):
+    """kv = xn . Wkv^T ([B,H,W,2 HD]) and (ctx, ctxs, kmax, ksum) of LinearAttention in one pass over the pixels (k_conv_sp.hip:
+    linattn_kvctx_kernel): k and v are written once and not read back."""
+    L, S = rt.lib(), rt.stream(xn)
+    B, H, W, _ = xn.shape
+    n, HD = H * W, heads * 32
+    dev = xn.device
+    wp = packed(w_qkv, "kv_fwd_sp")                           # (hi, lo | None) planes [1][2 HD][roundup32(dim)]
+    kv = torch.empty((B, H, W, 2 * HD), device=dev, dtype=torch.float32)
+    P_ = L.cdf_linattn_kvctx_parts(B, n)
+    ws = torch.empty((B * P_ * (2 * HD + heads * 1024),), device=dev, dtype=torch.float32)
+    L.cdf_linattn_kvctx(P(xn), ld_of(xn), P(wp[0]), P(wp[1]), wp[0].shape[-1], P(kv), 2 * HD, P(ws), B, n, dim, heads, S)
+    ctx = torch.empty((B, heads, 32, 32), device=dev, dtype=torch.float32)
+    ctxs = torch.empty_like(ctx)
+    kmax = torch.empty((B, HD), device=dev, dtype=torch.float32)
+    ksum = torch.empty((B, HD), device=dev, dtype=torch.float32)
+    L.cdf_linattn_finalize(P(ws), P_, P(ctx), P(ctxs), P(kmax), P(ksum), B, heads, scale, S)
+    return kv, ctx, ctxs, kmax, ksum
+
+
 def linattn_fold_bwd(xn, dy, Mb, Nb, ctx, ctxs, w_qkv, w_out, b_out, heads, scale):
     """Backward of linattn_fold w.r.t. everything but k | v: returns (dxn, dctx, rvec) with dxn = dy . N_b^T (the q path's share of the
     LayerNorm-output gradient); accumulates the gradients of Wq (rows 0 .. HD-1 of to_qkv), to_out.weight and to_out.bias."""

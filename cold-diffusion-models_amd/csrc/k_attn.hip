@@ -414,6 +414,20 @@ extern "C" int cdf_linattn_context(const float* qkv, int ld, int koff, float* ct
     return cdf_check_launch("linattn_context");
 }
 
+// Fold of nparts context partials per image and head (layout of cdf_linattn_context's workspace with nsplit = nparts:
+// max [B][nparts][HD] | ctx [B][nparts][heads][32][32] | sum [B][nparts][HD]) as written by cdf_linattn_kvctx (k_conv_sp.hip).
+extern "C" int cdf_linattn_finalize(const float* ws, int nparts, float* ctx, float* ctxs, float* kmax, float* ksum, int B, int heads,
+                                    float scale, void* stream) {
+    CDF_REQUIRE(ws && ctx && ctxs && kmax && ksum && nparts >= 1 && nparts <= 1024 && B > 0 && heads >= 1, "cdf_linattn_finalize: bad args");
+    const int HD = heads * LA_D;
+    const float* max_part = ws;
+    const float* ctx_part = max_part + (size_t)B * nparts * HD;
+    const float* sum_part = ctx_part + (size_t)B * nparts * heads * LA_D * LA_D;
+    CDF_LAUNCH(linattn_ctx1p_final_kernel, dim3(heads, B), dim3(1024), (size_t)nparts * LA_D * sizeof(float), CDF_S, ctx_part, sum_part, max_part,
+               nparts, HD, ctx, ctxs, scale, kmax, ksum);
+    return cdf_check_launch("linattn_finalize");
+}
+
 // Backward context pass: dctx[b,h,d,e] = scale * sum_n q[n,d] dout[n,e];  rvec[b, h*32+d] = sum_e dctx*ctx.
 extern "C" int cdf_linattn_dcontext(const float* qkv, int ld, const float* dout, int lddo, const float* ctx, float* dctx,
                                     float* rvec, float* ws, int B, int n, int heads, float scale, void* stream) {

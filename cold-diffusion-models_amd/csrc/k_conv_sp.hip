@@ -1988,6 +1988,220 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_row3_kernel(SpxWgradArgs a)
     }
 }
 
+// ================================================================================================
+// LinearAttention forward, k | v projection + context in ONE pass (round 2).
+//
+// kv = xn . Wkv^T is a K = dim <= 128 GEMM onto 256 channels: as a convolution launch it writes 1 KB per pixel, and the context
+// pass (softmax over the pixels of k, then k~^T v per head) reads it all back.  Here a block keeps a 128-pixel x 256-channel
+// tile -- ALL of k | v of its pixels -- : in-kernel-split operands exactly as conv_igemm_sp_kernel (xn fp32 -> bf16 hi / lo while it
+// is staged, weights pre-split), accumulators -> an LDS staging tile [128][256] that aliases the operand stages, from which
+//   * the tile leaves as full 1 KB rows (kv is still needed by the backward pass), and
+//   * each head's context partial is updated on the spot (online softmax: running column max m, acc = acc * exp(m_old - m) +
+//     exp(k - m)^T v on the fp32 matrix cores, running column sums), two waves per head, 64 pixels each.
+// A block walks a contiguous run of tiles of ONE image and writes one partial per head at the end; cdf_linattn_finalize
+// (k_attn.hip) folds the partials of an image.  k and v are never re-read: 537 -> 0 MB per micro-batch at 128 x 128.
+// 8 waves: GEMM wave (wm = w / 4: pixel half, wn = w % 4: channel quarter), context wave (head w / 2, pixel half w % 2).
+// ================================================================================================
+struct KvCtxArgs {
+    const float* xn;
+    const unsigned short* w_hi;
+    const unsigned short* w_lo;
+    float* kv;
+    float* max_part;      // [B][P][HD]
+    float* ctx_part;      // [B][P][heads][32][32]
+    float* sum_part;      // [B][P][HD]
+    int ldx, ldk, ldkv;
+    int n, dim, P, tiles_per_block;
+};
+
+template <int SPLIT>
+__global__ void __launch_bounds__(512, 1) linattn_kvctx_kernel(KvCtxArgs a) {
+    constexpr int BM = 128, BN = 256, BK = 32, AS = 40;      // AS: LDS row stride in bf16 elements (80 B)
+    constexpr int NPL = SPLIT == 1 ? 1 : 2;
+    constexpr int PLANE_A = BM * AS, PLANE_B = BN * AS;
+    constexpr int STAGE = NPL * (PLANE_A + PLANE_B);         // bf16 elements
+    constexpr int SP = BN + 8;                               // staging row pitch (floats)
+    constexpr int HD = 128, LD = 32;
+    CDF_DYN_SMEM(smem_raw);
+    unsigned short* smem = (unsigned short*)smem_raw;        // [2][STAGE] operand stages ...
+    float* stg = (float*)smem_raw;                           // ... aliased by the [128][SP] fp32 staging tile
+    float* sstat = (float*)(smem_raw + (size_t)BM * SP * sizeof(float));     // [4 heads][2 halves][32] tile maxima, then [4][2][32*32] final fold
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y, p = blockIdx.x;
+    const int tiles = a.n / BM;
+    const int t_lo = p * a.tiles_per_block;
+    int t_hi = t_lo + a.tiles_per_block;
+    if (t_hi > tiles) t_hi = tiles;
+    const int nch = a.dim / BK;
+    const float* xb = a.xn + (size_t)b * a.n * a.ldx;
+    float* kvb = a.kv + (size_t)b * a.n * a.ldkv;
+
+    // ---- operand load slots: A 128 rows x 8 float4 (2 per thread), B 256 rows x 4 uint4 per plane (2 per thread and plane)
+    const int a_row = tid >> 3, a_c4 = (tid & 7) * 4;
+    const int b_row = tid >> 2, b_q = tid & 3;
+    f32x4_t ra[2];
+    u32x4_v rbh[2], rbl[2];
+    rbl[0] = rbl[1] = u32x4_v{0u, 0u, 0u, 0u};
+    auto load_chunk = [&](int tile, int c) {
+        const float* xa = xb + (size_t)tile * BM * a.ldx + c * BK + a_c4;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) ra[q] = *(const f32x4_t*)(xa + (size_t)(a_row + 64 * q) * a.ldx);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const size_t off = (size_t)(b_row + 128 * q) * a.ldk + c * BK + b_q * 8;
+            rbh[q] = *(const u32x4_v*)(a.w_hi + off);
+            if (SPLIT > 1) rbl[q] = *(const u32x4_v*)(a.w_lo + off);
+        }
+    };
+    auto store_lds = [&](int buf) {
+        unsigned short* st = smem + buf * STAGE;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            uint2 hi, lo;
+            const float4 v = make_float4(ra[q].x, ra[q].y, ra[q].z, ra[q].w);
+            if (SPLIT > 1) {
+                cdf_split4_trunc(v, hi, lo);
+            } else {
+                hi.x = cdf_f2bf(v.x) | (cdf_f2bf(v.y) << 16);
+                hi.y = cdf_f2bf(v.z) | (cdf_f2bf(v.w) << 16);
+                lo = hi;
+            }
+            const int off = (a_row + 64 * q) * AS + a_c4;
+            *(uint2*)(st + off) = hi;
+            if (SPLIT > 1) *(uint2*)(st + PLANE_A + off) = lo;
+        }
+        unsigned short* sb = st + NPL * PLANE_A;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int off = (b_row + 128 * q) * AS + b_q * 8;
+            *(u32x4_v*)(sb + off) = rbh[q];
+            if (SPLIT > 1) *(u32x4_v*)(sb + PLANE_B + off) = rbl[q];
+        }
+    };
+
+    // ---- context state of this wave: head ch, pixel half cp
+    const int ch = wave >> 1, cp = wave & 1;
+    f32x16_t cacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
+    float m_run = -3.0e38f, psum = 0.f;                      // lane (i = l31): column d = i of this head (both pixel parities hold m_run)
+
+    if (t_lo < t_hi) load_chunk(t_lo, 0);
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        f32x16_t acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        store_lds(0);
+        __syncthreads();
+        for (int c = 0; c < nch; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nch) load_chunk(tile, c + 1);
+            const unsigned short* sa = smem + buf * STAGE;
+            const unsigned short* sb = sa + NPL * PLANE_A;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int k0 = ks * 16 + half * 8;
+                bf16x8_v ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int off = (wm * 64 + i * 32 + l31) * AS + k0;
+                    ah[i] = *(const bf16x8_v*)(sa + off);
+                    if (SPLIT > 1) al[i] = *(const bf16x8_v*)(sa + PLANE_A + off);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int off = (wn * 64 + j * 32 + l31) * AS + k0;
+                    bh[j] = *(const bf16x8_v*)(sb + off);
+                    if (SPLIT > 1) bl[j] = *(const bf16x8_v*)(sb + PLANE_B + off);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (SPLIT > 1) {
+                            acc[i][j] = CDF_MFMA_BF16(al[i], bh[j], acc[i][j]);
+                            acc[i][j] = CDF_MFMA_BF16(ah[i], bl[j], acc[i][j]);
+                        }
+                        acc[i][j] = CDF_MFMA_BF16(ah[i], bh[j], acc[i][j]);
+                    }
+            }
+            if (c + 1 < nch) store_lds(buf ^ 1);
+            __syncthreads();
+        }
+        // the next tile's first chunk travels while this tile's k | v are stored and folded into the context
+        if (tile + 1 < t_hi) load_chunk(tile + 1, 0);
+        // ---- accumulators -> staging tile [pixel][channel] (the operand stages are free: every wave is past the last barrier)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stg[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * SP + wn * 64 + j * 32 + l31] = acc[i][j][r];
+        __syncthreads();
+        // ---- k | v rows out: 64 float4 = one 1 KB row per wave instruction
+        {
+            float* dst = kvb + (size_t)tile * BM * a.ldkv;
+#pragma unroll 4
+            for (int e = tid; e < BM * (BN / 4); e += 512) {
+                const int px = e >> 6, c4 = (e & 63) * 4;
+                *(float4*)(dst + (size_t)px * a.ldkv + c4) = *(const float4*)(stg + px * SP + c4);
+            }
+        }
+        // ---- context: this wave's head, its 64 pixels.  Tile column max of k first (both waves of the head), then the update.
+        const float* kcol = stg + (cp * 64 + half) * SP + ch * LD + l31;           // pixel cp*64 + 2 s + half, column d = l31
+        const float* vcol = kcol + HD;
+        float m = -3.0e38f;
+#pragma unroll 8
+        for (int sx = 0; sx < 32; ++sx) m = fmaxf(m, kcol[2 * sx * SP]);
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (half == 0) sstat[(ch * 2 + cp) * LD + l31] = m;
+        __syncthreads();
+        const float m_tile = fmaxf(sstat[(ch * 2) * LD + l31], sstat[(ch * 2 + 1) * LD + l31]);
+        const float m_new = fmaxf(m_run, m_tile);
+        const float f = expf(m_run - m_new);                 // (first tile: exp(-inf) = 0 on zero accumulators)
+        // accumulator row of register r is d = (r & 3) + 8 (r >> 2) + 4 half: its factor lives in lane d (either half)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cacc[r] *= __shfl(f, (r & 3) + 8 * (r >> 2) + 4 * half);
+        psum *= f;
+        m_run = m_new;
+#pragma unroll 8
+        for (int sx = 0; sx < 32; ++sx) {
+            const float pk = expf(kcol[2 * sx * SP] - m_new);
+            psum += pk;
+            cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pk, vcol[2 * sx * SP], cacc, 0, 0, 0);
+        }
+        __syncthreads();                                      // the staging tile (and sstat) are rewritten by the next trip
+    }
+    // ---- one partial per (block, head): fold the two pixel halves
+    psum += __shfl_xor(psum, 32);
+    float* fold = sstat;                                      // [4 heads][2 halves][1024] needs 32 KB: use the staging region instead
+    fold = stg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fold[(wave * LD + (r & 3) + 8 * (r >> 2) + 4 * half) * LD + l31] = cacc[r];
+    float* fs = stg + 8 * LD * LD;                            // [8 waves][32] sums
+    if (half == 0) fs[wave * LD + l31] = psum;
+    __syncthreads();
+    const size_t pb = (size_t)b * a.P + p;
+    for (int e = tid; e < 4 * LD * LD; e += 512) {
+        const int h = e >> 10, k = e & 1023;
+        a.ctx_part[(pb * 4 + h) * (LD * LD) + k] = t_lo < t_hi ? fold[(2 * h) * LD * LD + k] + fold[(2 * h + 1) * LD * LD + k] : 0.f;
+    }
+    if (tid < HD) {
+        const int h = tid >> 5, d = tid & 31;
+        a.sum_part[pb * HD + tid] = t_lo < t_hi ? fs[(2 * h) * LD + d] + fs[(2 * h + 1) * LD + d] : 0.f;
+    }
+    // (both waves of a head carry the same running max)
+    if (cp == 0 && half == 0) a.max_part[pb * HD + ch * LD + l31] = m_run;
+}
+
 // dst_hi/lo[t][r][c] (c < ldc, zero padded) = split(src[c*s_c + r*s_r + t*s_t])
 __global__ void pack_weight_bf16_kernel(const float* src, unsigned short* dst_hi, unsigned short* dst_lo, int T, int R, int C,
                                         int ldc, long long s_t, long long s_r, long long s_c) {
@@ -2004,6 +2218,52 @@ __global__ void pack_weight_bf16_kernel(const float* src, unsigned short* dst_hi
 }
 
 // ================================================================================================
+// blocks per image of cdf_linattn_kvctx (= partials per image and head for cdf_linattn_finalize)
+static std::atomic<int> g_kvctx_slots{512};
+extern "C" int cdf_linattn_kvctx_slots(int slots) {          // tuning / test hook (process-wide): target number of blocks per launch
+    g_kvctx_slots.store(slots < 1 ? 1 : slots);
+    return 0;
+}
+extern "C" int cdf_linattn_kvctx_parts(int B, int n) {
+    const int tiles = n / 128;
+    if (tiles < 1 || B < 1) return 0;
+    int P = g_kvctx_slots.load() / B;                        // default ~2 blocks per CU queued: a block's last tile overlaps another's start
+    if (P < 1) P = 1;
+    if (P > tiles) P = tiles;
+    const int tpb = (tiles + P - 1) / P;
+    return (tiles + tpb - 1) / tpb;
+}
+
+extern "C" int cdf_linattn_kvctx(const float* xn, int ldx, const void* w_hi, const void* w_lo, int ldk, float* kv, int ldkv, float* ws, int B,
+                                 int n, int dim, int heads, void* stream) {
+    CDF_REQUIRE(xn && w_hi && kv && ws && B > 0, "cdf_linattn_kvctx: null pointer");
+    CDF_REQUIRE(heads == 4 && n >= 128 && n % 128 == 0 && dim >= 32 && dim % 32 == 0 && dim <= 512,
+                "cdf_linattn_kvctx: 4 heads, n %% 128 == 0, dim a multiple of 32 (<= 512); got heads=%d n=%d dim=%d", heads, n, dim);
+    CDF_REQUIRE(ldx % 4 == 0 && ldx >= dim && ldk % 8 == 0 && ldk >= dim && ldkv % 4 == 0 && ldkv >= 256 &&
+                ((((uintptr_t)xn) | ((uintptr_t)w_hi) | ((uintptr_t)w_lo) | ((uintptr_t)kv)) & 15) == 0,
+                "cdf_linattn_kvctx: pitches (xn % 4, weights % 8, kv % 4 and >= 256) / 16-byte alignment");
+    const int P = cdf_linattn_kvctx_parts(B, n), tiles = n / 128, HD = 128;
+    KvCtxArgs a;
+    a.xn = xn; a.w_hi = (const unsigned short*)w_hi; a.w_lo = (const unsigned short*)w_lo; a.kv = kv;
+    a.max_part = ws;
+    a.ctx_part = ws + (size_t)B * P * HD;
+    a.sum_part = a.ctx_part + (size_t)B * P * heads * 1024;
+    a.ldx = ldx; a.ldk = ldk; a.ldkv = ldkv; a.n = n; a.dim = dim; a.P = P;
+    a.tiles_per_block = (tiles + P - 1) / P;
+    const size_t lds = (size_t)128 * (256 + 8) * sizeof(float) + 8 * 32 * sizeof(float);
+#ifndef CDF_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)linattn_kvctx_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)linattn_kvctx_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+#endif
+    if (w_lo) CDF_LAUNCH((linattn_kvctx_kernel<3>), dim3(P, B), dim3(512), lds, CDF_S, a);
+    else CDF_LAUNCH((linattn_kvctx_kernel<1>), dim3(P, B), dim3(512), lds, CDF_S, a);
+    return cdf_check_launch("linattn_kvctx");
+}
+
 extern "C" int cdf_pack_weight_bf16(const float* src, void* dst_hi, void* dst_lo, int T, int R, int C, int ldc, long long s_t,
                                     long long s_r, long long s_c, void* stream) {
     CDF_REQUIRE(src && dst_hi && T > 0 && R > 0 && C > 0 && ldc >= C && ldc % 32 == 0, "cdf_pack_weight_bf16: bad args (ldc must be a multiple of 32)");

@@ -313,6 +313,16 @@ size_t cdf_linattn_ws_floats(int B, int n, int heads);
  * tensor (the q-free form of colddiff/ops.py linattn_fold: q never exists when dim <= heads*32). */
 int cdf_linattn_context(const float* qkv, int ld, int koff, float* ctx, float* ctxs, float* kmax, float* ksum, float* ws, int B,
                         int n, int heads, float scale, void* stream);
+/* cdf_linattn_kvctx (round 2): the k | v projection kv = xn . Wkv^T ([B,n,256], 4 heads; Wkv as bf16 hi [/ lo] planes [256][ldk], K contiguous:
+ * cdf_pack_weight_bf16; w_lo == NULL: single bf16 operands) AND the context partials of the same pixels in one pass -- k and v are written once
+ * and not read back by the forward pass.  n % 128 == 0, dim % 32 == 0.  ws: (2*128 + 4*1024) * B * cdf_linattn_kvctx_parts(B, n) floats;
+ * cdf_linattn_finalize(ws, nparts = cdf_linattn_kvctx_parts(B, n), ...) then yields what cdf_linattn_context yields (ctx, ctxs, kmax, ksum). */
+int cdf_linattn_kvctx_parts(int B, int n);
+int cdf_linattn_kvctx_slots(int slots);       /* tuning / test hook (process-wide): target block count per launch (default 512) */
+int cdf_linattn_kvctx(const float* xn, int ldx, const void* w_hi, const void* w_lo, int ldk, float* kv, int ldkv, float* ws, int B, int n,
+                      int dim, int heads, void* stream);
+int cdf_linattn_finalize(const float* ws, int nparts, float* ctx, float* ctxs, float* kmax, float* ksum, int B, int heads, float scale,
+                         void* stream);
 int cdf_linattn_dcontext(const float* qkv, int ld, const float* dout, int lddo, const float* ctx, float* dctx,
                          float* rvec, float* ws, int B, int n, int heads, float scale, void* stream);
 int cdf_linattn_softk(const float* qkv, int ld, const float* kmax, const float* ksum, float* pn, int ldp, int B, int n,

@@ -535,6 +535,48 @@ def test_pack_many_matches_single_packs(be):
             assert torch.equal(d1.cpu(), r1.cpu())
 
 
+@pytest.mark.parametrize("B,n,dim,slots,split", [(2, 256, 64, 512, 3), (1, 640, 64, 1, 3), (3, 384, 128, 4, 3), (1, 256, 96, 1, 1)])
+def test_linattn_kvctx_fused(be, B, n, dim, slots, split):
+    """cdf_linattn_kvctx + cdf_linattn_finalize: the k | v projection and the softmax context in one pass -- against torch (kv to the
+    split-precision GEMM tolerance, kmax exact for the kv it wrote, ctx / ksum from that kv), with one tile per block and with blocks that
+    walk several tiles (running max + rescaled accumulators: slots hook), k columns drifting by +-20 along the pixels."""
+    torch.manual_seed(n + dim)
+    heads, HD, scale = 4, 128, 32 ** -0.5
+    xn = torch.randn(B, n, dim)
+    w = torch.randn(3 * HD, dim) / math.sqrt(dim)
+    w[HD:2 * HD] *= 3.0                                    # wider k range: the per-tile maxima differ
+    xn[..., 0] += torch.linspace(-6, 6, n)                 # a drift along the pixels that k picks up through column 0 of W
+    kv_ref = xn.double() @ w[HD:].double().t()             # [B, n, 2 HD]
+    ldk = (dim + 31) // 32 * 32
+    wd = be.to(w)
+    whi = torch.zeros(1, 2 * HD, ldk, dtype=torch.int16, device=be.device)
+    wlo = torch.zeros_like(whi) if split == 3 else None
+    be.L.cdf_pack_weight_bf16(P(wd) + 4 * HD * dim, P(whi), P(wlo), 1, 2 * HD, dim, ldk, 1, dim, 1, be.stream())
+    kv = be.empty(B, n, 2 * HD)
+    try:
+        be.L.cdf_linattn_kvctx_slots(slots)
+        parts = be.L.cdf_linattn_kvctx_parts(B, n)
+        assert parts == min(max(slots // B, 1), n // 128) or parts >= 1
+        ws = be.empty(B * parts * (2 * HD + heads * 1024))
+        be.L.cdf_linattn_kvctx(P(be.to(xn)), dim, P(whi), P(wlo), ldk, P(kv), 2 * HD, P(ws), B, n, dim, heads, be.stream())
+    finally:
+        be.L.cdf_linattn_kvctx_slots(512)
+    ctx, ctxs, kmax, ksum = be.empty(B, heads, 32, 32), be.empty(B, heads, 32, 32), be.empty(B, HD), be.empty(B, HD)
+    be.L.cdf_linattn_finalize(P(ws), parts, P(ctx), P(ctxs), P(kmax), P(ksum), B, heads, scale, be.stream())
+    rel = 3e-5 if split == 3 else 2e-2
+    assert err(kv, kv_ref.float()) <= rel * kv_ref.abs().max().item()
+    kvc = kv.cpu().double()
+    k, v = kvc[..., :HD], kvc[..., HD:]
+    kmax_ref = k.max(1).values
+    e = torch.exp(k - kmax_ref[:, None])
+    ksum_ref = e.sum(1)
+    ctx_ref = torch.einsum("bnhd,bnhe->bhde", (e / ksum_ref[:, None]).view(B, n, heads, 32), v.view(B, n, heads, 32)).float()
+    assert torch.equal(kmax.cpu(), kmax_ref.float())
+    assert err(ksum, ksum_ref.float()) <= 1e-5 * ksum_ref.max().item()
+    assert err(ctx, ctx_ref) <= 2e-5 * max(1.0, ctx_ref.abs().max().item())
+    assert err(ctxs, ctx_ref * scale) <= 2e-5 * max(1.0, ctx_ref.abs().max().item())
+
+
 def test_small_ops(be):
     torch.manual_seed(0)
     L, S = be.L, be.stream()

@@ -70,7 +70,7 @@ def test_unet_golden(mbe):
     grad_check(net.named_parameters(), g["grads"])
 
 
-@pytest.mark.parametrize("dim,H", [(16, 12), (160, 8)])
+@pytest.mark.parametrize("dim,H", [(16, 12), (160, 8), (64, 16)])
 def test_linear_attention_block_all_forms(mbe, dim, H):
     """Residual(PreNorm(LinearAttention)) in its three arithmetic forms -- plain (per-head products + to_out conv), to_out folded into a
     per-image matrix, q folded in as well (k|v-only projection; only where dim <= heads*32) -- against a torch restatement of
