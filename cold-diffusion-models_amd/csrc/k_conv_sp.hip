@@ -2014,18 +2014,24 @@ struct KvCtxArgs {
     int n, dim, P, tiles_per_block;
 };
 
-template <int SPLIT>
+#ifndef CDF_KVCTX_ABLATE
+#define CDF_KVCTX_ABLATE 0   // probe builds only: 1 no context phase, 2 no k|v stores, 4 no GEMM MFMAs
+#endif
+// BK = 64 when dim % 64 == 0 (a dim = 64 tile is ONE chunk: all of the next tile's operands travel during the current tile's store /
+// context phase), else 32.  One LDS operand stage (the next chunk waits in registers), aliased by the staging tile.
+template <int SPLIT, int BK>
 __global__ void __launch_bounds__(512, 1) linattn_kvctx_kernel(KvCtxArgs a) {
-    constexpr int BM = 128, BN = 256, BK = 32, AS = 40;      // AS: LDS row stride in bf16 elements (80 B)
+    constexpr int BM = 128, BN = 256, AS = BK + 8;           // AS: LDS row stride in bf16 elements
     constexpr int NPL = SPLIT == 1 ? 1 : 2;
     constexpr int PLANE_A = BM * AS, PLANE_B = BN * AS;
-    constexpr int STAGE = NPL * (PLANE_A + PLANE_B);         // bf16 elements
     constexpr int SP = BN + 8;                               // staging row pitch (floats)
     constexpr int HD = 128, LD = 32;
+    constexpr int AV = BK / 4, AQ = BM * AV / 512;           // float4 per A row, A loads per thread
+    constexpr int BV = BK / 8, BQ = BN * BV / 512;           // uint4 per B row and plane, B loads per thread and plane
     CDF_DYN_SMEM(smem_raw);
-    unsigned short* smem = (unsigned short*)smem_raw;        // [2][STAGE] operand stages ...
+    unsigned short* smem = (unsigned short*)smem_raw;        // operand stage [A planes | B planes] ...
     float* stg = (float*)smem_raw;                           // ... aliased by the [128][SP] fp32 staging tile
-    float* sstat = (float*)(smem_raw + (size_t)BM * SP * sizeof(float));     // [4 heads][2 halves][32] tile maxima, then [4][2][32*32] final fold
+    float* sstat = (float*)(smem_raw + (size_t)BM * SP * sizeof(float));     // [2 pixel halves][128] column maxima of k
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -2039,27 +2045,26 @@ __global__ void __launch_bounds__(512, 1) linattn_kvctx_kernel(KvCtxArgs a) {
     const float* xb = a.xn + (size_t)b * a.n * a.ldx;
     float* kvb = a.kv + (size_t)b * a.n * a.ldkv;
 
-    // ---- operand load slots: A 128 rows x 8 float4 (2 per thread), B 256 rows x 4 uint4 per plane (2 per thread and plane)
-    const int a_row = tid >> 3, a_c4 = (tid & 7) * 4;
-    const int b_row = tid >> 2, b_q = tid & 3;
-    f32x4_t ra[2];
-    u32x4_v rbh[2], rbl[2];
-    rbl[0] = rbl[1] = u32x4_v{0u, 0u, 0u, 0u};
+    const int a_row = tid / AV, a_c4 = (tid % AV) * 4;       // + (512 / AV) rows per further load
+    const int b_row = tid / BV, b_q = tid % BV;
+    f32x4_t ra[AQ];
+    u32x4_v rbh[BQ], rbl[BQ];
+#pragma unroll
+    for (int q = 0; q < BQ; ++q) rbl[q] = u32x4_v{0u, 0u, 0u, 0u};
     auto load_chunk = [&](int tile, int c) {
         const float* xa = xb + (size_t)tile * BM * a.ldx + c * BK + a_c4;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) ra[q] = *(const f32x4_t*)(xa + (size_t)(a_row + 64 * q) * a.ldx);
+        for (int q = 0; q < AQ; ++q) ra[q] = *(const f32x4_t*)(xa + (size_t)(a_row + (512 / AV) * q) * a.ldx);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const size_t off = (size_t)(b_row + 128 * q) * a.ldk + c * BK + b_q * 8;
+        for (int q = 0; q < BQ; ++q) {
+            const size_t off = (size_t)(b_row + (512 / BV) * q) * a.ldk + c * BK + b_q * 8;
             rbh[q] = *(const u32x4_v*)(a.w_hi + off);
             if (SPLIT > 1) rbl[q] = *(const u32x4_v*)(a.w_lo + off);
         }
     };
-    auto store_lds = [&](int buf) {
-        unsigned short* st = smem + buf * STAGE;
+    auto store_lds = [&]() {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < AQ; ++q) {
             uint2 hi, lo;
             const float4 v = make_float4(ra[q].x, ra[q].y, ra[q].z, ra[q].w);
             if (SPLIT > 1) {
@@ -2069,21 +2074,22 @@ __global__ void __launch_bounds__(512, 1) linattn_kvctx_kernel(KvCtxArgs a) {
                 hi.y = cdf_f2bf(v.z) | (cdf_f2bf(v.w) << 16);
                 lo = hi;
             }
-            const int off = (a_row + 64 * q) * AS + a_c4;
-            *(uint2*)(st + off) = hi;
-            if (SPLIT > 1) *(uint2*)(st + PLANE_A + off) = lo;
+            const int off = (a_row + (512 / AV) * q) * AS + a_c4;
+            *(uint2*)(smem + off) = hi;
+            if (SPLIT > 1) *(uint2*)(smem + PLANE_A + off) = lo;
         }
-        unsigned short* sb = st + NPL * PLANE_A;
+        unsigned short* sb = smem + NPL * PLANE_A;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int off = (b_row + 128 * q) * AS + b_q * 8;
+        for (int q = 0; q < BQ; ++q) {
+            const int off = (b_row + (512 / BV) * q) * AS + b_q * 8;
             *(u32x4_v*)(sb + off) = rbh[q];
             if (SPLIT > 1) *(u32x4_v*)(sb + PLANE_B + off) = rbl[q];
         }
     };
 
-    // ---- context state of this wave: head ch, pixel half cp
-    const int ch = wave >> 1, cp = wave & 1;
+    // ---- context state: waves 0-3 own one head each (all 128 pixels of a tile); waves 4-7 stream the tile out meanwhile
+    const bool ctx_wave = wave < 4;
+    const int ch = wave & 3;
     f32x16_t cacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
@@ -2098,15 +2104,17 @@ __global__ void __launch_bounds__(512, 1) linattn_kvctx_kernel(KvCtxArgs a) {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        store_lds(0);
-        __syncthreads();
         for (int c = 0; c < nch; ++c) {
-            const int buf = c & 1;
+            if (c > 0) __syncthreads();                       // every wave is done with the previous chunk's fragments
+            store_lds();
+            __syncthreads();
+            // what is needed next travels during the MFMAs (and, for the last chunk, during the store / context phase)
             if (c + 1 < nch) load_chunk(tile, c + 1);
-            const unsigned short* sa = smem + buf * STAGE;
+            else if (tile + 1 < t_hi) load_chunk(tile + 1, 0);
+            const unsigned short* sa = smem;
             const unsigned short* sb = sa + NPL * PLANE_A;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < BK / 16; ++ks) {
                 const int k0 = ks * 16 + half * 8;
                 bf16x8_v ah[2], al[2], bh[2], bl[2];
 #pragma unroll
@@ -2125,19 +2133,21 @@ __global__ void __launch_bounds__(512, 1) linattn_kvctx_kernel(KvCtxArgs a) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
+#if CDF_KVCTX_ABLATE & 4
+                        acc[i][j][0] += (float)(ah[i][0] + bh[j][0] + al[i][0] + bl[j][0]);
+#else
                         if (SPLIT > 1) {
                             acc[i][j] = CDF_MFMA_BF16(al[i], bh[j], acc[i][j]);
                             acc[i][j] = CDF_MFMA_BF16(ah[i], bl[j], acc[i][j]);
                         }
                         acc[i][j] = CDF_MFMA_BF16(ah[i], bh[j], acc[i][j]);
+#endif
                     }
             }
-            if (c + 1 < nch) store_lds(buf ^ 1);
-            __syncthreads();
         }
-        // the next tile's first chunk travels while this tile's k | v are stored and folded into the context
-        if (tile + 1 < t_hi) load_chunk(tile + 1, 0);
-        // ---- accumulators -> staging tile [pixel][channel] (the operand stages are free: every wave is past the last barrier)
+        __syncthreads();                                      // the operand stage is free: it becomes the staging tile
+        // ---- accumulators -> staging tile [pixel][channel]; the k waves (channel quarters 0, 1) leave the column maxima of their
+        //      64 pixels next to it
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -2145,61 +2155,64 @@ __global__ void __launch_bounds__(512, 1) linattn_kvctx_kernel(KvCtxArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     stg[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * SP + wn * 64 + j * 32 + l31] = acc[i][j][r];
+        if (wn < 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float m = -3.0e38f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
+                m = fmaxf(m, __shfl_xor(m, 32));
+                if (half == 0) sstat[wm * HD + wn * 64 + j * 32 + l31] = m;
+            }
+        }
         __syncthreads();
-        // ---- k | v rows out: 64 float4 = one 1 KB row per wave instruction
-        {
+        if (!ctx_wave) {
+            // ---- k | v rows out: 64 float4 = one 1 KB row per wave instruction (waves 4-7: the stores' back-pressure stalls nobody else)
+#if !(CDF_KVCTX_ABLATE & 2)
             float* dst = kvb + (size_t)tile * BM * a.ldkv;
 #pragma unroll 4
-            for (int e = tid; e < BM * (BN / 4); e += 512) {
+            for (int e = tid - 256; e < BM * (BN / 4); e += 256) {
                 const int px = e >> 6, c4 = (e & 63) * 4;
                 *(float4*)(dst + (size_t)px * a.ldkv + c4) = *(const float4*)(stg + px * SP + c4);
             }
-        }
-        // ---- context: this wave's head, its 64 pixels.  Tile column max of k first (both waves of the head), then the update.
-        const float* kcol = stg + (cp * 64 + half) * SP + ch * LD + l31;           // pixel cp*64 + 2 s + half, column d = l31
-        const float* vcol = kcol + HD;
-        float m = -3.0e38f;
-#pragma unroll 8
-        for (int sx = 0; sx < 32; ++sx) m = fmaxf(m, kcol[2 * sx * SP]);
-        m = fmaxf(m, __shfl_xor(m, 32));
-        if (half == 0) sstat[(ch * 2 + cp) * LD + l31] = m;
-        __syncthreads();
-        const float m_tile = fmaxf(sstat[(ch * 2) * LD + l31], sstat[(ch * 2 + 1) * LD + l31]);
-        const float m_new = fmaxf(m_run, m_tile);
-        const float f = expf(m_run - m_new);                 // (first tile: exp(-inf) = 0 on zero accumulators)
-        // accumulator row of register r is d = (r & 3) + 8 (r >> 2) + 4 half: its factor lives in lane d (either half)
+#endif
+        } else {
+#if !(CDF_KVCTX_ABLATE & 1)
+            // ---- context of head ch: acc = acc * exp(m_old - m) + exp(k - m)^T v over the tile's 128 pixels
+            const float* kcol = stg + half * SP + ch * LD + l31;                       // pixel 2 s + half, column d = l31
+            const float* vcol = kcol + HD;
+            const float m_new = fmaxf(m_run, fmaxf(sstat[ch * LD + l31], sstat[HD + ch * LD + l31]));
+            const float f = expf(m_run - m_new);                                       // (first tile: exp(-inf) = 0 on zero accumulators)
+            // accumulator row of register r is d = (r & 3) + 8 (r >> 2) + 4 half: its factor lives in lane d
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cacc[r] *= __shfl(f, (r & 3) + 8 * (r >> 2) + 4 * half);
-        psum *= f;
-        m_run = m_new;
+            for (int r = 0; r < 16; ++r) cacc[r] *= __shfl(f, (r & 3) + 8 * (r >> 2) + 4 * half);
+            psum *= f;
+            m_run = m_new;
 #pragma unroll 8
-        for (int sx = 0; sx < 32; ++sx) {
-            const float pk = expf(kcol[2 * sx * SP] - m_new);
-            psum += pk;
-            cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pk, vcol[2 * sx * SP], cacc, 0, 0, 0);
+            for (int sx = 0; sx < 64; ++sx) {
+                const float pk = expf(kcol[2 * sx * SP] - m_new);
+                psum += pk;
+                cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pk, vcol[2 * sx * SP], cacc, 0, 0, 0);
+            }
+#endif
         }
         __syncthreads();                                      // the staging tile (and sstat) are rewritten by the next trip
     }
-    // ---- one partial per (block, head): fold the two pixel halves
+    // ---- one partial per (block, head)
     psum += __shfl_xor(psum, 32);
-    float* fold = sstat;                                      // [4 heads][2 halves][1024] needs 32 KB: use the staging region instead
-    fold = stg;
+    float* fold = stg;                                        // [4 heads][32][32], then [4][32] sums
+    if (ctx_wave) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) fold[(wave * LD + (r & 3) + 8 * (r >> 2) + 4 * half) * LD + l31] = cacc[r];
-    float* fs = stg + 8 * LD * LD;                            // [8 waves][32] sums
-    if (half == 0) fs[wave * LD + l31] = psum;
+        for (int r = 0; r < 16; ++r) fold[(ch * LD + (r & 3) + 8 * (r >> 2) + 4 * half) * LD + l31] = cacc[r];
+        if (half == 0) fold[4 * LD * LD + ch * LD + l31] = psum;
+    }
     __syncthreads();
     const size_t pb = (size_t)b * a.P + p;
-    for (int e = tid; e < 4 * LD * LD; e += 512) {
-        const int h = e >> 10, k = e & 1023;
-        a.ctx_part[(pb * 4 + h) * (LD * LD) + k] = t_lo < t_hi ? fold[(2 * h) * LD * LD + k] + fold[(2 * h + 1) * LD * LD + k] : 0.f;
-    }
-    if (tid < HD) {
-        const int h = tid >> 5, d = tid & 31;
-        a.sum_part[pb * HD + tid] = t_lo < t_hi ? fs[(2 * h) * LD + d] + fs[(2 * h + 1) * LD + d] : 0.f;
-    }
-    // (both waves of a head carry the same running max)
-    if (cp == 0 && half == 0) a.max_part[pb * HD + ch * LD + l31] = m_run;
+    for (int e = tid; e < 4 * LD * LD; e += 512) a.ctx_part[pb * 4 * (LD * LD) + e] = t_lo < t_hi ? fold[e] : 0.f;
+    if (tid < HD) a.sum_part[pb * HD + tid] = t_lo < t_hi ? fold[4 * LD * LD + tid] : 0.f;
+    if (ctx_wave && half == 0) a.max_part[pb * HD + ch * LD + l31] = m_run;
 }
 
 // dst_hi/lo[t][r][c] (c < ldc, zero padded) = split(src[c*s_c + r*s_r + t*s_t])
@@ -2254,13 +2267,20 @@ extern "C" int cdf_linattn_kvctx(const float* xn, int ldx, const void* w_hi, con
 #ifndef CDF_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)linattn_kvctx_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)linattn_kvctx_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)linattn_kvctx_kernel<1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)linattn_kvctx_kernel<3, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)linattn_kvctx_kernel<1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)linattn_kvctx_kernel<3, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
 #endif
-    if (w_lo) CDF_LAUNCH((linattn_kvctx_kernel<3>), dim3(P, B), dim3(512), lds, CDF_S, a);
-    else CDF_LAUNCH((linattn_kvctx_kernel<1>), dim3(P, B), dim3(512), lds, CDF_S, a);
+    if (dim % 64 == 0) {
+        if (w_lo) CDF_LAUNCH((linattn_kvctx_kernel<3, 64>), dim3(P, B), dim3(512), lds, CDF_S, a);
+        else CDF_LAUNCH((linattn_kvctx_kernel<1, 64>), dim3(P, B), dim3(512), lds, CDF_S, a);
+    } else {
+        if (w_lo) CDF_LAUNCH((linattn_kvctx_kernel<3, 32>), dim3(P, B), dim3(512), lds, CDF_S, a);
+        else CDF_LAUNCH((linattn_kvctx_kernel<1, 32>), dim3(P, B), dim3(512), lds, CDF_S, a);
+    }
     return cdf_check_launch("linattn_kvctx");
 }
 
