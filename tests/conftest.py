@@ -13,6 +13,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest tests` on a machine without a GPU skips the gpu-marked items instead of failing them (on the GPU box nothing is
+    skipped: a missing device there must fail loudly)."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this machine (gpu-marked tests run on the MI355X box with -m gpu)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 class Backend:
     """Where a kernel-level test runs.
 
