@@ -117,6 +117,8 @@ def get():
             _instance.cdf_conv_gemm_bf16x_tile(*[int(v) for v in tile.split("x")])
         if waves:
             _instance.cdf_conv_gemm_bf16x_waves(int(waves))
+        if os.environ.get("COLDDIFF_SPX_DEEP"):
+            _instance.cdf_conv_gemm_bf16x_deep(int(os.environ["COLDDIFF_SPX_DEEP"]))
         if os.environ.get("COLDDIFF_KVCTX_SLOTS"):
             _instance.cdf_linattn_kvctx_slots(int(os.environ["COLDDIFF_KVCTX_SLOTS"]))
         if os.environ.get("COLDDIFF_LINATTN_ONEPASS"):

@@ -328,9 +328,9 @@ class ConvNextBlockFn(torch.autograd.Function):
         # operands that feed several GEMMs (fwd now, dgrad/wgrad later, every N tile) are split into bf16 hi/lo ONCE, by
         # the kernel that produces them (LayerNorm, the GELU epilogue of conv1, the GELU' epilogue of conv2's dgrad)
         sp1, sp2 = want_presplit(dim, mid, 3), want_presplit(mid, dim_out, 3)
-        # When every consumer of a tensor reads its bf16 planes (fwd / dgrad GEMMs always, the wgrad GEMM from 2048
+        # When every consumer of a tensor reads its bf16 planes (fwd / dgrad GEMMs always, the wgrad GEMM from ops.WGRAD_SP_MIN_M
         # pixels up), its fp32 copy is not written at all: LN output, GELU output, conv2's data gradient.
-        lean = _LEAN and B * H * W >= 2048
+        lean = _LEAN and B * H * W >= ops.WGRAD_SP_MIN_M
         hn_s = None
         if m.has_norm:
             if sp1:
@@ -390,7 +390,7 @@ class ConvNextBlockFn(torch.autograd.Function):
         # conv2 -> (fused GELU') -> conv1
         do_s = ops.split_bf16(do) if a_s is not None else None
         if hn_s is not None:
-            lean = _LEAN and a_s is not None and a.shape[0] * a.shape[1] * a.shape[2] >= 2048
+            lean = _LEAN and a_s is not None and a.shape[0] * a.shape[1] * a.shape[2] >= ops.WGRAD_SP_MIN_M
             dpre, dpre_s = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=1, xs=a_s, dys=do_s, split_dx=True,
                                          planes_only=lean)
         else:

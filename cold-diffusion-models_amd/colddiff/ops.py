@@ -44,6 +44,9 @@ def new_feat(ref, B, H, W, C, zero=False):
 _pack_cache = {}          # (id(param), kind) -> [key, out, weakref, geom, last_used_epoch]
 _pack_tables = {}         # device -> (signature, device table tensor, nentries, nblocks): the cdf_pack_many descriptor table
 _PACK_ALL = __import__("os").environ.get("CDF_PACK_ALL", "1") != "0"
+# smallest pixel count whose weight gradient runs on the bf16 matrix cores (below, the fp32-MFMA kernel; 2048 until the end of round 2:
+# the 4 x 4-pixel level of the 32 x 32 configurations is M = 512 with 512 -> 1024 channels, 62 -> 28 us per launch)
+WGRAD_SP_MIN_M = int(__import__("os").environ.get("CDF_WGRAD_SP_MIN_M", "512"))
 _ATTN_KV_FUSED = __import__("os").environ.get("CDF_ATTN_KV_FUSED", "1") != "0"    # one-kernel k / v attention backward (k_attn.hip)
 
 
@@ -372,7 +375,7 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None, xa_s=No
     B = xa.shape[0]
     M = B * wplan.QH * wplan.QW
     ldo = r4(CB)
-    if xa_s is not None and xb_s is not None and CA >= 64 and CB >= 64 and M >= 2048:
+    if xa_s is not None and xb_s is not None and CA >= 64 and CB >= 64 and M >= WGRAD_SP_MIN_M:
         # both operands already split into bf16 hi/lo planes: copy + MFMA only (64-wide tiles for 64-channel sides);
         # xa / xb themselves may be shape-only stand-ins here
         dev = xa_s[0].device
@@ -390,7 +393,7 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None, xa_s=No
                                wplan.ntaps, wplan.desc, ns, P(bsum), S)
         _reduce_slabs(L, ws, gparam, ns, wplan.ntaps, CA, CB, ldo, s_t, s_r, s_c, bsum, gbias, S)
         return
-    if rt.precision != "f32" and CA >= 128 and CB >= 128 and M >= 2048:   # full 128x128 tiles only; thinner layers are faster on the fp32 kernel
+    if rt.precision != "f32" and CA >= 128 and CB >= 128 and M >= WGRAD_SP_MIN_M:   # full 128x128 tiles only; thinner layers are faster on the fp32 kernel
         # split-precision bf16 MFMA kernel: 128x128 tiles, resident twice per CU (512 slots)
         tiles = ((CA + 127) // 128) * ((CB + 127) // 128) * wplan.ntaps
         ns = best_nsplit(tiles, 512, M // 512)

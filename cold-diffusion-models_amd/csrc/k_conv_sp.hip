@@ -2408,6 +2408,11 @@ static std::atomic<int> g_spx_waves{0};                // 0 = automatic; 4 / 8 =
 static std::atomic<int> g_spx_max_bm{0};               // 0 / 256 = no cap; 128 = the automatic choice never takes the 256-row tile
 static std::atomic<int> g_spx_taprot{1};               // per-block row-group order of 3 x 3 taps when a tile is one image row
 
+static std::atomic<int> g_spx_deep{1};                     // small grids (<= 256 64-row tiles): six DMA stages, one block per CU
+extern "C" int cdf_conv_gemm_bf16x_deep(int enable) {
+    g_spx_deep.store(enable ? 1 : 0);
+    return 0;
+}
 static std::atomic<int> g_spx_dephase{1};              // the two waves of a SIMD run half a K step apart in the 8-wave tiles (tuning / test hook)
 
 extern "C" int cdf_conv_gemm_bf16x_dephase(int enable) {
@@ -2583,6 +2588,14 @@ static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cou
         }
     }
     if (m256) return launch_igemm_spx<NS, 256, 128, 4, 2, 3>(a, M, s);
+    // Grids that do not even give every CU one 64-row tile (the 4 x 4 / 8 x 8-pixel levels of the 32 x 32 configurations, small
+    // sampling batches): a block's life is its K loop, and with two stages every step waited out a whole DMA round trip (144 steps
+    // of 1.5 us for 512 -> 1024 channels at 4 x 4 pixels).  Six stages, one block per CU: five chunks in flight per block.
+    const long long tiles64 = (long long)cdf_cdiv(M, 64) * cdf_cdiv(Cout, n64 ? 64 : 128) * nphase;
+    if (m64 && tiles64 <= 256 && g_spx_deep) {
+        if (n64) return launch_igemm_spx<NS, 64, 64, 2, 2, 6, 1>(a, M, s);
+        return launch_igemm_spx<NS, 64, 128, 2, 2, 6, 1>(a, M, s);
+    }
     if (n64) return m64 ? launch_igemm_spx<NS, 64, 64, 2, 2, 2>(a, M, s) : launch_igemm_spx<NS, 128, 64, 2, 2, 2>(a, M, s);
     if (m64) return launch_igemm_spx<NS, 64, 128, 2, 2, 2>(a, M, s);
     // 128 x 128 with 8 waves (4 x 2 of 32 x 64), still two blocks per CU: 16 waves per CU instead of 8

@@ -189,6 +189,7 @@ int cdf_conv_gemm_bf16x_taprot(int enable);
  * SIMDs with waves 0..3; they multiply the fragments read in the previous K step first and read / request afterwards, so that one
  * wave of a SIMD feeds the matrix pipe while the other one reads LDS or issues global_load_lds.  Only the schedule depends on it. */
 int cdf_conv_gemm_bf16x_dephase(int enable);
+int cdf_conv_gemm_bf16x_deep(int enable);     /* 1 (default): grids of <= 256 64-row tiles run with six DMA stages, one block per CU */
 /* tuning / test hook: 3 x 3 stride-1 layers of cdf_conv_gemm_bf16x with the input tile (+ one-pixel halo) resident in LDS for
  * all nine taps.  enable: bit mask over the image width 16 (1), 32 (2), 64 (4), 128 (8), and 16 = at width 128 also for
  * layers with more than 64 output channels; 32 = the row-halo form (256-pixel tiles, input shared by the three dx taps of a row only)
