@@ -59,7 +59,7 @@ def parse_header(path=HEADER):
 
 
 # int-returning entry points that are pure host-side queries (sizes / counts), not status codes
-_QUERY = re.compile(r"(_blocks|_nchunk|_nsplit|_abi_version|_is_device_build|_lds_bytes|_is_row3|_ssim_tiles|_pack_entry_bytes|_pack_blocks|_kvctx_parts)$")
+_QUERY = re.compile(r"(_blocks|_nchunk|_nsplit|_abi_version|_is_device_build|_lds_bytes|_is_row3|_ssim_tiles|_pack_entry_bytes|_pack_blocks|_kvctx_parts|_bf16x_ksplit)$")
 
 
 class CdfError(RuntimeError):
@@ -117,6 +117,8 @@ def get():
             _instance.cdf_conv_gemm_bf16x_tile(*[int(v) for v in tile.split("x")])
         if waves:
             _instance.cdf_conv_gemm_bf16x_waves(int(waves))
+        if os.environ.get("COLDDIFF_SPX_SPLITK"):
+            _instance.cdf_conv_gemm_bf16x_splitk(int(os.environ["COLDDIFF_SPX_SPLITK"]))
         if os.environ.get("COLDDIFF_SPX_DEEP"):
             _instance.cdf_conv_gemm_bf16x_deep(int(os.environ["COLDDIFF_SPX_DEEP"]))
         if os.environ.get("COLDDIFF_KVCTX_SLOTS"):

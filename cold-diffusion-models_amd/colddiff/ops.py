@@ -267,11 +267,19 @@ def conv_gemm_presplit(plan, xs, Cin, wp, Cout, y=None, bias=None, sbias=None, r
     if y is None:
         y = shape_only(B, plan.OH, plan.OW, Cout) if planes_only else new_feat(hi, B, plan.OH, plan.OW, Cout)
     ldv = lambda t: 0 if t is None else ld_of(t)
+    # grids far below one tile per CU (a few hundred pixels): split-K through a workspace (include/colddiff.h)
+    M = B * plan.QH * plan.QW
+    ws, nws = None, 0
+    if M <= 4096 and hi.device.type != "meta":
+        ks = rt.lib().cdf_conv_gemm_bf16x_ksplit(M, Cout, plan.nphase, plan.desc[2])
+        if ks > 1:
+            nws = ks * M * r4(Cout)
+            ws = torch.empty((nws,), device=hi.device, dtype=torch.float32)
     rt.lib().cdf_conv_gemm_bf16x(P(hi), P(lo), hi.shape[-1], P(zero_page(hi.device)), P(wp[0]), P(wp[1]), wp[0].shape[-1], P(y), ld_of(y),
                                  B, plan.H, plan.W, Cin, plan.OH, plan.OW, Cout, plan.QH, plan.QW, plan.os, plan.istride, plan.nphase,
                                  plan.desc, P(bias), P(sbias), 0 if sbias is None else sbias.stride(0), P(res), ldv(res), P(pre),
                                  ldv(pre), P(mul), ldv(mul), act, mul_mode, accumulate, P(ys[0]) if ys else 0, P(ys[1]) if ys else 0,
-                                 ys[0].shape[-1] if ys else 0, rt.stream(hi))
+                                 ys[0].shape[-1] if ys else 0, P(ws), nws, rt.stream(hi))
     if split_out:
         return y, (ys if ys is not None else split_bf16(y))
     return y

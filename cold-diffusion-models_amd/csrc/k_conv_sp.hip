@@ -590,7 +590,22 @@ struct SpxArgs {
     unsigned short* ys_hi;         // nullable: bf16 hi / lo planes of the output (pitch ld_ys), written by the epilogue
     unsigned short* ys_lo;
     int ld_ys;
+    int ksplit;                    // > 1 (generic kernel, one phase): blockIdx.z takes ntaps / ksplit taps and writes its raw partial
+    float* ks_ws;                  //      sums to ks_ws[z][m][ks_ld]; conv_splitk_finish_kernel adds them up and runs the epilogue
+    int ks_ld;
     SpPhase ph[4];
+};
+
+// what cdf_epilogue_rows reads, for a raw store of the accumulator tile (split-K partial sums): rows m of a [M][ldy] slab
+struct RawEpiArgs {
+    int Cout, vec, os, QH, QW, OH, OW, ldy, ldp, ldm, ldr, ld_sbias, ld_ys, act, mul_mode, accumulate;
+    const float* bias;
+    const float* sbias;
+    float* pre;
+    const float* mul;
+    const float* res;
+    unsigned short* ys_hi;
+    unsigned short* ys_lo;
 };
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC = 512 / (64 * WM * WN), int NS = 3>
@@ -649,7 +664,10 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
         b_row[p] = n < a.Cout ? n : a.Cout - 1;
     }
     const int nchunks = (a.Cin + BK - 1) / BK;
-    const int niter = ph.ntaps * nchunks;
+    // split-K over the taps (small grids: see dispatch_gemm_bf16x): this block's share of the taps
+    const int ntaps_blk = a.ksplit > 1 ? ph.ntaps / a.ksplit : ph.ntaps;
+    const int tap_lo = a.ksplit > 1 ? (int)blockIdx.z * ntaps_blk : 0;
+    const int niter = ntaps_blk * nchunks;
 
     // Tap table -> LDS once, behind the stages (a dynamic index into the by-value kernel argument compiles to
     // per-iteration global byte loads in front of the tile loads).  CDF_MAX_TAPS + 1 entries: reading one past the
@@ -662,7 +680,8 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
     // readers of a row now read it at the same time and the L2 fetches it once.
     int* tap_lds = (int*)(smem + NSTAGE * STAGE);
     if (tid <= CDF_MAX_TAPS) {
-        int src = tid;
+        int src = tid + tap_lo;
+        if (src > CDF_MAX_TAPS) src = CDF_MAX_TAPS;
         if (a.taprot && tid < 9) {
             const int slot = tid / 3, kx = tid - 3 * slot;
 #pragma unroll
@@ -959,7 +978,56 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
     CDF_WAIT_DMA_LEAVE(0);                                   // the tail fetches (never read) must not land in the epilogue tile
     CDF_LDS_BARRIER();
 
+    if (a.ksplit > 1) {
+        // raw partial sums of this tap share -> slab z (rows m, pitch ks_ld); bias / activation / residual ... run in the finish kernel
+        RawEpiArgs r;
+        r.Cout = a.Cout; r.vec = (a.Cout & 3) == 0 ? 1 : 0; r.os = 1; r.QH = 1; r.QW = 1; r.OH = 1; r.OW = 1; r.ldy = a.ks_ld;
+        r.ldp = r.ldm = r.ldr = r.ld_sbias = r.ld_ys = 0; r.act = 0; r.mul_mode = 0; r.accumulate = 0;
+        r.bias = nullptr; r.sbias = nullptr; r.pre = nullptr; r.mul = nullptr; r.res = nullptr; r.ys_hi = nullptr; r.ys_lo = nullptr;
+        constexpr int CP = BN + 8, TM = BM / WM, TN = BN / WN;
+        float* cs = (float*)smem_raw;
+        const int half_ = lane >> 5, l31_ = lane & 31;
+#pragma unroll
+        for (int i = 0; i < TM / 32; ++i)
+#pragma unroll
+            for (int j = 0; j < TN / 32; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr)
+                    cs[(wm * TM + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half_) * CP + wn * TN + j * 32 + l31_] = acc[i][j][rr];
+        __syncthreads();
+        cdf_epilogue_rows<BN, BM, 64 * WM * WN>(r, ph, a.ks_ws + (size_t)blockIdx.z * M * a.ks_ld, cs, tile_m * BM, tile_n * BN, M, tid,
+                                                [](int p) { return p; });
+        return;
+    }
     cdf_sp_epilogue<BM, BN, WM, WN>(a, ph, acc, (float*)smem_raw, tile_m, tile_n, M, tid);
+}
+
+// Finish of a split-K launch: y = epilogue(sum_z ws[z][m][:]) for 64 x BN tiles (the epilogue of the GEMM itself: bias, per-sample
+// bias, activation + pre-activation, gradient multiply, residual, accumulate, bf16 planes).  grid = (tiles), block 256.
+template <int BN>
+__global__ void __launch_bounds__(256) conv_splitk_finish_kernel(SpxArgs a) {
+    constexpr int BM = 64, CP = BN + 8;
+    __shared__ __attribute__((aligned(16))) float cs[BM * CP];
+    const int tid = threadIdx.x;
+    const int M = a.B * a.QH * a.QW;
+    const int tiles_n = (a.Cout + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    constexpr int V = BN / 4;                                // float4 per tile row
+    for (int e = tid; e < BM * V; e += 256) {
+        const int r = e / V, c4 = (e - r * V) * 4;
+        const int m = tile_m * BM + r, n = tile_n * BN + c4;
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M && n < a.ks_ld) {
+            const float* p = a.ks_ws + (size_t)m * a.ks_ld + n;
+            for (int z = 0; z < a.ksplit; ++z) {
+                const float4 v = *(const float4*)(p + (size_t)z * M * a.ks_ld);
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+        }
+        *(float4*)(cs + r * CP + c4) = sum;
+    }
+    __syncthreads();
+    cdf_epilogue_rows<BN, BM, 256>(a, a.ph[0], a.y, cs, tile_m * BM, tile_n * BN, M, tid, [](int p) { return p; });
 }
 
 // ================================================================================================
@@ -2459,7 +2527,11 @@ static int launch_igemm_spx(const SpxArgs& a, int M, hipStream_t s) {
     }
 #endif
     const int tiles = cdf_cdiv(M, BM) * cdf_cdiv(a.Cout, BN);
-    CDF_LAUNCH((conv_igemm_spx_kernel<BM, BN, WM, WN, NSTAGE, OCC, NS>), dim3(tiles, a.nphase), dim3(64 * WM * WN), lds, s, a);
+    CDF_LAUNCH((conv_igemm_spx_kernel<BM, BN, WM, WN, NSTAGE, OCC, NS>), dim3(tiles, a.nphase, a.ksplit > 1 ? a.ksplit : 1), dim3(64 * WM * WN), lds, s, a);
+    if (a.ksplit > 1) {                                      // (BM == 64 by construction: see dispatch_gemm_bf16x)
+        if (BN == 64) CDF_LAUNCH((conv_splitk_finish_kernel<64>), dim3(tiles), dim3(256), 0, s, a);
+        else CDF_LAUNCH((conv_splitk_finish_kernel<128>), dim3(tiles), dim3(256), 0, s, a);
+    }
     return cdf_check_launch("conv_igemm_spx");
 }
 
@@ -2527,8 +2599,28 @@ static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s) {
     return cdf_check_launch("conv_igemm_rowhalo");
 }
 
+// Split-K factor of the generic pre-split GEMM for grids far below one 64-row tile per CU: the smallest divisor of the tap count
+// that brings the launch to >= 192 blocks (else the largest); 1 = no split.
+static std::atomic<int> g_spx_ksplit{1};
+extern "C" int cdf_conv_gemm_bf16x_splitk(int enable) {      // tuning / test hook (process-wide)
+    g_spx_ksplit.store(enable ? 1 : 0);
+    return 0;
+}
+static int spx_ksplit(int M, int Cout, int nphase, int ntaps) {
+    if (!g_spx_ksplit.load() || !g_spx_deep.load() || nphase != 1 || (ntaps != 9 && ntaps != 16)) return 1;
+    const bool n64 = Cout <= 64;
+    const long long tiles128 = (long long)cdf_cdiv(M, 128) * cdf_cdiv(Cout, n64 ? 64 : 128);
+    const long long tiles64 = (long long)cdf_cdiv(M, 64) * cdf_cdiv(Cout, n64 ? 64 : 128);
+    if (tiles128 >= 384 || tiles64 > 128) return 1;
+    for (int ks = 2; ks <= ntaps; ++ks)
+        if (ntaps % ks == 0 && tiles64 * ks >= 192) return ks;
+    return ntaps;
+}
+extern "C" int cdf_conv_gemm_bf16x_ksplit(int M, int Cout, int nphase, int ntaps) { return spx_ksplit(M, Cout, nphase, ntaps); }
+
 template <int NS>
-static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cout, int QH, int QW, int os, int is, int nphase, hipStream_t s) {
+static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cout, int QH, int QW, int os, int is, int nphase, long long ks_ws_floats,
+                               hipStream_t s) {
     // Tile choice: 64-wide N for Cout <= 64 (no half-empty MFMA columns); 64-row M tiles when 128-row tiles would
     // leave most of the 256 CUs x 2 resident blocks idle (deep, small-image layers: M = 8192 at 16 x 16); the 8-wave
     // 256 x 128 tile (3 stages, one block per CU) when it still gives every CU at least ~2 tiles.
@@ -2593,6 +2685,16 @@ static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cou
     // of 1.5 us for 512 -> 1024 channels at 4 x 4 pixels).  Six stages, one block per CU: five chunks in flight per block.
     const long long tiles64 = (long long)cdf_cdiv(M, 64) * cdf_cdiv(Cout, n64 ? 64 : 128) * nphase;
     if (m64 && tiles64 <= 256 && g_spx_deep) {
+        // ... and when even that leaves most CUs without a block, the taps are shared out over blockIdx.z (split-K, partial sums through
+        // the caller's workspace, conv_splitk_finish_kernel adds them up and runs the epilogue)
+        const int ks = spx_ksplit(M, Cout, nphase, a.ph[0].ntaps);
+        if (ks > 1 && a.ks_ws && ks_ws_floats >= (long long)ks * M * ((Cout + 3) / 4 * 4)) {
+            a.ksplit = ks;
+            a.ks_ld = (Cout + 3) / 4 * 4;
+            a.taprot = 0;
+        } else {
+            a.ksplit = 1;
+        }
         if (n64) return launch_igemm_spx<NS, 64, 64, 2, 2, 6, 1>(a, M, s);
         return launch_igemm_spx<NS, 64, 128, 2, 2, 6, 1>(a, M, s);
     }
@@ -2607,8 +2709,9 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
                                    int ldk, float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW,
                                    int os, int is, int nphase, const int* phase_desc, const float* bias, const float* sbias,
                                    int ld_sbias, const float* res, int ldr, float* pre, int ldp, const float* mul, int ldm, int act,
-                                   int mul_mode, int accumulate, void* y_hi, void* y_lo, int ld_ys, void* stream) {
+                                   int mul_mode, int accumulate, void* y_hi, void* y_lo, int ld_ys, float* ws, long long ws_floats, void* stream) {
     CDF_REQUIRE(x_hi && zero && w_hi && (y || (y_hi && !accumulate)), "cdf_conv_gemm_bf16x: null pointer");
+    CDF_REQUIRE(!ws || (((uintptr_t)ws) & 15) == 0, "cdf_conv_gemm_bf16x: the split-K workspace must be 16-byte aligned");
     CDF_REQUIRE((x_lo != nullptr) == (w_lo != nullptr), "cdf_conv_gemm_bf16x: pass both lo planes (split precision, 3 MFMAs per product) or neither (single-pass bf16)");
     CDF_REQUIRE((!y_hi && !y_lo) || (y_hi && ld_ys % 4 == 0 && ld_ys >= Cout && Cout % 4 == 0 && ((((uintptr_t)y_hi) | ((uintptr_t)y_lo)) & 7) == 0),
                 "cdf_conv_gemm_bf16x: output planes need Cout %% 4 == 0, ld_ys %% 4 == 0, 8-byte alignment (y_lo optional: hi-only planes)");
@@ -2628,8 +2731,9 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
     CDF_REQUIRE(!y_hi || a.vec, "cdf_conv_gemm_bf16x: split output planes need the vectorised epilogue (aligned pointers, pitches %% 4)");
     int rc = fill_phases(a.ph, nphase, phase_desc, "cdf_conv_gemm_bf16x");
     if (rc) return rc;
-    return x_lo ? dispatch_gemm_bf16x<3>(a, B, H, W, Cin, Cout, QH, QW, os, is, nphase, CDF_S)
-                : dispatch_gemm_bf16x<1>(a, B, H, W, Cin, Cout, QH, QW, os, is, nphase, CDF_S);
+    a.ksplit = 1; a.ks_ws = ws; a.ks_ld = 0;
+    return x_lo ? dispatch_gemm_bf16x<3>(a, B, H, W, Cin, Cout, QH, QW, os, is, nphase, ws ? ws_floats : 0, CDF_S)
+                : dispatch_gemm_bf16x<1>(a, B, H, W, Cin, Cout, QH, QW, os, is, nphase, ws ? ws_floats : 0, CDF_S);
 }
 
 static std::atomic<int> g_wgrad_stack{1};                  // tuning / test hook (cdf_conv_wgrad_bf16x_stack)

@@ -162,11 +162,16 @@ int cdf_split_bf16(const float* x, int ldx, void* hi, void* lo, int ldo, long lo
 /* cdf_conv_gemm_bf16x: y_hi / y_lo (nullable, pitch ld_ys) additionally receive the stored output split into bf16 hi / lo planes,
  * i.e. cdf_split_bf16 fused into the producer (needs Cout % 4 == 0 and the aligned / pitched layout of the vector epilogue).
  * With the planes given, y itself may be NULL (no fp32 copy is written; not with accumulate).  Same for cdf_layernorm_c_fwd. */
+/* ws / ws_floats (nullable): workspace for split-K launches.  A grid far below one tile per CU (M = B*QH*QW of a few hundred pixels: the
+ * 4 x 4 / 8 x 8 levels of the 32 x 32 configurations) shares the taps out over ks = cdf_conv_gemm_bf16x_ksplit(M, Cout, nphase, ntaps of
+ * phase 0) block groups whose partial sums go through ws (>= ks * M * roundup4(Cout) floats, 16-byte aligned) and a finish kernel that
+ * runs the epilogue; without a (large enough) workspace, or when the query returns 1, the launch is the plain one.  The library never allocates. */
+int cdf_conv_gemm_bf16x_ksplit(int M, int Cout, int nphase, int ntaps);
 int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo, int ldk,
                         float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW, int os, int is,
                         int nphase, const int* phase_desc, const float* bias, const float* sbias, int ld_sbias, const float* res,
                         int ldr, float* pre, int ldp, const float* mul, int ldm, int act, int mul_mode, int accumulate,
-                        void* y_hi, void* y_lo, int ld_ys, void* stream);
+                        void* y_hi, void* y_lo, int ld_ys, float* ws, long long ws_floats, void* stream);
 /* RE-ENTRANCY.  Every compute entry point is a pure function of its arguments: no mutable process-wide state is read on the product
  * path.  The `tuning / test hook` setters below each store one std::atomic word that later launches read once (autograd runs the
  * backward launches on its own thread, so the knobs have to be process-wide to be usable at all); they only choose between kernels
@@ -190,6 +195,7 @@ int cdf_conv_gemm_bf16x_taprot(int enable);
  * wave of a SIMD feeds the matrix pipe while the other one reads LDS or issues global_load_lds.  Only the schedule depends on it. */
 int cdf_conv_gemm_bf16x_dephase(int enable);
 int cdf_conv_gemm_bf16x_deep(int enable);     /* 1 (default): grids of <= 256 64-row tiles run with six DMA stages, one block per CU */
+int cdf_conv_gemm_bf16x_splitk(int enable);   /* 1 (default): ... and share the taps out over block groups when a workspace is given (see cdf_conv_gemm_bf16x) */
 /* tuning / test hook: 3 x 3 stride-1 layers of cdf_conv_gemm_bf16x with the input tile (+ one-pixel halo) resident in LDS for
  * all nine taps.  enable: bit mask over the image width 16 (1), 32 (2), 64 (4), 128 (8), and 16 = at width 128 also for
  * layers with more than 64 output channels; 32 = the row-halo form (256-pixel tiles, input shared by the three dx taps of a row only)

@@ -93,7 +93,7 @@ def test_argument_checks_of_the_gemm_and_blend_entry_points():
             raise AssertionError("expected CdfError containing %r" % text)
 
     # pre-split GEMM: unaligned operand, channel count not a multiple of 8, split planes without the vectorised epilogue layout
-    gemm = [p, p, 8, p, p, p, 32, p, 8, 1, 4, 4, 8, 4, 4, 8, 4, 4, 1, 1, 1, desc, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]
+    gemm = [p, p, 8, p, p, p, 32, p, 8, 1, 4, 4, 8, 4, 4, 8, 4, 4, 1, 1, 1, desc, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]
     bad = list(gemm); bad[0] = p + 2
     expect(lib.cdf_conv_gemm_bf16x, bad, "16B aligned")
     bad = list(gemm); bad[12] = 6

@@ -789,7 +789,18 @@ def _spx_case(be, B, Cin, Cout, H, k, s, p):
         y = be.zeros(B, pl.OH, pl.OW, r4(Co))
         be.L.cdf_conv_gemm_bf16x(P(xsplit[0]), P(xsplit[1]), xsplit[0].shape[-1], P(zero), P(wpair[0]), P(wpair[1]), wpair[0].shape[-1], P(y),
                                  y.shape[-1], B, pl.H, pl.W, Ci, pl.OH, pl.OW, Co, pl.QH, pl.QW, pl.os, pl.istride, pl.nphase, pl.desc,
-                                 P(bias_), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, be.stream())
+                                 P(bias_), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, be.stream())
+        # small grids: the same launch with a split-K workspace (taps shared out over block groups + finish kernel)
+        Mq = B * pl.QH * pl.QW
+        ks = be.L.cdf_conv_gemm_bf16x_ksplit(Mq, Co, pl.nphase, pl.desc[2])
+        if ks > 1:
+            ws = be.empty(ks * Mq * r4(Co))
+            y_ws = be.zeros(B, pl.OH, pl.OW, r4(Co))
+            be.L.cdf_conv_gemm_bf16x(P(xsplit[0]), P(xsplit[1]), xsplit[0].shape[-1], P(zero), P(wpair[0]), P(wpair[1]), wpair[0].shape[-1], P(y_ws),
+                                     y_ws.shape[-1], B, pl.H, pl.W, Ci, pl.OH, pl.OW, Co, pl.QH, pl.QW, pl.os, pl.istride, pl.nphase, pl.desc,
+                                     P(bias_), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, P(ws), ks * Mq * r4(Co), be.stream())
+            assert err(y_ws[..., :Co], y[..., :Co].cpu()) <= 2e-6 * max(1.0, y.abs().max().item()) * math.sqrt(ks)
+            return y_ws
         return y
 
     y = run(plan, xs, wf, Cin, Cout, be.to(bias))
@@ -802,7 +813,7 @@ def _spx_case(be, B, Cin, Cout, H, k, s, p):
         y2 = be.zeros(B, plan.OH, plan.OW, r4(Cout))
         be.L.cdf_conv_gemm_bf16x(P(xs[0]), P(xs[1]), xs[0].shape[-1], P(zero), P(wf[0]), P(wf[1]), wf[0].shape[-1], P(y2), y2.shape[-1], B,
                                  plan.H, plan.W, Cin, plan.OH, plan.OW, Cout, plan.QH, plan.QW, plan.os, plan.istride, plan.nphase,
-                                 plan.desc, P(be.to(bias)), 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, P(yh), P(yl), ld8, be.stream())
+                                 plan.desc, P(be.to(bias)), 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, P(yh), P(yl), ld8, 0, 0, be.stream())
         rh, rl = _split(be, y2[..., :Cout].contiguous(), single)
         assert torch.equal(yh.cpu(), rh.cpu()) and (single or torch.equal(yl.cpu(), rl.cpu()))
     M = B * wg.QH * wg.QW

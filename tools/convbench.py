@@ -95,12 +95,12 @@ if os.environ.get("KB_SPX", "1") == "1":
         xs = split(x); gs = split(gy)
         p = cd.conv_fwd(H,H,k,k,1,k//2,k//2,k//2,k//2)
         fl = 2.0*B*H*H*Cin*Cout*k*k
-        ms = timeit(lambda: L.cdf_conv_gemm_bf16x(P(xs[0]),P(xs[1]),Cin,P(zero),P(hi),P(lo),ldk,P(y),y.shape[-1],B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,S()))
+        ms = timeit(lambda: L.cdf_conv_gemm_bf16x(P(xs[0]),P(xs[1]),Cin,P(zero),P(hi),P(lo),ldk,P(y),y.shape[-1],B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,S()))
         print(f"spx   {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv", flush=True)
         if os.environ.get("KB_EPI", "1") == "1":      # the ConvNeXt conv1 form: bias + GELU, pre-activation kept, output as bf16 planes only
             bias = torch.randn(Cout, device=dev); pre = torch.empty(B,H,H,Cout,device=dev)
             yh = torch.empty(B,H,H,Cout,dtype=torch.int16,device=dev); yl = None if SINGLE else torch.empty_like(yh)
-            ms = timeit(lambda: L.cdf_conv_gemm_bf16x(P(xs[0]),P(xs[1]),Cin,P(zero),P(hi),P(lo),ldk,0,Cout,B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,P(bias),0,0,0,0,P(pre),Cout,0,0,1,0,0,P(yh),P(yl),Cout,S()))
+            ms = timeit(lambda: L.cdf_conv_gemm_bf16x(P(xs[0]),P(xs[1]),Cin,P(zero),P(hi),P(lo),ldk,0,Cout,B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,P(bias),0,0,0,0,P(pre),Cout,0,0,1,0,0,P(yh),P(yl),Cout,0,0,S()))
             print(f"spxG  {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv (bias+GELU, pre + planes out)", flush=True)
         wg = cd.conv_wgrad(H,H,k,k,1,k//2,k//2,k//2,k//2); M=B*H*H
         row3 = L.cdf_conv_wgrad_bf16x_is_row3(H, H, Cin, Cout, k*k, 1 if k == 3 else 0)
