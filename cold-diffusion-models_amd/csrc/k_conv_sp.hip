@@ -1002,29 +1002,32 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
     cdf_sp_epilogue<BM, BN, WM, WN>(a, ph, acc, (float*)smem_raw, tile_m, tile_n, M, tid);
 }
 
-// Finish of a split-K launch: y = epilogue(sum_z ws[z][m][:]) for 64 x BN tiles (the epilogue of the GEMM itself: bias, per-sample
-// bias, activation + pre-activation, gradient multiply, residual, accumulate, bf16 planes).  grid = (tiles), block 256.
+// Finish of a split-K launch: y = epilogue(sum_z ws[z][m][:]) for 16 x BN tiles (the epilogue of the GEMM itself: bias, per-sample
+// bias, activation + pre-activation, gradient multiply, residual, accumulate, bf16 planes).  Small tiles and all slab loads of an
+// element in flight at once: the tensors are a few hundred pixels, the kernel is pure latency.  grid = (row tiles x column tiles), block 256.
 template <int BN>
 __global__ void __launch_bounds__(256) conv_splitk_finish_kernel(SpxArgs a) {
-    constexpr int BM = 64, CP = BN + 8;
+    constexpr int BM = 16, CP = BN + 8;
     __shared__ __attribute__((aligned(16))) float cs[BM * CP];
     const int tid = threadIdx.x;
     const int M = a.B * a.QH * a.QW;
     const int tiles_n = (a.Cout + BN - 1) / BN;
     const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
     constexpr int V = BN / 4;                                // float4 per tile row
+    const size_t zs = (size_t)M * a.ks_ld;
     for (int e = tid; e < BM * V; e += 256) {
         const int r = e / V, c4 = (e - r * V) * 4;
         const int m = tile_m * BM + r, n = tile_n * BN + c4;
+        const bool ok = m < M && n < a.ks_ld;
+        const float* p = a.ks_ws + (ok ? (size_t)m * a.ks_ld + n : 0);
+        float4 v[CDF_MAX_TAPS];
+#pragma unroll
+        for (int z = 0; z < CDF_MAX_TAPS; ++z) v[z] = *(const float4*)(p + (z < a.ksplit ? z : 0) * zs);      // unconditional, clamped
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < M && n < a.ks_ld) {
-            const float* p = a.ks_ws + (size_t)m * a.ks_ld + n;
-            for (int z = 0; z < a.ksplit; ++z) {
-                const float4 v = *(const float4*)(p + (size_t)z * M * a.ks_ld);
-                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-            }
-        }
-        *(float4*)(cs + r * CP + c4) = sum;
+#pragma unroll
+        for (int z = 0; z < CDF_MAX_TAPS; ++z)
+            if (z < a.ksplit) { sum.x += v[z].x; sum.y += v[z].y; sum.z += v[z].z; sum.w += v[z].w; }
+        *(float4*)(cs + r * CP + c4) = ok ? sum : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     cdf_epilogue_rows<BN, BM, 256>(a, a.ph[0], a.y, cs, tile_m * BM, tile_n * BN, M, tid, [](int p) { return p; });
@@ -2528,9 +2531,10 @@ static int launch_igemm_spx(const SpxArgs& a, int M, hipStream_t s) {
 #endif
     const int tiles = cdf_cdiv(M, BM) * cdf_cdiv(a.Cout, BN);
     CDF_LAUNCH((conv_igemm_spx_kernel<BM, BN, WM, WN, NSTAGE, OCC, NS>), dim3(tiles, a.nphase, a.ksplit > 1 ? a.ksplit : 1), dim3(64 * WM * WN), lds, s, a);
-    if (a.ksplit > 1) {                                      // (BM == 64 by construction: see dispatch_gemm_bf16x)
-        if (BN == 64) CDF_LAUNCH((conv_splitk_finish_kernel<64>), dim3(tiles), dim3(256), 0, s, a);
-        else CDF_LAUNCH((conv_splitk_finish_kernel<128>), dim3(tiles), dim3(256), 0, s, a);
+    if (a.ksplit > 1) {
+        const int ftiles = cdf_cdiv(M, 16) * cdf_cdiv(a.Cout, BN);
+        if (BN == 64) CDF_LAUNCH((conv_splitk_finish_kernel<64>), dim3(ftiles), dim3(256), 0, s, a);
+        else CDF_LAUNCH((conv_splitk_finish_kernel<128>), dim3(ftiles), dim3(256), 0, s, a);
     }
     return cdf_check_launch("conv_igemm_spx");
 }
