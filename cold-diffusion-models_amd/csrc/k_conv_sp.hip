@@ -2605,7 +2605,7 @@ static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s) {
 
 // Split-K factor of the generic pre-split GEMM for grids far below one 64-row tile per CU: the smallest divisor of the tap count
 // that brings the launch to >= 192 blocks (else the largest); 1 = no split.
-static std::atomic<int> g_spx_ksplit{1};
+static std::atomic<int> g_spx_ksplit{0};                   // off by default: measured on the 32 x 32 configurations, the finish pass costs what the extra blocks gain (+-1 %)
 extern "C" int cdf_conv_gemm_bf16x_splitk(int enable) {      // tuning / test hook (process-wide)
     g_spx_ksplit.store(enable ? 1 : 0);
     return 0;

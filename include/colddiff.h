@@ -165,7 +165,8 @@ int cdf_split_bf16(const float* x, int ldx, void* hi, void* lo, int ldo, long lo
 /* ws / ws_floats (nullable): workspace for split-K launches.  A grid far below one tile per CU (M = B*QH*QW of a few hundred pixels: the
  * 4 x 4 / 8 x 8 levels of the 32 x 32 configurations) shares the taps out over ks = cdf_conv_gemm_bf16x_ksplit(M, Cout, nphase, ntaps of
  * phase 0) block groups whose partial sums go through ws (>= ks * M * roundup4(Cout) floats, 16-byte aligned) and a finish kernel that
- * runs the epilogue; without a (large enough) workspace, or when the query returns 1, the launch is the plain one.  The library never allocates. */
+ * runs the epilogue; without a (large enough) workspace, or when the query returns 1 (always, unless cdf_conv_gemm_bf16x_splitk(1) was called: the
+ * split is off by default), the launch is the plain one.  The library never allocates. */
 int cdf_conv_gemm_bf16x_ksplit(int M, int Cout, int nphase, int ntaps);
 int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo, int ldk,
                         float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW, int os, int is,
@@ -195,7 +196,7 @@ int cdf_conv_gemm_bf16x_taprot(int enable);
  * wave of a SIMD feeds the matrix pipe while the other one reads LDS or issues global_load_lds.  Only the schedule depends on it. */
 int cdf_conv_gemm_bf16x_dephase(int enable);
 int cdf_conv_gemm_bf16x_deep(int enable);     /* 1 (default): grids of <= 256 64-row tiles run with six DMA stages, one block per CU */
-int cdf_conv_gemm_bf16x_splitk(int enable);   /* 1 (default): ... and share the taps out over block groups when a workspace is given (see cdf_conv_gemm_bf16x) */
+int cdf_conv_gemm_bf16x_splitk(int enable);   /* 1: ... and share the taps out over block groups when a workspace is given (see cdf_conv_gemm_bf16x); default 0: measured +-1 % on the 32 x 32 configurations */
 /* tuning / test hook: 3 x 3 stride-1 layers of cdf_conv_gemm_bf16x with the input tile (+ one-pixel halo) resident in LDS for
  * all nine taps.  enable: bit mask over the image width 16 (1), 32 (2), 64 (4), 128 (8), and 16 = at width 128 also for
  * layers with more than 64 output channels; 32 = the row-halo form (256-pixel tiles, input shared by the three dx taps of a row only)

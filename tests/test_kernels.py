@@ -792,15 +792,19 @@ def _spx_case(be, B, Cin, Cout, H, k, s, p):
                                  P(bias_), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, be.stream())
         # small grids: the same launch with a split-K workspace (taps shared out over block groups + finish kernel)
         Mq = B * pl.QH * pl.QW
-        ks = be.L.cdf_conv_gemm_bf16x_ksplit(Mq, Co, pl.nphase, pl.desc[2])
-        if ks > 1:
-            ws = be.empty(ks * Mq * r4(Co))
-            y_ws = be.zeros(B, pl.OH, pl.OW, r4(Co))
-            be.L.cdf_conv_gemm_bf16x(P(xsplit[0]), P(xsplit[1]), xsplit[0].shape[-1], P(zero), P(wpair[0]), P(wpair[1]), wpair[0].shape[-1], P(y_ws),
-                                     y_ws.shape[-1], B, pl.H, pl.W, Ci, pl.OH, pl.OW, Co, pl.QH, pl.QW, pl.os, pl.istride, pl.nphase, pl.desc,
-                                     P(bias_), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, P(ws), ks * Mq * r4(Co), be.stream())
-            assert err(y_ws[..., :Co], y[..., :Co].cpu()) <= 2e-6 * max(1.0, y.abs().max().item()) * math.sqrt(ks)
-            return y_ws
+        try:
+            be.L.cdf_conv_gemm_bf16x_splitk(1)                # (off by default)
+            ks = be.L.cdf_conv_gemm_bf16x_ksplit(Mq, Co, pl.nphase, pl.desc[2])
+            if ks > 1:
+                ws = be.empty(ks * Mq * r4(Co))
+                y_ws = be.zeros(B, pl.OH, pl.OW, r4(Co))
+                be.L.cdf_conv_gemm_bf16x(P(xsplit[0]), P(xsplit[1]), xsplit[0].shape[-1], P(zero), P(wpair[0]), P(wpair[1]), wpair[0].shape[-1],
+                                         P(y_ws), y_ws.shape[-1], B, pl.H, pl.W, Ci, pl.OH, pl.OW, Co, pl.QH, pl.QW, pl.os, pl.istride, pl.nphase,
+                                         pl.desc, P(bias_), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, P(ws), ks * Mq * r4(Co), be.stream())
+                assert err(y_ws[..., :Co], y[..., :Co].cpu()) <= 2e-6 * max(1.0, y.abs().max().item()) * math.sqrt(ks)
+                return y_ws
+        finally:
+            be.L.cdf_conv_gemm_bf16x_splitk(0)
         return y
 
     y = run(plan, xs, wf, Cin, Cout, be.to(bias))
