@@ -429,14 +429,17 @@ def kv_forward(xn, dim, w_qkv):
 
 
 def kv_backward(xn, dim, dkv, w_qkv, dxn):
-    """dxn += dkv . Wkv;  rows HD .. 3 HD of to_qkv.weight.grad += dkv^T xn."""
+    """rows HD .. 3 HD of to_qkv.weight.grad += dkv^T xn;  dxn += dkv . Wkv (dxn None: the data gradient was taken elsewhere)."""
     HD = w_qkv.shape[0] // 3
     _, pd, pw = _conv_plans("conv", xn.shape[1], xn.shape[2], 1, 1, (0, 0, 0, 0))
     ops.wgrad_into(ops.grad_of(w_qkv)[HD:], pw, xn, dim, dkv, 2 * HD, 1, 1, dim)
+    if dxn is None:
+        return None
     return ops.conv_gemm(pd, dkv, 2 * HD, ops.packed(w_qkv, "kv_dgrad" + _sp_suffix(2 * HD, dim)), dim, y=dxn, accumulate=1)
 
 
 _ATTN_QFOLD = os.environ.get("CDF_ATTN_QFOLD", "1") != "0"   # q projection folded into the attention product too (dim <= heads*32)
+_ATTN_KVDG = os.environ.get("CDF_ATTN_KVDG", "1") != "0"     # k | v backward with its data gradient in one kernel (ops.linattn_bwd_kv_dgrad)
 _ATTN_KVCTX = os.environ.get("CDF_ATTN_KVCTX", "1") != "0"   # ... with the k|v projection and the context in one kernel (ops.linattn_kvctx)
 
 
@@ -488,8 +491,13 @@ class LinAttnBlockFn(torch.autograd.Function):
             dxn, dctx, rvec = ops.linattn_fold_bwd(xn, dy, Mb, Nb, cx, cxs, att.to_qkv.weight, att.to_out.weight, att.to_out.bias,
                                                    att.heads, att.scale)
             dkv = torch.empty(kv.shape, device=kv.device, dtype=torch.float32)
-            ops.linattn_bwd_core(kv, dctx, rvec, kmax, ksum, dkv, att.heads, koff=0)
-            kv_backward(xn, dim, dkv, att.to_qkv.weight, dxn)
+            if _ATTN_KVDG and ops.linattn_bwd_kv_dgrad_ok(kv, dim, att.heads):
+                # dk | dv and their data gradient in one pass; only the weight gradient reads dk | dv back
+                ops.linattn_bwd_kv_dgrad(kv, dctx, rvec, kmax, ksum, dkv, att.to_qkv.weight, dxn, dim, att.heads)
+                kv_backward(xn, dim, dkv, att.to_qkv.weight, None)
+            else:
+                ops.linattn_bwd_core(kv, dctx, rvec, kmax, ksum, dkv, att.heads, koff=0)
+                kv_backward(xn, dim, dkv, att.to_qkv.weight, dxn)
             dx = ops.layernorm_bwd(dxn, x, norm.g, norm.b, mean, rstd, add=dy)     # + the residual branch, same pass
             _done(ctx)
             return None, dx, None, None

@@ -740,6 +740,21 @@ def linattn_fold_bwd(xn, dy, Mb, Nb, ctx, ctxs, w_qkv, w_out, b_out, heads, scal
     return dxn, dctx, rvec
 
 
+def linattn_bwd_kv_dgrad_ok(kv, dim, heads):
+    return rt.precision != "f32" and heads == 4 and dim in (64, 128) and kv.shape[-1] == 256 and kv.device.type != "meta"
+
+
+def linattn_bwd_kv_dgrad(kv, dctx, rvec, kmax, ksum, dkv, w_qkv, dxn, dim, heads):
+    """dk | dv of a (k|v) tensor into dkv AND dxn += dkv . Wkv in the same pass (k_conv_sp.hip: linattn_bwd_kv_dg_kernel): the data
+    gradient of the k | v projection never reads dk | dv back."""
+    L = rt.lib()
+    B, H, W, _ = kv.shape
+    wd = packed(w_qkv, "kv_dgrad_sp")                         # (hi, lo | None) planes [1][dim][256]: K = the k|v channels, contiguous
+    L.cdf_linattn_bwd_kv_dgrad(P(kv), ld_of(kv), P(dctx), P(rvec), P(kmax), P(ksum), P(dkv), ld_of(dkv), P(wd[0]), P(wd[1]), wd[0].shape[-1],
+                               P(dxn), ld_of(dxn), B, H * W, dim, heads, rt.stream(kv))
+    return dkv
+
+
 def linattn_bwd_core(qkv, dctx, rvec, kmax, ksum, dqkv, heads, koff=None):
     """The softmax / v part of the attention backward given dctx and rvec (dq is already in dqkv).  koff: channel offset of k | v in
     qkv's rows and of dk | dv in dqkv's (default heads*32; 0: both are (k|v) tensors, fused kernel only)."""

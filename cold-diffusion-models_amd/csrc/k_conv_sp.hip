@@ -2286,6 +2286,160 @@ __global__ void __launch_bounds__(512, 1) linattn_kvctx_kernel(KvCtxArgs a) {
     if (ctx_wave && half == 0) a.max_part[pb * HD + ch * LD + l31] = m_run;
 }
 
+// ================================================================================================
+// LinearAttention backward, k | v gradient + its DATA gradient in one pass (round 2).
+//
+// linattn_bwd_kv_kernel (k_attn.hip) writes dk | dv ([B,n,256]) and the data gradient dxn += dkv . Wkv then reads all of it back
+// (537 MB per micro-batch at 128 x 128).  Here the block that produces a 32-pixel tile of dk | dv (one wave per head, exactly as in
+// that kernel: P recomputed, dP = v dctx^T and dv = P dctx on the fp32 matrix cores) also multiplies it with the 256 x dim weight
+// while it sits in LDS: per wave a [32 px x 64 ch] x [64 ch x dim] product in split precision (fragments split while they are read
+// from the fp32 tiles, weight fragments from the L1-resident bf16 hi / lo planes), the four heads' partial products are folded
+// through LDS and added to dxn (which already holds dy . N_b^T).  dk | dv still go to memory once: the weight gradient needs them.
+// NTN = dim / 32.  grid = (ceil(n / (32 TILES)), B), block = 256 (4 heads).
+// ================================================================================================
+#define KVB_D 32
+#define KVB_TP 36
+#define KVB_TILES 8
+template <int SPLIT, int NTN>
+__global__ void __launch_bounds__(256) linattn_bwd_kv_dg_kernel(const float* kv, int ld, const float* dctx, const float* rvec, const float* kmax,
+                                                               const float* ksum, float* dkv, int lddq, const unsigned short* w_hi,
+                                                               const unsigned short* w_lo, int ldk, float* dxn, int lddx, int n) {
+    constexpr int HD = 128, DIM = NTN * 32;
+    CDF_DYN_SMEM(smem_raw);
+    const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, b = blockIdx.y;
+    float* sp = (float*)smem_raw + (size_t)h * 4 * KVB_D * KVB_TP;         // this wave's P tile
+    float* sv = sp + KVB_D * KVB_TP;                                       // V tile
+    float* sk = sv + KVB_D * KVB_TP;                                       // dk tile
+    float* so = sk + KVB_D * KVB_TP;                                       // dv tile
+    float* part = sp;                                                      // [32][DIM] partial product of this head (aliases its four tiles)
+    const int i = lane & 31, hh = lane >> 5;
+    const int lr = lane >> 3, lc = (lane & 7) * 4;
+    const float* dc = dctx + ((size_t)b * 4 + h) * KVB_D * KVB_D;
+    float B1[16], B2[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        B1[s] = dc[i * KVB_D + 2 * s + hh];
+        B2[s] = dc[(2 * s + hh) * KVB_D + i];
+    }
+    const float rv = rvec[(size_t)b * HD + h * KVB_D + i];
+    const float4 km = *(const float4*)(kmax + (size_t)b * HD + h * KVB_D + lc);
+    const float4 ks = *(const float4*)(ksum + (size_t)b * HD + h * KVB_D + lc);
+    const float4 ri = make_float4(1.0f / ks.x, 1.0f / ks.y, 1.0f / ks.z, 1.0f / ks.w);
+    const float* kbase = kv + (size_t)b * n * ld + h * KVB_D + lc;
+    const float* vbase = kbase + HD;
+    float* dkbase = dkv + (size_t)b * n * lddq + h * KVB_D + lc;
+    float* dvbase = dkbase + HD;
+    float* dxb = dxn + (size_t)b * n * lddx;
+    const int p_begin = blockIdx.x * (KVB_D * KVB_TILES);
+    for (int t = 0; t < KVB_TILES; ++t) {
+        const int p0 = p_begin + t * KVB_D;
+        if (p0 >= n) break;                                                // (block-uniform)
+        float4 kq[4], vq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = p0 + lr + 8 * q;
+            const int pc = p < n ? p : n - 1;
+            kq[q] = *(const float4*)(kbase + (size_t)pc * ld);
+            vq[q] = *(const float4*)(vbase + (size_t)pc * ld);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool ok = p0 + lr + 8 * q < n;
+            float4 pn = make_float4(expf(kq[q].x - km.x) * ri.x, expf(kq[q].y - km.y) * ri.y, expf(kq[q].z - km.z) * ri.z, expf(kq[q].w - km.w) * ri.w);
+            if (!ok) { pn = make_float4(0.f, 0.f, 0.f, 0.f); vq[q] = pn; }
+            *(float4*)(sp + (lr + 8 * q) * KVB_TP + lc) = pn;
+            *(float4*)(sv + (lr + 8 * q) * KVB_TP + lc) = vq[q];
+        }
+        CDF_WAVE_SYNC();
+        // ---- dP = V dctx^T ; dk = P (dP - rvec)
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[i * KVB_TP + 2 * s + hh], B1[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int px = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            sk[px * KVB_TP + i] = sp[px * KVB_TP + i] * (acc[r] - rv);
+        }
+        // ---- dv = P dctx
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sp[i * KVB_TP + 2 * s + hh], B2[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) so[((r & 3) + 8 * (r >> 2) + 4 * hh) * KVB_TP + i] = acc[r];
+        CDF_WAVE_SYNC();
+        // ---- dk | dv rows out (the weight gradient reads them)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = p0 + lr + 8 * q;
+            if (p < n) {
+                *(float4*)(dkbase + (size_t)p * lddq) = *(const float4*)(sk + (lr + 8 * q) * KVB_TP + lc);
+                *(float4*)(dvbase + (size_t)p * lddq) = *(const float4*)(so + (lr + 8 * q) * KVB_TP + lc);
+            }
+        }
+        // ---- this head's share of dxn: [32 px] x [K = 64: dk (32) | dv (32)] x [dim], split precision
+        f32x16_t gacc[NTN];
+#pragma unroll
+        for (int j = 0; j < NTN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gacc[j][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                                      // 16 channels per step
+            const float* at = (s < 2 ? sk : so) + i * KVB_TP + (s & 1) * 16 + hh * 8;          // pixel i, 8 channels
+            const float4 a0 = *(const float4*)at, a1 = *(const float4*)(at + 4);
+            uint2 h0, l0, h1, l1;
+            if (SPLIT > 1) {
+                cdf_split4_trunc(a0, h0, l0);
+                cdf_split4_trunc(a1, h1, l1);
+            } else {
+                h0.x = cdf_f2bf(a0.x) | (cdf_f2bf(a0.y) << 16); h0.y = cdf_f2bf(a0.z) | (cdf_f2bf(a0.w) << 16);
+                h1.x = cdf_f2bf(a1.x) | (cdf_f2bf(a1.y) << 16); h1.y = cdf_f2bf(a1.z) | (cdf_f2bf(a1.w) << 16);
+                l0 = h0; l1 = h1;
+            }
+            const u32x4_v ahu = u32x4_v{h0.x, h0.y, h1.x, h1.y}, alu = u32x4_v{l0.x, l0.y, l1.x, l1.y};
+            const bf16x8_v ah = __builtin_bit_cast(bf16x8_v, ahu), al = __builtin_bit_cast(bf16x8_v, alu);
+            const int kcol = (s < 2 ? 0 : HD) + h * KVB_D + (s & 1) * 16 + hh * 8;               // channel of the 256-wide K index
+#pragma unroll
+            for (int j = 0; j < NTN; ++j) {
+                const size_t woff = (size_t)(j * 32 + i) * ldk + kcol;
+                const bf16x8_v bh = __builtin_bit_cast(bf16x8_v, *(const u32x4_v*)(w_hi + woff));
+                if (SPLIT > 1) {
+                    const bf16x8_v bl = __builtin_bit_cast(bf16x8_v, *(const u32x4_v*)(w_lo + woff));
+                    gacc[j] = CDF_MFMA_BF16(al, bh, gacc[j]);
+                    gacc[j] = CDF_MFMA_BF16(ah, bl, gacc[j]);
+                }
+                gacc[j] = CDF_MFMA_BF16(ah, bh, gacc[j]);
+            }
+        }
+        CDF_WAVE_SYNC();                                                   // this wave's tile reads are done: the tiles become its partial
+#pragma unroll
+        for (int j = 0; j < NTN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[((r & 3) + 8 * (r >> 2) + 4 * hh) * DIM + j * 32 + i] = gacc[j][r];
+        __syncthreads();
+        // ---- dxn[p0 + px][:] += sum over the four heads
+        {
+            const float* p0f = (const float*)smem_raw;
+            constexpr int WSTR = 4 * KVB_D * KVB_TP;                       // floats between two waves' regions
+            for (int e = threadIdx.x; e < 32 * DIM / 4; e += 256) {
+                const int px = e / (DIM / 4), c4 = (e - px * (DIM / 4)) * 4;
+                if (p0 + px < n) {
+                    const float4 v0 = *(const float4*)(p0f + px * DIM + c4), v1 = *(const float4*)(p0f + WSTR + px * DIM + c4);
+                    const float4 v2 = *(const float4*)(p0f + 2 * WSTR + px * DIM + c4), v3 = *(const float4*)(p0f + 3 * WSTR + px * DIM + c4);
+                    float4* dst = (float4*)(dxb + (size_t)(p0 + px) * lddx + c4);
+                    float4 o = *dst;
+                    o.x += (v0.x + v1.x) + (v2.x + v3.x); o.y += (v0.y + v1.y) + (v2.y + v3.y);
+                    o.z += (v0.z + v1.z) + (v2.z + v3.z); o.w += (v0.w + v1.w) + (v2.w + v3.w);
+                    *dst = o;
+                }
+            }
+        }
+        __syncthreads();                                                   // the tiles are rewritten by the next trip
+    }
+}
+
 // dst_hi/lo[t][r][c] (c < ldc, zero padded) = split(src[c*s_c + r*s_r + t*s_t])
 __global__ void pack_weight_bf16_kernel(const float* src, unsigned short* dst_hi, unsigned short* dst_lo, int T, int R, int C,
                                         int ldc, long long s_t, long long s_r, long long s_c) {
@@ -2353,6 +2507,36 @@ extern "C" int cdf_linattn_kvctx(const float* xn, int ldx, const void* w_hi, con
         else CDF_LAUNCH((linattn_kvctx_kernel<1, 32>), dim3(P, B), dim3(512), lds, CDF_S, a);
     }
     return cdf_check_launch("linattn_kvctx");
+}
+
+extern "C" int cdf_linattn_bwd_kv_dgrad(const float* kv, int ld, const float* dctx, const float* rvec, const float* kmax, const float* ksum,
+                                        float* dkv, int lddq, const void* w_hi, const void* w_lo, int ldk, float* dxn, int lddx, int B, int n,
+                                        int dim, int heads, void* stream) {
+    CDF_REQUIRE(kv && dctx && rvec && kmax && ksum && dkv && w_hi && dxn && B > 0 && n > 0, "cdf_linattn_bwd_kv_dgrad: null pointer");
+    CDF_REQUIRE(heads == 4 && (dim == 64 || dim == 128), "cdf_linattn_bwd_kv_dgrad: 4 heads, dim 64 or 128; got heads=%d dim=%d", heads, dim);
+    CDF_REQUIRE(ld % 4 == 0 && lddq % 4 == 0 && lddx % 4 == 0 && ld >= 256 && lddq >= 256 && lddx >= dim && ldk % 8 == 0 && ldk >= 256 &&
+                ((((uintptr_t)kv) | ((uintptr_t)dkv) | ((uintptr_t)kmax) | ((uintptr_t)ksum) | ((uintptr_t)w_hi) | ((uintptr_t)w_lo) | ((uintptr_t)dxn)) & 15) == 0,
+                "cdf_linattn_bwd_kv_dgrad: (k|v) rows of >= 256 floats, pitches %% 4 (weights %% 8, K = 256 contiguous), 16-byte alignment");
+    const size_t lds = (size_t)4 * 4 * KVB_D * KVB_TP * sizeof(float);     // 4 heads x (P, V, dk, dv) tiles; a head's [32][dim] partial fits its four tiles
+    static_assert(4 * KVB_D * KVB_TP >= 32 * 128, "the per-head partial aliases the head's tiles");
+    const dim3 grid(cdf_cdiv(n, KVB_D * KVB_TILES), B);
+#ifndef CDF_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)linattn_bwd_kv_dg_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)linattn_bwd_kv_dg_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)linattn_bwd_kv_dg_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)linattn_bwd_kv_dg_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+#endif
+#define CDF_KVDG(SP, NT)                                                                                                              \
+    CDF_LAUNCH((linattn_bwd_kv_dg_kernel<SP, NT>), grid, dim3(256), lds, CDF_S, kv, ld, dctx, rvec, kmax, ksum, dkv, lddq,            \
+               (const unsigned short*)w_hi, (const unsigned short*)w_lo, ldk, dxn, lddx, n)
+    if (w_lo) { if (dim == 64) CDF_KVDG(3, 2); else CDF_KVDG(3, 4); }
+    else { if (dim == 64) CDF_KVDG(1, 2); else CDF_KVDG(1, 4); }
+#undef CDF_KVDG
+    return cdf_check_launch("linattn_bwd_kv_dgrad");
 }
 
 extern "C" int cdf_pack_weight_bf16(const float* src, void* dst_hi, void* dst_lo, int T, int R, int C, int ldc, long long s_t,

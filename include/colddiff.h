@@ -331,6 +331,13 @@ int cdf_linattn_kvctx(const float* xn, int ldx, const void* w_hi, const void* w_
                       int dim, int heads, void* stream);
 int cdf_linattn_finalize(const float* ws, int nparts, float* ctx, float* ctxs, float* kmax, float* ksum, int B, int heads, float scale,
                          void* stream);
+/* cdf_linattn_bwd_kv_dgrad (round 2): cdf_linattn_bwd_kv on a (k|v) tensor (koff = dkoff = 0) AND the data gradient of the k | v projection
+ * in the same pass: dxn[b,n,:dim] += dkv[b,n,:] . Wkv, with Wkv as bf16 hi [/ lo] planes [dim][ldk >= 256] (K = the 256 k|v channels contiguous:
+ * the "data gradient" packing of the projection; w_lo == NULL: single bf16 operands).  dk | dv are still written (the weight gradient reads
+ * them) but not read back.  4 heads, dim 64 or 128. */
+int cdf_linattn_bwd_kv_dgrad(const float* kv, int ld, const float* dctx, const float* rvec, const float* kmax, const float* ksum, float* dkv,
+                             int lddq, const void* w_hi, const void* w_lo, int ldk, float* dxn, int lddx, int B, int n, int dim, int heads,
+                             void* stream);
 int cdf_linattn_dcontext(const float* qkv, int ld, const float* dout, int lddo, const float* ctx, float* dctx,
                          float* rvec, float* ws, int B, int n, int heads, float scale, void* stream);
 int cdf_linattn_softk(const float* qkv, int ld, const float* kmax, const float* ksum, float* pn, int ldp, int B, int n,

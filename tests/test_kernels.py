@@ -577,6 +577,37 @@ def test_linattn_kvctx_fused(be, B, n, dim, slots, split):
     assert err(ctxs, ctx_ref * scale) <= 2e-5 * max(1.0, ctx_ref.abs().max().item())
 
 
+@pytest.mark.parametrize("B,n,dim,split", [(2, 300, 64, 3), (1, 256, 128, 3), (1, 70, 64, 1)])
+def test_linattn_bwd_kv_dgrad_fused(be, B, n, dim, split):
+    """cdf_linattn_bwd_kv_dgrad = cdf_linattn_bwd_kv on a (k|v) tensor + dxn += dkv . Wkv in one pass: dk | dv bit-equal to the separate
+    kernel, dxn against the fp64 product (split-precision tolerance), ragged pixel counts, both weight widths, accumulation onto dxn."""
+    torch.manual_seed(n + dim)
+    heads, HD = 4, 128
+    kv = torch.randn(B, n, 2 * HD)
+    k = kv[..., :HD]
+    kmax = k.max(1).values
+    ksum = torch.exp(k - kmax[:, None]).sum(1)
+    dctx = torch.randn(B, heads, 32, 32) * 0.3
+    ctx = torch.randn(B, heads, 32, 32)
+    rvec = (dctx * ctx).sum(-1).reshape(B, HD)
+    w = torch.randn(3 * HD, dim) / math.sqrt(dim)
+    dxn0 = torch.randn(B, n, dim)
+    kvd, dctxd, rvd, kmd, ksd = be.to(kv), be.to(dctx), be.to(rvec), be.to(kmax), be.to(ksum)
+    ref = be.zeros(B, n, 2 * HD)
+    be.L.cdf_linattn_bwd_kv(P(kvd), 2 * HD, 0, P(dctxd), P(rvd), P(kmd), P(ksd), P(ref), 2 * HD, 0, B, n, heads, be.stream())
+    whi = torch.zeros(1, dim, 256, dtype=torch.int16, device=be.device)
+    wlo = torch.zeros_like(whi) if split == 3 else None
+    wd = be.to(w)
+    be.L.cdf_pack_weight_bf16(P(wd) + 4 * HD * dim, P(whi), P(wlo), 1, dim, 2 * HD, 256, 1, 1, dim, be.stream())
+    dkv, dxn = be.zeros(B, n, 2 * HD), be.to(dxn0)
+    be.L.cdf_linattn_bwd_kv_dgrad(P(kvd), 2 * HD, P(dctxd), P(rvd), P(kmd), P(ksd), P(dkv), 2 * HD, P(whi), P(wlo), 256, P(dxn), dim, B, n, dim,
+                                  heads, be.stream())
+    assert torch.equal(dkv.cpu(), ref.cpu())
+    want = dxn0.double() + ref.cpu().double() @ w[HD:].double()
+    rel = 3e-5 if split == 3 else 2e-2
+    assert err(dxn, want.float()) <= rel * max(1.0, want.abs().max().item())
+
+
 def test_small_ops(be):
     torch.manual_seed(0)
     L, S = be.L, be.stream()
