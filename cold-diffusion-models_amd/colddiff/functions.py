@@ -439,7 +439,8 @@ def kv_backward(xn, dim, dkv, w_qkv, dxn):
 
 
 _ATTN_QFOLD = os.environ.get("CDF_ATTN_QFOLD", "1") != "0"   # q projection folded into the attention product too (dim <= heads*32)
-_ATTN_KVDG = os.environ.get("CDF_ATTN_KVDG", "1") != "0"     # k | v backward with its data gradient in one kernel (ops.linattn_bwd_kv_dgrad)
+_ATTN_KVDG = os.environ.get("CDF_ATTN_KVDG", "0") != "0"     # k | v backward with its data gradient in one kernel (ops.linattn_bwd_kv_dgrad):
+                                                             # built, parity-tested, measured at +0.2 % (noise) on the train step => off
 _ATTN_KVCTX = os.environ.get("CDF_ATTN_KVCTX", "1") != "0"   # ... with the k|v projection and the context in one kernel (ops.linattn_kvctx)
 
 
