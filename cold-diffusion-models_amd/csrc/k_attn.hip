@@ -364,6 +364,16 @@ __global__ void softmax_rows_bwd_kernel(const float* p, const float* dp, float* 
 // ================================================================================================
 // C ABI
 // ================================================================================================
+static void la_final_attr() {
+#ifndef CDF_EMU
+    static bool done = false;
+    if (!done) {          // nsplit x 128 B of rescaling weights next to ~4 KB of static LDS: past the 64 KB default from ~480 partials up
+        (void)hipFuncSetAttribute((const void*)linattn_ctx1p_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        done = true;
+    }
+#endif
+}
+
 extern "C" int cdf_linattn_nsplit(int n) {       // 256 rows per split (the one-pass context kernel holds a split's k, v tile in LDS)
     int s = (n + 255) / 256;
     if (s < 1) s = 1;
@@ -404,6 +414,7 @@ extern "C" int cdf_linattn_context(const float* qkv, int ld, int koff, float* ct
         }
 #endif
         CDF_LAUNCH(linattn_ctx1p_kernel, dim3(heads, ns, B), dim3(256), lds, CDF_S, qkv, ld, koff, kmax_part, ctx_part, sum_part, n, HD);
+        la_final_attr();
         CDF_LAUNCH(linattn_ctx1p_final_kernel, dim3(heads, B), dim3(1024), (size_t)ns * LA_D * sizeof(float), CDF_S, (const float*)ctx_part,
                    (const float*)sum_part, (const float*)kmax_part, ns, HD, ctx, ctxs, scale, kmax, ksum);
         return cdf_check_launch("linattn_context");
@@ -423,6 +434,7 @@ extern "C" int cdf_linattn_finalize(const float* ws, int nparts, float* ctx, flo
     const float* max_part = ws;
     const float* ctx_part = max_part + (size_t)B * nparts * HD;
     const float* sum_part = ctx_part + (size_t)B * nparts * heads * LA_D * LA_D;
+    la_final_attr();
     CDF_LAUNCH(linattn_ctx1p_final_kernel, dim3(heads, B), dim3(1024), (size_t)nparts * LA_D * sizeof(float), CDF_S, ctx_part, sum_part, max_part,
                nparts, HD, ctx, ctxs, scale, kmax, ksum);
     return cdf_check_launch("linattn_finalize");
