@@ -368,7 +368,7 @@ static void la_final_attr() {
 #ifndef CDF_EMU
     static bool done = false;
     if (!done) {          // nsplit x 128 B of rescaling weights next to ~4 KB of static LDS: past the 64 KB default from ~480 partials up
-        (void)hipFuncSetAttribute((const void*)linattn_ctx1p_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)linattn_ctx1p_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);   // (+ ~4 KB static: the sum must stay under the 160 KB of a CU)
         done = true;
     }
 #endif
