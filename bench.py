@@ -50,7 +50,9 @@ TIMESTEPS = 200
 
 def step_roofline(batch, accum, ms_per_step, mfma_per_product, act="f32"):
     """SURVEY.md 8(d): bytes_step = B (A_train + D_bytes) accum + 3 W accum + 28 P (+ 1.2 P amortised EMA);
-    flops_step = B (F_train + D_flops) accum; t_roof = max(bytes / BW_HBM, flops x mfma_per_product / PEAK_MFMA[bf16])."""
+    flops_step = B (F_train + D_flops) accum; t_roof = max(bytes / BW_HBM, flops / PEAK_MFMA[bf16]) on ALGORITHMIC flops.
+    The MFMA instructions actually issued (3 per product in split precision) are reported separately as `mfma_issue_*`:
+    they say how busy the matrix pipe is, not how close the step is to its roofline."""
     P = UNET128_PARAMS
     W = 4.0 * P
     d_bytes = 3 * 3 * 128 * 128 * 4.0                       # noise q_sample: read x, read noise, write x_t (fp32)
@@ -58,15 +60,17 @@ def step_roofline(batch, accum, ms_per_step, mfma_per_product, act="f32"):
     flops_step = batch * accum * (3 * UNET128_FWD_GFLOP * 1e9 + 3 * 3 * 128 * 128)
     t = ms_per_step * 1e-3
     t_hbm = bytes_step / (PEAK_HBM_GBS * 1e9)
-    t_mfma = flops_step * mfma_per_product / (PEAK_BF16_MFMA_TFLOPS * 1e12)
-    return {"bytes_step": round(bytes_step), "flops_step": round(flops_step), "hbm_gbs": round(bytes_step / t / 1e9, 1),
+    t_mfma = flops_step / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+    return {"activation_bytes": act, "bytes_step": round(bytes_step), "flops_step": round(flops_step), "hbm_gbs": round(bytes_step / t / 1e9, 1),
             "hbm_frac_of_peak": round(bytes_step / t / 1e9 / PEAK_HBM_GBS, 4),
-            "algorithmic_tflops": round(flops_step / t / 1e12, 2), "mfma_per_product": mfma_per_product,
-            "mfma_issue_frac_of_bf16_peak": round(flops_step * mfma_per_product / t / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+            "algorithmic_tflops": round(flops_step / t / 1e12, 2),
+            "mfma_frac_of_bf16_peak": round(flops_step / t / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
             "t_roof_ms": round(1000 * max(t_hbm, t_mfma), 3), "t_roof_over_t": round(max(t_hbm, t_mfma) / t, 4),
             "bound": "mfma" if t_mfma >= t_hbm else "hbm",
-            "formula": "SURVEY 8(d): bytes = B(A_train+D)accum + 3W accum + 28P + 1.2P; flops = 3 x 67.41 GF/img; "
-                       "t_roof = max(bytes/8 TB/s, flops x mfma_per_product / 2.5 PF)"}
+            "mfma_per_product": mfma_per_product,
+            "mfma_issue_frac_of_bf16_peak": round(flops_step * mfma_per_product / t / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+            "formula": "SURVEY 8(d): bytes = B(A_train+D)accum + 3W accum + 28P + 1.2P; flops = 3 x 67.41 GF/img (algorithmic); "
+                       "t_roof = max(bytes/8 TB/s, flops/2.5 PF); mfma_issue_* = flops x mfma_per_product (pipe occupancy, not roofline)"}
 
 
 def build_workload(args, device):
@@ -495,10 +499,10 @@ def main():
                 out["bf16_mode"] = {"value": round(args.batch * args.accum / dtb, 2), "unit": "img/s", "ms_per_step": round(1000 * dtb, 3),
                                     "dtype": "bf16 GEMM operands (one MFMA per product), fp32 accumulate / master weights / norms / softmax / "
                                              "degradation / optimizer; bf16 planes are the only stored form of LN and GELU outputs",
-                                    "tolerance_vs_fp32_oracle": "UNet output max-abs <= 1e-2 (measured 2.5e-3 on a 64x64 dim-64 net), gradients ~2e-2 "
-                                                                "relative (tests/test_gpu_parity2.py::test_other_precision_modes_module_level)",
+                                    "tolerance_vs_fp32_oracle": dict(runtime.BF16_TOLERANCE, asserted_by="tests/test_gpu_parity2.py::"
+                                                                     "test_other_precision_modes_module_level[bf16] and ::test_bf16_mode_bench_shape_microstep"),
                                     "sample_ms_per_img_200step": sample_bf16, "sample_batch": args.sample_batch,
-                                    "step_roofline": step_roofline(args.batch, args.accum, 1000 * dtb, 1)}
+                                    "step_roofline": step_roofline(args.batch, args.accum, 1000 * dtb, 1, act="bf16")}
                 log(f"bf16 mode: {out['bf16_mode']['value']} img/s")
             del trainer
             torch.cuda.empty_cache()

@@ -53,7 +53,7 @@ class EvalMixin:
         assert self.ds is not None, "this evaluation method needs an image folder (the Trainer was built on synthetic data)"
         batch_size = min(batch_size, len(self.ds))            # (upstream hard-codes 100 with drop_last: smaller folders would yield nothing)
         if isinstance(self.ds, DeviceImageCache):
-            dl = DeviceLoader(self.ds, batch_size, augment=self.ds_augment, shuffle=False)
+            dl = DeviceLoader(self.ds, batch_size, shuffle=False)        # (the dataset's own chain: DataLoader(self.ds, ...))
             for _ in range(len(self.ds) // batch_size):
                 yield next(dl)
             return
@@ -63,10 +63,14 @@ class EvalMixin:
 
     def _dataset_item(self, idx):
         from .trainer import DeviceImageCache
+        """self.ds[idx] (DEBLUR:1578, 1717): the dataset's own transform chain -- a random crop where the dataset augments."""
         if isinstance(self.ds, DeviceImageCache):
-            c = (self.ds.S - self.ds.image_size) // 2
-            i32 = lambda v: torch.tensor([v], dtype=torch.int32, device=self.ds.data.device)
-            return self.ds.batch(torch.tensor([idx], device=self.ds.data.device), i32(c), i32(c), i32(0))[0]
+            if self.ds.recipe.crop == 'center' and not self.ds.recipe.flip:
+                return self.ds.item(idx)
+            from .trainer import DeviceLoader
+            dl = DeviceLoader(self.ds, 1, shuffle=False, seed=123457 + idx)
+            dl.order, dl.pos = torch.tensor([idx], device=self.ds.data.device), 0
+            return next(dl)[0]
         return self.ds[idx].to(self.device)
 
     def _save(self, img, name, nrow=6):

@@ -50,43 +50,113 @@ class EMA:
         flat.ema_update(ma_arena, model_arena, self.beta)
 
 
-# -- image folder datasets (DEBLUR:983-1026) with PIL only (torchvision is not a dependency) ----------
-def _load_image(path, size, augment):
+# -- image folder datasets with PIL only (torchvision is not a dependency) -------------------------------------------
+class Recipe:
+    """One of the reference's `transforms.Compose` chains, as data.  Every chain is
+    [deterministic resize] -> crop (random / centre, optionally after a zero border) -> [mirror] -> ToTensor -> t * 2 - 1.
+
+    resize: 'sq112'  transforms.Resize((int(1.12 s), int(1.12 s)))                    (DEBLUR:990, 1011)
+            'short'  transforms.Resize(s): shorter edge to s, aspect kept             (RESOL:824, DEFADE:564)
+            'none'   the file's own size                                              (DEFADE:588: RandomCrop first; the Resize(s)
+                                                                                       after an s x s crop returns its input)
+    pad:    RandomCrop(s, padding=pad), constant fill 0                               (RESOL:825, DEFADE:588)
+    crop:   'random' (RandomCrop) | 'center' (CenterCrop)
+    rgb:    img.convert('RGB') before the chain                                       (DENOISE:565, 588)"""
+
+    def __init__(self, name, resize, crop, flip, pad=0, rgb=False):
+        self.name, self.resize, self.crop, self.flip, self.pad, self.rgb = name, resize, crop, flip, pad, rgb
+
+    def with_rgb(self):
+        return Recipe(self.name, self.resize, self.crop, self.flip, self.pad, True)
+
+    def __repr__(self):
+        return f"Recipe({self.name}: resize={self.resize} pad={self.pad} crop={self.crop} flip={self.flip} rgb={self.rgb})"
+
+
+AUG1 = Recipe('Dataset_Aug1', 'sq112', 'random', True)                  # DEBLUR:983-1004
+CENTER112 = Recipe('Dataset', 'sq112', 'center', False)                 # DEBLUR:1006-1026
+AUG2 = Recipe('Dataset_Aug2', 'short', 'random', True, pad=4)           # RESOL:817-831
+CIFAR_PAD = Recipe('DatasetCifar10', 'none', 'random', True, pad=4)     # DEFADE:579-599
+CENTER_SHORT = Recipe('Dataset', 'short', 'center', False)              # DEFADE:557-576
+
+
+def center_offset(full, size):
+    """torchvision's CenterCrop: int(round((full - size) / 2.0)) with Python's round-half-to-even -- NOT (full - size) // 2:
+    143 -> 128 starts at 8, 71 -> 64 at 4, 35 -> 32 and 31 -> 28 at 2."""
+    return int(round((full - size) / 2.0))
+
+
+def resized(img, size, recipe):
+    """The deterministic head of the chain on a PIL image (convert, Resize)."""
+    from PIL import Image
+    if recipe.rgb:
+        img = img.convert('RGB')
+    if recipe.resize == 'sq112':
+        big = int(size * 1.12)
+        return img.resize((big, big), Image.BILINEAR)
+    if recipe.resize == 'short':
+        w, h = img.size
+        short, long = (w, h) if w <= h else (h, w)
+        if short == size:
+            return img                                   # torchvision returns the image itself
+        new_long = int(size * long / short)
+        return img.resize((size, new_long) if w <= h else (new_long, size), Image.BILINEAR)
+    return img
+
+
+def _load_image(path, size, recipe):
     from PIL import Image
     import numpy as np
-    img = Image.open(path)
-    big = int(size * 1.12)
-    img = img.resize((big, big), Image.BILINEAR)
-    if augment:
-        ox, oy = (int(torch.randint(0, big - size + 1, (1,))) for _ in range(2))
-    else:
-        ox = oy = (big - size) // 2          # CenterCrop
-    img = img.crop((ox, oy, ox + size, oy + size))
-    if augment and torch.rand(1).item() < 0.5:
-        img = img.transpose(Image.FLIP_LEFT_RIGHT)
-    arr = np.asarray(img, dtype=np.float32) / 255.0
+    img = resized(Image.open(path), size, recipe)
+    arr = np.asarray(img)
     if arr.ndim == 2:
         arr = arr[:, :, None]
-    return torch.from_numpy(arr).permute(2, 0, 1).contiguous() * 2 - 1
+    if recipe.pad:
+        arr = np.pad(arr, ((recipe.pad, recipe.pad), (recipe.pad, recipe.pad), (0, 0)))
+    H, W = arr.shape[:2]
+    assert H >= size and W >= size, f"{path}: {W}x{H} after the resize is smaller than the {size}x{size} crop"
+    if recipe.crop == 'random':
+        if H == size and W == size:
+            oy = ox = 0                                  # RandomCrop.get_params draws nothing in this case
+        else:
+            oy = int(torch.randint(0, H - size + 1, (1,)))          # i (top) first, then j (left)
+            ox = int(torch.randint(0, W - size + 1, (1,)))
+    else:
+        oy, ox = center_offset(H, size), center_offset(W, size)
+    arr = arr[oy:oy + size, ox:ox + size]
+    if recipe.flip and torch.rand(1).item() < 0.5:
+        arr = arr[:, ::-1]
+    t = torch.from_numpy(np.array(arr)).permute(2, 0, 1).float().div(255)   # ToTensor
+    return t * 2 - 1
 
 
 class Dataset(data.Dataset):
-    augment = False
+    recipe = CENTER112
 
-    def __init__(self, folder, image_size, exts=('jpg', 'jpeg', 'png')):
+    def __init__(self, folder, image_size, exts=('jpg', 'jpeg', 'png'), recipe=None):
         super().__init__()
         self.folder, self.image_size = folder, image_size
         self.paths = [p for ext in exts for p in Path(f'{folder}').glob(f'**/*.{ext}')]
+        if recipe is not None:
+            self.recipe = recipe
 
     def __len__(self):
         return len(self.paths)
 
     def __getitem__(self, index):
-        return _load_image(self.paths[index], self.image_size, self.augment)
+        return _load_image(self.paths[index], self.image_size, self.recipe)
 
 
 class Dataset_Aug1(Dataset):
-    augment = True
+    recipe = AUG1
+
+
+class Dataset_Aug2(Dataset):
+    recipe = AUG2
+
+
+class DatasetCifar10(Dataset):
+    recipe = CIFAR_PAD
 
 
 class SyntheticImages:
@@ -135,7 +205,18 @@ def _match_module_prefix(sd, target_keys):
 
 
 class Trainer(EvalMixin):
-    AUG_DATASETS = ('mnist', 'cifar10', 'flower', 'celebA', 'AFHQ', 'train')
+    # which transform chain a `dataset=` name selects (DEBLUR:1094-1114); the other packages override this table
+    drop_last = True
+    force_shuffle = False
+    image_size_from_model = False
+
+    @staticmethod
+    def recipe_for(dataset):
+        if dataset in ('mnist', 'cifar10', 'flower', 'celebA', 'AFHQ'):
+            return AUG1
+        if dataset == 'LSUN_train':                      # (upstream reads the LSUN lmdb through torchvision.datasets; a folder of its
+            return Recipe('LSUN_train', 'sq112', 'random', False)     # images gets the same chain: no mirror, DEBLUR:1098-1108)
+        return CENTER112
 
     def __init__(self, diffusion_model, folder, *, ema_decay=0.995, image_size=128, train_batch_size=32, train_lr=2e-5,
                  train_num_steps=100000, gradient_accumulate_every=2, fp16=False, step_start_ema=2000, update_ema_every=10,
@@ -150,10 +231,12 @@ class Trainer(EvalMixin):
         self.step_start_ema = step_start_ema
         self.save_and_sample_every = save_and_sample_every
         self.batch_size = train_batch_size
-        self.image_size = image_size
         self.gradient_accumulate_every = gradient_accumulate_every
         self.train_num_steps = train_num_steps
         self.core = unwrap(self.model)
+        # RESOL:874 / DEFADE:681 take the sampling size from the model; the dataset still crops to the `image_size` argument
+        self.image_size = self.core.image_size if self.image_size_from_model else image_size
+        self.data_image_size = image_size
         self.ema_core = unwrap(self.ema_model)
         # the denoising package feeds (image, fresh Gaussian noise) pairs (DENOISE:738-742)
         self.pair_noise = hasattr(self.core, 'sqrt_alphas_cumprod')
@@ -193,20 +276,26 @@ class Trainer(EvalMixin):
         """(dataset, endless batch iterator): image folder as in the reference (DEBLUR:1094-1096), or synthetic images."""
         if dataset == 'synthetic' or folder is None:
             # (every rank draws its own shard: the seed is offset by the rank)
-            return None, SyntheticImages(self.batch_size, self.core.channels, self.image_size, self.device, seed=seed + parallel.rank())
-        aug = dataset in self.AUG_DATASETS
-        self.ds_augment = aug
-        print(dataset, "DA used" if aug else "")
+            return None, SyntheticImages(self.batch_size, self.core.channels, self.data_image_size, self.device, seed=seed + parallel.rank())
+        recipe = self.recipe_for(dataset)
+        self.recipe = recipe
+        print(dataset, "DA used" if recipe.crop == 'random' else "")
+        shuffle = True if self.force_shuffle else shuffle
+        drop_last = self.drop_last or parallel.world_size() > 1      # (ranks must run the same number of equal micro-batches)
         if self.device_data:
-            cache = DeviceImageCache(folder, self.image_size, self.device)
-            return cache, DeviceLoader(cache, self.batch_size, augment=aug, shuffle=shuffle, seed=seed, rank=parallel.rank(),
-                                       world=parallel.world_size())
-        ds = (Dataset_Aug1 if aug else Dataset)(folder, self.image_size)
+            try:
+                cache = DeviceImageCache(folder, self.data_image_size, self.device, recipe=recipe)
+                return cache, DeviceLoader(cache, self.batch_size, shuffle=shuffle, seed=seed, rank=parallel.rank(),
+                                           world=parallel.world_size(), drop_last=drop_last)
+            except CacheUnfit as e:
+                print(f"device image cache not used ({e}); falling back to the host DataLoader")
+                self.device_data = False
+        ds = Dataset(folder, self.data_image_size, recipe=recipe)
         sampler = None
         if parallel.world_size() > 1:
             sampler = data.distributed.DistributedSampler(ds, shuffle=shuffle)
         dl = cycle(data.DataLoader(ds, batch_size=self.batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
-                                   pin_memory=self.device.type == 'cuda', num_workers=num_workers, drop_last=True), sampler)
+                                   pin_memory=self.device.type == 'cuda', num_workers=num_workers, drop_last=drop_last), sampler)
         return ds, dl
 
     # -- EMA / checkpoint --------------------------------------------------------------------------------
@@ -354,6 +443,10 @@ class DemixTrainer(Trainer):
         self.ds1, self.dl1 = self.ds, self.dl
         self.ds2, self.dl2 = self._make_loader(folder2, dataset, shuffle, num_workers, seed=7654321)
 
+    @staticmethod
+    def recipe_for(dataset):                   # DEMIX:636-643: 'train' augments; both datasets convert to RGB (DEMIX:545, 568)
+        return (AUG1 if dataset == 'train' else CENTER112).with_rgb()
+
     def _second(self, batch=None):
         d = next(self.dl2)
         if isinstance(d, (list, tuple)):
@@ -372,6 +465,10 @@ class DefadeGenTrainer(Trainer):
         super().__init__(diffusion_model, folder, **kw)
         self.pair_noise = False
 
+    @staticmethod
+    def recipe_for(dataset):                   # DEFGEN:682-687: 'train' augments; both datasets convert to RGB (DEFGEN:591, 614)
+        return (AUG1 if dataset == 'train' else CENTER112).with_rgb()
+
     def _second(self, batch):
         B, C, H, W = batch.shape
         c = torch.rand((B, C), device=batch.device) - 0.5
@@ -379,39 +476,63 @@ class DefadeGenTrainer(Trainer):
 
 
 # -- device-side input pipeline -----------------------------------------------------------------------
-class DeviceImageCache:
-    """The image folder of `Dataset_Aug1` / `Dataset` (DEBLUR:983-1026) decoded ONCE and kept in HBM as uint8, already resized to
-    S = int(1.12 image_size) -- the deterministic `transforms.Resize((S, S))` of the reference's chain, done with the same PIL call
-    (bilinear, PIL's reducing filter) on the host at cache-build time by a thread pool.  What is random per sample (crop offset,
-    mirror) or pure arithmetic (ToTensor, t*2-1) runs per batch in ONE kernel (cdf_augment_batch): the training loop never waits for
-    host image workers (the reference spawns 8-16 PIL processes, DEBLUR:1095, 1107, 1114).
-    CelebA (202 599 images) at S = 143: 12.4 GB of the MI355X's 288 GB."""
+class CacheUnfit(Exception):
+    """The folder cannot live in the device cache (ragged image sizes after the recipe's resize, or larger than the memory
+    budget): the Trainer falls back to the host Dataset + DataLoader."""
 
-    def __init__(self, folder, image_size, device, exts=('jpg', 'jpeg', 'png'), decode_threads=None, paths=None):
+
+class DeviceImageCache:
+    """An image folder decoded ONCE and kept in HBM as uint8 NHWC, already past the DETERMINISTIC head of the reference's
+    transform chain (`convert('RGB')`, `transforms.Resize(...)` -- done with the same PIL call on the host at cache-build time by a
+    thread pool).  What is random per sample (crop offset, mirror) or pure arithmetic (border, ToTensor, t*2-1) runs per batch in
+    ONE kernel (cdf_augment_batch_pad): the training loop never waits for host image workers (the reference spawns 8-16 PIL
+    processes, DEBLUR:1095, 1107, 1114).  CelebA (202 599 images) at S = 143: 12.4 GB of the MI355X's 288 GB.
+    Raises CacheUnfit when the images are not all of one size after the resize (`Resize(s)` keeps the aspect ratio) or when the
+    cache would not fit next to the model (budget: COLDDIFF_CACHE_FRACTION of the free HBM, default 0.5; pinned host staging buffer
+    of the same size, at most half of the free host RAM)."""
+
+    def __init__(self, folder, image_size, device, exts=('jpg', 'jpeg', 'png'), decode_threads=None, paths=None, recipe=None):
         import numpy as np
         from concurrent.futures import ThreadPoolExecutor
         from PIL import Image
+        self.recipe = recipe = recipe or AUG1
         self.image_size = image_size
-        self.S = int(image_size * 1.12)
         self.paths = list(paths) if paths is not None else [p for ext in exts for p in Path(f'{folder}').glob(f'**/*.{ext}')]
         assert len(self.paths) > 0, f"no images under {folder}"
-        S = self.S
 
         def load(p):
-            img = Image.open(p)
-            arr = np.asarray(img.resize((S, S), Image.BILINEAR))      # == transforms.Resize((S, S)) on a PIL image
+            arr = np.asarray(resized(Image.open(p), image_size, recipe))
             return arr[:, :, None] if arr.ndim == 2 else arr
 
         first = load(self.paths[0])
-        self.channels = first.shape[2]
+        self.SH, self.SW, self.channels = first.shape
+        self.S = self.SH                                            # (square caches: the 1.12x chains)
         n = len(self.paths)
-        host = torch.empty((n, S, S, self.channels), dtype=torch.uint8, pin_memory=torch.device(device).type == 'cuda')
+        dev = torch.device(device)
+        need = n * first.size
+        if dev.type == 'cuda':
+            free_hbm = torch.cuda.mem_get_info(dev)[0]
+            frac = float(os.environ.get("COLDDIFF_CACHE_FRACTION", "0.5"))
+            if need > frac * free_hbm:
+                raise CacheUnfit(f"{n} images of {self.SH}x{self.SW}x{self.channels} = {need / 2**30:.1f} GiB exceed "
+                                 f"{frac:.2f} of the free HBM ({free_hbm / 2**30:.1f} GiB)")
+            try:
+                import psutil
+                if need > 0.5 * psutil.virtual_memory().available:
+                    raise CacheUnfit(f"{need / 2**30:.1f} GiB of pinned staging exceed half of the free host memory")
+            except ImportError:
+                pass
+        pad = recipe.pad
+        if self.SH + 2 * pad < image_size or self.SW + 2 * pad < image_size:
+            raise CacheUnfit(f"{self.paths[0]}: {self.SW}x{self.SH} is smaller than the {image_size}x{image_size} crop")
+        host = torch.empty((n, self.SH, self.SW, self.channels), dtype=torch.uint8, pin_memory=dev.type == 'cuda')
         hv = host.numpy()
         hv[0] = first
 
         def fill(i):
             a = load(self.paths[i])
-            assert a.shape == first.shape, f"{self.paths[i]}: {a.shape} vs {first.shape} (mixed image modes in one folder)"
+            if a.shape != first.shape:
+                raise CacheUnfit(f"{self.paths[i]}: {a.shape} vs {first.shape} (ragged sizes / mixed image modes in one folder)")
             hv[i] = a
 
         with ThreadPoolExecutor(max_workers=decode_threads or min(32, os.cpu_count() or 1)) as ex:   # PIL releases the GIL while decoding / resizing
@@ -421,33 +542,56 @@ class DeviceImageCache:
     def __len__(self):
         return len(self.paths)
 
+    def span(self):
+        """(rows, columns) of valid crop offsets: the padded image minus the crop, plus one."""
+        p = self.recipe.pad
+        return self.SH + 2 * p - self.image_size + 1, self.SW + 2 * p - self.image_size + 1
+
+    def center(self):
+        p = self.recipe.pad
+        return center_offset(self.SH + 2 * p, self.image_size), center_offset(self.SW + 2 * p, self.image_size)
+
     def batch(self, idx, oy, ox, flip):
-        """[B, C, H, H] fp32 batch: images idx (int64 [B]) cropped at (oy, ox), mirrored where flip != 0 (int32 [B] each, on the device)."""
+        """[B, C, H, H] fp32 batch: images idx (int64 [B]) cropped at (oy, ox) of the bordered image, mirrored where flip != 0
+        (int32 [B] each, on the device)."""
         rt.check(self.data)
         B, H = idx.numel(), self.image_size
         out = torch.empty((B, self.channels, H, H), device=self.data.device, dtype=torch.float32)
-        rt.lib().cdf_augment_batch(rt.P(self.data), len(self.paths), self.S, self.channels, rt.P(idx), rt.P(oy), rt.P(ox), rt.P(flip), rt.P(out),
-                                   B, H, H, rt.stream(self.data))
+        rt.lib().cdf_augment_batch_pad(rt.P(self.data), len(self.paths), self.SH, self.SW, self.channels, self.recipe.pad, rt.P(idx), rt.P(oy),
+                                       rt.P(ox), rt.P(flip), rt.P(out), B, H, H, rt.stream(self.data))
         return out
+
+    def item(self, idx):
+        """Image idx as the non-random chain yields it ([C, H, H]; centre crop, no mirror)."""
+        dev = self.data.device
+        i32 = lambda v: torch.tensor([v], dtype=torch.int32, device=dev)
+        cy, cx = self.center()
+        return self.batch(torch.tensor([idx], device=dev), i32(cy), i32(cx), i32(0))[0]
 
 
 class DeviceLoader:
     """Endless batch iterator over a DeviceImageCache with the sampling semantics of the reference's loader: `shuffle=True`
-    permutes the indices every epoch, `drop_last=True`, batch_size images per step (DEBLUR:1095-1096); with several ranks every
-    rank takes the DistributedSampler slice perm[rank::world] of the SAME epoch permutation (seed + epoch on a CPU generator).
-    augment: RandomCrop(image_size) + RandomHorizontalFlip() (Dataset_Aug1), else CenterCrop (Dataset)."""
+    permutes the indices every epoch, `drop_last` as the package's DataLoader has it (DEBLUR:1095-1096 drops, RESOL:887 keeps the
+    short batch), batch_size images per step; with several ranks every rank takes the DistributedSampler slice perm[rank::world] of
+    the SAME epoch permutation (seed + epoch on a CPU generator).  Crop and mirror follow the cache's recipe: RandomCrop offsets
+    (row first, then column; none drawn when the image IS the crop size, like RandomCrop.get_params) and RandomHorizontalFlip(0.5),
+    or CenterCrop."""
 
-    def __init__(self, cache, batch_size, augment, shuffle=True, seed=123457, rank=0, world=1):
-        self.cache, self.batch_size, self.augment, self.shuffle = cache, batch_size, augment, shuffle
+    def __init__(self, cache, batch_size, shuffle=True, seed=123457, rank=0, world=1, drop_last=True, augment=None):
+        self.cache, self.batch_size, self.shuffle, self.drop_last = cache, batch_size, shuffle, drop_last
+        rec = cache.recipe
+        self.random_crop = rec.crop == 'random' if augment is None else bool(augment)
+        self.flip = rec.flip if augment is None else bool(augment)
         self.seed, self.rank, self.world = seed, rank, world
         self.epoch, self.pos, self.order = 0, 0, None
         dev = cache.data.device
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed + 7919 * rank)
         n = len(cache) // world if world > 1 else len(cache)
-        assert n >= batch_size, f"{len(cache)} images over {world} ranks: fewer than one batch of {batch_size}"
-        c = (cache.S - cache.image_size) // 2
-        self._center = torch.full((batch_size,), c, dtype=torch.int32, device=dev)
+        assert n >= batch_size or not drop_last, f"{len(cache)} images over {world} ranks: fewer than one batch of {batch_size}"
+        cy, cx = cache.center()
+        self._cy = torch.full((batch_size,), cy, dtype=torch.int32, device=dev)
+        self._cx = torch.full((batch_size,), cx, dtype=torch.int32, device=dev)
         self._noflip = torch.zeros((batch_size,), dtype=torch.int32, device=dev)
 
     def _new_epoch(self):
@@ -468,14 +612,68 @@ class DeviceLoader:
 
     def __next__(self):
         B = self.batch_size
-        if self.order is None or self.pos + B > self.order.numel():       # drop_last
+        left = 0 if self.order is None else self.order.numel() - self.pos
+        if left <= 0 or (left < B and self.drop_last):
             self._new_epoch()
+            left = self.order.numel()
+        B = min(B, left)                                                   # (short last batch when drop_last is off)
         idx = self.order[self.pos:self.pos + B].contiguous()
         self.pos += B
-        if not self.augment:
-            return self.cache.batch(idx, self._center, self._center, self._noflip)
-        dev, span = self.cache.data.device, self.cache.S - self.cache.image_size + 1
-        oy = torch.randint(0, span, (B,), generator=self.gen, device=dev, dtype=torch.int32)      # RandomCrop: i (top), then j (left)
-        ox = torch.randint(0, span, (B,), generator=self.gen, device=dev, dtype=torch.int32)
-        flip = (torch.rand((B,), generator=self.gen, device=dev) < 0.5).to(torch.int32)          # RandomHorizontalFlip(p = 0.5)
+        dev = self.cache.data.device
+        sy, sx = self.cache.span()
+        if self.random_crop and (sy > 1 or sx > 1):
+            oy = torch.randint(0, sy, (B,), generator=self.gen, device=dev, dtype=torch.int32)     # RandomCrop: i (top), then j (left)
+            ox = torch.randint(0, sx, (B,), generator=self.gen, device=dev, dtype=torch.int32)
+        elif self.random_crop:
+            oy = ox = self._noflip[:B]
+        else:
+            oy, ox = self._cy[:B], self._cx[:B]
+        if self.flip:
+            flip = (torch.rand((B,), generator=self.gen, device=dev) < 0.5).to(torch.int32)      # RandomHorizontalFlip(p = 0.5)
+        else:
+            flip = self._noflip[:B]
         return self.cache.batch(idx, oy, ox, flip)
+
+
+# -- the other packages' Trainers: same loop, their own `dataset=` tables and loader options ---------------------------------
+class DenoiseTrainer(Trainer):
+    """denoising_diffusion_pytorch.py:620-789: `dataset == 'train'` augments, everything else is the centre crop; both datasets
+    convert to RGB first (DENOISE:565, 588)."""
+
+    @staticmethod
+    def recipe_for(dataset):
+        return (AUG1 if dataset == 'train' else CENTER112).with_rgb()
+
+
+class ResolutionTrainer(Trainer):
+    """resolution_diffusion_pytorch.py:837-900: 'cifar10' / 'celebA' -> Dataset_Aug1, 'flower' -> Dataset_Aug2 (Resize(s),
+    RandomCrop(s, padding=4), mirror), else the centre crop; the DataLoader keeps the short last batch (no drop_last, RESOL:887);
+    image_size comes from the model (RESOL:874)."""
+    drop_last = False
+    image_size_from_model = True
+
+    @staticmethod
+    def recipe_for(dataset):
+        if dataset in ('cifar10', 'celebA'):
+            return AUG1
+        if dataset == 'flower':
+            return AUG2
+        return CENTER112
+
+
+class DefadeTrainer(Trainer):
+    """defading_diffusion_gaussian.py:651-705: 'cifar10' -> DatasetCifar10 (RandomCrop(s, padding=4) on the file's own size, mirror),
+    'celebA' -> DatasetCelebA (= Dataset_Aug1), 'celebA_test' -> DatasetCelebATest (1.12x, centre), else Resize(s) + CenterCrop(s);
+    always shuffled (DEFADE:695), no `shuffle=` argument upstream (accepted and ignored here)."""
+    force_shuffle = True
+    image_size_from_model = True
+
+    @staticmethod
+    def recipe_for(dataset):
+        if dataset == 'cifar10':
+            return CIFAR_PAD
+        if dataset == 'celebA':
+            return Recipe('DatasetCelebA', 'sq112', 'random', True)
+        if dataset == 'celebA_test':
+            return Recipe('DatasetCelebATest', 'sq112', 'center', False)
+        return CENTER_SHORT

@@ -3,6 +3,6 @@
 from colddiff.diffusion import ResolutionDiffusion as GaussianDiffusion
 from colddiff.unet import Unet
 from colddiff.model2 import Model
-from colddiff.trainer import Trainer
+from colddiff.trainer import ResolutionTrainer as Trainer
 
 __all__ = ["GaussianDiffusion", "Unet", "Trainer", "Model"]

@@ -229,6 +229,11 @@ int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda, const void
  * offsets must satisfy oy + H <= S, ox + W <= S (not checked on the device). */
 int cdf_augment_batch(const void* cache, long long N, int S, int C, const long long* idx, const int* oy, const int* ox,
                       const int* flip, float* out, int B, int H, int W, void* stream);
+/* The same over a rectangular cache [N][SH][SW][C] with RandomCrop's `padding=pad` border (constant fill 0, i.e. -1 after the
+ * conversion): (oy, ox) address the (SH + 2 pad) x (SW + 2 pad) padded image.  Replaces resolution_diffusion_pytorch.py:817-831
+ * (Dataset_Aug2: Resize(s), RandomCrop(s, padding=4)) and defading_diffusion_gaussian.py:579-599 (DatasetCifar10). */
+int cdf_augment_batch_pad(const void* cache, long long N, int SH, int SW, int C, int pad, const long long* idx, const int* oy,
+                          const int* ox, const int* flip, float* out, int B, int H, int W, void* stream);
 
 /* Metric step after sampling (deblurring_diffusion_pytorch.py:1677-1702): SSIM as pytorch_msssim.ssim computes it (11-tap Gaussian
  * window sigma 1.5 given by the caller as 11 HOST floats, "valid" filtering along H then W, C1 = (0.01 L)^2, C2 = (0.03 L)^2).
