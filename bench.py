@@ -390,6 +390,17 @@ def main():
     # Roofline pass: the SAME K steps again, now with a HIP-event pair around every MFMA GEMM launch (on the launch
     # stream).  Kept out of the timed region above because ~1000 event records per step cost 3 % of throughput; the
     # instrumented steps' own wall time is reported next to the kernel figures.
+    dp_stats = None
+    if world > 1 and trainer.sync is not None:
+        # how much of the gradient exchange the backward pass hides: a few further steps with events around every bucket's all-reduce
+        trainer.sync.profile = True
+        barrier()
+        for _ in range(min(args.steps, 4)):
+            trainer.train_step()
+            trainer.step += 1
+        barrier()
+        trainer.sync.profile = False
+        dp_stats = trainer.sync.stats()
     elapsed_instr = None
     if use_timer:
         timer.enabled = True
@@ -419,6 +430,10 @@ def main():
                    "gradient_accumulate_every": args.accum, "global_images_per_step": imgs_per_step,
                    "parallelism": f"dp{world}" if world > 1 else "single"},
     }
+    if dp_stats:
+        out["gradient_exchange"] = dict(dp_stats, backend=torch.distributed.get_backend(),
+                                        note="sum all-reduce of the flat fp32 gradient arena, bucketed in runs of whole tensors, issued on a side "
+                                             "stream during backward of the last accumulation micro-step; exposed = after backward ended")
     if parallel.rank() == 0:
         dom = max(kernels, key=lambda k: kernels[k]["share_of_step"]) if kernels else None
         if dom:

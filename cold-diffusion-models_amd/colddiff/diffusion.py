@@ -364,6 +364,11 @@ class DeblurDiffusion(nn.Module):
     # -- forward() in two phases, for the Trainer's degradation prefetch: the blur chain of micro-batch i+1 (up to T sequential
     # steps on B*C planes: 96 of 256 CUs at B = 32) does not depend on the network and runs on a side stream under the
     # forward / backward of micro-batch i.  prepare() + loss_prepared() == forward(): same draws, same kernels.
+    def can_prepare_async(self):
+        """True when q_sample is ONE sync-free launch (uniform kernel size, plane fits the LDS): only then does a side-stream
+        prefetch overlap with anything -- the per-step fallback reads max(t) on the host and would block the launching thread."""
+        return self._uniform() and D.blur_fits_lds(self.image_size, self.image_size, self.gaussian_kernels[0].weight.shape[-1])
+
     def prepare(self, x):
         b, c, h, w, device, img_size = *x.shape, x.device, self.image_size
         assert h == img_size and w == img_size, f'height and width of image must be {img_size}'

@@ -38,7 +38,12 @@ def pin_device():
     script (e.g. deblurring-diffusion-pytorch/celebA_128.py:100-102) land on the rank's own GPU under
     `python -m torch.distributed.run`.  Called at package import; a no-op without LOCAL_RANK or without a GPU."""
     if "LOCAL_RANK" in os.environ and torch.cuda.is_available():
-        torch.cuda.set_device(local_rank() % max(1, torch.cuda.device_count()))
+        n = torch.cuda.device_count()
+        if local_rank() >= n and os.environ.get("COLDDIFF_SHARE_GPU", "0") != "1":
+            # (RCCL rejects two ranks on one device with an opaque error; COLDDIFF_SHARE_GPU=1 is the test suite's gloo-on-one-GPU run)
+            raise RuntimeError(f"LOCAL_RANK={local_rank()} but only {n} GPU(s) are visible: launch one process per GPU "
+                               f"(--nproc-per-node <= {n}), or set COLDDIFF_SHARE_GPU=1 to share devices under the gloo backend")
+        torch.cuda.set_device(local_rank() % max(1, n))
 
 
 def init_distributed(backend=None):
@@ -50,9 +55,29 @@ def init_distributed(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if backend == "nccl":
+        lws = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+        assert torch.cuda.device_count() >= lws, (f"RCCL needs one GPU per local rank: LOCAL_WORLD_SIZE={lws}, "
+                                                  f"{torch.cuda.device_count()} visible")
         pin_device()
-    # generous timeout: at a milestone rank 0 runs the full T-step sampler + image / checkpoint I/O while the others wait
-    dist.init_process_group(backend=backend, rank=rank(), world_size=world_size(), timeout=datetime.timedelta(hours=2))
+    # default watchdog for the training collectives (a crashed rank / mismatched bucket sequence must surface in minutes); the
+    # milestone wait, where rank 0 runs the full T-step sampler + image / checkpoint I/O, goes through milestone_barrier()
+    dist.init_process_group(backend=backend, rank=rank(), world_size=world_size(),
+                            timeout=datetime.timedelta(minutes=int(os.environ.get("COLDDIFF_DIST_TIMEOUT_MIN", "10"))))
+
+
+_milestone_group = None
+
+
+def milestone_barrier():
+    """Barrier with a 2-hour limit on its own gloo group (host-side wait: no device collective sits in a stream meanwhile)."""
+    global _milestone_group
+    if world_size() == 1 or not dist.is_initialized():
+        return
+    if _milestone_group is None:
+        _milestone_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=2))
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    dist.barrier(group=_milestone_group)
 
 
 def decorrelate_rng():
@@ -107,6 +132,9 @@ class GradSync:
         self.pending = None
         self.head = 0
         self.works = []
+        # optional timing (bench.py): per step (backward-end event on the compute stream, [(start, end) per bucket on the comm stream])
+        self.profile = False
+        self._prof, self._cur = [], None
 
     # -- forward side ---------------------------------------------------------------------------------
     def begin(self):
@@ -128,6 +156,7 @@ class GradSync:
         self.pending = list(self.uses)
         self.head = 0
         self.works = []
+        self._cur = [] if (self.profile and self.on_gpu) else None
         self._drain()
 
     def _launch(self, b):
@@ -138,7 +167,14 @@ class GradSync:
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
+                if self._cur is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.comm_stream)
                 self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+                if self._cur is not None:
+                    self.works[-1].wait()                       # (stream-side wait: orders e1 behind the collective on the comm stream)
+                    e1.record(self.comm_stream)
+                    self._cur.append((e0, e1))
         else:
             self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
 
@@ -163,11 +199,33 @@ class GradSync:
         if not self.armed:
             return
         self._drain(force=True)        # (uses whose backward never ran, e.g. a detached branch: final now that backward is over)
+        if self._cur is not None:
+            bwd_end = torch.cuda.Event(enable_timing=True)
+            bwd_end.record(torch.cuda.current_stream())
+            self._prof.append((bwd_end, self._cur))
+            self._cur = None
         for w in self.works:
             w.wait()
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.armed = False
+
+
+    def stats(self):
+        """Timing of the profiled steps (call after a device synchronize): total all-reduce time on the comm stream, and the part of
+        it that ran AFTER the backward pass had finished on the compute stream (= exposed; the rest was hidden under backward)."""
+        if not self._prof:
+            return None
+        comm = exposed = 0.0
+        for bwd_end, evs in self._prof:
+            comm += sum(a.elapsed_time(b) for a, b in evs)
+            exposed += max(0.0, bwd_end.elapsed_time(evs[-1][1]))       # last bucket's end vs the end of backward
+        n = len(self._prof)
+        nbytes = 4 * sum(hi - lo for lo, hi in self.bounds)
+        return {"buckets": len(self.bounds), "bytes_per_step": nbytes, "allreduce_ms_per_step": round(comm / n, 3),
+                "exposed_ms_per_step": round(exposed / n, 3), "hidden_ms_per_step": round(max(0.0, comm - exposed) / n, 3),
+                "busbw_gbs": round(nbytes * 2 * (self.world - 1) / self.world / (comm / n * 1e-3) / 1e9, 1) if comm > 0 else None,
+                "steps": n}
 
 
 def set_engine(e):

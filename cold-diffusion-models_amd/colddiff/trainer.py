@@ -344,6 +344,8 @@ class Trainer(EvalMixin):
         return og_img if x2 is None else x2
 
     # -- degradation prefetch (deblurring: q_sample is up to T sequential blur steps on B*C planes, independent of the network) ----
+    # The trajectory is bit-identical to the non-prefetching loop BETWEEN milestones; a milestone's sample batch is drawn after the
+    # next micro-batch was already prefetched, i.e. one batch later in the data order than without prefetch.
     _pending = None
     _side = None
 
@@ -351,13 +353,17 @@ class Trainer(EvalMixin):
         """Only for the plain loop on a HIP device: not when a test / subclass replaced _loss, not for two-image packages."""
         return (self.device.type == 'cuda' and hasattr(self.core, 'prepare') and '_loss' not in self.__dict__
                 and type(self)._loss is Trainer._loss and not self.pair_noise and rt._lib_override is None
-                and getattr(self.core, 'train_routine', None) == 'Final' and os.environ.get("COLDDIFF_PREFETCH", "1") != "0")
+                and getattr(self.core, 'train_routine', None) == 'Final' and os.environ.get("COLDDIFF_PREFETCH", "1") != "0"
+                and getattr(self.core, 'can_prepare_async', lambda: True)())
 
     def _launch_prepare(self):
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream()
-            self._side.wait_stream(main)                     # once: model / kernel-stack tensors created on the main stream are complete
+        # every launch: whatever the main stream produced that the side stream reads (the epoch permutation a milestone's
+        # _next_batch rebuilt, kernel-stack tensors) is ordered before it.  Issued BEFORE forward i is enqueued, so the prefetch
+        # still overlaps with the forward / backward of micro-batch i.
+        self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             prep = self.core.prepare(self._next_batch())
             ev = torch.cuda.Event()
@@ -429,8 +435,7 @@ class Trainer(EvalMixin):
             self.save()
             if self.step % (self.save_and_sample_every * 100) == 0:
                 self.save(self.step)
-        if parallel.world_size() > 1:
-            torch.distributed.barrier()
+        parallel.milestone_barrier()
 
 
 class DemixTrainer(Trainer):

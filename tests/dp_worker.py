@@ -1,6 +1,8 @@
 """Worker for tests/test_dp.py: one rank of a multi-process gloo data-parallel run on the CPU simulator.
 
-argv: out_path nsteps bucket_bytes mode [hip]        ("hip": both ranks on cuda:0 with the product library, gloo moving CUDA tensors)
+argv: out_path nsteps bucket_bytes mode [hip|emu] [unet|model] [precision]
+  "hip": both ranks on cuda:0 with the product library, gloo moving CUDA tensors;  "model": the CIFAR `Model` (MODEL2:191-332)
+  instead of `Unet`;  precision: bf16x3 (default) | bf16 | f32
   mode 'once'  : loss = L1(x, f(q(x, e, t), t))                         (the denoising package's p_losses)
   mode 'twice' : the network runs TWICE per loss (as RESOL:702-716 'Final_random_mean_and_actual' does):
                  loss = L1(x, f(q(x,e,t), t)) + L1(x, f(q(x,-e,t), t))
@@ -21,8 +23,13 @@ from emu_util import install_emu  # noqa: E402
 ON_HIP = len(sys.argv) > 5 and sys.argv[5] == "hip"
 if not ON_HIP:
     install_emu()
-from colddiff import parallel  # noqa: E402
+from colddiff import parallel, runtime  # noqa: E402
 from denoising_diffusion_pytorch import GaussianDiffusion, Trainer, Unet  # noqa: E402
+from colddiff.model2 import Model  # noqa: E402
+
+NET = sys.argv[6] if len(sys.argv) > 6 else "unet"
+if len(sys.argv) > 7:
+    runtime.set_precision(sys.argv[7])
 
 out_path, nsteps, bucket_bytes, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 if bucket_bytes > 0:
@@ -32,7 +39,10 @@ parallel.init_distributed("gloo")
 rank, world = parallel.rank(), parallel.world_size()
 torch.manual_seed(0)
 with contextlib.redirect_stdout(io.StringIO()):
-    net = Unet(dim=8, dim_mults=(1, 2), channels=3)
+    if NET == "model":
+        net = Model(ch=32, out_ch=3, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(4,), dropout=0.0, in_channels=3, resolution=8)
+    else:
+        net = Unet(dim=8, dim_mults=(1, 2), channels=3)
 if rank == 1:      # ranks must converge to rank 0's weights through the initial broadcast
     with torch.no_grad():
         for p in net.parameters():

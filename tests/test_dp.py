@@ -51,11 +51,28 @@ def test_two_rank_training_on_the_gpu(tmp_path, bucket_bytes, mode, min_buckets)
     _two_rank_case(tmp_path, bucket_bytes, mode, min_buckets, hip=True)
 
 
-def _two_rank_case(tmp_path, bucket_bytes, mode, min_buckets, hip):
+@pytest.mark.parametrize("net,precision,tol", [("model", "bf16x3", 2e-5), ("unet", "bf16", 1e-3), ("model", "bf16", 1e-3)])
+def test_two_rank_other_networks_and_modes(tmp_path, net, precision, tol):
+    """The CIFAR `Model` path (ResnetBlockFn / AttnBlockFn announce their parameters too) and the bf16 arithmetic mode under the
+    same two-rank exchange: replicas bit-identical, and the weights after two steps (lr 1e-3: every weight moved by ~2e-3) within
+    `tol` of the global-batch fp32 oracle for all but 0.2 % of the elements (Adam's first steps move a
+    weight by ~lr whatever its gradient's magnitude, so the few elements whose gradient is at the rounding level -- biases in front of
+    a GroupNorm, time-MLP rows -- may differ by a fraction of lr = 1e-3; a lost or doubled shard would move most elements by ~lr)."""
+    _two_rank_case(tmp_path, 1024, "once", 8, hip=False, net=net, precision=precision, tol=tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("net,precision,tol", [("model", "bf16x3", 2e-5), ("unet", "bf16", 1e-3)])
+def test_two_rank_other_networks_and_modes_on_the_gpu(tmp_path, net, precision, tol):
+    _two_rank_case(tmp_path, 1024, "once", 8, hip=True, net=net, precision=precision, tol=tol)
+
+
+def _two_rank_case(tmp_path, bucket_bytes, mode, min_buckets, hip, net="unet", precision="bf16x3", tol=2e-5):
     out, nsteps = str(tmp_path / "w.pt"), 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(HERE, "dp_worker.py"), out, str(nsteps), str(bucket_bytes), mode] + (["hip"] if hip else [])
-    env = dict(os.environ, OMP_NUM_THREADS="2")
+           "--master-port", str(_free_port()), os.path.join(HERE, "dp_worker.py"), out, str(nsteps), str(bucket_bytes), mode,
+           "hip" if hip else "emu", net, precision]
+    env = dict(os.environ, OMP_NUM_THREADS="2", COLDDIFF_SHARE_GPU="1")      # (both ranks on cuda:0 in the hip runs)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     r0, r1 = torch.load(out + ".rank0"), torch.load(out + ".rank1")
@@ -69,20 +86,33 @@ def _two_rank_case(tmp_path, bucket_bytes, mode, min_buckets, hip):
     # single-process oracle over the global batch: 2 ranks x 2 micro-steps = accumulate 4
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "cold-diffusion-models_amd"))
     from colddiff.unet import Unet
+    from colddiff.model2 import Model
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
-        sd0 = {k: v.clone() for k, v in Unet(dim=8, dim_mults=(1, 2), channels=3).state_dict().items()}
+        if net == "model":
+            m = Model(ch=32, out_ch=3, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(4,), dropout=0.0, in_channels=3, resolution=8)
+            fwd = lambda p, x, t: O.model_forward(p, x, t, num_res_blocks=1, num_resolutions=2)
+        else:
+            m = Unet(dim=8, dim_mults=(1, 2), channels=3)
+            fwd = O.unet_forward
+        sd0 = {k: v.clone() for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(1)
     batches = [[[(torch.rand(2, 3, 8, 8, generator=g) * 2 - 1, torch.randn(2, 3, 8, 8, generator=g), torch.randint(0, 10, (2,), generator=g))
                  for _ in range(2)] for _ in range(2)] for _ in range(nsteps)]
     ca, cb = O.cosine_tables(10)
 
     def one(p, x, e, t):
-        return O.loss_fn(x, O.unet_forward(p, O.noise_q_sample(x, e, t, ca, cb), t))
+        return O.loss_fn(x, fwd(p, O.noise_q_sample(x, e, t, ca, cb), t))
 
     loss = one if mode == "once" else (lambda p, x, e, t: one(p, x, e, t) + one(p, x, -e, t))
     otr = O.OracleTrainer(sd0, loss, lr=1e-3, accumulate=4)
     for s in range(nsteps):
         otr.train_step([b for rank_b in batches[s] for b in rank_b])
+    bad = total = 0
     for k in sd0:
-        assert (w0[k] - otr.params[k].detach()).abs().max() <= 2e-5, k
+        err = (w0[k] - otr.params[k].detach()).abs()
+        if net == "unet" and precision == "bf16x3":
+            assert err.max() <= tol, (k, float(err.max()))
+        bad, total = bad + int((err > tol).sum()), total + err.numel()
+        assert err.max() <= 4.2e-3, (k, float(err.max()))         # (two steps of +-lr on either side bound any element)
+    assert bad <= (0.002 if precision == 'bf16x3' else 0.05) * total, (bad, total)   # (bf16 mode: 2-3 % of a tensor's max per gradient element)
