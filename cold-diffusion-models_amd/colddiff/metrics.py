@@ -2,9 +2,10 @@
 (deblurring_diffusion_pytorch.py:1677-1702 with Fid/fid_score.py:149-343 and pytorch_msssim.ssim).
 
 * rmse / ssim run on the MI355X (cdf_loss_fwd, cdf_ssim_partial); there is no CPU fallback.
-* FID = Frechet distance between the Gaussians fitted to InceptionV3 pool3 activations.  The activation statistics and the distance
-  are here; the InceptionV3 network itself needs the pretrained `pt_inception-2015-12-05` weights (a download in the reference,
-  Fid/inception.py) which this offline build cannot fetch: pass any feature extractor `model(batch [B,3,H,W] in [0,1]) -> [B, dims]`.
+* FID = Frechet distance between the Gaussians fitted to InceptionV3 activations: the network is colddiff.inception.InceptionV3 (the
+  reference's Fid/inception.py on the HIP kernels); its pretrained `pt_inception-2015-12-05` weights are a download upstream and are
+  read from a local file here ($COLDDIFF_FID_WEIGHTS / torch hub cache).  Any other feature extractor
+  `model(batch [B,3,H,W] in [0,1]) -> [B, dims]` (or a list of maps) can be passed as `model=`.
 """
 import ctypes
 import math
@@ -90,11 +91,11 @@ def calculate_activation_statistics(samples, model, batch_size=50, dims=2048, de
 
 
 def calculate_fid_given_samples(samples, batch_size=50, device='cuda:0', dims=2048, num_workers=1, model=None):
-    """FID of two sample collections `samples = [A, B]` (Fid/fid_score.py:331-343).  `model`: the feature extractor (InceptionV3
-    pool3 in the reference; its pretrained weights cannot be downloaded here, so it has to be supplied)."""
+    """FID of two sample collections `samples = [A, B]` (Fid/fid_score.py:331-343).  `model`: a feature extractor to use instead of
+    InceptionV3([BLOCK_INDEX_BY_DIM[dims]])."""
     if model is None:
-        raise RuntimeError("calculate_fid_given_samples: pass model=<feature extractor>; the pretrained InceptionV3 weights "
-                           "(pt_inception-2015-12-05, downloaded by the reference's Fid/inception.py) are not available offline")
+        from .inception import InceptionV3
+        model = InceptionV3([InceptionV3.BLOCK_INDEX_BY_DIM[dims]]).to(device)          # raises FileNotFoundError without the weight file
     m1, s1 = calculate_activation_statistics(samples[0], model, batch_size, dims, device)
     m2, s2 = calculate_activation_statistics(samples[1], model, batch_size, dims, device)
     return calculate_frechet_distance(m1, s1, m2, s2)

@@ -86,6 +86,9 @@ __device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph
         } else if (a.act == 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = cdf_silu(v[e]);
+        } else if (a.act == 3) {                             // ReLU (the FID InceptionV3's BasicConv2d, Fid/inception.py)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f); // relu
         }
         if (a.mul_mode) {
             cdf_ld4(u, a.mul + opix * a.ldm + co, nval, vec);

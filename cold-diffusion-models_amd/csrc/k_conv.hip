@@ -41,7 +41,7 @@ struct ConvArgs {
     const float* mul;    // nullable: epilogue multiplier source (activation-gradient fusion)
     int ldx, ldw, ldy, ld_sbias, ldr, ldp, ldm;
     int B, H, W, Cin, OH, OW, Cout, QH, QW, os, is;
-    int act;         // 0 none, 1 GELU, 2 SiLU
+    int act;         // 0 none, 1 GELU, 2 SiLU, 3 ReLU
     int mul_mode;    // 0 none, 1 v*=gelu'(mul), 2 v*=silu'(mul), 3 v*=mul
     int accumulate;  // y += v
     int nphase, vec;

@@ -29,13 +29,13 @@ __global__ void sinusoidal_kernel(const int64_t* t, const float* freq, float* ou
     }
 }
 
-// y = act(x) / dx = dy * act'(x) on row-major [rows, C] with pitches; act 1 GELU, 2 SiLU
+// y = act(x) / dx = dy * act'(x) on row-major [rows, C] with pitches; act 1 GELU, 2 SiLU, 3 ReLU (forward only: the FID extractor)
 __global__ void act_fwd_kernel(const float* x, int ldx, float* y, int ldy, long long rows, int C, int act) {
     CDF_EW_LOOP(i, rows * C) {
         const long long r = i / C;
         const int c = (int)(i % C);
         const float v = x[r * ldx + c];
-        y[r * ldy + c] = act == 1 ? cdf_gelu(v) : cdf_silu(v);
+        y[r * ldy + c] = act == 1 ? cdf_gelu(v) : (act == 2 ? cdf_silu(v) : fmaxf(v, 0.0f));
     }
 }
 __global__ void act_bwd_kernel(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, long long rows,
@@ -267,7 +267,7 @@ extern "C" int cdf_linear_small_wgrad(const float* dy, int ldd, const float* x, 
 }
 
 extern "C" int cdf_act_fwd(const float* x, int ldx, float* y, int ldy, long long rows, int C, int act, void* stream) {
-    CDF_REQUIRE(x && y && rows > 0 && C > 0 && (act == 1 || act == 2), "cdf_act_fwd: bad args");
+    CDF_REQUIRE(x && y && rows > 0 && C > 0 && act >= 1 && act <= 3, "cdf_act_fwd: bad args");
     CDF_LAUNCH(act_fwd_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, CDF_S, x, ldx, y, ldy, rows, C, act);
     return cdf_check_launch("act_fwd");
 }

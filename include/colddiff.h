@@ -110,7 +110,7 @@ int cdf_nhwc_to_nchw(const float* x, float* y, const float* add, int B, int C, i
  *   output pixel (qy*os+oy, qx*os+ox) of an OHxOW map.  phase_desc = per phase
  *   [oy, ox, ntaps, (dy, dx, wi) x ntaps] (ints, host memory).  Wp is [tap][Cin][ldw] (cdf_pack_weight)
  *   or, with b_trans, a plain [Cout][ldw>=Cin] matrix (one tap).  Epilogue, in order:
- *   v = acc + bias[co] + sbias[b][co]; pre = v; v = act(v) (1 GELU, 2 SiLU);
+ *   v = acc + bias[co] + sbias[b][co]; pre = v; v = act(v) (1 GELU, 2 SiLU, 3 ReLU);
  *   v *= {1: gelu'(mul), 2: silu'(mul), 3: mul}; v += res; accumulate ? y += v : y = v.
  *   batch * batch2 independent GEMMs run in one launch (blockIdx.z = outer*batch2 + inner) with element
  *   strides x_bs / w_bs / y_bs (outer) and x_bs2 / w_bs2 / y_bs2 (inner, e.g. attention heads). */
@@ -234,6 +234,18 @@ int cdf_augment_batch(const void* cache, long long N, int S, int C, const long l
  * (Dataset_Aug2: Resize(s), RandomCrop(s, padding=4)) and defading_diffusion_gaussian.py:579-599 (DatasetCifar10). */
 int cdf_augment_batch_pad(const void* cache, long long N, int SH, int SW, int C, int pad, const long long* idx, const int* oy,
                           const int* ox, const int* flip, float* out, int B, int H, int W, void* stream);
+
+/* The non-GEMM layers of the FID feature extractor (deblurring-diffusion-pytorch/Fid/inception.py:16-328; its BasicConv2d layers are the
+ * conv GEMM entry points with act = 3 (ReLU) and BatchNorm folded into weight / bias).  Feature maps are NHWC fp32 with a pixel pitch.
+ *   cdf_pool2d: k x k window, `stride`, zero `pad` (OH = (H + 2 pad - k) / stride + 1); mode 0 = max (nn.MaxPool2d(3, 2), inception.py:91, 100;
+ *               F.max_pool2d(x, 3, 1, 1), inception.py:323), mode 1 = average over the taps inside the image
+ *               (F.avg_pool2d(..., count_include_pad=False), inception.py:214, 243, 282).  C, ldx, ldy multiples of 4.
+ *   cdf_global_avgpool: y[b][c] = mean over HW pixels (nn.AdaptiveAvgPool2d((1, 1)), inception.py:122).
+ *   cdf_resize_bilinear_nhwc: x NCHW [B][C][H][W] -> y NHWC [B][OH][OW] (pitch ldy), F.interpolate(size, mode='bilinear',
+ *               align_corners=False) followed by mul * v + add (inception.py:146-153: 2 x - 1). */
+int cdf_pool2d(const float* x, int ldx, float* y, int ldy, int B, int H, int W, int C, int k, int stride, int pad, int mode, void* stream);
+int cdf_global_avgpool(const float* x, int ldx, float* y, int ldy, int B, int HW, int C, void* stream);
+int cdf_resize_bilinear_nhwc(const float* x, float* y, int ldy, int B, int C, int H, int W, int OH, int OW, float mul, float add, void* stream);
 
 /* Metric step after sampling (deblurring_diffusion_pytorch.py:1677-1702): SSIM as pytorch_msssim.ssim computes it (11-tap Gaussian
  * window sigma 1.5 given by the caller as 11 HOST floats, "valid" filtering along H then W, C1 = (0.01 L)^2, C2 = (0.03 L)^2).
@@ -394,7 +406,7 @@ int cdf_pack_cin4(const float* w, float* dst, int ldw, int Cout, int Cin, int k,
 int cdf_linear_small(const float* in, int ldi, const float* Wm, int ldw, const float* bias, float* out, int ldo, int M, int I, int J,
                      void* stream);
 int cdf_linear_small_wgrad(const float* dy, int ldd, const float* x, int ldx, float* dW, float* db, int M, int N, int K, void* stream);
-/* act 1 = exact GELU, 2 = SiLU on [rows, C] with pitches */
+/* act 1 = exact GELU, 2 = SiLU, 3 = ReLU (forward only) on [rows, C] with pitches */
 int cdf_act_fwd(const float* x, int ldx, float* y, int ldy, long long rows, int C, int act, void* stream);
 int cdf_act_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, long long rows, int C, int act,
                 int accumulate, void* stream);
