@@ -280,6 +280,160 @@ def extra_cases(net_sd):
     return out
 
 
+def ssim_msssim(X, Y, data_range=1.0, size_average=True, win_size=11, win_sigma=1.5, K=(0.01, 0.03)):
+    """pytorch_msssim 0.2.x `ssim` restated with torch ops (the package is not installed; the reference imports it at DEBLUR:1570):
+    _fspecial_gauss_1d, gaussian_filter = grouped 'valid' conv along H then W, _ssim.  Third-party, unpinned upstream."""
+    import torch.nn.functional as F
+    coords = torch.arange(win_size, dtype=torch.float32) - win_size // 2
+    g = torch.exp(-(coords ** 2) / (2 * win_sigma ** 2))
+    g = g / g.sum()
+    C = X.shape[1]
+
+    def filt(z):
+        z = F.conv2d(z, g.view(1, 1, -1, 1).repeat(C, 1, 1, 1), groups=C)
+        return F.conv2d(z, g.view(1, 1, 1, -1).repeat(C, 1, 1, 1), groups=C)
+
+    C1, C2 = (K[0] * data_range) ** 2, (K[1] * data_range) ** 2
+    mu1, mu2 = filt(X), filt(Y)
+    s1, s2, s12 = filt(X * X) - mu1 * mu1, filt(Y * Y) - mu2 * mu2, filt(X * Y) - mu1 * mu2
+    m = ((2 * mu1 * mu2 + C1) / (mu1 * mu1 + mu2 * mu2 + C1)) * ((2 * s12 + C2) / (s1 + s2 + C2))
+    per = m.flatten(2).mean(-1)
+    return per.mean() if size_average else per.mean(1)
+
+
+def evaluation_cases(net_sd):
+    """The deterministic parts of the reference Trainer's evaluation methods, captured by
+    running the UNMODIFIED methods on a reference Trainer object whose dataset is a fixed in-memory list of images:
+      * sample_as_a_mean_blur_torch_gmm_ablation (DEBLUR:1391-1456): the channel-mean matrix handed to the GMM's fit()
+      * sample_as_a_blur_torch_gmm (DEBLUR:1514-1564): the opt()-feature matrix handed to fit(), and -- with the GMM's sample() fixed --
+        the og / xt / direct_recons / recon images it saves
+      * fid_distance_decrease_from_manifold (DEBLUR:1567-1702): the four image sets handed to fid_func and to ssim, and the RMSE / SSIM
+        numbers it prints (SSIM through the restatement of pytorch_msssim above)
+    Harness notes: the GMM (pycave upstream) is a capturing stand-in; `pdb.set_trace()` (DEBLUR:1420) is a no-op; `utils.save_image`
+    captures; `torch.cuda.FloatTensor` is torch.FloatTensor on this CPU-only box; and F.interpolate's hard-coded `size=128`
+    (DEBLUR:1546: CelebA's image size) is mapped to this case's image_size 16 -- a 128 x 128 fixture set would be 20 MB."""
+    import contextlib
+    import io
+    import pathlib
+    import pdb
+    import tempfile
+    import types
+    out = {}
+    ref = ref_shim.load("deblurring")
+    mod = sys.modules[ref.Trainer.__module__]
+    S, T = 16, 3
+    g = torch.Generator().manual_seed(SEED + 21)
+    imgs = images(104, 3, S, g)                                   # 104 images: one DataLoader batch of 100 (drop_last) + 4 dropped
+    net = ref.Unet(dim=8, dim_mults=(1, 2), channels=3)
+    net.load_state_dict(net_sd)
+    d = ref.GaussianDiffusion(net, image_size=S, device_of_kernel="cpu", channels=3, timesteps=T, kernel_std=0.5, kernel_size=3,
+                              blur_routine="Incremental", sampling_routine="x0_step_down")
+    out["cfg"] = dict(image_size=S, T=T, kernel_std=0.5, kernel_size=3, blur_routine="Incremental", sampling_routine="x0_step_down")
+    out["images"] = imgs
+    out["kernels"] = [m.weight.detach().clone() for m in d.gaussian_kernels]
+
+    class ListDS(torch.utils.data.Dataset):
+        def __len__(self):
+            return imgs.shape[0]
+
+        def __getitem__(self, i):
+            return imgs[i]
+
+    tr = object.__new__(ref.Trainer)
+    tr.ds, tr.batch_size, tr.image_size = ListDS(), 4, S
+    tr.ema_model = types.SimpleNamespace(module=d)
+    tmp = tempfile.mkdtemp()
+    tr.results_folder = pathlib.Path(tmp) / "res"
+
+    saved = []
+    F_real = mod.F
+
+    class FProxy:
+        def __getattr__(self, k):
+            return getattr(F_real, k)
+
+        @staticmethod
+        def interpolate(x, size=None, **kw):
+            return F_real.interpolate(x, size=S if size == 128 else size, **kw)
+
+    class Stop(Exception):
+        pass
+
+    fixed = {}
+
+    class CaptureGMM:
+        last_fit = None
+
+        def __init__(self, **kw):
+            self.kw = kw
+
+        def fit(self, x):
+            CaptureGMM.last_fit = x.detach().clone()
+            if fixed.get("stop"):
+                raise Stop()
+
+        def sample(self, num_datapoints):
+            return fixed["og_x"][:num_datapoints].clone()
+
+        def get_params(self):
+            return {}
+
+    old = (mod.F, mod.utils.save_image, pdb.set_trace, torch.cuda.FloatTensor, sys.modules["pytorch_msssim"].ssim, mod.create_folder)
+    mod.F = FProxy()
+    mod.utils.save_image = lambda t, path, **kw: saved.append((os.path.basename(str(path)), t.detach().clone()))
+    pdb.set_trace = lambda *a, **k: None
+    torch.cuda.FloatTensor = torch.FloatTensor
+    ssim_calls = []
+
+    def ssim_capture(X, Y, **kw):
+        v = ssim_msssim(X, Y, **kw)
+        ssim_calls.append(v.clone())
+        return v
+
+    sys.modules["pytorch_msssim"].ssim = ssim_capture
+    mod.create_folder = lambda p: None
+    quiet = contextlib.redirect_stdout(io.StringIO())
+    try:
+        with torch.no_grad(), quiet:
+            # -- channel means (the ablation sampler stops at fit: its 6400-sample loop at 128 x 128 is not run) ------------
+            fixed["stop"] = True
+            try:
+                tr.sample_as_a_mean_blur_torch_gmm_ablation(CaptureGMM, ch=3, clusters=2, noise=0)
+            except Stop:
+                pass
+            out["channel_means"] = CaptureGMM.last_fit
+            # -- opt features + sample_from_blur with a fixed GMM sample -----------------------------------------------
+            fixed["stop"] = False
+            siz, sample_at = 4, 1
+            fixed["og_x"] = torch.randn(48, 3 * siz * siz, generator=g) * 0.3
+            saved.clear()
+            tr.sample_as_a_blur_torch_gmm(CaptureGMM, siz=siz, ch=3, clusters=2, sample_at=sample_at)
+            out["blur_gmm"] = dict(siz=siz, sample_at=sample_at, clusters=2, feats=CaptureGMM.last_fit, og_x=fixed["og_x"],
+                                   saved={name.split("-")[1]: t for name, t in saved})
+            # -- the metric sweep ------------------------------------------------------------------------------------
+            fid_calls = []
+
+            def fid_func(samples):
+                fid_calls.append([z.clone() for z in samples])
+                return float(len(fid_calls))
+
+            saved.clear()
+            cwd = os.getcwd()
+            os.chdir(tmp)                                                # (the method writes ./sanity_check/)
+            try:
+                tr.fid_distance_decrease_from_manifold(fid_func, start=0, end=40)
+            finally:
+                os.chdir(cwd)
+            orig = fid_calls[0][0]
+            sets = dict(orig=orig, blur=fid_calls[0][1], deblur=fid_calls[1][1], direct_deblur=fid_calls[2][1])
+            out["sweep"] = dict(start=0, end=40, sets=sets,
+                                rmse={k: torch.sqrt(torch.mean((orig - sets[k]) ** 2)) for k in ("blur", "deblur", "direct_deblur")},
+                                ssim=dict(zip(("blur", "deblur", "direct_deblur"), ssim_calls)))
+    finally:
+        mod.F, mod.utils.save_image, pdb.set_trace, torch.cuda.FloatTensor, sys.modules["pytorch_msssim"].ssim, mod.create_folder = old
+    return out
+
+
 def main():
     assert ref_shim.available(), "needs /root/reference (build container)"
     if "--mixing" in sys.argv:                                        # only (re)write mixing.pt
@@ -291,6 +445,11 @@ def main():
         sd = torch.load(os.path.join(HERE, "diffusion.pt"), weights_only=False)["deblur/net_sd"]
         torch.save(extra_cases(sd), os.path.join(HERE, "extras.pt"))
         print("extras.pt", os.path.getsize(os.path.join(HERE, "extras.pt")) // 1024, "KiB")
+        return
+    if "--evaluation" in sys.argv:                                    # only (re)write evaluation.pt
+        sd = torch.load(os.path.join(HERE, "diffusion.pt"), weights_only=False)["deblur/net_sd"]
+        torch.save(evaluation_cases(sd), os.path.join(HERE, "evaluation.pt"))
+        print("evaluation.pt", os.path.getsize(os.path.join(HERE, "evaluation.pt")) // 1024, "KiB")
         return
     if "--variants" in sys.argv:                                      # only (re)write variants.pt
         sd = torch.load(os.path.join(HERE, "diffusion.pt"), weights_only=False)["deblur/net_sd"]
@@ -305,6 +464,7 @@ def main():
     torch.save(variant_cases(dc["deblur/net_sd"]), os.path.join(HERE, "variants.pt"))
     torch.save(mixing_cases(dc["deblur/net_sd"]), os.path.join(HERE, "mixing.pt"))
     torch.save(extra_cases(dc["deblur/net_sd"]), os.path.join(HERE, "extras.pt"))
+    torch.save(evaluation_cases(dc["deblur/net_sd"]), os.path.join(HERE, "evaluation.pt"))
     # torchgeometry boundary: values observed when the reference builds its kernels through the shim
     k = ref_shim.get_gaussian_kernel2d((11, 11), (7.0, 7.0))
     print("k=11 sigma=7 centre %.10f corner %.10f" % (k[5, 5].item(), k[0, 0].item()))

@@ -77,25 +77,23 @@ def test_frechet_distance_and_fid_plumbing():
     A, B = torch.rand(40, 3, 8, 8), torch.rand(40, 3, 8, 8) * 0.5
     fid = metrics.calculate_fid_given_samples([A, B], batch_size=16, device='cpu', dims=3, model=feat)
     assert fid > 0 and abs(metrics.calculate_fid_given_samples([A, A], batch_size=16, device='cpu', dims=3, model=feat)) < 1e-8
-    with pytest.raises(RuntimeError, match="feature extractor"):
+    with pytest.raises(FileNotFoundError, match="pt_inception-2015-12-05"):      # no weight file offline: an error, not a random network
         metrics.calculate_fid_given_samples([A, B], device='cpu')
 
 
-def test_evaluation_samplers_on_a_folder(tmp_path):
-    """The reference Trainer's evaluation methods end to end on a folder of PNGs (simulator kernels): GMM samplers, the
-    degrade->restore metric sweep, test_from_data, save_training_data."""
+def test_evaluation_samplers_on_a_folder(tmp_path, dev):
+    """The reference Trainer's evaluation methods end to end on a folder of PNGs (emu: simulator kernels, hip: the MI355X with the
+    device-side image cache): GMM samplers, the degrade->restore metric sweep, test_from_data, save_training_data."""
     from colddiff import runtime
-    from emu_util import install_emu
-    install_emu()
     try:
         from deblurring_diffusion_pytorch import GaussianDiffusion, Trainer, Unet
         folder = str(tmp_path / "imgs")
         _write_images(folder, 8)
         torch.manual_seed(0)
         with contextlib.redirect_stdout(io.StringIO()):
-            net = Unet(dim=8, dim_mults=(1, 2), channels=3)
-            d = GaussianDiffusion(net, image_size=16, device_of_kernel="cpu", channels=3, timesteps=3, kernel_size=3, kernel_std=0.5,
-                                  sampling_routine="x0_step_down")
+            net = Unet(dim=8, dim_mults=(1, 2), channels=3).to(dev)
+            d = GaussianDiffusion(net, image_size=16, device_of_kernel=str(dev), channels=3, timesteps=3, kernel_size=3, kernel_std=0.5,
+                                  sampling_routine="x0_step_down").to(dev)
             tr = Trainer(d, folder, image_size=16, train_batch_size=4, train_num_steps=1, dataset="train", results_folder=str(tmp_path / "res"),
                          num_workers=0, device_data=True)
             res = tr.fid_distance_decrease_from_manifold(fid_func=None, start=-1, end=5, batch=4)
@@ -112,4 +110,80 @@ def test_evaluation_samplers_on_a_folder(tmp_path):
         names = os.listdir(str(tmp_path / "res"))
         assert "Gif-t-x0.gif" in names and "sample-recon-1-2-2.png" in names and "7.png" in names and "sample-xt-0.001-0-0.png" in names
     finally:
-        runtime._lib_override = None
+        pass
+
+
+def test_evaluation_samplers_vs_reference_golden(dev):
+    """tests/golden/evaluation.pt holds what the UNMODIFIED reference Trainer methods computed on a fixed in-memory dataset
+    (make_golden.py::evaluation_cases): the channel-mean matrix and the opt()-feature matrix handed to the GMM, the images
+    sample_as_a_blur_torch_gmm saves for a fixed GMM sample, and the image sets / RMSE / SSIM of fid_distance_decrease_from_manifold.
+    The same methods of this package's Trainer must reproduce them (emu: simulator kernels; hip: the MI355X)."""
+    from deblurring_diffusion_pytorch import GaussianDiffusion, Trainer, Unet
+    G = torch.load(os.path.join(os.path.dirname(__file__), "golden", "evaluation.pt"), weights_only=False)
+    sd = torch.load(os.path.join(os.path.dirname(__file__), "golden", "diffusion.pt"), weights_only=False)["deblur/net_sd"]
+    cfg, imgs = G["cfg"], G["images"]
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = Unet(dim=8, dim_mults=(1, 2), channels=3)
+        net.load_state_dict(sd)
+        d = GaussianDiffusion(net, image_size=cfg["image_size"], device_of_kernel=str(dev), channels=3, timesteps=cfg["T"],
+                              kernel_std=cfg["kernel_std"], kernel_size=cfg["kernel_size"], blur_routine=cfg["blur_routine"],
+                              sampling_routine=cfg["sampling_routine"]).to(dev)
+        for m, w in zip(d.gaussian_kernels, G["kernels"]):
+            assert torch.equal(m.weight.detach().cpu(), w)
+        tr = Trainer(d, None, image_size=cfg["image_size"], train_batch_size=4, train_num_steps=1, dataset="synthetic",
+                     results_folder=os.path.join(tmp, "res"))
+
+    class ListDS(torch.utils.data.Dataset):
+        def __len__(self):
+            return imgs.shape[0]
+
+        def __getitem__(self, i):
+            return imgs[i]
+
+    tr.ds = ListDS()
+    # -- channel means (DEBLUR:1399-1405) ------------------------------------------------------------------------------
+    cm = tr._channel_means(100).cpu()
+    assert cm.shape == G["channel_means"].shape == (100, 3)
+    assert (cm - G["channel_means"]).abs().max() <= 1e-6
+
+    # -- sample_as_a_blur_torch_gmm with the reference's GMM sample replayed (DEBLUR:1514-1564) ---------------------------
+    bg = G["blur_gmm"]
+    fits = []
+
+    class ReplayGMM:
+        def __init__(self, **kw):
+            assert kw["num_components"] == bg["clusters"] and kw["covariance_regularization"] == 0.0001 and kw["batch_size"] == 100
+
+        def fit(self, x):
+            fits.append(x.detach().cpu().clone())
+
+        def sample(self, num_datapoints):
+            return bg["og_x"][:num_datapoints].clone()
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        xt, direct, recon = tr.sample_as_a_blur_torch_gmm(ReplayGMM, siz=bg["siz"], ch=3, clusters=bg["clusters"], sample_at=bg["sample_at"],
+                                                          num_samples=48)
+    assert fits[0].shape == bg["feats"].shape and (fits[0] - bg["feats"]).abs().max() <= 1e-5
+    for name, got in (("xt", xt), ("direct_recons", direct), ("recon", recon)):
+        want = bg["saved"][name] * 2 - 1                                   # the reference saves (img + 1) / 2
+        assert (got.cpu() - want).abs().max() <= 2e-4, name
+
+    # -- fid_distance_decrease_from_manifold (DEBLUR:1567-1702) ---------------------------------------------------------------
+    sw = G["sweep"]
+    calls = []
+
+    def fid_func(samples):
+        calls.append([z.detach().cpu().clone() for z in samples])
+        return float(len(calls))
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = tr.fid_distance_decrease_from_manifold(fid_func=fid_func, start=sw["start"], end=sw["end"], batch=32)
+    assert len(calls) == 3 and calls[0][0].shape == sw["sets"]["orig"].shape == (40, 3, 16, 16)
+    for i, k in enumerate(("blur", "deblur", "direct_deblur")):
+        assert (calls[i][0] - sw["sets"]["orig"]).abs().max() <= 1e-6
+        assert (calls[i][1] - sw["sets"][k]).abs().max() <= 2e-4, k
+        assert abs(res[f"rmse_{k}"] - float(sw["rmse"][k])) <= 2e-5, (k, res[f"rmse_{k}"], float(sw["rmse"][k]))
+        assert abs(res[f"ssim_{k}"] - float(sw["ssim"][k])) <= 1e-4, (k, res[f"ssim_{k}"], float(sw["ssim"][k]))
+        assert res[f"fid_{k}"] == float(i + 1)
