@@ -547,6 +547,35 @@ class GroupNormFn(torch.autograd.Function):
         return None, dx, None, None
 
 
+class Upsample2Fn(torch.autograd.Function):
+    """F.interpolate(scale_factor=2, mode='nearest') alone: `Upsample(with_conv=False)` (Model2.py:36-50)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.upsample2(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.upsample2_bwd(dy.contiguous())                      # each source pixel collects its 2 x 2 copies
+
+
+class AvgPool2Fn(torch.autograd.Function):
+    """F.avg_pool2d(x, kernel_size=2, stride=2): `Downsample(with_conv=False)` (Model2.py:53-73)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, C = x.shape
+        y = torch.empty((B, H // 2, W // 2, C), device=x.device, dtype=torch.float32)
+        rt.lib().cdf_pool2d(P(rt.check(x)), ops.ld_of(x), P(y), C, B, H, W, C, 2, 2, 0, 1, rt.stream(x))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = ops.upsample2(dy.contiguous())                             # every input pixel gets a quarter of its window's gradient
+        rt.lib().cdf_scale(P(dx), dx.numel(), 0.25, rt.stream(dx))
+        return dx
+
+
 class UpsampleConvFn(torch.autograd.Function):
     """F.interpolate(scale 2, nearest) -> Conv2d 3x3 (Model2.py:36-50); the x2 map is rebuilt in backward."""
 

@@ -18,11 +18,12 @@ class Upsample(nn.Module):
     def __init__(self, in_channels, with_conv):
         super().__init__()
         self.with_conv = with_conv
-        if not with_conv:
-            raise NotImplementedError("resamp_with_conv=False is not used by any reference script")
-        self.conv = torch.nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+        if with_conv:
+            self.conv = torch.nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
 
     def forward(self, x):
+        if not self.with_conv:
+            return F_.Upsample2Fn.apply(x)                  # bare nearest x2 (Model2.py:46-49)
         return F_.UpsampleConvFn.apply(anchor(x), x, self.conv)
 
 
@@ -30,11 +31,12 @@ class Downsample(nn.Module):
     def __init__(self, in_channels, with_conv):
         super().__init__()
         self.with_conv = with_conv
-        if not with_conv:
-            raise NotImplementedError("resamp_with_conv=False is not used by any reference script")
-        self.conv = torch.nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
+        if with_conv:
+            self.conv = torch.nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
 
     def forward(self, x):
+        if not self.with_conv:
+            return F_.AvgPool2Fn.apply(x)                   # F.avg_pool2d(x, 2, 2) (Model2.py:71-72)
         # F.pad(x, (0,1,0,1)) then 3x3 stride 2: the asymmetric zero pad is folded into the gather
         return F_.ConvFn.apply(anchor(x), x, self.conv, x.shape[-1], "conv", 2, (0, 0, 1, 1))
 

@@ -35,9 +35,9 @@ def unet_case(ref):
             "x": x, "t": t, "y": y.detach(), "gy": gy, "grads": grads}
 
 
-def model_case(ref):
+def model_case(ref, **extra):
     torch.manual_seed(SEED)
-    cfg = dict(resolution=8, in_channels=3, out_ch=3, ch=32, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(4,), dropout=0.0)
+    cfg = dict(resolution=8, in_channels=3, out_ch=3, ch=32, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(4,), dropout=0.0, **extra)
     net = ref.Model(**cfg)
     g = torch.Generator().manual_seed(SEED)
     x, t = images(2, 3, 8, g), torch.tensor([0, 9])
@@ -446,6 +446,10 @@ def main():
         torch.save(extra_cases(sd), os.path.join(HERE, "extras.pt"))
         print("extras.pt", os.path.getsize(os.path.join(HERE, "extras.pt")) // 1024, "KiB")
         return
+    if "--model-noconv" in sys.argv:                                  # only (re)write model_noconv.pt: Model(resamp_with_conv=False), MODEL2:36-73
+        torch.save(model_case(ref_shim.load("deblurring"), resamp_with_conv=False), os.path.join(HERE, "model_noconv.pt"))
+        print("model_noconv.pt", os.path.getsize(os.path.join(HERE, "model_noconv.pt")) // 1024, "KiB")
+        return
     if "--evaluation" in sys.argv:                                    # only (re)write evaluation.pt
         sd = torch.load(os.path.join(HERE, "diffusion.pt"), weights_only=False)["deblur/net_sd"]
         torch.save(evaluation_cases(sd), os.path.join(HERE, "evaluation.pt"))
@@ -459,6 +463,7 @@ def main():
     ref = ref_shim.load("deblurring")
     torch.save(unet_case(ref), os.path.join(HERE, "unet_dim8.pt"))
     torch.save(model_case(ref), os.path.join(HERE, "model_ch32.pt"))
+    torch.save(model_case(ref, resamp_with_conv=False), os.path.join(HERE, "model_noconv.pt"))
     dc = diffusion_cases()
     torch.save(dc, os.path.join(HERE, "diffusion.pt"))
     torch.save(variant_cases(dc["deblur/net_sd"]), os.path.join(HERE, "variants.pt"))

@@ -122,9 +122,10 @@ def test_linear_attention_block_all_forms(mbe, dim, H):
         F_._ATTN_FUSED, F_._ATTN_QFOLD = saved
 
 
-def test_model_golden(mbe):
+@pytest.mark.parametrize("fixture", ["model_ch32.pt", "model_noconv.pt"])       # the latter: resamp_with_conv=False (avg-pool down, bare nearest up)
+def test_model_golden(mbe, fixture):
     from deblurring_diffusion_pytorch import Model
-    g = load("model_ch32.pt")
+    g = load(fixture)
     net = Model(**g["cfg"])
     assert list(net.state_dict().keys()) == list(g["sd"].keys())
     net.load_state_dict(g["sd"])
