@@ -503,14 +503,18 @@ def dwconv7(x, wp, bias, sbias, flip=0, y=None, accumulate=0, res=None):
     return y
 
 
-def dwconv7_wgrad(x, dy, w_param, b_param, want_dsb):
+def dwconv7_wgrad(x, dy, w_param, b_param, want_dsb, dsb_out=None):
+    """Accumulates weight / bias gradients; returns the per-sample bias gradient [B, Cp] (written into `dsb_out`, a [B, Cp] view with
+    any row pitch whose pad columns are already zero, when given)."""
     L = rt.lib()
     B, H, W, Cp = x.shape
     C = w_param.shape[0]
     ws = torch.empty((B * L.cdf_dwconv7_wgrad_nchunk(H) * 50 * C,), device=x.device, dtype=torch.float32)
-    dsb = torch.zeros((B, Cp), device=x.device, dtype=torch.float32) if want_dsb else None
-    L.cdf_dwconv7_wgrad(P(x), ld_of(x), P(dy), ld_of(dy), P(grad_of(w_param)), P(grad_of(b_param)), P(dsb), Cp, P(ws), B, H, W, C,
-                        1, rt.stream(x))
+    dsb = None
+    if want_dsb:
+        dsb = dsb_out if dsb_out is not None else torch.zeros((B, Cp), device=x.device, dtype=torch.float32)
+    L.cdf_dwconv7_wgrad(P(x), ld_of(x), P(dy), ld_of(dy), P(grad_of(w_param)), P(grad_of(b_param)), P(dsb),
+                        0 if dsb is None else dsb.stride(0), P(ws), B, H, W, C, 1, rt.stream(x))
     return dsb
 
 

@@ -41,6 +41,7 @@ class _Anchor(nn.Module):
 
 
 _CONCAT_FREE = __import__("os").environ.get("CDF_CONCAT_FREE", "1") != "0"
+_TIME_BIAS_ALL = __import__("os").environ.get("CDF_TIME_BIAS_ALL", "1") != "0"     # one launch for every block's time-bias Linear
 
 
 def anchor(t):
@@ -105,11 +106,10 @@ class ConvNextBlock(nn.Module):
         self.has_norm = norm
         self.has_res_conv = dim != dim_out
 
-    def forward(self, x, gelu_t=None, dest=None):
+    def forward(self, x, gelu_t=None, dest=None, tb=None):
         """x: NHWC feature map; gelu_t: GELU(time embedding) [B, time_dim] (shared by all blocks); dest: CatBuf whose first half
-        receives the output."""
-        tb = None
-        if exists(self.mlp):
+        receives the output; tb: this block's time bias when the caller computed all of them in one launch (F_.TimeBiasAll)."""
+        if tb is None and exists(self.mlp):
             assert exists(gelu_t), "time emb must be passed in"
             tb = F_.Linear.apply(anchor(x), gelu_t, self.mlp[1])
         return F_.ConvNextBlockFn.apply(anchor(x), x, tb, self, dest)
@@ -203,10 +203,20 @@ class Unet(nn.Module):
         # Skip connections without copies (DEBLUR:266, 274): the skip tensor of every level an up stage consumes is produced INSIDE its
         # concat buffer (second half), and the producer of the tensor it is concatenated with writes the first half (F_.CatBuf).
         nskip = len(self.ups)                                  # (the first level's skip is appended upstream but never consumed)
+        # every block's time bias in one launch (the blocks share GELU(t_emb)); tbs: block -> its [B, r4(dim)] column slice
+        tbs = {}
+        if _TIME_BIAS_ALL and gt is not None:
+            if "_tb_blocks" not in self.__dict__:
+                blocks = [b for stage in self.downs for b in stage[:2]] + [self.mid_block1, self.mid_block2] + \
+                         [b for stage in self.ups for b in stage[:2]]
+                self.__dict__["_tb_blocks"] = [b for b in blocks if exists(b.mlp)]
+                self.__dict__["_tb_lins"] = [b.mlp[1] for b in self._tb_blocks]
+            tbs = dict(zip(map(id, self._tb_blocks), F_.TimeBiasAll.apply(a, gt, self)))
+        T = lambda blk: tbs.get(id(blk))
         h = []
         for lvl, (convnext, convnext2, attn, downsample) in enumerate(self.downs):
-            x = convnext(x, gt)
-            x = convnext2(x, gt)
+            x = convnext(x, gt, tb=T(convnext))
+            x = convnext2(x, gt, tb=T(convnext2))
             cat = None
             if _CONCAT_FREE and lvl >= len(self.downs) - nskip:
                 B_, H_, W_, C_ = x.shape
@@ -216,15 +226,15 @@ class Unet(nn.Module):
             if not isinstance(downsample, nn.Identity):
                 x = F_.ConvFn.apply(a, x, downsample, x.shape[-1], "conv", 2, (1, 1, 1, 1))
 
-        x = self.mid_block1(x, gt)
+        x = self.mid_block1(x, gt, tb=T(self.mid_block1))
         x = self.mid_attn(x)
-        x = self.mid_block2(x, gt, h[-1][1])                   # (its output is the first half of the deepest concat)
+        x = self.mid_block2(x, gt, h[-1][1], tb=T(self.mid_block2))     # (its output is the first half of the deepest concat)
 
         for j, (convnext, convnext2, attn, upsample) in enumerate(self.ups):
             skip, cat = h.pop()
             x = F_.Join.apply(x, skip, cat) if cat is not None else F_.Concat.apply(x, skip)
-            x = convnext(x, gt)
-            x = convnext2(x, gt)
+            x = convnext(x, gt, tb=T(convnext))
+            x = convnext2(x, gt, tb=T(convnext2))
             x = attn(x)
             if not isinstance(upsample, nn.Identity):
                 nxt = h[-1][1] if j + 1 < len(self.ups) else None      # the next stage's concat buffer takes the upsampled map

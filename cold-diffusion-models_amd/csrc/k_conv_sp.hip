@@ -2730,6 +2730,11 @@ static std::atomic<int> g_spx_halo{47};                    // 3 x 3 stride-1 lay
                                                // > 64-channel outputs at width 128; 64: the row-halo kernel wherever it applies
                                                // (tuning / test hook)
 static std::atomic<long long> g_spx_halo_min_tiles{1};
+static std::atomic<int> g_spx_small_n64{1};                // LDS-resident-input kernel: 64-wide N tiles for grids below ~2/3 of the CUs (tuning / test hook)
+extern "C" int cdf_conv_gemm_bf16x_small_n64(int enable) {
+    g_spx_small_n64 = enable ? 1 : 0;
+    return 0;
+}
 static std::atomic<int> g_spx_halo_bm{0};                  // 0 = automatic, 128 / 256 = forced tile height of the halo kernel
 
 extern "C" int cdf_conv_gemm_bf16x_halo_bm(int bm) {
@@ -2838,9 +2843,14 @@ static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cou
     a.dephase = g_spx_dephase;
     // 3 x 3 stride-1 layers whose rows tile into 128-pixel strips: input tile resident in LDS (conv_igemm_halo_kernel)
     if (g_spx_halo && is3x3 && !g_spx_bm && QW == W && QH == H && Cin % 32 == 0 && Cin >= 64 && M % 128 == 0) {
+        const bool n64_in = n64;
         int dxs = 0;
         for (int t = 0; t < 9; ++t) dxs |= 1 << (a.ph[0].dx[t] + 1);
         const bool dx_ok = dxs == 7;                         // (is3x3: three groups of equal dy in {-1, 0, 1})
+        // Small grids (sampling batches, the 16 x 16 level): when 128-wide N tiles leave a third of the CUs without a block, 64-wide
+        // ones double the block count -- every block is then half as long, and the launch is one block's latency either way
+        // (1024 -> 512 channels at 16 x 16 pixels, 16 images: 128 tiles for 256 CUs).
+        const bool n64 = n64_in || (g_spx_small_n64 && !g_spx_bn && Cout > 64 && Cout % 64 == 0 && (long long)(M / 128) * cdf_cdiv(Cout, 128) < 176);
         const long long tiles = (long long)(M / 128) * cdf_cdiv(Cout, n64 ? 64 : 128);
         // row-halo kernel: 256-pixel tiles, input shared by the dx taps only.  Bit 32 (default): the > 64-channel outputs at
         // 128-pixel width, where it beats the generic 256 x 128 kernel (64 -> 128: 0.325 -> 0.298 ms); bit 64: wherever it applies

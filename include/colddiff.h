@@ -206,6 +206,8 @@ int cdf_conv_gemm_bf16x_splitk(int enable);   /* 1: ... and share the taps out o
 int cdf_conv_gemm_bf16x_halo(int enable, int min_tiles);
 /* tuning / test hook: pixels per tile of the LDS-resident-input kernel: 0 = automatic (256 where every CU still gets a tile), 128, 256 */
 int cdf_conv_gemm_bf16x_halo_bm(int bm);
+/* tuning / test hook: 64-wide N tiles in the LDS-resident-input kernel when 128-wide ones would give fewer than ~2/3 of the CUs a block (1, default) */
+int cdf_conv_gemm_bf16x_small_n64(int enable);
 /* Tuning / test hook: allow (1, default) or forbid (0) the two-taps-per-tile form of cdf_conv_wgrad_bf16x used when
  * CA <= 64 < CB.  Process-wide (an atomic word each); results do not depend on it. */
 int cdf_conv_wgrad_bf16x_stack(int enable);

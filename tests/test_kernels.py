@@ -901,6 +901,19 @@ def test_conv_presplit_halo(be, case):
         be.L.cdf_conv_gemm_bf16x_halo_bm(0)
 
 
+def test_conv_presplit_halo_small_grid_n64(be):
+    """Small grids (sampling batches, the 16 x 16 level): the LDS-resident-input kernel takes 64-wide N tiles for layers with MORE than
+    64 output channels when 128-wide ones would leave most CUs idle (cdf_conv_gemm_bf16x_small_n64).  192 and 128 output channels =
+    3 / 2 column tiles of 64 (forward / data gradient); the 128-wide choice must give the same numbers to rounding."""
+    case = (1, 128, 192, 16, 3, 1, 1)
+    _spx_case(be, *case)
+    be.L.cdf_conv_gemm_bf16x_small_n64(0)
+    try:
+        _spx_case(be, *case)
+    finally:
+        be.L.cdf_conv_gemm_bf16x_small_n64(1)
+
+
 @pytest.mark.parametrize("case", [(1, 136, 72, 16, 3, 1, 1), (2, 64, 136, 16, 3, 1, 1), (1, 136, 40, 32, 3, 1, 1)])
 def test_wgrad_presplit_row_of_taps(be, case):
     """Weight gradient of 3 x 3 same-size convolutions by one block per row of taps (conv_wgrad_row3_kernel): 16-wide images

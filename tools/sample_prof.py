@@ -49,7 +49,14 @@ def main():
         ms = run(a.batch)
         print(f"batch {a.batch}: {ms:.3f} ms per reverse step = {ms * 200 / a.batch:.2f} ms per image at T = 200")
         return
+    from colddiff import unet as U
+
+    def tba(v):
+        U._TIME_BIAS_ALL = v
+
     variants = [("default", lambda: None, lambda: None),
+                ("small_n64=0 (128-wide N tiles on small grids)", lambda: L.cdf_conv_gemm_bf16x_small_n64(0), lambda: L.cdf_conv_gemm_bf16x_small_n64(1)),
+                ("time-bias linears one by one", lambda: tba(False), lambda: tba(True)),
                 ("splitk=1", lambda: L.cdf_conv_gemm_bf16x_splitk(1), lambda: L.cdf_conv_gemm_bf16x_splitk(0)),
                 ("halo_bm=128", lambda: L.cdf_conv_gemm_bf16x_halo_bm(128), lambda: L.cdf_conv_gemm_bf16x_halo_bm(0)),
                 ("max_bm=128", lambda: L.cdf_conv_gemm_bf16x_max_bm(128), lambda: L.cdf_conv_gemm_bf16x_max_bm(0)),
@@ -63,7 +70,7 @@ def main():
             on()
             ms = min(run(batch) for _ in range(2))
             off()
-            print(f"batch {batch:3d}  {name:34s} {ms:8.3f} ms/step  {ms * 200 / batch:7.2f} ms/img", flush=True)
+            print(f"batch {batch:3d}  {name:48s} {ms:8.3f} ms/step  {ms * 200 / batch:7.2f} ms/img", flush=True)
 
 
 if __name__ == "__main__":
