@@ -58,6 +58,63 @@ def parse_header(path=HEADER):
     return protos
 
 
+def parse_struct(name, path=HEADER):
+    """Field names of `typedef struct <name> { int a; int b, c; ... } <name>;` in the header (all fields are C ints)."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    m = re.search(r"typedef\s+struct\s+%s\s*\{(.*?)\}\s*%s\s*;" % (name, name), src, flags=re.S)
+    if not m:
+        raise ValueError("colddiff.h: struct %s not found" % name)
+    fields = []
+    for decl in m.group(1).split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        assert decl.startswith("int "), "colddiff.h: %s has a non-int field: %r" % (name, decl)
+        fields += [f.strip() for f in decl[4:].split(",")]
+    return fields
+
+
+class GemmTuning:
+    """`cdf_gemm_tuning` of include/colddiff.h as a ctypes structure (fields read from the header): the OPTIONAL tuning argument of the
+    pre-split GEMM entry points.  The library holds no tuning state; whoever calls it passes one of these (or NULL for the defaults).
+    `from_env()` reads the COLDDIFF_SPX_* / COLDDIFF_WGRAD_* variables the measurement tools use -- in Python only."""
+    _cls = None
+
+    def __init__(self, lib):
+        if GemmTuning._cls is None:
+            names = parse_struct("cdf_gemm_tuning")
+            GemmTuning._cls = type("cdf_gemm_tuning", (ctypes.Structure,), {"_fields_": [(n, ctypes.c_int) for n in names]})
+        self.c = GemmTuning._cls()
+        lib.cdf_gemm_tuning_default(ctypes.byref(self.c))
+        assert self.c.size == ctypes.sizeof(self.c), "cdf_gemm_tuning: header and library disagree"
+        self.ptr = ctypes.addressof(self.c)
+
+    def set(self, **kw):
+        for k, v in kw.items():
+            assert hasattr(self.c, k), "cdf_gemm_tuning has no field %r" % k
+            setattr(self.c, k, int(v))
+        return self
+
+    def get(self, k):
+        return getattr(self.c, k)
+
+    def from_env(self):
+        env = os.environ.get
+        if env("COLDDIFF_SPX_TILE"):
+            bm, bn = (int(v) for v in env("COLDDIFF_SPX_TILE").split("x"))
+            self.set(tile_bm=bm, tile_bn=bn)
+        if env("COLDDIFF_SPX_HALO"):
+            v = [int(x) for x in env("COLDDIFF_SPX_HALO").split(",")]
+            self.set(halo=v[0], halo_min_tiles=v[1] if len(v) > 1 else 1)
+        for var, field in (("COLDDIFF_SPX_SPLITK", "splitk"), ("COLDDIFF_SPX_DEEP", "deep"), ("COLDDIFF_SPX_HALO_BM", "halo_bm"),
+                           ("COLDDIFF_SPX_MAX_BM", "max_bm"), ("COLDDIFF_SPX_DEPHASE", "dephase"), ("COLDDIFF_SPX_SMALL_N64", "small_n64"),
+                           ("COLDDIFF_WGRAD_ROW3", "wgrad_row3"), ("COLDDIFF_WGRAD_SWIZZLE", "wgrad_swizzle"), ("COLDDIFF_WGRAD_STACK", "wgrad_stack")):
+            if env(var):
+                self.set(**{field: int(env(var))})
+        return self
+
+
 # int-returning entry points that are pure host-side queries (sizes / counts), not status codes
 _QUERY = re.compile(r"(_blocks|_nchunk|_nsplit|_abi_version|_is_device_build|_lds_bytes|_is_row3|_ssim_tiles|_pack_entry_bytes|_pack_blocks|_kvctx_parts|_bf16x_ksplit)$")
 
@@ -111,33 +168,4 @@ def get():
     global _instance
     if _instance is None:
         _instance = Lib(LIB_PATH)
-        # tuning hooks of include/colddiff.h from the environment (results do not depend on them)
-        tile, waves = os.environ.get("COLDDIFF_SPX_TILE"), os.environ.get("COLDDIFF_SPX_WAVES")
-        if tile:
-            _instance.cdf_conv_gemm_bf16x_tile(*[int(v) for v in tile.split("x")])
-        if waves:
-            _instance.cdf_conv_gemm_bf16x_waves(int(waves))
-        if os.environ.get("COLDDIFF_SPX_SPLITK"):
-            _instance.cdf_conv_gemm_bf16x_splitk(int(os.environ["COLDDIFF_SPX_SPLITK"]))
-        if os.environ.get("COLDDIFF_SPX_DEEP"):
-            _instance.cdf_conv_gemm_bf16x_deep(int(os.environ["COLDDIFF_SPX_DEEP"]))
-        if os.environ.get("COLDDIFF_KVCTX_SLOTS"):
-            _instance.cdf_linattn_kvctx_slots(int(os.environ["COLDDIFF_KVCTX_SLOTS"]))
-        if os.environ.get("COLDDIFF_LINATTN_ONEPASS"):
-            _instance.cdf_linattn_onepass(int(os.environ["COLDDIFF_LINATTN_ONEPASS"]))
-        if os.environ.get("COLDDIFF_UNPACK_TILED"):
-            _instance.cdf_unpack_reduce_tiled(int(os.environ["COLDDIFF_UNPACK_TILED"]))
-        if os.environ.get("COLDDIFF_WGRAD_ROW3"):
-            _instance.cdf_conv_wgrad_bf16x_row3(int(os.environ["COLDDIFF_WGRAD_ROW3"]))
-        if os.environ.get("COLDDIFF_WGRAD_SWIZZLE"):
-            _instance.cdf_conv_wgrad_bf16x_swizzle(int(os.environ["COLDDIFF_WGRAD_SWIZZLE"]))
-        if os.environ.get("COLDDIFF_SPX_TAPROT"):
-            _instance.cdf_conv_gemm_bf16x_taprot(int(os.environ["COLDDIFF_SPX_TAPROT"]))
-        if os.environ.get("COLDDIFF_SPX_HALO"):
-            v = [int(x) for x in os.environ["COLDDIFF_SPX_HALO"].split(",")]
-            _instance.cdf_conv_gemm_bf16x_halo(v[0], v[1] if len(v) > 1 else 1)
-        if os.environ.get("COLDDIFF_SPX_HALO_BM"):
-            _instance.cdf_conv_gemm_bf16x_halo_bm(int(os.environ["COLDDIFF_SPX_HALO_BM"]))
-        if os.environ.get("COLDDIFF_SPX_MAX_BM"):
-            _instance.cdf_conv_gemm_bf16x_max_bm(int(os.environ["COLDDIFF_SPX_MAX_BM"]))
     return _instance

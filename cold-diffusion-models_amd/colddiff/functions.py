@@ -526,8 +526,6 @@ def kv_backward(xn, dim, dkv, w_qkv, dxn):
 
 
 _ATTN_QFOLD = os.environ.get("CDF_ATTN_QFOLD", "1") != "0"   # q projection folded into the attention product too (dim <= heads*32)
-_ATTN_KVDG = os.environ.get("CDF_ATTN_KVDG", "0") != "0"     # k | v backward with its data gradient in one kernel (ops.linattn_bwd_kv_dgrad):
-                                                             # built, parity-tested, measured at +0.2 % (noise) on the train step => off
 _ATTN_KVCTX = os.environ.get("CDF_ATTN_KVCTX", "1") != "0"   # ... with the k|v projection and the context in one kernel (ops.linattn_kvctx)
 
 
@@ -579,13 +577,8 @@ class LinAttnBlockFn(torch.autograd.Function):
             dxn, dctx, rvec = ops.linattn_fold_bwd(xn, dy, Mb, Nb, cx, cxs, att.to_qkv.weight, att.to_out.weight, att.to_out.bias,
                                                    att.heads, att.scale)
             dkv = torch.empty(kv.shape, device=kv.device, dtype=torch.float32)
-            if _ATTN_KVDG and ops.linattn_bwd_kv_dgrad_ok(kv, dim, att.heads):
-                # dk | dv and their data gradient in one pass; only the weight gradient reads dk | dv back
-                ops.linattn_bwd_kv_dgrad(kv, dctx, rvec, kmax, ksum, dkv, att.to_qkv.weight, dxn, dim, att.heads)
-                kv_backward(xn, dim, dkv, att.to_qkv.weight, None)
-            else:
-                ops.linattn_bwd_core(kv, dctx, rvec, kmax, ksum, dkv, att.heads, koff=0)
-                kv_backward(xn, dim, dkv, att.to_qkv.weight, dxn)
+            ops.linattn_bwd_core(kv, dctx, rvec, kmax, ksum, dkv, att.heads, koff=0)
+            kv_backward(xn, dim, dkv, att.to_qkv.weight, dxn)
             dx = ops.layernorm_bwd(dxn, x, norm.g, norm.b, mean, rstd, add=dy)     # + the residual branch, same pass
             _done(ctx)
             return None, dx, None, None

@@ -271,7 +271,7 @@ def conv_gemm_presplit(plan, xs, Cin, wp, Cout, y=None, bias=None, sbias=None, r
     M = B * plan.QH * plan.QW
     ws, nws = None, 0
     if M <= 4096 and hi.device.type != "meta":
-        ks = rt.lib().cdf_conv_gemm_bf16x_ksplit(M, Cout, plan.nphase, plan.desc[2])
+        ks = rt.lib().cdf_conv_gemm_bf16x_ksplit(M, Cout, plan.nphase, plan.desc[2], rt.tune_ptr())
         if ks > 1:
             nws = ks * M * r4(Cout)
             ws = torch.empty((nws,), device=hi.device, dtype=torch.float32)
@@ -279,7 +279,7 @@ def conv_gemm_presplit(plan, xs, Cin, wp, Cout, y=None, bias=None, sbias=None, r
                                  B, plan.H, plan.W, Cin, plan.OH, plan.OW, Cout, plan.QH, plan.QW, plan.os, plan.istride, plan.nphase,
                                  plan.desc, P(bias), P(sbias), 0 if sbias is None else sbias.stride(0), P(res), ldv(res), P(pre),
                                  ldv(pre), P(mul), ldv(mul), act, mul_mode, accumulate, P(ys[0]) if ys else 0, P(ys[1]) if ys else 0,
-                                 ys[0].shape[-1] if ys else 0, P(ws), nws, rt.stream(hi))
+                                 ys[0].shape[-1] if ys else 0, P(ws), nws, rt.tune_ptr(), rt.stream(hi))
     if split_out:
         return y, (ys if ys is not None else split_bf16(y))
     return y
@@ -317,9 +317,9 @@ def conv_cin4_bwd(x, dy, weight, bias, need_dx, dx=None, dx_accumulate=0):
     bsum = torch.empty((nch, Cout), device=x.device, dtype=torch.float32) if bias is not None else None
     L.cdf_conv_cin4_wgrad(P(x), P(dy), ld_of(dy), P(part), P(bsum), B, H, W, Cin, Cout, k, S)
     if bias is not None:
-        L.cdf_unpack_reduce_bias(P(part), P(grad_of(weight)), nch, KK, Cin, Cout, Cout, 1, KK, Cin * KK, P(bsum), P(grad_of(bias)), Cout, 1, S)
+        L.cdf_unpack_reduce_bias(P(part), P(grad_of(weight)), nch, KK, Cin, Cout, Cout, 1, KK, Cin * KK, P(bsum), P(grad_of(bias)), Cout, 1, 1, S)
     else:
-        L.cdf_unpack_reduce(P(part), P(grad_of(weight)), nch, KK, Cin, Cout, Cout, 1, KK, Cin * KK, 1, S)
+        L.cdf_unpack_reduce(P(part), P(grad_of(weight)), nch, KK, Cin, Cout, Cout, 1, KK, Cin * KK, 1, 1, S)
     if not need_dx:
         return None
     if dx is None:
@@ -389,7 +389,7 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None, xa_s=No
         dev = xa_s[0].device
         ntap_blocks = (wplan.ntaps + 1) // 2 if (CA <= 64 < CB and wplan.same_b) else wplan.ntaps    # two taps per tile there
         slots = 512
-        if L.cdf_conv_wgrad_bf16x_is_row3(wplan.QH, wplan.QW, CA, CB, wplan.ntaps, 1 if wplan.same3x3 else 0):
+        if L.cdf_conv_wgrad_bf16x_is_row3(wplan.QH, wplan.QW, CA, CB, wplan.ntaps, 1 if wplan.same3x3 else 0, rt.tune_ptr()):
             ntap_blocks, slots = 3, 256                                # one block per row of taps, one 512-thread block per CU
         tiles = (1 if CA <= 64 else (CA + 127) // 128) * (1 if CB <= 64 else (CB + 127) // 128) * ntap_blocks
         ns = best_nsplit(tiles, slots, M // 512)
@@ -398,7 +398,7 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None, xa_s=No
         bsum = torch.empty((ns, ldo), device=dev, dtype=torch.float32) if gbias is not None else None
         L.cdf_conv_wgrad_bf16x(P(xa_s[0]), P(xa_s[1]), xa_s[0].shape[-1], P(xb_s[0]), P(xb_s[1]), xb_s[0].shape[-1], P(zero_page(dev)),
                                P(ws), ldo, B, wplan.QH, wplan.QW, wplan.HA, wplan.WA, wplan.sa, wplan.HB, wplan.WB, wplan.sb, CA, CB,
-                               wplan.ntaps, wplan.desc, ns, P(bsum), S)
+                               wplan.ntaps, wplan.desc, ns, P(bsum), rt.tune_ptr(), S)
         _reduce_slabs(L, ws, gparam, ns, wplan.ntaps, CA, CB, ldo, s_t, s_r, s_c, bsum, gbias, S)
         return
     if rt.precision != "f32" and CA >= 128 and CB >= 128 and M >= WGRAD_SP_MIN_M:   # full 128x128 tiles only; thinner layers are faster on the fp32 kernel
@@ -427,9 +427,9 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None, xa_s=No
 def _reduce_slabs(L, ws, gparam, ns, ntaps, CA, CB, ldo, s_t, s_r, s_c, bsum, gbias, S):
     """gparam += sum over the split-K slabs (and gbias += sum over the bias partials, in the same launch)."""
     if gbias is not None:
-        L.cdf_unpack_reduce_bias(P(ws), P(gparam), ns, ntaps, CA, CB, ldo, s_t, s_r, s_c, P(bsum), P(gbias), ldo, 1, S)
+        L.cdf_unpack_reduce_bias(P(ws), P(gparam), ns, ntaps, CA, CB, ldo, s_t, s_r, s_c, P(bsum), P(gbias), ldo, 1, 1, S)
     else:
-        L.cdf_unpack_reduce(P(ws), P(gparam), ns, ntaps, CA, CB, ldo, s_t, s_r, s_c, 1, S)
+        L.cdf_unpack_reduce(P(ws), P(gparam), ns, ntaps, CA, CB, ldo, s_t, s_r, s_c, 1, 1, S)
 
 
 def colsum_into(gvec, x, C, nseg=1):
@@ -541,7 +541,7 @@ def linattn_fwd(qkv, heads, scale):
     kmax = torch.empty((B, HD), device=dev, dtype=torch.float32)
     ksum = torch.empty((B, HD), device=dev, dtype=torch.float32)
     ws = torch.empty((L.cdf_linattn_ws_floats(B, n, heads),), device=dev, dtype=torch.float32)
-    L.cdf_linattn_context(P(qkv), ld_of(qkv), HD, P(ctx), P(ctxs), P(kmax), P(ksum), P(ws), B, n, heads, scale, rt.stream(qkv))
+    L.cdf_linattn_context(P(qkv), ld_of(qkv), HD, P(ctx), P(ctxs), P(kmax), P(ksum), P(ws), B, n, heads, scale, 1, rt.stream(qkv))
     _head_gemm(qkv, 0, ctxs, out, 0, B, n, heads, False)          # out = q . (scale*ctx)
     return out, ctx, ctxs, kmax, ksum
 
@@ -624,9 +624,9 @@ def linattn_project_bwd(qkv, dy, Mb, ctx, ctxs, w_out, b_out, dqkv, heads, scale
     bsum = torch.empty((B * ns, ldw), device=dev, dtype=torch.float32) if b_out is not None else None    # column sums of dy as it streams by
     L.cdf_conv_wgrad(P(qkv), ldq, P(dy), lddy, P(ws), ldw, 1, 1, n, 1, n, 1, 1, n, 1, HD, dim, 1, wplan.desc, ns, B, n * ldq, n * lddy, -1, P(bsum), S)
     dMb = torch.empty((B, HD, ldw), device=dev, dtype=torch.float32)
-    L.cdf_unpack_reduce(P(ws), P(dMb), ns, B, HD, dim, ldw, HD * ldw, ldw, 1, 0, S)
+    L.cdf_unpack_reduce(P(ws), P(dMb), ns, B, HD, dim, ldw, HD * ldw, ldw, 1, 0, 1, S)
     if b_out is not None:
-        L.cdf_unpack_reduce(P(bsum), P(grad_of(b_out)), B * ns, 1, 1, dim, ldw, 0, 0, 1, 1, S)
+        L.cdf_unpack_reduce(P(bsum), P(grad_of(b_out)), B * ns, 1, 1, dim, ldw, 0, 0, 1, 1, 1, S)
     return _linattn_out_bwd(dMb, ctx, ctxs, w_out, heads, scale)
 
 
@@ -650,7 +650,7 @@ def _linattn_out_bwd(dMb, ctx, ctxs, w_out, heads, scale):
     nsw = max(1, min(16, (B * 32) // 64))                      # B * 32 contraction rows: a few blocks each instead of one long serial loop
     wsw = torch.empty((nsw, heads, 32, ldw), device=dev, dtype=torch.float32)
     L.cdf_conv_wgrad(P(ctxs), 32, P(dMb), ldw, P(wsw), ldw, B, 1, 32, heads, 32, 1, heads, 32, 1, 32, dim, heads, hp.desc, nsw, 1, 0, 0, 0, 0, S)
-    L.cdf_unpack_reduce(P(wsw), P(grad_of(w_out)), nsw, heads, 32, dim, ldw, 32, 1, HD, 1, S)
+    L.cdf_unpack_reduce(P(wsw), P(grad_of(w_out)), nsw, heads, 32, dim, ldw, 32, 1, HD, 1, 1, S)
     return dctx, rvec
 
 
@@ -697,9 +697,9 @@ def linattn_kvctx(xn, dim, w_qkv, heads, scale):
     dev = xn.device
     wp = packed(w_qkv, "kv_fwd_sp")                           # (hi, lo | None) planes [1][2 HD][roundup32(dim)]
     kv = torch.empty((B, H, W, 2 * HD), device=dev, dtype=torch.float32)
-    P_ = L.cdf_linattn_kvctx_parts(B, n)
+    P_ = L.cdf_linattn_kvctx_parts(B, n, rt.KVCTX_SLOTS)
     ws = torch.empty((B * P_ * (2 * HD + heads * 1024),), device=dev, dtype=torch.float32)
-    L.cdf_linattn_kvctx(P(xn), ld_of(xn), P(wp[0]), P(wp[1]), wp[0].shape[-1], P(kv), 2 * HD, P(ws), B, n, dim, heads, S)
+    L.cdf_linattn_kvctx(P(xn), ld_of(xn), P(wp[0]), P(wp[1]), wp[0].shape[-1], P(kv), 2 * HD, P(ws), B, n, dim, heads, rt.KVCTX_SLOTS, S)
     ctx = torch.empty((B, heads, 32, 32), device=dev, dtype=torch.float32)
     ctxs = torch.empty_like(ctx)
     kmax = torch.empty((B, HD), device=dev, dtype=torch.float32)
@@ -727,9 +727,9 @@ def linattn_fold_bwd(xn, dy, Mb, Nb, ctx, ctxs, w_qkv, w_out, b_out, heads, scal
     bsum = torch.empty((B * ns, ldw), device=dev, dtype=torch.float32) if b_out is not None else None
     L.cdf_conv_wgrad(P(xn), ldx, P(dy), lddy, P(ws), ldw, 1, 1, n, 1, n, 1, 1, n, 1, dim, dim, 1, wplan.desc, ns, B, n * ldx, n * lddy, -1, P(bsum), S)
     dNb = torch.empty((B, dim, ldw), device=dev, dtype=torch.float32)
-    L.cdf_unpack_reduce(P(ws), P(dNb), ns, B, dim, dim, ldw, dim * ldw, ldw, 1, 0, S)
+    L.cdf_unpack_reduce(P(ws), P(dNb), ns, B, dim, dim, ldw, dim * ldw, ldw, 1, 0, 1, S)
     if b_out is not None:
-        L.cdf_unpack_reduce(P(bsum), P(grad_of(b_out)), B * ns, 1, 1, dim, ldw, 0, 0, 1, 1, S)
+        L.cdf_unpack_reduce(P(bsum), P(grad_of(b_out)), B * ns, 1, 1, dim, ldw, 0, 0, 1, 1, 1, S)
     # dM_b = Wq . dN_b  (Wq = rows 0 .. HD-1 of the to_qkv weight, a plain [HD][dim] matrix in place)
     wq_rows = w_qkv.detach()
     dMb = torch.empty((B, HD, ldw), device=dev, dtype=torch.float32)
@@ -739,24 +739,9 @@ def linattn_fold_bwd(xn, dy, Mb, Nb, ctx, ctxs, w_qkv, w_out, b_out, heads, scal
     T = torch.empty((B, HD, ldw), device=dev, dtype=torch.float32)
     L.cdf_conv_gemm(P(Mb), ldw, P(dNb), ldw, P(T), ldw, 1, 1, HD, dim, 1, HD, dim, 1, HD, 1, 1, 1, _one_tap(HD).desc,
                     0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, B, HD * ldw, dim * ldw, HD * ldw, 1, 0, 0, 0, S)
-    L.cdf_unpack_reduce(P(T), P(grad_of(w_qkv)), B, 1, HD, dim, ldw, 0, dim, 1, 1, S)
+    L.cdf_unpack_reduce(P(T), P(grad_of(w_qkv)), B, 1, HD, dim, ldw, 0, dim, 1, 1, 1, S)
     dctx, rvec = _linattn_out_bwd(dMb, ctx, ctxs, w_out, heads, scale)
     return dxn, dctx, rvec
-
-
-def linattn_bwd_kv_dgrad_ok(kv, dim, heads):
-    return rt.precision != "f32" and heads == 4 and dim in (64, 128) and kv.shape[-1] == 256 and kv.device.type != "meta"
-
-
-def linattn_bwd_kv_dgrad(kv, dctx, rvec, kmax, ksum, dkv, w_qkv, dxn, dim, heads):
-    """dk | dv of a (k|v) tensor into dkv AND dxn += dkv . Wkv in the same pass (k_conv_sp.hip: linattn_bwd_kv_dg_kernel): the data
-    gradient of the k | v projection never reads dk | dv back."""
-    L = rt.lib()
-    B, H, W, _ = kv.shape
-    wd = packed(w_qkv, "kv_dgrad_sp")                         # (hi, lo | None) planes [1][dim][256]: K = the k|v channels, contiguous
-    L.cdf_linattn_bwd_kv_dgrad(P(kv), ld_of(kv), P(dctx), P(rvec), P(kmax), P(ksum), P(dkv), ld_of(dkv), P(wd[0]), P(wd[1]), wd[0].shape[-1],
-                               P(dxn), ld_of(dxn), B, H * W, dim, heads, rt.stream(kv))
-    return dkv
 
 
 def linattn_bwd_core(qkv, dctx, rvec, kmax, ksum, dqkv, heads, koff=None):
@@ -795,7 +780,7 @@ def linattn_context(qkv, heads, scale, koff=None):
     kmax = torch.empty((B, HD), device=dev, dtype=torch.float32)
     ksum = torch.empty((B, HD), device=dev, dtype=torch.float32)
     ws = torch.empty((L.cdf_linattn_ws_floats(B, n, heads),), device=dev, dtype=torch.float32)
-    L.cdf_linattn_context(P(qkv), ld_of(qkv), koff, P(ctx), P(ctxs), P(kmax), P(ksum), P(ws), B, n, heads, scale, rt.stream(qkv))
+    L.cdf_linattn_context(P(qkv), ld_of(qkv), koff, P(ctx), P(ctxs), P(kmax), P(ksum), P(ws), B, n, heads, scale, 1, rt.stream(qkv))
     return ctx, ctxs, kmax, ksum
 
 

@@ -41,6 +41,27 @@ def lib():
     return _lib_override if _lib_override is not None else _lib.get()
 
 
+# The tuning argument this process passes to the pre-split GEMM entry points (include/colddiff.h: cdf_gemm_tuning): defaults of the
+# library + the COLDDIFF_SPX_* / COLDDIFF_WGRAD_* environment variables.  Python-side state only; tools / tests change fields through
+# `tuning().set(field=value)`.
+_tuning = {}
+
+
+def tuning():
+    L = lib()
+    t = _tuning.get(id(L))
+    if t is None:
+        t = _tuning[id(L)] = _lib.GemmTuning(L).from_env()
+    return t
+
+
+def tune_ptr():
+    return tuning().ptr
+
+
+KVCTX_SLOTS = int(_os.environ.get("COLDDIFF_KVCTX_SLOTS", "0"))       # cdf_linattn_kvctx: target block count (0 = the library's default)
+
+
 def stream(t=None):
     if _lib_override is not None:
         return 0

@@ -380,12 +380,6 @@ extern "C" int cdf_linattn_nsplit(int n) {       // 256 rows per split (the one-
     return s;
 }
 
-static std::atomic<int> g_linattn_onepass{1};
-extern "C" int cdf_linattn_onepass(int on) {      // tuning / test hook (process-wide): one-pass context (online softmax) vs max pass + context pass
-    g_linattn_onepass.store(on ? 1 : 0);
-    return 0;
-}
-
 // ws >= B*nsplit*HD (kmax partials) + B*nsplit*heads*1024 (ctx partials) + B*nsplit*HD (sum partials) floats
 extern "C" size_t cdf_linattn_ws_floats(int B, int n, int heads) {
     const size_t ns = (size_t)cdf_linattn_nsplit(n), HD = (size_t)heads * LA_D;
@@ -395,7 +389,7 @@ extern "C" size_t cdf_linattn_ws_floats(int B, int n, int heads) {
 // Context pass: ctx[b,h,d,e] = sum_n softmax_n(k)[d,n] v[e,n]; ctxs = scale*ctx; kmax/ksum [B,HD] saved.
 // The output  out[n, h*32+e] = sum_d q[n, h*32+d] ctxs[h,d,e]  is a K=32 GEMM per (b, head): cdf_conv_gemm.
 extern "C" int cdf_linattn_context(const float* qkv, int ld, int koff, float* ctx, float* ctxs, float* kmax, float* ksum, float* ws,
-                                   int B, int n, int heads, float scale, void* stream) {
+                                   int B, int n, int heads, float scale, int onepass, void* stream) {
     CDF_REQUIRE(qkv && ctx && ctxs && kmax && ksum && ws, "cdf_linattn_context: null pointer");
     const int HD = heads * LA_D;
     CDF_REQUIRE(HD % 64 == 0 && ld % 4 == 0 && koff >= 0 && koff % 4 == 0 && ld >= koff + 2 * HD,
@@ -404,7 +398,7 @@ extern "C" int cdf_linattn_context(const float* qkv, int ld, int koff, float* ct
     float* kmax_part = ws;
     float* ctx_part = kmax_part + (size_t)B * ns * HD;
     float* sum_part = ctx_part + (size_t)B * ns * heads * LA_D * LA_D;
-    if (g_linattn_onepass.load() && ns <= 1024) {
+    if (onepass && ns <= 1024) {
         const size_t lds = ((size_t)2 * 256 * LA_D + 32 * LA_D + LA_D) * sizeof(float);
 #ifndef CDF_EMU
         static bool attr_done = false;

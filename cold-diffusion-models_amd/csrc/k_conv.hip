@@ -883,16 +883,9 @@ extern "C" int cdf_pack_weight(const float* src, float* dst, int T, int R, int C
     return cdf_check_launch("pack_weight");
 }
 
-static std::atomic<int> g_unpack_tiled{1};
-extern "C" int cdf_unpack_reduce_tiled(int on) {             // tuning / test hook (process-wide): the transposing tiled reduction (0 off, 1 c tiles fastest, 2 r tiles fastest per XCD)
-    g_unpack_tiled.store(on < 0 ? 0 : (on > 2 ? 2 : on));
-    return 0;
-}
-
 static int launch_unpack_reduce(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t, long long s_r,
-                                long long s_c, int accumulate, const float* bws, float* gb, int bC, int bld, hipStream_t s) {
-    int tiled_mode = g_unpack_tiled.load();
-    if (tiled_mode == 2 && s_r >= s_c) tiled_mode = 1;       // (transposed-conv weights: the runs of neighbouring C tiles continue each other)
+                                long long s_c, int accumulate, const float* bws, float* gb, int bC, int bld, int tiled, hipStream_t s) {
+    const int tiled_mode = tiled ? 1 : 0;                    // (1: c tiles fastest; an r-tiles-fastest-per-XCD order measured no different and is gone)
     if (s_c != 1 && C >= 32 && (T == 1 || T == 9 || T == 16) && tiled_mode) {
         const int RJ = T == 9 ? 4 : (T == 16 ? 2 : 32);
         const long long tiles = (long long)((C + 31) / 32) * ((R + RJ - 1) / RJ);
@@ -916,16 +909,16 @@ static int launch_unpack_reduce(const float* ws, float* g, int nsplit, int T, in
 }
 
 extern "C" int cdf_unpack_reduce(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t,
-                                 long long s_r, long long s_c, int accumulate, void* stream) {
+                                 long long s_r, long long s_c, int accumulate, int tiled, void* stream) {
     CDF_REQUIRE(ws && g && nsplit > 0 && T > 0 && R > 0 && C > 0 && ldc >= C, "cdf_unpack_reduce: bad args");
-    return launch_unpack_reduce(ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate, nullptr, nullptr, 0, 0, CDF_S);
+    return launch_unpack_reduce(ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate, nullptr, nullptr, 0, 0, tiled, CDF_S);
 }
 
 extern "C" int cdf_unpack_reduce_bias(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t,
                                       long long s_r, long long s_c, const float* bias_ws, float* gbias, int bias_ld, int accumulate,
-                                      void* stream) {
+                                      int tiled, void* stream) {
     CDF_REQUIRE(ws && g && bias_ws && gbias && nsplit > 0 && T > 0 && R > 0 && C > 0 && ldc >= C && bias_ld >= C, "cdf_unpack_reduce_bias: bad args");
-    return launch_unpack_reduce(ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate, bias_ws, gbias, C, bias_ld, CDF_S);
+    return launch_unpack_reduce(ws, g, nsplit, T, R, C, ldc, s_t, s_r, s_c, accumulate, bias_ws, gbias, C, bias_ld, tiled, CDF_S);
 }
 
 extern "C" int cdf_colsum_nchunk(int rows_per_seg) {

@@ -156,15 +156,12 @@ __device__ __forceinline__ void cdf_mma_sp(f32x16_t& acc, const bf16x8_v& ah, co
 // All products of one K chunk (two k16 steps) of a wave tile, TERM-MAJOR: consecutive MFMAs go to different accumulators
 // (al*bh for every tile, then ah*bl, then ah*bh), so no instruction waits for the result of the one just issued; the
 // summation order per accumulator is the same as in cdf_mma_sp.
-#ifndef CDF_TERM_MAJOR
-#define CDF_TERM_MAJOR 1
-#endif
 template <int NS, int MT, int NT>
 __device__ __forceinline__ void cdf_mma_tile(f32x16_t (&acc)[MT][NT], const bf16x8_v (&ah)[2][MT], const bf16x8_v (&al)[2][MT],
                                              const bf16x8_v (&bh)[2][NT], const bf16x8_v (&bl)[2][NT]) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        if constexpr (NS == 3 && CDF_TERM_MAJOR && !(CDF_ABLATE & 2)) {
+        if constexpr (NS == 3 && !(CDF_ABLATE & 2)) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -2286,161 +2283,6 @@ __global__ void __launch_bounds__(512, 1) linattn_kvctx_kernel(KvCtxArgs a) {
     if (ctx_wave && half == 0) a.max_part[pb * HD + ch * LD + l31] = m_run;
 }
 
-// ================================================================================================
-// LinearAttention backward, k | v gradient + its DATA gradient in one pass (round 2).
-//
-// linattn_bwd_kv_kernel (k_attn.hip) writes dk | dv ([B,n,256]) and the data gradient dxn += dkv . Wkv then reads all of it back
-// (537 MB per micro-batch at 128 x 128).  Here the block that produces a 32-pixel tile of dk | dv (one wave per head, exactly as in
-// that kernel: P recomputed, dP = v dctx^T and dv = P dctx on the fp32 matrix cores) also multiplies it with the 256 x dim weight
-// while it sits in LDS: per wave a [32 px x 64 ch] x [64 ch x dim] product in split precision (fragments split while they are read
-// from the fp32 tiles, weight fragments from the L1-resident bf16 hi / lo planes), the four heads' partial products are folded
-// through LDS and added to dxn (which already holds dy . N_b^T).  dk | dv still go to memory once: the weight gradient needs them.
-// NTN = dim / 32.  grid = (ceil(n / (32 TILES)), B), block = 256 (4 heads).
-// ================================================================================================
-#define KVB_D 32
-#define KVB_TP 36
-#define KVB_TILES 8
-template <int SPLIT, int NTN>
-__global__ void __launch_bounds__(256) linattn_bwd_kv_dg_kernel(const float* kv, int ld, const float* dctx, const float* rvec, const float* kmax,
-                                                               const float* ksum, float* dkv, int lddq, const unsigned short* w_hi,
-                                                               const unsigned short* w_lo, int ldk, float* dxn, int lddx, int n) {
-    constexpr int HD = 128, DIM = NTN * 32;
-    CDF_DYN_SMEM(smem_raw);
-    const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, b = blockIdx.y;
-    float* sp = (float*)smem_raw + (size_t)h * 4 * KVB_D * KVB_TP;         // this wave's P tile
-    float* sv = sp + KVB_D * KVB_TP;                                       // V tile
-    float* sk = sv + KVB_D * KVB_TP;                                       // dk tile
-    float* so = sk + KVB_D * KVB_TP;                                       // dv tile
-    float* part = sp;                                                      // [32][DIM] partial product of this head (aliases its four tiles)
-    const int i = lane & 31, hh = lane >> 5;
-    const int lr = lane >> 3, lc = (lane & 7) * 4;
-    const float* dc = dctx + ((size_t)b * 4 + h) * KVB_D * KVB_D;
-    float B1[16], B2[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        B1[s] = dc[i * KVB_D + 2 * s + hh];
-        B2[s] = dc[(2 * s + hh) * KVB_D + i];
-    }
-    const float rv = rvec[(size_t)b * HD + h * KVB_D + i];
-    const float4 km = *(const float4*)(kmax + (size_t)b * HD + h * KVB_D + lc);
-    const float4 ks = *(const float4*)(ksum + (size_t)b * HD + h * KVB_D + lc);
-    const float4 ri = make_float4(1.0f / ks.x, 1.0f / ks.y, 1.0f / ks.z, 1.0f / ks.w);
-    const float* kbase = kv + (size_t)b * n * ld + h * KVB_D + lc;
-    const float* vbase = kbase + HD;
-    float* dkbase = dkv + (size_t)b * n * lddq + h * KVB_D + lc;
-    float* dvbase = dkbase + HD;
-    float* dxb = dxn + (size_t)b * n * lddx;
-    const int p_begin = blockIdx.x * (KVB_D * KVB_TILES);
-    for (int t = 0; t < KVB_TILES; ++t) {
-        const int p0 = p_begin + t * KVB_D;
-        if (p0 >= n) break;                                                // (block-uniform)
-        float4 kq[4], vq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int p = p0 + lr + 8 * q;
-            const int pc = p < n ? p : n - 1;
-            kq[q] = *(const float4*)(kbase + (size_t)pc * ld);
-            vq[q] = *(const float4*)(vbase + (size_t)pc * ld);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool ok = p0 + lr + 8 * q < n;
-            float4 pn = make_float4(expf(kq[q].x - km.x) * ri.x, expf(kq[q].y - km.y) * ri.y, expf(kq[q].z - km.z) * ri.z, expf(kq[q].w - km.w) * ri.w);
-            if (!ok) { pn = make_float4(0.f, 0.f, 0.f, 0.f); vq[q] = pn; }
-            *(float4*)(sp + (lr + 8 * q) * KVB_TP + lc) = pn;
-            *(float4*)(sv + (lr + 8 * q) * KVB_TP + lc) = vq[q];
-        }
-        CDF_WAVE_SYNC();
-        // ---- dP = V dctx^T ; dk = P (dP - rvec)
-        f32x16_t acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[i * KVB_TP + 2 * s + hh], B1[s], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int px = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            sk[px * KVB_TP + i] = sp[px * KVB_TP + i] * (acc[r] - rv);
-        }
-        // ---- dv = P dctx
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sp[i * KVB_TP + 2 * s + hh], B2[s], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) so[((r & 3) + 8 * (r >> 2) + 4 * hh) * KVB_TP + i] = acc[r];
-        CDF_WAVE_SYNC();
-        // ---- dk | dv rows out (the weight gradient reads them)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int p = p0 + lr + 8 * q;
-            if (p < n) {
-                *(float4*)(dkbase + (size_t)p * lddq) = *(const float4*)(sk + (lr + 8 * q) * KVB_TP + lc);
-                *(float4*)(dvbase + (size_t)p * lddq) = *(const float4*)(so + (lr + 8 * q) * KVB_TP + lc);
-            }
-        }
-        // ---- this head's share of dxn: [32 px] x [K = 64: dk (32) | dv (32)] x [dim], split precision
-        f32x16_t gacc[NTN];
-#pragma unroll
-        for (int j = 0; j < NTN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) gacc[j][r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {                                      // 16 channels per step
-            const float* at = (s < 2 ? sk : so) + i * KVB_TP + (s & 1) * 16 + hh * 8;          // pixel i, 8 channels
-            const float4 a0 = *(const float4*)at, a1 = *(const float4*)(at + 4);
-            uint2 h0, l0, h1, l1;
-            if (SPLIT > 1) {
-                cdf_split4_trunc(a0, h0, l0);
-                cdf_split4_trunc(a1, h1, l1);
-            } else {
-                h0.x = cdf_f2bf(a0.x) | (cdf_f2bf(a0.y) << 16); h0.y = cdf_f2bf(a0.z) | (cdf_f2bf(a0.w) << 16);
-                h1.x = cdf_f2bf(a1.x) | (cdf_f2bf(a1.y) << 16); h1.y = cdf_f2bf(a1.z) | (cdf_f2bf(a1.w) << 16);
-                l0 = h0; l1 = h1;
-            }
-            const u32x4_v ahu = u32x4_v{h0.x, h0.y, h1.x, h1.y}, alu = u32x4_v{l0.x, l0.y, l1.x, l1.y};
-            const bf16x8_v ah = __builtin_bit_cast(bf16x8_v, ahu), al = __builtin_bit_cast(bf16x8_v, alu);
-            const int kcol = (s < 2 ? 0 : HD) + h * KVB_D + (s & 1) * 16 + hh * 8;               // channel of the 256-wide K index
-#pragma unroll
-            for (int j = 0; j < NTN; ++j) {
-                const size_t woff = (size_t)(j * 32 + i) * ldk + kcol;
-                const bf16x8_v bh = __builtin_bit_cast(bf16x8_v, *(const u32x4_v*)(w_hi + woff));
-                if (SPLIT > 1) {
-                    const bf16x8_v bl = __builtin_bit_cast(bf16x8_v, *(const u32x4_v*)(w_lo + woff));
-                    gacc[j] = CDF_MFMA_BF16(al, bh, gacc[j]);
-                    gacc[j] = CDF_MFMA_BF16(ah, bl, gacc[j]);
-                }
-                gacc[j] = CDF_MFMA_BF16(ah, bh, gacc[j]);
-            }
-        }
-        CDF_WAVE_SYNC();                                                   // this wave's tile reads are done: the tiles become its partial
-#pragma unroll
-        for (int j = 0; j < NTN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) part[((r & 3) + 8 * (r >> 2) + 4 * hh) * DIM + j * 32 + i] = gacc[j][r];
-        __syncthreads();
-        // ---- dxn[p0 + px][:] += sum over the four heads
-        {
-            const float* p0f = (const float*)smem_raw;
-            constexpr int WSTR = 4 * KVB_D * KVB_TP;                       // floats between two waves' regions
-            for (int e = threadIdx.x; e < 32 * DIM / 4; e += 256) {
-                const int px = e / (DIM / 4), c4 = (e - px * (DIM / 4)) * 4;
-                if (p0 + px < n) {
-                    const float4 v0 = *(const float4*)(p0f + px * DIM + c4), v1 = *(const float4*)(p0f + WSTR + px * DIM + c4);
-                    const float4 v2 = *(const float4*)(p0f + 2 * WSTR + px * DIM + c4), v3 = *(const float4*)(p0f + 3 * WSTR + px * DIM + c4);
-                    float4* dst = (float4*)(dxb + (size_t)(p0 + px) * lddx + c4);
-                    float4 o = *dst;
-                    o.x += (v0.x + v1.x) + (v2.x + v3.x); o.y += (v0.y + v1.y) + (v2.y + v3.y);
-                    o.z += (v0.z + v1.z) + (v2.z + v3.z); o.w += (v0.w + v1.w) + (v2.w + v3.w);
-                    *dst = o;
-                }
-            }
-        }
-        __syncthreads();                                                   // the tiles are rewritten by the next trip
-    }
-}
-
-// dst_hi/lo[t][r][c] (c < ldc, zero padded) = split(src[c*s_c + r*s_r + t*s_t])
 __global__ void pack_weight_bf16_kernel(const float* src, unsigned short* dst_hi, unsigned short* dst_lo, int T, int R, int C,
                                         int ldc, long long s_t, long long s_r, long long s_c) {
     const long long n = (long long)T * R * ldc;
@@ -2457,15 +2299,10 @@ __global__ void pack_weight_bf16_kernel(const float* src, unsigned short* dst_hi
 
 // ================================================================================================
 // blocks per image of cdf_linattn_kvctx (= partials per image and head for cdf_linattn_finalize)
-static std::atomic<int> g_kvctx_slots{512};
-extern "C" int cdf_linattn_kvctx_slots(int slots) {          // tuning / test hook (process-wide): target number of blocks per launch
-    g_kvctx_slots.store(slots < 1 ? 1 : slots);
-    return 0;
-}
-extern "C" int cdf_linattn_kvctx_parts(int B, int n) {
+extern "C" int cdf_linattn_kvctx_parts(int B, int n, int slots) {      // slots: target block count per launch (<= 0: the default, 512)
     const int tiles = n / 128;
     if (tiles < 1 || B < 1) return 0;
-    int P = g_kvctx_slots.load() / B;                        // default ~2 blocks per CU queued: a block's last tile overlaps another's start
+    int P = (slots > 0 ? slots : 512) / B;                        // default ~2 blocks per CU queued: a block's last tile overlaps another's start
     if (P < 1) P = 1;
     if (P > tiles) P = tiles;
     const int tpb = (tiles + P - 1) / P;
@@ -2473,14 +2310,14 @@ extern "C" int cdf_linattn_kvctx_parts(int B, int n) {
 }
 
 extern "C" int cdf_linattn_kvctx(const float* xn, int ldx, const void* w_hi, const void* w_lo, int ldk, float* kv, int ldkv, float* ws, int B,
-                                 int n, int dim, int heads, void* stream) {
+                                 int n, int dim, int heads, int slots, void* stream) {
     CDF_REQUIRE(xn && w_hi && kv && ws && B > 0, "cdf_linattn_kvctx: null pointer");
     CDF_REQUIRE(heads == 4 && n >= 128 && n % 128 == 0 && dim >= 32 && dim % 32 == 0 && dim <= 512,
                 "cdf_linattn_kvctx: 4 heads, n %% 128 == 0, dim a multiple of 32 (<= 512); got heads=%d n=%d dim=%d", heads, n, dim);
     CDF_REQUIRE(ldx % 4 == 0 && ldx >= dim && ldk % 8 == 0 && ldk >= dim && ldkv % 4 == 0 && ldkv >= 256 &&
                 ((((uintptr_t)xn) | ((uintptr_t)w_hi) | ((uintptr_t)w_lo) | ((uintptr_t)kv)) & 15) == 0,
                 "cdf_linattn_kvctx: pitches (xn % 4, weights % 8, kv % 4 and >= 256) / 16-byte alignment");
-    const int P = cdf_linattn_kvctx_parts(B, n), tiles = n / 128, HD = 128;
+    const int P = cdf_linattn_kvctx_parts(B, n, slots), tiles = n / 128, HD = 128;
     KvCtxArgs a;
     a.xn = xn; a.w_hi = (const unsigned short*)w_hi; a.w_lo = (const unsigned short*)w_lo; a.kv = kv;
     a.max_part = ws;
@@ -2507,36 +2344,6 @@ extern "C" int cdf_linattn_kvctx(const float* xn, int ldx, const void* w_hi, con
         else CDF_LAUNCH((linattn_kvctx_kernel<1, 32>), dim3(P, B), dim3(512), lds, CDF_S, a);
     }
     return cdf_check_launch("linattn_kvctx");
-}
-
-extern "C" int cdf_linattn_bwd_kv_dgrad(const float* kv, int ld, const float* dctx, const float* rvec, const float* kmax, const float* ksum,
-                                        float* dkv, int lddq, const void* w_hi, const void* w_lo, int ldk, float* dxn, int lddx, int B, int n,
-                                        int dim, int heads, void* stream) {
-    CDF_REQUIRE(kv && dctx && rvec && kmax && ksum && dkv && w_hi && dxn && B > 0 && n > 0, "cdf_linattn_bwd_kv_dgrad: null pointer");
-    CDF_REQUIRE(heads == 4 && (dim == 64 || dim == 128), "cdf_linattn_bwd_kv_dgrad: 4 heads, dim 64 or 128; got heads=%d dim=%d", heads, dim);
-    CDF_REQUIRE(ld % 4 == 0 && lddq % 4 == 0 && lddx % 4 == 0 && ld >= 256 && lddq >= 256 && lddx >= dim && ldk % 8 == 0 && ldk >= 256 &&
-                ((((uintptr_t)kv) | ((uintptr_t)dkv) | ((uintptr_t)kmax) | ((uintptr_t)ksum) | ((uintptr_t)w_hi) | ((uintptr_t)w_lo) | ((uintptr_t)dxn)) & 15) == 0,
-                "cdf_linattn_bwd_kv_dgrad: (k|v) rows of >= 256 floats, pitches %% 4 (weights %% 8, K = 256 contiguous), 16-byte alignment");
-    const size_t lds = (size_t)4 * 4 * KVB_D * KVB_TP * sizeof(float);     // 4 heads x (P, V, dk, dv) tiles; a head's [32][dim] partial fits its four tiles
-    static_assert(4 * KVB_D * KVB_TP >= 32 * 128, "the per-head partial aliases the head's tiles");
-    const dim3 grid(cdf_cdiv(n, KVB_D * KVB_TILES), B);
-#ifndef CDF_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)linattn_bwd_kv_dg_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)linattn_bwd_kv_dg_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)linattn_bwd_kv_dg_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)linattn_bwd_kv_dg_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-#endif
-#define CDF_KVDG(SP, NT)                                                                                                              \
-    CDF_LAUNCH((linattn_bwd_kv_dg_kernel<SP, NT>), grid, dim3(256), lds, CDF_S, kv, ld, dctx, rvec, kmax, ksum, dkv, lddq,            \
-               (const unsigned short*)w_hi, (const unsigned short*)w_lo, ldk, dxn, lddx, n)
-    if (w_lo) { if (dim == 64) CDF_KVDG(3, 2); else CDF_KVDG(3, 4); }
-    else { if (dim == 64) CDF_KVDG(1, 2); else CDF_KVDG(1, 4); }
-#undef CDF_KVDG
-    return cdf_check_launch("linattn_bwd_kv_dgrad");
 }
 
 extern "C" int cdf_pack_weight_bf16(const float* src, void* dst_hi, void* dst_lo, int T, int R, int C, int ldc, long long s_t,
@@ -2597,13 +2404,6 @@ extern "C" int cdf_conv_gemm_bf16(const float* x, int ldx, const void* w_hi, con
     return cdf_check_launch("conv_igemm_sp");
 }
 
-static std::atomic<int> g_wgrad_swizzle{1};                // tuning / test hook (cdf_conv_wgrad_bf16x_swizzle)
-
-extern "C" int cdf_conv_wgrad_bf16x_swizzle(int enable) {
-    g_wgrad_swizzle = enable ? 1 : 0;
-    return 0;
-}
-
 extern "C" int cdf_conv_wgrad_bf16(const float* xa, int lda, const float* xb, int ldb, float* ws, int ldo, int B, int QH, int QW,
                                    int HA, int WA, int sa, int HB, int WB, int sb, int CA, int CB, int ntaps, const int* tap_desc,
                                    int nsplit, float* bsum, void* stream) {
@@ -2613,7 +2413,7 @@ extern "C" int cdf_conv_wgrad_bf16(const float* xa, int lda, const float* xb, in
     SpWgradArgs a;
     a.xa = xa; a.xb = xb; a.out = ws; a.bsum = bsum; a.lda = lda; a.ldb = ldb; a.ldo = ldo;
     a.B = B; a.QH = QH; a.QW = QW; a.HA = HA; a.WA = WA; a.sa = sa; a.HB = HB; a.WB = WB; a.sb = sb;
-    a.CA = CA; a.CB = CB; a.ntaps = ntaps; a.nsplit = nsplit; a.xcd_swizzle = g_wgrad_swizzle;
+    a.CA = CA; a.CB = CB; a.ntaps = ntaps; a.nsplit = nsplit; a.xcd_swizzle = 1;
     const int M = B * QH * QW;
     a.m_per_split = cdf_cdiv(cdf_cdiv(M, nsplit), 32) * 32;
     for (int t = 0; t < ntaps; ++t) {
@@ -2658,46 +2458,27 @@ static int fill_phases(SpPhase* ph, int nphase, const int* pd, const char* who) 
     return CDF_OK;
 }
 
-static std::atomic<int> g_spx_bm{0}, g_spx_bn{0};     // 0 = automatic
-static std::atomic<int> g_spx_waves{0};                // 0 = automatic; 4 / 8 = waves of the 128 x 128 tile
-static std::atomic<int> g_spx_max_bm{0};               // 0 / 256 = no cap; 128 = the automatic choice never takes the 256-row tile
-static std::atomic<int> g_spx_taprot{1};               // per-block row-group order of 3 x 3 taps when a tile is one image row
-
-static std::atomic<int> g_spx_deep{1};                     // small grids (<= 256 64-row tiles): six DMA stages, one block per CU
-extern "C" int cdf_conv_gemm_bf16x_deep(int enable) {
-    g_spx_deep.store(enable ? 1 : 0);
+// ---- tuning: an explicit, optional argument of the GEMM entry points (include/colddiff.h: cdf_gemm_tuning) -----------------------------
+// No mutable process-wide state: a NULL pointer means these defaults, anything else is read once per call.  The choices only select
+// between kernels / tile shapes that compute the same sums (fp32 summation order aside).
+static const cdf_gemm_tuning kTuneDefault = {(int)sizeof(cdf_gemm_tuning), 0, 0, 0, 1, 1, 0, 47, 1, 0, 1, 1, 1, 1};
+extern "C" int cdf_gemm_tuning_default(cdf_gemm_tuning* t) {
+    CDF_REQUIRE(t, "cdf_gemm_tuning_default: null pointer");
+    *t = kTuneDefault;
     return 0;
 }
-static std::atomic<int> g_spx_dephase{1};              // the two waves of a SIMD run half a K step apart in the 8-wave tiles (tuning / test hook)
-
-extern "C" int cdf_conv_gemm_bf16x_dephase(int enable) {
-    g_spx_dephase = enable ? 1 : 0;
-    return 0;
+static const cdf_gemm_tuning* cdf_tune(const cdf_gemm_tuning* t) { return (t && t->size == (int)sizeof(cdf_gemm_tuning)) ? t : &kTuneDefault; }
+static bool cdf_tune_ok(const cdf_gemm_tuning* t) {
+    if (!t) return true;
+    const bool bm_ok = t->tile_bm == 0 || t->tile_bm == 64 || t->tile_bm == 128 || (t->tile_bm == 256 && (t->tile_bn == 0 || t->tile_bn == 128));
+    const bool bn_ok = t->tile_bn == 0 || t->tile_bn == 64 || t->tile_bn == 128;
+    return t->size == (int)sizeof(cdf_gemm_tuning) && bm_ok && bn_ok && (t->max_bm == 0 || t->max_bm == 128 || t->max_bm == 256) &&
+           (t->halo_bm == 0 || t->halo_bm == 128 || t->halo_bm == 256) && t->halo >= 0 && t->halo <= 127 && t->halo_min_tiles >= 0;
 }
-
-extern "C" int cdf_conv_gemm_bf16x_taprot(int enable) {
-    g_spx_taprot = enable ? 1 : 0;
-    return 0;
-}
-
-extern "C" int cdf_conv_gemm_bf16x_max_bm(int bm) {
-    CDF_REQUIRE(bm == 0 || bm == 128 || bm == 256, "cdf_conv_gemm_bf16x_max_bm: 0, 128 or 256");
-    g_spx_max_bm = bm;
-    return 0;
-}
-
-extern "C" int cdf_conv_gemm_bf16x_waves(int waves) {
-    CDF_REQUIRE(waves == 0 || waves == 4 || waves == 8, "cdf_conv_gemm_bf16x_waves: 0 (auto), 4 or 8");
-    g_spx_waves = waves;
-    return 0;
-}
-
-extern "C" int cdf_conv_gemm_bf16x_tile(int bm, int bn) {
-    CDF_REQUIRE((bm == 0 || bm == 64 || bm == 128 || bm == 256) && (bn == 0 || bn == 64 || bn == 128), "cdf_conv_gemm_bf16x_tile: bm is 0 (auto), 64, 128 or 256 (with bn = 128), bn 0, 64 or 128");
-    g_spx_bm = bm;
-    g_spx_bn = bn;
-    return 0;
-}
+#define CDF_TUNE_CHECK(t, who)                                                                                                          \
+    CDF_REQUIRE(cdf_tune_ok(t), who ": bad cdf_gemm_tuning (size %d, expected %d; tile_bm 0/64/128/256 (256 with tile_bn 0/128), tile_bn 0/64/128, " \
+                                    "max_bm 0/128/256, halo_bm 0/128/256, halo 0..127): start from cdf_gemm_tuning_default",            \
+                (t) ? (t)->size : 0, (int)sizeof(cdf_gemm_tuning))
 
 template <int NS, int BM, int BN, int WM, int WN, int NSTAGE, int OCC = 512 / (64 * WM * WN)>
 static int launch_igemm_spx(const SpxArgs& a, int M, hipStream_t s) {
@@ -2721,32 +2502,6 @@ static int launch_igemm_spx(const SpxArgs& a, int M, hipStream_t s) {
         else CDF_LAUNCH((conv_splitk_finish_kernel<128>), dim3(ftiles), dim3(256), 0, s, a);
     }
     return cdf_check_launch("conv_igemm_spx");
-}
-
-static std::atomic<int> g_spx_halo{47};                    // 3 x 3 stride-1 layers: input tile resident in LDS; bit mask over the image width
-                                               // 16 (1), 32 (2), 64 (4), 128 (8); 16: at width 128 also for 128-wide N tiles (measured
-                                               // level with the generic kernel there: only 3 weight stages fit next to 2 x 51 KB of halo;
-                                               // with 64-wide N tiles a 256-pixel tile fits and wins); 32: the row-halo kernel for the
-                                               // > 64-channel outputs at width 128; 64: the row-halo kernel wherever it applies
-                                               // (tuning / test hook)
-static std::atomic<long long> g_spx_halo_min_tiles{1};
-static std::atomic<int> g_spx_small_n64{1};                // LDS-resident-input kernel: 64-wide N tiles for grids below ~2/3 of the CUs (tuning / test hook)
-extern "C" int cdf_conv_gemm_bf16x_small_n64(int enable) {
-    g_spx_small_n64 = enable ? 1 : 0;
-    return 0;
-}
-static std::atomic<int> g_spx_halo_bm{0};                  // 0 = automatic, 128 / 256 = forced tile height of the halo kernel
-
-extern "C" int cdf_conv_gemm_bf16x_halo_bm(int bm) {
-    CDF_REQUIRE(bm == 0 || bm == 128 || bm == 256, "cdf_conv_gemm_bf16x_halo_bm: 0, 128 or 256");
-    g_spx_halo_bm = bm;
-    return 0;
-}
-
-extern "C" int cdf_conv_gemm_bf16x_halo(int enable, int min_tiles) {
-    g_spx_halo = enable & 127;
-    g_spx_halo_min_tiles = min_tiles > 0 ? min_tiles : 1;
-    return 0;
 }
 
 template <int NS, int W, int BN, int BM>
@@ -2794,13 +2549,8 @@ static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s) {
 
 // Split-K factor of the generic pre-split GEMM for grids far below one 64-row tile per CU: the smallest divisor of the tap count
 // that brings the launch to >= 192 blocks (else the largest); 1 = no split.
-static std::atomic<int> g_spx_ksplit{0};                   // off by default: measured on the 32 x 32 configurations, the finish pass costs what the extra blocks gain (+-1 %)
-extern "C" int cdf_conv_gemm_bf16x_splitk(int enable) {      // tuning / test hook (process-wide)
-    g_spx_ksplit.store(enable ? 1 : 0);
-    return 0;
-}
-static int spx_ksplit(int M, int Cout, int nphase, int ntaps) {
-    if (!g_spx_ksplit.load() || !g_spx_deep.load() || nphase != 1 || (ntaps != 9 && ntaps != 16)) return 1;
+static int spx_ksplit(int M, int Cout, int nphase, int ntaps, const cdf_gemm_tuning& T) {
+    if (!T.splitk || !T.deep || nphase != 1 || (ntaps != 9 && ntaps != 16)) return 1;
     const bool n64 = Cout <= 64;
     const long long tiles128 = (long long)cdf_cdiv(M, 128) * cdf_cdiv(Cout, n64 ? 64 : 128);
     const long long tiles64 = (long long)cdf_cdiv(M, 64) * cdf_cdiv(Cout, n64 ? 64 : 128);
@@ -2809,20 +2559,20 @@ static int spx_ksplit(int M, int Cout, int nphase, int ntaps) {
         if (ntaps % ks == 0 && tiles64 * ks >= 192) return ks;
     return ntaps;
 }
-extern "C" int cdf_conv_gemm_bf16x_ksplit(int M, int Cout, int nphase, int ntaps) { return spx_ksplit(M, Cout, nphase, ntaps); }
+extern "C" int cdf_conv_gemm_bf16x_ksplit(int M, int Cout, int nphase, int ntaps, const cdf_gemm_tuning* tune) { return spx_ksplit(M, Cout, nphase, ntaps, *cdf_tune(tune)); }
 
 template <int NS>
 static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cout, int QH, int QW, int os, int is, int nphase, long long ks_ws_floats,
-                               hipStream_t s) {
+                               const cdf_gemm_tuning& T, hipStream_t s) {
     // Tile choice: 64-wide N for Cout <= 64 (no half-empty MFMA columns); 64-row M tiles when 128-row tiles would
     // leave most of the 256 CUs x 2 resident blocks idle (deep, small-image layers: M = 8192 at 16 x 16); the 8-wave
     // 256 x 128 tile (3 stages, one block per CU) when it still gives every CU at least ~2 tiles.
     const int M = B * QH * QW;
-    const bool n64 = g_spx_bn ? g_spx_bn == 64 : Cout <= 64;
+    const bool n64 = T.tile_bn ? T.tile_bn == 64 : Cout <= 64;
     const long long tiles128 = (long long)cdf_cdiv(M, 128) * cdf_cdiv(Cout, n64 ? 64 : 128) * nphase;
     bool m64 = tiles128 < 384;
-    bool m256 = !n64 && tiles128 >= 1024 && g_spx_max_bm != 128;
-    if (g_spx_bm) { m64 = g_spx_bm == 64; m256 = g_spx_bm == 256 && !n64; }
+    bool m256 = !n64 && tiles128 >= 1024 && T.max_bm != 128;
+    if (T.tile_bm) { m64 = T.tile_bm == 64; m256 = T.tile_bm == 256 && !n64; }
     // 3 x 3, stride 1, three groups of equal dy covering three consecutive rows: candidates for the row-group rotation
     bool is3x3 = nphase == 1 && is == 1 && os == 1 && a.ph[0].ntaps == 9 && a.ph[0].oy == 0 && a.ph[0].ox == 0;
     if (is3x3) {
@@ -2834,15 +2584,15 @@ static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cou
         }
         is3x3 = is3x3 && seen == 7;
     }
-    const bool rot_ok = g_spx_taprot && is3x3;
+    const bool rot_ok = is3x3;
     // (measured at 128 x 128 images: 128 -> 64 channels 0.40 -> 0.37 ms with the rotation on its 128 x 64 tiles; for 64 -> 128
     // the two-row 256 x 128 tile without rotation stays ahead of one-row tiles with it, 0.405 vs 0.414 ms, so the tile
     // choice is not bent towards one-row tiles)
     const int bm = m256 ? 256 : (m64 ? 64 : 128);
     a.taprot = rot_ok && QW == bm;
-    a.dephase = g_spx_dephase;
+    a.dephase = T.dephase;
     // 3 x 3 stride-1 layers whose rows tile into 128-pixel strips: input tile resident in LDS (conv_igemm_halo_kernel)
-    if (g_spx_halo && is3x3 && !g_spx_bm && QW == W && QH == H && Cin % 32 == 0 && Cin >= 64 && M % 128 == 0) {
+    if (T.halo && is3x3 && !T.tile_bm && QW == W && QH == H && Cin % 32 == 0 && Cin >= 64 && M % 128 == 0) {
         const bool n64_in = n64;
         int dxs = 0;
         for (int t = 0; t < 9; ++t) dxs |= 1 << (a.ph[0].dx[t] + 1);
@@ -2850,25 +2600,25 @@ static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cou
         // Small grids (sampling batches, the 16 x 16 level): when 128-wide N tiles leave a third of the CUs without a block, 64-wide
         // ones double the block count -- every block is then half as long, and the launch is one block's latency either way
         // (1024 -> 512 channels at 16 x 16 pixels, 16 images: 128 tiles for 256 CUs).
-        const bool n64 = n64_in || (g_spx_small_n64 && !g_spx_bn && Cout > 64 && Cout % 64 == 0 && (long long)(M / 128) * cdf_cdiv(Cout, 128) < 176);
+        const bool n64 = n64_in || (T.small_n64 && !T.tile_bn && Cout > 64 && Cout % 64 == 0 && (long long)(M / 128) * cdf_cdiv(Cout, 128) < 176);
         const long long tiles = (long long)(M / 128) * cdf_cdiv(Cout, n64 ? 64 : 128);
         // row-halo kernel: 256-pixel tiles, input shared by the dx taps only.  Bit 32 (default): the > 64-channel outputs at
         // 128-pixel width, where it beats the generic 256 x 128 kernel (64 -> 128: 0.325 -> 0.298 ms); bit 64: wherever it applies
         // (at 64 pixels the halo kernel's 256-pixel tile stays ahead, 0.240 vs 0.252 ms)
-        if (dx_ok && M % 256 == 0 && ((g_spx_halo & 64) || ((g_spx_halo & 32) && W == 128 && !n64 && (long long)(M / 256) * cdf_cdiv(Cout, 128) >= 256))) {
+        if (dx_ok && M % 256 == 0 && ((T.halo & 64) || ((T.halo & 32) && W == 128 && !n64 && (long long)(M / 256) * cdf_cdiv(Cout, 128) >= 256))) {
 #define CDF_ROWHALO_CASE(WW)                                                                                           \
     if (W == WW && H % (256 / WW) == 0)                                                                                \
         return n64 ? launch_igemm_rowhalo<NS, WW, 64>(a, M, s) : launch_igemm_rowhalo<NS, WW, 128>(a, M, s);
             CDF_ROWHALO_CASE(128) CDF_ROWHALO_CASE(64) CDF_ROWHALO_CASE(32) CDF_ROWHALO_CASE(16)
 #undef CDF_ROWHALO_CASE
         }
-        if (dx_ok && tiles >= g_spx_halo_min_tiles) {
+        if (dx_ok && tiles >= (T.halo_min_tiles > 0 ? T.halo_min_tiles : 1)) {
 #define CDF_HALO_CASE(WW)                                                                                              \
-    if (W == WW && (g_spx_halo & (WW / 16)) && H % (128 / WW) == 0 && (WW < 128 || n64 || (g_spx_halo & 16))) {          \
+    if (W == WW && (T.halo & (WW / 16)) && H % (128 / WW) == 0 && (WW < 128 || n64 || (T.halo & 16))) {          \
         /* 256-pixel tiles (half the weight bytes per MFMA) when they still give every CU a tile and fit the LDS      \
            (at 128-pixel width only next to 64-wide weight stages) */                                                  \
-        if ((WW <= 64 || n64) && g_spx_halo_bm != 128 && H % (256 / WW) == 0 && M % 256 == 0 &&                          \
-            (g_spx_halo_bm == 256 || (long long)(M / 256) * cdf_cdiv(Cout, n64 ? 64 : 128) >= 256))                     \
+        if ((WW <= 64 || n64) && T.halo_bm != 128 && H % (256 / WW) == 0 && M % 256 == 0 &&                          \
+            (T.halo_bm == 256 || (long long)(M / 256) * cdf_cdiv(Cout, n64 ? 64 : 128) >= 256))                     \
             return n64 ? launch_igemm_halo<NS, WW, 64, 256>(a, M, s)                                                    \
                        : launch_igemm_halo<NS, WW, 128, WW <= 64 ? 256 : 128>(a, M, s);                                 \
         return n64 ? launch_igemm_halo<NS, WW, 64, 128>(a, M, s) : launch_igemm_halo<NS, WW, 128, 128>(a, M, s);        \
@@ -2882,10 +2632,10 @@ static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cou
     // sampling batches): a block's life is its K loop, and with two stages every step waited out a whole DMA round trip (144 steps
     // of 1.5 us for 512 -> 1024 channels at 4 x 4 pixels).  Six stages, one block per CU: five chunks in flight per block.
     const long long tiles64 = (long long)cdf_cdiv(M, 64) * cdf_cdiv(Cout, n64 ? 64 : 128) * nphase;
-    if (m64 && tiles64 <= 256 && g_spx_deep) {
+    if (m64 && tiles64 <= 256 && T.deep) {
         // ... and when even that leaves most CUs without a block, the taps are shared out over blockIdx.z (split-K, partial sums through
         // the caller's workspace, conv_splitk_finish_kernel adds them up and runs the epilogue)
-        const int ks = spx_ksplit(M, Cout, nphase, a.ph[0].ntaps);
+        const int ks = spx_ksplit(M, Cout, nphase, a.ph[0].ntaps, T);
         if (ks > 1 && a.ks_ws && ks_ws_floats >= (long long)ks * M * ((Cout + 3) / 4 * 4)) {
             a.ksplit = ks;
             a.ks_ld = (Cout + 3) / 4 * 4;
@@ -2898,8 +2648,6 @@ static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cou
     }
     if (n64) return m64 ? launch_igemm_spx<NS, 64, 64, 2, 2, 2>(a, M, s) : launch_igemm_spx<NS, 128, 64, 2, 2, 2>(a, M, s);
     if (m64) return launch_igemm_spx<NS, 64, 128, 2, 2, 2>(a, M, s);
-    // 128 x 128 with 8 waves (4 x 2 of 32 x 64), still two blocks per CU: 16 waves per CU instead of 8
-    if (g_spx_waves == 8) return launch_igemm_spx<NS, 128, 128, 4, 2, 2, 2>(a, M, s);
     return launch_igemm_spx<NS, 128, 128, 2, 2, 2>(a, M, s);
 }
 
@@ -2907,8 +2655,10 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
                                    int ldk, float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW,
                                    int os, int is, int nphase, const int* phase_desc, const float* bias, const float* sbias,
                                    int ld_sbias, const float* res, int ldr, float* pre, int ldp, const float* mul, int ldm, int act,
-                                   int mul_mode, int accumulate, void* y_hi, void* y_lo, int ld_ys, float* ws, long long ws_floats, void* stream) {
+                                   int mul_mode, int accumulate, void* y_hi, void* y_lo, int ld_ys, float* ws, long long ws_floats,
+                                   const cdf_gemm_tuning* tune, void* stream) {
     CDF_REQUIRE(x_hi && zero && w_hi && (y || (y_hi && !accumulate)), "cdf_conv_gemm_bf16x: null pointer");
+    CDF_TUNE_CHECK(tune, "cdf_conv_gemm_bf16x");
     CDF_REQUIRE(!ws || (((uintptr_t)ws) & 15) == 0, "cdf_conv_gemm_bf16x: the split-K workspace must be 16-byte aligned");
     CDF_REQUIRE((x_lo != nullptr) == (w_lo != nullptr), "cdf_conv_gemm_bf16x: pass both lo planes (split precision, 3 MFMAs per product) or neither (single-pass bf16)");
     CDF_REQUIRE((!y_hi && !y_lo) || (y_hi && ld_ys % 4 == 0 && ld_ys >= Cout && Cout % 4 == 0 && ((((uintptr_t)y_hi) | ((uintptr_t)y_lo)) & 7) == 0),
@@ -2930,15 +2680,8 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
     int rc = fill_phases(a.ph, nphase, phase_desc, "cdf_conv_gemm_bf16x");
     if (rc) return rc;
     a.ksplit = 1; a.ks_ws = ws; a.ks_ld = 0;
-    return x_lo ? dispatch_gemm_bf16x<3>(a, B, H, W, Cin, Cout, QH, QW, os, is, nphase, ws ? ws_floats : 0, CDF_S)
-                : dispatch_gemm_bf16x<1>(a, B, H, W, Cin, Cout, QH, QW, os, is, nphase, ws ? ws_floats : 0, CDF_S);
-}
-
-static std::atomic<int> g_wgrad_stack{1};                  // tuning / test hook (cdf_conv_wgrad_bf16x_stack)
-
-extern "C" int cdf_conv_wgrad_bf16x_stack(int enable) {
-    g_wgrad_stack = enable ? 1 : 0;
-    return 0;
+    return x_lo ? dispatch_gemm_bf16x<3>(a, B, H, W, Cin, Cout, QH, QW, os, is, nphase, ws ? ws_floats : 0, *cdf_tune(tune), CDF_S)
+                : dispatch_gemm_bf16x<1>(a, B, H, W, Cin, Cout, QH, QW, os, is, nphase, ws ? ws_floats : 0, *cdf_tune(tune), CDF_S);
 }
 
 template <int NS, int TA, int TB, bool STACK2 = false>
@@ -2958,17 +2701,10 @@ static int launch_wgrad_spx(const SpxWgradArgs& a, hipStream_t s) {
     return cdf_check_launch("conv_wgrad_spx");
 }
 
-static std::atomic<int> g_wgrad_row3{1};                   // tuning / test hook (cdf_conv_wgrad_bf16x_row3)
-
-extern "C" int cdf_conv_wgrad_bf16x_row3(int enable) {
-    g_wgrad_row3 = enable ? 1 : 0;
-    return 0;
-}
-
 // 1 if cdf_conv_wgrad_bf16x takes the row-of-taps kernel for this geometry (the caller sizes the split count by it:
 // 3 tap blocks per tile and one block per CU instead of 9 (or 5) and two)
-extern "C" int cdf_conv_wgrad_bf16x_is_row3(int QH, int QW, int CA, int CB, int ntaps, int same_size_3x3) {
-    return g_wgrad_row3 && same_size_3x3 && ntaps == 9 && (QW == 16 || QW == 32 || QW == 64 || QW == 128) && (QH * QW) % 32 == 0 &&
+extern "C" int cdf_conv_wgrad_bf16x_is_row3(int QH, int QW, int CA, int CB, int ntaps, int same_size_3x3, const cdf_gemm_tuning* tune) {
+    return cdf_tune(tune)->wgrad_row3 && same_size_3x3 && ntaps == 9 && (QW == 16 || QW == 32 || QW == 64 || QW == 128) && (QH * QW) % 32 == 0 &&
            (QW >= 32 || QH % (32 / QW) == 0) && !(CA <= 64 && CB <= 64);
 }
 
@@ -2990,9 +2726,10 @@ static int launch_wgrad_row3(const SpxWgradArgs& a, hipStream_t s) {
 }
 
 template <int NS>
-static int dispatch_wgrad_bf16x(SpxWgradArgs& a, int QH, int QW, int HA, int WA, int sa, int HB, int WB, int sb, int CA, int CB, int ntaps, hipStream_t s) {
+static int dispatch_wgrad_bf16x(SpxWgradArgs& a, int QH, int QW, int HA, int WA, int sa, int HB, int WB, int sb, int CA, int CB, int ntaps,
+                                const cdf_gemm_tuning& T, hipStream_t s) {
     // 3 x 3 stride-1 "same" convolutions (X shifted per tap, dY read in place): one block per row of taps
-    if (g_wgrad_row3 && ntaps == 9 && sa == 1 && sb == 1 && HA == QH && WA == QW && HB == QH && WB == QW &&
+    if (T.wgrad_row3 && ntaps == 9 && sa == 1 && sb == 1 && HA == QH && WA == QW && HB == QH && WB == QW &&
         (QW == 16 || QW == 32 || QW == 64 || QW == 128) && (QH * QW) % 32 == 0 && (QW >= 32 || QH % (32 / QW) == 0) && !(CA <= 64 && CB <= 64)) {
         bool ok = true;
         for (int g = 0; g < 3 && ok; ++g) {
@@ -3015,7 +2752,7 @@ static int dispatch_wgrad_bf16x(SpxWgradArgs& a, int QH, int QW, int HA, int WA,
     if (CA <= 64) {
         bool same_b = ntaps >= 2;                  // two taps can share the B rows only if B is read at one offset
         for (int t = 1; t < ntaps; ++t) same_b = same_b && a.dby[t] == a.dby[0] && a.dbx[t] == a.dbx[0];
-        if (same_b && g_wgrad_stack) return launch_wgrad_spx<NS, 128, 128, true>(a, s);
+        if (same_b && T.wgrad_stack) return launch_wgrad_spx<NS, 128, 128, true>(a, s);
         return launch_wgrad_spx<NS, 64, 128>(a, s);
     }
     if (CB <= 64) return launch_wgrad_spx<NS, 128, 64>(a, s);
@@ -3024,8 +2761,10 @@ static int dispatch_wgrad_bf16x(SpxWgradArgs& a, int QH, int QW, int HA, int WA,
 
 extern "C" int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, int ldb,
                                     const void* zero, float* ws, int ldo, int B, int QH, int QW, int HA, int WA, int sa, int HB, int WB,
-                                    int sb, int CA, int CB, int ntaps, const int* tap_desc, int nsplit, float* bsum, void* stream) {
+                                    int sb, int CA, int CB, int ntaps, const int* tap_desc, int nsplit, float* bsum, const cdf_gemm_tuning* tune,
+                                    void* stream) {
     CDF_REQUIRE(a_hi && b_hi && zero && ws, "cdf_conv_wgrad_bf16x: null pointer");
+    CDF_TUNE_CHECK(tune, "cdf_conv_wgrad_bf16x");
     CDF_REQUIRE((a_lo != nullptr) == (b_lo != nullptr), "cdf_conv_wgrad_bf16x: pass both lo planes (split precision) or neither (single-pass bf16)");
     CDF_REQUIRE(((((uintptr_t)a_hi) | ((uintptr_t)a_lo) | ((uintptr_t)b_hi) | ((uintptr_t)b_lo) | ((uintptr_t)zero)) & 15) == 0, "cdf_conv_wgrad_bf16x: operands must be 16B aligned");
     CDF_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && CA % 8 == 0 && CB % 8 == 0 && lda >= CA && ldb >= CB && ldo % 4 == 0 && ldo >= CB, "cdf_conv_wgrad_bf16x: channels / pitches must be multiples of 8");
@@ -3035,7 +2774,7 @@ extern "C" int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda,
     a.b_lo = (const unsigned short*)b_lo; a.zero = (const unsigned short*)zero; a.out = ws; a.bsum = bsum;
     a.lda = lda; a.ldb = ldb; a.ldo = ldo;
     a.B = B; a.QH = QH; a.QW = QW; a.HA = HA; a.WA = WA; a.sa = sa; a.HB = HB; a.WB = WB; a.sb = sb;
-    a.CA = CA; a.CB = CB; a.ntaps = ntaps; a.nsplit = nsplit; a.xcd_swizzle = g_wgrad_swizzle;
+    a.CA = CA; a.CB = CB; a.ntaps = ntaps; a.nsplit = nsplit; a.xcd_swizzle = cdf_tune(tune)->wgrad_swizzle;
     const int M = B * QH * QW;
     a.m_per_split = cdf_cdiv(cdf_cdiv(M, nsplit), 32) * 32;
     for (int t = 0; t < ntaps; ++t) {
@@ -3044,6 +2783,6 @@ extern "C" int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda,
         a.dby[t] = (signed char)tap_desc[4 * t + 2];
         a.dbx[t] = (signed char)tap_desc[4 * t + 3];
     }
-    return a_lo ? dispatch_wgrad_bf16x<3>(a, QH, QW, HA, WA, sa, HB, WB, sb, CA, CB, ntaps, CDF_S)
-                : dispatch_wgrad_bf16x<1>(a, QH, QW, HA, WA, sa, HB, WB, sb, CA, CB, ntaps, CDF_S);
+    return a_lo ? dispatch_wgrad_bf16x<3>(a, QH, QW, HA, WA, sa, HB, WB, sb, CA, CB, ntaps, *cdf_tune(tune), CDF_S)
+                : dispatch_wgrad_bf16x<1>(a, QH, QW, HA, WA, sa, HB, WB, sb, CA, CB, ntaps, *cdf_tune(tune), CDF_S);
 }

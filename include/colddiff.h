@@ -152,6 +152,32 @@ int cdf_conv_gemm_bf16(const float* x, int ldx, const void* w_hi, const void* w_
 int cdf_conv_wgrad_bf16(const float* xa, int lda, const float* xb, int ldb, float* ws, int ldo, int B, int QH, int QW, int HA,
                         int WA, int sa, int HB, int WB, int sb, int CA, int CB, int ntaps, const int* tap_desc, int nsplit,
                         float* bsum, void* stream);
+/* RE-ENTRANCY.  Every entry point is a pure function of its arguments: the library keeps NO mutable process-wide state (the only
+ * statics are one-time hipFuncSetAttribute(MaxDynamicSharedMemorySize) latches, idempotent).  What used to be process-wide tuning
+ * setters is an explicit, OPTIONAL argument of the pre-split GEMM entry points: `const cdf_gemm_tuning* tune`, NULL = the defaults
+ * below.  The fields only choose between kernels / tile shapes that compute the same sums (fp32 summation order aside), so two
+ * models in one process -- or forward and backward threads -- can use different settings.  Fill a struct with
+ * cdf_gemm_tuning_default() and change fields; `size` must stay sizeof(cdf_gemm_tuning) (checked: CDF_E_INVALID otherwise). */
+typedef struct cdf_gemm_tuning {
+    int size;            /* sizeof(cdf_gemm_tuning) */
+    int tile_bm;         /* 0: automatic; 64 / 128 / 256: force the row tile of the generic gather-GEMM (256 only with tile_bn 128) */
+    int tile_bn;         /* 0: automatic; 64 / 128: force its column tile */
+    int max_bm;          /* 0: none; 128: the automatic choice never takes the 256 x 128 tile */
+    int dephase;         /* 1: waves 4..7 of the 8-wave tiles multiply the previous K step's fragments first, read afterwards */
+    int deep;            /* 1: grids of <= 256 64-row tiles run with six DMA stages, one block per CU */
+    int splitk;          /* 0; 1: ... and share the taps out over block groups when a workspace is given (measured +-1 %) */
+    int halo;            /* 47: bit mask of the LDS-resident-input kernel over the image width 16 (1), 32 (2), 64 (4), 128 (8); 16 = at
+                            width 128 also for > 64 output channels; 32 = row-halo form (256-pixel tiles, input shared by the dx taps of
+                            a row) for the > 64-channel outputs at width 128; 64 = row-halo form wherever it applies; 0 = never */
+    int halo_min_tiles;  /* 1: smallest tile count (128 pixels x BN) the LDS-resident form is used for */
+    int halo_bm;         /* 0: automatic (256 pixels where every CU still gets a tile); 128 / 256 */
+    int small_n64;       /* 1: 64-wide N tiles in the LDS-resident form when 128-wide ones would give < ~2/3 of the CUs a block */
+    int wgrad_stack;     /* 1: two taps per 128-row tile in cdf_conv_wgrad_bf16x when CA <= 64 < CB */
+    int wgrad_swizzle;   /* 1: XCD-aware block order of cdf_conv_wgrad_bf16x (the taps of a pixel range share one XCD's L2) */
+    int wgrad_row3;      /* 1: weight gradients of 3 x 3 stride-1 same-size convolutions by one block per ROW of taps */
+} cdf_gemm_tuning;
+int cdf_gemm_tuning_default(cdf_gemm_tuning* t);
+
 /* Pre-split operand variants: an activation that feeds several GEMMs (forward, data gradient, weight
  * gradient, every N tile) is split ONCE into bf16 hi / lo planes [rows][ld] by cdf_split_bf16; the GEMMs
  * then only copy and multiply.  Every lo pointer is OPTIONAL: with x_lo == w_lo == NULL (a_lo == b_lo == NULL for the weight
@@ -165,63 +191,20 @@ int cdf_split_bf16(const float* x, int ldx, void* hi, void* lo, int ldo, long lo
 /* ws / ws_floats (nullable): workspace for split-K launches.  A grid far below one tile per CU (M = B*QH*QW of a few hundred pixels: the
  * 4 x 4 / 8 x 8 levels of the 32 x 32 configurations) shares the taps out over ks = cdf_conv_gemm_bf16x_ksplit(M, Cout, nphase, ntaps of
  * phase 0) block groups whose partial sums go through ws (>= ks * M * roundup4(Cout) floats, 16-byte aligned) and a finish kernel that
- * runs the epilogue; without a (large enough) workspace, or when the query returns 1 (always, unless cdf_conv_gemm_bf16x_splitk(1) was called: the
+ * runs the epilogue; without a (large enough) workspace, or when the query returns 1 (always, unless tune->splitk is set: the
  * split is off by default), the launch is the plain one.  The library never allocates. */
-int cdf_conv_gemm_bf16x_ksplit(int M, int Cout, int nphase, int ntaps);
+int cdf_conv_gemm_bf16x_ksplit(int M, int Cout, int nphase, int ntaps, const cdf_gemm_tuning* tune);
 int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo, int ldk,
                         float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW, int os, int is,
                         int nphase, const int* phase_desc, const float* bias, const float* sbias, int ld_sbias, const float* res,
                         int ldr, float* pre, int ldp, const float* mul, int ldm, int act, int mul_mode, int accumulate,
-                        void* y_hi, void* y_lo, int ld_ys, float* ws, long long ws_floats, void* stream);
-/* RE-ENTRANCY.  Every compute entry point is a pure function of its arguments: no mutable process-wide state is read on the product
- * path.  The `tuning / test hook` setters below each store one std::atomic word that later launches read once (autograd runs the
- * backward launches on its own thread, so the knobs have to be process-wide to be usable at all); they only choose between kernels
- * that compute the same sums, and the Python package never calls them -- tests, tools/convbench.py and tools/ablate.py do (or the
- * COLDDIFF_SPX_* / COLDDIFF_WGRAD_* environment variables read once when the library is loaded).  The only other statics are one-time
- * hipFuncSetAttribute(MaxDynamicSharedMemorySize) latches (idempotent).
- * Tuning / test hook: force the block tile of cdf_conv_gemm_bf16x (rows of pixels x output channels; bm 64, 128 or
- * 256 -- the latter with bn = 128 --, bn 64 or 128; 0 = automatic choice from the problem size).  Process-wide (an atomic word each); results
- * do not depend on it. */
-int cdf_conv_gemm_bf16x_tile(int bm, int bn);
-/* tuning / test hook: waves of the 128 x 128 tile of cdf_conv_gemm_bf16x: 0 (default: 4), 4 or 8 (4 x 2 waves of 32 x 64, two blocks per CU) */
-int cdf_conv_gemm_bf16x_waves(int waves);
-/* tuning / test hook: upper bound of the AUTOMATIC row-tile choice of cdf_conv_gemm_bf16x: 0 / 256 = none, 128 = never the 256 x 128 tile */
-int cdf_conv_gemm_bf16x_max_bm(int bm);
-/* tuning / test hook: per-block row-group order of the 3 x 3 taps when a tile of cdf_conv_gemm_bf16x is exactly one image row
- * (1, default: the three tiles that need an input row read it at the same time, one L2 fill instead of three) or the
- * table's order (0).  Only the fp32 summation order depends on it. */
-int cdf_conv_gemm_bf16x_taprot(int enable);
-/* tuning / test hook: de-phased waves in the 8-wave tiles of cdf_conv_gemm_bf16x (1, default): waves 4..7 of a block share their
- * SIMDs with waves 0..3; they multiply the fragments read in the previous K step first and read / request afterwards, so that one
- * wave of a SIMD feeds the matrix pipe while the other one reads LDS or issues global_load_lds.  Only the schedule depends on it. */
-int cdf_conv_gemm_bf16x_dephase(int enable);
-int cdf_conv_gemm_bf16x_deep(int enable);     /* 1 (default): grids of <= 256 64-row tiles run with six DMA stages, one block per CU */
-int cdf_conv_gemm_bf16x_splitk(int enable);   /* 1: ... and share the taps out over block groups when a workspace is given (see cdf_conv_gemm_bf16x); default 0: measured +-1 % on the 32 x 32 configurations */
-/* tuning / test hook: 3 x 3 stride-1 layers of cdf_conv_gemm_bf16x with the input tile (+ one-pixel halo) resident in LDS for
- * all nine taps.  enable: bit mask over the image width 16 (1), 32 (2), 64 (4), 128 (8), and 16 = at width 128 also for
- * layers with more than 64 output channels; 32 = the row-halo form (256-pixel tiles, input shared by the three dx taps of a row only)
- * for the > 64-channel outputs at width 128; 64 = the row-halo form wherever it applies; default 47; 0 = always the generic
- * gather kernel.  min_tiles: smallest tile count (128 pixels x BN) the LDS-resident form is used for.  Only the fp32
- * summation order depends on it. */
-int cdf_conv_gemm_bf16x_halo(int enable, int min_tiles);
-/* tuning / test hook: pixels per tile of the LDS-resident-input kernel: 0 = automatic (256 where every CU still gets a tile), 128, 256 */
-int cdf_conv_gemm_bf16x_halo_bm(int bm);
-/* tuning / test hook: 64-wide N tiles in the LDS-resident-input kernel when 128-wide ones would give fewer than ~2/3 of the CUs a block (1, default) */
-int cdf_conv_gemm_bf16x_small_n64(int enable);
-/* Tuning / test hook: allow (1, default) or forbid (0) the two-taps-per-tile form of cdf_conv_wgrad_bf16x used when
- * CA <= 64 < CB.  Process-wide (an atomic word each); results do not depend on it. */
-int cdf_conv_wgrad_bf16x_stack(int enable);
-/* Tuning / test hook: XCD-aware block order of cdf_conv_wgrad_bf16x (1, default: the taps of a pixel range share one
- * XCD's L2) or plain dispatch order (0).  Process-wide (an atomic word each); results do not depend on it. */
-int cdf_conv_wgrad_bf16x_swizzle(int enable);
-/* Tuning / test hook: weight gradients of 3 x 3 stride-1 same-size convolutions by one block per ROW of taps (1, default: dY and
- * X with a pixel of halo are loaded once for the three dx taps) or one block per tap (0).  cdf_conv_wgrad_bf16x_is_row3 tells the
- * caller whether a geometry takes that kernel (3 tap blocks per tile, one 512-thread block per CU) so that it can size nsplit. */
-int cdf_conv_wgrad_bf16x_row3(int enable);
-int cdf_conv_wgrad_bf16x_is_row3(int QH, int QW, int CA, int CB, int ntaps, int same_size_3x3);
+                        void* y_hi, void* y_lo, int ld_ys, float* ws, long long ws_floats, const cdf_gemm_tuning* tune, void* stream);
+/* cdf_conv_wgrad_bf16x_is_row3 tells the caller whether a geometry takes the row-of-taps kernel (3 tap blocks per tile, one 512-thread
+ * block per CU) so that it can size nsplit. */
+int cdf_conv_wgrad_bf16x_is_row3(int QH, int QW, int CA, int CB, int ntaps, int same_size_3x3, const cdf_gemm_tuning* tune);
 int cdf_conv_wgrad_bf16x(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, int ldb, const void* zero,
                          float* ws, int ldo, int B, int QH, int QW, int HA, int WA, int sa, int HB, int WB, int sb, int CA, int CB,
-                         int ntaps, const int* tap_desc, int nsplit, float* bsum, void* stream);
+                         int ntaps, const int* tap_desc, int nsplit, float* bsum, const cdf_gemm_tuning* tune, void* stream);
 
 /* Device-side input pipeline (replaces Dataset_Aug1 / Dataset + DataLoader, deblurring_diffusion_pytorch.py:983-1026, 1094-1096).
  * cache: [N][S][S][C] uint8 (NHWC) images already resized to S = int(1.12 image_size) (the deterministic Resize of the reference's
@@ -270,16 +253,14 @@ int cdf_pack_entry_bytes(void);
 int cdf_pack_blocks(int T, int R, int ldc, long long s_t);
 int cdf_pack_many(const void* table, int nentries, int nblocks, void* stream);
 int cdf_unpack_reduce(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t,
-                      long long s_r, long long s_c, int accumulate, void* stream);
+                      long long s_r, long long s_c, int accumulate, int tiled, void* stream);
 /* the same with the bias-gradient reduction of the same weight-gradient launch folded in (one launch instead of two):
  * gbias[c] (+)= sum_z bias_ws[z * bias_ld + c], c < C (the `bsum` partials of cdf_conv_wgrad*). */
 int cdf_unpack_reduce_bias(const float* ws, float* g, int nsplit, int T, int R, int C, int ldc, long long s_t, long long s_r,
-                           long long s_c, const float* bias_ws, float* gbias, int bias_ld, int accumulate, void* stream);
-/* tuning / test hook (process-wide, see RE-ENTRANCY): 1 / 2 (default 1) = parameter layouts whose fast index is not the slab's (s_c != 1, T in
- * {1, 9, 16}) are reduced by the LDS-tiled transposing kernel (contiguous runs per output channel instead of lone 4-byte
- * read-modify-writes; 2: tiles whose runs continue each other share an XCD -- measured: no difference); 0 = always the element-wise kernel.  Same sums either way up
- * to fp32 summation order. */
-int cdf_unpack_reduce_tiled(int on);
+                           long long s_c, const float* bias_ws, float* gbias, int bias_ld, int accumulate, int tiled, void* stream);
+/* `tiled` (both entry points): 1 (what the package passes) = parameter layouts whose fast index is not the slab's (s_c != 1, T in {1, 9, 16})
+ * are reduced by the LDS-tiled transposing kernel (contiguous runs per output channel instead of lone 4-byte read-modify-writes);
+ * 0 = always the element-wise kernel.  Same sums either way up to fp32 summation order. */
 
 /* out[seg][c] (+)= sum over the rows of segment seg of x[r*ld + c]  (bias / time-bias gradients);
  * ws >= nseg * cdf_colsum_nchunk(rows_per_seg) * C floats */
@@ -332,31 +313,24 @@ int cdf_dwconv7_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
  *   dk = P * (dP - rvec)                                  (cdf_linattn_dk)
  * ws >= cdf_linattn_ws_floats(B,n,heads) floats. */
 int cdf_linattn_nsplit(int n);
-/* tuning / test hook (process-wide, see RE-ENTRANCY): 1 (default) = cdf_linattn_context reads k and v ONCE (per-tile maxima, partials
- * rescaled in the finalize kernel: online softmax); 0 = column-max pass + context pass.  Same results up to fp32 rounding. */
-int cdf_linattn_onepass(int on);
 size_t cdf_linattn_ws_floats(int B, int n, int heads);
 /* koff: channel offset of k inside a row (v follows at koff + heads*32): heads*32 for the reference's (q|k|v) tensor, 0 for a (k|v)
  * tensor (the q-free form of colddiff/ops.py linattn_fold: q never exists when dim <= heads*32). */
+/* onepass: 1 (what the package passes) = k and v are read ONCE (per-tile maxima, partials rescaled in the finalize kernel: online softmax);
+ * 0 = column-max pass + context pass.  Same results up to fp32 rounding. */
 int cdf_linattn_context(const float* qkv, int ld, int koff, float* ctx, float* ctxs, float* kmax, float* ksum, float* ws, int B,
-                        int n, int heads, float scale, void* stream);
+                        int n, int heads, float scale, int onepass, void* stream);
 /* cdf_linattn_kvctx (round 2): the k | v projection kv = xn . Wkv^T ([B,n,256], 4 heads; Wkv as bf16 hi [/ lo] planes [256][ldk], K contiguous:
  * cdf_pack_weight_bf16; w_lo == NULL: single bf16 operands) AND the context partials of the same pixels in one pass -- k and v are written once
- * and not read back by the forward pass.  n % 128 == 0, dim % 32 == 0.  ws: (2*128 + 4*1024) * B * cdf_linattn_kvctx_parts(B, n) floats;
- * cdf_linattn_finalize(ws, nparts = cdf_linattn_kvctx_parts(B, n), ...) then yields what cdf_linattn_context yields (ctx, ctxs, kmax, ksum). */
-int cdf_linattn_kvctx_parts(int B, int n);
-int cdf_linattn_kvctx_slots(int slots);       /* tuning / test hook (process-wide): target block count per launch (default 512) */
+ * and not read back by the forward pass.  n % 128 == 0, dim % 32 == 0.  ws: (2*128 + 4*1024) * B * cdf_linattn_kvctx_parts(B, n, slots) floats;
+ * cdf_linattn_finalize(ws, nparts = cdf_linattn_kvctx_parts(B, n, slots), ...) then yields what cdf_linattn_context yields (ctx, ctxs, kmax, ksum). */
+/* slots (both): target block count per launch, <= 0 = the default 512 (about two blocks per CU queued); the SAME value must be given to
+ * cdf_linattn_kvctx_parts (workspace size, nparts of cdf_linattn_finalize) and to cdf_linattn_kvctx. */
+int cdf_linattn_kvctx_parts(int B, int n, int slots);
 int cdf_linattn_kvctx(const float* xn, int ldx, const void* w_hi, const void* w_lo, int ldk, float* kv, int ldkv, float* ws, int B, int n,
-                      int dim, int heads, void* stream);
+                      int dim, int heads, int slots, void* stream);
 int cdf_linattn_finalize(const float* ws, int nparts, float* ctx, float* ctxs, float* kmax, float* ksum, int B, int heads, float scale,
                          void* stream);
-/* cdf_linattn_bwd_kv_dgrad (round 2): cdf_linattn_bwd_kv on a (k|v) tensor (koff = dkoff = 0) AND the data gradient of the k | v projection
- * in the same pass: dxn[b,n,:dim] += dkv[b,n,:] . Wkv, with Wkv as bf16 hi [/ lo] planes [dim][ldk >= 256] (K = the 256 k|v channels contiguous:
- * the "data gradient" packing of the projection; w_lo == NULL: single bf16 operands).  dk | dv are still written (the weight gradient reads
- * them) but not read back.  4 heads, dim 64 or 128. */
-int cdf_linattn_bwd_kv_dgrad(const float* kv, int ld, const float* dctx, const float* rvec, const float* kmax, const float* ksum, float* dkv,
-                             int lddq, const void* w_hi, const void* w_lo, int ldk, float* dxn, int lddx, int B, int n, int dim, int heads,
-                             void* stream);
 int cdf_linattn_dcontext(const float* qkv, int ld, const float* dout, int lddo, const float* ctx, float* dctx,
                          float* rvec, float* ws, int B, int n, int heads, float scale, void* stream);
 int cdf_linattn_softk(const float* qkv, int ld, const float* kmax, const float* ksum, float* pn, int ldp, int B, int n,

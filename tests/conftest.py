@@ -46,6 +46,8 @@ class Backend:
             from emu_util import emu_lib
             self.L = emu_lib()
             self.device = torch.device("cpu")
+        from colddiff import _lib as _l
+        self.tune = _l.GemmTuning(self.L)          # the explicit tuning argument of the pre-split GEMM entry points (defaults; tests set fields)
 
     def to(self, t):
         """Device copy of t; kept alive until the end of the test (tests pass raw pointers inline)."""

@@ -93,7 +93,7 @@ def test_argument_checks_of_the_gemm_and_blend_entry_points():
             raise AssertionError("expected CdfError containing %r" % text)
 
     # pre-split GEMM: unaligned operand, channel count not a multiple of 8, split planes without the vectorised epilogue layout
-    gemm = [p, p, 8, p, p, p, 32, p, 8, 1, 4, 4, 8, 4, 4, 8, 4, 4, 1, 1, 1, desc, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]
+    gemm = [p, p, 8, p, p, p, 32, p, 8, 1, 4, 4, 8, 4, 4, 8, 4, 4, 1, 1, 1, desc, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]
     bad = list(gemm); bad[0] = p + 2
     expect(lib.cdf_conv_gemm_bf16x, bad, "16B aligned")
     bad = list(gemm); bad[12] = 6
@@ -101,10 +101,17 @@ def test_argument_checks_of_the_gemm_and_blend_entry_points():
     bad = list(gemm); bad[34], bad[35], bad[36] = p, p, 6
     expect(lib.cdf_conv_gemm_bf16x, bad, "output planes need")
     # weight gradient: tap count out of range
-    expect(lib.cdf_conv_wgrad_bf16x, [p, p, 8, p, p, 8, p, p, 8, 1, 4, 4, 4, 4, 1, 4, 4, 1, 8, 8, 0, desc, 1, 0, 0], "tap / split count")
+    expect(lib.cdf_conv_wgrad_bf16x, [p, p, 8, p, p, 8, p, p, 8, 1, 4, 4, 4, 4, 1, 4, 4, 1, 8, 8, 0, desc, 1, 0, 0, 0], "tap / split count")
     # per-pixel blend: t = 0 is not a reverse step
     expect(lib.cdf_blend_step, [p, p, p, p, p, 0, p, 16, 48, 0], "bad args")
     expect(lib.cdf_blend_qsample, [p, p, p, p, 0, p, 1, 3, 16, 0], "bad args")
-    # tuning hooks validate their values too
-    expect(lib.cdf_conv_gemm_bf16x_tile, [96, 128], "bm is 0")
-    expect(lib.cdf_conv_gemm_bf16x_halo_bm, [192], "0, 128 or 256")
+    # the optional tuning argument is validated: a struct of the wrong size (another header version) or with impossible tiles is refused;
+    # the library has no setters and no tuning state of its own
+    tune = _lib.GemmTuning(lib)
+    assert tune.get("halo") == 47 and tune.get("dephase") == 1 and tune.get("splitk") == 0 and tune.get("small_n64") == 1
+    bad = list(gemm); bad[-2] = tune.set(tile_bm=96).ptr
+    expect(lib.cdf_conv_gemm_bf16x, bad, "bad cdf_gemm_tuning")
+    bad = list(gemm); bad[-2] = tune.set(tile_bm=0, size=8).ptr
+    expect(lib.cdf_conv_gemm_bf16x, bad, "bad cdf_gemm_tuning")
+    assert not [n for n in lib.protos if n.endswith(("_tile", "_halo", "_halo_bm", "_dephase", "_deep", "_splitk", "_taprot", "_waves", "_row3",
+                                                     "_swizzle", "_stack", "_onepass", "_slots", "_tiled", "_max_bm", "_small_n64")) and n != "cdf_conv_wgrad_bf16x_is_row3"]

@@ -272,10 +272,10 @@ def _conv_case(be, B, Cin, Cout, H, k, s, p, transposed):
     be.L.cdf_conv_wgrad(P(xn), xn.shape[-1], P(gyn), gyn.shape[-1], P(ws), ldo, B, wg.QH, wg.QW, wg.HA, wg.WA, wg.sa, wg.HB, wg.WB, wg.sb,
                         Cin, Cout, wg.ntaps, wg.desc, ns, 1, 0, 0, 0, P(bsum), be.stream())
     dw = be.zeros(*wshape)
-    be.L.cdf_unpack_reduce(P(ws), P(dw), ns, KK, Cin, Cout, ldo, 1, s_r, s_c, 0, be.stream())
+    be.L.cdf_unpack_reduce(P(ws), P(dw), ns, KK, Cin, Cout, ldo, 1, s_r, s_c, 0, 1, be.stream())
     if bsum is not None:                        # fused bias gradient = column sums of dY
         db = be.zeros(Cout)
-        be.L.cdf_unpack_reduce(P(bsum), P(db), ns, 1, 1, Cout, ldo, 0, 0, 1, 0, be.stream())
+        be.L.cdf_unpack_reduce(P(bsum), P(db), ns, 1, 1, Cout, ldo, 0, 0, 1, 0, 1, be.stream())
         assert err(db, gy.sum((0, 2, 3))) <= 2e-6 * max(1.0, gy.sum((0, 2, 3)).abs().max().item()) * math.sqrt(M)
     tol = lambda ref: 2e-6 * max(1.0, ref.abs().max().item()) * math.sqrt(max(Cin * KK, 16))
     assert err(y[..., :Cout].permute(0, 3, 1, 2), yref) <= tol(yref)
@@ -468,17 +468,16 @@ def test_linattn_context_one_pass(be, B, n, heads, koff):
     res = []
     try:
         for onepass in (1, 0):
-            be.L.cdf_linattn_onepass(onepass)
             ctx, ctxs, kmax, ksum = be.empty(B, heads, 32, 32), be.empty(B, heads, 32, 32), be.empty(B, HD), be.empty(B, HD)
             ws = be.empty(be.L.cdf_linattn_ws_floats(B, n, heads))
-            be.L.cdf_linattn_context(P(td), ld, koff, P(ctx), P(ctxs), P(kmax), P(ksum), P(ws), B, n, heads, scale, be.stream())
+            be.L.cdf_linattn_context(P(td), ld, koff, P(ctx), P(ctxs), P(kmax), P(ksum), P(ws), B, n, heads, scale, onepass, be.stream())
             assert torch.equal(kmax.cpu(), kmax_ref.float())
             assert err(ksum, ksum_ref.float()) <= 1e-5 * ksum_ref.max().item()
             assert err(ctx, ctx_ref) <= 1e-5 * max(1.0, ctx_ref.abs().max().item())
             assert err(ctxs, ctx_ref * scale) <= 1e-5 * max(1.0, ctx_ref.abs().max().item())
             res.append(ctx.cpu().clone())
     finally:
-        be.L.cdf_linattn_onepass(1)
+        pass
     assert (res[0] - res[1]).abs().max().item() <= 1e-5 * max(1.0, ctx_ref.abs().max().item())
 
 
@@ -554,13 +553,12 @@ def test_linattn_kvctx_fused(be, B, n, dim, slots, split):
     be.L.cdf_pack_weight_bf16(P(wd) + 4 * HD * dim, P(whi), P(wlo), 1, 2 * HD, dim, ldk, 1, dim, 1, be.stream())
     kv = be.empty(B, n, 2 * HD)
     try:
-        be.L.cdf_linattn_kvctx_slots(slots)
-        parts = be.L.cdf_linattn_kvctx_parts(B, n)
+        parts = be.L.cdf_linattn_kvctx_parts(B, n, slots)
         assert parts == min(max(slots // B, 1), n // 128) or parts >= 1
         ws = be.empty(B * parts * (2 * HD + heads * 1024))
-        be.L.cdf_linattn_kvctx(P(be.to(xn)), dim, P(whi), P(wlo), ldk, P(kv), 2 * HD, P(ws), B, n, dim, heads, be.stream())
+        be.L.cdf_linattn_kvctx(P(be.to(xn)), dim, P(whi), P(wlo), ldk, P(kv), 2 * HD, P(ws), B, n, dim, heads, slots, be.stream())
     finally:
-        be.L.cdf_linattn_kvctx_slots(512)
+        pass
     ctx, ctxs, kmax, ksum = be.empty(B, heads, 32, 32), be.empty(B, heads, 32, 32), be.empty(B, HD), be.empty(B, HD)
     be.L.cdf_linattn_finalize(P(ws), parts, P(ctx), P(ctxs), P(kmax), P(ksum), B, heads, scale, be.stream())
     rel = 3e-5 if split == 3 else 2e-2
@@ -575,37 +573,6 @@ def test_linattn_kvctx_fused(be, B, n, dim, slots, split):
     assert err(ksum, ksum_ref.float()) <= 1e-5 * ksum_ref.max().item()
     assert err(ctx, ctx_ref) <= 2e-5 * max(1.0, ctx_ref.abs().max().item())
     assert err(ctxs, ctx_ref * scale) <= 2e-5 * max(1.0, ctx_ref.abs().max().item())
-
-
-@pytest.mark.parametrize("B,n,dim,split", [(2, 300, 64, 3), (1, 256, 128, 3), (1, 70, 64, 1)])
-def test_linattn_bwd_kv_dgrad_fused(be, B, n, dim, split):
-    """cdf_linattn_bwd_kv_dgrad = cdf_linattn_bwd_kv on a (k|v) tensor + dxn += dkv . Wkv in one pass: dk | dv bit-equal to the separate
-    kernel, dxn against the fp64 product (split-precision tolerance), ragged pixel counts, both weight widths, accumulation onto dxn."""
-    torch.manual_seed(n + dim)
-    heads, HD = 4, 128
-    kv = torch.randn(B, n, 2 * HD)
-    k = kv[..., :HD]
-    kmax = k.max(1).values
-    ksum = torch.exp(k - kmax[:, None]).sum(1)
-    dctx = torch.randn(B, heads, 32, 32) * 0.3
-    ctx = torch.randn(B, heads, 32, 32)
-    rvec = (dctx * ctx).sum(-1).reshape(B, HD)
-    w = torch.randn(3 * HD, dim) / math.sqrt(dim)
-    dxn0 = torch.randn(B, n, dim)
-    kvd, dctxd, rvd, kmd, ksd = be.to(kv), be.to(dctx), be.to(rvec), be.to(kmax), be.to(ksum)
-    ref = be.zeros(B, n, 2 * HD)
-    be.L.cdf_linattn_bwd_kv(P(kvd), 2 * HD, 0, P(dctxd), P(rvd), P(kmd), P(ksd), P(ref), 2 * HD, 0, B, n, heads, be.stream())
-    whi = torch.zeros(1, dim, 256, dtype=torch.int16, device=be.device)
-    wlo = torch.zeros_like(whi) if split == 3 else None
-    wd = be.to(w)
-    be.L.cdf_pack_weight_bf16(P(wd) + 4 * HD * dim, P(whi), P(wlo), 1, dim, 2 * HD, 256, 1, 1, dim, be.stream())
-    dkv, dxn = be.zeros(B, n, 2 * HD), be.to(dxn0)
-    be.L.cdf_linattn_bwd_kv_dgrad(P(kvd), 2 * HD, P(dctxd), P(rvd), P(kmd), P(ksd), P(dkv), 2 * HD, P(whi), P(wlo), 256, P(dxn), dim, B, n, dim,
-                                  heads, be.stream())
-    assert torch.equal(dkv.cpu(), ref.cpu())
-    want = dxn0.double() + ref.cpu().double() @ w[HD:].double()
-    rel = 3e-5 if split == 3 else 2e-2
-    assert err(dxn, want.float()) <= rel * max(1.0, want.abs().max().item())
 
 
 def test_small_ops(be):
@@ -726,11 +693,11 @@ def _sp_case(be, split, B, Cin, Cout, H, k, s, p, transposed):
                                  wg.sb, Cin, Cout, wg.ntaps, wg.desc, ns, 0 if transposed else P(bsum), be.stream())
         dw = be.zeros(*wshape)
         s_r, s_c = (Cout * KK, KK) if transposed else (KK, Cin * KK)
-        be.L.cdf_unpack_reduce(P(ws), P(dw), ns, KK, Cin, Cout, ldo, 1, s_r, s_c, 0, be.stream())
+        be.L.cdf_unpack_reduce(P(ws), P(dw), ns, KK, Cin, Cout, ldo, 1, s_r, s_c, 0, 1, be.stream())
         assert err(dw, w.grad) <= 3e-5 * max(1.0, w.grad.abs().max().item()) * math.sqrt(M / 16)
         if not transposed:
             db = be.zeros(Cout)
-            be.L.cdf_unpack_reduce(P(bsum), P(db), ns, 1, 1, Cout, ldo, 0, 0, 1, 0, be.stream())
+            be.L.cdf_unpack_reduce(P(bsum), P(db), ns, 1, 1, Cout, ldo, 0, 0, 1, 0, 1, be.stream())
             assert err(db, gy.sum((0, 2, 3))) <= 1e-5 * max(1.0, gy.sum((0, 2, 3)).abs().max().item()) * math.sqrt(M)
     rel = 3e-5 if split == 3 else 2e-2            # bf16x3 keeps 16 mantissa bits per operand; bf16 keeps 8
     tol = lambda ref: rel * max(1.0, ref.abs().max().item())
@@ -820,22 +787,22 @@ def _spx_case(be, B, Cin, Cout, H, k, s, p):
         y = be.zeros(B, pl.OH, pl.OW, r4(Co))
         be.L.cdf_conv_gemm_bf16x(P(xsplit[0]), P(xsplit[1]), xsplit[0].shape[-1], P(zero), P(wpair[0]), P(wpair[1]), wpair[0].shape[-1], P(y),
                                  y.shape[-1], B, pl.H, pl.W, Ci, pl.OH, pl.OW, Co, pl.QH, pl.QW, pl.os, pl.istride, pl.nphase, pl.desc,
-                                 P(bias_), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, be.stream())
+                                 P(bias_), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, be.tune.ptr, be.stream())
         # small grids: the same launch with a split-K workspace (taps shared out over block groups + finish kernel)
         Mq = B * pl.QH * pl.QW
         try:
-            be.L.cdf_conv_gemm_bf16x_splitk(1)                # (off by default)
-            ks = be.L.cdf_conv_gemm_bf16x_ksplit(Mq, Co, pl.nphase, pl.desc[2])
+            be.tune.set(splitk=1)                             # (off by default)
+            ks = be.L.cdf_conv_gemm_bf16x_ksplit(Mq, Co, pl.nphase, pl.desc[2], be.tune.ptr)
             if ks > 1:
                 ws = be.empty(ks * Mq * r4(Co))
                 y_ws = be.zeros(B, pl.OH, pl.OW, r4(Co))
                 be.L.cdf_conv_gemm_bf16x(P(xsplit[0]), P(xsplit[1]), xsplit[0].shape[-1], P(zero), P(wpair[0]), P(wpair[1]), wpair[0].shape[-1],
                                          P(y_ws), y_ws.shape[-1], B, pl.H, pl.W, Ci, pl.OH, pl.OW, Co, pl.QH, pl.QW, pl.os, pl.istride, pl.nphase,
-                                         pl.desc, P(bias_), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, P(ws), ks * Mq * r4(Co), be.stream())
+                                         pl.desc, P(bias_), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, P(ws), ks * Mq * r4(Co), be.tune.ptr, be.stream())
                 assert err(y_ws[..., :Co], y[..., :Co].cpu()) <= 2e-6 * max(1.0, y.abs().max().item()) * math.sqrt(ks)
                 return y_ws
         finally:
-            be.L.cdf_conv_gemm_bf16x_splitk(0)
+            be.tune.set(splitk=0)
         return y
 
     y = run(plan, xs, wf, Cin, Cout, be.to(bias))
@@ -848,17 +815,17 @@ def _spx_case(be, B, Cin, Cout, H, k, s, p):
         y2 = be.zeros(B, plan.OH, plan.OW, r4(Cout))
         be.L.cdf_conv_gemm_bf16x(P(xs[0]), P(xs[1]), xs[0].shape[-1], P(zero), P(wf[0]), P(wf[1]), wf[0].shape[-1], P(y2), y2.shape[-1], B,
                                  plan.H, plan.W, Cin, plan.OH, plan.OW, Cout, plan.QH, plan.QW, plan.os, plan.istride, plan.nphase,
-                                 plan.desc, P(be.to(bias)), 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, P(yh), P(yl), ld8, 0, 0, be.stream())
+                                 plan.desc, P(be.to(bias)), 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, P(yh), P(yl), ld8, 0, 0, be.tune.ptr, be.stream())
         rh, rl = _split(be, y2[..., :Cout].contiguous(), single)
         assert torch.equal(yh.cpu(), rh.cpu()) and (single or torch.equal(yl.cpu(), rl.cpu()))
     M = B * wg.QH * wg.QW
     ns, ldo = max(1, min(3, M // 32)), r4(Cout)
     ws, bsum = be.empty(ns, KK, Cin, ldo), be.empty(ns, ldo)
     be.L.cdf_conv_wgrad_bf16x(P(xs[0]), P(xs[1]), xs[0].shape[-1], P(gs[0]), P(gs[1]), gs[0].shape[-1], P(zero), P(ws), ldo, B, wg.QH, wg.QW,
-                              wg.HA, wg.WA, wg.sa, wg.HB, wg.WB, wg.sb, Cin, Cout, wg.ntaps, wg.desc, ns, P(bsum), be.stream())
+                              wg.HA, wg.WA, wg.sa, wg.HB, wg.WB, wg.sb, Cin, Cout, wg.ntaps, wg.desc, ns, P(bsum), be.tune.ptr, be.stream())
     dw, db = be.zeros(Cout, Cin, k, k), be.zeros(Cout)
-    be.L.cdf_unpack_reduce(P(ws), P(dw), ns, KK, Cin, Cout, ldo, 1, KK, Cin * KK, 0, be.stream())
-    be.L.cdf_unpack_reduce(P(bsum), P(db), ns, 1, 1, Cout, ldo, 0, 0, 1, 0, be.stream())
+    be.L.cdf_unpack_reduce(P(ws), P(dw), ns, KK, Cin, Cout, ldo, 1, KK, Cin * KK, 0, 1, be.stream())
+    be.L.cdf_unpack_reduce(P(bsum), P(db), ns, 1, 1, Cout, ldo, 0, 0, 1, 0, 1, be.stream())
     tol = lambda ref: 3e-5 * max(1.0, ref.abs().max().item())
     assert err(y[..., :Cout].permute(0, 3, 1, 2), yref) <= tol(yref)
     assert err(dx[..., :Cin].permute(0, 3, 1, 2), dx_ref) <= tol(dx_ref)
@@ -871,17 +838,15 @@ def test_conv_presplit(be, case):
     _spx_case(be, *case)
 
 
-@pytest.mark.parametrize("tile", [(256, 128, 0), (128, 128, 4), (128, 128, 8), (128, 64, 0), (64, 128, 0), (64, 64, 0)])
+@pytest.mark.parametrize("tile", [(256, 128), (128, 128), (128, 64), (64, 128), (64, 64)])
 def test_conv_presplit_forced_tiles(be, tile):
-    """Every block-tile instantiation of the pre-split GEMM (incl. the 8-wave form of the 128 x 128 tile) on a shape with
-    ragged M and N tiles (the automatic choice would only ever pick the 64-row tiles at emulator-sized problems)."""
-    be.L.cdf_conv_gemm_bf16x_tile(*tile[:2])
-    be.L.cdf_conv_gemm_bf16x_waves(tile[2])
+    """Every block-tile instantiation of the pre-split GEMM on a shape with ragged M and N tiles (the automatic choice would only
+    ever pick the 64-row tiles at emulator-sized problems)."""
+    be.tune.set(tile_bm=tile[0], tile_bn=tile[1])
     try:
         _spx_case(be, 3, 40, 72, 7, 3, 1, 1)
     finally:
-        be.L.cdf_conv_gemm_bf16x_tile(0, 0)
-        be.L.cdf_conv_gemm_bf16x_waves(0)
+        be.tune.set(tile_bm=0, tile_bn=0)
 
 
 @pytest.mark.parametrize("case", [(1, 64, 96, 16, 3, 1, 1), (2, 96, 40, 16, 3, 1, 1), (1, 64, 72, 32, 3, 1, 1)])
@@ -889,29 +854,29 @@ def test_conv_presplit_halo(be, case):
     """3 x 3 stride-1 layers with the input tile resident in LDS (conv_igemm_halo_kernel): 128-pixel strips of 16- and 32-wide
     images, 128- and 64-wide N tiles, several channel chunks, forward taps and the mirrored taps of the data gradient; the
     generic kernel must give the same numbers to rounding."""
-    be.L.cdf_conv_gemm_bf16x_halo(31, 1)
+    be.tune.set(halo=31, halo_min_tiles=1)
     try:
         for bm in (128, 256):                         # both tile heights of the LDS-resident kernel
-            be.L.cdf_conv_gemm_bf16x_halo_bm(bm)
+            be.tune.set(halo_bm=bm)
             _spx_case(be, *case)
-        be.L.cdf_conv_gemm_bf16x_halo(0, 1)
+        be.tune.set(halo=0, halo_min_tiles=1)
         _spx_case(be, *case)
     finally:
-        be.L.cdf_conv_gemm_bf16x_halo(47, 1)
-        be.L.cdf_conv_gemm_bf16x_halo_bm(0)
+        be.tune.set(halo=47, halo_min_tiles=1)
+        be.tune.set(halo_bm=0)
 
 
 def test_conv_presplit_halo_small_grid_n64(be):
     """Small grids (sampling batches, the 16 x 16 level): the LDS-resident-input kernel takes 64-wide N tiles for layers with MORE than
-    64 output channels when 128-wide ones would leave most CUs idle (cdf_conv_gemm_bf16x_small_n64).  192 and 128 output channels =
+    64 output channels when 128-wide ones would leave most CUs idle (cdf_gemm_tuning.small_n64).  192 and 128 output channels =
     3 / 2 column tiles of 64 (forward / data gradient); the 128-wide choice must give the same numbers to rounding."""
     case = (1, 128, 192, 16, 3, 1, 1)
     _spx_case(be, *case)
-    be.L.cdf_conv_gemm_bf16x_small_n64(0)
+    be.tune.set(small_n64=0)
     try:
         _spx_case(be, *case)
     finally:
-        be.L.cdf_conv_gemm_bf16x_small_n64(1)
+        be.tune.set(small_n64=1)
 
 
 @pytest.mark.parametrize("case", [(1, 136, 72, 16, 3, 1, 1), (2, 64, 136, 16, 3, 1, 1), (1, 136, 40, 32, 3, 1, 1)])
@@ -920,11 +885,11 @@ def test_wgrad_presplit_row_of_taps(be, case):
     (a chunk spans two image rows) and 32-wide ones, the three tile shapes 128x128 / 64x128 / 128x64 with ragged channel tiles,
     several splits; and the per-tap kernel on the same data."""
     _spx_case(be, *case)
-    be.L.cdf_conv_wgrad_bf16x_row3(0)
+    be.tune.set(wgrad_row3=0)
     try:
         _spx_case(be, *case)
     finally:
-        be.L.cdf_conv_wgrad_bf16x_row3(1)
+        be.tune.set(wgrad_row3=1)
 
 
 @pytest.mark.parametrize("case", [(1, 64, 96, 16, 3, 1, 1), (2, 96, 40, 16, 3, 1, 1), (1, 64, 72, 32, 3, 1, 1)])
@@ -933,22 +898,22 @@ def test_conv_presplit_rowhalo_emu(case):
     the halo hook; by default it serves the 128-pixel layers, which the GPU cases cover).  Simulator only, to keep the GPU suite short."""
     from conftest import Backend
     be = Backend("emu")
-    be.L.cdf_conv_gemm_bf16x_halo(64 | 47, 1)
+    be.tune.set(halo=64 | 47, halo_min_tiles=1)
     try:
         _spx_case(be, *case)
     finally:
-        be.L.cdf_conv_gemm_bf16x_halo(47, 1)
+        be.tune.set(halo=47, halo_min_tiles=1)
         be._keep.clear()
 
 
 def test_conv_presplit_row_tiles(be):
     """A tile that is exactly one image row (W = 64 with the 64-row tile): the 3 x 3 taps run in a per-tile row-group
-    order (cdf_conv_gemm_bf16x_taprot) -- every tap must still be taken exactly once, forward and data gradient."""
-    be.L.cdf_conv_gemm_bf16x_tile(64, 64)
+    order -- every tap must still be taken exactly once, forward and data gradient."""
+    be.tune.set(tile_bm=64, tile_bn=64)
     try:
         _spx_case(be, 1, 8, 16, 64, 3, 1, 1)
     finally:
-        be.L.cdf_conv_gemm_bf16x_tile(0, 0)
+        be.tune.set(tile_bm=0, tile_bn=0)
 
 
 @pytest.mark.gpu
@@ -957,14 +922,14 @@ def test_conv_presplit_large(case):
     from conftest import Backend
     be = Backend("hip")
     _spx_case(be, *case)
-    be.L.cdf_conv_gemm_bf16x_halo(31, 1)          # LDS-resident input tiles at every width (128 is off by default), both tile heights
+    be.tune.set(halo=31, halo_min_tiles=1)          # LDS-resident input tiles at every width (128 is off by default), both tile heights
     try:
         for bm in (128, 256):
-            be.L.cdf_conv_gemm_bf16x_halo_bm(bm)
+            be.tune.set(halo_bm=bm)
             _spx_case(be, *case)
     finally:
-        be.L.cdf_conv_gemm_bf16x_halo(47, 1)
-        be.L.cdf_conv_gemm_bf16x_halo_bm(0)
+        be.tune.set(halo=47, halo_min_tiles=1)
+        be.tune.set(halo_bm=0)
 
 
 @pytest.mark.parametrize("ns", [1, 3, 7, 31, 32, 37, 64, 70, 227])
@@ -977,15 +942,15 @@ def test_unpack_reduce(be, ns):
         ws = torch.randn(ns, T, R, ldc)
         g0 = torch.randn(C, R, T)
         g = be.to(g0)
-        be.L.cdf_unpack_reduce(P(be.to(ws)), P(g), ns, T, R, C, ldc, 1, T, R * T, 1, be.stream())
+        be.L.cdf_unpack_reduce(P(be.to(ws)), P(g), ns, T, R, C, ldc, 1, T, R * T, 1, 1, be.stream())
         ref = g0 + ws[..., :C].double().sum(0).permute(2, 1, 0).float()
         assert err(g, ref) <= 2e-6 * math.sqrt(ns) * max(1.0, ref.abs().max().item())
-        be.L.cdf_unpack_reduce(P(be.to(ws)), P(g), ns, T, R, C, ldc, 1, T, R * T, 0, be.stream())
+        be.L.cdf_unpack_reduce(P(be.to(ws)), P(g), ns, T, R, C, ldc, 1, T, R * T, 0, 1, be.stream())
         assert err(g, ref - g0) <= 2e-6 * math.sqrt(ns) * max(1.0, ref.abs().max().item())
         # with the bias-partial reduction folded into the same launch
         bws, gb0 = torch.randn(ns, ldc), torch.randn(C)
         g, gb = be.to(g0), be.to(gb0)
-        be.L.cdf_unpack_reduce_bias(P(be.to(ws)), P(g), ns, T, R, C, ldc, 1, T, R * T, P(be.to(bws)), P(gb), ldc, 1, be.stream())
+        be.L.cdf_unpack_reduce_bias(P(be.to(ws)), P(g), ns, T, R, C, ldc, 1, T, R * T, P(be.to(bws)), P(gb), ldc, 1, 1, be.stream())
         assert err(g, ref) <= 2e-6 * math.sqrt(ns) * max(1.0, ref.abs().max().item())
         assert err(gb, gb0 + bws[:, :C].double().sum(0).float()) <= 2e-6 * math.sqrt(ns) * 4
 
@@ -1008,19 +973,16 @@ def test_unpack_reduce_tiled(be, T, R, C, conv_t, ns):
     bws, gb0 = torch.randn(ns, ldc), torch.randn(C)
     tol = 2e-6 * math.sqrt(ns) * max(1.0, (g0 + ref_add).abs().max().item())
     outs = []
-    try:
-        for tiled in (2, 1, 0):
-            be.L.cdf_unpack_reduce_tiled(tiled)
+    if True:
+        for tiled in (1, 1, 0):
             g, gb = be.to(g0), be.to(gb0)
-            be.L.cdf_unpack_reduce_bias(P(be.to(ws)), P(g), ns, T, R, C, ldc, 1, s_r, s_c, P(be.to(bws)), P(gb), ldc, 1, be.stream())
+            be.L.cdf_unpack_reduce_bias(P(be.to(ws)), P(g), ns, T, R, C, ldc, 1, s_r, s_c, P(be.to(bws)), P(gb), ldc, 1, tiled, be.stream())
             assert err(g, g0 + ref_add) <= tol
             assert err(gb, gb0 + bws[:, :C].double().sum(0).float()) <= 2e-6 * math.sqrt(ns) * 4
             g2 = be.to(g0)
-            be.L.cdf_unpack_reduce(P(be.to(ws)), P(g2), ns, T, R, C, ldc, 1, s_r, s_c, 0, be.stream())
+            be.L.cdf_unpack_reduce(P(be.to(ws)), P(g2), ns, T, R, C, ldc, 1, s_r, s_c, 0, tiled, be.stream())
             assert err(g2, ref_add) <= tol
             outs.append(g2.detach().cpu().clone())
-    finally:
-        be.L.cdf_unpack_reduce_tiled(1)
     assert (outs[0] - outs[2]).abs().max().item() <= tol and torch.equal(outs[0], outs[1])
 
 
@@ -1093,8 +1055,8 @@ def test_conv_cin4_direct(be, B, H, Cin, Cout, k, act):
     part, bsum = be.empty(nch, KK * Cin, Cout), be.empty(nch, Cout)
     be.L.cdf_conv_cin4_wgrad(P(xd), P(gd), Cout, P(part), P(bsum), B, H, H, Cin, Cout, k, be.stream())
     dw, db = be.zeros(Cout, Cin, k, k), be.zeros(Cout)
-    be.L.cdf_unpack_reduce(P(part), P(dw), nch, KK, Cin, Cout, Cout, 1, KK, Cin * KK, 0, be.stream())
-    be.L.cdf_unpack_reduce(P(bsum), P(db), nch, 1, 1, Cout, Cout, 0, 0, 1, 0, be.stream())
+    be.L.cdf_unpack_reduce(P(part), P(dw), nch, KK, Cin, Cout, Cout, 1, KK, Cin * KK, 0, 1, be.stream())
+    be.L.cdf_unpack_reduce(P(bsum), P(db), nch, 1, 1, Cout, Cout, 0, 0, 1, 0, 1, be.stream())
     assert err(dw, conv.weight.grad) <= 5e-5 * max(1.0, conv.weight.grad.abs().max().item())
     assert err(db, conv.bias.grad) <= 5e-5 * max(1.0, conv.bias.grad.abs().max().item())
 

@@ -5,23 +5,19 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "cold-diffusion-models_amd"))
 from colddiff import _lib, convdesc as cd
 L = _lib.get(); dev = torch.device("cuda:0")
+# tuning: the explicit cdf_gemm_tuning argument (the library has no setters); KB_* environment knobs fill its fields
+TUNE = _lib.GemmTuning(L)
 if os.environ.get('KB_TILE'):
-    L.cdf_conv_gemm_bf16x_tile(*[int(v) for v in os.environ['KB_TILE'].split('x')])
-if os.environ.get('KB_ROW3'):
-    L.cdf_conv_wgrad_bf16x_row3(int(os.environ['KB_ROW3']))
-if os.environ.get('KB_WSWZ'):
-    L.cdf_conv_wgrad_bf16x_swizzle(int(os.environ['KB_WSWZ']))
-if os.environ.get('KB_TAPROT'):
-    L.cdf_conv_gemm_bf16x_taprot(int(os.environ['KB_TAPROT']))
+    bm_, bn_ = (int(v) for v in os.environ['KB_TILE'].split('x'))
+    TUNE.set(tile_bm=bm_, tile_bn=bn_)
 if os.environ.get('KB_HALO'):
-    L.cdf_conv_gemm_bf16x_halo(*[int(v) for v in os.environ['KB_HALO'].split(',')])
-if os.environ.get('KB_HALO_BM'):
-    L.cdf_conv_gemm_bf16x_halo_bm(int(os.environ['KB_HALO_BM']))
-if os.environ.get('KB_DEPHASE'):
-    L.cdf_conv_gemm_bf16x_dephase(int(os.environ['KB_DEPHASE']))
+    h_ = [int(v) for v in os.environ['KB_HALO'].split(',')]
+    TUNE.set(halo=h_[0], halo_min_tiles=h_[1] if len(h_) > 1 else 1)
+for var_, field_ in (('KB_ROW3', 'wgrad_row3'), ('KB_WSWZ', 'wgrad_swizzle'), ('KB_HALO_BM', 'halo_bm'), ('KB_DEPHASE', 'dephase'),
+                     ('KB_SMALL_N64', 'small_n64'), ('KB_MAX_BM', 'max_bm')):
+    if os.environ.get(var_):
+        TUNE.set(**{field_: int(os.environ[var_])})
 SINGLE = os.environ.get('KB_SINGLE', '0') == '1'      # hi-only planes: single-pass bf16 (NS = 1 kernels)
-if os.environ.get('KB_WAVES'):
-    L.cdf_conv_gemm_bf16x_waves(int(os.environ['KB_WAVES']))
 
 S = lambda: torch.cuda.current_stream().cuda_stream
 P = lambda t: 0 if t is None else t.data_ptr()
@@ -74,7 +70,7 @@ if os.environ.get("KB_SPW", "1") == "1":
         tiles = ((Cin+127)//128)*((Cout+127)//128)*k*k
         ns = max(1, min(512//tiles if tiles <= 512 else 1, M//512))
         ws = torch.empty(ns,k*k,Cin,r4(Cout),device=dev)
-        ms = timeit(lambda: L.cdf_conv_wgrad_bf16(P(x),x.shape[-1],P(y),y.shape[-1],P(ws),r4(Cout),B,H,H,H,H,1,H,H,1,Cin,Cout,k*k,wg.desc,ns,0,S()))
+        ms = timeit(lambda: L.cdf_conv_wgrad_bf16(P(x),x.shape[-1],P(y),y.shape[-1],P(ws),r4(Cout),B,H,H,H,H,1,H,H,1,Cin,Cout,k*k,wg.desc,ns,0,TUNE.ptr,S()))
         fl = 2.0*B*H*H*Cin*Cout*k*k
         print(f"spW   {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv (ns={ns})", flush=True)
 # ---- pre-split operand kernels ---------------------------------------------------------------------------
@@ -95,15 +91,15 @@ if os.environ.get("KB_SPX", "1") == "1":
         xs = split(x); gs = split(gy)
         p = cd.conv_fwd(H,H,k,k,1,k//2,k//2,k//2,k//2)
         fl = 2.0*B*H*H*Cin*Cout*k*k
-        ms = timeit(lambda: L.cdf_conv_gemm_bf16x(P(xs[0]),P(xs[1]),Cin,P(zero),P(hi),P(lo),ldk,P(y),y.shape[-1],B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,S()))
+        ms = timeit(lambda: L.cdf_conv_gemm_bf16x(P(xs[0]),P(xs[1]),Cin,P(zero),P(hi),P(lo),ldk,P(y),y.shape[-1],B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,TUNE.ptr,S()))
         print(f"spx   {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv", flush=True)
         if os.environ.get("KB_EPI", "1") == "1":      # the ConvNeXt conv1 form: bias + GELU, pre-activation kept, output as bf16 planes only
             bias = torch.randn(Cout, device=dev); pre = torch.empty(B,H,H,Cout,device=dev)
             yh = torch.empty(B,H,H,Cout,dtype=torch.int16,device=dev); yl = None if SINGLE else torch.empty_like(yh)
-            ms = timeit(lambda: L.cdf_conv_gemm_bf16x(P(xs[0]),P(xs[1]),Cin,P(zero),P(hi),P(lo),ldk,0,Cout,B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,P(bias),0,0,0,0,P(pre),Cout,0,0,1,0,0,P(yh),P(yl),Cout,0,0,S()))
+            ms = timeit(lambda: L.cdf_conv_gemm_bf16x(P(xs[0]),P(xs[1]),Cin,P(zero),P(hi),P(lo),ldk,0,Cout,B,H,H,Cin,H,H,Cout,H,H,1,1,1,p.desc,P(bias),0,0,0,0,P(pre),Cout,0,0,1,0,0,P(yh),P(yl),Cout,0,0,TUNE.ptr,S()))
             print(f"spxG  {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv (bias+GELU, pre + planes out)", flush=True)
         wg = cd.conv_wgrad(H,H,k,k,1,k//2,k//2,k//2,k//2); M=B*H*H
-        row3 = L.cdf_conv_wgrad_bf16x_is_row3(H, H, Cin, Cout, k*k, 1 if k == 3 else 0)
+        row3 = L.cdf_conv_wgrad_bf16x_is_row3(H, H, Cin, Cout, k*k, 1 if k == 3 else 0, TUNE.ptr)
         tiles = ((Cin+127)//128)*((Cout+127)//128)*(3 if row3 else k*k)
         slots = 256 if row3 else 512
         best, bc = 1, None
@@ -112,5 +108,5 @@ if os.environ.get("KB_SPX", "1") == "1":
             if bc is None or c_ < bc - 1e-9: best, bc = ns_, c_
         ns = best
         ws = torch.empty(ns,k*k,Cin,r4(Cout),device=dev)
-        ms = timeit(lambda: L.cdf_conv_wgrad_bf16x(P(xs[0]),P(xs[1]),Cin,P(gs[0]),P(gs[1]),Cout,P(zero),P(ws),r4(Cout),B,H,H,H,H,1,H,H,1,Cin,Cout,k*k,wg.desc,ns,0,S()))
+        ms = timeit(lambda: L.cdf_conv_wgrad_bf16x(P(xs[0]),P(xs[1]),Cin,P(gs[0]),P(gs[1]),Cout,P(zero),P(ws),r4(Cout),B,H,H,H,H,1,H,H,1,Cin,Cout,k*k,wg.desc,ns,0,TUNE.ptr,S()))
         print(f"spxW  {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv (ns={ns})", flush=True)

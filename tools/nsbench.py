@@ -30,8 +30,8 @@ for (Cin, Cout, H) in [(512, 1024, 16), (1024, 512, 16), (256, 512, 32), (512, 2
     for ns in sorted(set([1, 2, 3, 4, 6, 8, 12, 16, 32, 64, auto])):
         if ns > M // 512: continue
         ws = torch.empty(ns, k * k, Cin, r4(Cout), device=dev)
-        f1 = lambda: L.cdf_conv_wgrad_bf16x(P(xs[0]), P(xs[1]), Cin, P(gs[0]), P(gs[1]), Cout, P(zero), P(ws), r4(Cout), B, H, H, H, H, 1, H, H, 1, Cin, Cout, k * k, wg.desc, ns, 0, S())
-        f2 = lambda: L.cdf_unpack_reduce(P(ws), P(dw), ns, k * k, Cin, Cout, r4(Cout), 1, k * k, Cin * k * k, 1, S())
+        f1 = lambda: L.cdf_conv_wgrad_bf16x(P(xs[0]), P(xs[1]), Cin, P(gs[0]), P(gs[1]), Cout, P(zero), P(ws), r4(Cout), B, H, H, H, H, 1, H, H, 1, Cin, Cout, k * k, wg.desc, ns, 0, 0, S())
+        f2 = lambda: L.cdf_unpack_reduce(P(ws), P(dw), ns, k * k, Cin, Cout, r4(Cout), 1, k * k, Cin * k * k, 1, 1, S())
         t1, t2 = timeit(f1), timeit(f2)
         res.append((ns, t1, t2))
     print(f"{Cin}->{Cout}@{H} (auto ns={auto}): " + "  ".join(f"ns{ns}{'*' if ns == auto else ''}: {1000*t1:.0f}+{1000*t2:.0f}={1000*(t1+t2):.0f}us" for ns, t1, t2 in res), flush=True)

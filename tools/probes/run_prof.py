@@ -9,14 +9,14 @@ os.environ["COLDDIFF_LIB"] = os.path.join(REPO, "tools/_ablate/prof/lib_prof.so"
 from colddiff import _lib, convdesc as cd
 L = _lib.get(); dev = torch.device("cuda:0")
 raw = ctypes.CDLL(os.environ["COLDDIFF_LIB"])
-L.cdf_conv_gemm_bf16x_halo(0, 1)
+TUNE = _lib.GemmTuning(L).set(halo=0)
 P = lambda t: 0 if t is None else t.data_ptr()
 S = lambda: torch.cuda.current_stream().cuda_stream
 def split(t):
     C = t.shape[-1]; hi = torch.empty(t.shape, dtype=torch.int16, device=dev); lo = torch.empty_like(hi)
     L.cdf_split_bf16(P(t), C, P(hi), P(lo), C, t.numel()//C, C, S()); return hi, lo
 for (Cin, Cout, H, tile) in [(512, 1024, 16, (128, 128)), (512, 1024, 16, (256, 128)), (64, 128, 128, (256, 128)), (128, 64, 128, (128, 64))]:
-    L.cdf_conv_gemm_bf16x_tile(*tile)
+    TUNE.set(tile_bm=tile[0], tile_bn=tile[1])
     B, k = 32, 3
     x = torch.randn(B, H, H, Cin, device=dev); y = torch.empty(B, H, H, Cout, device=dev)
     ldk = (Cin + 31) // 32 * 32
@@ -27,7 +27,7 @@ for (Cin, Cout, H, tile) in [(512, 1024, 16, (128, 128)), (512, 1024, 16, (256, 
     p = cd.conv_fwd(H, H, k, k, 1, 1, 1, 1, 1)
     for _ in range(3):
         L.cdf_conv_gemm_bf16x(P(xs[0]), P(xs[1]), Cin, P(zero), P(hi), P(lo), ldk, P(y), Cout, B, H, H, Cin, H, H, Cout, H, H, 1, 1, 1, p.desc,
-                              0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, S())
+                              0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, TUNE.ptr, S())
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * (64 * 8 * 6))()
     raw.cdf_debug_read_prof(buf)

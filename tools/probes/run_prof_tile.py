@@ -12,7 +12,7 @@ S = lambda: torch.cuda.current_stream().cuda_stream
 def split(t):
     C = t.shape[-1]; hi = torch.empty(t.shape, dtype=torch.int16, device=dev); lo = torch.empty_like(hi)
     L.cdf_split_bf16(P(t), C, P(hi), P(lo), C, t.numel()//C, C, S()); return hi, lo
-L.cdf_conv_gemm_bf16x_halo(64 | 47, 1)          # row-halo kernel wherever it applies
+TUNE = _lib.GemmTuning(L).set(halo=64 | 47)          # row-halo kernel wherever it applies
 for persist in (0,):
     pass
     for (Cin, Cout, H) in [(64, 128, 128), (128, 64, 128), (128, 256, 64), (512, 1024, 16)]:
@@ -25,7 +25,7 @@ for persist in (0,):
         xs = split(x); zero = torch.zeros(64, device=dev)
         p = cd.conv_fwd(H, H, k, k, 1, 1, 1, 1, 1)
         f = lambda: L.cdf_conv_gemm_bf16x(P(xs[0]), P(xs[1]), Cin, P(zero), P(hi), P(lo), ldk, P(y), Cout, B, H, H, Cin, H, H, Cout, H, H, 1, 1, 1, p.desc,
-                                          0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, S())
+                                          0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, TUNE.ptr, S())
         for _ in range(3): f()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

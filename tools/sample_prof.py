@@ -33,6 +33,7 @@ def main():
         net = Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=3).to(dev)
     d = GaussianDiffusion(net, image_size=128, channels=3, timesteps=200, loss_type='l1', sampling_routine='x0_step_down').to(dev)
     L = runtime.lib()
+    TUNE = runtime.tuning()                                   # the process's cdf_gemm_tuning argument (Python-side; the library has no setters)
 
     def run(batch):
         noise = torch.randn(batch, 3, 128, 128, device=dev)
@@ -55,15 +56,15 @@ def main():
         U._TIME_BIAS_ALL = v
 
     variants = [("default", lambda: None, lambda: None),
-                ("small_n64=0 (128-wide N tiles on small grids)", lambda: L.cdf_conv_gemm_bf16x_small_n64(0), lambda: L.cdf_conv_gemm_bf16x_small_n64(1)),
+                ("small_n64=0 (128-wide N tiles on small grids)", lambda: TUNE.set(small_n64=0), lambda: TUNE.set(small_n64=1)),
                 ("time-bias linears one by one", lambda: tba(False), lambda: tba(True)),
-                ("splitk=1", lambda: L.cdf_conv_gemm_bf16x_splitk(1), lambda: L.cdf_conv_gemm_bf16x_splitk(0)),
-                ("halo_bm=128", lambda: L.cdf_conv_gemm_bf16x_halo_bm(128), lambda: L.cdf_conv_gemm_bf16x_halo_bm(0)),
-                ("max_bm=128", lambda: L.cdf_conv_gemm_bf16x_max_bm(128), lambda: L.cdf_conv_gemm_bf16x_max_bm(0)),
-                ("deep=0", lambda: L.cdf_conv_gemm_bf16x_deep(0), lambda: L.cdf_conv_gemm_bf16x_deep(1)),
-                ("tile 128x64", lambda: L.cdf_conv_gemm_bf16x_tile(128, 64), lambda: L.cdf_conv_gemm_bf16x_tile(0, 0)),
-                ("halo=0 (generic gather kernel)", lambda: L.cdf_conv_gemm_bf16x_halo(0, 1), lambda: L.cdf_conv_gemm_bf16x_halo(47, 1)),
-                ("halo min_tiles=200", lambda: L.cdf_conv_gemm_bf16x_halo(47, 200), lambda: L.cdf_conv_gemm_bf16x_halo(47, 1)),
+                ("splitk=1", lambda: TUNE.set(splitk=1), lambda: TUNE.set(splitk=0)),
+                ("halo_bm=128", lambda: TUNE.set(halo_bm=128), lambda: TUNE.set(halo_bm=0)),
+                ("max_bm=128", lambda: TUNE.set(max_bm=128), lambda: TUNE.set(max_bm=0)),
+                ("deep=0", lambda: TUNE.set(deep=0), lambda: TUNE.set(deep=1)),
+                ("tile 128x64", lambda: TUNE.set(tile_bm=128, tile_bn=64), lambda: TUNE.set(tile_bm=0, tile_bn=0)),
+                ("halo=0 (generic gather kernel)", lambda: TUNE.set(halo=0), lambda: TUNE.set(halo=47)),
+                ("halo min_tiles=200", lambda: TUNE.set(halo_min_tiles=200), lambda: TUNE.set(halo_min_tiles=1)),
                 ("default again", lambda: None, lambda: None)]
     for batch in (a.batch, 64):
         for name, on, off in variants:
