@@ -70,7 +70,7 @@ if os.environ.get("KB_SPW", "1") == "1":
         tiles = ((Cin+127)//128)*((Cout+127)//128)*k*k
         ns = max(1, min(512//tiles if tiles <= 512 else 1, M//512))
         ws = torch.empty(ns,k*k,Cin,r4(Cout),device=dev)
-        ms = timeit(lambda: L.cdf_conv_wgrad_bf16(P(x),x.shape[-1],P(y),y.shape[-1],P(ws),r4(Cout),B,H,H,H,H,1,H,H,1,Cin,Cout,k*k,wg.desc,ns,0,TUNE.ptr,S()))
+        ms = timeit(lambda: L.cdf_conv_wgrad_bf16(P(x),x.shape[-1],P(y),y.shape[-1],P(ws),r4(Cout),B,H,H,H,H,1,H,H,1,Cin,Cout,k*k,wg.desc,ns,0,S()))
         fl = 2.0*B*H*H*Cin*Cout*k*k
         print(f"spW   {Cin:5d}->{Cout:5d} @{H:3d} k{k}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF-equiv (ns={ns})", flush=True)
 # ---- pre-split operand kernels ---------------------------------------------------------------------------
