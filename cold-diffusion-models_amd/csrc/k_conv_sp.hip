@@ -1346,10 +1346,9 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
 // generic 256 x 128 kernel; at 64 pixels the halo kernel's 256-pixel tile stays ahead (0.240 vs 0.252 ms).  Used for the > 64-channel
 // outputs at 128-pixel width (bits 32 / 64 of cdf_conv_gemm_bf16x_halo).
 // ================================================================================================
-template <int W, int BN, int NS = 3, int BM = 256, int NB = 4>          // BM = 256 or 512 pixels (512: four 128-pixel rows, 64-wide N tiles, 3 weight stages)
+template <int W, int BN, int NS = 3>
 __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
-    constexpr int WM = 4, WN = 2, NW = 8, BK = 32, RE = 32, MT = BM / WM / 32;
-    static_assert(NB == 3 || NB == 4, "three or four weight stages");
+    constexpr int BM = 256, WM = 4, WN = 2, NW = 8, BK = 32, RE = 32, MT = BM / WM / 32, NB = 4;
     constexpr int TH = BM / W, HW2 = W + 2, RH = TH * HW2;                 // rows of one (chunk, dy) image
     constexpr int NSEG = (RH + 15) / 16, HRP = NSEG * 16;
     constexpr int TAG = (NSEG + NW - 1) / NW;                              // segments per wave and group, all requested in its first step
@@ -1518,9 +1517,9 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
             asm volatile("s_nop 0" ::"v"(acc[0][0][0]));          // (the last MFMA result is due here)
             const unsigned long long q3 = __builtin_readcyclecounter();
 #endif
-            // the weights of step + 1 (requested NB - 2 steps ago, AFTER that step's row requests) have landed; still in flight: the
-            // requests of the last NB - 2 steps -- as many weight steps, plus one group of rows if one of them was a group's first step
-            if (i3 <= NB - 3)
+            // the weights of step + 1 (requested 2 steps ago, AFTER that step's row requests) have landed; still in flight: the
+            // requests of the last two steps -- two weight steps, plus one group of rows if one of them was a group's first step
+            if (i3 <= 1)
                 CDF_WAIT_DMA_LEAVE((NB - 2) * PB + PAG);
             else
                 CDF_WAIT_DMA_LEAVE((NB - 2) * PB);
@@ -2474,11 +2473,11 @@ static bool cdf_tune_ok(const cdf_gemm_tuning* t) {
     const bool bm_ok = t->tile_bm == 0 || t->tile_bm == 64 || t->tile_bm == 128 || (t->tile_bm == 256 && (t->tile_bn == 0 || t->tile_bn == 128));
     const bool bn_ok = t->tile_bn == 0 || t->tile_bn == 64 || t->tile_bn == 128;
     return t->size == (int)sizeof(cdf_gemm_tuning) && bm_ok && bn_ok && (t->max_bm == 0 || t->max_bm == 128 || t->max_bm == 256) &&
-           (t->halo_bm == 0 || t->halo_bm == 128 || t->halo_bm == 256) && t->halo >= 0 && t->halo <= 255 && t->halo_min_tiles >= 0;
+           (t->halo_bm == 0 || t->halo_bm == 128 || t->halo_bm == 256) && t->halo >= 0 && t->halo <= 127 && t->halo_min_tiles >= 0;
 }
 #define CDF_TUNE_CHECK(t, who)                                                                                                          \
     CDF_REQUIRE(cdf_tune_ok(t), who ": bad cdf_gemm_tuning (size %d, expected %d; tile_bm 0/64/128/256 (256 with tile_bn 0/128), tile_bn 0/64/128, " \
-                                    "max_bm 0/128/256, halo_bm 0/128/256, halo 0..255): start from cdf_gemm_tuning_default",            \
+                                    "max_bm 0/128/256, halo_bm 0/128/256, halo 0..127): start from cdf_gemm_tuning_default",            \
                 (t) ? (t)->size : 0, (int)sizeof(cdf_gemm_tuning))
 
 template <int NS, int BM, int BN, int WM, int WN, int NSTAGE, int OCC = 512 / (64 * WM * WN)>
@@ -2529,22 +2528,22 @@ static int launch_igemm_halo(const SpxArgs& a, int M, hipStream_t s) {
     return cdf_check_launch("conv_igemm_halo");
 }
 
-template <int NS, int W, int BN, int BM = 256, int NB = 4>
+template <int NS, int W, int BN>
 static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s) {
-    constexpr int TH = BM / W, RH = TH * (W + 2), HRP = (RH + 15) / 16 * 16;
-    constexpr size_t stages = (size_t)2 * 2 * HRP * 64 + (size_t)NB * 2 * BN * 64;
-    constexpr size_t epi = (size_t)BM * (BN + 8) * sizeof(float);
+    constexpr int TH = 256 / W, RH = TH * (W + 2), HRP = (RH + 15) / 16 * 16;
+    constexpr size_t stages = (size_t)2 * 2 * HRP * 64 + (size_t)4 * 2 * BN * 64;
+    constexpr size_t epi = (size_t)256 * (BN + 8) * sizeof(float);
     constexpr size_t lds = stages > epi ? stages : epi;
     static_assert(lds <= 160 * 1024, "row-halo tile does not fit the LDS");
 #ifndef CDF_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_kernel<W, BN, NS, BM, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_kernel<W, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
 #endif
-    const int tiles = (M / BM) * cdf_cdiv(a.Cout, BN);
-    CDF_LAUNCH((conv_igemm_rowhalo_kernel<W, BN, NS, BM, NB>), dim3(tiles), dim3(512), lds, s, a);
+    const int tiles = (M / 256) * cdf_cdiv(a.Cout, BN);
+    CDF_LAUNCH((conv_igemm_rowhalo_kernel<W, BN, NS>), dim3(tiles), dim3(512), lds, s, a);
     return cdf_check_launch("conv_igemm_rowhalo");
 }
 
@@ -2606,12 +2605,6 @@ static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cou
         // row-halo kernel: 256-pixel tiles, input shared by the dx taps only.  Bit 32 (default): the > 64-channel outputs at
         // 128-pixel width, where it beats the generic 256 x 128 kernel (64 -> 128: 0.325 -> 0.298 ms); bit 64: wherever it applies
         // (at 64 pixels the halo kernel's 256-pixel tile stays ahead, 0.240 vs 0.252 ms)
-        // ... and with 512-pixel tiles (four rows; half the barriers and weight-fragment reads per MFMA of the 256 x 64 tile) for the
-        // <= 64-channel outputs at 128-pixel width (bit 128)
-        if (dx_ok && (T.halo & 128) && n64 && M % 512 == 0) {
-            if (W == 128 && H % 4 == 0 && (long long)(M / 512) * cdf_cdiv(Cout, 64) >= 256) return launch_igemm_rowhalo<NS, 128, 64, 512, 3>(a, M, s);
-            if (W == 32 && H % 16 == 0 && (T.halo & 64)) return launch_igemm_rowhalo<NS, 32, 64, 512, 3>(a, M, s);      // (simulator-sized test geometry)
-        }
         if (dx_ok && M % 256 == 0 && ((T.halo & 64) || ((T.halo & 32) && W == 128 && !n64 && (long long)(M / 256) * cdf_cdiv(Cout, 128) >= 256))) {
 #define CDF_ROWHALO_CASE(WW)                                                                                           \
     if (W == WW && H % (256 / WW) == 0)                                                                                \

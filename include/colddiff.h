@@ -168,8 +168,7 @@ typedef struct cdf_gemm_tuning {
     int splitk;          /* 0; 1: ... and share the taps out over block groups when a workspace is given (measured +-1 %) */
     int halo;            /* 47: bit mask of the LDS-resident-input kernel over the image width 16 (1), 32 (2), 64 (4), 128 (8); 16 = at
                             width 128 also for > 64 output channels; 32 = row-halo form (256-pixel tiles, input shared by the dx taps of
-                            a row) for the > 64-channel outputs at width 128; 64 = row-halo form wherever it applies; 128 = row-halo form with 512-pixel
-                            tiles for the <= 64-channel outputs at width 128; 0 = never */
+                            a row) for the > 64-channel outputs at width 128; 64 = row-halo form wherever it applies; 0 = never */
     int halo_min_tiles;  /* 1: smallest tile count (128 pixels x BN) the LDS-resident form is used for */
     int halo_bm;         /* 0: automatic (256 pixels where every CU still gets a tile); 128 / 256 */
     int small_n64;       /* 1: 64-wide N tiles in the LDS-resident form when 128-wide ones would give < ~2/3 of the CUs a block */

@@ -906,19 +906,6 @@ def test_conv_presplit_rowhalo_emu(case):
         be._keep.clear()
 
 
-def test_conv_presplit_rowhalo_512_emu():
-    """Row-halo form with 512-pixel tiles (four-row tiles at 128 pixels in the product; sixteen 32-pixel rows here), 64-wide N tiles,
-    three weight stages: bit 128 of cdf_gemm_tuning.halo.  Forward and mirrored-tap data gradient, two channel chunks, ragged Cout."""
-    from conftest import Backend
-    be = Backend("emu")
-    be.tune.set(halo=128 | 64 | 47)
-    try:
-        _spx_case(be, 1, 64, 40, 32, 3, 1, 1)
-    finally:
-        be.tune.set(halo=47)
-        be._keep.clear()
-
-
 def test_conv_presplit_row_tiles(be):
     """A tile that is exactly one image row (W = 64 with the 64-row tile): the 3 x 3 taps run in a per-tile row-group
     order -- every tap must still be taken exactly once, forward and data gradient."""
