@@ -31,6 +31,14 @@ __device__ __forceinline__ void f4_fma(float4& acc, const float4& a, const float
 //   outputs.  Row pitch = (TBW+6) pixels + 64 B: the two thread rows inside a 16-lane ds_read_b128 group land 32
 //   banks apart (conflict-free).  68 KB + 6 KB of weights: two blocks per CU overlap one's loads with the other's FMAs.
 // grid = (tiles_x * tiles_y * B, ceil(C4 / 8)).
+// Round 3 (PMC on MI355X, 64 channels at 128 x 128: VALU active 55 % of the SIMD time -- the kernel is VALU-bound, a wave64 VALU
+// instruction occupies its SIMD for 4 cycles and only v_pk_fma_f32 reaches the 157 TFLOP/s vector peak):
+//   * the halo loads are unconditional from clamped addresses and the out-of-image select happens when the values go to LDS
+//     (a select right behind the load parked the wave on s_waitcnt before the other loads were even requested);
+//   * the two (halo row, output row) pairs whose kernel row falls outside 0..6 are peeled off instead of multiplying by zero
+//     weights behind a per-component select: 448 v_cndmask and 1/8 of the FMAs per thread gone.
+// (A block walking several tiles with the next halo requested under the current tile's FMAs was built and measured: slower,
+//  218 VGPRs and no gain from the overlap -- the waves do not wait for HBM, they wait for the vector ALU.)
 template <int TBW, int TBH>
 __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx, const float* w, int ldw, const float* bias,
                                                          const float* sbias, int ld_sbias, float* y, int ldy, int B, int H,
@@ -62,28 +70,27 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx
         const int tap = flip ? DW_TAPS - 1 - tp : tp;
         wl[i] = (cq0 + l) < C4 ? *(const float4*)(w + (long long)tap * ldw + (cq0 + l) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // all of a thread's halo loads are issued before the first LDS store (a rolled loop would wait for each load in turn)
     const float* xb = x + (long long)b * H * W * ldx;
     constexpr int NHALO = HH_ * HW_ * 8, NIT = (NHALO + 255) / 256;
     float4 hv[NIT];
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) {
+    for (int k = 0; k < NIT; ++k) {                          // every load requested before anything is used
         const int i = tid + 256 * k;
         const int l = i & 7, p = i >> 3;
         const int hy = p / HW_, hx = p - hy * HW_;
         const int iy = Y0 + hy - 3, ix = X0 + hx - 3;
-        const bool ok = i < NHALO && iy >= 0 && iy < H && ix >= 0 && ix < W && (cq0 + l) < C4;
         const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
         const int lc = (cq0 + l) < C4 ? cq0 + l : 0;
-        const float4 v = *(const float4*)(xb + ((long long)iyc * W + ixc) * ldx + lc * 4);
-        hv[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        hv[k] = *(const float4*)(xb + ((long long)iyc * W + ixc) * ldx + lc * 4);
     }
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
         const int i = tid + 256 * k;
         const int l = i & 7, p = i >> 3;
         const int hy = p / HW_, hx = p - hy * HW_;
-        if (i < NHALO) halo[hy * RP + hx * 8 + l] = hv[k];
+        const int iy = Y0 + hy - 3, ix = X0 + hx - 3;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W && (cq0 + l) < C4;
+        if (i < NHALO) halo[hy * RP + hx * 8 + l] = ok ? hv[k] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
 
@@ -96,27 +103,30 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx
     for (int o = 0; o < 2; ++o)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[o][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // rolled on purpose: unrolled, hipcc hoists all 80 window reads + 49 weight reads to the top and spills
-#pragma unroll 1
-    for (int r = 0; r < 8; ++r) {                            // halo row y0 + r feeds output row o through ky = r - o
+    // halo row y0 + r feeds output row o through kernel row ky = r - o: r = 0 only o = 0, r = 7 only o = 1, r = 1..6 both
+    auto row_step = [&](int r, bool do0, bool do1) {
         float4 win[10];
         const float4* hrow = halo + (y0 + r) * RP + x0 * 8 + l8;
 #pragma unroll
         for (int q = 0; q < 10; ++q) win[q] = hrow[q * 8];
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-            const int ky = r - o;
-            const bool kv = ky >= 0 && ky < DW_K;            // uniform; the two invalid (r, o) pairs multiply by zero weights
-            const float4* wrow = wl + (kv ? ky : 0) * DW_K * 8 + l8;
+            if (!(o == 0 ? do0 : do1)) continue;            // (compile-time per call site)
+            const float4* wrow = wl + (r - o) * DW_K * 8 + l8;
 #pragma unroll
             for (int kx = 0; kx < DW_K; ++kx) {
-                float4 wv = wrow[kx * 8];
-                if (!kv) wv = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 wv = wrow[kx * 8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) f4_fma(acc[o][j], win[kx + j], wv);
             }
         }
-    }
+    };
+    row_step(0, true, false);
+    // rolled on purpose: unrolled, hipcc hoists all window + weight reads to the top and spills
+#pragma unroll 1
+    for (int r = 1; r < 7; ++r) row_step(r, true, true);
+    row_step(7, false, true);
+
     if (cq >= C4) return;
     const int c = cq * 4;
     float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -143,8 +153,8 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx
                 v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
             }
             if (res) {                                       // fused residual (e.g. dx = dy + conv^T(dh))
-                const float4 r = *(const float4*)(res + (((long long)b * H + oy) * W + ox) * ldr + c);
-                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                const float4 rv = *(const float4*)(res + (((long long)b * H + oy) * W + ox) * ldr + c);
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             }
             *(float4*)dst = v;
         }

@@ -395,8 +395,9 @@ def test_groupnorm(be, B, HW, C, silu):
     assert err(y, yref) <= 1e-5 and err(dx, x.grad) <= 2e-5 and err(dga, ga.grad) <= 1e-4 and err(dbe, bt.grad) <= 1e-4
 
 
-@pytest.mark.parametrize("B,C,H", [(2, 8, 8), (1, 3, 8), (2, 64, 4), (1, 68, 12)])
+@pytest.mark.parametrize("B,C,H", [(2, 8, 8), (1, 3, 8), (2, 64, 4), (1, 68, 12), (3, 8, 40), (1, 36, 40), (5, 4, 16)])
 def test_dwconv7(be, B, C, H):
+    """(40 x 40 images: 2 x 5 tiles of 32 x 8 pixels per image, ragged at the right edge; 16 x 16: the square tile.)"""
     torch.manual_seed(0)
     Cp = r4(C)
     x, w = torch.randn(B, C, H, H, requires_grad=True), (torch.randn(C, 1, 7, 7) / 7).requires_grad_()
@@ -420,7 +421,8 @@ def test_dwconv7(be, B, C, H):
     ws, dw, dbias, dsb = be.empty(B * nch * 50 * C), be.zeros(C, 1, 7, 7), be.zeros(C), be.zeros(B, Cp)
     be.L.cdf_dwconv7_wgrad(P(xn), Cp, P(dyn), Cp, P(dw), P(dbias), P(dsb), Cp, P(ws), B, H, H, C, 0, be.stream())
     assert err(y[..., :C].permute(0, 3, 1, 2), yref) <= 1e-5 and err(dx[..., :C].permute(0, 3, 1, 2), x.grad) <= 1e-5
-    assert err(dw, w.grad) <= 5e-5 and err(dbias, bias.grad) <= 5e-5 and err(dsb[:, :C], sb.grad) <= 5e-5
+    rel = lambda ref: 5e-5 * max(1.0, ref.abs().max().item())          # (sums over B * H * W pixels)
+    assert err(dw, w.grad) <= rel(w.grad) and err(dbias, bias.grad) <= rel(bias.grad) and err(dsb[:, :C], sb.grad) <= rel(sb.grad)
 
 
 @pytest.mark.parametrize("B,n", [(1, 16), (2, 64), (1, 600)])
