@@ -66,8 +66,6 @@ class FusedAdam:
         a = self.arena
         assert a.intact(), "parameters were moved after the optimizer was built (call .cuda() before creating the Trainer)"
         self.step_count += 1
-        from . import ops
-        ops.side_join()                                      # (no-op after a finished backward pass: its final callback joined already)
         g = self.param_groups[0]
         rt.lib().cdf_adam_step(P(a.data), P(a.grad), P(self.exp_avg), P(self.exp_avg_sq), a.numel, g["lr"], g["betas"][0], g["betas"][1],
                                g["eps"], self.step_count, rt.stream(a.data))

@@ -332,7 +332,6 @@ class TimeBiasAll(torch.autograd.Function):
         (gt,) = ctx.saved_tensors
         lins, offs, J = ctx.owner._tb_lins, ctx.offs, ctx.J
         B, K = gt.shape
-        ops.side_join()                                       # (the blocks' bias gradients were written on the gradient side stream)
         L, S = rt.lib(), rt.stream(gt)
         gcat = ctx.slot.buffer()
         for a, l, g in zip(offs, lins, grads):

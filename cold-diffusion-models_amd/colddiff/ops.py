@@ -363,53 +363,6 @@ def conv_gemm(plan, x, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None, p
     return y
 
 
-# ---------------------------------------------------------------------------------------------------
-# gradient side stream
-# ---------------------------------------------------------------------------------------------------
-# Work whose only consumer is the optimizer step -- the split-K slab reductions into weight.grad and the depthwise weight gradient --
-# is HBM-bound and off the critical path of the backward pass, which is a chain of MFMA-bound GEMMs with the memory system mostly idle.
-# It is enqueued on a second stream behind an event and joins the main stream when the backward pass ends (autograd final callback),
-# before the gradient exchange of its bucket (parallel.GradSync) and before anything on the main stream reads what it wrote.
-_GRAD_SIDE = __import__("os").environ.get("CDF_GRAD_SIDE_STREAM", "1") != "0"
-_side_streams, _side_pending, _side_cb = {}, set(), [False]
-
-
-def side_stream(t):
-    """The side stream of t's device, made to wait for everything enqueued on the current stream so far; None when not applicable
-    (CPU simulator, switch off)."""
-    if not _GRAD_SIDE or not t.is_cuda or rt._lib_override is not None:
-        return None
-    dev = t.device
-    s = _side_streams.get(dev)
-    if s is None:
-        s = _side_streams[dev] = torch.cuda.Stream(device=dev)
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(dev))
-    s.wait_event(ev)
-    _side_pending.add(dev)
-    if not _side_cb[0]:
-        try:                                                 # join when this backward pass is over (whoever reads .grad next is ordered behind it)
-            torch.autograd.Variable._execution_engine.queue_callback(side_join)
-            _side_cb[0] = True
-        except RuntimeError:                                 # not inside a backward pass: the caller joins (side_join) itself
-            pass
-    return s
-
-
-def side_join():
-    """The current stream waits for the side stream(s)."""
-    _side_cb[0] = False
-    for dev in list(_side_pending):
-        torch.cuda.current_stream(dev).wait_stream(_side_streams[dev])
-    _side_pending.clear()
-
-
-def side_wait_into(stream, dev):
-    """`stream` (the gradient-exchange stream) waits for the side stream of dev, if anything is pending there."""
-    if dev in _side_pending:
-        stream.wait_stream(_side_streams[dev])
-
-
 def best_nsplit(tiles, slots, max_ns, cap=256):
     """Split-K factor: time ~ ceil(tiles*ns / slots) / ns (equal-length block rounds per unit of work).
     The SMALLEST ns within 3 % of the optimum wins: every split costs a partial-sum slab that is written and
@@ -472,13 +425,7 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None, xa_s=No
 
 
 def _reduce_slabs(L, ws, gparam, ns, ntaps, CA, CB, ldo, s_t, s_r, s_c, bsum, gbias, S):
-    """gparam += sum over the split-K slabs (and gbias += sum over the bias partials, in the same launch); on the gradient side stream."""
-    side = side_stream(ws)
-    if side is not None:
-        S = side.cuda_stream
-        ws.record_stream(side)
-        if bsum is not None:
-            bsum.record_stream(side)
+    """gparam += sum over the split-K slabs (and gbias += sum over the bias partials, in the same launch)."""
     if gbias is not None:
         L.cdf_unpack_reduce_bias(P(ws), P(gparam), ns, ntaps, CA, CB, ldo, s_t, s_r, s_c, P(bsum), P(gbias), ldo, 1, 1, S)
     else:
@@ -566,16 +513,8 @@ def dwconv7_wgrad(x, dy, w_param, b_param, want_dsb, dsb_out=None):
     dsb = None
     if want_dsb:
         dsb = dsb_out if dsb_out is not None else torch.zeros((B, Cp), device=x.device, dtype=torch.float32)
-    gw, gb = grad_of(w_param), grad_of(b_param)
-    S = rt.stream(x)
-    # (the per-sample bias gradient is read by the time-MLP backward on the main stream: only the form that writes into the shared
-    #  slot -- consumed when the whole backward pass is over -- goes to the side stream)
-    side = side_stream(x) if (dsb is None or dsb_out is not None) else None
-    if side is not None:
-        S = side.cuda_stream
-        for t in (x, dy, ws):
-            t.record_stream(side)
-    L.cdf_dwconv7_wgrad(P(x), ld_of(x), P(dy), ld_of(dy), P(gw), P(gb), P(dsb), 0 if dsb is None else dsb.stride(0), P(ws), B, H, W, C, 1, S)
+    L.cdf_dwconv7_wgrad(P(x), ld_of(x), P(dy), ld_of(dy), P(grad_of(w_param)), P(grad_of(b_param)), P(dsb),
+                        0 if dsb is None else dsb.stride(0), P(ws), B, H, W, C, 1, rt.stream(x))
     return dsb
 
 

@@ -166,8 +166,6 @@ class GradSync:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
-            from . import ops
-            ops.side_wait_into(self.comm_stream, buf.device)     # slab reductions / depthwise weight gradients still on the side stream
             with torch.cuda.stream(self.comm_stream):
                 if self._cur is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
