@@ -259,7 +259,7 @@ def timed_train(trainer, steps, warmup):
 
 
 def secondary_workloads(device):
-    """BASELINE configs 2 and 4 on the same engine (secondary keys; the judged line stays config 3)."""
+    """BASELINE configs 1, 2, 4 and 5 on the same engine (secondary keys; the judged line stays config 3)."""
     import contextlib
     import io
     from colddiff.trainer import Trainer
@@ -307,6 +307,20 @@ def secondary_workloads(device):
                                         "workload": "Model(ch=128,(1,2,2,2),attn@16,dropout 0.1) @32x32, blur Special_6_routine T=50, 2 x 128 img + Adam"}
     del tr, d, net
     torch.cuda.empty_cache()
+    # ---- configs 1 and 5 (the remaining BASELINE configurations; the builders are those of tools/cfgbench.py) ---------------------------
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import cfgbench
+    for cfg, key in (("1", "cfg1_mnist32_deblur_train"), ("5r", "cfg5_afhq128_resolution_train"), ("5f", "cfg5_afhq128_defading_train")):
+        torch.manual_seed(123457)
+        d, size, batch, desc = cfgbench.build(cfg, device)
+        with quiet():
+            tr = Trainer(d, None, image_size=size, train_batch_size=batch, train_lr=2e-5, train_num_steps=10 ** 9, gradient_accumulate_every=2,
+                         dataset='synthetic', results_folder=res)
+        tr.quiet = True
+        dt = timed_train(tr, 5, 2)
+        out[key] = {"img_per_s": round(2 * batch / dt, 1), "ms_per_step": round(1000 * dt, 2), "workload": desc + ", 2 micro-steps + Adam"}
+        del tr, d
+        torch.cuda.empty_cache()
     return out
 
 
@@ -344,7 +358,7 @@ def main():
     ap.add_argument("--sample-batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sample", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the bf16-mode line, the config 2 / 4 secondary workloads and the self-check")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the bf16-mode line, the config 1 / 2 / 4 / 5 secondary workloads and the self-check")
     args = ap.parse_args()
 
     from colddiff import parallel, runtime

@@ -56,8 +56,8 @@ def build(cfg, device):
             from defading_diffusion_pytorch import GaussianDiffusion, Unet
             net = Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=3).to(device)
             d = GaussianDiffusion(net, image_size=128, device_of_kernel='cuda', channels=3, timesteps=100, loss_type='l1',
-                                  kernel_std=0.1, fade_routine='Incremental', sampling_routine='x0_step_down').to(device)
-            return d, 128, 32, "AFHQ 128x128 defading T=100 Incremental, Unet(64,(1,2,4,8)), batch 32"
+                                  kernel_std=0.2, initial_mask=1, fade_routine='Incremental', sampling_routine='x0_step_down').to(device)
+            return d, 128, 32, "AFHQ 128x128 defading T=100 Incremental kernel_std=0.2 initial_mask=1 (README.md:127,133), Unet(64,(1,2,4,8)), batch 32"
     raise SystemExit("unknown cfg " + cfg)
 
 
