@@ -162,12 +162,13 @@ def test_evaluation_samplers_vs_reference_golden(dev):
         def sample(self, num_datapoints):
             return bg["og_x"][:num_datapoints].clone()
 
+    ns = 48 if dev.type == "cuda" else 8                                   # (samples are independent: the simulator replays the first 8 of the 48)
     with contextlib.redirect_stdout(io.StringIO()):
         xt, direct, recon = tr.sample_as_a_blur_torch_gmm(ReplayGMM, siz=bg["siz"], ch=3, clusters=bg["clusters"], sample_at=bg["sample_at"],
-                                                          num_samples=48)
+                                                          num_samples=ns)
     assert fits[0].shape == bg["feats"].shape and (fits[0] - bg["feats"]).abs().max() <= 1e-5
     for name, got in (("xt", xt), ("direct_recons", direct), ("recon", recon)):
-        want = bg["saved"][name] * 2 - 1                                   # the reference saves (img + 1) / 2
+        want = bg["saved"][name][:ns] * 2 - 1                              # the reference saves (img + 1) / 2
         assert (got.cpu() - want).abs().max() <= 2e-4, name
 
     # -- fid_distance_decrease_from_manifold (DEBLUR:1567-1702) ---------------------------------------------------------------
