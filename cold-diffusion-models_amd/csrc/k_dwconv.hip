@@ -163,12 +163,141 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx
 
 // Weight gradient partials: part[((b*nchunk + chunk)*50 + tap)*C + c], tap 49 = sum of dy (bias gradients).
 //   dw[c][ky][kx] = sum_{b,y,x} x[b, y+ky-3, x+kx-3, c] * dy[b, y, x, c]
+// Round 3 (rewritten).  The round-2 kernel had every wave fetch its own dy strips and its own x windows straight from global
+// memory: 520 float4 load instructions per wave, rocprofv3 FETCH_SIZE 3.6x the two tensors at 128 x 128 x 64, 1.6 TB/s.  Now a block
+// owns (image, chunk of rows, 32 channels) and walks it in 32 x 4-pixel tiles: the tile of dy and the (32+6) x (4+6) halo of x go to
+// LDS ONCE (coalesced 128-byte pixels, all of a thread's loads in flight together), and thread (channel quad, g) accumulates one
+// (kernel row ky, tile row r) pair -- g = 7 r + ky, 28 of the 32 thread groups busy -- over the 32 pixels of that row: 14 + 8 LDS
+// reads per 56 float4 FMAs, seven accumulators that stay in registers across every tile of the chunk.  The four tile rows are folded
+// through LDS at the end; grid = (ceil(C/32), nchunk, B) in the XCD-aware order (consecutive chunks share 6 of their 10 halo rows).
+#define DWG_TW 32
+#define DWG_TR 4
+__global__ void __launch_bounds__(256, 2) dwconv7_wgrad_partial_kernel(const float* x, int ldx, const float* dy, int lddy,
+                                                                      float* part, int H, int W, int C, int rows_per_chunk) {
+    constexpr int HWX = DWG_TW + 6, HRX = DWG_TR + 6;        // halo extent of x
+    constexpr int RPX = HWX * 8 + 8;                         // row pitches in float4: adjacent rows 32 banks apart (two thread groups of a
+    constexpr int RPD = DWG_TW * 8 + 8;                      // 16-lane ds_read_b128 group read adjacent rows)
+    __shared__ float4 xs[HRX * RPX];                         // 49.9 KB
+    __shared__ float4 ds[DWG_TR * RPD];                      // 16.9 KB   (+ reused for the final fold)
+    const int tid = threadIdx.x;
+    const int vid = cdf_xcd_order(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+    const int bid_c = vid % (int)gridDim.x, bid_chunk = (vid / (int)gridDim.x) % (int)gridDim.y, b = vid / (int)(gridDim.x * gridDim.y);
+    const int C4 = (C + 3) >> 2, cq0 = bid_c * 8;
+    const int ya = bid_chunk * rows_per_chunk;
+    int yb = ya + rows_per_chunk;
+    if (yb > H) yb = H;
+    const int l8 = tid & 7, g = tid >> 3;
+    const bool busy = g < 7 * DWG_TR;
+    const int r = busy ? g / 7 : 0, ky = busy ? g - 7 * r : 0;
+    const float* xb = x + (long long)b * H * W * ldx;
+    const float* db = dy + (long long)b * H * W * lddy;
+    const int lq = (cq0 + l8) < C4 ? cq0 + l8 : 0;           // (clamped channel quad for the loads; masked when stored)
+    const bool qok = (cq0 + l8) < C4;
+
+    float4 acc[DW_K], dsum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < DW_K; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    constexpr int NX = HRX * HWX, NXI = (NX * 8 + 255) / 256;          // halo float4 per thread
+    constexpr int ND = DWG_TR * DWG_TW, NDI = ND * 8 / 256;
+    const int tiles_w = (W + DWG_TW - 1) / DWG_TW;
+    for (int y0 = ya; y0 < yb; y0 += DWG_TR) {
+        for (int tx = 0; tx < tiles_w; ++tx) {
+            const int X0 = tx * DWG_TW;
+            float4 hx[NXI], hd[NDI];
+#pragma unroll
+            for (int k = 0; k < NXI; ++k) {                  // unconditional loads from clamped addresses; masks applied at the LDS store
+                const int i = tid + 256 * k, p = i >> 3;
+                const int hy = p / HWX, hxx = p - hy * HWX;
+                const int iy = y0 + hy - 3, ix = X0 + hxx - 3;
+                const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+                hx[k] = *(const float4*)(xb + ((long long)iyc * W + ixc) * ldx + lq * 4);
+            }
+#pragma unroll
+            for (int k = 0; k < NDI; ++k) {
+                const int i = tid + 256 * k, p = i >> 3;
+                const int ty = p / DWG_TW, px = p - ty * DWG_TW;
+                const int iy = y0 + ty, ix = X0 + px;
+                const int iyc = iy >= H ? H - 1 : iy, ixc = ix >= W ? W - 1 : ix;
+                hd[k] = *(const float4*)(db + ((long long)iyc * W + ixc) * lddy + lq * 4);
+            }
+#pragma unroll
+            for (int k = 0; k < NXI; ++k) {
+                const int i = tid + 256 * k, p = i >> 3;
+                const int hy = p / HWX, hxx = p - hy * HWX;
+                const int iy = y0 + hy - 3, ix = X0 + hxx - 3;
+                const bool ok = qok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                if (p < NX) xs[hy * RPX + hxx * 8 + l8] = ok ? hx[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < NDI; ++k) {
+                const int i = tid + 256 * k, p = i >> 3;
+                const int ty = p / DWG_TW, px = p - ty * DWG_TW;
+                const bool ok = qok && y0 + ty < yb && X0 + px < W;          // rows past the chunk belong to the next block
+                ds[ty * RPD + px * 8 + l8] = ok ? hd[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            __syncthreads();
+            if (busy) {
+                const float4* xrow = xs + (r + ky) * RPX + l8;
+                const float4* drow = ds + r * RPD + l8;
+#pragma unroll 1
+                for (int p0 = 0; p0 < DWG_TW; p0 += 8) {     // rolled: 4 strips of 8 pixels (22 LDS reads, 56 float4 FMAs each)
+                    float4 d[8], win[14];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d[j] = drow[(p0 + j) * 8];
+#pragma unroll
+                    for (int q = 0; q < 14; ++q) win[q] = xrow[(p0 + q) * 8];
+#pragma unroll
+                    for (int kx = 0; kx < DW_K; ++kx)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) f4_fma(acc[kx], win[kx + j], d[j]);
+                    if (ky == 0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { dsum.x += d[j].x; dsum.y += d[j].y; dsum.z += d[j].z; dsum.w += d[j].w; }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // fold the DWG_TR tile rows: fold[r][ky * 7 + kx | 49][l8] through LDS (xs is free now), then threads (tap, l8) write the 50 x 32 slab
+    float4* fold = xs;                                       // [DWG_TR][50][8]
+    if (busy) {
+#pragma unroll
+        for (int kx = 0; kx < DW_K; ++kx) fold[(r * 50 + ky * DW_K + kx) * 8 + l8] = acc[kx];
+        if (ky == 0) fold[(r * 50 + DW_TAPS) * 8 + l8] = dsum;
+    }
+    __syncthreads();
+    float* dst = part + (((long long)b * gridDim.y + bid_chunk) * (DW_TAPS + 1)) * C;
+    for (int i = tid; i < 50 * 8; i += 256) {
+        const int tap = i >> 3, q = i & 7;
+        float4 v = fold[(0 * 50 + tap) * 8 + q];
+#pragma unroll
+        for (int rr = 1; rr < DWG_TR; ++rr) {
+            const float4 u = fold[(rr * 50 + tap) * 8 + q];
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        const int c = (cq0 + q) * 4;
+        if (cq0 + q >= C4) continue;
+        float* pp = dst + (long long)tap * C + c;
+        if (c + 3 < C && (C & 3) == 0) {
+            *(float4*)pp = v;
+        } else {
+            if (c + 0 < C) pp[0] = v.x;
+            if (c + 1 < C) pp[1] = v.y;
+            if (c + 2 < C) pp[2] = v.z;
+            if (c + 3 < C) pp[3] = v.w;
+        }
+    }
+}
+
+// Narrow images (W < 32: the 16 x 16 level, where half of a 32-pixel tile would be padding): the round-2 form, straight from global memory.
 // Same two floors as the forward kernel (read x and dy once, 49 FMA per element).  grid = (ceil(C/64), nchunk, B),
 // block 256 = 4 waves.  Wave w owns kernel rows ky = 2w, 2w+1 (wave 3: ky = 6 and the dy sum): 14 taps x 4 channels
 // of accumulators per lane.  Lanes: 16 channel-quads (float4, 256 B coalesced) x 4 strips of 8 pixels in flight;
 // per strip a wave loads the dy strip (8 float4) and one 14-wide x window per kernel row, all unconditionally.
 // The 4 strip slots are folded with two cross-lane adds at the end.
-__global__ void __launch_bounds__(256) dwconv7_wgrad_partial_kernel(const float* x, int ldx, const float* dy, int lddy,
+__global__ void __launch_bounds__(256) dwconv7_wgrad_partial_narrow_kernel(const float* x, int ldx, const float* dy, int lddy,
                                                                    float* part, int H, int W, int C, int rows_per_chunk) {
     constexpr int TW = 8;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: branches on it are uniform
@@ -341,7 +470,10 @@ extern "C" int cdf_dwconv7_wgrad(const float* x, int ldx, const float* dy, int l
     CDF_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && ldx >= ((C + 3) & ~3) && lddy >= ((C + 3) & ~3) && ((((uintptr_t)x) | ((uintptr_t)dy)) & 15) == 0,
                 "cdf_dwconv7_wgrad: pitches must be multiples of 4 and >= roundup4(C), pointers 16B aligned");
     const int nchunk = cdf_dwconv7_wgrad_nchunk(H), rpc = cdf_cdiv(H, nchunk);
-    CDF_LAUNCH(dwconv7_wgrad_partial_kernel, dim3(cdf_cdiv(C, 64), nchunk, B), dim3(256), 0, CDF_S, x, ldx, dy, lddy, ws, H, W, C, rpc);
+    if (W >= 32)
+        CDF_LAUNCH(dwconv7_wgrad_partial_kernel, dim3(cdf_cdiv(C, 32), nchunk, B), dim3(256), 0, CDF_S, x, ldx, dy, lddy, ws, H, W, C, rpc);
+    else
+        CDF_LAUNCH(dwconv7_wgrad_partial_narrow_kernel, dim3(cdf_cdiv(C, 64), nchunk, B), dim3(256), 0, CDF_S, x, ldx, dy, lddy, ws, H, W, C, rpc);
     CDF_LAUNCH(dwconv7_wgrad_final_kernel, dim3(cdf_cdiv(C, 64), DW_TAPS + 1), dim3(1024), 0, CDF_S, (const float*)ws, B, nchunk, C, dw, dbias, dsb, ld_dsb, accumulate);
     return cdf_check_launch("dwconv7_wgrad");
 }
