@@ -324,15 +324,24 @@ def secondary_workloads(device):
     return out
 
 
+def _profile(name):
+    """Newest committed profiles/round<N>_<name> (bench.py cannot run the profiler on itself)."""
+    for rnd in (3, 2, 1):
+        path = os.path.join(REPO, "profiles", "round%d_%s" % (rnd, name))
+        if os.path.exists(path):
+            return path
+    return None
+
+
 def bandwidth_classes():
     """HBM GB/s of the bandwidth-bound kernel classes: bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     (tools/pmc_traffic.py) divided by the average launch duration of the committed rocprofv3 --kernel-trace of the same command
     (bench.py cannot run the profiler on itself)."""
-    tp, kp = os.path.join(REPO, "profiles", "round2_pmc_traffic.json"), os.path.join(REPO, "profiles", "round2_kernel_trace.json")
-    if not (os.path.exists(tp) and os.path.exists(kp)):
+    tp, kp = _profile("pmc_traffic.json"), _profile("kernel_trace.json")
+    if not (tp and kp):
         return None
     traffic, trace = json.load(open(tp))["kernels"], json.load(open(kp))
-    classes = {"depthwise 7x7": ("dwconv7_kernel", "dwconv7_wgrad_partial_kernel"), "channel LayerNorm": ("layernorm_c_fwd_kernel", "layernorm_c_bwd_kernel"),
+    classes = {"depthwise 7x7": ("dwconv7_kernel", "dwconv7_wgrad_partial_kernel", "dwconv7_wgrad_partial_narrow_kernel"), "channel LayerNorm": ("layernorm_c_fwd_kernel", "layernorm_c_bwd_kernel"),
                "Adam": ("adam_kernel",), "operand split": ("split_bf16_kernel",), "split-K reduction": ("unpack_reduce_",),
                "linear attention": ("linattn_",)}
     out = {}
@@ -344,7 +353,8 @@ def bandwidth_classes():
                 t += trace[k]["total_ms"] * 1e-3
         if t > 0:
             out[name] = {"hbm_gbs": round(b / t / 1e9, 1), "frac_of_peak": round(b / t / 1e9 / PEAK_HBM_GBS, 3)}
-    out["source"] = "profiles/round2_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per launch) / profiles/round2_kernel_trace.json (avg duration)"
+    out["source"] = "%s (FETCH_SIZE x2 + WRITE_SIZE per launch) / %s (avg duration): committed rocprofv3 passes over this same command" % (
+        os.path.relpath(tp, REPO), os.path.relpath(kp, REPO))
     return out
 
 
@@ -466,10 +476,8 @@ def main():
                                            % (args.steps, 1000 * elapsed_instr / args.steps, 1000 * elapsed / args.steps)}
             # HBM traffic of that kernel group from the committed rocprofv3 --pmc passes over this same command
             # (tools/pmc_traffic.py; bench.py cannot run the profiler on itself)
-            tpath = os.path.join(REPO, "profiles", "round2_pmc_traffic.json")
-            if not os.path.exists(tpath):
-                tpath = os.path.join(REPO, "profiles", "round1_pmc_traffic.json")
-            if os.path.exists(tpath) and dom == "conv_igemm_sp":
+            tpath = _profile("pmc_traffic.json")
+            if tpath and dom == "conv_igemm_sp":
                 g = json.load(open(tpath)).get("conv_igemm_sp")
                 if g:
                     out["roofline"]["traffic"] = round(g["hbm_bytes_per_launch"])

@@ -1,6 +1,6 @@
 # Round artifacts on the GPU box (run through gpurun from the repo root): kernel traces of the train step in both arithmetic modes
-# and the two PMC passes.  Copy the summaries from gpurun_out/ into profiles/ afterwards (profiles/round2_*), then run bench.py
-# (its hbm_bound_kernel_classes figures read profiles/round2_pmc_traffic.json and profiles/round2_kernel_trace.json).
+# and the two PMC passes.  Copy the summaries from gpurun_out/final into profiles/ afterwards (profiles/round<N>_*), then run bench.py
+# (its hbm_bound_kernel_classes / roofline.traffic figures read the newest profiles/round<N>_pmc_traffic.json and _kernel_trace.json).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; mkdir -p $O
 B="python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-sample --no-secondary"
@@ -14,3 +14,7 @@ B2="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sample --no-seco
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmcF -- $B2 > $O/pmcF.log 2>&1; tail -1 $O/pmcF.log | cut -c1-200
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmcW -- $B2 > $O/pmcW.log 2>&1; tail -1 $O/pmcW.log | cut -c1-200
 python tools/pmc_traffic.py /tmp/pmcF /tmp/pmcW $O/pmc_traffic.json $O/pmc_traffic.md; head -6 $O/pmc_traffic.md; tail -3 $O/pmc_traffic.md
+# the sampler (200-step gen_sample at the sample batch): which kernels a reverse step spends its time in
+rm -rf /tmp/prof_smp
+timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_smp -- python tools/sample_prof.py --steps 20 > $O/sample_trace.log 2>&1
+python tools/prof_summary.py /tmp/prof_smp $O/sample_kernel_trace.md > /dev/null 2>&1; grep "ms per" $O/sample_trace.log; tail -1 $O/sample_kernel_trace.md
