@@ -151,7 +151,7 @@ class GemmTimer:
             for e0, e1, f, key in recs:
                 t, n, fl = agg.get(key, (0.0, 0, 0.0))
                 agg[key] = (t + e0.elapsed_time(e1), n + 1, fl + f)
-        for key, (t, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
+        for key, (t, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("CDF_BENCH_SHAPES_N", "40"))]:
             log("%8.3f ms/step %4d launches %7.1f TF  %s" % (t / steps, n // steps, fl / (t * 1e-3) / 1e12 if t > 0 else 0, key))
 
     def summary(self, steps, elapsed_s):

@@ -47,6 +47,7 @@ _PACK_ALL = __import__("os").environ.get("CDF_PACK_ALL", "1") != "0"
 # smallest pixel count whose weight gradient runs on the bf16 matrix cores (below, the fp32-MFMA kernel; 2048 until the end of round 2:
 # the 4 x 4-pixel level of the 32 x 32 configurations is M = 512 with 512 -> 1024 channels, 62 -> 28 us per launch)
 WGRAD_SP_MIN_M = int(__import__("os").environ.get("CDF_WGRAD_SP_MIN_M", "512"))
+_SP_WGRAD_MIN_PIX = int(__import__("os").environ.get("CDF_SP_WGRAD_MIN_PIX", "128"))   # smallest pixel count per split of the in-kernel-split weight gradient
 _ATTN_KV_FUSED = __import__("os").environ.get("CDF_ATTN_KV_FUSED", "1") != "0"    # one-kernel k / v attention backward (k_attn.hip)
 
 
@@ -404,7 +405,9 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None, xa_s=No
     if rt.precision != "f32" and CA >= 128 and CB >= 128 and M >= WGRAD_SP_MIN_M:   # full 128x128 tiles only; thinner layers are faster on the fp32 kernel
         # split-precision bf16 MFMA kernel: 128x128 tiles, resident twice per CU (512 slots)
         tiles = ((CA + 127) // 128) * ((CB + 127) // 128) * wplan.ntaps
-        ns = best_nsplit(tiles, 512, M // 512)
+        # (a block of this kernel walks its pixels in dependent 32-pixel steps of ~4 us each -- load, split, transposing LDS pass, MFMA --
+        #  so a thin layer at 16 x 16 pixels took 70 us for 1 GFLOP with M // 512 = 16 splits: splits down to _SP_WGRAD_MIN_PIX pixels)
+        ns = best_nsplit(tiles, 512, max(1, M // _SP_WGRAD_MIN_PIX))
         ws = torch.empty((ns, wplan.ntaps, CA, ldo), device=xa.device, dtype=torch.float32)
         S = rt.stream(xa)
         bsum = torch.empty((ns, ldo), device=xa.device, dtype=torch.float32) if gbias is not None else None
