@@ -1795,9 +1795,17 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
                     cdf_mma_sp<NS>(acc[i][j], ah[i], al[i], bh[j], bl[j]);
                 }
         }
+#if !(CDF_WG_ABLATE & 8)
         if (it + 1 < niter) store_lds(buf ^ 1);
+#endif
         __syncthreads();
     }
+#if CDF_WG_ABLATE & 4
+    if (a.m_per_split != -12345) {
+        if (acc[0][0][0] == 123.456f && acc[1][0][3] == 1.f && acc[2][NT - 1][5] == 2.f) a.out[0] = 1.f;
+        return;
+    }
+#endif
 
     float* red = (float*)smem_raw;
     if (do_bsum) {                                 // [32 px][TB] partial column sums -> one row
@@ -1857,6 +1865,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
 // linear in the chunk index (no per-tap decode); the row / image borders are a per-lane mask.  8 waves (32 x TB/WB tiles, three
 // accumulator sets), one block per CU; grid (tiles, 3 tap rows, splits) in the XCD-aware order of cdf_wgrad_block.
 // ================================================================================================
+#ifndef CDF_WG_ABLATE
+#define CDF_WG_ABLATE 0   // probe builds only (tools/wg_ablate.py): 1 no global loads in the loop, 4 no slab stores, 8 no LDS stores in the loop
+#endif
 template <int TA, int TB, int NS = 3>
 __global__ void __launch_bounds__(512, 1) conv_wgrad_row3_kernel(SpxWgradArgs a) {
     constexpr int BK = 32, NTHR = 512;
@@ -1975,7 +1986,9 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_row3_kernel(SpxWgradArgs a)
     __syncthreads();
     for (int it = 0; it < niter; ++it) {
         const int buf = it & 1;
+#if !(CDF_WG_ABLATE & 1)
         if (it + 1 < niter) load_global(it + 1);
+#endif
         const unsigned short* sa = smem + buf * STAGE;
         const unsigned short* sb = sa + 2 * PLANE_A;
 #pragma unroll
@@ -2007,9 +2020,17 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_row3_kernel(SpxWgradArgs a)
                 }
             }
         }
+#if !(CDF_WG_ABLATE & 8)
         if (it + 1 < niter) store_lds(buf ^ 1);
+#endif
         __syncthreads();
     }
+#if CDF_WG_ABLATE & 4
+    if (a.m_per_split != -12345) {
+        if (acc[0][0][0] == 123.456f && acc[1][0][3] == 1.f && acc[2][NT - 1][5] == 2.f) a.out[0] = 1.f;
+        return;
+    }
+#endif
 
     float* red = (float*)smem_raw;
     if (do_bsum) {                                 // [32 px][TB] partial column sums -> one row
