@@ -24,7 +24,12 @@ for p in (os.path.join(REPO, "cold-diffusion-models_amd"), REPO):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# multi-process GPU work on these hosts needs dmabuf IPC (RCCL / hipIpcGetMemHandle fail with the legacy mode); the image exports it
+# already -- keep it when somebody launches with a scrubbed environment.  Must be set before the HIP runtime starts.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch  # noqa: E402
+
 
 def log(msg):
     sys.stderr.write("[bench %7.1fs] %s\n" % (time.perf_counter() - _T0, msg))

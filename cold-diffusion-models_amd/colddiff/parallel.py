@@ -12,8 +12,12 @@ Launch with `python -m torch.distributed.run --nproc-per-node N ...` (RANK / LOC
 import datetime
 import os
 
-import torch
-import torch.distributed as dist
+# dmabuf IPC for RCCL / cross-process device memory on these hosts (the legacy mode fails in hipIpcGetMemHandle); must be in the
+# environment before the HIP runtime starts, i.e. before the first torch.cuda call below.  A value the launcher set wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 from . import runtime as rt
 
