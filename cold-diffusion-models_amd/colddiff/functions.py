@@ -378,7 +378,9 @@ class ConvFn(torch.autograd.Function):
         # 4x4 stride-2 down / transposed up-sampling convs: every input pixel feeds several taps and N tiles, and the
         # same planes serve the weight gradient -> split once, use the LDS-DMA kernels (1x1 convs read x once: not worth it)
         xs = ops.split_bf16(x) if (_AUTO_PRESPLIT and (k > 1 or _PRESPLIT_1X1) and want_presplit(Cin, Cout, k)) else None
-        y = conv_forward(x, Cin, mod.weight, mod.bias, kind, stride, pad, xs=xs, **({"y": dest.first()} if dest is not None else {}))
+        # dest: a CatBuf (the conv writes its first half) or the destination view itself (a skip tensor written into its second half)
+        ydst = dest.first() if isinstance(dest, CatBuf) else dest
+        y = conv_forward(x, Cin, mod.weight, mod.bias, kind, stride, pad, xs=xs, **({"y": ydst} if ydst is not None else {}))
         ctx.mod, ctx.cfg = mod, (Cin, kind, stride, pad)
         _used(ctx, mod)
         ctx.has_xs = xs is not None
@@ -631,40 +633,40 @@ class Upsample2Fn(torch.autograd.Function):
     """F.interpolate(scale_factor=2, mode='nearest') alone: `Upsample(with_conv=False)` (Model2.py:36-50)."""
 
     @staticmethod
-    def forward(ctx, x):
-        return ops.upsample2(x)
+    def forward(ctx, x, out=None):
+        return ops.upsample2(x, out=out)
 
     @staticmethod
     def backward(ctx, dy):
-        return ops.upsample2_bwd(dy.contiguous())                      # each source pixel collects its 2 x 2 copies
+        return ops.upsample2_bwd(dy.contiguous()), None                # each source pixel collects its 2 x 2 copies
 
 
 class AvgPool2Fn(torch.autograd.Function):
     """F.avg_pool2d(x, kernel_size=2, stride=2): `Downsample(with_conv=False)` (Model2.py:53-73)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, out=None):
         B, H, W, C = x.shape
-        y = torch.empty((B, H // 2, W // 2, C), device=x.device, dtype=torch.float32)
-        rt.lib().cdf_pool2d(P(rt.check(x)), ops.ld_of(x), P(y), C, B, H, W, C, 2, 2, 0, 1, rt.stream(x))
+        y = torch.empty((B, H // 2, W // 2, C), device=x.device, dtype=torch.float32) if out is None else out
+        rt.lib().cdf_pool2d(P(rt.check(x)), ops.ld_of(x), P(y), ops.ld_of(y), B, H, W, C, 2, 2, 0, 1, rt.stream(x))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dx = ops.upsample2(dy.contiguous())                             # every input pixel gets a quarter of its window's gradient
         rt.lib().cdf_scale(P(dx), dx.numel(), 0.25, rt.stream(dx))
-        return dx
+        return dx, None
 
 
 class UpsampleConvFn(torch.autograd.Function):
     """F.interpolate(scale 2, nearest) -> Conv2d 3x3 (Model2.py:36-50); the x2 map is rebuilt in backward."""
 
     @staticmethod
-    def forward(ctx, anchor, x, conv):
+    def forward(ctx, anchor, x, conv, out=None):
         up = ops.upsample2(x)
         C = x.shape[-1]
         ctx.sp = _AUTO_PRESPLIT and want_presplit(C, conv.weight.shape[0], 3)
-        y = conv_forward(up, C, conv.weight, conv.bias, xs=ops.split_bf16(up) if ctx.sp else None)
+        y = conv_forward(up, C, conv.weight, conv.bias, xs=ops.split_bf16(up) if ctx.sp else None, **({"y": out} if out is not None else {}))
         ctx.conv = conv
         _used(ctx, conv)
         ctx.save_for_backward(x)
@@ -677,14 +679,14 @@ class UpsampleConvFn(torch.autograd.Function):
         ups, dys = (ops.split_bf16(up), ops.split_bf16(dy)) if ctx.sp else (None, None)
         dup = conv_backward(up, x.shape[-1], dy, ctx.conv.weight, ctx.conv.bias, xs=ups, dys=dys)
         _done(ctx)
-        return None, ops.upsample2_bwd(dup), None
+        return None, ops.upsample2_bwd(dup), None, None
 
 
 class ResnetBlockFn(torch.autograd.Function):
     """ResnetBlock.forward (Model2.py:114-133): GN+swish -> conv1 (+temb bias) -> GN+swish -> dropout -> conv2 (+shortcut)."""
 
     @staticmethod
-    def forward(ctx, anchor, x, tbias, m):
+    def forward(ctx, anchor, x, tbias, m, out=None):
         cin, cout = m.in_channels, m.out_channels
         # the 3x3 convs' operands are split into bf16 hi/lo planes once (forward, data gradient and weight gradient read them)
         sp1 = _AUTO_PRESPLIT and want_presplit(cin, cout, 3)
@@ -704,7 +706,7 @@ class ResnetBlockFn(torch.autograd.Function):
         else:
             sc = x
         h3_s = ops.split_bf16(h3) if sp2 else None
-        o = conv_forward(h3, cout, m.conv2.weight, m.conv2.bias, res=sc, xs=h3_s)
+        o = conv_forward(h3, cout, m.conv2.weight, m.conv2.bias, res=sc, xs=h3_s, **({"y": out} if out is not None else {}))
         ctx.m, ctx.drop = m, (p, seed)
         _used(ctx, m.norm1, m.conv1, m.norm2, m.conv2, sc_mod if cin != cout else None)
         ctx.split = (sp1, sp2)
@@ -733,14 +735,14 @@ class ResnetBlockFn(torch.autograd.Function):
         dh1 = conv_backward(h1, cin, dh2, m.conv1.weight, m.conv1.bias, xs=h1_s, dys=ops.split_bf16(dh2) if h1_s is not None else None)
         ops.groupnorm_bwd(dh1, x, m.norm1.weight, m.norm1.bias, mean1, rstd1, GN_GROUPS, True, dx=dx)
         _done(ctx)
-        return None, dx, dtb, None
+        return None, dx, dtb, None, None
 
 
 class AttnBlockFn(torch.autograd.Function):
     """AttnBlock.forward (Model2.py:164-188): GN -> q,k,v 1x1 -> softmax(q k^T C^-0.5) v -> proj_out + x."""
 
     @staticmethod
-    def forward(ctx, anchor, x, m):
+    def forward(ctx, anchor, x, m, out=None):
         B, H, W, C = x.shape
         n = H * W
         hn, mean, rstd = ops.groupnorm_fwd(x, m.norm.weight, m.norm.bias, GN_GROUPS, GN_EPS, False)
@@ -750,7 +752,7 @@ class AttnBlockFn(torch.autograd.Function):
         s = ops.bgemm_nt(q, k)                               # [B, n, n]  w_[b,i,j] = sum_c q[b,i,c] k[b,j,c]
         pm = ops.softmax_rows(s, n, float(int(C) ** (-0.5)))
         o = ops.bgemm_nn(pm, v, K=n).view(B, H, W, C)        # h_[b,i,c] = sum_j P[b,i,j] v[b,j,c]
-        y = conv_forward(o, C, m.proj_out.weight, m.proj_out.bias, res=x)
+        y = conv_forward(o, C, m.proj_out.weight, m.proj_out.bias, res=x, **({"y": out} if out is not None else {}))
         ctx.m = m
         _used(ctx, m.norm, m.q, m.k, m.v, m.proj_out)
         ctx.save_for_backward(x, hn, mean, rstd, q, k, v, pm, o)
@@ -775,4 +777,4 @@ class AttnBlockFn(torch.autograd.Function):
         dx = ops.copy_feat(dy)
         ops.groupnorm_bwd(dhn, x, m.norm.weight, m.norm.bias, mean, rstd, GN_GROUPS, False, dx=dx)
         _done(ctx)
-        return None, dx, None
+        return None, dx, None, None

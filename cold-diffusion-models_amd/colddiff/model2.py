@@ -21,10 +21,10 @@ class Upsample(nn.Module):
         if with_conv:
             self.conv = torch.nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         if not self.with_conv:
-            return F_.Upsample2Fn.apply(x)                  # bare nearest x2 (Model2.py:46-49)
-        return F_.UpsampleConvFn.apply(anchor(x), x, self.conv)
+            return F_.Upsample2Fn.apply(x, out)             # bare nearest x2 (Model2.py:46-49)
+        return F_.UpsampleConvFn.apply(anchor(x), x, self.conv, out)
 
 
 class Downsample(nn.Module):
@@ -34,11 +34,11 @@ class Downsample(nn.Module):
         if with_conv:
             self.conv = torch.nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         if not self.with_conv:
-            return F_.AvgPool2Fn.apply(x)                   # F.avg_pool2d(x, 2, 2) (Model2.py:71-72)
+            return F_.AvgPool2Fn.apply(x, out)              # F.avg_pool2d(x, 2, 2) (Model2.py:71-72)
         # F.pad(x, (0,1,0,1)) then 3x3 stride 2: the asymmetric zero pad is folded into the gather
-        return F_.ConvFn.apply(anchor(x), x, self.conv, x.shape[-1], "conv", 2, (0, 0, 1, 1))
+        return F_.ConvFn.apply(anchor(x), x, self.conv, x.shape[-1], "conv", 2, (0, 0, 1, 1), out)
 
 
 def Normalize(in_channels):
@@ -64,9 +64,9 @@ class ResnetBlock(nn.Module):
             else:
                 self.nin_shortcut = torch.nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
 
-    def forward(self, x, swish_temb):
+    def forward(self, x, swish_temb, out=None):
         tb = F_.Linear.apply(anchor(x), swish_temb, self.temb_proj)
-        return F_.ResnetBlockFn.apply(anchor(x), x, tb, self)
+        return F_.ResnetBlockFn.apply(anchor(x), x, tb, self, out)
 
 
 class AttnBlock(nn.Module):
@@ -79,8 +79,8 @@ class AttnBlock(nn.Module):
         self.v = torch.nn.Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
         self.proj_out = torch.nn.Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
 
-    def forward(self, x):
-        return F_.AttnBlockFn.apply(anchor(x), x, self)
+    def forward(self, x, out=None):
+        return F_.AttnBlockFn.apply(anchor(x), x, self, out)
 
 
 class Model(nn.Module):
@@ -145,6 +145,17 @@ class Model(nn.Module):
         self.norm_out = Normalize(block_in)
         self.conv_out = torch.nn.Conv2d(block_in, out_ch, kernel_size=3, stride=1, padding=1)
 
+        # torch.cat([h, hs.pop()], dim=1) (Model2.py:310-311) without the copy: the buffer of every concatenation is allocated when its
+        # SKIP half is produced on the way down (functions.CatBuf), and whoever produces `h` on the way up writes the first half.
+        # _skip_cx[j] = channels of the `h` that meets the j-th pushed skip tensor = its consumer's in_channels - the skip's channels.
+        skip_ch = [ch]
+        for i_level in range(self.num_resolutions):
+            skip_ch += [ch * ch_mult[i_level]] * (self.num_res_blocks + (1 if i_level != self.num_resolutions - 1 else 0))
+        consumers = [self.up[i_level].block[i_block].in_channels for i_level in reversed(range(self.num_resolutions))
+                     for i_block in range(self.num_res_blocks + 1)]
+        assert len(consumers) == len(skip_ch)
+        self._skip_cx = [consumers[len(skip_ch) - 1 - j] - c for j, c in enumerate(skip_ch)]
+
         half = self.ch // 2
         freq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))   # Model2.py:16-18
         self.register_buffer("_freq", freq, persistent=False)
@@ -161,28 +172,47 @@ class Model(nn.Module):
         st = F_.Act.apply(temb, F_.ACT_SILU)        # nonlinearity(temb), shared by every ResnetBlock
 
         h = F_.ToNHWC.apply(x.float())
-        hs = [F_.ConvFn.apply(a, h, self.conv_in, self.in_channels, "conv", 1, (1, 1, 1, 1))]
+        B, R = h.shape[0], self.resolution
+        hs, cats = [], []
+
+        def skip_dst(res, c):                               # the concat buffer of the next skip tensor; returns its second half
+            cats.append(F_.CatBuf(h, B, res, res, self._skip_cx[len(cats)], c))
+            return cats[-1].second()
+
+        hs.append(F_.ConvFn.apply(a, h, self.conv_in, self.in_channels, "conv", 1, (1, 1, 1, 1), skip_dst(R, self.ch)))
+        res = R
         for i_level in range(self.num_resolutions):
+            lvl = self.down[i_level]
             for i_block in range(self.num_res_blocks):
-                h = self.down[i_level].block[i_block](hs[-1], st)
-                if len(self.down[i_level].attn) > 0:
-                    h = self.down[i_level].attn[i_block](h)
+                c = lvl.block[i_block].out_channels
+                if len(lvl.attn) > 0:
+                    h = lvl.attn[i_block](lvl.block[i_block](hs[-1], st), skip_dst(res, c))
+                else:
+                    h = lvl.block[i_block](hs[-1], st, skip_dst(res, c))
                 hs.append(h)
             if i_level != self.num_resolutions - 1:
-                hs.append(self.down[i_level].downsample(hs[-1]))
+                res //= 2
+                hs.append(lvl.downsample(hs[-1], skip_dst(res, hs[-1].shape[-1])))
 
         h = hs[-1]
         h = self.mid.block_1(h, st)
         h = self.mid.attn_1(h)
-        h = self.mid.block_2(h, st)
+        h = self.mid.block_2(h, st, cats[-1].first())
 
         for i_level in reversed(range(self.num_resolutions)):
+            lvl = self.up[i_level]
             for i_block in range(self.num_res_blocks + 1):
-                h = self.up[i_level].block[i_block](F_.Concat.apply(h, hs.pop()), st)
-                if len(self.up[i_level].attn) > 0:
-                    h = self.up[i_level].attn[i_block](h)
+                hcat = F_.Join.apply(h, hs.pop(), cats.pop())
+                # where this block's result goes: the first half of the next concatenation -- directly, or through the upsampler
+                nxt = cats[-1].first() if cats else None
+                via_up = i_block == self.num_res_blocks and i_level != 0
+                dst = None if via_up else nxt
+                if len(lvl.attn) > 0:
+                    h = lvl.attn[i_block](lvl.block[i_block](hcat, st), dst)
+                else:
+                    h = lvl.block[i_block](hcat, st, dst)
             if i_level != 0:
-                h = self.up[i_level].upsample(h)
+                h = lvl.upsample(h, cats[-1].first())
 
         h = F_.GroupNormFn.apply(a, h, self.norm_out, True)
         h = F_.ConvFn.apply(a, h, self.conv_out, h.shape[-1], "conv", 1, (1, 1, 1, 1))

@@ -888,10 +888,10 @@ def softmax_rows_bwd(p, dp, n, scale):
     return ds
 
 
-def upsample2(x):
+def upsample2(x, out=None):
     B, H, W, C = x.shape
-    y = torch.empty((B, 2 * H, 2 * W, C), device=x.device, dtype=torch.float32)
-    rt.lib().cdf_upsample2(P(x), ld_of(x), P(y), C, B, H, W, C, rt.stream(x))
+    y = torch.empty((B, 2 * H, 2 * W, C), device=x.device, dtype=torch.float32) if out is None else out
+    rt.lib().cdf_upsample2(P(x), ld_of(x), P(y), ld_of(y), B, H, W, C, rt.stream(x))
     return y
 
 
