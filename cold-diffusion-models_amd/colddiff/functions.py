@@ -691,21 +691,28 @@ class ResnetBlockFn(torch.autograd.Function):
         # the 3x3 convs' operands are split into bf16 hi/lo planes once (forward, data gradient and weight gradient read them)
         sp1 = _AUTO_PRESPLIT and want_presplit(cin, cout, 3)
         sp2 = _AUTO_PRESPLIT and want_presplit(cout, cout, 3)
-        h1, mean1, rstd1 = ops.groupnorm_fwd(x, m.norm1.weight, m.norm1.bias, GN_GROUPS, GN_EPS, True)
-        h1_s = ops.split_bf16(h1) if sp1 else None
+        # GroupNorm + SiLU (+ dropout) write the next conv's bf16 operand planes themselves; when every consumer reads the planes
+        # (fwd / dgrad GEMMs always, the weight-gradient GEMM from ops.WGRAD_SP_MIN_M pixels up) the fp32 copy is not written at all
+        B, H, W, _ = x.shape
+        lean = _LEAN and B * H * W >= ops.WGRAD_SP_MIN_M
+        if sp1:
+            h1, mean1, rstd1, h1_s = ops.groupnorm_fwd(x, m.norm1.weight, m.norm1.bias, GN_GROUPS, GN_EPS, True, split_out=True, planes_only=lean)
+        else:
+            (h1, mean1, rstd1), h1_s = ops.groupnorm_fwd(x, m.norm1.weight, m.norm1.bias, GN_GROUPS, GN_EPS, True), None
         h2 = conv_forward(h1, cin, m.conv1.weight, m.conv1.bias, sbias=tbias, xs=h1_s)
-        h3, mean2, rstd2 = ops.groupnorm_fwd(h2, m.norm2.weight, m.norm2.bias, GN_GROUPS, GN_EPS, True)
         p = m.dropout.p if m.training else 0.0
-        seed = 0
-        if p > 0:
-            seed = _seed()
-            h3 = ops.dropout(h3, p, seed)
+        seed = _seed() if p > 0 else 0
+        drop = (p, seed) if p > 0 else None
+        if sp2:
+            h3, mean2, rstd2, h3_s = ops.groupnorm_fwd(h2, m.norm2.weight, m.norm2.bias, GN_GROUPS, GN_EPS, True, split_out=True, planes_only=lean,
+                                                       drop=drop)
+        else:
+            (h3, mean2, rstd2), h3_s = ops.groupnorm_fwd(h2, m.norm2.weight, m.norm2.bias, GN_GROUPS, GN_EPS, True, drop=drop), None
         if cin != cout:
             sc_mod = m.conv_shortcut if m.use_conv_shortcut else m.nin_shortcut
             sc = conv_forward(x, cin, sc_mod.weight, sc_mod.bias)
         else:
             sc = x
-        h3_s = ops.split_bf16(h3) if sp2 else None
         o = conv_forward(h3, cout, m.conv2.weight, m.conv2.bias, res=sc, xs=h3_s, **({"y": out} if out is not None else {}))
         ctx.m, ctx.drop = m, (p, seed)
         _used(ctx, m.norm1, m.conv1, m.norm2, m.conv2, sc_mod if cin != cout else None)
@@ -728,9 +735,7 @@ class ResnetBlockFn(torch.autograd.Function):
         else:
             dx = ops.copy_feat(do)
         dh3 = conv_backward(h3, cout, do, m.conv2.weight, m.conv2.bias, xs=h3_s, dys=ops.split_bf16(do) if h3_s is not None else None)
-        if p > 0:
-            dh3 = ops.dropout(dh3, p, seed)
-        dh2 = ops.groupnorm_bwd(dh3, h2, m.norm2.weight, m.norm2.bias, mean2, rstd2, GN_GROUPS, True)
+        dh2 = ops.groupnorm_bwd(dh3, h2, m.norm2.weight, m.norm2.bias, mean2, rstd2, GN_GROUPS, True, drop=(p, seed) if p > 0 else None)
         dtb = ops.colsum_new(dh2, cout, dh2.shape[0])
         dh1 = conv_backward(h1, cin, dh2, m.conv1.weight, m.conv1.bias, xs=h1_s, dys=ops.split_bf16(dh2) if h1_s is not None else None)
         ops.groupnorm_bwd(dh1, x, m.norm1.weight, m.norm1.bias, mean1, rstd1, GN_GROUPS, True, dx=dx)

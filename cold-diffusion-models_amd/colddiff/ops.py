@@ -804,21 +804,29 @@ def nhwc_to_nchw(x, C, add=None):
 # ---------------------------------------------------------------------------------------------------
 # GroupNorm / batched GEMMs / resampling (the DDPM `Model` family)
 # ---------------------------------------------------------------------------------------------------
-def groupnorm_fwd(x, gamma, beta, groups, eps, silu):
+def groupnorm_fwd(x, gamma, beta, groups, eps, silu, split_out=False, planes_only=False, drop=None):
+    """drop = (p, seed): the dropout of ops.dropout applied to the activated output in the same pass; split_out: also return the
+    output's bf16 (hi, lo) planes (fused cdf_split_bf16); planes_only: do not materialise the fp32 output (shape_only stand-in)."""
     L = rt.lib()
     B, H, W, C = x.shape
     HW = H * W
     nch = L.cdf_groupnorm_nchunk(HW)
-    y = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+    planes_only = planes_only and split_out
+    y = shape_only(B, H, W, C) if planes_only else torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
     mean = torch.empty((B * groups,), device=x.device, dtype=torch.float32)
     rstd = torch.empty((B * groups,), device=x.device, dtype=torch.float32)
     ws = torch.empty((B * nch * 2 * C,), device=x.device, dtype=torch.float32)
-    L.cdf_groupnorm_fwd(P(x), ld_of(x), P(y), C, P(gamma), P(beta), P(mean), P(rstd), P(ws), B, HW, C, groups, eps, 1 if silu else 0,
-                        rt.stream(x))
+    ys = split_planes_like(x, B, H, W, C) if split_out else None
+    p, seed = drop if drop is not None else (0.0, 0)
+    L.cdf_groupnorm_fwd_ex(P(x), ld_of(x), P(y), C, P(gamma), P(beta), P(mean), P(rstd), P(ws), B, HW, C, groups, eps, 1 if silu else 0,
+                           float(p), int(seed), P(ys[0]) if ys else 0, P(ys[1]) if ys else 0, ys[0].shape[-1] if ys else 0, rt.stream(x))
+    if split_out:
+        return y, mean, rstd, ys
     return y, mean, rstd
 
 
-def groupnorm_bwd(dy, x, gamma_p, beta_p, mean, rstd, groups, silu, dx=None):
+def groupnorm_bwd(dy, x, gamma_p, beta_p, mean, rstd, groups, silu, dx=None, drop=None):
+    """drop = (p, seed): dy is the gradient of the dropped output (groupnorm_fwd(..., drop=...)); the mask is applied in the same pass"""
     L = rt.lib()
     B, H, W, C = x.shape
     HW = H * W
@@ -827,8 +835,9 @@ def groupnorm_bwd(dy, x, gamma_p, beta_p, mean, rstd, groups, silu, dx=None):
     if dx is None:
         dx = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
     ws = torch.empty((B * nch * 2 * C + B * 2 * C + B * groups * 2,), device=x.device, dtype=torch.float32)
-    L.cdf_groupnorm_bwd(P(dy), ld_of(dy), P(x), ld_of(x), P(gamma_p), P(beta_p), P(mean), P(rstd), P(dx), ld_of(dx),
-                        P(grad_of(gamma_p)), P(grad_of(beta_p)), P(ws), B, HW, C, groups, 1 if silu else 0, acc, 1, rt.stream(x))
+    p, seed = drop if drop is not None else (0.0, 0)
+    L.cdf_groupnorm_bwd_ex(P(dy), ld_of(dy), P(x), ld_of(x), P(gamma_p), P(beta_p), P(mean), P(rstd), P(dx), ld_of(dx),
+                           P(grad_of(gamma_p)), P(grad_of(beta_p)), P(ws), B, HW, C, groups, 1 if silu else 0, acc, 1, float(p), int(seed), rt.stream(x))
     return dx
 
 

@@ -140,6 +140,16 @@ __device__ __forceinline__ float cdf_group_sum(float v, int width) {
     return v;
 }
 
+// counter-based dropout mask (Model2.py:94,124 nn.Dropout; the mask stream is this hash, not torch's Philox): element idx of a
+// [rows][C] map (idx = row * C + c) is kept iff cdf_hash32(seed, idx) >= p * 2^32; kept values are scaled by 1 / (1 - p)
+__device__ __forceinline__ unsigned cdf_hash32(unsigned long long seed, unsigned long long idx) {
+    unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (unsigned)(z >> 32);
+}
+
 // exact (erf) GELU, matches torch.nn.GELU(approximate='none')
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute), branch-free, ~14 instructions; also hands back
 // exp(-z^2), which the GELU derivative needs anyway.  libm's erff is two divergent paths of ~35 instructions each:

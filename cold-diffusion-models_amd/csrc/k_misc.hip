@@ -94,14 +94,7 @@ __global__ void upsample2_bwd_kernel(const float* dy, int lddy, float* dx, int l
     }
 }
 
-// counter-based dropout mask: keep iff hash(seed, index) >= p*2^32 ; y = x * keep / (1-p)
-__device__ __forceinline__ unsigned cdf_hash32(unsigned long long seed, unsigned long long idx) {
-    unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (unsigned)(z >> 32);
-}
+// counter-based dropout mask (cdf_hash32, cdf_common.h): keep iff hash(seed, index) >= p*2^32 ; y = x * keep / (1-p)
 __global__ void dropout_kernel(const float* x, int ldx, float* y, int ldy, long long rows, int C, float p,
                                unsigned long long seed) {
     const unsigned thr = (unsigned)((double)p * 4294967296.0);

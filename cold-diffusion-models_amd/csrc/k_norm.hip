@@ -236,7 +236,11 @@ __global__ void __launch_bounds__(1024) norm_param_reduce_kernel(const float* pa
 // part layout [B][nchunk][2][C]; grid = (ceil(C/64), nchunk, B); block 256 = 4 row lanes x 64 ch
 __global__ void groupnorm_partial_kernel(const float* x, int ldx, const float* dy, int lddy, const float* gamma,
                                          const float* beta, const float* mean, const float* rstd, float* part, int HW,
-                                         int rows_per_chunk, int C, int groups, int mode, int silu) {
+                                         int rows_per_chunk, int C, int groups, int mode, int silu, float p_drop,
+                                         unsigned long long seed) {
+    // p_drop > 0 (mode 1): dy is the gradient of the DROPPED output, the mask (cdf_dropout's, element (b HW + r) C + c) is applied here
+    const unsigned thr = (unsigned)((double)p_drop * 4294967296.0);
+    const float inv = 1.0f / (1.0f - p_drop);
     __shared__ float red[2][4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, b = blockIdx.z;
     const int r0 = blockIdx.y * rows_per_chunk;
@@ -278,6 +282,7 @@ __global__ void groupnorm_partial_kernel(const float* x, int ldx, const float* d
                 for (int u = 0; u < 4; ++u) {
                     const float xh = (xv[u] - mu) * rs;
                     float dz = dv[u];
+                    if (p_drop > 0.f) dz = cdf_hash32(seed, (unsigned long long)((long long)b * HW + r + 4 * u) * C + c) >= thr ? dz * inv : 0.f;
                     if (silu) dz *= cdf_silu_grad(xh * ga + be);
                     p0 += dz;
                     p1 += dz * xh;
@@ -286,6 +291,7 @@ __global__ void groupnorm_partial_kernel(const float* x, int ldx, const float* d
             for (; r < r1; r += 4) {
                 const float xh = (xp[(long long)r * ldx] - mu) * rs;
                 float dz = dp[(long long)r * lddy];
+                if (p_drop > 0.f) dz = cdf_hash32(seed, (unsigned long long)((long long)b * HW + r) * C + c) >= thr ? dz * inv : 0.f;
                 if (silu) dz *= cdf_silu_grad(xh * ga + be);
                 p0 += dz;
                 p1 += dz * xh;
@@ -375,10 +381,15 @@ __global__ void __launch_bounds__(1024) groupnorm_bwd_param_kernel(const float* 
     }
 }
 
-// y = act((x-mean)*rstd*gamma+beta); float4 over channels
+// y = drop(act((x-mean)*rstd*gamma+beta)); float4 over channels.  Optional tail of the ResnetBlock chain (Model2.py:118-126): the
+// dropout mask of cdf_dropout (same hash, same element index) and the result again as bf16 hi / lo planes (the next conv's operand
+// split, bit-equal to cdf_split_bf16 of y); y may be null when only the planes are wanted.
 __global__ void groupnorm_apply_kernel(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
-                                       const float* mean, const float* rstd, int B, int HW, int C, int groups, int silu) {
+                                       const float* mean, const float* rstd, int B, int HW, int C, int groups, int silu, float p_drop,
+                                       unsigned long long seed, unsigned short* y_hi, unsigned short* y_lo, int ld_ys) {
     const int c4n = C / 4, cg = C / groups;
+    const unsigned thr = (unsigned)((double)p_drop * 4294967296.0);
+    const float inv = 1.0f / (1.0f - p_drop);
     const long long n = (long long)B * HW * c4n;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % c4n) * 4;
@@ -392,8 +403,10 @@ __global__ void groupnorm_apply_kernel(const float* x, int ldx, float* y, int ld
             const int gi = (c + e) / cg;
             const float z = (in[e] - mean[b * groups + gi]) * rstd[b * groups + gi] * gaa[e] + bee[e];
             o[e] = silu ? cdf_silu(z) : z;
+            if (p_drop > 0.f) o[e] = cdf_hash32(seed, (unsigned long long)(pix * C + c + e)) >= thr ? o[e] * inv : 0.f;
         }
-        *(float4*)(y + pix * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+        if (y) *(float4*)(y + pix * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+        if (y_hi) cdf_split_store4(y_hi + pix * ld_ys + c, y_lo ? y_lo + pix * ld_ys + c : nullptr, o);
     }
 }
 
@@ -401,8 +414,10 @@ __global__ void groupnorm_apply_kernel(const float* x, int ldx, float* y, int ld
 __global__ void groupnorm_bwd_apply_kernel(const float* dy, int lddy, const float* x, int ldx, const float* gamma,
                                            const float* beta, const float* mean, const float* rstd, const float* s12,
                                            float* dx, int lddx, int B, int HW, int C, int groups, int silu,
-                                           int accumulate) {
+                                           int accumulate, float p_drop, unsigned long long seed) {
     const int c4n = C / 4, cg = C / groups;
+    const unsigned thr = (unsigned)((double)p_drop * 4294967296.0);
+    const float inv = 1.0f / (1.0f - p_drop);
     const long long n = (long long)B * HW * c4n;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % c4n) * 4;
@@ -417,6 +432,7 @@ __global__ void groupnorm_bwd_apply_kernel(const float* dy, int lddy, const floa
             const int gi = (c + e) / cg, sg = b * groups + gi;
             const float rs = rstd[sg], xh = (in[e] - mean[sg]) * rs;
             float dz = dd[e];
+            if (p_drop > 0.f) dz = cdf_hash32(seed, (unsigned long long)(pix * C + c + e)) >= thr ? dz * inv : 0.f;
             if (silu) dz *= cdf_silu_grad(xh * gaa[e] + bee[e]);
             o[e] = rs * (dz * gaa[e] - s12[2 * sg] - xh * s12[2 * sg + 1]);
         }
@@ -514,35 +530,46 @@ extern "C" int cdf_groupnorm_nchunk(int HW) {
 }
 
 // ws: >= B * nchunk * 2 * C floats ; mean/rstd: [B][groups]
-extern "C" int cdf_groupnorm_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
-                                 float* mean, float* rstd, float* ws, int B, int HW, int C, int groups, float eps,
-                                 int silu, void* stream) {
-    CDF_REQUIRE(x && y && gamma && beta && mean && rstd && ws, "cdf_groupnorm_fwd: null pointer");
-    CDF_REQUIRE(C % groups == 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "cdf_groupnorm_fwd: C=%d groups=%d", C, groups);
+extern "C" int cdf_groupnorm_fwd_ex(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
+                                    float* mean, float* rstd, float* ws, int B, int HW, int C, int groups, float eps,
+                                    int silu, float p_drop, long long seed, void* y_hi, void* y_lo, int ld_ys, void* stream) {
+    CDF_REQUIRE(x && (y || y_hi) && gamma && beta && mean && rstd && ws, "cdf_groupnorm_fwd: null pointer");
+    CDF_REQUIRE(C % groups == 0 && C % 4 == 0 && ldx % 4 == 0 && (!y || ldy % 4 == 0), "cdf_groupnorm_fwd: C=%d groups=%d", C, groups);
+    CDF_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "cdf_groupnorm_fwd: dropout probability %g", (double)p_drop);
+    CDF_REQUIRE(!y_hi || (ld_ys % 4 == 0 && ld_ys >= C && ((((uintptr_t)y_hi) | ((uintptr_t)y_lo)) & 7) == 0), "cdf_groupnorm_fwd: bad output planes");
+    CDF_REQUIRE(y_hi || !y_lo, "cdf_groupnorm_fwd: lo plane without hi plane");
     const int nchunk = cdf_groupnorm_nchunk(HW), rpc = cdf_cdiv(HW, nchunk);
     CDF_LAUNCH(groupnorm_partial_kernel, dim3(cdf_cdiv(C, 64), nchunk, B), dim3(256), 0, CDF_S, x, ldx, (const float*)nullptr, 0,
-               gamma, beta, (const float*)nullptr, (const float*)nullptr, ws, HW, rpc, C, groups, 0, 0);
+               gamma, beta, (const float*)nullptr, (const float*)nullptr, ws, HW, rpc, C, groups, 0, 0, 0.f, 0ull);
     CDF_LAUNCH(groupnorm_stats_kernel, dim3(B), dim3(64), 0, CDF_S, (const float*)ws, nchunk, C, groups, HW, eps, mean, rstd);
     const long long n = (long long)B * HW * (C / 4);
     int grid = (int)((n + 255) / 256);
     if (grid > 4096) grid = 4096;
-    CDF_LAUNCH(groupnorm_apply_kernel, dim3(grid), dim3(256), 0, CDF_S, x, ldx, y, ldy, gamma, beta, (const float*)mean, (const float*)rstd, B, HW, C, groups, silu);
+    CDF_LAUNCH(groupnorm_apply_kernel, dim3(grid), dim3(256), 0, CDF_S, x, ldx, y, ldy, gamma, beta, (const float*)mean, (const float*)rstd, B, HW, C, groups, silu,
+               p_drop, (unsigned long long)seed, (unsigned short*)y_hi, (unsigned short*)y_lo, ld_ys);
     return cdf_check_launch("groupnorm_fwd");
+}
+extern "C" int cdf_groupnorm_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
+                                 float* mean, float* rstd, float* ws, int B, int HW, int C, int groups, float eps,
+                                 int silu, void* stream) {
+    CDF_REQUIRE(y, "cdf_groupnorm_fwd: null pointer");
+    return cdf_groupnorm_fwd_ex(x, ldx, y, ldy, gamma, beta, mean, rstd, ws, B, HW, C, groups, eps, silu, 0.f, 0, nullptr, nullptr, 0, stream);
 }
 
 // ws: >= B*nchunk*2*C + B*2*C + B*groups*2 floats
-extern "C" int cdf_groupnorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma,
-                                 const float* beta, const float* mean, const float* rstd, float* dx, int lddx,
-                                 float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int groups, int silu,
-                                 int accumulate_dx, int accumulate_param, void* stream) {
+extern "C" int cdf_groupnorm_bwd_ex(const float* dy, int lddy, const float* x, int ldx, const float* gamma,
+                                    const float* beta, const float* mean, const float* rstd, float* dx, int lddx,
+                                    float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int groups, int silu,
+                                    int accumulate_dx, int accumulate_param, float p_drop, long long seed, void* stream) {
     CDF_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta && ws, "cdf_groupnorm_bwd: null pointer");
     CDF_REQUIRE(C % groups == 0 && C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "cdf_groupnorm_bwd: bad C / pitch");
+    CDF_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "cdf_groupnorm_bwd: dropout probability %g", (double)p_drop);
     const int nchunk = cdf_groupnorm_nchunk(HW), rpc = cdf_cdiv(HW, nchunk);
     float* part = ws;
     float* ab = part + (size_t)B * nchunk * 2 * C;
     float* s12 = ab + (size_t)B * 2 * C;
     CDF_LAUNCH(groupnorm_partial_kernel, dim3(cdf_cdiv(C, 64), nchunk, B), dim3(256), 0, CDF_S, x, ldx, dy, lddy, gamma, beta, mean, rstd,
-               part, HW, rpc, C, groups, 1, silu);
+               part, HW, rpc, C, groups, 1, silu, p_drop, (unsigned long long)seed);
     CDF_LAUNCH(groupnorm_bwd_reduce_kernel, dim3(cdf_cdiv(B * 2 * C, 256)), dim3(256), 0, CDF_S, (const float*)part, nchunk, B, C, ab);
     CDF_LAUNCH(groupnorm_bwd_group_kernel, dim3(cdf_cdiv(B * groups, 256)), dim3(256), 0, CDF_S, (const float*)ab, B, C, groups, HW, gamma, s12);
     CDF_LAUNCH(groupnorm_bwd_param_kernel, dim3(cdf_cdiv(C, 64)), dim3(1024), 0, CDF_S, (const float*)ab, B, C, dgamma, dbeta, accumulate_param);
@@ -550,6 +577,13 @@ extern "C" int cdf_groupnorm_bwd(const float* dy, int lddy, const float* x, int 
     int grid = (int)((n + 255) / 256);
     if (grid > 4096) grid = 4096;
     CDF_LAUNCH(groupnorm_bwd_apply_kernel, dim3(grid), dim3(256), 0, CDF_S, dy, lddy, x, ldx, gamma, beta, mean, rstd, (const float*)s12,
-               dx, lddx, B, HW, C, groups, silu, accumulate_dx);
+               dx, lddx, B, HW, C, groups, silu, accumulate_dx, p_drop, (unsigned long long)seed);
     return cdf_check_launch("groupnorm_bwd");
+}
+extern "C" int cdf_groupnorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma,
+                                 const float* beta, const float* mean, const float* rstd, float* dx, int lddx,
+                                 float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int groups, int silu,
+                                 int accumulate_dx, int accumulate_param, void* stream) {
+    return cdf_groupnorm_bwd_ex(dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dgamma, dbeta, ws, B, HW, C, groups, silu, accumulate_dx,
+                                accumulate_param, 0.f, 0, stream);
 }

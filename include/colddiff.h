@@ -286,6 +286,17 @@ int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, int ldx, cons
 int cdf_groupnorm_nchunk(int HW);
 int cdf_groupnorm_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta, float* mean,
                       float* rstd, float* ws, int B, int HW, int C, int groups, float eps, int silu, void* stream);
+/* the same with the tail of ResnetBlock.forward fused in (Model2.py:118-126): p_drop > 0 applies cdf_dropout's mask (seed, element
+ * index row * C + c) to the activated output; y_hi / y_lo (nullable, pitch ld_ys): the result again as bf16 hi / lo planes, bit-equal
+ * to cdf_split_bf16 of y (y_lo null: hi only); y itself may then be null (planes only). */
+/* backward of the same: p_drop > 0 says dy is the gradient of the DROPPED output; the mask is applied while dy is read */
+int cdf_groupnorm_bwd_ex(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta,
+                         const float* mean, const float* rstd, float* dx, int lddx, float* dgamma, float* dbeta, float* ws,
+                         int B, int HW, int C, int groups, int silu, int accumulate_dx, int accumulate_param, float p_drop,
+                         long long seed, void* stream);
+int cdf_groupnorm_fwd_ex(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta, float* mean,
+                         float* rstd, float* ws, int B, int HW, int C, int groups, float eps, int silu, float p_drop,
+                         long long seed, void* y_hi, void* y_lo, int ld_ys, void* stream);
 int cdf_groupnorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta,
                       const float* mean, const float* rstd, float* dx, int lddx, float* dgamma, float* dbeta, float* ws,
                       int B, int HW, int C, int groups, int silu, int accumulate_dx, int accumulate_param,

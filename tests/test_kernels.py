@@ -393,6 +393,21 @@ def test_groupnorm(be, B, HW, C, silu):
     dx, dga, dbe = be.empty(B, HW, C), be.zeros(C), be.zeros(C)
     be.L.cdf_groupnorm_bwd(P(be.to(dy)), C, P(xd), C, P(gd), P(bd), P(mean), P(rstd), P(dx), C, P(dga), P(dbe), P(ws), B, HW, C, 32, silu, 0, 0, be.stream())
     assert err(y, yref) <= 1e-5 and err(dx, x.grad) <= 2e-5 and err(dga, ga.grad) <= 1e-4 and err(dbe, bt.grad) <= 1e-4
+    # the fused tail of ResnetBlock.forward: dropout with cdf_dropout's mask, the output again as bf16 planes (bit-equal to
+    # cdf_split_bf16 of it), with and without the fp32 copy
+    pdrop, seed, ld8 = 0.25, 12345, (C + 7) // 8 * 8
+    yd, y2 = be.empty(B, HW, C), be.empty(B, HW, C)
+    be.L.cdf_dropout(P(y), C, P(yd), C, B * HW, C, pdrop, seed, be.stream())
+    hi, lo = (torch.zeros(B, HW, ld8, dtype=torch.int16, device=be.device) for _ in range(2))
+    be.L.cdf_groupnorm_fwd_ex(P(xd), C, P(y2), C, P(gd), P(bd), P(mean), P(rstd), P(ws), B, HW, C, 32, 1e-6, silu, pdrop, seed, P(hi), P(lo), ld8,
+                              be.stream())
+    assert torch.equal(y2.cpu(), yd.cpu()) and 0.5 < float((yd.cpu() != 0).float().mean()) < 0.95
+    rh, rl = (torch.zeros(B, HW, ld8, dtype=torch.int16, device=be.device) for _ in range(2))
+    be.L.cdf_split_bf16(P(yd), C, P(rh), P(rl), ld8, B * HW, C, be.stream())
+    assert torch.equal(hi.cpu(), rh.cpu()) and torch.equal(lo.cpu(), rl.cpu())
+    hi2 = torch.zeros_like(hi)
+    be.L.cdf_groupnorm_fwd_ex(P(xd), C, 0, 0, P(gd), P(bd), P(mean), P(rstd), P(ws), B, HW, C, 32, 1e-6, silu, pdrop, seed, P(hi2), 0, ld8, be.stream())
+    assert torch.equal(hi2.cpu(), rh.cpu())
 
 
 @pytest.mark.parametrize("B,C,H", [(2, 8, 8), (1, 3, 8), (2, 64, 4), (1, 68, 12), (3, 8, 40), (1, 36, 40), (5, 4, 16)])

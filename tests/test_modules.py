@@ -642,6 +642,42 @@ def test_resampling_conv_presplit(mbe, kind):
         assert (p_.grad.cpu() - r.grad).abs().max().item() <= tol * max(r.grad.abs().max().item(), 1e-3), n
 
 
+def test_resnet_block_dropout_in_training(mbe, monkeypatch):
+    """ResnetBlock in training mode with dropout 0.25 (MODEL2:94,124): the mask is the engine's own counter-based stream (not torch's
+    Philox), so the check replays it -- cdf_dropout on ones with the block's seed -- into a torch restatement of the
+    block: forward and every gradient.  Covers GroupNorm + SiLU + dropout + operand split fused in one pass, planes-only and not."""
+    from colddiff.model2 import ResnetBlock
+    from colddiff import functions as F_
+    from colddiff import ops
+    import torch.nn.functional as F
+    torch.manual_seed(11)
+    monkeypatch.setattr(F_, "_seed", lambda: 424242)
+    for lean in (True, False):
+        monkeypatch.setattr(F_, "_LEAN", lean)
+        blk = ResnetBlock(in_channels=64, out_channels=128, dropout=0.25, temb_channels=32).train()
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+        blk = blk.to(mbe.device)
+        x, temb, g = torch.randn(8, 64, 16, 16), torch.randn(8, 32), torch.randn(8, 128, 16, 16)
+        mask = ops.dropout(torch.ones(8, 16, 16, 128, device=mbe.device), 0.25, 424242).cpu().permute(0, 3, 1, 2)   # 0 or 1 / (1 - p)
+        assert 0.6 < float((mask != 0).float().mean()) < 0.9
+        sw = lambda v: v * torch.sigmoid(v)
+        xr = x.clone().requires_grad_(True)
+        h = F.conv2d(sw(F.group_norm(xr, 32, sd['norm1.weight'], sd['norm1.bias'], eps=1e-6)), sd['conv1.weight'], sd['conv1.bias'], padding=1)
+        h = h + F.linear(sw(temb), sd['temb_proj.weight'], sd['temb_proj.bias'])[:, :, None, None]
+        h = sw(F.group_norm(h, 32, sd['norm2.weight'], sd['norm2.bias'], eps=1e-6)) * mask
+        yr = F.conv2d(xr, sd['nin_shortcut.weight'], sd['nin_shortcut.bias']) + F.conv2d(h, sd['conv2.weight'], sd['conv2.bias'], padding=1)
+        yr.backward(g)
+        xd = mbe.to(x).requires_grad_(True)
+        y = F_.ToNCHW.apply(blk(F_.ToNHWC.apply(xd), mbe.to(sw(temb))), 128, None)
+        y.backward(mbe.to(g))
+        tol = 1e-4
+        assert (y.detach().cpu() - yr.detach()).abs().max().item() <= tol * yr.abs().max().item()
+        assert (xd.grad.cpu() - xr.grad).abs().max().item() <= tol * xr.grad.abs().max().item()
+        for n, p_ in blk.named_parameters():
+            r = sd[n].grad
+            assert (p_.grad.cpu() - r).abs().max().item() <= tol * max(r.abs().max().item(), 1e-3), (lean, n)
+
+
 def test_resnet_block_presplit_operands(mbe):
     """CIFAR `Model` ResnetBlock (MODEL2:114-133) with its 3x3 convs on pre-split bf16 planes: forward and every
     gradient against the oracle at the fp32 parity bound."""
