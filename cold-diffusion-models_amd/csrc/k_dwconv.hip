@@ -70,27 +70,43 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx
         const int tap = flip ? DW_TAPS - 1 - tp : tp;
         wl[i] = (cq0 + l) < C4 ? *(const float4*)(w + (long long)tap * ldw + (cq0 + l) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // Index arithmetic of the 17 halo loads without 32-bit multiplies or 64-bit VALU math (round 3: integer multiplies run at a quarter
+    // of the FMA rate and were, with the per-load divisions, more vector work than the 784 packed FMAs): element offsets inside one
+    // image are 24-bit x 24-bit products (host: H W pitch < 2^30), the image base is a scalar, and (hy, hx) of slot k follow from
+    // slot k - 1 by adding 32 pixels.
     const float* xb = x + (long long)b * H * W * ldx;
     constexpr int NHALO = HH_ * HW_ * 8, NIT = (NHALO + 255) / 256;
+    constexpr int STEP_Y = 32 / HW_, STEP_X = 32 % HW_;      // 32 pixels further in the [HH_][HW_] halo
+    const int l_ = tid & 7;
+    const unsigned lc4 = (unsigned)(((cq0 + l_) < C4 ? cq0 + l_ : 0) * 4);
+    const bool lok = (cq0 + l_) < C4;
     float4 hv[NIT];
+    {
+        int hy = 0, hx = tid >> 3;                           // (tid >> 3 < 32 <= HW_)
+        if (hx >= HW_) { hx -= HW_; ++hy; }
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) {                          // every load requested before anything is used
-        const int i = tid + 256 * k;
-        const int l = i & 7, p = i >> 3;
-        const int hy = p / HW_, hx = p - hy * HW_;
-        const int iy = Y0 + hy - 3, ix = X0 + hx - 3;
-        const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-        const int lc = (cq0 + l) < C4 ? cq0 + l : 0;
-        hv[k] = *(const float4*)(xb + ((long long)iyc * W + ixc) * ldx + lc * 4);
+        for (int k = 0; k < NIT; ++k) {                      // every load requested before anything is used
+            const int iy = Y0 + hy - 3, ix = X0 + hx - 3;
+            const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+            const unsigned off = __umul24(__umul24((unsigned)iyc, (unsigned)W) + (unsigned)ixc, (unsigned)ldx) + lc4;
+            hv[k] = *(const float4*)(xb + off);
+            hy += STEP_Y;
+            hx += STEP_X;
+            if (hx >= HW_) { hx -= HW_; ++hy; }
+        }
     }
+    {
+        int hy = 0, hx = tid >> 3;
+        if (hx >= HW_) { hx -= HW_; ++hy; }
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-        const int i = tid + 256 * k;
-        const int l = i & 7, p = i >> 3;
-        const int hy = p / HW_, hx = p - hy * HW_;
-        const int iy = Y0 + hy - 3, ix = X0 + hx - 3;
-        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W && (cq0 + l) < C4;
-        if (i < NHALO) halo[hy * RP + hx * 8 + l] = ok ? hv[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < NIT; ++k) {
+            const int iy = Y0 + hy - 3, ix = X0 + hx - 3;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W && lok;
+            if (hy < HH_) halo[__umul24((unsigned)hy, (unsigned)RP) + hx * 8 + l_] = ok ? hv[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            hy += STEP_Y;
+            hx += STEP_X;
+            if (hx >= HW_) { hx -= HW_; ++hy; }
+        }
     }
     __syncthreads();
 
@@ -138,25 +154,31 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx
         const float4 sv = *(const float4*)(sbias + (long long)b * ld_sbias + c);
         add.x += sv.x; add.y += sv.y; add.z += sv.z; add.w += sv.w;
     }
+    float* yb = y + (long long)b * H * W * ldy;
+    const float* rb = res ? res + (long long)b * H * W * ldr : nullptr;
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
         const int oy = Y0 + y0 + o;
         if (oy >= H) break;
+        const unsigned pix0 = __umul24((unsigned)oy, (unsigned)W) + (unsigned)(X0 + x0);
+        unsigned offy = __umul24(pix0, (unsigned)ldy) + (unsigned)c, offr = __umul24(pix0, (unsigned)ldr) + (unsigned)c;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ox = X0 + x0 + j;
             if (ox >= W) break;
-            float* dst = y + (((long long)b * H + oy) * W + ox) * ldy + c;
+            float* dst = yb + offy;
             float4 v = make_float4(acc[o][j].x + add.x, acc[o][j].y + add.y, acc[o][j].z + add.z, acc[o][j].w + add.w);
             if (accumulate) {
                 const float4 old = *(const float4*)dst;
                 v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
             }
             if (res) {                                       // fused residual (e.g. dx = dy + conv^T(dh))
-                const float4 rv = *(const float4*)(res + (((long long)b * H + oy) * W + ox) * ldr + c);
+                const float4 rv = *(const float4*)(rb + offr);
                 v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             }
             *(float4*)dst = v;
+            offy += (unsigned)ldy;
+            offr += (unsigned)ldr;
         }
     }
 }
@@ -451,6 +473,11 @@ extern "C" int cdf_dwconv7(const float* x, int ldx, const float* w, int ldw, con
     const int Cp = (C + 3) & ~3;
     CDF_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldw % 4 == 0 && ldx >= Cp && ldy >= Cp && ldw >= Cp, "cdf_dwconv7: pitches must be multiples of 4 and >= roundup4(C)");
     CDF_REQUIRE(!bias || (C % 4 == 0), "cdf_dwconv7: bias with C %% 4 != 0 needs a padded bias (pass a padded vector and C rounded up)");
+    {   // the kernel's per-image element offsets are 24 x 24-bit products kept in 32 bits
+        const long long ldmax = ldx > ldy ? (ldx > ldr ? ldx : ldr) : (ldy > ldr ? ldy : ldr);
+        CDF_REQUIRE((long long)H * W < (1 << 24) && ldmax < (1 << 24) && (long long)H * W * ldmax < (1LL << 30),
+                    "cdf_dwconv7: image of %d x %d pixels at pitch %lld is beyond the kernel's 32-bit per-image offsets", H, W, ldmax);
+    }
     if (W <= 16) return launch_dwconv7<16, 16>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S);
     return launch_dwconv7<32, 8>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S);
 }

@@ -205,6 +205,7 @@ static inline T __shfl(T v, int src, int width = 64) {
     return hipemu::shfl_from(v, (l & ~(width - 1)) + (src & (width - 1)));
 }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return hipemu::shfl_from(v, 0); }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }    // v_mul_u32_u24: low 32 bits of a 24 x 24-bit product
 
 // ---- MFMA (fragment layouts per CDNA4 ISA; see cdna_hip_programming.md §3) ------------------
 // 32x32x2 f32: A lane l -> A[i=l&31][k=l>>5], B lane l -> B[k=l>>5][j=l&31],
