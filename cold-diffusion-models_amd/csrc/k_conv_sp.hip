@@ -61,6 +61,9 @@ extern "C" int cdf_debug_read_prof_tile(void* dst) { return (int)hipMemcpyFromSy
 #define CDF_HALO_PIPE 0  // 1: conv_igemm_halo_kernel reads the fragments of tap step s+1 under the MFMAs of step s (needs >= 4 weight stages).
                          // Measured on MI355X: 2-3 % SLOWER than the plain loop (twice the VGPRs, same matrix-pipe gaps) => off.
 #endif
+#ifndef CDF_ROWHALO_TAPROW_OUTER
+#define CDF_ROWHALO_TAPROW_OUTER 1   // row-halo kernel K loop: 1 tap row / chunk / dx, 0 chunk / tap row / dx (see the kernel)
+#endif
 #ifndef CDF_SPX_PIPE
 #define CDF_SPX_PIPE 0   // 1: half-chunk software pipeline in conv_igemm_spx_kernel (fragment reads of the next half-chunk under the
                          // current MFMAs, barrier between two MFMA groups).  Measured on MI355X: identical kernel and step times
@@ -1346,7 +1349,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
 // generic 256 x 128 kernel; at 64 pixels the halo kernel's 256-pixel tile stays ahead (0.240 vs 0.252 ms).  Used for the > 64-channel
 // outputs at 128-pixel width (bits 32 / 64 of cdf_conv_gemm_bf16x_halo).
 // ================================================================================================
-template <int W, int BN, int NS = 3>
+template <int W, int BN, int NS = 3, int NCH = 0>
 __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
     constexpr int BM = 256, WM = 4, WN = 2, NW = 8, BK = 32, RE = 32, MT = BM / WM / 32, NB = 4;
     constexpr int TH = BM / W, HW2 = W + 2, RH = TH * HW2;                 // rows of one (chunk, dy) image
@@ -1395,9 +1398,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
     }
     const int nchunks = a.Cin / BK;
 
-    auto fetch_a = [&](int c, int g, int buf) {              // rows of (chunk c, tap row g) -> buffer buf: all of this wave's segments
-        if (c >= nchunks) { c = nchunks - 1; g = 2; }        // past the end: the last group again, into the idle buffer
-        const int dy = ph.dy[3 * g];
+    auto fetch_a = [&](int c, int dy, int buf) {             // rows of (chunk c, tap row with offset dy) -> buffer buf: all of this wave's segments
 #pragma unroll
         for (int q = 0; q < TAG; ++q) {
             const int y = y0 + a_ry[q] + dy;
@@ -1408,9 +1409,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
             if constexpr (NS == 3) CDF_GLDS16_K(ok ? a.x_lo + off : a.zero, seg + PLANE_A);
         }
     };
-    auto fetch_b = [&](int c, int t, int stage) {
-        if (c >= nchunks) c = nchunks - 1;
-        const int wi = ph.wi[t];
+    auto fetch_b = [&](int c, int wi, int stage) {           // weights of (chunk c, tap with weight index wi)
         unsigned short* st = bst0 + stage * BSTAGE;
 #pragma unroll
         for (int p = 0; p < SBI; ++p) {
@@ -1442,9 +1441,9 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
     const int swb = (l31 >> 2) & 3;
 
     // ---- prologue: rows of (chunk 0, tap row 0), weights of steps 0 .. 2
-    fetch_a(0, 0, 0);
+    fetch_a(0, ph.dy[0], 0);
 #pragma unroll
-    for (int u = 0; u < NB - 1; ++u) fetch_b(0, u, u);
+    for (int u = 0; u < NB - 1; ++u) fetch_b(0, ph.wi[u], u);
     CDF_WAIT_DMA_LEAVE((NB - 2) * PB);
     CDF_LDS_BARRIER();
     const unsigned long long pt1 = CDF_PROF_T();
@@ -1468,6 +1467,88 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
 #if CDF_PROFILE
     unsigned long long qt[6] = {0, 0, 0, 0, 0, 0};            // shader clocks in: DMA issue, fragment reads (until landed), MFMAs, DMA wait, barrier; steps
 #endif
+    static_assert(NB == 4, "the weights of a step are requested exactly one tap-row group (3 steps) ahead");
+    if constexpr (NCH > 0) {
+    // K loop with a compile-time chunk count, fully unrolled: tap row, chunk, dx -- the chunks of one tap row in consecutive groups.  A
+    // 32-channel chunk is 64 bytes of a pixel, half a 128-byte line, and a half-line request costs the whole line
+    // (profiles/round3_fetch_half_lines.md): with the chunk loop outermost the second half of a line is asked for nine tap steps after
+    // the first and mostly comes over the fabric again.  (Rolled loops in this order made hipcc keep the per-tap-row addresses live
+    // across the chunk loop: 24-82 VGPR spills.)
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int i3 = 0; i3 < 3; ++i3) {
+                const int t = 3 * g + i3;
+#if CDF_PROFILE
+                const unsigned long long q0 = __builtin_readcyclecounter();
+#endif
+                // the group one ahead: (g, c + 1), or (g + 1, 0) after the last chunk; past the end the last group again (idle buffer / stage)
+                const bool lastc = c + 1 == NCH;
+                const int nc = lastc ? (g < 2 ? 0 : c) : c + 1, ng = lastc && g < 2 ? g + 1 : g;
+                if (i3 == 0) fetch_a(nc, ph.dy[3 * ng], par ^ 1);
+                fetch_b(nc, ph.wi[3 * ng + i3], rd == 0 ? NB - 1 : rd - 1);
+#if CDF_PROFILE
+                const unsigned long long q1 = __builtin_readcyclecounter();
+#endif
+                const unsigned short* sa = abuf0 + par * ABUF;
+                const unsigned short* sb = bst0 + rd * BSTAGE;
+                rd = rd + 1 == NB ? 0 : rd + 1;
+                const int dx = ph.dx[t];
+                auto read_frags = [&]() {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) {
+                            const int row = row0[i] + dx;
+                            const int off = row * RE + ((ks * 2 + half) ^ ((row >> 2) & 3)) * 8;
+                            ah[ks][i] = *(const bf16x8_v*)(sa + off);
+                            if constexpr (NS == 3) al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
+                        }
+                        const int kc = ((ks * 2 + half) ^ swb) * 8;
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            const int offb = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
+                            bh[ks][j] = *(const bf16x8_v*)(sb + offb);
+                            if constexpr (NS == 3) bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + offb);
+                        }
+                    }
+                };
+                if (late) {                                      // de-phased waves: see conv_igemm_halo_kernel
+                    mma_frags();
+                    CDF_SCHED_FENCE();                           // (the reads overwrite the fragments just multiplied: hoisting them doubles the live set)
+                }
+                read_frags();
+#if CDF_PROFILE
+                CDF_WAIT_LDS();
+                const unsigned long long q2 = __builtin_readcyclecounter();
+#endif
+                if (!late) mma_frags();
+#if CDF_PROFILE
+                asm volatile("s_nop 0" ::"v"(acc[0][0][0]));          // (the last MFMA result is due here)
+                const unsigned long long q3 = __builtin_readcyclecounter();
+#endif
+                // the weights of step + 1 (requested 2 steps ago, AFTER that step's row requests) have landed; still in flight: the
+                // requests of the last two steps -- two weight steps, plus one group of rows if one of them was a group's first step
+                if (i3 <= 1)
+                    CDF_WAIT_DMA_LEAVE((NB - 2) * PB + PAG);
+                else
+                    CDF_WAIT_DMA_LEAVE((NB - 2) * PB);
+#if CDF_PROFILE
+                const unsigned long long q4 = __builtin_readcyclecounter();
+#endif
+                CDF_LDS_BARRIER();
+#if CDF_PROFILE
+                // (late waves multiply between q1 and q2: their "fragment reads" column contains their MFMAs)
+                const unsigned long long q5 = __builtin_readcyclecounter();
+                qt[0] += q1 - q0; qt[1] += q2 - q1; qt[2] += q3 - q2; qt[3] += q4 - q3; qt[4] += q5 - q4; ++qt[5];
+#endif
+                if (i3 == 2) par ^= 1;
+            }
+        }
+    }
+    } else {
     for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -1475,8 +1556,14 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
 #if CDF_PROFILE
             const unsigned long long q0 = __builtin_readcyclecounter();
 #endif
-            if (i3 == 0) fetch_a(g == 2 ? c + 1 : c, g == 2 ? 0 : g + 1, par ^ 1);      // the next tap row's input rows
-            fetch_b(t + NB - 1 < 9 ? c : c + 1, (t + NB - 1) % 9, rd == 0 ? NB - 1 : rd - 1);
+            if (i3 == 0) {                                   // the next tap row's input rows (past the end: the last group again, into the idle buffer)
+                const bool end = g == 2 && c + 1 >= nchunks;
+                fetch_a(g == 2 && !end ? c + 1 : c, ph.dy[3 * (g == 2 ? (end ? 2 : 0) : g + 1)], par ^ 1);
+            }
+            {
+                const int cw = t + NB - 1 < 9 ? c : c + 1;
+                fetch_b(cw < nchunks ? cw : nchunks - 1, ph.wi[(t + NB - 1) % 9], rd == 0 ? NB - 1 : rd - 1);
+            }
 #if CDF_PROFILE
             const unsigned long long q1 = __builtin_readcyclecounter();
 #endif
@@ -1534,6 +1621,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
 #endif
             if (i3 == 2) par ^= 1;
         }
+    }
     }
     if (late) mma_frags();
     CDF_WAIT_DMA_LEAVE(0);
@@ -2559,12 +2647,18 @@ static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s) {
 #ifndef CDF_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_kernel<W, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_kernel<W, BN, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_kernel<W, BN, NS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
 #endif
     const int tiles = (M / 256) * cdf_cdiv(a.Cout, BN);
-    CDF_LAUNCH((conv_igemm_rowhalo_kernel<W, BN, NS>), dim3(tiles), dim3(512), lds, s, a);
+    // two channel chunks (64 input channels: a pixel is ONE 128-byte line per plane): the unrolled tap-row-outermost K loop, 64 -> 128
+    // at 128 x 128 0.294 -> 0.283 ms (GELU epilogue 0.332 -> 0.326); with four chunks (128 channels) it measured +-0.5 %: not instantiated
+    if (CDF_ROWHALO_TAPROW_OUTER && a.Cin == 64)
+        CDF_LAUNCH((conv_igemm_rowhalo_kernel<W, BN, NS, 2>), dim3(tiles), dim3(512), lds, s, a);
+    else
+        CDF_LAUNCH((conv_igemm_rowhalo_kernel<W, BN, NS, 0>), dim3(tiles), dim3(512), lds, s, a);
     return cdf_check_launch("conv_igemm_rowhalo");
 }
 
