@@ -56,6 +56,12 @@ __device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph
     const int qhw = a.QH * a.QW;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) cdf_ld4(bv, a.bias + co, nval, vec);
+    // Element offsets of the row in the five tensors the epilogue may touch, carried from row to row: the pixel index moves by a small
+    // step (RPS for the kernels whose tile pixels are a contiguous range), so offset += step * pitch is one 32 x 32 -> 64-bit multiply-add
+    // (or, with a constant step, a loop-invariant the compiler hoists) instead of a 64 x 32-bit product per tensor and row -- the GELU /
+    // residual epilogues of the short-K layers are VALU-bound and these products were a third of their vector work.
+    long long prev = 0, o_pre = co, o_mul = co, o_res = co, o_y = co, o_ys = co;
+    bool first = true;
     for (int p = tid / TPR; p < RP; p += RPS) {
         const int m = m_base + rowmap(p);
         if (m >= M) continue;
@@ -71,6 +77,15 @@ __device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph
             opix = ((long long)b * a.OH + qy * a.os + ph.oy) * a.OW + qx * a.os + ph.ox;
         }
         opix += pix_off;
+        if (first) {
+            o_pre += opix * a.ldp; o_mul += opix * a.ldm; o_res += opix * a.ldr; o_y += opix * a.ldy; o_ys += opix * a.ld_ys;
+            first = false;
+        } else {
+            const int d = (int)(opix - prev);
+            o_pre += (long long)d * a.ldp; o_mul += (long long)d * a.ldm; o_res += (long long)d * a.ldr; o_y += (long long)d * a.ldy;
+            o_ys += (long long)d * a.ld_ys;
+        }
+        prev = opix;
         const float4 t = *(const float4*)(cs + p * CP + c4);
         float v[4] = {t.x + bv[0], t.y + bv[1], t.z + bv[2], t.w + bv[3]};
         float u[4];
@@ -79,7 +94,7 @@ __device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += u[e];
         }
-        if (a.pre) cdf_st4(a.pre + opix * a.ldp + co, v, nval, vec);
+        if (a.pre) cdf_st4(a.pre + o_pre, v, nval, vec);
         if (a.act == 1) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = cdf_gelu(v[e]);
@@ -91,17 +106,17 @@ __device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f); // relu
         }
         if (a.mul_mode) {
-            cdf_ld4(u, a.mul + opix * a.ldm + co, nval, vec);
+            cdf_ld4(u, a.mul + o_mul, nval, vec);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= (a.mul_mode == 1 ? cdf_gelu_grad(u[e]) : (a.mul_mode == 2 ? cdf_silu_grad(u[e]) : u[e]));
         }
         if (a.res) {
-            cdf_ld4(u, a.res + opix * a.ldr + co, nval, vec);
+            cdf_ld4(u, a.res + o_res, nval, vec);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += u[e];
         }
         if (Y) {                                             // (null: only the split planes below are wanted)
-            float* dst = Y + opix * a.ldy + co;
+            float* dst = Y + o_y;
             if (a.accumulate) {
                 cdf_ld4(u, dst, nval, vec);
 #pragma unroll
@@ -110,6 +125,6 @@ __device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph
             cdf_st4(dst, v, nval, vec);
         }
         if (a.ys_hi && vec)                                  // the consumer GEMMs' bf16 hi / lo planes of the same values
-            cdf_split_store4(a.ys_hi + opix * a.ld_ys + co, a.ys_lo ? a.ys_lo + opix * a.ld_ys + co : nullptr, v);
+            cdf_split_store4(a.ys_hi + o_ys, a.ys_lo ? a.ys_lo + o_ys : nullptr, v);
     }
 }
