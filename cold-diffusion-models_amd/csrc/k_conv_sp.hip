@@ -1644,6 +1644,234 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
 #endif
 }
 
+// ================================================================================================
+// The row-halo kernel as ONE operand stream over all the tiles of a CU (round 3).
+//
+// Per 256-pixel tile of a short-K layer (64 -> 128 at 128 x 128: 18 tap steps) the kernel above spends ~24 us in its K loop, ~7 us
+// before it (until the first rows and weights have arrived -- every CU starts its next tile at the same moment) and ~8 us after it
+// (epilogue until the stores are acknowledged), one block per CU, nothing overlapped.  Here a block is resident and walks its tiles
+// (tile j of block b = the XCD-aware index of b + j gridDim.x), and the operand pipeline simply runs on across the tile boundary:
+// with THREE weight stages a tile's 9 NCH steps are a whole number of stage rotations and (NCH even) of row-buffer alternations, so
+// the requests the single-tile kernel wastes at the end of its loop (the "group after the last", the "steps after the last") ARE the
+// next tile's first rows and weights, landing in row buffer 0 and weight stages 0, 1 while the epilogue runs.  The epilogue goes in two
+// passes of 128 rows through a staging tile that aliases only what is idle then -- row buffer 1, weight stage 2 and the tail of the LDS:
+//     LDS:  rows 0 | weights 0 | weights 1 | rows 1 | weights 2 | ...        staging [128][BN + 8] floats from "rows 1" on
+// K loop: tap row, chunk, dx (fully unrolled, see above); 8 waves (4 x 2 of 64 x 64), late waves de-phased as in the other kernels.
+// ================================================================================================
+template <int W, int BN, int NS = 3, int NCH = 2>
+__global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_stream_kernel(SpxArgs a) {
+    constexpr int BM = 256, WM = 4, WN = 2, NW = 8, BK = 32, RE = 32, MT = BM / WM / 32, NB = 3;
+    static_assert(NCH % 2 == 0, "an even number of tap-row groups per tile returns the pipeline to row buffer 0");
+    constexpr int TH = BM / W, HW2 = W + 2, RH = TH * HW2;
+    constexpr int NSEG = (RH + 15) / 16, HRP = NSEG * 16;
+    constexpr int TAG = (NSEG + NW - 1) / NW;
+    constexpr int NT = BN / WN / 32;
+    constexpr int SB = BN / 16 / NW;
+    static_assert(SB * NW * 16 == BN || BN == 64, "B tile must split into 16-row segments");
+    constexpr int SBI = BN == 64 ? 1 : SB;
+    constexpr int PLANE_A = HRP * RE, ABUF = 2 * PLANE_A;
+    constexpr int PLANE_B = BN * RE, BSTAGE = 2 * PLANE_B;
+    constexpr int OFF_A1 = ABUF + 2 * BSTAGE, OFF_B2 = OFF_A1 + ABUF;          // (elements) rows 0 | weights 0 | weights 1 | rows 1 | weights 2
+    CDF_DYN_SMEM(smem_raw);
+    unsigned short* smem = (unsigned short*)smem_raw;
+    float* const cs = (float*)(smem + OFF_A1);                                   // epilogue staging: rows 1, weights 2 and the tail are idle then
+    constexpr int CP = BN + 8;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int M = a.B * a.QH * a.QW;
+    const int tiles_n = (a.Cout + BN - 1) / BN, tiles_m = M / BM, ntiles = tiles_m * tiles_n;
+    const SpPhase& ph = a.ph[0];
+    const int tpi = a.H / TH;
+
+    const int srow = lane >> 2;
+    const int q8 = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+    int a_seg[TAG], a_ry[TAG], a_x[TAG];
+#pragma unroll
+    for (int q = 0; q < TAG; ++q) {
+        int g = wave + NW * q;
+        if (g >= NSEG) g -= (g / NSEG) * NSEG;
+        a_seg[q] = g;
+        const int r = g * 16 + srow;
+        a_ry[q] = r < RH ? r / HW2 : -(1 << 20);
+        a_x[q] = r - (r / HW2) * HW2 - 1;
+    }
+    // rows of (tile position (img, y0), chunk c, tap row offset dy) -> row buffer buf; img < 0: no such tile, zero page
+    auto fetch_a = [&](int img, int y0, int c, int dy, int buf) {
+        unsigned short* base = smem + (buf ? OFF_A1 : 0);
+#pragma unroll
+        for (int q = 0; q < TAG; ++q) {
+            const int y = y0 + a_ry[q] + dy;
+            const bool ok = img >= 0 && (unsigned)y < (unsigned)a.H && (unsigned)a_x[q] < (unsigned)W;
+            const size_t off = ((size_t)(((ok ? img : 0) * a.H + (ok ? y : 0)) * W + (ok ? a_x[q] : 0))) * (unsigned)a.ldx + (unsigned)(c * BK + q8);
+            unsigned short* seg = base + a_seg[q] * 16 * RE;
+            CDF_GLDS16_K(ok ? a.x_hi + off : a.zero, seg);
+            if constexpr (NS == 3) CDF_GLDS16_K(ok ? a.x_lo + off : a.zero, seg + PLANE_A);
+        }
+    };
+    auto fetch_b = [&](int tile_n, int c, int wi, int stage) {       // weights of (N tile, chunk c, tap with weight index wi) -> stage
+        unsigned short* st = smem + (stage == 2 ? OFF_B2 : ABUF + stage * BSTAGE);
+#pragma unroll
+        for (int p = 0; p < SBI; ++p) {
+            const int seg = BN == 64 ? (wave & 3) : wave * SB + p;
+            const int n = tile_n * BN + seg * 16 + srow;
+            const int brow = n < a.Cout ? n : a.Cout - 1;
+            const size_t woff = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)brow) * (unsigned)a.ldk + (unsigned)(c * BK + q8);
+            CDF_GLDS16_K(a.w_hi + woff, st + seg * 16 * RE);
+            if constexpr (NS == 3) CDF_GLDS16_K(a.w_lo + woff, st + PLANE_B + seg * 16 * RE);
+        }
+    };
+    constexpr int NPL = NS == 3 ? 2 : 1;
+    constexpr int PB = NPL * SBI, PAG = NPL * TAG;           // DMA instructions per wave: one weight step, one group of rows
+
+    const int half = lane >> 5, l31 = lane & 31;
+    int row0[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int pix = wm * (BM / WM) + i * 32 + l31;
+        const int py = pix / W, px = pix - py * W;
+        row0[i] = py * HW2 + px + 1;
+    }
+    const int swb = (l31 >> 2) & 3;
+    const bool late = a.dephase != 0 && wave >= NW / 2;      // (wave-uniform)
+
+    auto tile_pos = [&](int v, int& img, int& y0, int& tn, int& tm) {    // virtual block id -> tile (img < 0: past the last tile)
+        if (v < ntiles) {
+            const int tile = cdf_sp_swizzle(v, ntiles);
+            tm = tile / tiles_n;
+            tn = tile - tm * tiles_n;
+            img = tm / tpi;
+            y0 = (tm - img * tpi) * TH;
+        } else {
+            img = -1; y0 = 0; tn = 0; tm = 0;
+        }
+    };
+    int img, y0, tile_n, tile_m;
+    int v = blockIdx.x;
+    tile_pos(v, img, y0, tile_n, tile_m);
+    // ---- pipeline fill: rows of (chunk 0, tap row 0), weights of steps 0, 1 of the first tile
+    fetch_a(img, y0, 0, ph.dy[0], 0);
+    fetch_b(tile_n, 0, ph.wi[0], 0);
+    fetch_b(tile_n, 0, ph.wi[1], 1);
+    CDF_WAIT_DMA_LEAVE(PB);                                  // rows and the weights of step 0 have landed
+    CDF_LDS_BARRIER();
+
+    while (img >= 0) {
+        int img_n, y0_n, tile_n_n, tile_m_n;
+        tile_pos(v + gridDim.x, img_n, y0_n, tile_n_n, tile_m_n);
+        f32x16_t acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        bf16x8_v ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+        if (late) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { ah[ks][i][e] = 0; al[ks][i][e] = 0; }
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { bh[ks][j][e] = 0; bl[ks][j][e] = 0; }
+            }
+        }
+        auto mma_frags = [&]() { cdf_mma_tile<NS, MT, NT>(acc, ah, al, bh, bl); };
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+                for (int i3 = 0; i3 < 3; ++i3) {
+                    const int t = 3 * g + i3;
+                    const int step = (g * NCH + c) * 3 + i3;                     // 0 .. 9 NCH - 1
+                    const int par = (g * NCH + c) & 1, rd = step % NB;
+                    // requests: the weights two steps ahead, then (first step of a group) the next group's rows -- past this tile's last
+                    // step / group they are the NEXT tile's first ones.  Weights first: loads complete in order, and the rows (from HBM)
+                    // are not needed before the end of the group, the weights (from L2) at the end of the next step.
+                    {
+                        const int s2 = step + 2, gc2 = (s2 / 3) % (3 * NCH);     // group of the step two ahead (wraps into the next tile)
+                        const bool over = s2 >= 9 * NCH;
+                        const int g2 = gc2 / NCH, c2 = gc2 - g2 * NCH;
+                        fetch_b(over ? tile_n_n : tile_n, c2, ph.wi[3 * g2 + s2 % 3], s2 % NB);
+                    }
+                    if (i3 == 0) {
+                        const bool lastc = c + 1 == NCH, over = lastc && g == 2;
+                        const int nc = lastc ? 0 : c + 1, ng = over ? 0 : (lastc ? g + 1 : g);
+                        fetch_a(over ? img_n : img, over ? y0_n : y0, nc, ph.dy[3 * ng], par ^ 1);
+                    }
+                    // (the buffer bases as opaque scalars: as constants beyond the 64 KB reach of a ds_read immediate they made hipcc keep one
+                    //  precomputed fragment address per (buffer, dx, fragment) live across the whole tile loop -- 58 VGPRs spilled)
+                    int sa_e = par ? OFF_A1 : 0, sb_e = rd == 2 ? OFF_B2 : ABUF + rd * BSTAGE;
+#ifndef CDF_EMU
+                    asm volatile("" : "+s"(sa_e), "+s"(sb_e));
+#endif
+                    const unsigned short* sa = smem + sa_e;
+                    const unsigned short* sb = smem + sb_e;
+                    const int dx = ph.dx[t];
+                    auto read_frags = [&]() {
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                            for (int i = 0; i < MT; ++i) {
+                                const int row = row0[i] + dx;
+                                const int off = row * RE + ((ks * 2 + half) ^ ((row >> 2) & 3)) * 8;
+                                ah[ks][i] = *(const bf16x8_v*)(sa + off);
+                                if constexpr (NS == 3) al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
+                            }
+                            const int kc = ((ks * 2 + half) ^ swb) * 8;
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) {
+                                const int offb = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
+                                bh[ks][j] = *(const bf16x8_v*)(sb + offb);
+                                if constexpr (NS == 3) bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + offb);
+                            }
+                        }
+                    };
+                    if (late) {
+                        mma_frags();
+                        CDF_SCHED_FENCE();
+                    }
+                    read_frags();
+                    if (!late) mma_frags();
+                    // the weights of step + 1 have landed (requested one step ago, before that step's row request); may still be in
+                    // flight: this step's weights and the rows requested in this group's first step -- those only at the group's end not
+                    if (i3 <= 1)
+                        CDF_WAIT_DMA_LEAVE(PB + PAG);
+                    else
+                        CDF_WAIT_DMA_LEAVE(PB);
+                    CDF_LDS_BARRIER();
+                }
+            }
+        }
+        if (late) mma_frags();
+        // (the last barrier of the loop: every wave is done with this tile's rows and weights; in flight / landed: the next tile's
+        // rows 0 and weights 0, 1 -- none of them under the staging tile)
+#pragma unroll 1
+        for (int hp = 0; hp < 2; ++hp) {
+            if ((wm >> 1) == hp) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            cs[((wm & 1) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * (BN / WN) + j * 32 + l31] = acc[i][j][r];
+            }
+            CDF_LDS_BARRIER();                                   // (LDS traffic only: the stores of the previous pass keep draining)
+            cdf_epilogue_rows<BN, 128, 512>(a, ph, a.y, cs, tile_m * BM + hp * 128, tile_n * BN, M, tid, [](int p) { return p; });
+            CDF_LDS_BARRIER();
+        }
+        img = img_n; y0 = y0_n; tile_n = tile_n_n; tile_m = tile_m_n;
+        v += gridDim.x;
+    }
+    CDF_WAIT_DMA_LEAVE(0);                                   // (the requests past the last tile fetched the zero page / weights: let them land)
+}
+
 // weight gradient with both operands pre-split ([pixels][ld] bf16 hi / lo planes)
 struct SpxWgradArgs {
     const unsigned short* a_hi;
@@ -2570,7 +2798,7 @@ static int fill_phases(SpPhase* ph, int nphase, const int* pd, const char* who) 
 // ---- tuning: an explicit, optional argument of the GEMM entry points (include/colddiff.h: cdf_gemm_tuning) -----------------------------
 // No mutable process-wide state: a NULL pointer means these defaults, anything else is read once per call.  The choices only select
 // between kernels / tile shapes that compute the same sums (fp32 summation order aside).
-static const cdf_gemm_tuning kTuneDefault = {(int)sizeof(cdf_gemm_tuning), 0, 0, 0, 1, 1, 0, 47, 1, 0, 1, 1, 1, 1};
+static const cdf_gemm_tuning kTuneDefault = {(int)sizeof(cdf_gemm_tuning), 0, 0, 0, 1, 1, 0, 47, 1, 0, 1, 1, 1, 1, 1};
 extern "C" int cdf_gemm_tuning_default(cdf_gemm_tuning* t) {
     CDF_REQUIRE(t, "cdf_gemm_tuning_default: null pointer");
     *t = kTuneDefault;
@@ -2637,8 +2865,22 @@ static int launch_igemm_halo(const SpxArgs& a, int M, hipStream_t s) {
     return cdf_check_launch("conv_igemm_halo");
 }
 
+static int cdf_num_cus() {                                     // CUs of the current device (blocks of the resident kernels), a multiple of 8 XCDs
+#ifdef CDF_EMU
+    return 8;
+#else
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount >= 8) ? p.multiProcessorCount / 8 * 8 : 256;
+    }
+    return n;
+#endif
+}
+
 template <int NS, int W, int BN>
-static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s) {
+static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s, bool stream_tiles = false) {
     constexpr int TH = 256 / W, RH = TH * (W + 2), HRP = (RH + 15) / 16 * 16;
     constexpr size_t stages = (size_t)2 * 2 * HRP * 64 + (size_t)4 * 2 * BN * 64;
     constexpr size_t epi = (size_t)256 * (BN + 8) * sizeof(float);
@@ -2653,6 +2895,25 @@ static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s) {
     }
 #endif
     const int tiles = (M / 256) * cdf_cdiv(a.Cout, BN);
+    if (stream_tiles && (a.Cin == 64 || a.Cin == 128)) {       // resident blocks, one operand stream over all the tiles of a CU
+        constexpr size_t st_a = (size_t)2 * HRP * 64, st_b = (size_t)2 * BN * 64;
+        constexpr size_t lds_s = (st_a + 2 * st_b) + ((st_a + st_b) > (size_t)128 * (BN + 8) * 4 ? (st_a + st_b) : (size_t)128 * (BN + 8) * 4);
+        static_assert(lds_s <= 160 * 1024, "streaming row-halo tile does not fit the LDS");
+#ifndef CDF_EMU
+        static bool attr2_done = false;
+        if (!attr2_done) {
+            (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_stream_kernel<W, BN, NS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_stream_kernel<W, BN, NS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr2_done = true;
+        }
+#endif
+        const int ncu = cdf_num_cus(), grid = tiles < ncu ? tiles : ncu;
+        if (a.Cin == 64)
+            CDF_LAUNCH((conv_igemm_rowhalo_stream_kernel<W, BN, NS, 2>), dim3(grid), dim3(512), lds_s, s, a);
+        else
+            CDF_LAUNCH((conv_igemm_rowhalo_stream_kernel<W, BN, NS, 4>), dim3(grid), dim3(512), lds_s, s, a);
+        return cdf_check_launch("conv_igemm_rowhalo_stream");
+    }
     // two channel chunks (64 input channels: a pixel is ONE 128-byte line per plane): the unrolled tap-row-outermost K loop, 64 -> 128
     // at 128 x 128 0.294 -> 0.283 ms (GELU epilogue 0.332 -> 0.326); with four chunks (128 channels) it measured +-0.5 %: not instantiated
     if (CDF_ROWHALO_TAPROW_OUTER && a.Cin == 64)
@@ -2723,7 +2984,7 @@ static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cou
         if (dx_ok && M % 256 == 0 && ((T.halo & 64) || ((T.halo & 32) && W == 128 && !n64 && (long long)(M / 256) * cdf_cdiv(Cout, 128) >= 256))) {
 #define CDF_ROWHALO_CASE(WW)                                                                                           \
     if (W == WW && H % (256 / WW) == 0)                                                                                \
-        return n64 ? launch_igemm_rowhalo<NS, WW, 64>(a, M, s) : launch_igemm_rowhalo<NS, WW, 128>(a, M, s);
+        return n64 ? launch_igemm_rowhalo<NS, WW, 64>(a, M, s, T.rowhalo_stream != 0) : launch_igemm_rowhalo<NS, WW, 128>(a, M, s, T.rowhalo_stream != 0);
             CDF_ROWHALO_CASE(128) CDF_ROWHALO_CASE(64) CDF_ROWHALO_CASE(32) CDF_ROWHALO_CASE(16)
 #undef CDF_ROWHALO_CASE
         }
