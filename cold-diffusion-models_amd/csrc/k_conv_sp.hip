@@ -2841,6 +2841,20 @@ static int launch_igemm_spx(const SpxArgs& a, int M, hipStream_t s) {
     return cdf_check_launch("conv_igemm_spx");
 }
 
+static int cdf_num_cus() {                                     // CUs of the current device (blocks of the resident kernels), a multiple of 8 XCDs
+#ifdef CDF_EMU
+    return 8;
+#else
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount >= 8) ? p.multiProcessorCount / 8 * 8 : 256;
+    }
+    return n;
+#endif
+}
+
 template <int NS, int W, int BN, int BM>
 static int launch_igemm_halo(const SpxArgs& a, int M, hipStream_t s) {
     // weight stages: as many as fit next to the two halo buffers
@@ -2863,20 +2877,6 @@ static int launch_igemm_halo(const SpxArgs& a, int M, hipStream_t s) {
     const int tiles = (M / BM) * cdf_cdiv(a.Cout, BN);
     CDF_LAUNCH((conv_igemm_halo_kernel<W, BN, NB, BM, NS>), dim3(tiles), dim3(512), lds, s, a);
     return cdf_check_launch("conv_igemm_halo");
-}
-
-static int cdf_num_cus() {                                     // CUs of the current device (blocks of the resident kernels), a multiple of 8 XCDs
-#ifdef CDF_EMU
-    return 8;
-#else
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount >= 8) ? p.multiProcessorCount / 8 * 8 : 256;
-    }
-    return n;
-#endif
 }
 
 template <int NS, int W, int BN>
