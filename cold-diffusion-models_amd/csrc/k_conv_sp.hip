@@ -2798,7 +2798,7 @@ static int fill_phases(SpPhase* ph, int nphase, const int* pd, const char* who) 
 // ---- tuning: an explicit, optional argument of the GEMM entry points (include/colddiff.h: cdf_gemm_tuning) -----------------------------
 // No mutable process-wide state: a NULL pointer means these defaults, anything else is read once per call.  The choices only select
 // between kernels / tile shapes that compute the same sums (fp32 summation order aside).
-static const cdf_gemm_tuning kTuneDefault = {(int)sizeof(cdf_gemm_tuning), 0, 0, 0, 1, 1, 0, 47, 1, 0, 1, 1, 1, 1, 1};
+static const cdf_gemm_tuning kTuneDefault = {(int)sizeof(cdf_gemm_tuning), 0, 0, 0, 1, 1, 1, 47, 1, 0, 1, 1, 1, 1, 1};
 extern "C" int cdf_gemm_tuning_default(cdf_gemm_tuning* t) {
     CDF_REQUIRE(t, "cdf_gemm_tuning_default: null pointer");
     *t = kTuneDefault;

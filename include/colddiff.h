@@ -165,7 +165,8 @@ typedef struct cdf_gemm_tuning {
     int max_bm;          /* 0: none; 128: the automatic choice never takes the 256 x 128 tile */
     int dephase;         /* 1: waves 4..7 of the 8-wave tiles multiply the previous K step's fragments first, read afterwards */
     int deep;            /* 1: grids of <= 256 64-row tiles run with six DMA stages, one block per CU */
-    int splitk;          /* 0; 1: ... and share the taps out over block groups when a workspace is given (measured +-1 %) */
+    int splitk;          /* 1: ... and share the taps out over block groups when a workspace is given (the 4 x 4 / 8 x 8 levels of the 32 x 32
+                            configurations: MNIST config +8..16 %, CIFAR-10 config +2.5 %; nothing at 128 x 128); 0: never */
     int halo;            /* 47: bit mask of the LDS-resident-input kernel over the image width 16 (1), 32 (2), 64 (4), 128 (8); 16 = at
                             width 128 also for > 64 output channels; 32 = row-halo form (256-pixel tiles, input shared by the dx taps of
                             a row) for the > 64-channel outputs at width 128; 64 = row-halo form wherever it applies; 0 = never */
@@ -193,8 +194,8 @@ int cdf_split_bf16(const float* x, int ldx, void* hi, void* lo, int ldo, long lo
 /* ws / ws_floats (nullable): workspace for split-K launches.  A grid far below one tile per CU (M = B*QH*QW of a few hundred pixels: the
  * 4 x 4 / 8 x 8 levels of the 32 x 32 configurations) shares the taps out over ks = cdf_conv_gemm_bf16x_ksplit(M, Cout, nphase, ntaps of
  * phase 0) block groups whose partial sums go through ws (>= ks * M * roundup4(Cout) floats, 16-byte aligned) and a finish kernel that
- * runs the epilogue; without a (large enough) workspace, or when the query returns 1 (always, unless tune->splitk is set: the
- * split is off by default), the launch is the plain one.  The library never allocates. */
+ * runs the epilogue; without a (large enough) workspace, or when the query returns 1 (always with tune->splitk = 0), the launch is the
+ * plain one.  The library never allocates. */
 int cdf_conv_gemm_bf16x_ksplit(int M, int Cout, int nphase, int ntaps, const cdf_gemm_tuning* tune);
 int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo, int ldk,
                         float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW, int os, int is,

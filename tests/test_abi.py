@@ -108,7 +108,7 @@ def test_argument_checks_of_the_gemm_and_blend_entry_points():
     # the optional tuning argument is validated: a struct of the wrong size (another header version) or with impossible tiles is refused;
     # the library has no setters and no tuning state of its own
     tune = _lib.GemmTuning(lib)
-    assert tune.get("halo") == 47 and tune.get("dephase") == 1 and tune.get("splitk") == 0 and tune.get("small_n64") == 1
+    assert tune.get("halo") == 47 and tune.get("dephase") == 1 and tune.get("splitk") == 1 and tune.get("small_n64") == 1
     bad = list(gemm); bad[-2] = tune.set(tile_bm=96).ptr
     expect(lib.cdf_conv_gemm_bf16x, bad, "bad cdf_gemm_tuning")
     bad = list(gemm); bad[-2] = tune.set(tile_bm=0, size=8).ptr

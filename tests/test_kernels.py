@@ -808,7 +808,6 @@ def _spx_case(be, B, Cin, Cout, H, k, s, p):
         # small grids: the same launch with a split-K workspace (taps shared out over block groups + finish kernel)
         Mq = B * pl.QH * pl.QW
         try:
-            be.tune.set(splitk=1)                             # (off by default)
             ks = be.L.cdf_conv_gemm_bf16x_ksplit(Mq, Co, pl.nphase, pl.desc[2], be.tune.ptr)
             if ks > 1:
                 ws = be.empty(ks * Mq * r4(Co))
@@ -819,7 +818,7 @@ def _spx_case(be, B, Cin, Cout, H, k, s, p):
                 assert err(y_ws[..., :Co], y[..., :Co].cpu()) <= 2e-6 * max(1.0, y.abs().max().item()) * math.sqrt(ks)
                 return y_ws
         finally:
-            be.tune.set(splitk=0)
+            pass
         return y
 
     y = run(plan, xs, wf, Cin, Cout, be.to(bias))

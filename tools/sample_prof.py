@@ -58,7 +58,7 @@ def main():
     variants = [("default", lambda: None, lambda: None),
                 ("small_n64=0 (128-wide N tiles on small grids)", lambda: TUNE.set(small_n64=0), lambda: TUNE.set(small_n64=1)),
                 ("time-bias linears one by one", lambda: tba(False), lambda: tba(True)),
-                ("splitk=1", lambda: TUNE.set(splitk=1), lambda: TUNE.set(splitk=0)),
+                ("splitk=0", lambda: TUNE.set(splitk=0), lambda: TUNE.set(splitk=1)),
                 ("halo_bm=128", lambda: TUNE.set(halo_bm=128), lambda: TUNE.set(halo_bm=0)),
                 ("max_bm=128", lambda: TUNE.set(max_bm=128), lambda: TUNE.set(max_bm=0)),
                 ("deep=0", lambda: TUNE.set(deep=0), lambda: TUNE.set(deep=1)),
