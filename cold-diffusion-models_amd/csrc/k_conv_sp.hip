@@ -1658,10 +1658,15 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
 //     LDS:  rows 0 | weights 0 | weights 1 | rows 1 | weights 2 | ...        staging [128][BN + 8] floats from "rows 1" on
 // K loop: tap row, chunk, dx (fully unrolled, see above); 8 waves (4 x 2 of 64 x 64), late waves de-phased as in the other kernels.
 // ================================================================================================
-template <int W, int BN, int NS = 3, int NCH = 2>
+// BM = 512 (with BN = 64, at 128-pixel width): the 64-channel outputs.  Their 256 x 64 tiles give a wave 12 MFMAs per tap step against the same
+// barrier, DMA issue and A-fragment reads as a 256 x 128 tile's 24 -- the K loop of 128 -> 64 at 128 x 128 keeps the matrix cores 64 % busy.  512
+// pixels x 64 channels as 8 x 1 waves of 64 x 64 is the 256 x 128 tile's per-wave work again (row buffers of 4 image rows; staging in two passes of 256 rows).
+template <int W, int BN, int NS = 3, int NCH = 2, int BM = 256>
 __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_stream_kernel(SpxArgs a) {
-    constexpr int BM = 256, WM = 4, WN = 2, NW = 8, BK = 32, RE = 32, MT = BM / WM / 32, NB = 3;
+    constexpr int WM = BM / 64, WN = 8 / WM, NW = 8, BK = 32, RE = 32, MT = BM / WM / 32, NB = 3;
+    static_assert((BM == 256 || BM == 512) && WM * WN == 8 && MT == 2, "8 waves of 64-row tiles");
     static_assert(NCH % 2 == 0, "an even number of tap-row groups per tile returns the pipeline to row buffer 0");
+    constexpr int EROWS = BM / 2;                                                 // rows per epilogue pass
     constexpr int TH = BM / W, HW2 = W + 2, RH = TH * HW2;
     constexpr int NSEG = (RH + 15) / 16, HRP = NSEG * 16;
     constexpr int TAG = (NSEG + NW - 1) / NW;
@@ -1676,6 +1681,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_stream_kernel(SpxAr
     unsigned short* smem = (unsigned short*)smem_raw;
     float* const cs = (float*)(smem + OFF_A1);                                   // epilogue staging: rows 1, weights 2 and the tail are idle then
     constexpr int CP = BN + 8;
+    static_assert((size_t)OFF_A1 * 2 + (size_t)EROWS * CP * 4 <= 160 * 1024, "the staging tile must fit behind the live operand buffers");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -1853,17 +1859,17 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_stream_kernel(SpxAr
         // rows 0 and weights 0, 1 -- none of them under the staging tile)
 #pragma unroll 1
         for (int hp = 0; hp < 2; ++hp) {
-            if ((wm >> 1) == hp) {
+            if ((wm * 64) / EROWS == hp) {                   // this wave's 64 rows belong to pass hp
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            cs[((wm & 1) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * (BN / WN) + j * 32 + l31] = acc[i][j][r];
+                            cs[(wm * 64 - hp * EROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * (BN / WN) + j * 32 + l31] = acc[i][j][r];
             }
             CDF_LDS_BARRIER();                                   // (LDS traffic only: the stores of the previous pass keep draining)
-            cdf_epilogue_rows<BN, 128, 512>(a, ph, a.y, cs, tile_m * BM + hp * 128, tile_n * BN, M, tid, [](int p) { return p; });
+            cdf_epilogue_rows<BN, EROWS, 512>(a, ph, a.y, cs, tile_m * BM + hp * EROWS, tile_n * BN, M, tid, [](int p) { return p; });
             CDF_LDS_BARRIER();
         }
         img = img_n; y0 = y0_n; tile_n = tile_n_n; tile_m = tile_m_n;
@@ -2798,7 +2804,7 @@ static int fill_phases(SpPhase* ph, int nphase, const int* pd, const char* who) 
 // ---- tuning: an explicit, optional argument of the GEMM entry points (include/colddiff.h: cdf_gemm_tuning) -----------------------------
 // No mutable process-wide state: a NULL pointer means these defaults, anything else is read once per call.  The choices only select
 // between kernels / tile shapes that compute the same sums (fp32 summation order aside).
-static const cdf_gemm_tuning kTuneDefault = {(int)sizeof(cdf_gemm_tuning), 0, 0, 0, 1, 1, 1, 47, 1, 0, 1, 1, 1, 1, 1};
+static const cdf_gemm_tuning kTuneDefault = {(int)sizeof(cdf_gemm_tuning), 0, 0, 0, 1, 1, 1, 47, 1, 0, 1, 1, 1, 1, 3};
 extern "C" int cdf_gemm_tuning_default(cdf_gemm_tuning* t) {
     CDF_REQUIRE(t, "cdf_gemm_tuning_default: null pointer");
     *t = kTuneDefault;
@@ -2923,6 +2929,30 @@ static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s, bool str
     return cdf_check_launch("conv_igemm_rowhalo");
 }
 
+// 512-pixel x 64-channel resident tiles at 128-pixel width (conv_igemm_rowhalo_stream_kernel<.., BM = 512>): 64 / 128 input channels
+template <int NS>
+static int launch_igemm_rowhalo_stream512(const SpxArgs& a, int M, hipStream_t s) {
+    constexpr int W = 128, BN = 64, TH = 512 / W, RH = TH * (W + 2), HRP = (RH + 15) / 16 * 16;
+    constexpr size_t st_a = (size_t)2 * HRP * 64, st_b = (size_t)2 * BN * 64, off_a1 = st_a + 2 * st_b;
+    constexpr size_t cs = (size_t)256 * (BN + 8) * 4;
+    constexpr size_t lds_s = off_a1 + (st_a + st_b > cs ? st_a + st_b : cs);
+    static_assert(lds_s <= 160 * 1024, "512-pixel streaming tile does not fit the LDS");
+#ifndef CDF_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_stream_kernel<W, BN, NS, 2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_stream_kernel<W, BN, NS, 4, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+#endif
+    const int tiles = (M / 512) * cdf_cdiv(a.Cout, BN), ncu = cdf_num_cus(), grid = tiles < ncu ? tiles : ncu;
+    if (a.Cin == 64)
+        CDF_LAUNCH((conv_igemm_rowhalo_stream_kernel<W, BN, NS, 2, 512>), dim3(grid), dim3(512), lds_s, s, a);
+    else
+        CDF_LAUNCH((conv_igemm_rowhalo_stream_kernel<W, BN, NS, 4, 512>), dim3(grid), dim3(512), lds_s, s, a);
+    return cdf_check_launch("conv_igemm_rowhalo_stream512");
+}
+
 // Split-K factor of the generic pre-split GEMM for grids far below one 64-row tile per CU: the smallest divisor of the tap count
 // that brings the launch to >= 192 blocks (else the largest); 1 = no split.
 static int spx_ksplit(int M, int Cout, int nphase, int ntaps, const cdf_gemm_tuning& T) {
@@ -2981,10 +3011,14 @@ static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cou
         // row-halo kernel: 256-pixel tiles, input shared by the dx taps only.  Bit 32 (default): the > 64-channel outputs at
         // 128-pixel width, where it beats the generic 256 x 128 kernel (64 -> 128: 0.325 -> 0.298 ms); bit 64: wherever it applies
         // (at 64 pixels the halo kernel's 256-pixel tile stays ahead, 0.240 vs 0.252 ms)
+        // 64-channel outputs at 128-pixel width from 64 / 128 input channels: resident 512-pixel x 64-channel tiles (rowhalo_stream bit 2)
+        if ((T.rowhalo_stream & 2) && dx_ok && W == 128 && n64 && Cout <= 64 && (Cin == 64 || Cin == 128) && H % 4 == 0 && M % 512 == 0 &&
+            (M / 512) >= ((T.rowhalo_stream & 4) ? 1 : 256) && (T.halo & 8))
+            return launch_igemm_rowhalo_stream512<NS>(a, M, s);
         if (dx_ok && M % 256 == 0 && ((T.halo & 64) || ((T.halo & 32) && W == 128 && !n64 && (long long)(M / 256) * cdf_cdiv(Cout, 128) >= 256))) {
 #define CDF_ROWHALO_CASE(WW)                                                                                           \
     if (W == WW && H % (256 / WW) == 0)                                                                                \
-        return n64 ? launch_igemm_rowhalo<NS, WW, 64>(a, M, s, T.rowhalo_stream != 0) : launch_igemm_rowhalo<NS, WW, 128>(a, M, s, T.rowhalo_stream != 0);
+        return n64 ? launch_igemm_rowhalo<NS, WW, 64>(a, M, s, (T.rowhalo_stream & 1) != 0) : launch_igemm_rowhalo<NS, WW, 128>(a, M, s, (T.rowhalo_stream & 1) != 0);
             CDF_ROWHALO_CASE(128) CDF_ROWHALO_CASE(64) CDF_ROWHALO_CASE(32) CDF_ROWHALO_CASE(16)
 #undef CDF_ROWHALO_CASE
         }

@@ -925,7 +925,21 @@ def test_conv_presplit_rowhalo_emu(case):
             be.tune.set(rowhalo_stream=0)
             _spx_case(be, *case)
     finally:
-        be.tune.set(halo=47, halo_min_tiles=1, rowhalo_stream=1)
+        be.tune.set(halo=47, halo_min_tiles=1, rowhalo_stream=3)
+        be._keep.clear()
+
+
+def test_conv_presplit_rowhalo_512_emu():
+    """The resident row-halo form with 512-pixel x 64-channel tiles (64-channel outputs at 128-pixel width): one 128 x 128 image = 32 tiles
+    on the simulator's 8 "CUs" (4 tiles per block), 64 input channels, 40 outputs (ragged N tile); bit 4 of rowhalo_stream lifts the
+    256-tile threshold of the default dispatch.  The GPU suite runs the form at full size inside the network tests."""
+    from conftest import Backend
+    be = Backend("emu")
+    be.tune.set(rowhalo_stream=7)
+    try:
+        _spx_case(be, 1, 64, 40, 128, 3, 1, 1)
+    finally:
+        be.tune.set(rowhalo_stream=3)
         be._keep.clear()
 
 
