@@ -2804,7 +2804,7 @@ static int fill_phases(SpPhase* ph, int nphase, const int* pd, const char* who) 
 // ---- tuning: an explicit, optional argument of the GEMM entry points (include/colddiff.h: cdf_gemm_tuning) -----------------------------
 // No mutable process-wide state: a NULL pointer means these defaults, anything else is read once per call.  The choices only select
 // between kernels / tile shapes that compute the same sums (fp32 summation order aside).
-static const cdf_gemm_tuning kTuneDefault = {(int)sizeof(cdf_gemm_tuning), 0, 0, 0, 1, 1, 1, 47, 1, 0, 1, 1, 1, 1, 3};
+static const cdf_gemm_tuning kTuneDefault = {(int)sizeof(cdf_gemm_tuning), 0, 0, 0, 1, 1, 1, 47, 1, 0, 1, 1, 1, 1, 1};
 extern "C" int cdf_gemm_tuning_default(cdf_gemm_tuning* t) {
     CDF_REQUIRE(t, "cdf_gemm_tuning_default: null pointer");
     *t = kTuneDefault;
@@ -3011,7 +3011,9 @@ static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cou
         // row-halo kernel: 256-pixel tiles, input shared by the dx taps only.  Bit 32 (default): the > 64-channel outputs at
         // 128-pixel width, where it beats the generic 256 x 128 kernel (64 -> 128: 0.325 -> 0.298 ms); bit 64: wherever it applies
         // (at 64 pixels the halo kernel's 256-pixel tile stays ahead, 0.240 vs 0.252 ms)
-        // 64-channel outputs at 128-pixel width from 64 / 128 input channels: resident 512-pixel x 64-channel tiles (rowhalo_stream bit 2)
+        // 64-channel outputs at 128-pixel width from 64 / 128 input channels: resident 512-pixel x 64-channel tiles (rowhalo_stream bit 2; OFF by
+        // default: 6 % faster per launch than the LDS-resident-input kernel, but the per-tap-row input rows make it fetch 3.2x the bytes
+        // -- 1194 vs 370 MB per launch for 128 -> 64 at 128 x 128 -- and the step does not resolve the difference)
         if ((T.rowhalo_stream & 2) && dx_ok && W == 128 && n64 && Cout <= 64 && (Cin == 64 || Cin == 128) && H % 4 == 0 && M % 512 == 0 &&
             (M / 512) >= ((T.rowhalo_stream & 4) ? 1 : 256) && (T.halo & 8))
             return launch_igemm_rowhalo_stream512<NS>(a, M, s);

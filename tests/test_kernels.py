@@ -925,7 +925,7 @@ def test_conv_presplit_rowhalo_emu(case):
             be.tune.set(rowhalo_stream=0)
             _spx_case(be, *case)
     finally:
-        be.tune.set(halo=47, halo_min_tiles=1, rowhalo_stream=3)
+        be.tune.set(halo=47, halo_min_tiles=1, rowhalo_stream=1)
         be._keep.clear()
 
 
@@ -939,7 +939,7 @@ def test_conv_presplit_rowhalo_512_emu():
     try:
         _spx_case(be, 1, 64, 40, 128, 3, 1, 1)
     finally:
-        be.tune.set(rowhalo_stream=3)
+        be.tune.set(rowhalo_stream=1)
         be._keep.clear()
 
 
