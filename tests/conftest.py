@@ -13,6 +13,32 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (`-m "not gpu"`) runs the kernels on a single-threaded host simulator: ~13 minutes in one process.  When pytest-xdist is
+    there, spread it over worker processes (COLDDIFF_TEST_WORKERS=0 keeps one process; an explicit -n wins).  Never for the GPU suite: those
+    tests share one device and the harness looks at the process that loads the HIP library."""
+    if "PYTEST_XDIST_WORKER" in os.environ or os.environ.get("COLDDIFF_TEST_WORKERS", "") == "0":
+        return None
+    opt = config.option
+    if "".join(getattr(opt, "markexpr", "").split()) != "notgpu" or not hasattr(opt, "numprocesses") or opt.numprocesses:
+        return None
+    if getattr(opt, "collectonly", False) or getattr(opt, "usepdb", False):
+        return None
+    n = int(os.environ.get("COLDDIFF_TEST_WORKERS", "0") or 0) or max(1, min(6, (os.cpu_count() or 2) - 2))
+    if n < 2:
+        return None
+    try:                                                     # the simulator library is built once, here, not by six racing workers
+        from emu_util import _build_module
+        _build_module().build_emu()
+    except Exception:
+        return None
+    os.environ.setdefault("OMP_NUM_THREADS", "2")            # (inherited by the workers: torch's CPU ops would otherwise each take every core)
+    os.environ.setdefault("MKL_NUM_THREADS", "2")
+    opt.numprocesses = n                                     # (xdist's own hook, which runs after this one, turns it into worker specs)
+    return None
+
+
 def pytest_collection_modifyitems(config, items):
     """A plain `pytest tests` on a machine without a GPU skips the gpu-marked items instead of failing them (on the GPU box nothing is
     skipped: a missing device there must fail loudly)."""
