@@ -102,6 +102,14 @@ def test_argument_checks_of_the_gemm_and_blend_entry_points():
     expect(lib.cdf_conv_gemm_bf16x, bad, "output planes need")
     # weight gradient: tap count out of range
     expect(lib.cdf_conv_wgrad_bf16x, [p, p, 8, p, p, 8, p, p, 8, 1, 4, 4, 4, 4, 1, 4, 4, 1, 8, 8, 0, desc, 1, 0, 0, 0], "tap / split count")
+    # depthwise 7 x 7: the kernel's per-image element offsets are 24 x 24-bit products kept in 32 bits -- larger images are refused, not wrapped
+    expect(lib.cdf_dwconv7, [p, 4096, p, 4096, 0, 0, 0, p, 4096, 1, 1024, 1024, 4096, 0, 0, 0, 0, 0], "32-bit per-image offsets")
+    # fused GroupNorm tail: dropout probability out of range, output planes without a hi plane
+    gn = [p, 32, p, 32, p, p, p, p, p, 1, 16, 32, 32, 1e-6, 1, 0.0, 0, 0, 0, 0, 0]
+    bad = list(gn); bad[15] = 1.0
+    expect(lib.cdf_groupnorm_fwd_ex, bad, "dropout probability")
+    bad = list(gn); bad[18] = p
+    expect(lib.cdf_groupnorm_fwd_ex, bad, "lo plane without hi plane")
     # per-pixel blend: t = 0 is not a reverse step
     expect(lib.cdf_blend_step, [p, p, p, p, p, 0, p, 16, 48, 0], "bad args")
     expect(lib.cdf_blend_qsample, [p, p, p, p, 0, p, 1, 3, 16, 0], "bad args")
