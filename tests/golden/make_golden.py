@@ -280,6 +280,36 @@ def extra_cases(net_sd):
     return out
 
 
+def fullsize_cases(net_sd):
+    """Defading 'Random_Incremental' (+- discrete) at the 128 x 128 size of BASELINE config 5 with the README's schedule
+    (README.md:125-126: T = 50, kernel_std 0.1, initial_mask 1): q_sample and a six-step `sample(t=6)` of the UNMODIFIED reference
+    with its two randint draws replayed (DEFADE:359-368, 496-516).  Images come from the seeded generator (stored as uint8 levels)."""
+    import contextlib
+    import io
+    out = {}
+    g = torch.Generator().manual_seed(SEED + 21)
+    ref = ref_shim.load("deblurring")
+    net = ref.Unet(dim=8, dim_mults=(1, 2), channels=3)
+    net.load_state_dict(net_sd)
+    ref = ref_shim.load("defading")
+    S, T, B = 128, 50, 2
+    for discrete in (False, True):
+        d = ref.GaussianDiffusion(net, image_size=S, device_of_kernel="cpu", channels=3, timesteps=T, kernel_std=0.1, initial_mask=1,
+                                  fade_routine="Random_Incremental", sampling_routine="x0_step_down", discrete=discrete)
+        lv = torch.randint(0, 256, (B, 3, S, S), generator=g)
+        x, t = lv.float() / 255 * 2 - 1, torch.tensor([T - 1, 17])
+        torch.manual_seed(SEED + 23)
+        rx, ry = torch.randint(0, S + 1, (B,)), torch.randint(0, S + 1, (B,))
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            torch.manual_seed(SEED + 23)
+            xq = d.q_sample(x, t)
+            torch.manual_seed(SEED + 23)
+            xt, direct, img = d.sample(batch_size=B, faded_recon_sample=x, t=6)
+        out[f"defade128/Random_Incremental/{int(discrete)}"] = dict(T=T, levels=lv.to(torch.uint8), t=t, q=xq, xt=xt, direct=direct, img=img,
+                                                                    rand_x=rx, rand_y=ry, kernel_std=0.1, initial_mask=1, sample_t=6)
+    return out
+
+
 def ssim_msssim(X, Y, data_range=1.0, size_average=True, win_size=11, win_sigma=1.5, K=(0.01, 0.03)):
     """pytorch_msssim 0.2.x `ssim` restated with torch ops (the package is not installed; the reference imports it at DEBLUR:1570):
     _fspecial_gauss_1d, gaussian_filter = grouped 'valid' conv along H then W, _ssim.  Third-party, unpinned upstream."""
@@ -450,6 +480,11 @@ def main():
         torch.save(model_case(ref_shim.load("deblurring"), resamp_with_conv=False), os.path.join(HERE, "model_noconv.pt"))
         print("model_noconv.pt", os.path.getsize(os.path.join(HERE, "model_noconv.pt")) // 1024, "KiB")
         return
+    if "--fullsize" in sys.argv:                                      # only (re)write fullsize.pt
+        sd = torch.load(os.path.join(HERE, "diffusion.pt"), weights_only=False)["deblur/net_sd"]
+        torch.save(fullsize_cases(sd), os.path.join(HERE, "fullsize.pt"))
+        print("fullsize.pt", os.path.getsize(os.path.join(HERE, "fullsize.pt")) // 1024, "KiB")
+        return
     if "--evaluation" in sys.argv:                                    # only (re)write evaluation.pt
         sd = torch.load(os.path.join(HERE, "diffusion.pt"), weights_only=False)["deblur/net_sd"]
         torch.save(evaluation_cases(sd), os.path.join(HERE, "evaluation.pt"))
@@ -470,6 +505,7 @@ def main():
     torch.save(mixing_cases(dc["deblur/net_sd"]), os.path.join(HERE, "mixing.pt"))
     torch.save(extra_cases(dc["deblur/net_sd"]), os.path.join(HERE, "extras.pt"))
     torch.save(evaluation_cases(dc["deblur/net_sd"]), os.path.join(HERE, "evaluation.pt"))
+    torch.save(fullsize_cases(dc["deblur/net_sd"]), os.path.join(HERE, "fullsize.pt"))
     # torchgeometry boundary: values observed when the reference builds its kernels through the shim
     k = ref_shim.get_gaussian_kernel2d((11, 11), (7.0, 7.0))
     print("k=11 sigma=7 centre %.10f corner %.10f" % (k[5, 5].item(), k[0, 0].item()))

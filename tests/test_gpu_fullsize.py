@@ -152,3 +152,76 @@ def test_sampler_full_T_denoise():
     for t in range(200, 0, -1):
         ref = ref - cb[t - 1] * noise.cpu() + (cb[t - 2] * noise.cpu() if t - 1 != 0 else 0)
     assert (img.cpu() - ref).abs().max().item() <= 1e-4
+
+
+def _celeba_unet(seed):
+    from denoising_diffusion_pytorch import Unet
+    torch.manual_seed(seed)
+    net = quiet(Unet, dim=64, dim_mults=(1, 2, 4, 8), channels=3)
+    return net, {k: v.clone() for k, v in net.state_dict().items()}
+
+
+def test_cfg3_gen_sample_full_T_real_net_vs_oracle():
+    """BASELINE config 3 end to end: `gen_sample` (x0_step_down, fixed noise; DENOISE:383-434) over all T = 200 reverse steps at
+    128 x 128 with the real (random-init, 56.6 M-parameter) Unet, one image, against the oracle's sampler on CPU.  The single-call
+    bound is 1e-4; over the trajectory the final image must stay within 5e-4 max(1, |img|max)."""
+    from denoising_diffusion_pytorch import GaussianDiffusion
+    net, sd = _celeba_unet(31)
+    T = 200
+    g = torch.Generator().manual_seed(123457)
+    noise = torch.randn(1, 3, 128, 128, generator=g)
+    d = GaussianDiffusion(net, image_size=128, channels=3, timesteps=T, sampling_routine="x0_step_down").to(DEV)
+    with torch.no_grad():
+        _, direct, img = quiet(d.gen_sample, batch_size=1, img=noise.to(DEV))
+        ca, cb = O.cosine_tables(T)
+        _, rdirect, rimg = O.noise_sample(lambda z, s: O.unet_forward(sd, z, s), noise, T, ca, cb, fixed_noise=True)
+    e0, e1 = (direct.cpu() - rdirect).abs().max().item(), (img.cpu() - rimg).abs().max().item()
+    print("cfg3 T=200 128x128 gen_sample: first-step error", e0, "final-image error", e1, "|img|max", rimg.abs().max().item())
+    assert e0 <= 1e-4 and e1 <= 5e-4 * max(1.0, rimg.abs().max().item())
+
+
+def test_cfg4_algorithm2_full_T_real_net_vs_oracle():
+    """BASELINE config 4 end to end: `sample` = blur to x_T, then Algorithm 2 (x0_step_down, DEBLUR:393-455) with the
+    Exponential_reflect chain (T = 200, k = 15, std 0.01) at 128 x 128 and the real Unet, one image, against the oracle:
+    T forward blurs, T network calls, T (T + 1) / 2 + T (T - 1) / 2 blur steps on the way back."""
+    from deblurring_diffusion_pytorch import GaussianDiffusion
+    net, sd = _celeba_unet(37)
+    T = 200
+    g = torch.Generator().manual_seed(123457)
+    x = torch.randint(0, 256, (1, 3, 128, 128), generator=g).float() / 255 * 2 - 1
+    d = GaussianDiffusion(net, image_size=128, device_of_kernel="cuda", channels=3, timesteps=T, kernel_std=0.01, kernel_size=15,
+                          blur_routine="Exponential_reflect", sampling_routine="x0_step_down").to(DEV)
+    ws = [m.weight.detach().cpu() for m in d.gaussian_kernels]
+    modes = [m.padding_mode for m in d.gaussian_kernels]
+    with torch.no_grad():
+        xt, direct, img = quiet(d.sample, batch_size=1, img=x.to(DEV))
+        rxt, rdirect, rimg = O.cold_sample(lambda z, s: O.unet_forward(sd, z, s), lambda z, i: O.blur_step(z, ws[i], modes[i]), x, T, "x0_step_down")
+    ex, e0, e1 = (xt.cpu() - rxt).abs().max().item(), (direct.cpu() - rdirect).abs().max().item(), (img.cpu() - rimg).abs().max().item()
+    print("cfg4 T=200 128x128 Alg. 2: x_T error", ex, "first-step error", e0, "final-image error", e1, "|img|max", rimg.abs().max().item())
+    assert ex <= 1e-5 and e0 <= 1e-4 and e1 <= 5e-4 * max(1.0, rimg.abs().max().item())
+
+
+def test_cfg5_random_incremental_fade_128_vs_reference_golden():
+    """Defading 'Random_Incremental' (+- discrete) at 128 x 128 with the README schedule (README.md:125-126; T = 50, std 0.1):
+    vectors the UNMODIFIED reference produced (tests/golden/make_golden.py::fullsize_cases) with its per-sample crop offsets
+    replayed -- masks, q_sample and x_T bit-exact (DEFADE:496-535), the six-step Algorithm-2 walk within 1e-4 (DEFADE:354-425)."""
+    import os
+    from deblurring_diffusion_pytorch import Unet
+    from defading_diffusion_pytorch import GaussianDiffusion
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = torch.load(os.path.join(gold, "fullsize.pt"), weights_only=False)
+    net = quiet(Unet, dim=8, dim_mults=(1, 2), channels=3)
+    net.load_state_dict(torch.load(os.path.join(gold, "diffusion.pt"), weights_only=False)["deblur/net_sd"])
+    net = net.to(DEV)
+    for key, c in g.items():
+        discrete = key.endswith("/1")
+        d = GaussianDiffusion(net, image_size=128, device_of_kernel="cuda", channels=3, timesteps=c["T"], kernel_std=c["kernel_std"],
+                              initial_mask=c["initial_mask"], fade_routine="Random_Incremental", sampling_routine="x0_step_down", discrete=discrete)
+        assert torch.equal(d.fade_kernels.cpu(), O.fade_kernels("Random_Incremental", c["T"], 128, c["kernel_std"], c["initial_mask"]))
+        d._offsets = lambda b, dev, c=c: (c["rand_x"].to(dev), c["rand_y"].to(dev))
+        x = (c["levels"].float() / 255 * 2 - 1).to(DEV)
+        with torch.no_grad():
+            assert torch.equal(d.q_sample(x, c["t"].to(DEV)).cpu(), c["q"]), key
+            xt, direct, img = d.sample(batch_size=x.shape[0], faded_recon_sample=x, t=c["sample_t"])
+        assert torch.equal(xt.cpu(), c["xt"]), key
+        assert (direct.cpu() - c["direct"]).abs().max() <= 1e-4 and (img.cpu() - c["img"]).abs().max() <= 1e-4, key

@@ -444,6 +444,20 @@ def test_defading_golden(mbe):
     assert torch.equal(q, O.fade_q_sample(x, t, d.fade_kernels.cpu(), rx, ry, discrete=True))
 
 
+def test_random_incremental_fade_128_q_sample_golden(mbe):
+    """Defading 'Random_Incremental' (+- discrete) at 128 x 128, README schedule (README.md:125-126): q_sample bit-exact against the
+    reference-generated tests/golden/fullsize.pt with the reference's crop offsets replayed (DEFADE:496-535).  (The six-step sampler
+    of the same fixture runs on the MI355X: tests/test_gpu_fullsize.py.)"""
+    from defading_diffusion_pytorch import GaussianDiffusion
+    for key, c in load("fullsize.pt").items():
+        d = GaussianDiffusion(torch.nn.Identity(), image_size=128, device_of_kernel="cuda", channels=3, timesteps=c["T"], kernel_std=c["kernel_std"],
+                              initial_mask=c["initial_mask"], fade_routine="Random_Incremental", discrete=key.endswith("/1"))
+        d._offsets = lambda b, dev, c=c: (c["rand_x"].to(dev), c["rand_y"].to(dev))
+        x = mbe.to(c["levels"].float() / 255 * 2 - 1)
+        with torch.no_grad():
+            assert torch.equal(d.q_sample(x, mbe.to(c["t"])).cpu(), c["q"]), key
+
+
 def test_extras_golden_discrete_individual_and_random_fades(mbe):
     """Reference-generated vectors (tests/golden/make_golden.py: extra_cases) for the branches that round 1 only compared with the
     oracle: deblurring `discrete=True` (DEBLUR:413-415, 441-444, 937-940, 954-958), blur_routine 'Individual_Incremental'

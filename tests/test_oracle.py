@@ -181,6 +181,149 @@ def test_mixing_packages_match_golden():
                 assert (ps[k].grad - ref).abs().max() <= 2e-6 * max(1.0, ref.abs().max().item()), k
 
 
+def test_fullsize_random_fade_matches_golden():
+    """Defading 'Random_Incremental' (+- discrete) at 128 x 128 with the README schedule (README.md:125-126), reference-generated
+    (make_golden.py::fullsize_cases): the restated masks, q_sample with the replayed crop offsets (bit-exact) and the six-step
+    Algorithm-2 walk (DEFADE:354-425)."""
+    g = load("fullsize.pt")
+    sd = load("diffusion.pt")["deblur/net_sd"]
+    net = lambda im, st: O.unet_forward(sd, im, st)
+    for key, c in g.items():
+        discrete = key.endswith("/1")
+        x = c["levels"].float() / 255 * 2 - 1
+        masks = O.fade_kernels("Random_Incremental", c["T"], 128, c["kernel_std"], c["initial_mask"])
+        rx, ry = c["rand_x"], c["rand_y"]
+        assert torch.equal(O.fade_q_sample(x, c["t"], masks, rx, ry, discrete=discrete), c["q"]), key
+        crop = lambda i: torch.stack([masks[i][rx[b]:rx[b] + 128, ry[b]:ry[b] + 128] for b in range(x.shape[0])]).unsqueeze(1)
+        st = c["sample_t"]
+        z = x
+        for i in range(st):
+            z = crop(i) * z
+        z = O.quantise8(z) if discrete else z
+        assert torch.equal(z, c["xt"]), key
+        with torch.no_grad():
+            # (cold_sample degrades first; here the start is already faded + quantised: walk back with the shared reverse update)
+            img, t, direct = z, st, None
+            while t:
+                r = net(img, torch.full((x.shape[0],), t - 1, dtype=torch.long))
+                direct = r if direct is None else direct
+                img = O._reverse_update(lambda u, i: crop(i) * u, img, r, t, "x0_step_down")
+                t -= 1
+        assert (direct - c["direct"]).abs().max() <= 1e-6 and (img - c["img"]).abs().max() <= 2e-6, key
+
+
+def _same(a, b, path=""):
+    if isinstance(a, torch.Tensor):
+        assert isinstance(b, torch.Tensor) and a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b), path
+    elif isinstance(a, dict):
+        assert set(a) == set(b), (path, set(a) ^ set(b))
+        for k in a:
+            _same(a[k], b[k], f"{path}/{k}")
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), path
+        for i, (u, v) in enumerate(zip(a, b)):
+            _same(u, v, f"{path}[{i}]")
+    else:
+        assert a == b, (path, a, b)
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree only exists in the build container")
+def test_make_golden_regenerates_every_committed_fixture():
+    """tests/golden/*.pt ARE what the unmodified reference produces: re-run every generator of make_golden.py against
+    /root/reference and require bit-equality with the committed files (every tensor, key and scalar)."""
+    import contextlib
+    import io
+    import sys
+    sys.path.insert(0, GOLD)
+    try:
+        import make_golden as M
+    finally:
+        sys.path.remove(GOLD)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = ref_shim.load("deblurring")
+        _same(M.unet_case(ref), load("unet_dim8.pt"), "unet_dim8")
+        _same(M.model_case(ref), load("model_ch32.pt"), "model_ch32")
+        _same(M.model_case(ref, resamp_with_conv=False), load("model_noconv.pt"), "model_noconv")
+        dc = M.diffusion_cases()
+        _same(dc, load("diffusion.pt"), "diffusion")
+        sd = dc["deblur/net_sd"]
+        _same(M.variant_cases(sd), load("variants.pt"), "variants")
+        _same(M.mixing_cases(sd), load("mixing.pt"), "mixing")
+        _same(M.extra_cases(sd), load("extras.pt"), "extras")
+        _same(M.evaluation_cases(sd), load("evaluation.pt"), "evaluation")
+        _same(M.fullsize_cases(sd), load("fullsize.pt"), "fullsize")
+    made = {"unet_dim8.pt", "model_ch32.pt", "model_noconv.pt", "diffusion.pt", "variants.pt", "mixing.pt", "extras.pt", "evaluation.pt", "fullsize.pt"}
+    assert made == {f for f in os.listdir(GOLD) if f.endswith(".pt")}          # no fixture without a generator
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree only exists in the build container")
+def test_oracle_vs_live_reference_degradations_and_samplers():
+    """q_sample + sample of the four packages, live against the imported reference at a size and schedule no fixture holds
+    (24 x 24, its own seeds): blur (DEBLUR:393-455, 927-960), noise (DENOISE:342-434, 517-522), pixelation (RESOL:417-459, 630-652),
+    fading (DEFADE:354-425, 496-535)."""
+    import contextlib
+    import io
+    S, B = 24, 2
+    g = torch.Generator().manual_seed(4242)
+    x = torch.randint(0, 256, (B, 3, S, S), generator=g).float() / 255 * 2 - 1
+    quiet = lambda: contextlib.redirect_stdout(io.StringIO())
+    ref = ref_shim.load("deblurring")
+    torch.manual_seed(99)
+    with quiet():
+        rnet = ref.Unet(dim=8, dim_mults=(1, 2), channels=3)
+    sd = {k: v.clone() for k, v in rnet.state_dict().items()}
+    net = lambda im, st: O.unet_forward(sd, im, st)
+    with torch.no_grad(), quiet():
+        # ---- blur
+        for routine, ks, std in (("Incremental", 5, 0.3), ("Exponential_reflect", 7, 0.05)):
+            for sampling in ("default", "x0_step_down"):
+                T, t = 6, torch.tensor([5, 2])
+                d = ref.GaussianDiffusion(rnet, image_size=S, device_of_kernel="cpu", channels=3, timesteps=T, kernel_std=std, kernel_size=ks,
+                                          blur_routine=routine, sampling_routine=sampling)
+                ws = [m.weight.detach() for m in d.gaussian_kernels]
+                modes = [m.padding_mode for m in d.gaussian_kernels]
+                assert torch.equal(d.q_sample(x, t), O.blur_q_sample(x, t, ws, modes, T))
+                xt, direct, img = d.sample(batch_size=B, img=x)
+                oxt, odirect, oimg = O.cold_sample(net, lambda z, i: O.blur_step(z, ws[i], modes[i]), x, T, sampling)
+                assert torch.equal(xt, oxt) and torch.equal(direct, odirect) and (img - oimg).abs().max() <= 1e-6
+        # ---- noise
+        ref = ref_shim.load("denoising")
+        T, t = 7, torch.tensor([6, 1])
+        e = torch.randn(B, 3, S, S, generator=g)
+        ca, cb = O.cosine_tables(T)
+        for sampling in ("x0_step_down", "ddim"):
+            d = ref.GaussianDiffusion(rnet, image_size=S, channels=3, timesteps=T, sampling_routine=sampling)
+            assert torch.equal(d.q_sample(x, e, t), O.noise_q_sample(x, e, t, ca, cb))
+            for got, want in ((d.gen_sample(batch_size=B, img=e), O.noise_sample(net, e, T, ca, cb, fixed_noise=sampling == "x0_step_down")),
+                              (d.sample(batch_size=B, img=e), O.noise_sample(net, e, T, ca, cb, fixed_noise=False))):
+                assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and (got[2] - want[2]).abs().max() <= 2e-6
+        # ---- pixelation
+        ref = ref_shim.load("resolution")
+        for routine, mode in (("Incremental", "bicubic"), ("Incremental_area_factor_2", "area")):
+            T = 3
+            t = torch.tensor([2, 0])
+            d = ref.GaussianDiffusion(rnet, image_size=S, device_of_kernel="cpu", channels=3, timesteps=T, resolution_routine=routine,
+                                      sampling_routine="x0_step_down")
+            sizes = O.pixelate_sizes(routine, T, S)
+            assert torch.equal(d.q_sample(x, t), O.pixelate_q_sample(x, t, sizes, mode))
+            xt, direct, img = d.sample(batch_size=B, img=x)
+            oxt, odirect, oimg = O.cold_sample(net, lambda z, i: O.pixelate_step(z, sizes[i], mode), x, T, "x0_step_down")
+            assert torch.equal(xt, oxt) and torch.equal(direct, odirect) and (img - oimg).abs().max() <= 1e-6
+        # ---- fading
+        ref = ref_shim.load("defading")
+        for routine in ("Incremental", "Constant"):
+            for sampling in ("default", "x0_step_down"):
+                T, t = 5, torch.tensor([4, 1])
+                d = ref.GaussianDiffusion(rnet, image_size=S, device_of_kernel="cpu", channels=3, timesteps=T, kernel_std=0.4, initial_mask=2,
+                                          fade_routine=routine, sampling_routine=sampling)
+                masks = O.fade_kernels(routine, T, S, 0.4, 2)
+                assert torch.equal(d.fade_kernels, masks)
+                assert torch.equal(d.q_sample(x, t), O.fade_q_sample(x, t, masks))
+                xt, direct, img = d.sample(batch_size=B, faded_recon_sample=x)
+                oxt, odirect, oimg = O.cold_sample(net, lambda z, i: masks[i] * z, x, T, sampling)
+                assert torch.equal(xt, oxt) and torch.equal(direct, odirect) and (img - oimg).abs().max() <= 1e-6
+
+
 @pytest.mark.skipif(not ref_shim.available(), reason="reference tree only exists in the build container")
 def test_oracle_bit_exact_vs_live_reference():
     ref = ref_shim.load("deblurring")
