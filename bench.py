@@ -250,17 +250,25 @@ def selfcheck(diffusion, device):
             "note": "p_losses (q_sample -> UNet -> L1) of the benchmarked weights on a 2-image sub-batch, HIP path vs oracle/cold_oracle.py"}
 
 
-def timed_train(trainer, steps, warmup):
+def timed_train(trainer, steps, warmup, reps=1):
+    """Seconds per step: `warmup` untimed steps, then the median over `reps` repetitions of `steps` timed steps."""
     for _ in range(warmup):
         trainer.train_step()
         trainer.step += 1
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        trainer.train_step()
-        trainer.step += 1
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps
+    out = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            trainer.train_step()
+            trainer.step += 1
+        torch.cuda.synchronize()
+        out.append((time.perf_counter() - t0) / steps)
+    return sorted(out)[len(out) // 2]
+
+
+SEC_STEPS, SEC_WARMUP = 20, 5            # secondary workloads: timed steps / warm-up steps (the 32 x 32 ones: median of 3 repetitions)
+SEC_TIMING = "%d timed steps after %d warm-up" % (SEC_STEPS, SEC_WARMUP)
 
 
 def secondary_workloads(device):
@@ -281,8 +289,8 @@ def secondary_workloads(device):
         tr = Trainer(d, None, image_size=128, train_batch_size=32, train_lr=2e-5, train_num_steps=10 ** 9, gradient_accumulate_every=2,
                      dataset='synthetic', results_folder=res)
     tr.quiet = True
-    dt = timed_train(tr, 5, 2)
-    out["cfg4_celeba128_deblur_train"] = {"img_per_s": round(64 / dt, 1), "ms_per_step": round(1000 * dt, 2),
+    dt = timed_train(tr, SEC_STEPS, SEC_WARMUP)
+    out["cfg4_celeba128_deblur_train"] = {"img_per_s": round(64 / dt, 1), "ms_per_step": round(1000 * dt, 2), "timing": SEC_TIMING,
                                           "workload": "Unet(64,(1,2,4,8)) @128x128, blur Exponential_reflect T=200 k=15 std=0.01, 2 x 32 img + Adam"}
     with torch.no_grad():
         x = tr._next_batch()[:16]
@@ -307,8 +315,8 @@ def secondary_workloads(device):
         tr = Trainer(d, None, image_size=32, train_batch_size=128, train_lr=2e-5, train_num_steps=10 ** 9, gradient_accumulate_every=2,
                      dataset='synthetic', results_folder=res)
     tr.quiet = True
-    dt = timed_train(tr, 10, 3)
-    out["cfg2_cifar10_deblur_train"] = {"img_per_s": round(256 / dt, 1), "ms_per_step": round(1000 * dt, 2),
+    dt = timed_train(tr, SEC_STEPS, SEC_WARMUP, reps=3)
+    out["cfg2_cifar10_deblur_train"] = {"img_per_s": round(256 / dt, 1), "ms_per_step": round(1000 * dt, 2), "timing": SEC_TIMING + ", median of 3",
                                         "workload": "Model(ch=128,(1,2,2,2),attn@16,dropout 0.1) @32x32, blur Special_6_routine T=50, 2 x 128 img + Adam"}
     del tr, d, net
     torch.cuda.empty_cache()
@@ -322,8 +330,10 @@ def secondary_workloads(device):
             tr = Trainer(d, None, image_size=size, train_batch_size=batch, train_lr=2e-5, train_num_steps=10 ** 9, gradient_accumulate_every=2,
                          dataset='synthetic', results_folder=res)
         tr.quiet = True
-        dt = timed_train(tr, 5, 2)
-        out[key] = {"img_per_s": round(2 * batch / dt, 1), "ms_per_step": round(1000 * dt, 2), "workload": desc + ", 2 micro-steps + Adam"}
+        reps = 3 if cfg == "1" else 1
+        dt = timed_train(tr, SEC_STEPS, SEC_WARMUP, reps=reps)
+        out[key] = {"img_per_s": round(2 * batch / dt, 1), "ms_per_step": round(1000 * dt, 2), "workload": desc + ", 2 micro-steps + Adam",
+                    "timing": SEC_TIMING + (", median of 3" if reps > 1 else "")}
         del tr, d
         torch.cuda.empty_cache()
     return out
@@ -331,11 +341,23 @@ def secondary_workloads(device):
 
 def _profile(name):
     """Newest committed profiles/round<N>_<name> (bench.py cannot run the profiler on itself)."""
-    for rnd in (3, 2, 1):
+    for rnd in (4, 3, 2, 1):
         path = os.path.join(REPO, "profiles", "round%d_%s" % (rnd, name))
         if os.path.exists(path):
             return path
     return None
+
+
+def _provenance(path, doc):
+    """Is this committed profile a measurement of the kernels this process runs?  tools/prof_summary.py / tools/pmc_traffic.py stamp the git
+    HEAD and a digest of csrc/*.hip, csrc/*.h, include/*.h into what they write (tools/provenance.py); a profile without a stamp, or
+    with another digest, describes other kernels and nothing is quoted from it."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import provenance
+    st = doc.get("provenance") or doc.get("_provenance") or {}
+    now = provenance.csrc_sha16()
+    return {"file": os.path.relpath(path, REPO), "profile_git_head": st.get("git_head"), "profile_csrc_sha16": st.get("csrc_sha16"),
+            "running_csrc_sha16": now, "match": st.get("csrc_sha16") == now}
 
 
 def bandwidth_classes():
@@ -345,7 +367,12 @@ def bandwidth_classes():
     tp, kp = _profile("pmc_traffic.json"), _profile("kernel_trace.json")
     if not (tp and kp):
         return None
-    traffic, trace = json.load(open(tp))["kernels"], json.load(open(kp))
+    tdoc, trace = json.load(open(tp)), json.load(open(kp))
+    prov = [_provenance(tp, tdoc), _provenance(kp, trace)]
+    if not all(p["match"] for p in prov):
+        return {"stale": True, "provenance": prov,
+                "note": "the committed profiles were taken from other kernel sources than the ones running: no per-class figures quoted"}
+    traffic = tdoc["kernels"]
     classes = {"depthwise 7x7": ("dwconv7_kernel", "dwconv7_wgrad_partial_kernel", "dwconv7_wgrad_partial_narrow_kernel"), "channel LayerNorm": ("layernorm_c_fwd_kernel", "layernorm_c_bwd_kernel"),
                "Adam": ("adam_kernel",), "operand split": ("split_bf16_kernel",), "split-K reduction": ("unpack_reduce_",),
                "linear attention": ("linattn_",)}
@@ -360,6 +387,7 @@ def bandwidth_classes():
             out[name] = {"hbm_gbs": round(b / t / 1e9, 1), "frac_of_peak": round(b / t / 1e9 / PEAK_HBM_GBS, 3)}
     out["source"] = "%s (FETCH_SIZE x2 + WRITE_SIZE per launch) / %s (avg duration): committed rocprofv3 passes over this same command" % (
         os.path.relpath(tp, REPO), os.path.relpath(kp, REPO))
+    out["provenance"] = prov
     return out
 
 
@@ -483,8 +511,11 @@ def main():
             # (tools/pmc_traffic.py; bench.py cannot run the profiler on itself)
             tpath = _profile("pmc_traffic.json")
             if tpath and dom == "conv_igemm_sp":
-                g = json.load(open(tpath)).get("conv_igemm_sp")
-                if g:
+                tdoc = json.load(open(tpath))
+                prov = _provenance(tpath, tdoc)
+                out["roofline"]["traffic_provenance"] = prov
+                g = tdoc.get("conv_igemm_sp")
+                if g and prov["match"]:            # a profile of other kernel sources is not quoted: traffic stays null
                     out["roofline"]["traffic"] = round(g["hbm_bytes_per_launch"])
                     out["roofline"]["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, %s)" % os.path.relpath(tpath, REPO)
         out["gemm_kernels"] = kernels
@@ -546,6 +577,17 @@ def main():
                                     "sample_ms_per_img_200step": sample_bf16, "sample_batch": args.sample_batch,
                                     "step_roofline": step_roofline(args.batch, args.accum, 1000 * dtb, 1, act="bf16")}
                 log(f"bf16 mode: {out['bf16_mode']['value']} img/s")
+                # third, LABELLED line: the lower anchor -- every GEMM on the exact-fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32,
+                # 157 TFLOP/s dense), i.e. IEEE fp32 products; `value` above keeps 16 mantissa bits per operand and drops a_lo b_lo
+                runtime.set_precision("f32")
+                runtime.bump_weights_epoch()
+                dtf = timed_train(trainer, max(2, args.steps // 2), 1)
+                runtime.set_precision("bf16x3")
+                runtime.bump_weights_epoch()
+                out["f32_mode"] = {"value": round(args.batch * args.accum / dtf, 2), "unit": "img/s", "ms_per_step": round(1000 * dtf, 3),
+                                   "dtype": "f32 everywhere: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) for every GEMM (COLDDIFF_PRECISION=f32)",
+                                   "step_frac_of_f32_mfma_peak": round(3 * UNET128_FWD_GFLOP * args.batch * args.accum / dtf / 1e3 / PEAK_F32_MFMA_TFLOPS, 4)}
+                log(f"f32 mode: {out['f32_mode']['value']} img/s")
             del trainer
             torch.cuda.empty_cache()
             out["secondary"] = secondary_workloads(device)

@@ -134,6 +134,18 @@ class Lib:
         self.path = path
         self._dll = ctypes.CDLL(path)
         self.protos = parse_header()
+        # header and library must be the same ABI revision BEFORE any call: a library built from another revision of colddiff.h would
+        # read shifted arguments (e.g. the stream pointer as a flag)
+        want = int(re.search(r"^\s*#\s*define\s+CDF_ABI_VERSION\s+(\d+)", open(HEADER).read(), flags=re.M).group(1))
+        try:
+            ver = self._dll.cdf_abi_version
+        except AttributeError:
+            raise CdfError("colddiff: %s does not export cdf_abi_version" % path)
+        ver.restype, ver.argtypes = ctypes.c_int, []
+        if ver() != want:
+            raise CdfError("colddiff: %s is ABI version %d, include/colddiff.h is version %d -- rebuild the library from this tree "
+                           "(python __graft_entry__.py)" % (path, ver(), want))
+        self.abi_version = want
         for name, (restype, argtypes) in self.protos.items():
             try:
                 fn = getattr(self._dll, name)

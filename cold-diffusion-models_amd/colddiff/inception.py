@@ -349,13 +349,23 @@ class InceptionV3(nn.Module):
         # (without a resize the same kernel is an exact copy: scale 1 puts every source index on a pixel with weight 1)
         rt.lib().cdf_resize_bilinear_nhwc(P(inp), P(x), 4, B, 3, H, W, OH, OW, mul, add, rt.stream(inp))
         outp = []
-        for idx, block in enumerate(self.blocks):
-            for layer in block:
-                x = layer.run(x)
-            if idx in self.output_blocks:
-                outp.append(ops.nhwc_to_nchw(x, x.shape[-1]))
-            if idx == self.last_needed_block:
-                break
+        # The metric must not depend on the training arithmetic: under COLDDIFF_PRECISION=bf16 (single-bf16 GEMM operands) the 94 conv
+        # layers would drift from pytorch-fid's fp32 features.  The extractor always runs parity-grade (split precision, or exact fp32
+        # when the process is in f32 mode).
+        saved = rt.precision
+        if saved == "bf16":
+            rt.set_precision("bf16x3")
+        try:
+            for idx, block in enumerate(self.blocks):
+                for layer in block:
+                    x = layer.run(x)
+                if idx in self.output_blocks:
+                    outp.append(ops.nhwc_to_nchw(x, x.shape[-1]))
+                if idx == self.last_needed_block:
+                    break
+        finally:
+            if saved != rt.precision:
+                rt.set_precision(saved)
         return outp
 
 

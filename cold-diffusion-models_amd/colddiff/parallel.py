@@ -67,17 +67,24 @@ def init_distributed(backend=None):
     # milestone wait, where rank 0 runs the full T-step sampler + image / checkpoint I/O, goes through milestone_barrier()
     dist.init_process_group(backend=backend, rank=rank(), world_size=world_size(),
                             timeout=datetime.timedelta(minutes=int(os.environ.get("COLDDIFF_DIST_TIMEOUT_MIN", "10"))))
+    # the long-wait group is created HERE, while every rank is at the same point: created lazily inside the first milestone, its
+    # rendezvous itself ran under maximal rank skew (rank 0 still sampling) against the short default timeout
+    global _milestone_group
+    _milestone_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=2))
 
 
 _milestone_group = None
 
 
 def milestone_barrier():
-    """Barrier with a 2-hour limit on its own gloo group (host-side wait: no device collective sits in a stream meanwhile)."""
+    """Barrier with a 2-hour limit on its own gloo group (host-side wait: no device collective sits in a stream meanwhile).
+    EVERY rank-0-only long phase that is followed by a collective must end in this barrier -- Trainer milestones (sampling + checkpoint),
+    EvalMixin FID / sampling runs under torchrun, a DeviceImageCache build before the initial broadcast -- because the training
+    collectives' own watchdog is COLDDIFF_DIST_TIMEOUT_MIN (10 minutes)."""
     global _milestone_group
     if world_size() == 1 or not dist.is_initialized():
         return
-    if _milestone_group is None:
+    if _milestone_group is None:                  # (a process group somebody else initialised: all ranks reach their first barrier together)
         _milestone_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=2))
     if torch.cuda.is_available():
         torch.cuda.synchronize()

@@ -264,6 +264,9 @@ class Trainer(EvalMixin):
         if parallel.world_size() > 1:
             self.sync = parallel.GradSync(self.arena)
             parallel.set_engine(self.sync)
+            # ranks may arrive here minutes apart (each decoded its image folder into its device cache above): wait on the long-timeout
+            # host group first, so that the broadcast's own watchdog only ever covers the broadcast
+            parallel.milestone_barrier()
             # every rank starts from rank 0's weights (the reference replicates GPU 0's module)
             torch.distributed.broadcast(self.arena.data, src=0)
             rt.bump_weights_epoch()
@@ -672,6 +675,11 @@ class DefadeTrainer(Trainer):
     always shuffled (DEFADE:695), no `shuffle=` argument upstream (accepted and ignored here)."""
     force_shuffle = True
     image_size_from_model = True
+
+    def __init__(self, diffusion_model, folder, *, train_num_steps=700000, save_and_sample_every=10000, **kw):
+        # this package's own defaults (DEFADE:661, 666); its scripts (cifar10_train.py, celebA_train.py) do not pass
+        # save_and_sample_every, so a ported script must checkpoint / run the T-step sampler every 10000 steps, not every 1000
+        super().__init__(diffusion_model, folder, train_num_steps=train_num_steps, save_and_sample_every=save_and_sample_every, **kw)
 
     @staticmethod
     def recipe_for(dataset):

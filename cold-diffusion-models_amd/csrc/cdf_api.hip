@@ -26,7 +26,7 @@ int cdf_check_launch(const char* what) {
 
 extern "C" const char* cdf_last_error(void) { return g_cdf_err; }
 
-extern "C" int cdf_abi_version(void) { return 1; }
+extern "C" int cdf_abi_version(void) { return CDF_ABI_VERSION; }
 
 // 1 when this is the gfx950 device build, 0 for the host SIMT-simulator build used by CPU tests.
 extern "C" int cdf_is_device_build(void) {

@@ -37,6 +37,20 @@
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 #endif
+// One-time-PER-DEVICE latch for hipFuncSetAttribute(MaxDynamicSharedMemorySize): a process may drive several devices, and a function
+// attribute belongs to the device that was current when it was set.  Unsynchronised on purpose -- a race only repeats an idempotent call.
+#ifndef CDF_EMU
+struct CdfDeviceLatch {
+    unsigned long long seen = 0;                             // bit d: set on device d (ordinals >= 64 always repeat the call)
+    bool first() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+        if (seen & (1ull << d)) return false;
+        seen |= 1ull << d;
+        return true;
+    }
+};
+#endif
 // Order the LDS accesses of ONE wave against each other (a wave's LDS operations execute in order on the hardware: only the compiler
 // must not move them; the fiber simulator really has to let the other lanes catch up).
 #ifdef CDF_EMU

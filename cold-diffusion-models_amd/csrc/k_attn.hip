@@ -366,10 +366,9 @@ __global__ void softmax_rows_bwd_kernel(const float* p, const float* dp, float* 
 // ================================================================================================
 static void la_final_attr() {
 #ifndef CDF_EMU
-    static bool done = false;
-    if (!done) {          // nsplit x 128 B of rescaling weights next to ~4 KB of static LDS: past the 64 KB default from ~480 partials up
+    static CdfDeviceLatch done;
+    if (done.first()) {          // nsplit x 128 B of rescaling weights next to ~4 KB of static LDS: past the 64 KB default from ~480 partials up
         (void)hipFuncSetAttribute((const void*)linattn_ctx1p_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);   // (+ ~4 KB static: the sum must stay under the 160 KB of a CU)
-        done = true;
     }
 #endif
 }
@@ -401,10 +400,9 @@ extern "C" int cdf_linattn_context(const float* qkv, int ld, int koff, float* ct
     if (onepass && ns <= 1024) {
         const size_t lds = ((size_t)2 * 256 * LA_D + 32 * LA_D + LA_D) * sizeof(float);
 #ifndef CDF_EMU
-        static bool attr_done = false;
-        if (!attr_done) {
+        static CdfDeviceLatch attr_done;
+        if (attr_done.first()) {
             (void)hipFuncSetAttribute((const void*)linattn_ctx1p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_done = true;
         }
 #endif
         CDF_LAUNCH(linattn_ctx1p_kernel, dim3(heads, ns, B), dim3(256), lds, CDF_S, qkv, ld, koff, kmax_part, ctx_part, sum_part, n, HD);

@@ -2670,13 +2670,12 @@ extern "C" int cdf_linattn_kvctx(const float* xn, int ldx, const void* w_hi, con
     a.tiles_per_block = (tiles + P - 1) / P;
     const size_t lds = (size_t)128 * (256 + 8) * sizeof(float) + 8 * 32 * sizeof(float);
 #ifndef CDF_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CdfDeviceLatch attr_done;
+    if (attr_done.first()) {
         (void)hipFuncSetAttribute((const void*)linattn_kvctx_kernel<1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)linattn_kvctx_kernel<3, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)linattn_kvctx_kernel<1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)linattn_kvctx_kernel<3, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
 #endif
     if (dim % 64 == 0) {
@@ -2730,11 +2729,10 @@ extern "C" int cdf_conv_gemm_bf16(const float* x, int ldx, const void* w_hi, con
     const int M = B * QH * QW;
     const int tiles = cdf_cdiv(M, 128) * cdf_cdiv(Cout, 128);
 #ifndef CDF_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CdfDeviceLatch attr_done;
+    if (attr_done.first()) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_sp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_igemm_sp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
 #endif
     if (split == 1) {
@@ -2766,10 +2764,9 @@ extern "C" int cdf_conv_wgrad_bf16(const float* xa, int lda, const float* xb, in
         a.dbx[t] = (signed char)tap_desc[4 * t + 3];
     }
 #ifndef CDF_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CdfDeviceLatch attr_done;
+    if (attr_done.first()) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_sp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
 #endif
     const size_t lds = (size_t)2 * 4 * 32 * 128 * sizeof(unsigned short);
@@ -2831,10 +2828,9 @@ static int launch_igemm_spx(const SpxArgs& a, int M, hipStream_t s) {
                                                              // 256 x 128 x 3 stages: 144 KB, one block per CU
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
 #ifndef CDF_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CdfDeviceLatch attr_done;
+    if (attr_done.first()) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_spx_kernel<BM, BN, WM, WN, NSTAGE, OCC, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
 #endif
     const int tiles = cdf_cdiv(M, BM) * cdf_cdiv(a.Cout, BN);
@@ -2851,13 +2847,14 @@ static int cdf_num_cus() {                                     // CUs of the cur
 #ifdef CDF_EMU
     return 8;
 #else
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount >= 8) ? p.multiProcessorCount / 8 * 8 : 256;
+    static int n[64] = {0};                                  // per device ordinal (a process may drive several devices)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!n[dev]) {
+        int cus = 0;
+        n[dev] = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8) ? cus / 8 * 8 : 256;
     }
-    return n;
+    return n[dev];
 #endif
 }
 
@@ -2874,10 +2871,9 @@ static int launch_igemm_halo(const SpxArgs& a, int M, hipStream_t s) {
     constexpr size_t lds = stages > epi ? stages : epi;
     static_assert(lds <= 160 * 1024, "halo tile does not fit the LDS");
 #ifndef CDF_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CdfDeviceLatch attr_done;
+    if (attr_done.first()) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_halo_kernel<W, BN, NB, BM, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
 #endif
     const int tiles = (M / BM) * cdf_cdiv(a.Cout, BN);
@@ -2893,11 +2889,10 @@ static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s, bool str
     constexpr size_t lds = stages > epi ? stages : epi;
     static_assert(lds <= 160 * 1024, "row-halo tile does not fit the LDS");
 #ifndef CDF_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CdfDeviceLatch attr_done;
+    if (attr_done.first()) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_kernel<W, BN, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_kernel<W, BN, NS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
 #endif
     const int tiles = (M / 256) * cdf_cdiv(a.Cout, BN);
@@ -2906,11 +2901,10 @@ static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s, bool str
         constexpr size_t lds_s = (st_a + 2 * st_b) + ((st_a + st_b) > (size_t)128 * (BN + 8) * 4 ? (st_a + st_b) : (size_t)128 * (BN + 8) * 4);
         static_assert(lds_s <= 160 * 1024, "streaming row-halo tile does not fit the LDS");
 #ifndef CDF_EMU
-        static bool attr2_done = false;
-        if (!attr2_done) {
+        static CdfDeviceLatch attr2_done;
+        if (attr2_done.first()) {
             (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_stream_kernel<W, BN, NS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_stream_kernel<W, BN, NS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr2_done = true;
         }
 #endif
         const int ncu = cdf_num_cus(), grid = tiles < ncu ? tiles : ncu;
@@ -2938,11 +2932,10 @@ static int launch_igemm_rowhalo_stream512(const SpxArgs& a, int M, hipStream_t s
     constexpr size_t lds_s = off_a1 + (st_a + st_b > cs ? st_a + st_b : cs);
     static_assert(lds_s <= 160 * 1024, "512-pixel streaming tile does not fit the LDS");
 #ifndef CDF_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CdfDeviceLatch attr_done;
+    if (attr_done.first()) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_stream_kernel<W, BN, NS, 2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_stream_kernel<W, BN, NS, 4, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
 #endif
     const int tiles = (M / 512) * cdf_cdiv(a.Cout, BN), ncu = cdf_num_cus(), grid = tiles < ncu ? tiles : ncu;
@@ -3102,10 +3095,9 @@ static int launch_wgrad_spx(const SpxWgradArgs& a, hipStream_t s) {
     constexpr size_t epi = (size_t)TA * (TB + 8) * sizeof(float);
     constexpr size_t lds = 2 * stage > epi ? 2 * stage : epi;
 #ifndef CDF_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CdfDeviceLatch attr_done;
+    if (attr_done.first()) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_spx_kernel<TA, TB, STACK2, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
 #endif
     const int tiles = (STACK2 ? 1 : cdf_cdiv(a.CA, TA)) * cdf_cdiv(a.CB, TB);
@@ -3126,10 +3118,9 @@ static int launch_wgrad_row3(const SpxWgradArgs& a, hipStream_t s) {
     constexpr size_t epi = (size_t)TA * (TB + 8) * sizeof(float);
     constexpr size_t lds = 2 * stage > epi ? 2 * stage : epi;
 #ifndef CDF_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CdfDeviceLatch attr_done;
+    if (attr_done.first()) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_row3_kernel<TA, TB, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
 #endif
     const int tiles = cdf_cdiv(a.CA, TA) * cdf_cdiv(a.CB, TB);

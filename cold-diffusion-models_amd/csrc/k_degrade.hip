@@ -685,14 +685,13 @@ extern "C" int cdf_blur_chain(const float* x, float* y, float* snap, const float
     if (nt > 1024) nt = 1024;
     if (nt < 64) nt = 64;
 #ifndef CDF_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CdfDeviceLatch attr_done;
+    if (attr_done.first()) {
         // allow > 64 KB dynamic LDS for every instantiation
 #define CDF_SET_LDS(K, SW) (void)hipFuncSetAttribute((const void*)blur_plane_lds_kernel<K, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
         CDF_SET_LDS(3, 8); CDF_SET_LDS(11, 8); CDF_SET_LDS(15, 8); CDF_SET_LDS(27, 8); CDF_SET_LDS(0, 8);
         CDF_SET_LDS(3, 4); CDF_SET_LDS(11, 4); CDF_SET_LDS(15, 4); CDF_SET_LDS(27, 4); CDF_SET_LDS(0, 4);
 #undef CDF_SET_LDS
-        attr_done = true;
     }
 #endif
 #define CDF_BLUR_CASE(K)                                                      \
@@ -712,10 +711,9 @@ extern "C" int cdf_blur_chain(const float* x, float* y, float* snap, const float
 template <int K>
 static int launch_blur_sep(const BlurArgs& a, int nt, size_t lds, hipStream_t s) {
 #ifndef CDF_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CdfDeviceLatch attr_done;
+    if (attr_done.first()) {
         (void)hipFuncSetAttribute((const void*)blur_plane_sep_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
 #endif
     CDF_LAUNCH((blur_plane_sep_kernel<K>), dim3(a.B * a.C), dim3(nt), lds, s, a);
@@ -786,10 +784,9 @@ extern "C" int cdf_pixelate_chain(const float* x, float* y, float* snap, const f
     PixArgs a{x, y, snap, img, sizes, t, B, C, H, step_lo, step_hi, mode};
     int nt = H * H >= 4096 ? 1024 : 256;
 #ifndef CDF_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CdfDeviceLatch attr_done;
+    if (attr_done.first()) {
         (void)hipFuncSetAttribute((const void*)pixelate_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
 #endif
     CDF_LAUNCH(pixelate_plane_kernel, dim3(B * C), dim3(nt), lds, CDF_S, a);

@@ -452,10 +452,9 @@ static int launch_dwconv7(const float* x, int ldx, const float* w, int ldw, cons
                           int ldy, int B, int H, int W, int C4, int flip, int accumulate, const float* res, int ldr, hipStream_t s) {
     constexpr size_t lds = ((size_t)(TBH + 6) * ((TBW + 6) * 8 + 4) + DW_TAPS * 8) * sizeof(float4);
 #ifndef CDF_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CdfDeviceLatch attr_done;
+    if (attr_done.first()) {
         (void)hipFuncSetAttribute((const void*)dwconv7_kernel<TBW, TBH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
 #endif
     const long long tiles = (long long)B * cdf_cdiv(H, TBH) * cdf_cdiv(W, TBW);

@@ -501,13 +501,12 @@ extern "C" int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, in
     const int G = 4 * (64 / LP);
     const size_t lds = (size_t)G * 2 * C * sizeof(float);
 #ifndef CDF_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CdfDeviceLatch attr_done;
+    if (attr_done.first()) {
         (void)hipFuncSetAttribute((const void*)layernorm_c_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)layernorm_c_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)layernorm_c_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)layernorm_c_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
 #endif
 #define CDF_LN_BWD(N) CDF_LAUNCH((layernorm_c_bwd_kernel<N>), dim3(nb), dim3(256), lds, CDF_S, dy, lddy, x, ldx, g, mean, rstd, dx, lddx, part, M, C, LP, add, ldadd)

@@ -25,6 +25,11 @@
 extern "C" {
 #endif
 
+/* Bumped whenever an exported signature changes incompatibly (rounds 1-3 all answered 1 while arguments were added: `tiled`,
+ * `onepass`, `slots`, `tune`).  cdf_abi_version() returns the value the LIBRARY was built with; a binding compares it with the
+ * header it was generated from before the first call (colddiff/_lib.py does) -- a mismatched pair would read shifted arguments. */
+#define CDF_ABI_VERSION 4
+
 #define CDF_E_INVALID (-1)
 #define CDF_E_UNSUPPORTED (-2)
 #define CDF_E_LAUNCH (-3)
@@ -152,8 +157,9 @@ int cdf_conv_gemm_bf16(const float* x, int ldx, const void* w_hi, const void* w_
 int cdf_conv_wgrad_bf16(const float* xa, int lda, const float* xb, int ldb, float* ws, int ldo, int B, int QH, int QW, int HA,
                         int WA, int sa, int HB, int WB, int sb, int CA, int CB, int ntaps, const int* tap_desc, int nsplit,
                         float* bsum, void* stream);
-/* RE-ENTRANCY.  Every entry point is a pure function of its arguments: the library keeps NO mutable process-wide state (the only
- * statics are one-time hipFuncSetAttribute(MaxDynamicSharedMemorySize) latches, idempotent).  What used to be process-wide tuning
+/* RE-ENTRANCY.  Every entry point is a pure function of its arguments: the library keeps NO mutable process-wide state that changes results (the only
+ * statics are caches keyed by the CURRENT DEVICE ordinal: one-time hipFuncSetAttribute(MaxDynamicSharedMemorySize) latches and the CU
+ * count the resident kernels size their grids by -- idempotent, a process may drive several devices).  What used to be process-wide tuning
  * setters is an explicit, OPTIONAL argument of the pre-split GEMM entry points: `const cdf_gemm_tuning* tune`, NULL = the defaults
  * below.  The fields only choose between kernels / tile shapes that compute the same sums (fp32 summation order aside), so two
  * models in one process -- or forward and backward threads -- can use different settings.  Fill a struct with

@@ -56,6 +56,9 @@ def main():
                                                             summary["conv_igemm_sp"]["write_bytes_per_launch"])
     summary["method"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over the same bench.py command; KiB -> bytes; "
                          "FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 bytes)")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import provenance
+    summary["provenance"] = provenance.stamp()
     json.dump(summary, open(out_json, "w"), indent=1)
     if out_md:
         with open(out_md, "w") as f:

@@ -50,8 +50,11 @@ def main():
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(txt + "\n")
     if len(sys.argv) > 3:
-        json.dump({k: {"calls": v[0], "total_ms": round(v[1], 4), "avg_us": round(1e3 * v[1] / v[0], 2)} for k, v in fam.items()},
-                  open(sys.argv[3], "w"), indent=1)
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import provenance
+        out = {k: {"calls": v[0], "total_ms": round(v[1], 4), "avg_us": round(1e3 * v[1] / v[0], 2)} for k, v in fam.items()}
+        out["_provenance"] = provenance.stamp()              # (not a kernel: readers skip keys that start with "_")
+        json.dump(out, open(sys.argv[3], "w"), indent=1)
 
 
 if __name__ == "__main__":
