@@ -109,7 +109,7 @@ class GemmTuning:
             self.set(halo=v[0], halo_min_tiles=v[1] if len(v) > 1 else 1)
         for var, field in (("COLDDIFF_SPX_SPLITK", "splitk"), ("COLDDIFF_SPX_DEEP", "deep"), ("COLDDIFF_SPX_HALO_BM", "halo_bm"),
                            ("COLDDIFF_SPX_MAX_BM", "max_bm"), ("COLDDIFF_SPX_DEPHASE", "dephase"), ("COLDDIFF_SPX_SMALL_N64", "small_n64"),
-                           ("COLDDIFF_WGRAD_ROW3", "wgrad_row3"), ("COLDDIFF_ROWHALO_STREAM", "rowhalo_stream"), ("COLDDIFF_WGRAD_SWIZZLE", "wgrad_swizzle"), ("COLDDIFF_WGRAD_STACK", "wgrad_stack")):
+                           ("COLDDIFF_WGRAD_ROW3", "wgrad_row3"), ("COLDDIFF_ROWHALO_STREAM", "rowhalo_stream"), ("COLDDIFF_WGRAD_SWIZZLE", "wgrad_swizzle"), ("COLDDIFF_WGRAD_STACK", "wgrad_stack"), ("COLDDIFF_RESIDENT_RESERVE", "resident_reserve")):
             if env(var):
                 self.set(**{field: int(env(var))})
         return self

@@ -138,13 +138,14 @@ class GradSync:
                 self.bucket_of[id(p)] = b
         self.order = list(range(len(self.bounds) - 1, -1, -1))
         self.comm_stream = torch.cuda.Stream() if self.on_gpu else None
-        if self.world > 1 and self.on_gpu and "COLDDIFF_ROWHALO_STREAM" not in os.environ:
+        if self.world > 1 and self.on_gpu:
             # The resident ("streaming") GEMM blocks hold every CU for a whole launch with a FIXED share of the tiles each; the collective
-            # kernels of the bucket all-reduces run concurrently and take CUs of their own, and a resident block that finds its CU taken
-            # runs its whole share after everybody else (the launch then takes up to twice as long).  One block per tile degrades
-            # gracefully instead, so multi-rank training uses that form (a per-tile work counter was measured: the atomic's return has to be
-            # waited for behind the wave's operand DMA, which costs what the resident form gains).
-            rt.tuning().set(rowhalo_stream=0)
+            # kernels of the bucket all-reduces run concurrently and need CUs of their own, and a resident block that finds its CU taken
+            # would run its whole share after everybody else (the launch then takes up to twice as long).  Multi-rank training therefore
+            # runs the SAME kernels as N = 1 with a few CUs left out of the resident grids (cdf_gemm_tuning.resident_reserve; RCCL's
+            # channels are one workgroup each, 32 covers its default channel count on this part) -- round 3 switched the resident form
+            # off instead, i.e. N > 1 ran other GEMM kernels than the N = 1 line.
+            rt.tuning().set(resident_reserve=int(os.environ.get("COLDDIFF_RESIDENT_RESERVE", "32")))
         self.armed = False
         self.uses = [0] * len(self.bounds)
         self.pending = None

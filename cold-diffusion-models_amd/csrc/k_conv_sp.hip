@@ -42,37 +42,6 @@ struct SpPhase {
     signed char dy[CDF_MAX_TAPS], dx[CDF_MAX_TAPS], wi[CDF_MAX_TAPS];
 };
 
-#ifndef CDF_PROFILE
-#define CDF_PROFILE 0    // 1: s_memtime stamps around the phases of the pre-split GEMM's K step (tools/_ablate probes only)
-#endif
-#if CDF_PROFILE
-__device__ unsigned long long cdf_prof[64 * 8 * 6];
-extern "C" int cdf_debug_read_prof(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(cdf_prof), sizeof(cdf_prof)); }
-// first 256 blocks of conv_igemm_rowhalo_kernel (thread 0): 100 MHz ticks in [prologue until the first data landed, K loop,
-// epilogue until its stores are acknowledged], tiles (tools/probes/run_prof_tile.py)
-__device__ unsigned long long cdf_prof_tile[256 * 4];
-extern "C" int cdf_debug_read_prof_tile(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(cdf_prof_tile), sizeof(cdf_prof_tile)); }
-#define CDF_PROF_T() wall_clock64()
-#endif
-#if !CDF_PROFILE
-#define CDF_PROF_T() 0ull
-#endif
-#ifndef CDF_HALO_PIPE
-#define CDF_HALO_PIPE 0  // 1: conv_igemm_halo_kernel reads the fragments of tap step s+1 under the MFMAs of step s (needs >= 4 weight stages).
-                         // Measured on MI355X: 2-3 % SLOWER than the plain loop (twice the VGPRs, same matrix-pipe gaps) => off.
-#endif
-#ifndef CDF_ROWHALO_TAPROW_OUTER
-#define CDF_ROWHALO_TAPROW_OUTER 1   // row-halo kernel K loop: 1 tap row / chunk / dx, 0 chunk / tap row / dx (see the kernel)
-#endif
-#ifndef CDF_SPX_PIPE
-#define CDF_SPX_PIPE 0   // 1: half-chunk software pipeline in conv_igemm_spx_kernel (fragment reads of the next half-chunk under the
-                         // current MFMAs, barrier between two MFMA groups).  Measured on MI355X: identical kernel and step times
-                         // (LDS latency after the barrier is not what idles the matrix pipe) at +36 VGPRs => off.
-#endif
-#ifndef CDF_ABLATE
-#define CDF_ABLATE 0     // tuning aid (tools/ablate.py), pre-split GEMM: 1 no operand DMA in the K loop, 2 no MFMAs, 4 no epilogue
-#endif                   // stores, 8 no fragment LDS reads.  Always 0 in the product build (results are wrong otherwise).
-
 // Block tile BM x BN, WM x WN waves of (BM/WM) x (BN/WN): the whole tile goes through LDS in one pass (cdf_epilogue.h).
 constexpr int CDF_SP_CPITCH = 136;
 constexpr size_t CDF_SP_EPI_LDS = (size_t)128 * CDF_SP_CPITCH * sizeof(float);
@@ -91,9 +60,6 @@ __device__ __forceinline__ void cdf_sp_epilogue(const Args& a, const SpPhase& ph
             for (int r = 0; r < 16; ++r)
                 cs[(wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * TN + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
-#if CDF_ABLATE & 4
-    if (acc[0][0][0] != 12345.678f) return;
-#endif
     cdf_epilogue_rows<BN, BM, 64 * WM * WN>(a, ph, a.y, cs, tile_m * BM, tile_n * BN, M, tid, [](int p) { return p; });
 }
 
@@ -144,16 +110,11 @@ __device__ __forceinline__ int cdf_sp_swizzle(int bid, int nblk) {
 // fp32 accumulate); NS = 1: single-pass bf16 operands (the hi planes only; al / bl are never read and their loads fold away).
 template <int NS>
 __device__ __forceinline__ void cdf_mma_sp(f32x16_t& acc, const bf16x8_v& ah, const bf16x8_v& al, const bf16x8_v& bh, const bf16x8_v& bl) {
-#if CDF_ABLATE & 2
-    asm volatile("" ::"v"(ah), "v"(al), "v"(bh), "v"(bl));
-    (void)acc;
-#else
     if constexpr (NS == 3) {
         acc = CDF_MFMA_BF16(al, bh, acc);
         acc = CDF_MFMA_BF16(ah, bl, acc);
     }
     acc = CDF_MFMA_BF16(ah, bh, acc);
-#endif
 }
 
 // All products of one K chunk (two k16 steps) of a wave tile, TERM-MAJOR: consecutive MFMAs go to different accumulators
@@ -164,7 +125,7 @@ __device__ __forceinline__ void cdf_mma_tile(f32x16_t (&acc)[MT][NT], const bf16
                                              const bf16x8_v (&bh)[2][NT], const bf16x8_v (&bl)[2][NT]) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        if constexpr (NS == 3 && !(CDF_ABLATE & 2)) {
+        if constexpr (NS == 3) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -564,11 +525,7 @@ __global__ void split_bf16_kernel(const float* x, int ldx, unsigned short* hi, u
     }
 }
 
-#if CDF_ABLATE & 1
-#define CDF_GLDS16_K(g, l) ((void)(g), (void)(l))       // tuning aid: no operand DMA inside the K loops of the LDS-resident-input kernels
-#else
 #define CDF_GLDS16_K(g, l) CDF_GLDS16(g, l)
-#endif
 
 struct SpxArgs {
     const unsigned short* x_hi;
@@ -730,7 +687,6 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
     auto fetch = [&](int buf) {
         unsigned short* st = smem + buf * STAGE;
         const bool cok = !ragged || (c0 + q8) < a.Cin;       // (false only in the ragged last chunk of a tap)
-#if !(CDF_ABLATE & 1)
 #pragma unroll
         for (int p = 0; p < SA; ++p) {
             unsigned short* seg = st + (wave * SA + p) * 16 * RE;
@@ -743,9 +699,6 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
             CDF_GLDS16(pb_hi[p], seg);                       // (weights are zero padded along K to the chunk size)
             if constexpr (NS == 3) CDF_GLDS16(pb_lo[p], seg + PLANE_B);
         }
-#else
-        (void)st; (void)cok;
-#endif
         const bool more = issued + 1 < niter;                // block-uniform
         issued += more ? 1 : 0;
         if (more) {
@@ -780,86 +733,6 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
     const int half = lane >> 5, l31 = lane & 31;
     const int sw = (l31 >> 2) & 3;                           // read-side swizzle (tile row offsets are multiples of 32)
     constexpr int PIECES = (NS == 3 ? 2 : 1) * (SA + SB);    // this wave's DMA instructions per chunk
-#if CDF_SPX_PIPE
-    // Software pipeline at HALF-chunk granularity (a chunk = two k16 steps).  Fragment set F[h] holds k-step h of a chunk:
-    //     top of step it : F[0] = chunk it, k-step 0 (read during the previous step)
-    //     read F[1] <- chunk it, k-step 1 ; MFMAs on F[0]              (F[1]'s LDS latency hides behind them)
-    //     wait: own DMA pieces of chunk it+1 landed ; barrier           (every wave has read ALL of chunk it: its stage is free,
-    //                                                                    and chunk it+1 is visible)
-    //     DMA chunk it+NSTAGE -> the stage of chunk it ; read F[0] <- chunk it+1, k-step 0 ; MFMAs on F[1]
-    // One barrier per chunk as before, but it sits BETWEEN two MFMA groups: the matrix pipe still has the first group in
-    // flight while the waves meet, and the group after the barrier has its operands in registers already.  Before, every
-    // barrier was followed by 8 ds_reads whose latency the two in-phase waves of a SIMD (one block per CU) waited out
-    // together.  NSTAGE chunks are in flight instead of NSTAGE - 1.  Same registers: the two sets are the old ah/al/bh/bl[2].
-    bf16x8_v ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
-    auto read_half = [&](int buf, int ks) {
-        const unsigned short* sa = smem + buf * STAGE;
-        const unsigned short* sb = sa + 2 * PLANE_A;
-        const int kc = ((ks * 2 + half) ^ sw) * 8;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int off = (wm * (BM / WM) + i * 32 + l31) * RE + kc;
-            ah[ks][i] = *(const bf16x8_v*)(sa + off);
-            al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int off = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
-            bh[ks][j] = *(const bf16x8_v*)(sb + off);
-            bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + off);
-        }
-    };
-    // term-major: the three MFMAs on one accumulator tile are MT*NT instructions apart instead of back to back
-    // (same summation order per accumulator)
-    auto mfma_half = [&](int ks) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = CDF_MFMA_BF16(al[ks][i], bh[ks][j], acc[i][j]);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bl[ks][j], acc[i][j]);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = CDF_MFMA_BF16(ah[ks][i], bh[ks][j], acc[i][j]);
-    };
-    if (niter > 0) {
-#pragma unroll
-        for (int d = 0; d < NSTAGE; ++d) fetch(d);           // chunks 0 .. NSTAGE-1 (past the end: the last one again, never read)
-    }
-    CDF_WAIT_DMA_LEAVE((NSTAGE - 1) * PIECES);               // chunk 0 has landed
-    CDF_LDS_BARRIER();
-    read_half(0, 0);
-    CDF_WAIT_LDS();                                          // (same bookkeeping reason as at the end of the loop body)
-    int buf = 0;
-    for (int it = 0; it < niter; ++it) {
-        // (the scheduling fences keep hipcc from sinking the fragment reads down to their first use, which is exactly the
-        // exposed LDS latency this loop exists to hide)
-        read_half(buf, 1);
-        CDF_SCHED_FENCE();
-        mfma_half(0);
-        CDF_SCHED_FENCE();                                   // (the MFMAs stay in front of the barrier: they cover F[1]'s latency and the wait)
-        CDF_WAIT_DMA_LEAVE((NSTAGE - 2) * PIECES);           // this wave's pieces of chunk it + 1 have landed ...
-        CDF_LDS_BARRIER();                                   // ... everybody's have, and chunk it is fully read (lgkmcnt(0) inside)
-        const int freed = buf;
-        buf = buf + 1 == NSTAGE ? 0 : buf + 1;
-        read_half(buf, 0);                                   // (after the last chunk: a stale stage, never multiplied)
-        CDF_SCHED_FENCE();
-        mfma_half(1);
-        fetch(freed);                                        // chunk it + NSTAGE into the stage just freed: address arithmetic and
-                                                             // DMA issue interleave with the MFMAs above (no fence in between)
-        CDF_SCHED_FENCE();
-        CDF_WAIT_LDS();                                      // free (F[0] was requested 12 MFMAs ago), but it tells hipcc's wait-count
-                                                             // pass that nothing is pending at the loop head: without it the first MFMA
-                                                             // of the next trip waits for the F[1] reads issued just before it
-    }
-#else
-#if CDF_ABLATE & 8
-    bf16x8_v abl_frag;
-    for (int e = 0; e < 8; ++e) abl_frag[e] = (short)(0x3f80 + lane + e);
-#endif
     // chunk c lives in stage c % NSTAGE; NSTAGE - 1 chunks are in flight ahead of the one being multiplied
     int fbuf = 0;                                            // stage of the next fetch
     if (niter > 0) {
@@ -899,82 +772,36 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int off = (wm * (BM / WM) + i * 32 + l31) * RE + kc;
-#if CDF_ABLATE & 8
-                ah[ks][i] = abl_frag; al[ks][i] = abl_frag; (void)off;
-#else
                 ah[ks][i] = *(const bf16x8_v*)(sa + off);
                 if constexpr (NS == 3) al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
-#endif
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int off = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
-#if CDF_ABLATE & 8
-                bh[ks][j] = abl_frag; bl[ks][j] = abl_frag; (void)off;
-#else
                 bh[ks][j] = *(const bf16x8_v*)(sb + off);
                 if constexpr (NS == 3) bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + off);
-#endif
             }
         }
     };
     auto mma_frags = [&]() {
-#if CDF_ABLATE & 2
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(ah[ks][i]), "v"(al[ks][i]));
-#pragma unroll
-            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(bh[ks][j]), "v"(bl[ks][j]));
-        }
-#else
         cdf_mma_tile<NS, MT, NT>(acc, ah, al, bh, bl);
-#endif
     };
-#if CDF_PROFILE
-    unsigned long long pt_dma = 0, pt_mma = 0, pt_wait = 0, pt_bar = 0;
-    const unsigned long long pt_begin = __builtin_readcyclecounter();
-#endif
     for (int it = 0; it < niter; ++it) {
         if (late) {
             mma_frags();
             CDF_SCHED_FENCE();
         }
-#if CDF_PROFILE
-        const unsigned long long p0 = __builtin_readcyclecounter();
-#endif
         fetch(fbuf);                                         // chunk it + NSTAGE - 1
-#if CDF_PROFILE
-        const unsigned long long p1 = __builtin_readcyclecounter();
-#endif
         fbuf = fbuf + 1 == NSTAGE ? 0 : fbuf + 1;
         const unsigned short* sa = smem + buf * STAGE;
         const unsigned short* sb = sa + 2 * PLANE_A;
         buf = buf + 1 == NSTAGE ? 0 : buf + 1;
         read_frags(sa, sb);
         if (!late) mma_frags();
-#if CDF_PROFILE
-        asm volatile("s_nop 0" ::"v"(acc[0][0][0]));          // (the last MFMA result is due: the matrix work of the step is done here)
-        const unsigned long long p2 = __builtin_readcyclecounter();
-#endif
         CDF_WAIT_DMA_LEAVE((NSTAGE - 2) * PIECES);           // this wave's pieces of chunk it + 1 have landed ...
-#if CDF_PROFILE
-        const unsigned long long p3 = __builtin_readcyclecounter();
-#endif
         CDF_LDS_BARRIER();                                   // ... and so have everybody else's; chunk it is fully consumed
-#if CDF_PROFILE
-        const unsigned long long p4 = __builtin_readcyclecounter();
-        pt_dma += p1 - p0; pt_mma += p2 - p1; pt_wait += p3 - p2; pt_bar += p4 - p3;
-#endif
     }
     if (late) mma_frags();                                   // the fragments of the last chunk
-#if CDF_PROFILE
-    if (lane == 0 && blockIdx.x < 64) {
-        unsigned long long* o = cdf_prof + (blockIdx.x * NW + wave) * 6;
-        o[0] = pt_dma; o[1] = pt_mma; o[2] = pt_wait; o[3] = pt_bar; o[4] = __builtin_readcyclecounter() - pt_begin; o[5] = niter;
-    }
-#endif
-#endif
     CDF_WAIT_DMA_LEAVE(0);                                   // the tail fetches (never read) must not land in the epilogue tile
     CDF_LDS_BARRIER();
 
@@ -1172,87 +999,6 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
 #pragma unroll
     for (int u = 0; u < NB - 1; ++u) fetch_b(u / 9, u % 9, u);  // (NB - 1 <= 9: all in chunk 0)
     int rd = 0;                                              // weight stage of the current step
-  if constexpr (CDF_HALO_PIPE != 0 && NB >= 4 && MT == 1) {
-    // Software pipeline over whole tap steps: the fragments of step s+1 are read while the MFMAs of step s run, so the barrier
-    // at the end of a step has to make the data of step s+2 visible (hence a wave waits for ITS pieces of step s+2 before it);
-    // in-kernel timing of the unpipelined loop: 12 reads -> their latency -> 12 MFMAs -> barrier, the matrix pipe idle for the
-    // first and the last part of every step.  Two fragment sets; NB >= 4 weight stages.
-    CDF_WAIT_DMA_LEAVE((NB - 3) * PB);                       // halo 0 and the weights of steps 0 and 1 have landed
-    CDF_LDS_BARRIER();
-    bf16x8_v fa_h[2][2], fa_l[2][2], fb_h[2][2][NT], fb_l[2][2][NT];     // [set][k-step]
-    auto read_frags = [&](int set, const unsigned short* sa, int t, int stage) {
-        const int row = row0[0] + (int)ph.dy[t] * HW2 + (int)ph.dx[t];
-        const int swa = (row >> 2) & 3;
-        const unsigned short* sb = bst0 + stage * BSTAGE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int off = row * RE + ((ks * 2 + half) ^ swa) * 8;
-            fa_h[set][ks] = *(const bf16x8_v*)(sa + off);
-            fa_l[set][ks] = *(const bf16x8_v*)(sa + PLANE_A + off);
-            const int kc = ((ks * 2 + half) ^ swb) * 8;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int offb = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
-                fb_h[set][ks][j] = *(const bf16x8_v*)(sb + offb);
-                fb_l[set][ks][j] = *(const bf16x8_v*)(sb + PLANE_B + offb);
-            }
-        }
-    };
-    auto mfma_set = [&](int set) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[0][j] = CDF_MFMA_BF16(fa_l[set][ks], fb_h[set][ks][j], acc[0][j]);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[0][j] = CDF_MFMA_BF16(fa_h[set][ks], fb_l[set][ks][j], acc[0][j]);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[0][j] = CDF_MFMA_BF16(fa_h[set][ks], fb_h[set][ks][j], acc[0][j]);
-        }
-    };
-    read_frags(0, abuf0, 0, 0);
-    CDF_WAIT_LDS();
-    for (int c = 0; c < nchunks; ++c) {
-        const unsigned short* sa = abuf0 + (c & 1) * ABUF;
-        const unsigned short* sa_next = abuf0 + ((c + 1) & 1) * ABUF;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            // fragments of step + 1 (past the last step: stale data, never multiplied) ...
-            const int rd1 = rd + 1 == NB ? 0 : rd + 1;
-            read_frags((t + 1) & 1, t + 1 < 9 ? sa : sa_next, (t + 1) % 9, rd1);
-            CDF_SCHED_FENCE();
-            // ... under the MFMAs of this step
-            mfma_set(t & 1);
-            // requests: one halo segment of the next chunk (first TA steps), the weights of step + NB-1 into the stage read a step ago
-            if (t < TA) fetch_a(t, (c + 1) & 1);
-            if (t == TA - 1 && c + 2 < nchunks) advance_a();
-            fetch_b(t + NB - 1 < 9 ? c : c + 1, (t + NB - 1) % 9, rd == 0 ? NB - 1 : rd - 1);
-            rd = rd1;
-            CDF_SCHED_FENCE();
-            // this wave's pieces of step + 2 (requested NB - 3 steps ago) have landed; still in flight: the requests since then
-            switch (cdf_halo_parts(t, NB - 3, TA)) {
-                case 0: CDF_WAIT_DMA_LEAVE((NB - 3) * PB); break;
-                case 1: CDF_WAIT_DMA_LEAVE((NB - 3) * PB + PA); break;
-                case 2: CDF_WAIT_DMA_LEAVE((NB - 3) * PB + 2 * PA); break;
-                default: CDF_WAIT_DMA_LEAVE((NB - 3) * PB + 3 * PA); break;
-            }
-            CDF_LDS_BARRIER();                               // (lgkmcnt(0) inside: the fragments of step + 1 are in registers)
-            CDF_WAIT_LDS();                                  // (no-op after the barrier's own wait; tells hipcc's wait-count pass so,
-                                                             // else it parks an lgkmcnt(0) between the next reads and the MFMAs)
-        }
-        // nine steps: the next chunk's first fragments sit in set 1 -- every chunk starts from set 0 (48 register moves per
-        // nine steps; indexing the sets by a runtime parity would put them in scratch)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            fa_h[0][ks] = fa_h[1][ks];
-            fa_l[0][ks] = fa_l[1][ks];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                fb_h[0][ks][j] = fb_h[1][ks][j];
-                fb_l[0][ks][j] = fb_l[1][ks][j];
-            }
-        }
-    }
-  } else {                                                 // (3 weight stages: W = 128 with BN = 128)
     CDF_WAIT_DMA_LEAVE((NB - 2) * PB);                       // the halo and the weights of step 0 have landed
     CDF_LDS_BARRIER();
     bf16x8_v ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
@@ -1327,7 +1073,6 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
         }
     }
     if (late) mma_frags();                                   // the fragments of the last step
-  }
     CDF_WAIT_DMA_LEAVE(0);                                   // the tail requests (never read) must not land in the epilogue tile
     CDF_LDS_BARRIER();
 
@@ -1370,7 +1115,6 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int M = a.B * a.QH * a.QW;
     const int tiles_n = (a.Cout + BN - 1) / BN, tiles_m = M / BM;
-    const unsigned long long pt0 = CDF_PROF_T();             // (profile builds only)
     const int tile = cdf_sp_swizzle(blockIdx.x, tiles_m * tiles_n);
     const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
     const SpPhase& ph = a.ph[0];
@@ -1446,7 +1190,6 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
     for (int u = 0; u < NB - 1; ++u) fetch_b(0, ph.wi[u], u);
     CDF_WAIT_DMA_LEAVE((NB - 2) * PB);
     CDF_LDS_BARRIER();
-    const unsigned long long pt1 = CDF_PROF_T();
     bf16x8_v ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
     const bool late = a.dephase != 0 && wave >= NW / 2;      // (wave-uniform)
     if (late) {
@@ -1464,9 +1207,6 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
     }
     auto mma_frags = [&]() { cdf_mma_tile<NS, MT, NT>(acc, ah, al, bh, bl); };
     int rd = 0, par = 0;                                     // weight stage / row buffer of the current step
-#if CDF_PROFILE
-    unsigned long long qt[6] = {0, 0, 0, 0, 0, 0};            // shader clocks in: DMA issue, fragment reads (until landed), MFMAs, DMA wait, barrier; steps
-#endif
     static_assert(NB == 4, "the weights of a step are requested exactly one tap-row group (3 steps) ahead");
     if constexpr (NCH > 0) {
     // K loop with a compile-time chunk count, fully unrolled: tap row, chunk, dx -- the chunks of one tap row in consecutive groups.  A
@@ -1481,17 +1221,11 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
 #pragma unroll
             for (int i3 = 0; i3 < 3; ++i3) {
                 const int t = 3 * g + i3;
-#if CDF_PROFILE
-                const unsigned long long q0 = __builtin_readcyclecounter();
-#endif
                 // the group one ahead: (g, c + 1), or (g + 1, 0) after the last chunk; past the end the last group again (idle buffer / stage)
                 const bool lastc = c + 1 == NCH;
                 const int nc = lastc ? (g < 2 ? 0 : c) : c + 1, ng = lastc && g < 2 ? g + 1 : g;
                 if (i3 == 0) fetch_a(nc, ph.dy[3 * ng], par ^ 1);
                 fetch_b(nc, ph.wi[3 * ng + i3], rd == 0 ? NB - 1 : rd - 1);
-#if CDF_PROFILE
-                const unsigned long long q1 = __builtin_readcyclecounter();
-#endif
                 const unsigned short* sa = abuf0 + par * ABUF;
                 const unsigned short* sb = bst0 + rd * BSTAGE;
                 rd = rd + 1 == NB ? 0 : rd + 1;
@@ -1520,30 +1254,14 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
                     CDF_SCHED_FENCE();                           // (the reads overwrite the fragments just multiplied: hoisting them doubles the live set)
                 }
                 read_frags();
-#if CDF_PROFILE
-                CDF_WAIT_LDS();
-                const unsigned long long q2 = __builtin_readcyclecounter();
-#endif
                 if (!late) mma_frags();
-#if CDF_PROFILE
-                asm volatile("s_nop 0" ::"v"(acc[0][0][0]));          // (the last MFMA result is due here)
-                const unsigned long long q3 = __builtin_readcyclecounter();
-#endif
                 // the weights of step + 1 (requested 2 steps ago, AFTER that step's row requests) have landed; still in flight: the
                 // requests of the last two steps -- two weight steps, plus one group of rows if one of them was a group's first step
                 if (i3 <= 1)
                     CDF_WAIT_DMA_LEAVE((NB - 2) * PB + PAG);
                 else
                     CDF_WAIT_DMA_LEAVE((NB - 2) * PB);
-#if CDF_PROFILE
-                const unsigned long long q4 = __builtin_readcyclecounter();
-#endif
                 CDF_LDS_BARRIER();
-#if CDF_PROFILE
-                // (late waves multiply between q1 and q2: their "fragment reads" column contains their MFMAs)
-                const unsigned long long q5 = __builtin_readcyclecounter();
-                qt[0] += q1 - q0; qt[1] += q2 - q1; qt[2] += q3 - q2; qt[3] += q4 - q3; qt[4] += q5 - q4; ++qt[5];
-#endif
                 if (i3 == 2) par ^= 1;
             }
         }
@@ -1553,9 +1271,6 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int g = t / 3, i3 = t - 3 * g;
-#if CDF_PROFILE
-            const unsigned long long q0 = __builtin_readcyclecounter();
-#endif
             if (i3 == 0) {                                   // the next tap row's input rows (past the end: the last group again, into the idle buffer)
                 const bool end = g == 2 && c + 1 >= nchunks;
                 fetch_a(g == 2 && !end ? c + 1 : c, ph.dy[3 * (g == 2 ? (end ? 2 : 0) : g + 1)], par ^ 1);
@@ -1564,9 +1279,6 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
                 const int cw = t + NB - 1 < 9 ? c : c + 1;
                 fetch_b(cw < nchunks ? cw : nchunks - 1, ph.wi[(t + NB - 1) % 9], rd == 0 ? NB - 1 : rd - 1);
             }
-#if CDF_PROFILE
-            const unsigned long long q1 = __builtin_readcyclecounter();
-#endif
             const unsigned short* sa = abuf0 + par * ABUF;
             const unsigned short* sb = bst0 + rd * BSTAGE;
             rd = rd + 1 == NB ? 0 : rd + 1;
@@ -1595,30 +1307,14 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
                 CDF_SCHED_FENCE();                           // (the reads overwrite the fragments just multiplied: hoisting them doubles the live set)
             }
             read_frags();
-#if CDF_PROFILE
-            CDF_WAIT_LDS();
-            const unsigned long long q2 = __builtin_readcyclecounter();
-#endif
             if (!late) mma_frags();
-#if CDF_PROFILE
-            asm volatile("s_nop 0" ::"v"(acc[0][0][0]));          // (the last MFMA result is due here)
-            const unsigned long long q3 = __builtin_readcyclecounter();
-#endif
             // the weights of step + 1 (requested 2 steps ago, AFTER that step's row requests) have landed; still in flight: the
             // requests of the last two steps -- two weight steps, plus one group of rows if one of them was a group's first step
             if (i3 <= 1)
                 CDF_WAIT_DMA_LEAVE((NB - 2) * PB + PAG);
             else
                 CDF_WAIT_DMA_LEAVE((NB - 2) * PB);
-#if CDF_PROFILE
-            const unsigned long long q4 = __builtin_readcyclecounter();
-#endif
             CDF_LDS_BARRIER();
-#if CDF_PROFILE
-            // (late waves multiply between q1 and q2: their "fragment reads" column contains their MFMAs)
-            const unsigned long long q5 = __builtin_readcyclecounter();
-            qt[0] += q1 - q0; qt[1] += q2 - q1; qt[2] += q3 - q2; qt[3] += q4 - q3; qt[4] += q5 - q4; ++qt[5];
-#endif
             if (i3 == 2) par ^= 1;
         }
     }
@@ -1626,22 +1322,8 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
     if (late) mma_frags();
     CDF_WAIT_DMA_LEAVE(0);
     CDF_LDS_BARRIER();
-    const unsigned long long pt2 = CDF_PROF_T();
 
     cdf_sp_epilogue<BM, BN, WM, WN>(a, ph, acc, (float*)smem_raw, tile_m, tile_n, M, tid);
-#if CDF_PROFILE
-    CDF_WAIT_DMA_LEAVE(0);                                   // (count the epilogue until its stores are acknowledged)
-    if (tid == 0 && blockIdx.x < 256) {
-        unsigned long long* o = cdf_prof_tile + blockIdx.x * 4;
-        o[0] = pt1 - pt0; o[1] = pt2 - pt1; o[2] = CDF_PROF_T() - pt2; o[3] = 1;
-    }
-    if (lane == 0 && blockIdx.x < 64) {
-        unsigned long long* o = cdf_prof + (blockIdx.x * NW + wave) * 6;
-        for (int i = 0; i < 6; ++i) o[i] = qt[i];
-    }
-#else
-    (void)pt0; (void)pt1; (void)pt2;
-#endif
 }
 
 // ================================================================================================
@@ -1658,13 +1340,10 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
 //     LDS:  rows 0 | weights 0 | weights 1 | rows 1 | weights 2 | ...        staging [128][BN + 8] floats from "rows 1" on
 // K loop: tap row, chunk, dx (fully unrolled, see above); 8 waves (4 x 2 of 64 x 64), late waves de-phased as in the other kernels.
 // ================================================================================================
-// BM = 512 (with BN = 64, at 128-pixel width): the 64-channel outputs.  Their 256 x 64 tiles give a wave 12 MFMAs per tap step against the same
-// barrier, DMA issue and A-fragment reads as a 256 x 128 tile's 24 -- the K loop of 128 -> 64 at 128 x 128 keeps the matrix cores 64 % busy.  512
-// pixels x 64 channels as 8 x 1 waves of 64 x 64 is the 256 x 128 tile's per-wave work again (row buffers of 4 image rows; staging in two passes of 256 rows).
 template <int W, int BN, int NS = 3, int NCH = 2, int BM = 256>
 __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_stream_kernel(SpxArgs a) {
     constexpr int WM = BM / 64, WN = 8 / WM, NW = 8, BK = 32, RE = 32, MT = BM / WM / 32, NB = 3;
-    static_assert((BM == 256 || BM == 512) && WM * WN == 8 && MT == 2, "8 waves of 64-row tiles");
+    static_assert(BM == 256 && WM * WN == 8 && MT == 2, "8 waves (4 x 2) of 64-row tiles");
     static_assert(NCH % 2 == 0, "an even number of tap-row groups per tile returns the pipeline to row buffer 0");
     constexpr int EROWS = BM / 2;                                                 // rows per epilogue pass
     constexpr int TH = BM / W, HW2 = W + 2, RH = TH * HW2;
@@ -1916,9 +1595,6 @@ __device__ __forceinline__ void cdf_bf16x8_accum(float* acc8, const u32x4_v& h, 
 // read: the 16 lanes of a group hand in the addresses of a [4 px][16 ch] block (lane t: pixel t>>2, channels
 // 4(t&3)..+3) and lane t receives channel t's 4 pixels.  Pitch T+32 puts the 4 pixel rows of a group 16 banks
 // apart and the second group of the 32-lane pass 8 banks further: conflict-free.
-#ifndef CDF_WGRAD_TR
-#define CDF_WGRAD_TR 1
-#endif
 
 template <int T>
 struct SpxWgradSlot {                  // one operand's share of a thread's loads for a 32-pixel chunk
@@ -2074,7 +1750,6 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
             bf16x8_v ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-#if CDF_WGRAD_TR
                 const unsigned short* pa = sa + tra + ks * 16 * SA::PITCH + i * 32;
                 const bf16x4_v h0 = cdf_lds_read_tr16(pa), h1 = cdf_lds_read_tr16(pa + 4 * SA::PITCH);
                 ah[i] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -2082,18 +1757,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
                     const bf16x4_v l0 = cdf_lds_read_tr16(pa + PLANE_A), l1 = cdf_lds_read_tr16(pa + PLANE_A + 4 * SA::PITCH);
                     al[i] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
-#else
-                const unsigned short* pa = sa + (ks * 16 + half * 8) * SA::PITCH + wm * (TA / 2) + i * 32 + l31;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    ah[i][e] = (short)pa[e * SA::PITCH];
-                    al[i][e] = (short)pa[PLANE_A + e * SA::PITCH];
-                }
-#endif
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-#if CDF_WGRAD_TR
                 const unsigned short* pb = sb + trb + ks * 16 * SB::PITCH + j * 32;
                 const bf16x4_v h0 = cdf_lds_read_tr16(pb), h1 = cdf_lds_read_tr16(pb + 4 * SB::PITCH);
                 bh[j] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -2101,14 +1767,6 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
                     const bf16x4_v l0 = cdf_lds_read_tr16(pb + PLANE_B), l1 = cdf_lds_read_tr16(pb + PLANE_B + 4 * SB::PITCH);
                     bl[j] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
-#else
-                const unsigned short* pb = sb + (ks * 16 + half * 8) * SB::PITCH + wn * (TB / 2) + j * 32 + l31;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    bh[j][e] = (short)pb[e * SB::PITCH];
-                    bl[j][e] = (short)pb[PLANE_B + e * SB::PITCH];
-                }
-#endif
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -2117,17 +1775,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
                     cdf_mma_sp<NS>(acc[i][j], ah[i], al[i], bh[j], bl[j]);
                 }
         }
-#if !(CDF_WG_ABLATE & 8)
         if (it + 1 < niter) store_lds(buf ^ 1);
-#endif
         __syncthreads();
     }
-#if CDF_WG_ABLATE & 4
-    if (a.m_per_split != -12345) {
-        if (acc[0][0][0] == 123.456f && acc[1][0][3] == 1.f && acc[2][NT - 1][5] == 2.f) a.out[0] = 1.f;
-        return;
-    }
-#endif
 
     float* red = (float*)smem_raw;
     if (do_bsum) {                                 // [32 px][TB] partial column sums -> one row
@@ -2187,9 +1837,6 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_spx_kernel(SpxWgradArgs a) 
 // linear in the chunk index (no per-tap decode); the row / image borders are a per-lane mask.  8 waves (32 x TB/WB tiles, three
 // accumulator sets), one block per CU; grid (tiles, 3 tap rows, splits) in the XCD-aware order of cdf_wgrad_block.
 // ================================================================================================
-#ifndef CDF_WG_ABLATE
-#define CDF_WG_ABLATE 0   // probe builds only (tools/wg_ablate.py): 1 no global loads in the loop, 4 no slab stores, 8 no LDS stores in the loop
-#endif
 template <int TA, int TB, int NS = 3>
 __global__ void __launch_bounds__(512, 1) conv_wgrad_row3_kernel(SpxWgradArgs a) {
     constexpr int BK = 32, NTHR = 512;
@@ -2308,9 +1955,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_row3_kernel(SpxWgradArgs a)
     __syncthreads();
     for (int it = 0; it < niter; ++it) {
         const int buf = it & 1;
-#if !(CDF_WG_ABLATE & 1)
         if (it + 1 < niter) load_global(it + 1);
-#endif
         const unsigned short* sa = smem + buf * STAGE;
         const unsigned short* sb = sa + 2 * PLANE_A;
 #pragma unroll
@@ -2342,17 +1987,9 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_row3_kernel(SpxWgradArgs a)
                 }
             }
         }
-#if !(CDF_WG_ABLATE & 8)
         if (it + 1 < niter) store_lds(buf ^ 1);
-#endif
         __syncthreads();
     }
-#if CDF_WG_ABLATE & 4
-    if (a.m_per_split != -12345) {
-        if (acc[0][0][0] == 123.456f && acc[1][0][3] == 1.f && acc[2][NT - 1][5] == 2.f) a.out[0] = 1.f;
-        return;
-    }
-#endif
 
     float* red = (float*)smem_raw;
     if (do_bsum) {                                 // [32 px][TB] partial column sums -> one row
@@ -2425,9 +2062,6 @@ struct KvCtxArgs {
     int n, dim, P, tiles_per_block;
 };
 
-#ifndef CDF_KVCTX_ABLATE
-#define CDF_KVCTX_ABLATE 0   // probe builds only: 1 no context phase, 2 no k|v stores, 4 no GEMM MFMAs
-#endif
 // BK = 64 when dim % 64 == 0 (a dim = 64 tile is ONE chunk: all of the next tile's operands travel during the current tile's store /
 // context phase), else 32.  One LDS operand stage (the next chunk waits in registers), aliased by the staging tile.
 template <int SPLIT, int BK>
@@ -2544,15 +2178,11 @@ __global__ void __launch_bounds__(512, 1) linattn_kvctx_kernel(KvCtxArgs a) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-#if CDF_KVCTX_ABLATE & 4
-                        acc[i][j][0] += (float)(ah[i][0] + bh[j][0] + al[i][0] + bl[j][0]);
-#else
                         if (SPLIT > 1) {
                             acc[i][j] = CDF_MFMA_BF16(al[i], bh[j], acc[i][j]);
                             acc[i][j] = CDF_MFMA_BF16(ah[i], bl[j], acc[i][j]);
                         }
                         acc[i][j] = CDF_MFMA_BF16(ah[i], bh[j], acc[i][j]);
-#endif
                     }
             }
         }
@@ -2581,16 +2211,13 @@ __global__ void __launch_bounds__(512, 1) linattn_kvctx_kernel(KvCtxArgs a) {
         __syncthreads();
         if (!ctx_wave) {
             // ---- k | v rows out: 64 float4 = one 1 KB row per wave instruction (waves 4-7: the stores' back-pressure stalls nobody else)
-#if !(CDF_KVCTX_ABLATE & 2)
             float* dst = kvb + (size_t)tile * BM * a.ldkv;
 #pragma unroll 4
             for (int e = tid - 256; e < BM * (BN / 4); e += 256) {
                 const int px = e >> 6, c4 = (e & 63) * 4;
                 *(float4*)(dst + (size_t)px * a.ldkv + c4) = *(const float4*)(stg + px * SP + c4);
             }
-#endif
         } else {
-#if !(CDF_KVCTX_ABLATE & 1)
             // ---- context of head ch: acc = acc * exp(m_old - m) + exp(k - m)^T v over the tile's 128 pixels
             const float* kcol = stg + half * SP + ch * LD + l31;                       // pixel 2 s + half, column d = l31
             const float* vcol = kcol + HD;
@@ -2607,7 +2234,6 @@ __global__ void __launch_bounds__(512, 1) linattn_kvctx_kernel(KvCtxArgs a) {
                 psum += pk;
                 cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pk, vcol[2 * sx * SP], cacc, 0, 0, 0);
             }
-#endif
         }
         __syncthreads();                                      // the staging tile (and sstat) are rewritten by the next trip
     }
@@ -2801,7 +2427,7 @@ static int fill_phases(SpPhase* ph, int nphase, const int* pd, const char* who) 
 // ---- tuning: an explicit, optional argument of the GEMM entry points (include/colddiff.h: cdf_gemm_tuning) -----------------------------
 // No mutable process-wide state: a NULL pointer means these defaults, anything else is read once per call.  The choices only select
 // between kernels / tile shapes that compute the same sums (fp32 summation order aside).
-static const cdf_gemm_tuning kTuneDefault = {(int)sizeof(cdf_gemm_tuning), 0, 0, 0, 1, 1, 1, 47, 1, 0, 1, 1, 1, 1, 1};
+static const cdf_gemm_tuning kTuneDefault = {(int)sizeof(cdf_gemm_tuning), 0, 0, 0, 1, 1, 1, 47, 1, 0, 1, 1, 1, 1, 1, 0};
 extern "C" int cdf_gemm_tuning_default(cdf_gemm_tuning* t) {
     CDF_REQUIRE(t, "cdf_gemm_tuning_default: null pointer");
     *t = kTuneDefault;
@@ -2813,11 +2439,11 @@ static bool cdf_tune_ok(const cdf_gemm_tuning* t) {
     const bool bm_ok = t->tile_bm == 0 || t->tile_bm == 64 || t->tile_bm == 128 || (t->tile_bm == 256 && (t->tile_bn == 0 || t->tile_bn == 128));
     const bool bn_ok = t->tile_bn == 0 || t->tile_bn == 64 || t->tile_bn == 128;
     return t->size == (int)sizeof(cdf_gemm_tuning) && bm_ok && bn_ok && (t->max_bm == 0 || t->max_bm == 128 || t->max_bm == 256) &&
-           (t->halo_bm == 0 || t->halo_bm == 128 || t->halo_bm == 256) && t->halo >= 0 && t->halo <= 127 && t->halo_min_tiles >= 0;
+           (t->halo_bm == 0 || t->halo_bm == 128 || t->halo_bm == 256) && t->halo >= 0 && t->halo <= 127 && t->halo_min_tiles >= 0 && t->resident_reserve >= 0 && t->resident_reserve <= 248 && (t->rowhalo_stream == 0 || t->rowhalo_stream == 1);
 }
 #define CDF_TUNE_CHECK(t, who)                                                                                                          \
     CDF_REQUIRE(cdf_tune_ok(t), who ": bad cdf_gemm_tuning (size %d, expected %d; tile_bm 0/64/128/256 (256 with tile_bn 0/128), tile_bn 0/64/128, " \
-                                    "max_bm 0/128/256, halo_bm 0/128/256, halo 0..127): start from cdf_gemm_tuning_default",            \
+                                    "max_bm 0/128/256, halo_bm 0/128/256, halo 0..127, rowhalo_stream 0/1, resident_reserve 0..248): start from cdf_gemm_tuning_default",            \
                 (t) ? (t)->size : 0, (int)sizeof(cdf_gemm_tuning))
 
 template <int NS, int BM, int BN, int WM, int WN, int NSTAGE, int OCC = 512 / (64 * WM * WN)>
@@ -2882,7 +2508,7 @@ static int launch_igemm_halo(const SpxArgs& a, int M, hipStream_t s) {
 }
 
 template <int NS, int W, int BN>
-static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s, bool stream_tiles = false) {
+static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s, bool stream_tiles = false, int reserve = 0) {
     constexpr int TH = 256 / W, RH = TH * (W + 2), HRP = (RH + 15) / 16 * 16;
     constexpr size_t stages = (size_t)2 * 2 * HRP * 64 + (size_t)4 * 2 * BN * 64;
     constexpr size_t epi = (size_t)256 * (BN + 8) * sizeof(float);
@@ -2907,7 +2533,12 @@ static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s, bool str
             (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_stream_kernel<W, BN, NS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
 #endif
-        const int ncu = cdf_num_cus(), grid = tiles < ncu ? tiles : ncu;
+        // resident blocks: one per CU -- minus the CUs the caller keeps free for kernels that run concurrently (cdf_gemm_tuning.resident_reserve:
+        // the collectives of a multi-rank gradient exchange; a resident block that finds its CU taken would run its fixed share of the tiles
+        // after everybody else), in whole XCD rounds
+        int ncu = cdf_num_cus() - (reserve + 7) / 8 * 8;
+        if (ncu < 8) ncu = 8;
+        const int grid = tiles < ncu ? tiles : ncu;
         if (a.Cin == 64)
             CDF_LAUNCH((conv_igemm_rowhalo_stream_kernel<W, BN, NS, 2>), dim3(grid), dim3(512), lds_s, s, a);
         else
@@ -2916,34 +2547,11 @@ static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s, bool str
     }
     // two channel chunks (64 input channels: a pixel is ONE 128-byte line per plane): the unrolled tap-row-outermost K loop, 64 -> 128
     // at 128 x 128 0.294 -> 0.283 ms (GELU epilogue 0.332 -> 0.326); with four chunks (128 channels) it measured +-0.5 %: not instantiated
-    if (CDF_ROWHALO_TAPROW_OUTER && a.Cin == 64)
+    if (a.Cin == 64)
         CDF_LAUNCH((conv_igemm_rowhalo_kernel<W, BN, NS, 2>), dim3(tiles), dim3(512), lds, s, a);
     else
         CDF_LAUNCH((conv_igemm_rowhalo_kernel<W, BN, NS, 0>), dim3(tiles), dim3(512), lds, s, a);
     return cdf_check_launch("conv_igemm_rowhalo");
-}
-
-// 512-pixel x 64-channel resident tiles at 128-pixel width (conv_igemm_rowhalo_stream_kernel<.., BM = 512>): 64 / 128 input channels
-template <int NS>
-static int launch_igemm_rowhalo_stream512(const SpxArgs& a, int M, hipStream_t s) {
-    constexpr int W = 128, BN = 64, TH = 512 / W, RH = TH * (W + 2), HRP = (RH + 15) / 16 * 16;
-    constexpr size_t st_a = (size_t)2 * HRP * 64, st_b = (size_t)2 * BN * 64, off_a1 = st_a + 2 * st_b;
-    constexpr size_t cs = (size_t)256 * (BN + 8) * 4;
-    constexpr size_t lds_s = off_a1 + (st_a + st_b > cs ? st_a + st_b : cs);
-    static_assert(lds_s <= 160 * 1024, "512-pixel streaming tile does not fit the LDS");
-#ifndef CDF_EMU
-    static CdfDeviceLatch attr_done;
-    if (attr_done.first()) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_stream_kernel<W, BN, NS, 2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_stream_kernel<W, BN, NS, 4, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
-#endif
-    const int tiles = (M / 512) * cdf_cdiv(a.Cout, BN), ncu = cdf_num_cus(), grid = tiles < ncu ? tiles : ncu;
-    if (a.Cin == 64)
-        CDF_LAUNCH((conv_igemm_rowhalo_stream_kernel<W, BN, NS, 2, 512>), dim3(grid), dim3(512), lds_s, s, a);
-    else
-        CDF_LAUNCH((conv_igemm_rowhalo_stream_kernel<W, BN, NS, 4, 512>), dim3(grid), dim3(512), lds_s, s, a);
-    return cdf_check_launch("conv_igemm_rowhalo_stream512");
 }
 
 // Split-K factor of the generic pre-split GEMM for grids far below one 64-row tile per CU: the smallest divisor of the tap count
@@ -3004,16 +2612,10 @@ static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cou
         // row-halo kernel: 256-pixel tiles, input shared by the dx taps only.  Bit 32 (default): the > 64-channel outputs at
         // 128-pixel width, where it beats the generic 256 x 128 kernel (64 -> 128: 0.325 -> 0.298 ms); bit 64: wherever it applies
         // (at 64 pixels the halo kernel's 256-pixel tile stays ahead, 0.240 vs 0.252 ms)
-        // 64-channel outputs at 128-pixel width from 64 / 128 input channels: resident 512-pixel x 64-channel tiles (rowhalo_stream bit 2; OFF by
-        // default: 6 % faster per launch than the LDS-resident-input kernel, but the per-tap-row input rows make it fetch 3.2x the bytes
-        // -- 1194 vs 370 MB per launch for 128 -> 64 at 128 x 128 -- and the step does not resolve the difference)
-        if ((T.rowhalo_stream & 2) && dx_ok && W == 128 && n64 && Cout <= 64 && (Cin == 64 || Cin == 128) && H % 4 == 0 && M % 512 == 0 &&
-            (M / 512) >= ((T.rowhalo_stream & 4) ? 1 : 256) && (T.halo & 8))
-            return launch_igemm_rowhalo_stream512<NS>(a, M, s);
         if (dx_ok && M % 256 == 0 && ((T.halo & 64) || ((T.halo & 32) && W == 128 && !n64 && (long long)(M / 256) * cdf_cdiv(Cout, 128) >= 256))) {
 #define CDF_ROWHALO_CASE(WW)                                                                                           \
     if (W == WW && H % (256 / WW) == 0)                                                                                \
-        return n64 ? launch_igemm_rowhalo<NS, WW, 64>(a, M, s, (T.rowhalo_stream & 1) != 0) : launch_igemm_rowhalo<NS, WW, 128>(a, M, s, (T.rowhalo_stream & 1) != 0);
+        return n64 ? launch_igemm_rowhalo<NS, WW, 64>(a, M, s, (T.rowhalo_stream & 1) != 0, T.resident_reserve) : launch_igemm_rowhalo<NS, WW, 128>(a, M, s, (T.rowhalo_stream & 1) != 0, T.resident_reserve);
             CDF_ROWHALO_CASE(128) CDF_ROWHALO_CASE(64) CDF_ROWHALO_CASE(32) CDF_ROWHALO_CASE(16)
 #undef CDF_ROWHALO_CASE
         }

@@ -182,10 +182,11 @@ typedef struct cdf_gemm_tuning {
     int wgrad_stack;     /* 1: two taps per 128-row tile in cdf_conv_wgrad_bf16x when CA <= 64 < CB */
     int wgrad_swizzle;   /* 1: XCD-aware block order of cdf_conv_wgrad_bf16x (the taps of a pixel range share one XCD's L2) */
     int wgrad_row3;      /* 1: weight gradients of 3 x 3 stride-1 same-size convolutions by one block per ROW of taps */
-    int rowhalo_stream;  /* 1 = bit 1: the row-halo GEMM with 64 / 128 input channels runs as resident blocks with one operand stream over all the
-                            tiles of a CU (the next tile's first rows and weights arrive under the current tile's epilogue); bit 2 (off): the 64-channel
-                            outputs at 128-pixel width take the same form with 512-pixel x 64-channel tiles (from 256 tiles up; bit 4: from one tile up,
-                            for tests) -- 6 % faster per launch at 3.2x the fetched bytes; 0: one block per tile everywhere */
+    int rowhalo_stream;  /* 1: the row-halo GEMM with 64 / 128 input channels runs as resident blocks with one operand stream over all the
+                            tiles of a CU (the next tile's first rows and weights arrive under the current tile's epilogue); 0: one block per tile */
+    int resident_reserve;/* 0: CUs the resident kernels leave free (rounded up to whole rounds of the 8 XCDs).  Multi-rank training sets it: the
+                            collective kernels of the gradient exchange run concurrently with backward and need CUs of their own -- a resident
+                            block that finds its CU taken would run its fixed share of the tiles after everybody else */
 } cdf_gemm_tuning;
 int cdf_gemm_tuning_default(cdf_gemm_tuning* t);
 

@@ -96,13 +96,26 @@ def load(which):
     install_stubs()
     folder, pkg = PACKAGES[which]
     path = os.path.join(REFERENCE_ROOT, folder)
-    # two packages share module names (Model2, defading_diffusion_pytorch): import fresh each time
-    for name in list(sys.modules):
-        if name == pkg or name.startswith(pkg + "."):
-            del sys.modules[name]
+    # two packages share module names (Model2, defading_diffusion_pytorch): import fresh each time -- and leave sys.modules as it was
+    # found: the drop-in packages of this repository carry the SAME names, and a test that runs after this call must get those, not
+    # the reference (which would make its parity check compare the reference with itself)
+    mine = lambda name: name == pkg or name.startswith(pkg + ".")
+    saved = {name: m for name, m in sys.modules.items() if mine(name)}
+    for name in saved:
+        del sys.modules[name]
     sys.path.insert(0, path)
     try:
         mod = importlib.import_module(pkg)
     finally:
         sys.path.remove(path)
+        ref_modules = {n: m for n, m in sys.modules.items() if mine(n)}
+        for name in ref_modules:
+            del sys.modules[name]
+        sys.modules.update(saved)
+    mod._cdf_ref_modules = ref_modules          # (the reference's own submodules by dotted name, e.g. for patching module globals)
     return mod
+
+
+def submodule(mod, dotted):
+    """The reference submodule `dotted` (e.g. Trainer.__module__) of a package returned by load()."""
+    return mod._cdf_ref_modules[dotted]

@@ -1,7 +1,7 @@
 """Worker for tests/test_dp.py: one rank of a multi-process gloo data-parallel run on the CPU simulator.
 
 argv: out_path nsteps bucket_bytes mode [hip|emu] [unet|model] [precision]
-  "hip": both ranks on cuda:0 with the product library, gloo moving CUDA tensors;  "model": the CIFAR `Model` (MODEL2:191-332)
+  "hip": both ranks on cuda:0 with the product library, gloo moving CUDA tensors;  "rccl": rank r on cuda:r, RCCL;  "model": the CIFAR `Model` (MODEL2:191-332)
   instead of `Unet`;  precision: bf16x3 (default) | bf16 | f32
   mode 'once'  : loss = L1(x, f(q(x, e, t), t))                         (the denoising package's p_losses)
   mode 'twice' : the network runs TWICE per loss (as RESOL:702-716 'Final_random_mean_and_actual' does):
@@ -20,7 +20,9 @@ for p in (os.path.join(REPO, "cold-diffusion-models_amd"), HERE, REPO):
 import torch  # noqa: E402
 from emu_util import install_emu  # noqa: E402
 
-ON_HIP = len(sys.argv) > 5 and sys.argv[5] == "hip"
+RCCL = len(sys.argv) > 5 and sys.argv[5] == "rccl"      # one GPU per rank, RCCL carrying the buckets (needs >= 2 devices)
+ON_HIP = len(sys.argv) > 5 and sys.argv[5] in ("hip", "rccl")
+DEV = "cuda:%d" % (int(os.environ.get("LOCAL_RANK", "0")) if RCCL else 0)
 if not ON_HIP:
     install_emu()
 from colddiff import parallel, runtime  # noqa: E402
@@ -35,7 +37,7 @@ out_path, nsteps, bucket_bytes, mode = sys.argv[1], int(sys.argv[2]), int(sys.ar
 if bucket_bytes > 0:
     parallel.BUCKET_BYTES = bucket_bytes
     parallel.GradSync.__init__.__defaults__ = (bucket_bytes,)
-parallel.init_distributed("gloo")
+parallel.init_distributed("nccl" if RCCL else "gloo")
 rank, world = parallel.rank(), parallel.world_size()
 torch.manual_seed(0)
 with contextlib.redirect_stdout(io.StringIO()):
@@ -48,10 +50,10 @@ if rank == 1:      # ranks must converge to rank 0's weights through the initial
         for p in net.parameters():
             p.add_(1.0)
 if ON_HIP:
-    net = net.to("cuda:0")
+    net = net.to(DEV)
 diff = GaussianDiffusion(net, image_size=8, channels=3, timesteps=10)
 if ON_HIP:
-    diff = diff.to("cuda:0")
+    diff = diff.to(DEV)
 tr = Trainer(diff, None, image_size=8, train_batch_size=2, train_lr=1e-3, train_num_steps=nsteps, gradient_accumulate_every=2,
              dataset="synthetic", results_folder=os.path.join(os.path.dirname(out_path), f"res{rank}"))
 # the per-rank RNG streams must differ after construction (every rank draws its own t / noise)
@@ -92,7 +94,7 @@ batches = [[[(torch.rand(2, 3, 8, 8, generator=g) * 2 - 1, torch.randn(2, 3, 8, 
 
 def loss_of(x, e, t):
     if ON_HIP:
-        x, e, t = x.to("cuda:0"), e.to("cuda:0"), t.to("cuda:0")
+        x, e, t = x.to(DEV), e.to(DEV), t.to(DEV)
     if mode == "once":
         return tr.core.p_losses(x, e, t)
     return tr.core.p_losses(x, e, t) + tr.core.p_losses(x, -e, t)

@@ -307,7 +307,23 @@ def fullsize_cases(net_sd):
             xt, direct, img = d.sample(batch_size=B, faded_recon_sample=x, t=6)
         out[f"defade128/Random_Incremental/{int(discrete)}"] = dict(T=T, levels=lv.to(torch.uint8), t=t, q=xq, xt=xt, direct=direct, img=img,
                                                                     rand_x=rx, rand_y=ry, kernel_std=0.1, initial_mask=1, sample_t=6)
+    # The masks are 1 - k / max(k) with k = g g^T, g the normalised 1-D Gaussian whose taps come from torch.exp -- which is NOT
+    # correctly rounded and differs by an ulp between CPU vector ISAs (the GPU box's host gave other masks than this container, and with
+    # them 230 of 98304 q values one or two ulps away).  The fixture therefore carries the reference's OWN 1-D Gaussians (50 x 257
+    # floats; everything after the exp is exactly rounded IEEE arithmetic, so the [50, 257, 257] table is rebuilt bit-exactly from them).
+    g1 = torch.stack([ref_shim.gaussian_1d(2 * S + 1, 0.1 * (i + 1)) for i in range(T)])
+    assert torch.equal(masks_from_g1(g1), d.fade_kernels)
+    out["defade128/g1d"] = g1
     return out
+
+
+def masks_from_g1(g1):
+    """[T, n] normalised 1-D Gaussians -> the fade masks of DEFADE:328-352: (1 - g g^T / max(g g^T))[1:, 1:] per step."""
+    ks = []
+    for g in g1:
+        k = torch.matmul(g.unsqueeze(-1), g.unsqueeze(-1).t())
+        ks.append((torch.ones_like(k) - k / torch.max(k))[1:, 1:])
+    return torch.stack(ks)
 
 
 def ssim_msssim(X, Y, data_range=1.0, size_average=True, win_size=11, win_sigma=1.5, K=(0.01, 0.03)):
@@ -350,7 +366,7 @@ def evaluation_cases(net_sd):
     import types
     out = {}
     ref = ref_shim.load("deblurring")
-    mod = sys.modules[ref.Trainer.__module__]
+    mod = ref_shim.submodule(ref, ref.Trainer.__module__)
     S, T = 16, 3
     g = torch.Generator().manual_seed(SEED + 21)
     imgs = images(104, 3, S, g)                                   # 104 images: one DataLoader batch of 100 (drop_last) + 4 dropped

@@ -67,12 +67,27 @@ def test_two_rank_other_networks_and_modes_on_the_gpu(tmp_path, net, precision, 
     _two_rank_case(tmp_path, 1024, "once", 8, hip=True, net=net, precision=precision, tol=tol)
 
 
+def _gpu_count():
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpu_count() < 2, reason="RCCL needs one GPU per rank: runs the day a lease has >= 2 devices (the driver's boxes have one)")
+@pytest.mark.parametrize("bucket_bytes,mode,min_buckets", [(1024, "twice", 8), (0, "once", 1)])
+def test_two_rank_training_over_rccl(tmp_path, bucket_bytes, mode, min_buckets):
+    """The real thing: rank r on cuda:r, the gradient buckets all-reduced by RCCL over xGMI on the side stream while backward runs
+    (SURVEY 8(e)); same checks as the gloo runs -- replicas bit-identical, weights within 2e-5 of the global-batch oracle."""
+    _two_rank_case(tmp_path, bucket_bytes, mode, min_buckets, hip="rccl")
+
+
 def _two_rank_case(tmp_path, bucket_bytes, mode, min_buckets, hip, net="unet", precision="bf16x3", tol=2e-5):
     out, nsteps = str(tmp_path / "w.pt"), 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(HERE, "dp_worker.py"), out, str(nsteps), str(bucket_bytes), mode,
-           "hip" if hip else "emu", net, precision]
-    env = dict(os.environ, OMP_NUM_THREADS="2", COLDDIFF_SHARE_GPU="1")      # (both ranks on cuda:0 in the hip runs)
+           hip if isinstance(hip, str) else ("hip" if hip else "emu"), net, precision]
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if hip != "rccl":
+        env["COLDDIFF_SHARE_GPU"] = "1"                       # (both ranks on cuda:0 in the hip runs)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     r0, r1 = torch.load(out + ".rank0"), torch.load(out + ".rank1")

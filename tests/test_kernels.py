@@ -929,17 +929,17 @@ def test_conv_presplit_rowhalo_emu(case):
         be._keep.clear()
 
 
-def test_conv_presplit_rowhalo_512_emu():
-    """The resident row-halo form with 512-pixel x 64-channel tiles (64-channel outputs at 128-pixel width): one 128 x 128 image = 32 tiles
-    on the simulator's 8 "CUs" (4 tiles per block), 64 input channels, 40 outputs (ragged N tile); bit 4 of rowhalo_stream lifts the
-    256-tile threshold of the default dispatch.  The GPU suite runs the form at full size inside the network tests."""
+def test_conv_presplit_rowhalo_resident_reserve_emu():
+    """cdf_gemm_tuning.resident_reserve: the resident row-halo blocks leave CUs free for concurrent kernels (multi-rank training: the
+    gradient exchange's collectives).  The simulator has 8 "CUs"; any reserve still leaves one round of 8 blocks, and the tile walk
+    is by gridDim.x, so the result is the same sums -- checked against the fp32 reference like every other case."""
     from conftest import Backend
     be = Backend("emu")
-    be.tune.set(rowhalo_stream=7)
+    be.tune.set(halo=64 | 47, halo_min_tiles=1, resident_reserve=32)
     try:
-        _spx_case(be, 1, 64, 40, 128, 3, 1, 1)
+        _spx_case(be, 5, 64, 136, 16, 3, 1, 1)
     finally:
-        be.tune.set(rowhalo_stream=1)
+        be.tune.set(halo=47, halo_min_tiles=1, resident_reserve=0)
         be._keep.clear()
 
 
