@@ -1,8 +1,8 @@
 // k_dwconv.hip — depthwise 7x7 convolution of the ConvNeXt block on NHWC feature maps.
 //   reference: nn.Conv2d(dim, dim, 7, padding=3, groups=dim) + time-embedding bias
 //   deblurring_diffusion_pytorch.py:145,157-162
-// HBM-bound (49 MAC per element): a block stages its input halo in LDS, each thread produces a 4 x 4-pixel x 4-channel tile from a
-// sliding 10-wide register window; lanes run along channels (coalesced 16 B).
+// HBM-bound (49 MAC per element): each thread produces a 4-pixel x 4-channel strip so that one
+// 10x7 window of float4 loads feeds 196 float4 FMAs; lanes run along channels (coalesced 16 B).
 // Weights are packed [49][Cp] (cdf_pack_weight with R=1), Cp = C rounded up to 4, zero padded.
 #include "cdf_common.h"
 #include "colddiff.h"
@@ -20,36 +20,33 @@ __device__ __forceinline__ void f4_fma(float4& acc, const float4& a, const float
 // y[b,y,x,c] = sum_k x[b,y+ky-3,x+kx-3,c] * w[k][c] (+ bias[c] + sbias[b][c]);  flip => mirrored taps (dgrad)
 //
 // Per layer: 8 B/element of HBM traffic against 49 FMA/element -- on MI355X the two floors are about equal
-// (134 MB in + 134 MB out = 54 us, 1.6 G FMA = 24 us of packed FMAs at 128x128x64, batch 32), so neither may be wasted, and the
+// (134 MB in + 134 MB out = 54 us, 1.6 G FMA = 42 us at 128x128x64, batch 32), so neither may be wasted, and the
 // loads must not be latency-bound (a register-window version with 10 dependent-ish loads per row ran at 4x the
 // floor).  Stencil through LDS:
-//   a block owns a TBW x TBH = 256-pixel output tile (32 x 8, or 16 x 16 for narrow images) of 32 channels (8 float4 lanes, 128 B
-//   coalesced) and brings its (TBW+6) x (TBH+6) input halo into LDS with ~34 independent, unconditional float4 loads per thread
-//   (clamped address + select), 2.1x the tile's own bytes and L2/MALL-resident for the neighbours.
-// Round 4 -- thread tiles of 4 x 4 output pixels (128 threads per block; rounds 1-3: 4 x 2 with 256 threads).  PMC said the forward
-// pass was LDS-read-bound, not HBM- or FMA-bound: with a 4 x 2 tile a thread slides its 10-wide register window over 8 halo rows and
-// reads the 49 weights for 8 outputs, (80 + 49) ds_read_b128 per 392 float4 FMAs = 0.33 per FMA, i.e. 10 k LDS-pipe cycles per 512
-// pixels of a CU against 6.3 k cycles of packed FMAs.  A 4 x 4 tile reads 10 rows x 10 + 49 = 149 per 784 FMAs = 0.19 per FMA
-// (4.8 k cycles): the vector ALU is the on-chip bound again.  Row pitch = (TBW+6) pixels + 64 B as before (the two thread rows inside
-// a 16-lane ds_read_b128 group land 32 banks apart, conflict-free).  68 KB + 6 KB of weights: two blocks per CU (one wave per SIMD)
-// overlap one's loads with the other's FMAs.
+//   block = 256 threads = 32 channels (8 float4 lanes, 128 B coalesced) x 32 thread tiles of 4 x 2 output pixels,
+//   i.e. a TBW x TBH = 256-pixel output tile (32 x 8, or 16 x 16 for narrow images);
+//   the (TBW+6) x (TBH+6) input halo goes to LDS with ~17 independent, unconditional float4 loads per thread
+//   (clamped address + select), 2.1x the tile's own bytes and L2/MALL-resident for the neighbours;
+//   each thread then slides a 10-wide register window over 8 halo rows: 80 ds_read_b128 + 49 weight reads per 8
+//   outputs.  Row pitch = (TBW+6) pixels + 64 B: the two thread rows inside a 16-lane ds_read_b128 group land 32
+//   banks apart (conflict-free).  68 KB + 6 KB of weights: two blocks per CU overlap one's loads with the other's FMAs.
 // grid = (tiles_x * tiles_y * B, ceil(C4 / 8)).
-// Round 3 (PMC on MI355X, 64 channels at 128 x 128: VALU active 55 % of the SIMD time, a wave64 VALU instruction occupies its SIMD
-// for 4 cycles and only v_pk_fma_f32 reaches the 157 TFLOP/s vector peak):
+// Round 3 (PMC on MI355X, 64 channels at 128 x 128: VALU active 55 % of the SIMD time -- the kernel is VALU-bound, a wave64 VALU
+// instruction occupies its SIMD for 4 cycles and only v_pk_fma_f32 reaches the 157 TFLOP/s vector peak):
 //   * the halo loads are unconditional from clamped addresses and the out-of-image select happens when the values go to LDS
 //     (a select right behind the load parked the wave on s_waitcnt before the other loads were even requested);
-//   * the (halo row, output row) pairs whose kernel row falls outside 0..6 are peeled off instead of multiplying by zero weights.
+//   * the two (halo row, output row) pairs whose kernel row falls outside 0..6 are peeled off instead of multiplying by zero
+//     weights behind a per-component select: 448 v_cndmask and 1/8 of the FMAs per thread gone.
 // (A block walking several tiles with the next halo requested under the current tile's FMAs was built and measured: slower,
-//  218 VGPRs and no gain from the overlap.)
+//  218 VGPRs and no gain from the overlap -- the waves do not wait for HBM, they wait for the vector ALU.)
 template <int TBW, int TBH>
-__global__ void __launch_bounds__(128, 2) dwconv7_kernel(const float* x, int ldx, const float* w, int ldw, const float* bias,
+__global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx, const float* w, int ldw, const float* bias,
                                                          const float* sbias, int ld_sbias, float* y, int ldy, int B, int H,
                                                          int W, int C4, int flip, int accumulate, const float* res, int ldr) {
     constexpr int HW_ = TBW + 6, HH_ = TBH + 6;              // halo extent
     constexpr int RP = HW_ * 8 + 4;                          // row pitch in float4 (pixels x 8 channel quads + 64 B)
-    constexpr int TX = TBW / 4, TY = TBH / 4;                // thread tiles (4 x 4 pixels)
-    constexpr int NTHR = 128;
-    static_assert(TX * TY * 8 == NTHR, "256 output pixels x 32 channels per block of 128 threads");
+    constexpr int TX = TBW / 4, TY = TBH / 2;                // thread tiles
+    static_assert(TX * TY == 32, "256 output pixels per block");
     CDF_DYN_SMEM(smem_raw);
     float4* halo = (float4*)smem_raw;                        // [HH_][RP]
     float4* wl = halo + HH_ * RP;                            // [49][8]
@@ -58,7 +55,8 @@ __global__ void __launch_bounds__(128, 2) dwconv7_kernel(const float* x, int ldx
     const int tiles_w = (W + TBW - 1) / TBW, tiles_h = (H + TBH - 1) / TBH;
     // XCD-aware tile order: the (TBW+6) x (TBH+6) halo is 2.1x the tile, i.e. half of what a block reads is shared with its
     // neighbours.  In dispatch order the neighbours sit on other XCDs and every L2 fetched the shared rows from HBM again
-    // (rocprofv3 FETCH_SIZE: 2.3x the tensor); an XCD now walks a contiguous run of tiles of one channel group.
+    // (rocprofv3 FETCH_SIZE: 2.3x the tensor); an XCD now walks a contiguous run of tiles of one channel group (its 64 resident
+    // blocks = one 128 x 128 image).
     const int vid = cdf_xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
     int t = vid % (int)gridDim.x;
     const int bx = t % tiles_w;
@@ -67,42 +65,41 @@ __global__ void __launch_bounds__(128, 2) dwconv7_kernel(const float* x, int ldx
     const int X0 = bx * TBW, Y0 = by * TBH;
     const int cq0 = (vid / (int)gridDim.x) * 8;
 
-    for (int i = tid; i < DW_TAPS * 8; i += NTHR) {
+    for (int i = tid; i < DW_TAPS * 8; i += 256) {
         const int tp = i >> 3, l = i & 7;
         const int tap = flip ? DW_TAPS - 1 - tp : tp;
         wl[i] = (cq0 + l) < C4 ? *(const float4*)(w + (long long)tap * ldw + (cq0 + l) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // Index arithmetic of the halo loads without 32-bit multiplies or 64-bit VALU math (round 3: integer multiplies run at a quarter
-    // of the FMA rate and were, with the per-load divisions, more vector work than the packed FMAs): element offsets inside one
+    // Index arithmetic of the 17 halo loads without 32-bit multiplies or 64-bit VALU math (round 3: integer multiplies run at a quarter
+    // of the FMA rate and were, with the per-load divisions, more vector work than the 784 packed FMAs): element offsets inside one
     // image are 24-bit x 24-bit products (host: H W pitch < 2^30), the image base is a scalar, and (hy, hx) of slot k follow from
-    // slot k - 1 by adding 16 pixels.
+    // slot k - 1 by adding 32 pixels.
     const float* xb = x + (long long)b * H * W * ldx;
-    constexpr int NHALO = HH_ * HW_ * 8, NIT = (NHALO + NTHR - 1) / NTHR;
-    constexpr int PSTEP = NTHR / 8;                          // pixels a round of loads advances by
-    constexpr int STEP_Y = PSTEP / HW_, STEP_X = PSTEP % HW_;
-    static_assert(PSTEP <= HW_, "a round of loads stays inside two halo rows");
+    constexpr int NHALO = HH_ * HW_ * 8, NIT = (NHALO + 255) / 256;
+    constexpr int STEP_Y = 32 / HW_, STEP_X = 32 % HW_;      // 32 pixels further in the [HH_][HW_] halo
     const int l_ = tid & 7;
     const unsigned lc4 = (unsigned)(((cq0 + l_) < C4 ? cq0 + l_ : 0) * 4);
     const bool lok = (cq0 + l_) < C4;
-    // two batches of <= 17 loads: all 34 in flight at once need 136 data + 34 address registers next to everything else (25 spills)
-    constexpr int NB1 = (NIT + 1) / 2;
-    int hy = 0, hx = tid >> 3;                               // (tid >> 3 < 16 <= HW_)
+    float4 hv[NIT];
+    {
+        int hy = 0, hx = tid >> 3;                           // (tid >> 3 < 32 <= HW_)
+        if (hx >= HW_) { hx -= HW_; ++hy; }
 #pragma unroll
-    for (int k0 = 0; k0 < NIT; k0 += NB1) {
-        float4 hv[NB1];
-        int hy1 = hy, hx1 = hx;
-#pragma unroll
-        for (int k = 0; k < NB1; ++k) {                      // every load of the batch requested before anything is used
-            const int iy = Y0 + hy1 - 3, ix = X0 + hx1 - 3;
+        for (int k = 0; k < NIT; ++k) {                      // every load requested before anything is used
+            const int iy = Y0 + hy - 3, ix = X0 + hx - 3;
             const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
             const unsigned off = __umul24(__umul24((unsigned)iyc, (unsigned)W) + (unsigned)ixc, (unsigned)ldx) + lc4;
             hv[k] = *(const float4*)(xb + off);
-            hy1 += STEP_Y;
-            hx1 += STEP_X;
-            if (hx1 >= HW_) { hx1 -= HW_; ++hy1; }
+            hy += STEP_Y;
+            hx += STEP_X;
+            if (hx >= HW_) { hx -= HW_; ++hy; }
         }
+    }
+    {
+        int hy = 0, hx = tid >> 3;
+        if (hx >= HW_) { hx -= HW_; ++hy; }
 #pragma unroll
-        for (int k = 0; k < NB1; ++k) {
+        for (int k = 0; k < NIT; ++k) {
             const int iy = Y0 + hy - 3, ix = X0 + hx - 3;
             const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W && lok;
             if (hy < HH_) halo[__umul24((unsigned)hy, (unsigned)RP) + hx * 8 + l_] = ok ? hv[k] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -116,26 +113,22 @@ __global__ void __launch_bounds__(128, 2) dwconv7_kernel(const float* x, int ldx
     // lanes: channel quad (8) fastest, then thread row (TY), then thread column (TX)
     const int l8 = tid & 7, ty = (tid >> 3) % TY, tx = (tid >> 3) / TY;
     const int cq = cq0 + l8;
-    const int x0 = tx * 4, y0 = ty * 4;                      // inside the tile
-    float4 acc[4][4];
+    const int x0 = tx * 4, y0 = ty * 2;                      // inside the tile
+    float4 acc[2][4];
 #pragma unroll
-    for (int o = 0; o < 4; ++o)
+    for (int o = 0; o < 2; ++o)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[o][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // halo row y0 + r (r = 0 .. 9) feeds output row o through kernel row ky = r - o, 0 <= ky <= 6: o in [max(0, r - 6), min(3, r)].
-    // ONE rolled loop over the ten halo rows; which outputs a row reaches is a wave-uniform (scalar) branch per output row.  Unrolled
-    // or peeled, hipcc hoists the window and weight reads of several rows to the top and spills (94 VGPRs in the peeled form).
-#pragma unroll 1
-    for (int r = 0; r < 10; ++r) {
+    // halo row y0 + r feeds output row o through kernel row ky = r - o: r = 0 only o = 0, r = 7 only o = 1, r = 1..6 both
+    auto row_step = [&](int r, bool do0, bool do1) {
         float4 win[10];
         const float4* hrow = halo + (y0 + r) * RP + x0 * 8 + l8;
 #pragma unroll
         for (int q = 0; q < 10; ++q) win[q] = hrow[q * 8];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const int ky = r - o;                            // (uniform)
-            if (ky < 0 || ky >= DW_K) continue;
-            const float4* wrow = wl + ky * DW_K * 8 + l8;
+        for (int o = 0; o < 2; ++o) {
+            if (!(o == 0 ? do0 : do1)) continue;            // (compile-time per call site)
+            const float4* wrow = wl + (r - o) * DW_K * 8 + l8;
 #pragma unroll
             for (int kx = 0; kx < DW_K; ++kx) {
                 const float4 wv = wrow[kx * 8];
@@ -143,7 +136,12 @@ __global__ void __launch_bounds__(128, 2) dwconv7_kernel(const float* x, int ldx
                 for (int j = 0; j < 4; ++j) f4_fma(acc[o][j], win[kx + j], wv);
             }
         }
-    }
+    };
+    row_step(0, true, false);
+    // rolled on purpose: unrolled, hipcc hoists all window + weight reads to the top and spills
+#pragma unroll 1
+    for (int r = 1; r < 7; ++r) row_step(r, true, true);
+    row_step(7, false, true);
 
     if (cq >= C4) return;
     const int c = cq * 4;
@@ -159,7 +157,7 @@ __global__ void __launch_bounds__(128, 2) dwconv7_kernel(const float* x, int ldx
     float* yb = y + (long long)b * H * W * ldy;
     const float* rb = res ? res + (long long)b * H * W * ldr : nullptr;
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
+    for (int o = 0; o < 2; ++o) {
         const int oy = Y0 + y0 + o;
         if (oy >= H) break;
         const unsigned pix0 = __umul24((unsigned)oy, (unsigned)W) + (unsigned)(X0 + x0);
@@ -460,7 +458,7 @@ static int launch_dwconv7(const float* x, int ldx, const float* w, int ldw, cons
     }
 #endif
     const long long tiles = (long long)B * cdf_cdiv(H, TBH) * cdf_cdiv(W, TBW);
-    CDF_LAUNCH((dwconv7_kernel<TBW, TBH>), dim3((unsigned)tiles, cdf_cdiv(C4, 8)), dim3(128), lds, s, x, ldx, w, ldw, bias, sbias, ld_sbias, y,
+    CDF_LAUNCH((dwconv7_kernel<TBW, TBH>), dim3((unsigned)tiles, cdf_cdiv(C4, 8)), dim3(256), lds, s, x, ldx, w, ldw, bias, sbias, ld_sbias, y,
                ldy, B, H, W, C4, flip, accumulate, res, ldr);
     return cdf_check_launch("dwconv7");
 }

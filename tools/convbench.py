@@ -14,7 +14,7 @@ if os.environ.get('KB_HALO'):
     h_ = [int(v) for v in os.environ['KB_HALO'].split(',')]
     TUNE.set(halo=h_[0], halo_min_tiles=h_[1] if len(h_) > 1 else 1)
 for var_, field_ in (('KB_ROW3', 'wgrad_row3'), ('KB_WSWZ', 'wgrad_swizzle'), ('KB_HALO_BM', 'halo_bm'), ('KB_DEPHASE', 'dephase'),
-                     ('KB_SMALL_N64', 'small_n64'), ('KB_MAX_BM', 'max_bm')):
+                     ('KB_SMALL_N64', 'small_n64'), ('KB_MAX_BM', 'max_bm'), ('KB_ROWHALO_STREAM', 'rowhalo_stream')):
     if os.environ.get(var_):
         TUNE.set(**{field_: int(os.environ[var_])})
 SINGLE = os.environ.get('KB_SINGLE', '0') == '1'      # hi-only planes: single-pass bf16 (NS = 1 kernels)
