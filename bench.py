@@ -9,9 +9,13 @@ Workload (BASELINE.json config 3, the single-GPU CelebA-128 case; SURVEY.md §8(
   Unet(dim=64, dim_mults=(1,2,4,8), channels=3) at 128x128, denoising GaussianDiffusion(T=200,
   x0_step_down), synthetic 8-bit-quantised images, random-init weights.
 A *step* is one optimizer step exactly as Trainer.train() does it (DEBLUR:1188-1204): 2 accumulation
-micro-steps of 32 images (q_sample -> UNet fwd -> L1 -> bwd) + Adam (+ EMA every 10th step); with
-N > 1 each rank does the same work on its own shard and gradients are all-reduced over RCCL
-(weak scaling).  `value` = images/s over all ranks.  Rank 0 prints ONE JSON line.
+micro-batches of 32 images (q_sample -> UNet fwd -> L1 -> bwd) + Adam (+ EMA every 10th step).  Since
+round 4 the engine degrades the micro-batches one by one (the reference's data order and draws) and runs
+them through the network as ONE 64-image pass -- the same gradient sum (colddiff/trainer.py: fused
+accumulation; tests/test_modules.py::test_fused_accumulation_*); the line also carries the step with
+separate micro-steps (`accumulation.unfused_*`, COLDDIFF_FUSE_ACCUM=0).  With N > 1 each rank does the
+same work on its own shard and gradients are all-reduced over RCCL (weak scaling).  `value` = images/s
+over all ranks.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -483,7 +487,9 @@ def main():
         "vs_baseline": None, "dtype": "f32" if runtime.precision == "f32" else ("f32 storage/accumulate; dense-conv GEMM operands " + runtime.precision),
         "data": "synthetic",
         "config": {"workload": "CelebA-128 denoising cold diffusion (BASELINE config 3): Unet(dim=64,(1,2,4,8),ch=3) @128x128, T=200, "
-                               "optimizer step = 2 micro-steps x 32 img + Adam + EMA/10", "per_gpu_batch": args.batch,
+                               "optimizer step = %d micro-batches x %d img (%s) + Adam + EMA/10"
+                               % (args.accum, args.batch, "one fused forward / backward pass over all of them: same draws, same gradient sum"
+                                  if trainer._can_fuse() else "separate micro-steps"), "per_gpu_batch": args.batch,
                    "gradient_accumulate_every": args.accum, "global_images_per_step": imgs_per_step,
                    "parallelism": f"dp{world}" if world > 1 else "single"},
     }
@@ -548,6 +554,15 @@ def main():
                     torch.cuda.synchronize()
                     out["sample_ms_per_img_200step_batch64"] = round(1000 * (time.perf_counter() - ts) / 64, 2)
                     del noise64
+        if world == 1 and not args.no_secondary and trainer._can_fuse():
+            # the same optimizer step with the reference's separate micro-steps (what rounds 1-3 timed): labelled, beside `value`
+            os.environ["COLDDIFF_FUSE_ACCUM"] = "0"
+            dtu = timed_train(trainer, args.steps, 2)
+            del os.environ["COLDDIFF_FUSE_ACCUM"]
+            out["accumulation"] = {"fused": True, "unfused_img_per_s": round(args.batch * args.accum / dtu, 2), "unfused_ms_per_step": round(1000 * dtu, 3),
+                                   "note": "fused = the %d micro-batches of a step as one pass (loss of the concatenated batch = mean of the micro-batch "
+                                           "losses); unfused = (loss_i / %d).backward() per micro-batch as DEBLUR:1188-1195 writes it" % (args.accum, args.accum)}
+            log(f"unfused accumulation: {out['accumulation']['unfused_img_per_s']} img/s")
         if world == 1 and not args.no_secondary:
             out["selfcheck"] = selfcheck(diffusion, device)
             log("self-check: loss hip %.6f oracle %.6f" % (out["selfcheck"]["microstep_loss_hip"], out["selfcheck"]["microstep_loss_oracle"]))

@@ -25,7 +25,38 @@ def _full_step(batch_size, value, device):
 # ===================================================================================================
 # deblurring
 # ===================================================================================================
-class DeblurDiffusion(nn.Module):
+class TwoPhase:
+    """forward() in two phases -- prepare() draws t exactly as forward() does and runs the degradation, loss_prepared() runs the
+    network and the loss: prepare + loss_prepared == forward, same draws in the same order, same kernels.  The Trainer uses it to
+    (a) degrade the next micro-batch on a side stream under the current forward / backward (deblurring) and (b) run the
+    `gradient_accumulate_every` micro-batches of an optimizer step as ONE pass of the network (`Trainer._can_fuse`): the loss of the
+    concatenated batch is the mean of the micro-batch losses, so its gradient is the sum of the (loss_i / accumulate).backward() calls
+    of DEBLUR:1188-1195 -- nothing in these networks couples samples (channel LayerNorm is per pixel, GroupNorm per sample)."""
+
+    def fusable(self):
+        return getattr(self, 'train_routine', 'Final') == 'Final'
+
+    def _draw_t(self, x):
+        b, c, h, w = x.shape
+        assert h == self.image_size and w == self.image_size, f'height and width of image must be {self.image_size}'
+        return torch.randint(0, self.num_timesteps, (b,), device=x.device).long()
+
+    def _network(self):
+        return self.defade_fn if hasattr(self, 'defade_fn') else self.denoise_fn
+
+    def prepare(self, x, x2=None, t=None):
+        """-> (target, t, degraded input): what p_losses hands to the network and to the loss ('Final' training routine)."""
+        assert self.fusable()
+        if t is None:
+            t = self._draw_t(x)
+        return x, t, (self.q_sample(x_start=x, t=t) if x2 is None else self.q_sample(x_start=x, x_end=x2, t=t))
+
+    def loss_prepared(self, prep):
+        x_start, t, x_deg = prep
+        return D.loss(x_start, self._network()(x_deg, t), self.loss_type)
+
+
+class DeblurDiffusion(TwoPhase, nn.Module):
     def __init__(self, denoise_fn, *, image_size, device_of_kernel, channels=3, timesteps=1000, loss_type='l1', kernel_std=0.1,
                  kernel_size=3, blur_routine='Incremental', train_routine='Final', sampling_routine='default', discrete=False):
         super().__init__()
@@ -369,17 +400,6 @@ class DeblurDiffusion(nn.Module):
         prefetch overlap with anything -- the per-step fallback reads max(t) on the host and would block the launching thread."""
         return self._uniform() and D.blur_fits_lds(self.image_size, self.image_size, self.gaussian_kernels[0].weight.shape[-1])
 
-    def prepare(self, x):
-        b, c, h, w, device, img_size = *x.shape, x.device, self.image_size
-        assert h == img_size and w == img_size, f'height and width of image must be {img_size}'
-        assert self.train_routine == 'Final'
-        t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
-        return x, t, self.q_sample(x_start=x, t=t)
-
-    def loss_prepared(self, prep):
-        x_start, t, x_blur = prep
-        return D.loss(x_start, self.denoise_fn(x_blur, t), self.loss_type)
-
 
 # ===================================================================================================
 # denoising ("hot" Gaussian-noise baseline with cold-style samplers)
@@ -393,7 +413,7 @@ def cosine_beta_schedule(timesteps, s=0.008):
     return torch.clip(betas, 0, 0.999)
 
 
-class DenoiseDiffusion(nn.Module):
+class DenoiseDiffusion(TwoPhase, nn.Module):
     def __init__(self, denoise_fn, *, image_size, channels=3, timesteps=1000, loss_type='l1', train_routine='Final',
                  sampling_routine='default', discrete=False):
         super().__init__()
@@ -576,7 +596,7 @@ def get_reverse_kernels_with_schedule(timesteps, size, kernel_std, initial_mask)
     return torch.stack(out)
 
 
-class DefadeGenDiffusion(nn.Module):
+class DefadeGenDiffusion(TwoPhase, nn.Module):
     def __init__(self, denoise_fn, *, image_size, channels=3, timesteps=1000, loss_type='l1', train_routine='Final',
                  sampling_routine='default', reverse=False, kernel_std=0.15, initial_mask=11):
         super().__init__()
@@ -672,7 +692,7 @@ class DefadeGenDiffusion(nn.Module):
 # ===================================================================================================
 # resolution (pixelation)
 # ===================================================================================================
-class ResolutionDiffusion(nn.Module):
+class ResolutionDiffusion(TwoPhase, nn.Module):
     _MODES = {'': 'bicubic', '_bilinear': 'bilinear', '_area': 'area', '_bicubic': 'bicubic'}
 
     def __init__(self, denoise_fn, *, image_size, device_of_kernel, channels=3, timesteps=1000, loss_type='l1',
@@ -899,7 +919,7 @@ class ResolutionDiffusion(nn.Module):
 # ===================================================================================================
 # defading (Gaussian-mask inpainting)
 # ===================================================================================================
-class DefadeDiffusion(nn.Module):
+class DefadeDiffusion(TwoPhase, nn.Module):
     def __init__(self, defade_fn, *, image_size, device_of_kernel, channels=3, timesteps=1000, loss_type='l1', kernel_std=0.1,
                  initial_mask=11, fade_routine='Incremental', sampling_routine='default', discrete=False):
         super().__init__()

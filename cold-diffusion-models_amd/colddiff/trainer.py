@@ -351,13 +351,64 @@ class Trainer(EvalMixin):
     # next micro-batch was already prefetched, i.e. one batch later in the data order than without prefetch.
     _pending = None
     _side = None
+    _pending_q = None            # (fused accumulation: the next step's micro-batches, in draw order)
 
     def _can_prefetch(self):
         """Only for the plain loop on a HIP device: not when a test / subclass replaced _loss, not for two-image packages."""
-        return (self.device.type == 'cuda' and hasattr(self.core, 'prepare') and '_loss' not in self.__dict__
+        return (self.device.type == 'cuda' and hasattr(self.core, 'can_prepare_async') and '_loss' not in self.__dict__
                 and type(self)._loss is Trainer._loss and not self.pair_noise and rt._lib_override is None
                 and getattr(self.core, 'train_routine', None) == 'Final' and os.environ.get("COLDDIFF_PREFETCH", "1") != "0"
-                and getattr(self.core, 'can_prepare_async', lambda: True)())
+                and self.core.can_prepare_async())
+
+    # -- fused gradient accumulation -------------------------------------------------------------------------------------------
+    # The reference runs `gradient_accumulate_every` micro-batches one after the other, (loss_i / accumulate).backward() each
+    # (DEBLUR:1188-1195) -- a memory measure for 16 GB cards.  With 288 GB of HBM the micro-batches of one optimizer step are
+    # degraded one by one (same data order, same t / noise / offset draws in the same order) and then go through the network as ONE
+    # batch: the loss of the concatenated batch is the mean of the micro-batch losses, so one backward pass yields the same
+    # gradient sum, every GEMM sees twice the rows (the 16 x 16 layers fill the chip, the weight gradients need half the split-K
+    # slabs), weights are read once per step instead of per micro-batch and the launch count halves.
+    # CelebA-128 step (2 x 32 images): 58.4 -> 53.2 ms, 1096 -> 1202 img/s in one call (profiles/round4_fused_accumulation_ab.txt).
+    FUSE_MAX_PIXELS = int(os.environ.get("COLDDIFF_FUSE_MAX_PIXELS", str(1 << 21)))     # 128 images of 128 x 128 (~90 GB of activations)
+
+    def _can_fuse(self):
+        """The plain loop only (not when a test / subclass replaced _loss), equal-sized micro-batches (the loaders that may end an
+        epoch on a short batch do not fuse), a core whose training routine has the two-phase form."""
+        acc = self.gradient_accumulate_every
+        return (acc > 1 and '_loss' not in self.__dict__ and type(self)._loss is Trainer._loss and os.environ.get("COLDDIFF_FUSE_ACCUM", "1") != "0"
+                and hasattr(self.core, 'prepare') and self.core.fusable() and (self.drop_last or self.ds is None or parallel.world_size() > 1)
+                and acc * self.batch_size * self.data_image_size ** 2 <= self.FUSE_MAX_PIXELS)
+
+    def _prepare_micro(self):
+        """One micro-batch in the reference's order of draws: the data batch, the second image / fresh noise (DENOISE:738-742), then
+        forward()'s t (and whatever the degradation draws)."""
+        batch = self._next_batch()
+        x2 = self._second(batch)
+        return self.core.prepare(batch) if x2 is None else self.core.prepare(batch, x2)
+
+    def _fused_step(self, acc, prefetch):
+        if self.sync is not None:
+            self.sync.begin()
+        if prefetch:
+            # all of the NEXT step's micro-batches are degraded on the side stream under this step's forward / backward
+            if self._pending_q is None:
+                self._pending_q = []
+            while len(self._pending_q) < acc:
+                self._pending_q.append(self._launch_prepare())
+            preps = []
+            for _ in range(acc):
+                prep, ev = self._pending_q.pop(0)
+                torch.cuda.current_stream().wait_event(ev)
+                preps.append(prep)
+            for _ in range(acc):
+                self._pending_q.append(self._launch_prepare())
+        else:
+            preps = [self._prepare_micro() for _ in range(acc)]
+        prep = tuple(torch.cat(parts) for parts in zip(*preps))
+        loss = torch.mean(self.core.loss_prepared(prep))          # = the mean of the micro-batch losses (equal sizes)
+        if self.sync is not None:
+            self.sync.arm()
+        (loss * (1.0 / parallel.world_size())).backward()
+        return loss.detach()
 
     def _launch_prepare(self):
         main = torch.cuda.current_stream()
@@ -386,7 +437,10 @@ class Trainer(EvalMixin):
         scale = 1.0 / (acc * parallel.world_size())
         total = None
         prefetch = self._can_prefetch()
-        for i in range(acc):
+        fused = self._can_fuse()
+        if fused:
+            total = self._fused_step(acc, prefetch) * acc
+        for i in range(0 if fused else acc):
             if self.sync is not None:
                 self.sync.begin()
             if prefetch:

@@ -579,6 +579,73 @@ def test_trainer_matches_oracle(mbe, tmp_path):
     assert tr.step == 7 and all(torch.equal(v, tr.model.state_dict()[k]) for k, v in before.items())
 
 
+def test_fused_accumulation_matches_oracle_micro_steps(mbe, tmp_path):
+    """Trainer's fused gradient accumulation (the micro-batches of an optimizer step through the network as ONE batch) against the
+    oracle's loop of separate (loss_i / 2).backward() micro-steps (DEBLUR:1188-1195): loss and every weight after each of 3 steps."""
+    from denoising_diffusion_pytorch import GaussianDiffusion, Trainer, Unet
+    torch.manual_seed(0)
+    net = quiet(Unet, dim=8, dim_mults=(1, 2), channels=3).to(mbe.device)
+    diff = GaussianDiffusion(net, image_size=8, channels=3, timesteps=10, sampling_routine="x0_step_down").to(mbe.device)
+    sd0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    tr = Trainer(diff, None, image_size=8, train_batch_size=2, train_lr=2e-5, train_num_steps=3, gradient_accumulate_every=2,
+                 dataset="synthetic", results_folder=str(tmp_path / "res"))
+    assert tr._can_fuse()
+    g = torch.Generator().manual_seed(1)
+    batches = [[(torch.rand(2, 3, 8, 8, generator=g) * 2 - 1, torch.randn(2, 3, 8, 8, generator=g), torch.randint(0, 10, (2,), generator=g))
+                for _ in range(2)] for _ in range(3)]
+    ca, cb = O.cosine_tables(10)
+    otr = O.OracleTrainer(sd0, lambda p, x, e, t: O.loss_fn(x, O.unet_forward(p, O.noise_q_sample(x, e, t, ca, cb), t)), lr=2e-5, accumulate=2)
+    for s in range(3):
+        it = iter(batches[s])
+
+        def micro(it=it):
+            x, e, t = (mbe.to(v) for v in next(it))
+            return tr.core.prepare(x, e, t=t)
+        tr._prepare_micro = micro
+        loss = tr.train_step()
+        tr.step += 1
+        lo = otr.train_step(batches[s])
+        assert abs(loss.item() - lo) <= 1e-5
+        for k in sd0:
+            assert (net.state_dict()[k].cpu() - otr.params[k].detach()).abs().max() <= 1e-6, k
+
+
+@pytest.mark.parametrize("package", ["denoising", "deblurring", "defading", "resolution"])
+def test_fused_accumulation_same_draws_same_trajectory(mbe, tmp_path, monkeypatch, package):
+    """Fused and unfused accumulation consume the data loader and the RNG in the same order (batch, second image, t, offsets per
+    micro-batch), so from one seed they follow the same trajectory: losses and weights after 3 steps agree to fp32 summation order."""
+    import importlib
+    pkg = importlib.import_module(package + "_diffusion_pytorch")
+    out = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("COLDDIFF_FUSE_ACCUM", fuse)
+        torch.manual_seed(3)
+        net = quiet(pkg.Unet, dim=8, dim_mults=(1, 2), channels=3).to(mbe.device)
+        kw = dict(image_size=16, channels=3, timesteps=6)
+        if package == "deblurring":
+            kw.update(device_of_kernel="cuda", kernel_size=3, kernel_std=0.5, blur_routine="Incremental")
+        elif package == "defading":
+            kw.update(device_of_kernel="cuda", kernel_std=0.5, fade_routine="Random_Incremental")
+        elif package == "resolution":
+            kw.update(device_of_kernel="cuda", timesteps=3, resolution_routine="Incremental_factor_2")
+        d = pkg.GaussianDiffusion(net, **kw).to(mbe.device)
+        tr = pkg.Trainer(d, None, image_size=16, train_batch_size=2, train_lr=1e-3, train_num_steps=3, gradient_accumulate_every=2,
+                         dataset="synthetic", results_folder=str(tmp_path / ("res" + fuse)))
+        assert tr._can_fuse() == (fuse == "1")
+        torch.manual_seed(5)
+        losses = []
+        for _ in range(3):
+            losses.append(tr.train_step().item())
+            tr.step += 1
+        out.append((losses, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}))
+    for a, b in zip(out[0][0], out[1][0]):
+        assert abs(a - b) <= 2e-6 * max(1.0, abs(a)), (out[0][0], out[1][0])
+    for k, v in out[0][1].items():
+        # three Adam steps of lr 1e-3: an element whose gradient is at the rounding level may move by a fraction of lr either way
+        assert (v - out[1][1][k]).abs().max() <= 2e-4, k
+        assert ((v - out[1][1][k]).abs() > 2e-6).float().mean() <= 0.02, k
+
+
 def test_no_cpu_fallback():
     """Without the test-only simulator override the operators refuse CPU tensors."""
     from colddiff import runtime
