@@ -1,6 +1,6 @@
 """Worker for tests/test_dp.py: one rank of a multi-process gloo data-parallel run on the CPU simulator.
 
-argv: out_path nsteps bucket_bytes mode [hip|emu] [unet|model] [precision]
+argv: out_path nsteps bucket_bytes mode [hip|emu|rccl] [unet|model] [precision] [fused]
   "hip": both ranks on cuda:0 with the product library, gloo moving CUDA tensors;  "rccl": rank r on cuda:r, RCCL;  "model": the CIFAR `Model` (MODEL2:191-332)
   instead of `Unet`;  precision: bf16x3 (default) | bf16 | f32
   mode 'once'  : loss = L1(x, f(q(x, e, t), t))                         (the denoising package's p_losses)
@@ -100,9 +100,21 @@ def loss_of(x, e, t):
     return tr.core.p_losses(x, e, t) + tr.core.p_losses(x, -e, t)
 
 
+FUSED = len(sys.argv) > 8 and sys.argv[8] == "fused"      # the rank's two micro-batches as ONE pass (Trainer's fused accumulation)
 for s in range(nsteps):
     it = iter(batches[s][rank])
-    tr._loss = lambda batch, it=it: loss_of(*next(it))
+    if FUSED:
+        assert mode == "once"
+
+        def micro(it=it):
+            x, e, t = next(it)
+            if ON_HIP:
+                x, e, t = x.to(DEV), e.to(DEV), t.to(DEV)
+            return tr.core.prepare(x, e, t=t)
+        tr._prepare_micro = micro
+        assert tr._can_fuse()
+    else:
+        tr._loss = lambda batch, it=it: loss_of(*next(it))
     tr.train_step()
     tr.step += 1
 assert all(pend == 0 for _, pend in launch_log), launch_log

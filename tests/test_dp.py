@@ -80,11 +80,23 @@ def test_two_rank_training_over_rccl(tmp_path, bucket_bytes, mode, min_buckets):
     _two_rank_case(tmp_path, bucket_bytes, mode, min_buckets, hip="rccl")
 
 
-def _two_rank_case(tmp_path, bucket_bytes, mode, min_buckets, hip, net="unet", precision="bf16x3", tol=2e-5):
+def test_two_rank_fused_accumulation(tmp_path):
+    """The default training path since round 4: every rank runs its two micro-batches as ONE pass (Trainer._fused_step) -- one
+    begin / arm per step, every bucket still issued during the single backward -- and the ranks' weights match the global-batch
+    oracle of four separate micro-steps."""
+    _two_rank_case(tmp_path, 1024, "once", 8, hip=False, fused=True)
+
+
+@pytest.mark.gpu
+def test_two_rank_fused_accumulation_on_the_gpu(tmp_path):
+    _two_rank_case(tmp_path, 1024, "once", 8, hip=True, fused=True)
+
+
+def _two_rank_case(tmp_path, bucket_bytes, mode, min_buckets, hip, net="unet", precision="bf16x3", tol=2e-5, fused=False):
     out, nsteps = str(tmp_path / "w.pt"), 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(HERE, "dp_worker.py"), out, str(nsteps), str(bucket_bytes), mode,
-           hip if isinstance(hip, str) else ("hip" if hip else "emu"), net, precision]
+           hip if isinstance(hip, str) else ("hip" if hip else "emu"), net, precision] + (["fused"] if fused else [])
     env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if hip != "rccl":
         env["COLDDIFF_SHARE_GPU"] = "1"                       # (both ranks on cuda:0 in the hip runs)
