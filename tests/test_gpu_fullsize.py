@@ -174,41 +174,67 @@ def _celeba_unet(seed):
     return net, {k: v.clone() for k, v in net.state_dict().items()}
 
 
-def test_cfg3_gen_sample_full_T_real_net_vs_oracle():
+T_FULL = 200
+
+
+@pytest.fixture(scope="module")
+def full_T_oracles():
+    """The two 200-step oracle trajectories (200 CPU calls of the 56.6 M-parameter Unet each, ~3 minutes apiece on the box's host) run
+    CONCURRENTLY in two threads, started here, while the tests drive the MI355X; a one-image conv forward does not scale to all host
+    cores, so two at a time take about as long as one."""
+    from concurrent.futures import ThreadPoolExecutor
+    g = torch.Generator().manual_seed(123457)
+    noise = torch.randn(1, 3, 128, 128, generator=g)
+    x = torch.randint(0, 256, (1, 3, 128, 128), generator=g).float() / 255 * 2 - 1
+    net3, sd3 = _celeba_unet(31)
+    net4, sd4 = _celeba_unet(37)
+    sig = O.blur_sigmas("Exponential_reflect", T_FULL, 15, 0.01)
+    ws = [O.gaussian_kernel2d((k, k), (s_, s_))[None, None].repeat(3, 1, 1, 1) for k, s_, _ in sig]
+    modes = [m for _, _, m in sig]
+
+    def cfg3():
+        with torch.no_grad():
+            ca, cb = O.cosine_tables(T_FULL)
+            return O.noise_sample(lambda z, s: O.unet_forward(sd3, z, s), noise, T_FULL, ca, cb, fixed_noise=True)
+
+    def cfg4():
+        with torch.no_grad():
+            return O.cold_sample(lambda z, s: O.unet_forward(sd4, z, s), lambda z, i: O.blur_step(z, ws[i], modes[i]), x, T_FULL, "x0_step_down")
+
+    ex = ThreadPoolExecutor(max_workers=2)
+    out = {"noise": noise, "x": x, "net3": net3, "net4": net4, "ws": ws, "modes": modes, "cfg3": ex.submit(cfg3), "cfg4": ex.submit(cfg4)}
+    yield out
+    ex.shutdown(wait=True)
+
+
+def test_cfg3_gen_sample_full_T_real_net_vs_oracle(full_T_oracles):
     """BASELINE config 3 end to end: `gen_sample` (x0_step_down, fixed noise; DENOISE:383-434) over all T = 200 reverse steps at
     128 x 128 with the real (random-init, 56.6 M-parameter) Unet, one image, against the oracle's sampler on CPU.  The single-call
     bound is 1e-4; over the trajectory the final image must stay within 5e-4 max(1, |img|max)."""
     from denoising_diffusion_pytorch import GaussianDiffusion
-    net, sd = _celeba_unet(31)
-    T = 200
-    g = torch.Generator().manual_seed(123457)
-    noise = torch.randn(1, 3, 128, 128, generator=g)
-    d = GaussianDiffusion(net, image_size=128, channels=3, timesteps=T, sampling_routine="x0_step_down").to(DEV)
+    f = full_T_oracles
+    d = GaussianDiffusion(f["net3"], image_size=128, channels=3, timesteps=T_FULL, sampling_routine="x0_step_down").to(DEV)
     with torch.no_grad():
-        _, direct, img = quiet(d.gen_sample, batch_size=1, img=noise.to(DEV))
-        ca, cb = O.cosine_tables(T)
-        _, rdirect, rimg = O.noise_sample(lambda z, s: O.unet_forward(sd, z, s), noise, T, ca, cb, fixed_noise=True)
+        _, direct, img = quiet(d.gen_sample, batch_size=1, img=f["noise"].to(DEV))
+    _, rdirect, rimg = f["cfg3"].result()
     e0, e1 = (direct.cpu() - rdirect).abs().max().item(), (img.cpu() - rimg).abs().max().item()
     print("cfg3 T=200 128x128 gen_sample: first-step error", e0, "final-image error", e1, "|img|max", rimg.abs().max().item())
     assert e0 <= 1e-4 and e1 <= 5e-4 * max(1.0, rimg.abs().max().item())
 
 
-def test_cfg4_algorithm2_full_T_real_net_vs_oracle():
+def test_cfg4_algorithm2_full_T_real_net_vs_oracle(full_T_oracles):
     """BASELINE config 4 end to end: `sample` = blur to x_T, then Algorithm 2 (x0_step_down, DEBLUR:393-455) with the
     Exponential_reflect chain (T = 200, k = 15, std 0.01) at 128 x 128 and the real Unet, one image, against the oracle:
     T forward blurs, T network calls, T (T + 1) / 2 + T (T - 1) / 2 blur steps on the way back."""
     from deblurring_diffusion_pytorch import GaussianDiffusion
-    net, sd = _celeba_unet(37)
-    T = 200
-    g = torch.Generator().manual_seed(123457)
-    x = torch.randint(0, 256, (1, 3, 128, 128), generator=g).float() / 255 * 2 - 1
-    d = GaussianDiffusion(net, image_size=128, device_of_kernel="cuda", channels=3, timesteps=T, kernel_std=0.01, kernel_size=15,
+    f = full_T_oracles
+    d = GaussianDiffusion(f["net4"], image_size=128, device_of_kernel="cuda", channels=3, timesteps=T_FULL, kernel_std=0.01, kernel_size=15,
                           blur_routine="Exponential_reflect", sampling_routine="x0_step_down").to(DEV)
-    ws = [m.weight.detach().cpu() for m in d.gaussian_kernels]
-    modes = [m.padding_mode for m in d.gaussian_kernels]
+    for m, w, mode in zip(d.gaussian_kernels, f["ws"], f["modes"]):      # the oracle thread blurs with the restated kernels: the same ones
+        assert torch.equal(m.weight.detach().cpu(), w) and m.padding_mode == mode
     with torch.no_grad():
-        xt, direct, img = quiet(d.sample, batch_size=1, img=x.to(DEV))
-        rxt, rdirect, rimg = O.cold_sample(lambda z, s: O.unet_forward(sd, z, s), lambda z, i: O.blur_step(z, ws[i], modes[i]), x, T, "x0_step_down")
+        xt, direct, img = quiet(d.sample, batch_size=1, img=f["x"].to(DEV))
+    rxt, rdirect, rimg = f["cfg4"].result()
     ex, e0, e1 = (xt.cpu() - rxt).abs().max().item(), (direct.cpu() - rdirect).abs().max().item(), (img.cpu() - rimg).abs().max().item()
     print("cfg4 T=200 128x128 Alg. 2: x_T error", ex, "first-step error", e0, "final-image error", e1, "|img|max", rimg.abs().max().item())
     assert ex <= 1e-5 and e0 <= 1e-4 and e1 <= 5e-4 * max(1.0, rimg.abs().max().item())
