@@ -364,6 +364,20 @@ def _provenance(path, doc):
             "running_csrc_sha16": now, "match": st.get("csrc_sha16") == now}
 
 
+def measured_bytes_step(profile_name):
+    """HBM bytes per optimizer step as the PMC counters saw them (sum over every kernel of FETCH_SIZE x 2 + WRITE_SIZE per launch x its
+    launches, divided by the Adam launches of the run): tools/pmc_traffic.py over two rocprofv3 --pmc passes of this same command, committed
+    under profiles/.  None when there is no such profile or it was taken from other kernel sources."""
+    tp = _profile(profile_name)
+    if not tp:
+        return None
+    doc = json.load(open(tp))
+    prov = _provenance(tp, doc)
+    if not prov["match"] or not doc.get("hbm_bytes_per_optimizer_step"):
+        return {"bytes_step": None, "provenance": prov}
+    return {"bytes_step": round(doc["hbm_bytes_per_optimizer_step"]), "optimizer_steps_in_profile": doc["optimizer_steps"], "provenance": prov}
+
+
 def bandwidth_classes():
     """HBM GB/s of the bandwidth-bound kernel classes: bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     (tools/pmc_traffic.py) divided by the average launch duration of the committed rocprofv3 --kernel-trace of the same command
@@ -528,6 +542,11 @@ def main():
         # whole-step view: layer-boundary bytes and 3 x F_fwd flops per image against the HBM / MFMA roofs
         npp = {"bf16x3": 3, "bf16": 1}.get(runtime.precision, 16)      # MFMAs per algorithmic product (f32: the 16x slower fp32 MFMA)
         out["step_roofline"] = step_roofline(args.batch, args.accum, 1000 * elapsed / args.steps, npp)
+        mb = measured_bytes_step("pmc_traffic.json")
+        if mb:
+            out["step_roofline"]["measured_hbm_bytes_step"] = mb["bytes_step"]
+            out["step_roofline"]["measured_over_algorithmic_bytes"] = round(mb["bytes_step"] / out["step_roofline"]["bytes_step"], 3) if mb["bytes_step"] else None
+            out["step_roofline"]["measured_provenance"] = mb["provenance"]
         step_tflops = 3 * UNET128_FWD_GFLOP * args.batch * args.accum * args.steps / elapsed / 1e3
         out["step_algorithmic_tflops"] = round(step_tflops, 2)
         out["step_frac_of_f32_mfma_peak"] = round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)
@@ -586,11 +605,21 @@ def main():
                 runtime.bump_weights_epoch()
                 out["bf16_mode"] = {"value": round(args.batch * args.accum / dtb, 2), "unit": "img/s", "ms_per_step": round(1000 * dtb, 3),
                                     "dtype": "bf16 GEMM operands (one MFMA per product), fp32 accumulate / master weights / norms / softmax / "
-                                             "degradation / optimizer; bf16 planes are the only stored form of LN and GELU outputs",
+                                             "degradation / optimizer; bf16 planes are the only stored form of LN and GELU outputs; the residual "
+                                             "stream, depthwise outputs and pre-activations stay fp32",
                                     "tolerance_vs_fp32_oracle": dict(runtime.BF16_TOLERANCE, asserted_by="tests/test_gpu_parity2.py::"
                                                                      "test_other_precision_modes_module_level[bf16] and ::test_bf16_mode_bench_shape_microstep"),
                                     "sample_ms_per_img_200step": sample_bf16, "sample_batch": args.sample_batch,
-                                    "step_roofline": step_roofline(args.batch, args.accum, 1000 * dtb, 1, act="bf16")}
+                                    # the engine AS BUILT keeps the residual stream, the depthwise output and the pre-activations in fp32
+                                    # (bf16 are the GEMM operand planes): its layer-boundary bytes are the fp32 figure; what SURVEY 8(d)'s bf16
+                                    # column would give is printed beside it, labelled as not built (the accounting must describe
+                                    # the engine that exists)
+                                    "step_roofline": step_roofline(args.batch, args.accum, 1000 * dtb, 1, act="f32"),
+                                    "step_roofline_if_bf16_activation_storage_NOT_BUILT": step_roofline(args.batch, args.accum, 1000 * dtb, 1, act="bf16")}
+                mbb = measured_bytes_step("pmc_traffic_bf16.json")
+                if mbb:
+                    out["bf16_mode"]["step_roofline"]["measured_hbm_bytes_step"] = mbb["bytes_step"]
+                    out["bf16_mode"]["step_roofline"]["measured_provenance"] = mbb["provenance"]
                 log(f"bf16 mode: {out['bf16_mode']['value']} img/s")
                 # third, LABELLED line: the lower anchor -- every GEMM on the exact-fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32,
                 # 157 TFLOP/s dense), i.e. IEEE fp32 products; `value` above keeps 16 mantissa bits per operand and drops a_lo b_lo

@@ -54,6 +54,12 @@ def main():
         }
         summary["conv_igemm_sp"]["hbm_bytes_per_launch"] = (summary["conv_igemm_sp"]["fetch_bytes_per_launch"] +
                                                             summary["conv_igemm_sp"]["write_bytes_per_launch"])
+    # whole-run totals: bytes moved per optimizer step = sum over every kernel of (bytes per launch x launches) / Adam launches
+    steps = res.get("adam_kernel", {}).get("launches", 0)
+    summary["total_hbm_bytes"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in res.values())
+    summary["optimizer_steps"] = steps
+    if steps:
+        summary["hbm_bytes_per_optimizer_step"] = summary["total_hbm_bytes"] / steps
     summary["method"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over the same bench.py command; KiB -> bytes; "
                          "FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 bytes)")
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
