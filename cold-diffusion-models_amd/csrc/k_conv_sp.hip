@@ -1080,265 +1080,28 @@ __global__ void __launch_bounds__(512, 1) conv_igemm_halo_kernel(SpxArgs a) {
 }
 
 // ================================================================================================
-// 3 x 3 stride-1 convolutions, 256-pixel tiles with the input rows of ONE TAP ROW resident in LDS ("row-halo" kernel).
+// 3 x 3 stride-1 convolutions with 64 / 128 input channels, 256-pixel tiles, the input rows of ONE TAP ROW resident in LDS, resident
+// blocks with ONE operand stream over all the tiles of a CU ("row-halo stream" kernel).
 //
-// The halo kernel above keeps (TH + 2) x (W + 2) pixels per channel chunk; at 128-pixel width two such buffers leave room
-// for the weight stages of a 128-wide N tile only with 128-pixel tiles, where it is no faster than the generic kernel.  This
-// variant shares the input across the three dx taps only: per (channel chunk, dy) it fetches the tile's TH rows shifted by
-// dy, with one pixel of halo left and right (TH x (W + 2) rows of 64 B, both planes, double buffered), and the three taps of
-// that row read their A fragments at pixel offsets -1, 0, +1.  A bytes per chunk 3 x 33 KB instead of 9 x 32 KB; with the
-// 256-pixel tile the weights cost half per MFMA: 141 bytes of DMA per MFMA against 250 (generic 256 x 128).  K loop:
-// chunk, dy group, dx; the rows of the next group are requested in the first step of a group, the weights 3 steps ahead
-// (4 stages).  8 waves (4 x 2 of 64 x 64).  Requires the taps in dy-major order (checked by the host).
-// Measured (MI355X): 64 -> 128 channels at 128 x 128 pixels 0.325 -> 0.298 ms (with the GELU epilogue 0.406 -> 0.381) against the
-// generic 256 x 128 kernel; at 64 pixels the halo kernel's 256-pixel tile stays ahead (0.240 vs 0.252 ms).  Used for the > 64-channel
-// outputs at 128-pixel width (bits 32 / 64 of cdf_conv_gemm_bf16x_halo).
-// ================================================================================================
-template <int W, int BN, int NS = 3, int NCH = 0>
-__global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_kernel(SpxArgs a) {
-    constexpr int BM = 256, WM = 4, WN = 2, NW = 8, BK = 32, RE = 32, MT = BM / WM / 32, NB = 4;
-    constexpr int TH = BM / W, HW2 = W + 2, RH = TH * HW2;                 // rows of one (chunk, dy) image
-    constexpr int NSEG = (RH + 15) / 16, HRP = NSEG * 16;
-    constexpr int TAG = (NSEG + NW - 1) / NW;                              // segments per wave and group, all requested in its first step
-    constexpr int NT = BN / WN / 32;
-    constexpr int SB = BN / 16 / NW;
-    static_assert(SB * NW * 16 == BN || BN == 64, "B tile must split into 16-row segments");
-    constexpr int SBI = BN == 64 ? 1 : SB;
-    constexpr int PLANE_A = HRP * RE, ABUF = 2 * PLANE_A;
-    constexpr int PLANE_B = BN * RE, BSTAGE = 2 * PLANE_B;
-    CDF_DYN_SMEM(smem_raw);
-    unsigned short* smem = (unsigned short*)smem_raw;
-    unsigned short* const abuf0 = smem;
-    unsigned short* const bst0 = smem + 2 * ABUF;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int M = a.B * a.QH * a.QW;
-    const int tiles_n = (a.Cout + BN - 1) / BN, tiles_m = M / BM;
-    const int tile = cdf_sp_swizzle(blockIdx.x, tiles_m * tiles_n);
-    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
-    const SpPhase& ph = a.ph[0];
-    const int tpi = a.H / TH;
-    const int img = tile_m / tpi, y0 = (tile_m - img * tpi) * TH;
-
-    const int srow = lane >> 2;
-    const int q8 = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
-    int a_seg[TAG], a_ry[TAG], a_x[TAG];
-#pragma unroll
-    for (int q = 0; q < TAG; ++q) {
-        int g = wave + NW * q;
-        if (g >= NSEG) g -= (g / NSEG) * NSEG;                 // (repeats: same bytes to the same place, equal DMA counts per wave)
-        a_seg[q] = g;
-        const int r = g * 16 + srow;
-        a_ry[q] = r < RH ? r / HW2 : -(1 << 20);               // rows past the image of the group: always outside
-        a_x[q] = r - (r / HW2) * HW2 - 1;
-    }
-    int b_row[SBI];
-#pragma unroll
-    for (int p = 0; p < SBI; ++p) {
-        const int seg = BN == 64 ? (wave & 3) : wave * SB + p;
-        const int n = tile_n * BN + seg * 16 + srow;
-        b_row[p] = n < a.Cout ? n : a.Cout - 1;
-    }
-    const int nchunks = a.Cin / BK;
-
-    auto fetch_a = [&](int c, int dy, int buf) {             // rows of (chunk c, tap row with offset dy) -> buffer buf: all of this wave's segments
-#pragma unroll
-        for (int q = 0; q < TAG; ++q) {
-            const int y = y0 + a_ry[q] + dy;
-            const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)a_x[q] < (unsigned)W;
-            const size_t off = ((size_t)((img * a.H + (ok ? y : 0)) * W + (ok ? a_x[q] : 0))) * (unsigned)a.ldx + (unsigned)(c * BK + q8);
-            unsigned short* seg = abuf0 + buf * ABUF + a_seg[q] * 16 * RE;
-            CDF_GLDS16_K(ok ? a.x_hi + off : a.zero, seg);
-            if constexpr (NS == 3) CDF_GLDS16_K(ok ? a.x_lo + off : a.zero, seg + PLANE_A);
-        }
-    };
-    auto fetch_b = [&](int c, int wi, int stage) {           // weights of (chunk c, tap with weight index wi)
-        unsigned short* st = bst0 + stage * BSTAGE;
-#pragma unroll
-        for (int p = 0; p < SBI; ++p) {
-            const int seg = BN == 64 ? (wave & 3) : wave * SB + p;
-            const size_t woff = (size_t)((unsigned)wi * (unsigned)a.Cout + (unsigned)b_row[p]) * (unsigned)a.ldk + (unsigned)(c * BK + q8);
-            CDF_GLDS16_K(a.w_hi + woff, st + seg * 16 * RE);
-            if constexpr (NS == 3) CDF_GLDS16_K(a.w_lo + woff, st + PLANE_B + seg * 16 * RE);
-        }
-    };
-    constexpr int NPL = NS == 3 ? 2 : 1;
-    constexpr int PB = NPL * SBI, PAG = NPL * TAG;           // DMA instructions per wave: one weight step, one group of rows
-
-    f32x16_t acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int half = lane >> 5, l31 = lane & 31;
-    int row0[MT];                                            // this lane's A fragment rows for dx = 0
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int pix = wm * (BM / WM) + i * 32 + l31;
-        const int py = pix / W, px = pix - py * W;
-        row0[i] = py * HW2 + px + 1;
-    }
-    const int swb = (l31 >> 2) & 3;
-
-    // ---- prologue: rows of (chunk 0, tap row 0), weights of steps 0 .. 2
-    fetch_a(0, ph.dy[0], 0);
-#pragma unroll
-    for (int u = 0; u < NB - 1; ++u) fetch_b(0, ph.wi[u], u);
-    CDF_WAIT_DMA_LEAVE((NB - 2) * PB);
-    CDF_LDS_BARRIER();
-    bf16x8_v ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
-    const bool late = a.dephase != 0 && wave >= NW / 2;      // (wave-uniform)
-    if (late) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { ah[ks][i][e] = 0; al[ks][i][e] = 0; }
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { bh[ks][j][e] = 0; bl[ks][j][e] = 0; }
-        }
-    }
-    auto mma_frags = [&]() { cdf_mma_tile<NS, MT, NT>(acc, ah, al, bh, bl); };
-    int rd = 0, par = 0;                                     // weight stage / row buffer of the current step
-    static_assert(NB == 4, "the weights of a step are requested exactly one tap-row group (3 steps) ahead");
-    if constexpr (NCH > 0) {
-    // K loop with a compile-time chunk count, fully unrolled: tap row, chunk, dx -- the chunks of one tap row in consecutive groups.  A
-    // 32-channel chunk is 64 bytes of a pixel, half a 128-byte line, and a half-line request costs the whole line
-    // (profiles/round3_fetch_half_lines.md): with the chunk loop outermost the second half of a line is asked for nine tap steps after
-    // the first and mostly comes over the fabric again.  (Rolled loops in this order made hipcc keep the per-tap-row addresses live
-    // across the chunk loop: 24-82 VGPR spills.)
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-#pragma unroll
-            for (int i3 = 0; i3 < 3; ++i3) {
-                const int t = 3 * g + i3;
-                // the group one ahead: (g, c + 1), or (g + 1, 0) after the last chunk; past the end the last group again (idle buffer / stage)
-                const bool lastc = c + 1 == NCH;
-                const int nc = lastc ? (g < 2 ? 0 : c) : c + 1, ng = lastc && g < 2 ? g + 1 : g;
-                if (i3 == 0) fetch_a(nc, ph.dy[3 * ng], par ^ 1);
-                fetch_b(nc, ph.wi[3 * ng + i3], rd == 0 ? NB - 1 : rd - 1);
-                const unsigned short* sa = abuf0 + par * ABUF;
-                const unsigned short* sb = bst0 + rd * BSTAGE;
-                rd = rd + 1 == NB ? 0 : rd + 1;
-                const int dx = ph.dx[t];
-                auto read_frags = [&]() {
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                        for (int i = 0; i < MT; ++i) {
-                            const int row = row0[i] + dx;
-                            const int off = row * RE + ((ks * 2 + half) ^ ((row >> 2) & 3)) * 8;
-                            ah[ks][i] = *(const bf16x8_v*)(sa + off);
-                            if constexpr (NS == 3) al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
-                        }
-                        const int kc = ((ks * 2 + half) ^ swb) * 8;
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) {
-                            const int offb = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
-                            bh[ks][j] = *(const bf16x8_v*)(sb + offb);
-                            if constexpr (NS == 3) bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + offb);
-                        }
-                    }
-                };
-                if (late) {                                      // de-phased waves: see conv_igemm_halo_kernel
-                    mma_frags();
-                    CDF_SCHED_FENCE();                           // (the reads overwrite the fragments just multiplied: hoisting them doubles the live set)
-                }
-                read_frags();
-                if (!late) mma_frags();
-                // the weights of step + 1 (requested 2 steps ago, AFTER that step's row requests) have landed; still in flight: the
-                // requests of the last two steps -- two weight steps, plus one group of rows if one of them was a group's first step
-                if (i3 <= 1)
-                    CDF_WAIT_DMA_LEAVE((NB - 2) * PB + PAG);
-                else
-                    CDF_WAIT_DMA_LEAVE((NB - 2) * PB);
-                CDF_LDS_BARRIER();
-                if (i3 == 2) par ^= 1;
-            }
-        }
-    }
-    } else {
-    for (int c = 0; c < nchunks; ++c) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int g = t / 3, i3 = t - 3 * g;
-            if (i3 == 0) {                                   // the next tap row's input rows (past the end: the last group again, into the idle buffer)
-                const bool end = g == 2 && c + 1 >= nchunks;
-                fetch_a(g == 2 && !end ? c + 1 : c, ph.dy[3 * (g == 2 ? (end ? 2 : 0) : g + 1)], par ^ 1);
-            }
-            {
-                const int cw = t + NB - 1 < 9 ? c : c + 1;
-                fetch_b(cw < nchunks ? cw : nchunks - 1, ph.wi[(t + NB - 1) % 9], rd == 0 ? NB - 1 : rd - 1);
-            }
-            const unsigned short* sa = abuf0 + par * ABUF;
-            const unsigned short* sb = bst0 + rd * BSTAGE;
-            rd = rd + 1 == NB ? 0 : rd + 1;
-            const int dx = ph.dx[t];
-            auto read_frags = [&]() {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        const int row = row0[i] + dx;
-                        const int off = row * RE + ((ks * 2 + half) ^ ((row >> 2) & 3)) * 8;
-                        ah[ks][i] = *(const bf16x8_v*)(sa + off);
-                        if constexpr (NS == 3) al[ks][i] = *(const bf16x8_v*)(sa + PLANE_A + off);
-                    }
-                    const int kc = ((ks * 2 + half) ^ swb) * 8;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const int offb = (wn * (BN / WN) + j * 32 + l31) * RE + kc;
-                        bh[ks][j] = *(const bf16x8_v*)(sb + offb);
-                        if constexpr (NS == 3) bl[ks][j] = *(const bf16x8_v*)(sb + PLANE_B + offb);
-                    }
-                }
-            };
-            if (late) {                                      // de-phased waves: see conv_igemm_halo_kernel
-                mma_frags();
-                CDF_SCHED_FENCE();                           // (the reads overwrite the fragments just multiplied: hoisting them doubles the live set)
-            }
-            read_frags();
-            if (!late) mma_frags();
-            // the weights of step + 1 (requested 2 steps ago, AFTER that step's row requests) have landed; still in flight: the
-            // requests of the last two steps -- two weight steps, plus one group of rows if one of them was a group's first step
-            if (i3 <= 1)
-                CDF_WAIT_DMA_LEAVE((NB - 2) * PB + PAG);
-            else
-                CDF_WAIT_DMA_LEAVE((NB - 2) * PB);
-            CDF_LDS_BARRIER();
-            if (i3 == 2) par ^= 1;
-        }
-    }
-    }
-    if (late) mma_frags();
-    CDF_WAIT_DMA_LEAVE(0);
-    CDF_LDS_BARRIER();
-
-    cdf_sp_epilogue<BM, BN, WM, WN>(a, ph, acc, (float*)smem_raw, tile_m, tile_n, M, tid);
-}
-
-// ================================================================================================
-// The row-halo kernel as ONE operand stream over all the tiles of a CU (round 3).
+// The halo kernel above keeps (TH + 2) x (W + 2) pixels per channel chunk; at 128-pixel width two such buffers leave room for the weight
+// stages of a 128-wide N tile only with 128-pixel tiles, where it is no faster than the generic kernel.  This form shares the input
+// across the three dx taps only: per (channel chunk, dy) it fetches the tile's TH rows shifted by dy with one pixel of halo left and
+// right (TH x (W + 2) rows of 64 B, both planes, double buffered), and the three taps of that row read their A fragments at pixel offsets
+// -1, 0, +1: 141 bytes of DMA per MFMA against 250 for the generic 256 x 128 tile (64 -> 128 at 128 x 128: 0.325 -> 0.298 ms as one block
+// per tile, round 2).  Requires the taps in dy-major order (checked by the host).  Used for the > 64-channel outputs at 128-pixel width.
 //
-// Per 256-pixel tile of a short-K layer (64 -> 128 at 128 x 128: 18 tap steps) the kernel above spends ~24 us in its K loop, ~7 us
-// before it (until the first rows and weights have arrived -- every CU starts its next tile at the same moment) and ~8 us after it
-// (epilogue until the stores are acknowledged), one block per CU, nothing overlapped.  Here a block is resident and walks its tiles
-// (tile j of block b = the XCD-aware index of b + j gridDim.x), and the operand pipeline simply runs on across the tile boundary:
-// with THREE weight stages a tile's 9 NCH steps are a whole number of stage rotations and (NCH even) of row-buffer alternations, so
-// the requests the single-tile kernel wastes at the end of its loop (the "group after the last", the "steps after the last") ARE the
-// next tile's first rows and weights, landing in row buffer 0 and weight stages 0, 1 while the epilogue runs.  The epilogue goes in two
-// passes of 128 rows through a staging tile that aliases only what is idle then -- row buffer 1, weight stage 2 and the tail of the LDS:
+// Round 3: per 256-pixel tile of such a short-K layer (18 tap steps) a one-tile block spent ~24 us in its K loop, ~7 us before it (until
+// the first rows and weights have arrived) and ~8 us after it (epilogue until the stores are acknowledged), one block per CU, nothing
+// overlapped.  Here a block is resident and walks its tiles (tile j of block b = the XCD-aware index of b + j gridDim.x), and the operand
+// pipeline runs on across the tile boundary: with THREE weight stages a tile's 9 NCH steps are a whole number of stage rotations and
+// (NCH even) of row-buffer alternations, so the requests a one-tile loop wastes past its last step ARE the next tile's first rows and
+// weights, landing in row buffer 0 and weight stages 0, 1 while the epilogue runs.  The epilogue goes in two passes of 128 rows through
+// a staging tile that aliases only what is idle then -- row buffer 1, weight stage 2 and the tail of the LDS:
 //     LDS:  rows 0 | weights 0 | weights 1 | rows 1 | weights 2 | ...        staging [128][BN + 8] floats from "rows 1" on
-// K loop: tap row, chunk, dx (fully unrolled, see above); 8 waves (4 x 2 of 64 x 64), late waves de-phased as in the other kernels.
+// K loop: tap row, chunk, dx, fully unrolled (the two half-line chunks of a 64-channel pixel in consecutive groups: a 32-channel chunk
+// is half a 128-byte line, and half-line reads cost full lines); 8 waves (4 x 2 of 64 x 64), late waves de-phased as in the other kernels.
+// -6 ... -9 % against the one-tile form (removed in round 4, profiles/round3_rowhalo_stream_ab.txt).  Round 4, measured and not kept:
+// blocks walking CONTIGUOUS runs of tiles (profiles/round4_rowhalo_strips_ab.txt).
 // ================================================================================================
 template <int W, int BN, int NS = 3, int NCH = 2, int BM = 256>
 __global__ void __launch_bounds__(512, 1) conv_igemm_rowhalo_stream_kernel(SpxArgs a) {
@@ -2508,50 +2271,30 @@ static int launch_igemm_halo(const SpxArgs& a, int M, hipStream_t s) {
 }
 
 template <int NS, int W, int BN>
-static int launch_igemm_rowhalo(const SpxArgs& a, int M, hipStream_t s, bool stream_tiles = false, int reserve = 0) {
+static int launch_igemm_rowhalo_stream(const SpxArgs& a, int M, hipStream_t s, int reserve) {
     constexpr int TH = 256 / W, RH = TH * (W + 2), HRP = (RH + 15) / 16 * 16;
-    constexpr size_t stages = (size_t)2 * 2 * HRP * 64 + (size_t)4 * 2 * BN * 64;
-    constexpr size_t epi = (size_t)256 * (BN + 8) * sizeof(float);
-    constexpr size_t lds = stages > epi ? stages : epi;
-    static_assert(lds <= 160 * 1024, "row-halo tile does not fit the LDS");
+    constexpr size_t st_a = (size_t)2 * HRP * 64, st_b = (size_t)2 * BN * 64;
+    constexpr size_t lds_s = (st_a + 2 * st_b) + ((st_a + st_b) > (size_t)128 * (BN + 8) * 4 ? (st_a + st_b) : (size_t)128 * (BN + 8) * 4);
+    static_assert(lds_s <= 160 * 1024, "streaming row-halo tile does not fit the LDS");
 #ifndef CDF_EMU
     static CdfDeviceLatch attr_done;
     if (attr_done.first()) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_kernel<W, BN, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_kernel<W, BN, NS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_stream_kernel<W, BN, NS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_stream_kernel<W, BN, NS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
 #endif
     const int tiles = (M / 256) * cdf_cdiv(a.Cout, BN);
-    if (stream_tiles && (a.Cin == 64 || a.Cin == 128)) {       // resident blocks, one operand stream over all the tiles of a CU
-        constexpr size_t st_a = (size_t)2 * HRP * 64, st_b = (size_t)2 * BN * 64;
-        constexpr size_t lds_s = (st_a + 2 * st_b) + ((st_a + st_b) > (size_t)128 * (BN + 8) * 4 ? (st_a + st_b) : (size_t)128 * (BN + 8) * 4);
-        static_assert(lds_s <= 160 * 1024, "streaming row-halo tile does not fit the LDS");
-#ifndef CDF_EMU
-        static CdfDeviceLatch attr2_done;
-        if (attr2_done.first()) {
-            (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_stream_kernel<W, BN, NS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)conv_igemm_rowhalo_stream_kernel<W, BN, NS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        }
-#endif
-        // resident blocks: one per CU -- minus the CUs the caller keeps free for kernels that run concurrently (cdf_gemm_tuning.resident_reserve:
-        // the collectives of a multi-rank gradient exchange; a resident block that finds its CU taken would run its fixed share of the tiles
-        // after everybody else), in whole XCD rounds
-        int ncu = cdf_num_cus() - (reserve + 7) / 8 * 8;
-        if (ncu < 8) ncu = 8;
-        const int grid = tiles < ncu ? tiles : ncu;
-        if (a.Cin == 64)
-            CDF_LAUNCH((conv_igemm_rowhalo_stream_kernel<W, BN, NS, 2>), dim3(grid), dim3(512), lds_s, s, a);
-        else
-            CDF_LAUNCH((conv_igemm_rowhalo_stream_kernel<W, BN, NS, 4>), dim3(grid), dim3(512), lds_s, s, a);
-        return cdf_check_launch("conv_igemm_rowhalo_stream");
-    }
-    // two channel chunks (64 input channels: a pixel is ONE 128-byte line per plane): the unrolled tap-row-outermost K loop, 64 -> 128
-    // at 128 x 128 0.294 -> 0.283 ms (GELU epilogue 0.332 -> 0.326); with four chunks (128 channels) it measured +-0.5 %: not instantiated
+    // resident blocks: one per CU -- minus the CUs the caller keeps free for kernels that run concurrently (cdf_gemm_tuning.resident_reserve:
+    // the collectives of a multi-rank gradient exchange; a resident block that finds its CU taken would run its fixed share of the tiles
+    // after everybody else), in whole XCD rounds
+    int ncu = cdf_num_cus() - (reserve + 7) / 8 * 8;
+    if (ncu < 8) ncu = 8;
+    const int grid = tiles < ncu ? tiles : ncu;
     if (a.Cin == 64)
-        CDF_LAUNCH((conv_igemm_rowhalo_kernel<W, BN, NS, 2>), dim3(tiles), dim3(512), lds, s, a);
+        CDF_LAUNCH((conv_igemm_rowhalo_stream_kernel<W, BN, NS, 2>), dim3(grid), dim3(512), lds_s, s, a);
     else
-        CDF_LAUNCH((conv_igemm_rowhalo_kernel<W, BN, NS, 0>), dim3(tiles), dim3(512), lds, s, a);
-    return cdf_check_launch("conv_igemm_rowhalo");
+        CDF_LAUNCH((conv_igemm_rowhalo_stream_kernel<W, BN, NS, 4>), dim3(grid), dim3(512), lds_s, s, a);
+    return cdf_check_launch("conv_igemm_rowhalo_stream");
 }
 
 // Split-K factor of the generic pre-split GEMM for grids far below one 64-row tile per CU: the smallest divisor of the tap count
@@ -2612,10 +2355,11 @@ static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cou
         // row-halo kernel: 256-pixel tiles, input shared by the dx taps only.  Bit 32 (default): the > 64-channel outputs at
         // 128-pixel width, where it beats the generic 256 x 128 kernel (64 -> 128: 0.325 -> 0.298 ms); bit 64: wherever it applies
         // (at 64 pixels the halo kernel's 256-pixel tile stays ahead, 0.240 vs 0.252 ms)
-        if (dx_ok && M % 256 == 0 && ((T.halo & 64) || ((T.halo & 32) && W == 128 && !n64 && (long long)(M / 256) * cdf_cdiv(Cout, 128) >= 256))) {
+        if (dx_ok && M % 256 == 0 && (T.rowhalo_stream & 1) && (Cin == 64 || Cin == 128) &&
+            ((T.halo & 64) || ((T.halo & 32) && W == 128 && !n64 && (long long)(M / 256) * cdf_cdiv(Cout, 128) >= 256))) {
 #define CDF_ROWHALO_CASE(WW)                                                                                           \
     if (W == WW && H % (256 / WW) == 0)                                                                                \
-        return n64 ? launch_igemm_rowhalo<NS, WW, 64>(a, M, s, (T.rowhalo_stream & 1) != 0, T.resident_reserve) : launch_igemm_rowhalo<NS, WW, 128>(a, M, s, (T.rowhalo_stream & 1) != 0, T.resident_reserve);
+        return n64 ? launch_igemm_rowhalo_stream<NS, WW, 64>(a, M, s, T.resident_reserve) : launch_igemm_rowhalo_stream<NS, WW, 128>(a, M, s, T.resident_reserve);
             CDF_ROWHALO_CASE(128) CDF_ROWHALO_CASE(64) CDF_ROWHALO_CASE(32) CDF_ROWHALO_CASE(16)
 #undef CDF_ROWHALO_CASE
         }

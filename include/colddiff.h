@@ -183,7 +183,8 @@ typedef struct cdf_gemm_tuning {
     int wgrad_swizzle;   /* 1: XCD-aware block order of cdf_conv_wgrad_bf16x (the taps of a pixel range share one XCD's L2) */
     int wgrad_row3;      /* 1: weight gradients of 3 x 3 stride-1 same-size convolutions by one block per ROW of taps */
     int rowhalo_stream;  /* 1: the row-halo GEMM with 64 / 128 input channels runs as resident blocks with one operand stream over all the
-                            tiles of a CU (the next tile's first rows and weights arrive under the current tile's epilogue); 0: one block per tile */
+                            tiles of a CU (the next tile's first rows and weights arrive under the current tile's epilogue); 0: those layers take the LDS-resident-input
+                            / generic kernels (the one-tile row-halo kernel of rounds 2-3 is gone) */
     int resident_reserve;/* 0: CUs the resident kernels leave free (rounded up to whole rounds of the 8 XCDs).  Multi-rank training sets it: the
                             collective kernels of the gradient exchange run concurrently with backward and need CUs of their own -- a resident
                             block that finds its CU taken would run its fixed share of the tiles after everybody else */

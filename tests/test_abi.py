@@ -46,7 +46,7 @@ def test_hot_kernels_use_no_scratch():
         pytest.skip("hipcc not available")
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(repo, "cold-diffusion-models_amd", "csrc")
-    hot = {"k_conv_sp.hip": ("conv_igemm_spx_kernel", "conv_igemm_halo_kernel", "conv_igemm_rowhalo_kernel", "conv_igemm_rowhalo_stream_kernel", "conv_wgrad_spx_kernel", "conv_wgrad_row3_kernel", "conv_igemm_sp_kernel",
+    hot = {"k_conv_sp.hip": ("conv_igemm_spx_kernel", "conv_igemm_halo_kernel", "conv_igemm_rowhalo_stream_kernel", "conv_wgrad_spx_kernel", "conv_wgrad_row3_kernel", "conv_igemm_sp_kernel",
                              "conv_wgrad_sp_kernel", "split_bf16_kernel"),
            "k_conv.hip": ("conv_igemm_kernel", "unpack_reduce_kernel"),
            "k_dwconv.hip": ("dwconv7_kernel", "dwconv7_wgrad_partial_kernel"),

@@ -911,11 +911,11 @@ def test_wgrad_presplit_row_of_taps(be, case):
 @pytest.mark.parametrize("case", [(1, 64, 96, 16, 3, 1, 1), (2, 96, 40, 16, 3, 1, 1), (1, 64, 72, 32, 3, 1, 1), (1, 128, 72, 16, 3, 1, 1),
                                   (3, 64, 40, 32, 3, 1, 1), (5, 64, 136, 16, 3, 1, 1), (9, 128, 40, 16, 3, 1, 1)])
 def test_conv_presplit_rowhalo_emu(case):
-    """Row-halo form of the 3 x 3 GEMM (256-pixel tiles, input shared by the dx taps of a row) forced at every width (bit 64 of
-    the halo hook; by default it serves the 128-pixel layers, which the GPU cases cover).  64 input channels take the unrolled K loop
-    with the tap row outermost (2 chunks), 96 / 128 the rolled chunk-outermost one; with 64 input channels the blocks are resident and
-    stream their tiles (the simulator has 8 "CUs": the last two cases are 12 and 10 tiles, i.e. blocks with two tiles and with one),
-    and the same cases run again as one block per tile (rowhalo_stream = 0).  Simulator only, to keep the GPU suite short."""
+    """Row-halo stream form of the 3 x 3 GEMM (256-pixel tiles, input shared by the dx taps of a row, resident blocks) forced at every
+    width (bit 64 of the halo hook; by default it serves the 128-pixel layers, which the GPU cases cover).  It takes 64 / 128 input
+    channels (2 / 4 chunks per tap row, K loop fully unrolled); the simulator has 8 "CUs", so the last two cases (12 and 10 tiles) have
+    blocks with two tiles and with one.  96 input channels, and every case again with rowhalo_stream = 0, fall through to the
+    LDS-resident-input kernel (same sums).  Simulator only, to keep the GPU suite short."""
     from conftest import Backend
     be = Backend("emu")
     be.tune.set(halo=64 | 47, halo_min_tiles=1)

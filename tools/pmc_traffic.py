@@ -43,7 +43,7 @@ def main():
         res[k] = {"launches": n, "fetch_bytes_per_launch": 2.0 * f * 1024 / max(nf, 1), "write_bytes_per_launch": w * 1024 / max(nw, 1)}
         res[k]["hbm_bytes_per_launch"] = res[k]["fetch_bytes_per_launch"] + res[k]["write_bytes_per_launch"]
     # the group bench.py reports as the dominant kernel: every pre-split / in-kernel-split bf16x3 forward + data-gradient GEMM
-    grp = [v for k, v in res.items() if k.startswith(("conv_igemm_spx_kernel", "conv_igemm_sp_kernel", "conv_igemm_halo_kernel", "conv_igemm_rowhalo_kernel", "conv_igemm_rowhalo_stream_kernel"))]
+    grp = [v for k, v in res.items() if k.startswith(("conv_igemm_spx_kernel", "conv_igemm_sp_kernel", "conv_igemm_halo_kernel", "conv_igemm_rowhalo_stream_kernel"))]
     n = sum(v["launches"] for v in grp)
     summary = {"kernels": res}
     if n:
