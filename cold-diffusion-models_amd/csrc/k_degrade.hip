@@ -218,11 +218,92 @@ __global__ void __launch_bounds__(1024) blur_plane_sep_kernel(BlurArgs a) {
     const int strips_per_row = W / 4, nstrips = strips_per_row * H;
     constexpr int H4 = K > 0 ? ((K / 2 + 3) & ~3) : 0;               // aligned left reach of the fast row pass
     constexpr int NV = K > 0 ? (2 * H4 + 4) / 4 : 1;                 // float4s covering [x0 - H4, x0 + 4 + H4)
+    // Round 4: 4 x 4-pixel register tiles for the compile-time kernel sizes (planes whose height is a multiple of 4).  With one
+    // 4-pixel strip per thread the column pass read a float4 of T per tap (15 ds_read_b128 + 15 weight reads per 60 FMAs at k = 15)
+    // and mapped its row index per tap; a 4 x 4 tile slides over k + 3 rows once (18 reads per 240 FMAs, the factors in registers),
+    // and the row pass keeps the same 20-float window per row.  Every output still sums its taps in ascending order: bit-identical
+    // to the strip form.  k = 15 at 128 x 128: 17.9 -> 12.2 us per step (profiles/round4_blur_tiles_ab.txt).
+    const bool tiled = K > 0 && K <= 15 && (H & 3) == 0;     // (k = 27: the tile's window and factors do not fit 128 registers)
+    const int tiles_per_row = W / 4, ntiles = tiles_per_row * (H / 4);
     for (int s = a.step_lo; s <= hi; ++s) {
         if (s == hi && prev_out)
             for (int i = tid; i < H * W; i += nt) prev_out[poff + i] = U[i];
         const float* gy = wt + (s & 1) * 128;
         const float* gx = gy + 64;
+        if (tiled) {
+            constexpr int KK = (K > 0 && K <= 15) ? K : 1;
+            // (the factors are read from LDS where they are used -- broadcast reads; k of them in registers, duplicated into pairs for
+            // the packed FMAs, cost 30 registers and spilled)
+            // pass along x: T[y][x] = sum_kx gx[kx] U[y][map(x + kx - h)], four rows of a tile one after the other
+            for (int tl = tid; tl < ntiles; tl += nt) {
+                const int ty = tl / tiles_per_row, x0 = (tl - ty * tiles_per_row) * 4, y0 = ty * 4;
+                const bool inner = x0 >= H4 && x0 + 4 + H4 <= W;
+#pragma unroll 1
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float* row = U + (y0 + rr) * W;
+                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (inner) {
+                        float r[NV * 4];
+#pragma unroll
+                        for (int q = 0; q < NV; ++q) {
+                            const float4 v = *(const float4*)(row + x0 - H4 + 4 * q);
+                            r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+                        }
+#pragma unroll
+                        for (int kx = 0; kx < KK; ++kx) {
+                            const float wv = gx[kx];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[j] = fmaf(wv, r[H4 - KK / 2 + kx + j], acc[j]);
+                        }
+                    } else {
+                        for (int e = 0; e < k + 3; ++e) {        // the strip's k + 3 source pixels, each mapped once
+                            const float v = row[cdf_pad_near(x0 + e - h, W, a.pad_mode)];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int kx = e - j;
+                                if (kx >= 0 && kx < k) acc[j] = fmaf(gx[kx], v, acc[j]);
+                            }
+                        }
+                    }
+                    *(float4*)(T + (y0 + rr) * W + x0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                }
+            }
+            fetch_w(s + 1);                                  // lands before the barrier that ends this step
+            __syncthreads();
+            // pass along y: U[y][x] = sum_ky gy[ky] T[map(y + ky - h)][x]: the tile's k + 3 source rows, each read once; source row e
+            // feeds output row j with factor gy[e - j] -- a window of four factors that slides by one per row
+            for (int tl = tid; tl < ntiles; tl += nt) {
+                const int ty = tl / tiles_per_row, x0 = (tl - ty * tiles_per_row) * 4, y0 = ty * 4;
+                float4 acc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                float wj[4] = {0.f, 0.f, 0.f, 0.f};          // wj[j] = gy[e - j]
+#pragma unroll
+                for (int e = 0; e < KK + 3; ++e) {
+                    wj[3] = wj[2]; wj[2] = wj[1]; wj[1] = wj[0];
+                    wj[0] = e < KK ? gy[e] : 0.f;
+                    const int sy = cdf_pad_near(y0 + e - h, H, a.pad_mode);
+                    const float4 v = *(const float4*)(T + sy * W + x0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (e - j >= 0 && e - j < KK) {
+                            acc[j].x = fmaf(wj[j], v.x, acc[j].x); acc[j].y = fmaf(wj[j], v.y, acc[j].y);
+                            acc[j].z = fmaf(wj[j], v.z, acc[j].z); acc[j].w = fmaf(wj[j], v.w, acc[j].w);
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *(float4*)(U + (y0 + j) * W + x0) = acc[j];
+            }
+            __syncthreads();
+            if (s == a.collapse_step) {
+                float part = 0.f;
+                for (int i = tid; i < H * W; i += nt) part += U[i];
+                const float mean = cdf_block_sum(part, red) / (float)(H * W);
+                for (int i = tid; i < H * W; i += nt) U[i] = mean;
+                __syncthreads();
+            }
+            continue;
+        }
         // pass along x: T[y][x] = sum_kx gx[kx] U[y][map(x + kx - h)]
         for (int st = tid; st < nstrips; st += nt) {
             const int y = st / strips_per_row, x0 = (st - y * strips_per_row) * 4;
