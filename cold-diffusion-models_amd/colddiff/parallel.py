@@ -9,6 +9,7 @@ buckets on a side stream as soon as the blocks that own a bucket have finished t
 (so it overlaps with the rest of the backward pass), on the last accumulation micro-step only.
 Launch with `python -m torch.distributed.run --nproc-per-node N ...` (RANK / LOCAL_RANK / WORLD_SIZE).
 """
+import contextlib
 import datetime
 import os
 
@@ -50,6 +51,22 @@ def pin_device():
         torch.cuda.set_device(local_rank() % max(1, n))
 
 
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """gloo announces every new group on the PROCESS's stdout ("[Gloo] Rank 0 is connected to ...") from C++; a launcher that reads one
+    JSON line from rank 0's stdout (bench.py's contract) must not find that there: file descriptor 1 points at stderr for the duration."""
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def init_distributed(backend=None):
     """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
     if world_size() == 1 or dist.is_initialized():
@@ -65,12 +82,13 @@ def init_distributed(backend=None):
         pin_device()
     # default watchdog for the training collectives (a crashed rank / mismatched bucket sequence must surface in minutes); the
     # milestone wait, where rank 0 runs the full T-step sampler + image / checkpoint I/O, goes through milestone_barrier()
-    dist.init_process_group(backend=backend, rank=rank(), world_size=world_size(),
-                            timeout=datetime.timedelta(minutes=int(os.environ.get("COLDDIFF_DIST_TIMEOUT_MIN", "10"))))
-    # the long-wait group is created HERE, while every rank is at the same point: created lazily inside the first milestone, its
-    # rendezvous itself ran under maximal rank skew (rank 0 still sampling) against the short default timeout
-    global _milestone_group
-    _milestone_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=2))
+    with _stdout_to_stderr():
+        dist.init_process_group(backend=backend, rank=rank(), world_size=world_size(),
+                                timeout=datetime.timedelta(minutes=int(os.environ.get("COLDDIFF_DIST_TIMEOUT_MIN", "10"))))
+        # the long-wait group is created HERE, while every rank is at the same point: created lazily inside the first milestone, its
+        # rendezvous itself ran under maximal rank skew (rank 0 still sampling) against the short default timeout
+        global _milestone_group
+        _milestone_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=2))
 
 
 _milestone_group = None
@@ -85,7 +103,8 @@ def milestone_barrier():
     if world_size() == 1 or not dist.is_initialized():
         return
     if _milestone_group is None:                  # (a process group somebody else initialised: all ranks reach their first barrier together)
-        _milestone_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=2))
+        with _stdout_to_stderr():
+            _milestone_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=2))
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     dist.barrier(group=_milestone_group)
