@@ -431,8 +431,8 @@ class Trainer(EvalMixin):
         return self.core(batch) if x2 is None else self.core(batch, x2)
 
     def train_step(self):
-        """One optimizer step = gradient_accumulate_every micro-steps + Adam (+ EMA); returns the
-        mean micro-step loss as a 0-dim device tensor (no host sync)."""
+        """One optimizer step = gradient_accumulate_every micro-batches (one fused pass when `_can_fuse()`, else one forward /
+        backward each: DEBLUR:1188-1195) + Adam (+ EMA); returns the mean micro-batch loss as a 0-dim device tensor (no host sync)."""
         acc = self.gradient_accumulate_every
         scale = 1.0 / (acc * parallel.world_size())
         total = None
