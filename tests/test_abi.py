@@ -123,3 +123,34 @@ def test_argument_checks_of_the_gemm_and_blend_entry_points():
     expect(lib.cdf_conv_gemm_bf16x, bad, "bad cdf_gemm_tuning")
     assert not [n for n in lib.protos if n.endswith(("_tile", "_halo", "_halo_bm", "_dephase", "_deep", "_splitk", "_taprot", "_waves", "_row3",
                                                      "_swizzle", "_stack", "_onepass", "_slots", "_tiled", "_max_bm", "_small_n64")) and n != "cdf_conv_wgrad_bf16x_is_row3"]
+
+
+def test_bench_quotes_profiles_only_with_matching_provenance(tmp_path):
+    """bench.py's traffic / per-class figures come from committed rocprofv3 summaries: a summary stamped with another digest of the
+    kernel sources (or with none, like the round-1..3 files) must not be quoted (VERDICT r3, weak #8)."""
+    import importlib.util
+    import json
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cdf_bench", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sys.path.insert(0, os.path.join(repo, "tools"))
+    import provenance
+    now = provenance.csrc_sha16()
+    assert len(now) == 16 and provenance.stamp()["csrc_sha16"] == now
+    p = str(tmp_path / "x.json")
+    assert bench._provenance(p, {"provenance": {"git_head": "abc", "csrc_sha16": now}})["match"] is True
+    assert bench._provenance(p, {"_provenance": {"git_head": "abc", "csrc_sha16": now}})["match"] is True      # (kernel-trace summaries)
+    assert bench._provenance(p, {"provenance": {"git_head": "abc", "csrc_sha16": "0" * 16}})["match"] is False
+    assert bench._provenance(p, {})["match"] is False                                                            # unstamped: never quoted
+    # the digest follows the sources: any byte of a kernel file changes it
+    src = os.path.join(repo, "cold-diffusion-models_amd", "csrc", "k_misc.hip")
+    data, st = open(src, "rb").read(), os.stat(src)
+    try:
+        open(src, "ab").write(b"\n// x\n")
+        assert provenance.csrc_sha16() != now
+    finally:
+        open(src, "wb").write(data)
+        os.utime(src, ns=(st.st_atime_ns, st.st_mtime_ns))       # (the build caches objects by mtime: leave no trace)
+    assert provenance.csrc_sha16() == now
