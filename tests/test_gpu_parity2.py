@@ -2,7 +2,7 @@
 BASELINE configs actually run, checked against the CPU oracle on the MI355X.
 
   * cfg1 network `Unet(dim=64, channels=1)` at 32x32 (mnist_train.py:64-92)
-  * the BENCH shape: one B=32, 128x128 micro-step (the auto-chooser's 256-pixel halo / 256x128 tiles), loss + every gradient
+  * the BENCH shape: the fused 2 x 32-image, 128x128 pass of one optimizer step (Trainer._fused_step), loss + every gradient
   * bicubic / bilinear `Incremental_factor_2` pixelation at 128x128 against ATen (RESOL:371-372)
   * split-precision (bf16x3) GEMMs on wide-dynamic-range operands, and the other arithmetic modes at module level
   * multi-step sampler drift on a real net (T=50, 32x32)
@@ -58,34 +58,74 @@ def test_cfg1_unet_one_channel_32():
     _grad_check(net, {k: v.grad for k, v in ps.items()})
 
 
-def test_bench_shape_microstep_vs_oracle():
-    """The shape bench.py times: Unet128, B=32 at 128x128 (=> the large-M tile choices: 256-pixel halo tiles, 256x128 generic
-    tiles, lean plane-only tensors), one micro-step of the denoising package (q_sample -> UNet -> L1 -> backward).
-    The oracle processes the same 32 images in chunks of 4 (gradients of a mean are additive over samples)."""
-    from denoising_diffusion_pytorch import GaussianDiffusion, Unet
+BENCH_B, BENCH_ACC, BENCH_T = 32, 2, 200     # bench.py's optimizer step: gradient_accumulate_every = 2 micro-batches of 32 images
+
+
+@pytest.fixture(scope="module")
+def bench_step_oracle():
+    """The oracle side of the step bench.py times, computed ONCE for the bf16x3 and the bf16 test (a thread, so the CPU works while
+    the MI355X does): the reference's optimizer-step semantics (DEBLUR:1188-1195) -- two micro-batches of 32, (loss_i / 2).backward()
+    each -- i.e. loss = mean of the two micro-batch losses, gradient = the sum of both backward passes; 16 chunks of 4 images
+    (gradients of a mean are additive over samples)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from denoising_diffusion_pytorch import Unet
     torch.manual_seed(123457)
     net = quiet(Unet, dim=64, dim_mults=(1, 2, 4, 8), channels=3)
     sd = {k: v.clone() for k, v in net.state_dict().items()}
-    B, T = 32, 200
     g = torch.Generator().manual_seed(123457)
-    x = torch.randint(0, 256, (B, 3, 128, 128), generator=g).float() / 255 * 2 - 1
-    e = torch.randn(B, 3, 128, 128, generator=g)
-    t = torch.randint(0, T, (B,), generator=g)
-    diff = GaussianDiffusion(net, image_size=128, channels=3, timesteps=T, loss_type='l1').to(DEV)
-    loss = diff.p_losses(x.to(DEV), e.to(DEV), t.to(DEV))
-    loss.backward()
+    n = BENCH_B * BENCH_ACC
+    x = torch.randint(0, 256, (n, 3, 128, 128), generator=g).float() / 255 * 2 - 1
+    e = torch.randn(n, 3, 128, 128, generator=g)
+    t = torch.randint(0, BENCH_T, (n,), generator=g)
+
+    def run():
+        ca, cb = O.cosine_tables(BENCH_T)
+        ps = {k: v.clone().requires_grad_() for k, v in sd.items()}
+        micro = []
+        for m in range(BENCH_ACC):
+            tot = 0.0
+            for i in range(m * BENCH_B, (m + 1) * BENCH_B, 4):
+                s = slice(i, i + 4)
+                li = (x[s] - O.unet_forward(ps, O.noise_q_sample(x[s], e[s], t[s], ca, cb), t[s])).abs().sum() / (BENCH_B * 3 * 128 * 128)
+                (li / BENCH_ACC).backward()
+                tot += li.item()
+            micro.append(tot)
+        return sum(micro) / BENCH_ACC, {k: v.grad for k, v in ps.items()}
+
+    ex = ThreadPoolExecutor(max_workers=1)
+    yield {"sd": sd, "x": x, "e": e, "t": t, "oracle": ex.submit(run)}
+    ex.shutdown(wait=True)
+
+
+def _fused_bench_step(f):
+    """One optimizer step's forward / backward through `Trainer._fused_step` -- the ONE 64-image pass bench.py times (tile selection,
+    halo_bm, split-K nsplit and the resident grids all depend on M = B H W) -- with the data / noise / t draws replaced by the fixture's."""
+    from denoising_diffusion_pytorch import GaussianDiffusion, Trainer, Unet
+    net = quiet(Unet, dim=64, dim_mults=(1, 2, 4, 8), channels=3)
+    net.load_state_dict(f["sd"])
+    diff = GaussianDiffusion(net.to(DEV), image_size=128, channels=3, timesteps=BENCH_T, loss_type='l1').to(DEV)
+    tr = quiet(Trainer, diff, None, image_size=128, train_batch_size=BENCH_B, train_lr=2e-5, train_num_steps=1, gradient_accumulate_every=BENCH_ACC,
+               dataset="synthetic", results_folder="/tmp/cdf_bench_shape_res")
+    assert tr._can_fuse(), "the bench's step must take the fused path"
+    xs = iter(f["x"].split(BENCH_B))
+    es = iter(f["e"].split(BENCH_B))
+    ts = iter(f["t"].split(BENCH_B))
+    tr._next_batch = lambda: next(xs).to(DEV)
+    tr._second = lambda batch: next(es).to(DEV)
+    tr.core._draw_t = lambda x: next(ts).to(DEV)
+    loss = tr._fused_step(BENCH_ACC, False)
     torch.cuda.synchronize()
-    ca, cb = O.cosine_tables(T)
-    ps = {k: v.clone().requires_grad_() for k, v in sd.items()}
-    total = 0.0
-    for i in range(0, B, 4):
-        s = slice(i, i + 4)
-        li = (x[s] - O.unet_forward(ps, O.noise_q_sample(x[s], e[s], t[s], ca, cb), t[s])).abs().sum() / x.numel()
-        li.backward()
-        total += li.item()
-    assert abs(loss.item() - total) <= 2e-5 * abs(total), (loss.item(), total)
-    worst = _grad_check(net, {k: v.grad for k, v in ps.items()})
-    print("bench-shape micro-step: loss", loss.item(), "oracle", total, "worst grad error / limit", worst)
+    return tr, net, loss.item()
+
+
+def test_bench_shape_fused_step_vs_oracle(bench_step_oracle):
+    """The pass bench.py times -- Unet128, 2 x 32 images at 128 x 128 as ONE 64-image pass (`Trainer._fused_step`), denoising package:
+    q_sample -> UNet -> L1 -> backward -- against the oracle's two separate micro-steps: loss to 2e-5 relative, every gradient."""
+    _, net, loss = _fused_bench_step(bench_step_oracle)
+    total, grads = bench_step_oracle["oracle"].result()
+    worst = _grad_check(net, grads)
+    print("bench-shape fused step (B=64): loss", loss, "oracle", total, "rel", abs(loss - total) / abs(total), "worst grad error / limit", worst)
+    assert abs(loss - total) <= 2e-5 * abs(total), (loss, total)
 
 
 @pytest.mark.parametrize("routine,mode", [("Incremental_factor_2", "bicubic"), ("Incremental_bilinear_factor_2", "bilinear")])
@@ -191,39 +231,20 @@ def test_other_precision_modes_module_level(mode, tol, gtol):
         print(mode, "forward max-abs error", err, "worst gradient error / limit", worst, "(limit", gtol, ")")
 
 
-def test_bf16_mode_bench_shape_microstep():
-    """The bf16 line of bench.py at ITS shape: Unet128, B=32 at 128x128, one denoising micro-step in COLDDIFF_PRECISION=bf16 against
-    the fp32 oracle (chunks of 4 images): loss within BF16_LOSS_TOL relative, every gradient tensor within BF16_GRAD_TOL."""
-    from denoising_diffusion_pytorch import GaussianDiffusion, Unet
+def test_bf16_mode_bench_shape_fused_step(bench_step_oracle):
+    """The bf16 line of bench.py at ITS shape: the same fused 64-image pass in COLDDIFF_PRECISION=bf16 against the fp32 oracle:
+    loss within BF16_LOSS_TOL relative, every gradient tensor within BF16_GRAD_TOL."""
     with _precision("bf16"):
-        torch.manual_seed(123457)
-        net = quiet(Unet, dim=64, dim_mults=(1, 2, 4, 8), channels=3)
-        sd = {k: v.clone() for k, v in net.state_dict().items()}
-        B, T = 32, 200
-        g = torch.Generator().manual_seed(123457)
-        x = torch.randint(0, 256, (B, 3, 128, 128), generator=g).float() / 255 * 2 - 1
-        e = torch.randn(B, 3, 128, 128, generator=g)
-        t = torch.randint(0, T, (B,), generator=g)
-        diff = GaussianDiffusion(net, image_size=128, channels=3, timesteps=T, loss_type='l1').to(DEV)
-        loss = diff.p_losses(x.to(DEV), e.to(DEV), t.to(DEV))
-        loss.backward()
-        torch.cuda.synchronize()
-    ca, cb = O.cosine_tables(T)
-    ps = {k: v.clone().requires_grad_() for k, v in sd.items()}
-    total = 0.0
-    for i in range(0, B, 4):
-        s = slice(i, i + 4)
-        li = (x[s] - O.unet_forward(ps, O.noise_q_sample(x[s], e[s], t[s], ca, cb), t[s])).abs().sum() / x.numel()
-        li.backward()
-        total += li.item()
-    assert abs(loss.item() - total) <= BF16_LOSS_TOL * abs(total), (loss.item(), total)
-    worst = _grad_check(net, {k: v.grad for k, v in ps.items()}, tol=BF16_GRAD_TOL)
-    print("bf16 bench-shape micro-step: loss", loss.item(), "oracle", total, "worst grad error / limit", worst)
+        _, net, loss = _fused_bench_step(bench_step_oracle)
+    total, grads = bench_step_oracle["oracle"].result()
+    worst = _grad_check(net, grads, tol=BF16_GRAD_TOL)
+    print("bf16 bench-shape fused step (B=64): loss", loss, "oracle", total, "rel", abs(loss - total) / abs(total), "worst grad error / limit", worst)
+    assert abs(loss - total) <= BF16_LOSS_TOL * abs(total), (loss, total)
 
 
 def test_sampler_drift_real_net_T50():
     """Alg. 2 over 50 reverse steps with a real (random-init, dim 64) network at 32x32: the error of a single UNet call must not
-    compound beyond the 1e-4 parity bound x a small factor over the whole trajectory (compared with the oracle's sampler)."""
+    leave the 1e-4 parity bound over the whole trajectory (measured 5e-6) (compared with the oracle's sampler)."""
     from denoising_diffusion_pytorch import GaussianDiffusion, Unet
     torch.manual_seed(11)
     net = quiet(Unet, dim=64, dim_mults=(1, 2, 4, 8), channels=3)
@@ -237,7 +258,7 @@ def test_sampler_drift_real_net_T50():
         _, rdirect, rimg = O.noise_sample(lambda z, s: O.unet_forward(sd, z, s), noise, T, ca, cb, fixed_noise=True)
     e0, e1 = (direct.cpu() - rdirect).abs().max().item(), (img.cpu() - rimg).abs().max().item()
     print("T=50 sampler: first-step error", e0, "final-image error", e1, "|img|max", rimg.abs().max().item())
-    assert e0 <= 1e-4 and e1 <= 5e-4 * max(1.0, rimg.abs().max().item())
+    assert e0 <= 1e-4 and e1 <= 1e-4
 
 
 def test_gradsync_single_rank_rccl():
