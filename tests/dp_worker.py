@@ -45,10 +45,10 @@ with contextlib.redirect_stdout(io.StringIO()):
         net = Model(ch=32, out_ch=3, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(4,), dropout=0.0, in_channels=3, resolution=8)
     else:
         net = Unet(dim=8, dim_mults=(1, 2), channels=3)
-if rank == 1:      # ranks must converge to rank 0's weights through the initial broadcast
+if rank >= 1:      # ranks must converge to rank 0's weights through the initial broadcast
     with torch.no_grad():
         for p in net.parameters():
-            p.add_(1.0)
+            p.add_(float(rank))
 if ON_HIP:
     net = net.to(DEV)
 diff = GaussianDiffusion(net, image_size=8, channels=3, timesteps=10)
@@ -122,5 +122,5 @@ assert [b for b, _ in launch_log[:len(sync.bounds)]] == sync.order          # sa
 if ON_HIP:
     torch.cuda.synchronize()
 torch.save({"sd": {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, "buckets": len(sync.bounds),
-            "max_uses": max(sync.uses), "early": min(early)}, out_path + f".rank{rank}")
+            "max_uses": max(sync.uses), "early": min(early), "order": [b for b, _ in launch_log]}, out_path + f".rank{rank}")
 torch.distributed.barrier()

@@ -263,6 +263,18 @@ def test_device_loader_rank_shards():
     assert loaders[0].gen.initial_seed() != loaders[1].gen.initial_seed()                 # ranks draw different crops / mirrors
     loaders[0]._new_epoch()
     assert loaders[0].order.tolist() != a                                                  # reshuffled every epoch (set_epoch)
+    # nothing two-rank-shaped: 4 and 8 ranks (the node of SURVEY 8(e)) -- shards pairwise disjoint, equal-sized, covering all but
+    # the n % world images DistributedSampler(drop_last) leaves out, per-rank augmentation streams all different
+    FakeCache.__len__ = lambda self: 37
+    for world in (4, 8):
+        lds = [DeviceLoader(FakeCache(), 2, seed=3, rank=r, world=world) for r in range(world)]
+        for ld in lds:
+            ld._new_epoch()
+        shards = [ld.order.tolist() for ld in lds]
+        assert all(len(sh) == 37 // world for sh in shards)
+        union = set().union(*shards)
+        assert len(union) == world * (37 // world) and union <= set(range(37))
+        assert len({ld.gen.initial_seed() for ld in lds}) == world
 
 
 @pytest.mark.parametrize("device_data", [False, True])

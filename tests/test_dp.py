@@ -92,25 +92,35 @@ def test_two_rank_fused_accumulation_on_the_gpu(tmp_path):
     _two_rank_case(tmp_path, 1024, "once", 8, hip=True, fused=True)
 
 
-def _two_rank_case(tmp_path, bucket_bytes, mode, min_buckets, hip, net="unet", precision="bf16x3", tol=2e-5, fused=False):
+@pytest.mark.parametrize("world,fused", [(4, True), (8, True), (4, False)])
+def test_four_and_eight_rank_training(tmp_path, world, fused):
+    """Nothing in the exchange is two-rank-shaped: the node of SURVEY 8(e) -- 4 and 8 ranks over gloo on the simulator,
+    fused accumulation (the default path) and plain micro-steps -- replicas bit-identical, weights vs the global-batch oracle of
+    2 * world micro-batches, buckets issued in the same order on every rank, per-rank RNG streams all different."""
+    _two_rank_case(tmp_path, 1024, "once", 8, hip=False, fused=fused, world=world)
+
+
+def _two_rank_case(tmp_path, bucket_bytes, mode, min_buckets, hip, net="unet", precision="bf16x3", tol=2e-5, fused=False, world=2):
     out, nsteps = str(tmp_path / "w.pt"), 2
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(HERE, "dp_worker.py"), out, str(nsteps), str(bucket_bytes), mode,
            hip if isinstance(hip, str) else ("hip" if hip else "emu"), net, precision] + (["fused"] if fused else [])
-    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, OMP_NUM_THREADS="2" if world <= 2 else "1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if hip != "rccl":
         env["COLDDIFF_SHARE_GPU"] = "1"                       # (both ranks on cuda:0 in the hip runs)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    r0, r1 = torch.load(out + ".rank0"), torch.load(out + ".rank1")
-    w0, w1 = r0["sd"], r1["sd"]
+    ranks = [torch.load(out + f".rank{i}") for i in range(world)]
+    r0, w0 = ranks[0], ranks[0]["sd"]
     assert r0["buckets"] >= min_buckets, r0["buckets"]
     assert r0["max_uses"] >= (2 if mode == "twice" else 1)
     if r0["buckets"] >= 8:
         assert r0["early"] >= r0["buckets"] // 2, r0        # most buckets are issued DURING backward, not after it
-    for k in w0:
-        assert torch.equal(w0[k], w1[k]), k                      # replicas stay in lock-step, bit for bit
-    # single-process oracle over the global batch: 2 ranks x 2 micro-steps = accumulate 4
+    for ri in ranks[1:]:
+        assert ri["order"] == r0["order"] and ri["buckets"] == r0["buckets"]          # one collective sequence on every rank
+        for k in w0:
+            assert torch.equal(w0[k], ri["sd"][k]), k            # replicas stay in lock-step, bit for bit
+    # single-process oracle over the global batch: world ranks x 2 micro-steps = accumulate 2 * world
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "cold-diffusion-models_amd"))
     from colddiff.unet import Unet
     from colddiff.model2 import Model
@@ -125,14 +135,14 @@ def _two_rank_case(tmp_path, bucket_bytes, mode, min_buckets, hip, net="unet", p
         sd0 = {k: v.clone() for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(1)
     batches = [[[(torch.rand(2, 3, 8, 8, generator=g) * 2 - 1, torch.randn(2, 3, 8, 8, generator=g), torch.randint(0, 10, (2,), generator=g))
-                 for _ in range(2)] for _ in range(2)] for _ in range(nsteps)]
+                 for _ in range(2)] for _ in range(world)] for _ in range(nsteps)]
     ca, cb = O.cosine_tables(10)
 
     def one(p, x, e, t):
         return O.loss_fn(x, fwd(p, O.noise_q_sample(x, e, t, ca, cb), t))
 
     loss = one if mode == "once" else (lambda p, x, e, t: one(p, x, e, t) + one(p, x, -e, t))
-    otr = O.OracleTrainer(sd0, loss, lr=1e-3, accumulate=4)
+    otr = O.OracleTrainer(sd0, loss, lr=1e-3, accumulate=2 * world)
     for s in range(nsteps):
         otr.train_step([b for rank_b in batches[s] for b in rank_b])
     bad = total = 0
