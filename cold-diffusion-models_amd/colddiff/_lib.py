@@ -111,8 +111,14 @@ class GemmTuning:
                            ("COLDDIFF_SPX_MAX_BM", "max_bm"), ("COLDDIFF_SPX_DEPHASE", "dephase"), ("COLDDIFF_SPX_SMALL_N64", "small_n64"),
                            ("COLDDIFF_WGRAD_ROW3", "wgrad_row3"), ("COLDDIFF_ROWHALO_STREAM", "rowhalo_stream"), ("COLDDIFF_WGRAD_SWIZZLE", "wgrad_swizzle"), ("COLDDIFF_WGRAD_STACK", "wgrad_stack"), ("COLDDIFF_RESIDENT_RESERVE", "resident_reserve")):
             if env(var):
-                self.set(**{field: int(env(var))})
+                v = int(env(var))
+                lo, hi = self._RANGE.get(field, (None, None))
+                if lo is not None and not lo <= v <= hi:       # named here: the library only says `bad cdf_gemm_tuning` (on every GEMM call)
+                    raise ValueError(f"{var}={v}: cdf_gemm_tuning.{field} takes {lo}..{hi}")
+                self.set(**{field: v})
         return self
+
+    _RANGE = {"rowhalo_stream": (0, 1), "resident_reserve": (0, 248), "halo_bm": (0, 256), "max_bm": (0, 256)}
 
 
 # int-returning entry points that are pure host-side queries (sizes / counts), not status codes

@@ -156,6 +156,7 @@ class GradSync:
             for p in arena.params[i:j]:
                 self.bucket_of[id(p)] = b
         self.order = list(range(len(self.bounds) - 1, -1, -1))
+        self.resident_reserve, self.resident_reserve_source = 0, "single rank / CPU: resident grids take every CU"
         self.comm_stream = torch.cuda.Stream() if self.on_gpu else None
         if self.world > 1 and self.on_gpu:
             # The resident ("streaming") GEMM blocks hold every CU for a whole launch with a FIXED share of the tiles each; the collective
@@ -164,7 +165,8 @@ class GradSync:
             # runs the SAME kernels as N = 1 with a few CUs left out of the resident grids (cdf_gemm_tuning.resident_reserve; RCCL's
             # channels are one workgroup each, 32 covers its default channel count on this part) -- round 3 switched the resident form
             # off instead, i.e. N > 1 ran other GEMM kernels than the N = 1 line.
-            rt.tuning().set(resident_reserve=int(os.environ.get("COLDDIFF_RESIDENT_RESERVE", "32")))
+            self.resident_reserve, self.resident_reserve_source = resident_reserve()
+            rt.tuning().set(resident_reserve=self.resident_reserve)
         self.armed = False
         self.uses = [0] * len(self.bounds)
         self.pending = None
@@ -263,7 +265,41 @@ class GradSync:
         return {"buckets": len(self.bounds), "bytes_per_step": nbytes, "allreduce_ms_per_step": round(comm / n, 3),
                 "exposed_ms_per_step": round(exposed / n, 3), "hidden_ms_per_step": round(max(0.0, comm - exposed) / n, 3),
                 "busbw_gbs": round(nbytes * 2 * (self.world - 1) / self.world / (comm / n * 1e-3) / 1e9, 1) if comm > 0 else None,
-                "steps": n}
+                "steps": n, "resident_reserve_cus": self.resident_reserve, "resident_reserve_from": self.resident_reserve_source}
+
+
+RESERVE_MAX = 248          # cdf_gemm_tuning.resident_reserve's range (include/colddiff.h): at least one XCD round of CUs stays in the grid
+
+
+def resident_reserve(env=None):
+    """CUs the resident GEMM grids leave free for the collective kernels that run beside backward -> (count, where it came from).
+    An RCCL channel is one workgroup, and a workgroup that finds every CU held by a resident block waits for a whole launch -- so the
+    reserve is RCCL's channel count, in whole rounds of the 8 XCDs: COLDDIFF_RESIDENT_RESERVE when set (validated HERE, with the
+    variable's name in the error, instead of failing every GEMM call with the library's generic `bad cdf_gemm_tuning`), else
+    NCCL_MAX_NCHANNELS (the user's cap on the channel count -- RCCL reads the NCCL_* names), else NCCL_MIN_NCHANNELS if that is larger than
+    the default, else 32 (RCCL's default upper channel count per collective on this part)."""
+    env = os.environ if env is None else env
+
+    def num(name):
+        v = env.get(name)
+        if v is None or v == "":
+            return None
+        try:
+            return int(v)
+        except ValueError:
+            raise ValueError(f"{name}={v!r}: expected an integer") from None
+
+    v = num("COLDDIFF_RESIDENT_RESERVE")
+    if v is not None:
+        if not 0 <= v <= RESERVE_MAX:
+            raise ValueError(f"COLDDIFF_RESIDENT_RESERVE={v}: the resident GEMM grids can leave 0..{RESERVE_MAX} CUs free")
+        return v, "COLDDIFF_RESIDENT_RESERVE"
+    cap, floor = num("NCCL_MAX_NCHANNELS"), num("NCCL_MIN_NCHANNELS")
+    if cap is not None and cap > 0:
+        return min(RESERVE_MAX, (max(cap, floor or 0) + 7) // 8 * 8), "NCCL_MAX_NCHANNELS"
+    if floor is not None and floor > 32:
+        return min(RESERVE_MAX, (floor + 7) // 8 * 8), "NCCL_MIN_NCHANNELS"
+    return 32, "default (RCCL's default channel count)"
 
 
 def set_engine(e):

@@ -348,10 +348,12 @@ class Trainer(EvalMixin):
 
     # -- degradation prefetch (deblurring: q_sample is up to T sequential blur steps on B*C planes, independent of the network) ----
     # The trajectory is bit-identical to the non-prefetching loop BETWEEN milestones; a milestone's sample batch is drawn after the
-    # next micro-batch was already prefetched, i.e. one batch later in the data order than without prefetch.
-    _pending = None
+    # micro-batches in the queue were already prefetched, i.e. one batch later in the data order than without prefetch for the plain
+    # loop and `gradient_accumulate_every` batches later with fused accumulation.  ONE queue serves both loops (draw order = launch
+    # order), so switching COLDDIFF_FUSE_ACCUM / falling back after an out-of-memory mid-run skips nothing and leaks nothing.
     _side = None
-    _pending_q = None            # (fused accumulation: the next step's micro-batches, in draw order)
+    _pending_q = None            # prefetched micro-batches [(prep, event)], oldest first
+    _fuse_off = False            # set by the out-of-memory fallback of _fused_step
 
     def _can_prefetch(self):
         """Only for the plain loop on a HIP device: not when a test / subclass replaced _loss, not for two-image packages."""
@@ -374,7 +376,7 @@ class Trainer(EvalMixin):
         """The plain loop only (not when a test / subclass replaced _loss), equal-sized micro-batches (the loaders that may end an
         epoch on a short batch do not fuse), a core whose training routine has the two-phase form."""
         acc = self.gradient_accumulate_every
-        return (acc > 1 and '_loss' not in self.__dict__ and type(self)._loss is Trainer._loss and os.environ.get("COLDDIFF_FUSE_ACCUM", "1") != "0"
+        return (acc > 1 and not self._fuse_off and '_loss' not in self.__dict__ and type(self)._loss is Trainer._loss and os.environ.get("COLDDIFF_FUSE_ACCUM", "1") != "0"
                 and hasattr(self.core, 'prepare') and self.core.fusable() and (self.drop_last or self.ds is None or parallel.world_size() > 1)
                 and acc * self.batch_size * self.data_image_size ** 2 <= self.FUSE_MAX_PIXELS)
 
@@ -385,6 +387,19 @@ class Trainer(EvalMixin):
         x2 = self._second(batch)
         return self.core.prepare(batch) if x2 is None else self.core.prepare(batch, x2)
 
+    def _take_prepared(self, keep):
+        """The oldest prefetched micro-batch (launched now if the queue is empty), ordered before the compute stream's next kernel;
+        afterwards the queue is topped up to `keep` entries."""
+        if self._pending_q is None:
+            self._pending_q = []
+        if not self._pending_q:
+            self._pending_q.append(self._launch_prepare())
+        prep, ev = self._pending_q.pop(0)
+        torch.cuda.current_stream().wait_event(ev)
+        while len(self._pending_q) < keep:
+            self._pending_q.append(self._launch_prepare())
+        return prep
+
     def _fused_step(self, acc, prefetch):
         if self.sync is not None:
             self.sync.begin()
@@ -394,21 +409,36 @@ class Trainer(EvalMixin):
                 self._pending_q = []
             while len(self._pending_q) < acc:
                 self._pending_q.append(self._launch_prepare())
-            preps = []
-            for _ in range(acc):
-                prep, ev = self._pending_q.pop(0)
-                torch.cuda.current_stream().wait_event(ev)
-                preps.append(prep)
+            preps = [self._take_prepared(0) for _ in range(acc)]
             for _ in range(acc):
                 self._pending_q.append(self._launch_prepare())
         else:
             preps = [self._prepare_micro() for _ in range(acc)]
-        prep = tuple(torch.cat(parts) for parts in zip(*preps))
-        loss = torch.mean(self.core.loss_prepared(prep))          # = the mean of the micro-batch losses (equal sizes)
-        if self.sync is not None:
-            self.sync.arm()
-        (loss * (1.0 / parallel.world_size())).backward()
-        return loss.detach()
+        try:
+            prep = tuple(torch.cat(parts) for parts in zip(*preps))
+            loss = torch.mean(self.core.loss_prepared(prep))          # = the mean of the micro-batch losses (equal sizes)
+            if self.sync is not None:
+                self.sync.arm()
+            (loss * (1.0 / parallel.world_size())).backward()
+            return loss.detach()
+        except torch.OutOfMemoryError:
+            # FUSE_MAX_PIXELS counts pixels, not model width: a wide model / a shared device may not hold `acc` micro-batches of
+            # activations where the reference's one-by-one loop fits.  Single rank only (on several ranks the others are already inside
+            # their collectives): drop what the aborted pass left, switch fusion off for this Trainer and run the SAME prepared
+            # micro-batches one after the other -- the step's data, t and noise draws are unchanged.
+            if self.sync is not None:
+                raise
+            prep = loss = None
+            self._fuse_off = True
+            torch.cuda.empty_cache()
+            self.opt.zero_grad()
+            print(f"fused accumulation of {acc} micro-batches does not fit in device memory: running them one by one from here on")
+            total = None
+            for p_i in preps:
+                l_i = torch.mean(self.core.loss_prepared(p_i))
+                (l_i * (1.0 / acc)).backward()
+                total = l_i.detach() if total is None else total + l_i.detach()
+            return total / acc
 
     def _launch_prepare(self):
         main = torch.cuda.current_stream()
@@ -444,11 +474,7 @@ class Trainer(EvalMixin):
             if self.sync is not None:
                 self.sync.begin()
             if prefetch:
-                if self._pending is None:
-                    self._pending = self._launch_prepare()
-                prep, ev = self._pending
-                torch.cuda.current_stream().wait_event(ev)
-                self._pending = self._launch_prepare()       # micro-batch i+1 is degraded under the forward / backward of micro-batch i
+                prep = self._take_prepared(1)                # micro-batch i+1 is degraded under the forward / backward of micro-batch i
                 loss = torch.mean(self.core.loss_prepared(prep))
             else:
                 loss = torch.mean(self._loss(self._next_batch()))

@@ -2287,8 +2287,13 @@ static int launch_igemm_rowhalo_stream(const SpxArgs& a, int M, hipStream_t s, i
     // resident blocks: one per CU -- minus the CUs the caller keeps free for kernels that run concurrently (cdf_gemm_tuning.resident_reserve:
     // the collectives of a multi-rank gradient exchange; a resident block that finds its CU taken would run its fixed share of the tiles
     // after everybody else), in whole XCD rounds
+#ifdef CDF_EMU
+    int ncu = cdf_num_cus() - reserve;      // (the simulator's 8 "CUs" are not XCD rounds: a reserve really shrinks the grid there, so the CPU
+    if (ncu < 1) ncu = 1;                   //  suite walks several tiles per resident block -- down to ONE block taking every tile)
+#else
     int ncu = cdf_num_cus() - (reserve + 7) / 8 * 8;
     if (ncu < 8) ncu = 8;
+#endif
     const int grid = tiles < ncu ? tiles : ncu;
     if (a.Cin == 64)
         CDF_LAUNCH((conv_igemm_rowhalo_stream_kernel<W, BN, NS, 2>), dim3(grid), dim3(512), lds_s, s, a);

@@ -36,6 +36,28 @@ def test_buckets_are_whole_tensors():
             assert sum(sizes[i:j]) >= per and sum(sizes[i:j - 1]) < per         # closed as soon as it is big enough
 
 
+def test_resident_reserve_is_sized_from_the_channel_count():
+    """CUs left out of the resident GEMM grids under world > 1 = RCCL's channel count in whole XCD rounds:
+    the explicit variable wins and is validated with its name in the error; else NCCL_MAX_NCHANNELS / a raised NCCL_MIN_NCHANNELS."""
+    from colddiff.parallel import resident_reserve
+    assert resident_reserve({}) == (32, "default (RCCL's default channel count)")
+    assert resident_reserve({"NCCL_MAX_NCHANNELS": "12"})[0] == 16
+    assert resident_reserve({"NCCL_MAX_NCHANNELS": "64"})[0] == 64
+    assert resident_reserve({"NCCL_MIN_NCHANNELS": "48"})[0] == 48
+    assert resident_reserve({"NCCL_MIN_NCHANNELS": "4"})[0] == 32
+    assert resident_reserve({"COLDDIFF_RESIDENT_RESERVE": "0", "NCCL_MAX_NCHANNELS": "64"}) == (0, "COLDDIFF_RESIDENT_RESERVE")
+    with pytest.raises(ValueError, match="COLDDIFF_RESIDENT_RESERVE"):
+        resident_reserve({"COLDDIFF_RESIDENT_RESERVE": "400"})
+    from colddiff import _lib
+    from emu_util import emu_lib
+    os.environ["COLDDIFF_ROWHALO_STREAM"] = "3"               # accepted by earlier rounds' libraries; now refused BY NAME, in Python
+    try:
+        with pytest.raises(ValueError, match="COLDDIFF_ROWHALO_STREAM"):
+            _lib.GemmTuning(emu_lib()).from_env()
+    finally:
+        del os.environ["COLDDIFF_ROWHALO_STREAM"]
+
+
 @pytest.mark.parametrize("bucket_bytes,mode,min_buckets", [(512, "once", 8), (1024, "once", 8), (4096, "once", 8), (0, "once", 1),
                                                             (1024, "twice", 8)])
 def test_two_rank_training_matches_global_batch(tmp_path, bucket_bytes, mode, min_buckets):

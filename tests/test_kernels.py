@@ -929,13 +929,15 @@ def test_conv_presplit_rowhalo_emu(case):
         be._keep.clear()
 
 
-def test_conv_presplit_rowhalo_resident_reserve_emu():
+@pytest.mark.parametrize("reserve", [5, 32])
+def test_conv_presplit_rowhalo_resident_reserve_emu(reserve):
     """cdf_gemm_tuning.resident_reserve: the resident row-halo blocks leave CUs free for concurrent kernels (multi-rank training: the
-    gradient exchange's collectives).  The simulator has 8 "CUs"; any reserve still leaves one round of 8 blocks, and the tile walk
-    is by gridDim.x, so the result is the same sums -- checked against the fp32 reference like every other case."""
+    gradient exchange's collectives) -- the grid every multi-rank step launches (224 of 256 blocks on the MI355X).  The simulator has
+    8 "CUs" and takes the reserve literally: 3 blocks (reserve 5) and ONE block (reserve 32) walk the 10 tiles, i.e. several tiles per
+    resident block with the operand stream running across tile boundaries; same sums, checked against the fp32 reference."""
     from conftest import Backend
     be = Backend("emu")
-    be.tune.set(halo=64 | 47, halo_min_tiles=1, resident_reserve=32)
+    be.tune.set(halo=64 | 47, halo_min_tiles=1, resident_reserve=reserve)
     try:
         _spx_case(be, 5, 64, 136, 16, 3, 1, 1)
     finally:

@@ -646,6 +646,38 @@ def test_fused_accumulation_same_draws_same_trajectory(mbe, tmp_path, monkeypatc
         assert ((v - out[1][1][k]).abs() > 2e-6).float().mean() <= 0.02, k
 
 
+def test_fused_accumulation_falls_back_when_memory_runs_out(mbe, tmp_path):
+    """FUSE_MAX_PIXELS counts pixels, not model width -- if the one fused pass does not fit where the reference's
+    micro-step loop does, the step is rerun unfused on the SAME prepared micro-batches (same data / t / noise draws) and fusion stays
+    off for this Trainer: loss and weights equal the plain loop's."""
+    from denoising_diffusion_pytorch import GaussianDiffusion, Trainer, Unet
+    out = []
+    for oom in (False, True):
+        torch.manual_seed(0)
+        net = quiet(Unet, dim=8, dim_mults=(1, 2), channels=3).to(mbe.device)
+        diff = GaussianDiffusion(net, image_size=8, channels=3, timesteps=10).to(mbe.device)
+        tr = Trainer(diff, None, image_size=8, train_batch_size=2, train_lr=1e-3, train_num_steps=2, gradient_accumulate_every=2,
+                     dataset="synthetic", results_folder=str(tmp_path / f"res{int(oom)}"))
+        if oom:
+            real = tr.core.loss_prepared
+
+            def starved(prep):
+                if prep[0].shape[0] > 2:                      # the 4-image fused batch "does not fit"
+                    raise torch.OutOfMemoryError("simulated")
+                return real(prep)
+            tr.core.loss_prepared = starved
+        else:
+            tr._fuse_off = True                               # the plain loop, same draws
+        torch.manual_seed(5)
+        losses = []
+        for _ in range(2):
+            losses.append(quiet(tr.train_step).item())
+            tr.step += 1
+        assert tr._fuse_off and not tr._can_fuse()
+        out.append((losses, tr.arena.data.clone()))
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
+
+
 def test_no_cpu_fallback():
     """Without the test-only simulator override the operators refuse CPU tensors."""
     from colddiff import runtime
