@@ -70,12 +70,16 @@ def step_roofline(batch, accum, ms_per_step, mfma_per_product, act="f32"):
     t = ms_per_step * 1e-3
     t_hbm = bytes_step / (PEAK_HBM_GBS * 1e9)
     t_mfma = flops_step / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+    t_issue = flops_step * mfma_per_product / (PEAK_BF16_MFMA_TFLOPS * 1e12)     # what the matrix pipe must ISSUE in this arithmetic mode
     return {"activation_bytes": act, "bytes_step": round(bytes_step), "flops_step": round(flops_step), "hbm_gbs": round(bytes_step / t / 1e9, 1),
             "hbm_frac_of_peak": round(bytes_step / t / 1e9 / PEAK_HBM_GBS, 4),
             "algorithmic_tflops": round(flops_step / t / 1e12, 2),
             "mfma_frac_of_bf16_peak": round(flops_step / t / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
             "t_roof_ms": round(1000 * max(t_hbm, t_mfma), 3), "t_roof_over_t": round(max(t_hbm, t_mfma) / t, 4),
-            "bound": "mfma" if t_mfma >= t_hbm else "hbm",
+            # `t_roof` prices ALGORITHMIC flops at one MFMA per product (conservative for bf16x3); the label says which pipe actually bounds
+            # the step in this mode: the MFMAs that must be issued (flops x mfma_per_product) against the HBM bytes
+            "t_roof_issue_ms": round(1000 * t_issue, 3), "t_hbm_ms": round(1000 * t_hbm, 3),
+            "bound": "mfma" if t_issue >= t_hbm else "hbm",
             "mfma_per_product": mfma_per_product,
             "mfma_issue_frac_of_bf16_peak": round(flops_step * mfma_per_product / t / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
             "formula": "SURVEY 8(d): bytes = B(A_train+D)accum + 3W accum + 28P + 1.2P; flops = 3 x 67.41 GF/img (algorithmic); "
@@ -143,6 +147,15 @@ class GemmTimer:
         # conv_wgrad: (xa,lda,xb,ldb,ws,ldo,B,QH,QW,HA,WA,sa,HB,WB,sb,CA,CB,ntaps,desc,nsplit,batch,...)
         return 2.0 * a[6] * a[7] * a[8] * a[15] * a[16] * a[17] * a[20]
 
+    def _bytes(self, kind, a):
+        """ALGORITHMIC HBM bytes of a launch (SURVEY 8(d) counts layer-boundary tensors in fp32): input map + output map + weights,
+        each once -- what `traffic` (PMC) is compared with."""
+        if kind == "cdf_conv_gemm_bf16x":
+            return 4.0 * (a[9] * a[10] * a[11] * a[12] + a[9] * a[13] * a[14] * a[15] + self._ntaps(a[21], a[20]) * a[12] * a[15])
+        if kind == "cdf_conv_gemm_bf16":
+            return 4.0 * (a[7] * a[8] * a[9] * a[10] + a[7] * a[11] * a[12] * a[13] + self._ntaps(a[19], a[18]) * a[10] * a[13])
+        return None
+
     def _call(self, entry, a):
         if not self.enabled:
             return self.orig[entry](*a)
@@ -150,7 +163,8 @@ class GemmTimer:
         e0.record()
         r = self.orig[entry](*a)
         e1.record()
-        self.records[self.ENTRY[entry]].append((e0, e1, self._flops(entry, a), (entry,) + tuple(x for x in a[6:21] if isinstance(x, int) and x < 1 << 20)))
+        self.records[self.ENTRY[entry]].append((e0, e1, self._flops(entry, a), (entry,) + tuple(x for x in a[6:21] if isinstance(x, int) and x < 1 << 20),
+                                                self._bytes(entry, a)))
         return r
 
     def dump_shapes(self, steps):
@@ -175,6 +189,8 @@ class GemmTimer:
                          "frac": round(tf / self.PEAK[kind], 4), "launches_per_step": len(recs) // max(1, steps),
                          "avg_launch_ms": round(ms / len(recs), 4), "algorithmic_gflop_per_step": round(fl / max(1, steps) / 1e9, 1),
                          "share_of_step": round(ms / (1000 * elapsed_s), 3)}
+            if all(r[4] is not None for r in recs):
+                out[kind]["algorithmic_bytes_per_launch"] = round(sum(r[4] for r in recs) / len(recs))
             if kind == "conv_igemm_sp":
                 # the group mixes two regimes: the pre-split 3x3 / 4x4 GEMMs (matrix-core-bound) and the in-kernel-split 1x1 attention
                 # projections (K = 64 ... 512 against 256 ... 1536 output channels: HBM-bound streams) -- same figures per entry point
@@ -232,10 +248,28 @@ def cpu_baseline(args):
     for _ in range(n):
         tr.train_step(batches())
     dt = (time.perf_counter() - t0) / n
-    return {"value": round(Bc * args.accum / dt, 3), "unit": "img/s", "cores": ncores, "kind": "port",
-            "sample": f"oracle/cold_oracle.py = bit-exact port of the reference's PyTorch CPU path (tests/test_oracle.py pins it to the live "
-                      f"reference; /root/reference does not exist on the GPU box): same optimizer step, {args.accum} micro-steps x {Bc} images "
-                      f"at 128x128, {n} timed steps after {nwarm} warm-up, {ncores} threads"}
+    out = {"value": round(Bc * args.accum / dt, 3), "unit": "img/s", "cores": ncores, "kind": "port", "batch_per_micro_step": Bc,
+           "sample": f"oracle/cold_oracle.py = bit-exact port of the reference's PyTorch CPU path (tests/test_oracle.py pins it to the live "
+                     f"reference; /root/reference does not exist on the GPU box): same optimizer step, {args.accum} micro-steps x {Bc} images "
+                     f"at 128x128, {n} timed steps after {nwarm} warm-up, {ncores} threads"}
+    # a 2-image convolution does not scale to 64 cores -- the same step at 8 images per micro-step (a batch the host's
+    # threads can share), bounded to ~40 s: one warm-up + as many timed steps as fit; `value` above stays the comparable figure of rounds 1-4
+    Bc = 8
+    t0 = time.perf_counter()
+    tr.train_step(batches())
+    warm8 = time.perf_counter() - t0
+    n8 = max(1, min(3, int(30.0 / max(warm8, 1e-3))))
+    if warm8 < 25.0:
+        t0 = time.perf_counter()
+        for _ in range(n8):
+            tr.train_step(batches())
+        dt8 = (time.perf_counter() - t0) / n8
+        timed = f"{n8} timed steps after 1 warm-up"
+    else:
+        dt8, timed = warm8, "the single (first) step: the host is too slow for a warm-up inside the 40 s bound"
+    out["batch8"] = {"value": round(Bc * args.accum / dt8, 3), "unit": "img/s", "cores": ncores, "batch_per_micro_step": Bc,
+                     "sample": f"same port, same optimizer step at {args.accum} micro-steps x {Bc} images, {timed}, {ncores} threads"}
+    return out
 
 
 def selfcheck(diffusion, device):
@@ -345,7 +379,7 @@ def secondary_workloads(device):
 
 def _profile(name):
     """Newest committed profiles/round<N>_<name> (bench.py cannot run the profiler on itself)."""
-    for rnd in (4, 3, 2, 1):
+    for rnd in (5, 4, 3, 2, 1):
         path = os.path.join(REPO, "profiles", "round%d_%s" % (rnd, name))
         if os.path.exists(path):
             return path
@@ -518,6 +552,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": dom, "arithmetic": d["arithmetic"], "achieved": d["achieved"], "peak": d["peak"],
                                "unit": "TFLOP/s", "frac": d["frac"], "traffic": None, "launches_per_step": d["launches_per_step"],
                                "avg_launch_ms": d["avg_launch_ms"], "algorithmic_gflop_per_step": d["algorithmic_gflop_per_step"],
+                               "algorithmic_bytes_per_launch": d.get("algorithmic_bytes_per_launch"),
                                # the data-sheet peak above is what `frac` is taken against; the same instruction sustains 1.82 PF on random bf16
                                # operands with nothing else running (profiles/round2_mfma_power.md): MFMA issue rate against that ceiling
                                "mfma_issue_tflops": round(d["achieved"] * npp_of(runtime.precision), 1),
@@ -537,6 +572,8 @@ def main():
                 g = tdoc.get("conv_igemm_sp")
                 if g and prov["match"]:            # a profile of other kernel sources is not quoted: traffic stays null
                     out["roofline"]["traffic"] = round(g["hbm_bytes_per_launch"])
+                    if d.get("algorithmic_bytes_per_launch"):
+                        out["roofline"]["traffic_over_algorithmic_bytes"] = round(g["hbm_bytes_per_launch"] / d["algorithmic_bytes_per_launch"], 3)
                     out["roofline"]["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, %s)" % os.path.relpath(tpath, REPO)
         out["gemm_kernels"] = kernels
         # whole-step view: layer-boundary bytes and 3 x F_fwd flops per image against the HBM / MFMA roofs

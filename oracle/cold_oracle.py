@@ -5,7 +5,7 @@ the HIP engine and to serve as bench.py's `cpu_baseline` ("port"); the product n
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this module.
 
 Parity status: the reference ships no tests / golden vectors for this path, so the
-oracle is pinned against the reference ITSELF: tests/test_oracle_vs_reference.py imports the
+oracle is pinned against the reference ITSELF: tests/test_oracle.py imports the
 unmodified reference (oracle/ref_shim.py, build container only) and requires bit-equality on CPU,
 and tests/golden/*.pt hold reference-generated vectors (tests/golden/make_golden.py) that travel to
 the GPU box.  The torchgeometry Gaussian-kernel generator is restated from its published source
