@@ -171,7 +171,7 @@ class GemmTimer:
         """Per-shape time table (stderr) — which GEMMs the step spends its time in."""
         agg = {}
         for recs in self.records.values():
-            for e0, e1, f, key in recs:
+            for e0, e1, f, key, *_ in recs:
                 t, n, fl = agg.get(key, (0.0, 0, 0.0))
                 agg[key] = (t + e0.elapsed_time(e1), n + 1, fl + f)
         for key, (t, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("CDF_BENCH_SHAPES_N", "40"))]:

@@ -103,6 +103,49 @@ __device__ __forceinline__ void cdf_split_store4(unsigned short* hi, unsigned sh
     if (lo) *(uint2*)lo = l;          // lo == nullptr: hi-only planes (single-pass bf16 operands)
 }
 
+// ---- activation storage type ---------------------------------------------------------------------
+// "bf16" arithmetic mode with bf16 ACTIVATION STORAGE (BASELINE configs 3 / 5): feature maps between kernels are ONE bf16 plane
+// [pixels][ld] (the GEMMs' "hi" plane IS the tensor); accumulation, statistics and parameters stay fp32.  The HBM-bound kernels are
+// instantiated for both storage types: a 4-channel quad is a float4 (16 B) or four bf16 (8 B) in memory and a float4 in registers.
+// Offsets are in ELEMENTS of the tensor's own type.
+template <bool BF> struct cdf_quad { typedef float4 raw; typedef float elem; };
+template <> struct cdf_quad<true> { typedef uint2 raw; typedef unsigned short elem; };
+__device__ __forceinline__ float4 cdf_quad_cvt(const float4& r) { return r; }
+__device__ __forceinline__ float4 cdf_quad_cvt(const uint2& r) {
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xFFFF0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xFFFF0000u));
+}
+// (the offset keeps its own integer type: a scalar base + 32-bit unsigned offset stays a 32-bit address computation)
+template <bool BF, class Off>
+__device__ __forceinline__ typename cdf_quad<BF>::raw cdf_quad_ld(const void* base, Off off) {           // the raw load (convert where the value is used)
+    if constexpr (BF) return *(const uint2*)((const unsigned short*)base + off);
+    else return *(const float4*)((const float*)base + off);
+}
+template <bool BF, class Off>
+__device__ __forceinline__ void cdf_quad_st(void* base, Off off, const float4& v) {                      // round to nearest even
+    if constexpr (BF) {
+        uint2 h;
+        h.x = cdf_pack2bf(v.x, v.y);
+        h.y = cdf_pack2bf(v.z, v.w);
+        *(uint2*)((unsigned short*)base + off) = h;
+    } else {
+        *(float4*)((float*)base + off) = v;
+    }
+}
+// runtime-selected forms for the GEMM epilogues (the flag is a kernel argument: a scalar branch)
+__device__ __forceinline__ void cdf_ld4_bf(float* v, const void* base, long long off) {
+    const float4 t = cdf_quad_cvt(*(const uint2*)((const unsigned short*)base + off));
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void cdf_st4_bf(void* base, long long off, const float* v) {
+    uint2 h;
+    h.x = cdf_pack2bf(v[0], v[1]);
+    h.y = cdf_pack2bf(v[2], v[3]);
+    *(uint2*)((unsigned short*)base + off) = h;
+}
+#define CDF_IO_RES_BF16 1    /* epilogue operand types (io_bf16 bit mask of the *_io GEMM entry points): residual read as bf16 */
+#define CDF_IO_PRE_BF16 2    /* pre-activation written as bf16 */
+#define CDF_IO_MUL_BF16 4    /* activation-gradient source read as bf16 */
+
 // ---- status codes (returned by every extern "C" entry point) -------------------------
 #define CDF_OK 0
 #define CDF_E_INVALID (-1)      // bad argument (shape, alignment, null pointer)

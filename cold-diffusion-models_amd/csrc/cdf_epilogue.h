@@ -8,6 +8,7 @@
 // and of every fused operand (bias, per-sample bias, pre-activation, activation-gradient source, residual),
 // BN/4 lanes = one contiguous pixel row.
 // Args::ys_hi / ys_lo / ld_ys (optional): the stored values again as bf16 hi / lo planes (operand split fused into the producer).
+// Args::io_bf (CDF_IO_*_BF16 bits): res / pre / mul are bf16 tensors (bf16 activation storage; needs the vector layout, checked on the host).
 // Args::vec (host-computed, cdf_epi_vec_ok) = all pitches % 4 == 0, Cout % 4 == 0, 16-byte-aligned pointers;
 // otherwise the same code runs with per-element accesses.
 #pragma once
@@ -94,7 +95,10 @@ __device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += u[e];
         }
-        if (a.pre) cdf_st4(a.pre + o_pre, v, nval, vec);
+        if (a.pre) {
+            if (a.io_bf & CDF_IO_PRE_BF16) cdf_st4_bf(a.pre, o_pre, v);
+            else cdf_st4(a.pre + o_pre, v, nval, vec);
+        }
         if (a.act == 1) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = cdf_gelu(v[e]);
@@ -106,12 +110,14 @@ __device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f); // relu
         }
         if (a.mul_mode) {
-            cdf_ld4(u, a.mul + o_mul, nval, vec);
+            if (a.io_bf & CDF_IO_MUL_BF16) cdf_ld4_bf(u, a.mul, o_mul);
+            else cdf_ld4(u, a.mul + o_mul, nval, vec);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= (a.mul_mode == 1 ? cdf_gelu_grad(u[e]) : (a.mul_mode == 2 ? cdf_silu_grad(u[e]) : u[e]));
         }
         if (a.res) {
-            cdf_ld4(u, a.res + o_res, nval, vec);
+            if (a.io_bf & CDF_IO_RES_BF16) cdf_ld4_bf(u, a.res, o_res);
+            else cdf_ld4(u, a.res + o_res, nval, vec);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += u[e];
         }

@@ -48,6 +48,7 @@ struct ConvArgs {
     unsigned short* ys_hi;   // (unused by the fp32 kernels: always null)
     unsigned short* ys_lo;
     int ld_ys;
+    int io_bf;               // CDF_IO_*_BF16 bits (cdf_epilogue.h): always 0 for the fp32 entry points
     long long x_bs, w_bs, y_bs;     // blockIdx.z = outer*batch2 + inner: outer batch strides (elements)
     long long x_bs2, w_bs2, y_bs2;  // inner batch strides (e.g. attention heads)
     int epi_follow;                 // batched launch whose y offsets are whole rows (y_bs % ldy == 0, y_bs2 % ldy == 0) and that has epilogue
@@ -708,7 +709,7 @@ extern "C" int cdf_conv_gemm(const float* x, int ldx, const float* w, int ldw, f
                     "of y (y_bs and y_bs2 multiples of ldy) and no per-sample bias");
         a.epi_follow = 1;
     }
-    a.ys_hi = nullptr; a.ys_lo = nullptr; a.ld_ys = 0;
+    a.ys_hi = nullptr; a.ys_lo = nullptr; a.ld_ys = 0; a.io_bf = 0;
     batch *= batch2;
     // phase_desc: per phase [oy, ox, ntaps, (dy, dx, wi) * ntaps]
     const int* pd = phase_desc;

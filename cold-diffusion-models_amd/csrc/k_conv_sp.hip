@@ -79,6 +79,7 @@ struct SpArgs {
     unsigned short* ys_hi;         // nullable: bf16 hi / lo planes of the output (pitch ld_ys), written by the epilogue
     unsigned short* ys_lo;
     int ld_ys;
+    int io_bf;                     // CDF_IO_*_BF16 bits (cdf_epilogue.h)
     SpPhase ph[4];
 };
 
@@ -525,6 +526,16 @@ __global__ void split_bf16_kernel(const float* x, int ldx, unsigned short* hi, u
     }
 }
 
+// the way back (bf16 activation storage): a bf16 tensor widened to fp32 for a kernel that has no bf16-input form (exact conversion)
+__global__ void widen_bf16_kernel(const unsigned short* x, int ldx, float* y, int ldy, long long rows, int C4) {
+    const long long n = rows * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const long long r = i / C4;
+        *(float4*)(y + r * ldy + c) = cdf_quad_cvt(*(const uint2*)(x + r * ldx + c));
+    }
+}
+
 #define CDF_GLDS16_K(g, l) CDF_GLDS16(g, l)
 
 struct SpxArgs {
@@ -550,12 +561,13 @@ struct SpxArgs {
     int ksplit;                    // > 1 (generic kernel, one phase): blockIdx.z takes ntaps / ksplit taps and writes its raw partial
     float* ks_ws;                  //      sums to ks_ws[z][m][ks_ld]; conv_splitk_finish_kernel adds them up and runs the epilogue
     int ks_ld;
+    int io_bf;                     // CDF_IO_*_BF16 bits (cdf_epilogue.h): res / pre / mul are bf16 tensors (bf16 activation storage)
     SpPhase ph[4];
 };
 
 // what cdf_epilogue_rows reads, for a raw store of the accumulator tile (split-K partial sums): rows m of a [M][ldy] slab
 struct RawEpiArgs {
-    int Cout, vec, os, QH, QW, OH, OW, ldy, ldp, ldm, ldr, ld_sbias, ld_ys, act, mul_mode, accumulate;
+    int Cout, vec, os, QH, QW, OH, OW, ldy, ldp, ldm, ldr, ld_sbias, ld_ys, act, mul_mode, accumulate, io_bf;
     const float* bias;
     const float* sbias;
     float* pre;
@@ -810,7 +822,7 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_igemm_spx_kernel(SpxAr
         RawEpiArgs r;
         r.Cout = a.Cout; r.vec = (a.Cout & 3) == 0 ? 1 : 0; r.os = 1; r.QH = 1; r.QW = 1; r.OH = 1; r.OW = 1; r.ldy = a.ks_ld;
         r.ldp = r.ldm = r.ldr = r.ld_sbias = r.ld_ys = 0; r.act = 0; r.mul_mode = 0; r.accumulate = 0;
-        r.bias = nullptr; r.sbias = nullptr; r.pre = nullptr; r.mul = nullptr; r.res = nullptr; r.ys_hi = nullptr; r.ys_lo = nullptr;
+        r.bias = nullptr; r.sbias = nullptr; r.pre = nullptr; r.mul = nullptr; r.res = nullptr; r.ys_hi = nullptr; r.ys_lo = nullptr; r.io_bf = 0;
         constexpr int CP = BN + 8, TM = BM / WM, TN = BN / WN;
         float* cs = (float*)smem_raw;
         const int half_ = lane >> 5, l31_ = lane & 31;
@@ -2103,7 +2115,7 @@ extern "C" int cdf_conv_gemm_bf16(const float* x, int ldx, const void* w_hi, con
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.QH = QH; a.QW = QW; a.os = os; a.is = is;
     a.act = act; a.mul_mode = mul_mode; a.accumulate = accumulate; a.nphase = nphase;
     a.vec = cdf_epi_vec_ok(Cout, y, ldy, bias, sbias, ld_sbias, res, ldr, pre, ldp, mul, ldm);
-    a.ys_hi = nullptr; a.ys_lo = nullptr; a.ld_ys = 0;
+    a.ys_hi = nullptr; a.ys_lo = nullptr; a.ld_ys = 0; a.io_bf = 0;
     const int* pd = phase_desc;
     for (int p = 0; p < nphase; ++p) {
         a.ph[p].oy = pd[0]; a.ph[p].ox = pd[1]; a.ph[p].ntaps = pd[2];
@@ -2171,6 +2183,15 @@ extern "C" int cdf_split_bf16(const float* x, int ldx, void* hi, void* lo, int l
     if (g > 8192) g = 8192;
     CDF_LAUNCH(split_bf16_kernel, dim3((int)g), dim3(256), 0, CDF_S, x, ldx, (unsigned short*)hi, (unsigned short*)lo, ldo, rows, C / 4);
     return cdf_check_launch("split_bf16");
+}
+
+extern "C" int cdf_bf16_to_f32(const void* x, int ldx, float* y, int ldy, long long rows, int C, void* stream) {
+    CDF_REQUIRE(x && y && rows > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C && (((uintptr_t)x) & 7) == 0 &&
+                (((uintptr_t)y) & 15) == 0, "cdf_bf16_to_f32: bad args (C %% 4, pitches %% 4, x 8-byte / y 16-byte aligned)");
+    long long g = (rows * (C / 4) + 255) / 256;
+    if (g > 8192) g = 8192;
+    CDF_LAUNCH(widen_bf16_kernel, dim3((int)g), dim3(256), 0, CDF_S, (const unsigned short*)x, ldx, y, ldy, rows, C / 4);
+    return cdf_check_launch("bf16_to_f32");
 }
 
 static int fill_phases(SpPhase* ph, int nphase, const int* pd, const char* who) {
@@ -2407,12 +2428,36 @@ static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cou
     return launch_igemm_spx<NS, 128, 128, 2, 2, 2>(a, M, s);
 }
 
+extern "C" int cdf_conv_gemm_bf16x_io(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo,
+                                      int ldk, float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW,
+                                      int os, int is, int nphase, const int* phase_desc, const float* bias, const float* sbias,
+                                      int ld_sbias, const void* res, int ldr, void* pre, int ldp, const void* mul, int ldm, int act,
+                                      int mul_mode, int accumulate, int io_bf16, void* y_hi, void* y_lo, int ld_ys, float* ws,
+                                      long long ws_floats, const cdf_gemm_tuning* tune, void* stream);
+
 extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo,
                                    int ldk, float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW,
                                    int os, int is, int nphase, const int* phase_desc, const float* bias, const float* sbias,
                                    int ld_sbias, const float* res, int ldr, float* pre, int ldp, const float* mul, int ldm, int act,
                                    int mul_mode, int accumulate, void* y_hi, void* y_lo, int ld_ys, float* ws, long long ws_floats,
                                    const cdf_gemm_tuning* tune, void* stream) {
+    return cdf_conv_gemm_bf16x_io(x_hi, x_lo, ldx, zero, w_hi, w_lo, ldk, y, ldy, B, H, W, Cin, OH, OW, Cout, QH, QW, os, is, nphase, phase_desc,
+                                  bias, sbias, ld_sbias, res, ldr, pre, ldp, mul, ldm, act, mul_mode, accumulate, 0, y_hi, y_lo, ld_ys, ws,
+                                  ws_floats, tune, stream);
+}
+
+// ... with typed epilogue operands (io_bf16: CDF_IO_RES_BF16 | CDF_IO_PRE_BF16 | CDF_IO_MUL_BF16 -- that operand is ONE bf16 plane with its
+// pitch in bf16 elements): the bf16-activation-storage engine, where every feature map between kernels is a bf16 tensor.
+extern "C" int cdf_conv_gemm_bf16x_io(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo,
+                                      int ldk, float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW,
+                                      int os, int is, int nphase, const int* phase_desc, const float* bias, const float* sbias,
+                                      int ld_sbias, const void* res_, int ldr, void* pre_, int ldp, const void* mul_, int ldm, int act,
+                                      int mul_mode, int accumulate, int io_bf16, void* y_hi, void* y_lo, int ld_ys, float* ws,
+                                      long long ws_floats, const cdf_gemm_tuning* tune, void* stream) {
+    const float* res = (const float*)res_;
+    float* pre = (float*)pre_;
+    const float* mul = (const float*)mul_;
+    CDF_REQUIRE((io_bf16 & ~7) == 0, "cdf_conv_gemm_bf16x_io: io_bf16 has unknown bits (%d)", io_bf16);
     CDF_REQUIRE(x_hi && zero && w_hi && (y || (y_hi && !accumulate)), "cdf_conv_gemm_bf16x: null pointer");
     CDF_TUNE_CHECK(tune, "cdf_conv_gemm_bf16x");
     CDF_REQUIRE(!ws || (((uintptr_t)ws) & 15) == 0, "cdf_conv_gemm_bf16x: the split-K workspace must be 16-byte aligned");
@@ -2432,7 +2477,9 @@ extern "C" int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, 
     a.act = act; a.mul_mode = mul_mode; a.accumulate = accumulate; a.nphase = nphase;
     a.vec = cdf_epi_vec_ok(Cout, y, ldy, bias, sbias, ld_sbias, res, ldr, pre, ldp, mul, ldm);
     a.ys_hi = (unsigned short*)y_hi; a.ys_lo = (unsigned short*)y_lo; a.ld_ys = ld_ys;
+    a.io_bf = io_bf16;
     CDF_REQUIRE(!y_hi || a.vec, "cdf_conv_gemm_bf16x: split output planes need the vectorised epilogue (aligned pointers, pitches %% 4)");
+    CDF_REQUIRE(!io_bf16 || a.vec, "cdf_conv_gemm_bf16x_io: bf16 epilogue operands need the vectorised epilogue (16-byte-aligned pointers, pitches %% 4, Cout %% 4)");
     int rc = fill_phases(a.ph, nphase, phase_desc, "cdf_conv_gemm_bf16x");
     if (rc) return rc;
     a.ksplit = 1; a.ks_ws = ws; a.ks_ld = 0;

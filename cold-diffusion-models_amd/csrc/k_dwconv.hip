@@ -39,10 +39,14 @@ __device__ __forceinline__ void f4_fma(float4& acc, const float4& a, const float
 //     weights behind a per-component select: 448 v_cndmask and 1/8 of the FMAs per thread gone.
 // (A block walking several tiles with the next halo requested under the current tile's FMAs was built and measured: slower,
 //  218 VGPRs and no gain from the overlap -- the waves do not wait for HBM, they wait for the vector ALU.)
-template <int TBW, int TBH>
-__global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx, const float* w, int ldw, const float* bias,
-                                                         const float* sbias, int ld_sbias, float* y, int ldy, int B, int H,
-                                                         int W, int C4, int flip, int accumulate, const float* res, int ldr) {
+// BF (bf16 activation storage): x, y and res are bf16 tensors (pitches in bf16 elements): the halo comes in as 8-byte quads and is
+// widened when it goes to LDS, the result is rounded to nearest even when it leaves; weights, biases and the arithmetic stay fp32.
+template <int TBW, int TBH, bool BF>
+__global__ void __launch_bounds__(256, 2) dwconv7_kernel(const void* x, int ldx, const float* w, int ldw, const float* bias,
+                                                         const float* sbias, int ld_sbias, void* y, int ldy, int B, int H,
+                                                         int W, int C4, int flip, int accumulate, const void* res, int ldr) {
+    typedef typename cdf_quad<BF>::raw raw_t;
+    typedef typename cdf_quad<BF>::elem elem_t;
     constexpr int HW_ = TBW + 6, HH_ = TBH + 6;              // halo extent
     constexpr int RP = HW_ * 8 + 4;                          // row pitch in float4 (pixels x 8 channel quads + 64 B)
     constexpr int TX = TBW / 4, TY = TBH / 2;                // thread tiles
@@ -74,13 +78,13 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx
     // of the FMA rate and were, with the per-load divisions, more vector work than the 784 packed FMAs): element offsets inside one
     // image are 24-bit x 24-bit products (host: H W pitch < 2^30), the image base is a scalar, and (hy, hx) of slot k follow from
     // slot k - 1 by adding 32 pixels.
-    const float* xb = x + (long long)b * H * W * ldx;
+    const elem_t* xb = (const elem_t*)x + (long long)b * H * W * ldx;
     constexpr int NHALO = HH_ * HW_ * 8, NIT = (NHALO + 255) / 256;
     constexpr int STEP_Y = 32 / HW_, STEP_X = 32 % HW_;      // 32 pixels further in the [HH_][HW_] halo
     const int l_ = tid & 7;
     const unsigned lc4 = (unsigned)(((cq0 + l_) < C4 ? cq0 + l_ : 0) * 4);
     const bool lok = (cq0 + l_) < C4;
-    float4 hv[NIT];
+    raw_t hv[NIT];
     {
         int hy = 0, hx = tid >> 3;                           // (tid >> 3 < 32 <= HW_)
         if (hx >= HW_) { hx -= HW_; ++hy; }
@@ -89,7 +93,7 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx
             const int iy = Y0 + hy - 3, ix = X0 + hx - 3;
             const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
             const unsigned off = __umul24(__umul24((unsigned)iyc, (unsigned)W) + (unsigned)ixc, (unsigned)ldx) + lc4;
-            hv[k] = *(const float4*)(xb + off);
+            hv[k] = cdf_quad_ld<BF>(xb, off);
             hy += STEP_Y;
             hx += STEP_X;
             if (hx >= HW_) { hx -= HW_; ++hy; }
@@ -102,7 +106,7 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx
         for (int k = 0; k < NIT; ++k) {
             const int iy = Y0 + hy - 3, ix = X0 + hx - 3;
             const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W && lok;
-            if (hy < HH_) halo[__umul24((unsigned)hy, (unsigned)RP) + hx * 8 + l_] = ok ? hv[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hy < HH_) halo[__umul24((unsigned)hy, (unsigned)RP) + hx * 8 + l_] = ok ? cdf_quad_cvt(hv[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
             hy += STEP_Y;
             hx += STEP_X;
             if (hx >= HW_) { hx -= HW_; ++hy; }
@@ -154,8 +158,8 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx
         const float4 sv = *(const float4*)(sbias + (long long)b * ld_sbias + c);
         add.x += sv.x; add.y += sv.y; add.z += sv.z; add.w += sv.w;
     }
-    float* yb = y + (long long)b * H * W * ldy;
-    const float* rb = res ? res + (long long)b * H * W * ldr : nullptr;
+    elem_t* yb = (elem_t*)y + (long long)b * H * W * ldy;
+    const elem_t* rb = res ? (const elem_t*)res + (long long)b * H * W * ldr : nullptr;
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
         const int oy = Y0 + y0 + o;
@@ -166,17 +170,16 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx
         for (int j = 0; j < 4; ++j) {
             const int ox = X0 + x0 + j;
             if (ox >= W) break;
-            float* dst = yb + offy;
             float4 v = make_float4(acc[o][j].x + add.x, acc[o][j].y + add.y, acc[o][j].z + add.z, acc[o][j].w + add.w);
             if (accumulate) {
-                const float4 old = *(const float4*)dst;
+                const float4 old = cdf_quad_cvt(cdf_quad_ld<BF>(yb, offy));
                 v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
             }
             if (res) {                                       // fused residual (e.g. dx = dy + conv^T(dh))
-                const float4 rv = *(const float4*)(rb + offr);
+                const float4 rv = cdf_quad_cvt(cdf_quad_ld<BF>(rb, offr));
                 v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             }
-            *(float4*)dst = v;
+            cdf_quad_st<BF>(yb, offy, v);
             offy += (unsigned)ldy;
             offr += (unsigned)ldr;
         }
@@ -194,8 +197,10 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const float* x, int ldx
 // through LDS at the end; grid = (ceil(C/32), nchunk, B) in the XCD-aware order (consecutive chunks share 6 of their 10 halo rows).
 #define DWG_TW 32
 #define DWG_TR 4
-__global__ void __launch_bounds__(256, 2) dwconv7_wgrad_partial_kernel(const float* x, int ldx, const float* dy, int lddy,
+template <bool BF>       // BF: x and dy are bf16 tensors (bf16 activation storage); partial sums and everything downstream stay fp32
+__global__ void __launch_bounds__(256, 2) dwconv7_wgrad_partial_kernel(const void* x, int ldx, const void* dy, int lddy,
                                                                       float* part, int H, int W, int C, int rows_per_chunk) {
+    typedef typename cdf_quad<BF>::raw raw_t;
     constexpr int HWX = DWG_TW + 6, HRX = DWG_TR + 6;        // halo extent of x
     constexpr int RPX = HWX * 8 + 8;                         // row pitches in float4: adjacent rows 32 banks apart (two thread groups of a
     constexpr int RPD = DWG_TW * 8 + 8;                      // 16-lane ds_read_b128 group read adjacent rows)
@@ -211,8 +216,9 @@ __global__ void __launch_bounds__(256, 2) dwconv7_wgrad_partial_kernel(const flo
     const int l8 = tid & 7, g = tid >> 3;
     const bool busy = g < 7 * DWG_TR;
     const int r = busy ? g / 7 : 0, ky = busy ? g - 7 * r : 0;
-    const float* xb = x + (long long)b * H * W * ldx;
-    const float* db = dy + (long long)b * H * W * lddy;
+    typedef typename cdf_quad<BF>::elem elem_t;
+    const elem_t* xb = (const elem_t*)x + (long long)b * H * W * ldx;
+    const elem_t* db = (const elem_t*)dy + (long long)b * H * W * lddy;
     const int lq = (cq0 + l8) < C4 ? cq0 + l8 : 0;           // (clamped channel quad for the loads; masked when stored)
     const bool qok = (cq0 + l8) < C4;
 
@@ -226,14 +232,14 @@ __global__ void __launch_bounds__(256, 2) dwconv7_wgrad_partial_kernel(const flo
     for (int y0 = ya; y0 < yb; y0 += DWG_TR) {
         for (int tx = 0; tx < tiles_w; ++tx) {
             const int X0 = tx * DWG_TW;
-            float4 hx[NXI], hd[NDI];
+            raw_t hx[NXI], hd[NDI];
 #pragma unroll
             for (int k = 0; k < NXI; ++k) {                  // unconditional loads from clamped addresses; masks applied at the LDS store
                 const int i = tid + 256 * k, p = i >> 3;
                 const int hy = p / HWX, hxx = p - hy * HWX;
                 const int iy = y0 + hy - 3, ix = X0 + hxx - 3;
                 const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-                hx[k] = *(const float4*)(xb + ((long long)iyc * W + ixc) * ldx + lq * 4);
+                hx[k] = cdf_quad_ld<BF>(xb, ((long long)iyc * W + ixc) * ldx + lq * 4);
             }
 #pragma unroll
             for (int k = 0; k < NDI; ++k) {
@@ -241,7 +247,7 @@ __global__ void __launch_bounds__(256, 2) dwconv7_wgrad_partial_kernel(const flo
                 const int ty = p / DWG_TW, px = p - ty * DWG_TW;
                 const int iy = y0 + ty, ix = X0 + px;
                 const int iyc = iy >= H ? H - 1 : iy, ixc = ix >= W ? W - 1 : ix;
-                hd[k] = *(const float4*)(db + ((long long)iyc * W + ixc) * lddy + lq * 4);
+                hd[k] = cdf_quad_ld<BF>(db, ((long long)iyc * W + ixc) * lddy + lq * 4);
             }
 #pragma unroll
             for (int k = 0; k < NXI; ++k) {
@@ -249,14 +255,14 @@ __global__ void __launch_bounds__(256, 2) dwconv7_wgrad_partial_kernel(const flo
                 const int hy = p / HWX, hxx = p - hy * HWX;
                 const int iy = y0 + hy - 3, ix = X0 + hxx - 3;
                 const bool ok = qok && iy >= 0 && iy < H && ix >= 0 && ix < W;
-                if (p < NX) xs[hy * RPX + hxx * 8 + l8] = ok ? hx[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < NX) xs[hy * RPX + hxx * 8 + l8] = ok ? cdf_quad_cvt(hx[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int k = 0; k < NDI; ++k) {
                 const int i = tid + 256 * k, p = i >> 3;
                 const int ty = p / DWG_TW, px = p - ty * DWG_TW;
                 const bool ok = qok && y0 + ty < yb && X0 + px < W;          // rows past the chunk belong to the next block
-                ds[ty * RPD + px * 8 + l8] = ok ? hd[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                ds[ty * RPD + px * 8 + l8] = ok ? cdf_quad_cvt(hd[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             __syncthreads();
             if (busy) {
@@ -319,7 +325,8 @@ __global__ void __launch_bounds__(256, 2) dwconv7_wgrad_partial_kernel(const flo
 // of accumulators per lane.  Lanes: 16 channel-quads (float4, 256 B coalesced) x 4 strips of 8 pixels in flight;
 // per strip a wave loads the dy strip (8 float4) and one 14-wide x window per kernel row, all unconditionally.
 // The 4 strip slots are folded with two cross-lane adds at the end.
-__global__ void __launch_bounds__(256) dwconv7_wgrad_partial_narrow_kernel(const float* x, int ldx, const float* dy, int lddy,
+template <bool BF>
+__global__ void __launch_bounds__(256) dwconv7_wgrad_partial_narrow_kernel(const void* x, int ldx, const void* dy, int lddy,
                                                                    float* part, int H, int W, int C, int rows_per_chunk) {
     constexpr int TW = 8;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: branches on it are uniform
@@ -348,11 +355,11 @@ __global__ void __launch_bounds__(256) dwconv7_wgrad_partial_narrow_kernel(const
     for (int s = slot; s < nstrips; s += 4) {
         const int yy = y0 + s / strips_w, xs = (s % strips_w) * TW;
         float4 d[TW];
-        const float* drow = dy + (((long long)b * H + yy) * W) * lddy + cc;
+        const long long drow = (((long long)b * H + yy) * W) * lddy + cc;
 #pragma unroll
         for (int j = 0; j < TW; ++j) {
             const int ix = xs + j;
-            const float4 v = *(const float4*)(drow + (long long)(ix < W ? ix : W - 1) * lddy);
+            const float4 v = cdf_quad_cvt(cdf_quad_ld<BF>(dy, drow + (long long)(ix < W ? ix : W - 1) * lddy));
             d[j] = (cv && ix < W) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
@@ -360,12 +367,12 @@ __global__ void __launch_bounds__(256) dwconv7_wgrad_partial_narrow_kernel(const
             if (r >= nky) break;                               // wave-uniform
             const int iy = yy + ky0 + r - 3;
             const bool rowok = iy >= 0 && iy < H;
-            const float* row = x + (((long long)b * H + (iy < 0 ? 0 : (iy >= H ? H - 1 : iy))) * W) * ldx + cc;
+            const long long row = (((long long)b * H + (iy < 0 ? 0 : (iy >= H ? H - 1 : iy))) * W) * ldx + cc;
             float4 win[TW + 6];
 #pragma unroll
             for (int q = 0; q < TW + 6; ++q) {
                 const int ix = xs + q - 3;
-                const float4 v = *(const float4*)(row + (long long)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * ldx);
+                const float4 v = cdf_quad_cvt(cdf_quad_ld<BF>(x, row + (long long)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * ldx));
                 win[q] = (rowok && ix >= 0 && ix < W) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
@@ -447,28 +454,31 @@ __global__ void __launch_bounds__(1024) dwconv7_wgrad_final_kernel(const float* 
     }
 }
 
-template <int TBW, int TBH>
-static int launch_dwconv7(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias, int ld_sbias, float* y,
-                          int ldy, int B, int H, int W, int C4, int flip, int accumulate, const float* res, int ldr, hipStream_t s) {
+template <int TBW, int TBH, bool BF>
+static int launch_dwconv7(const void* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias, int ld_sbias, void* y,
+                          int ldy, int B, int H, int W, int C4, int flip, int accumulate, const void* res, int ldr, hipStream_t s) {
     constexpr size_t lds = ((size_t)(TBH + 6) * ((TBW + 6) * 8 + 4) + DW_TAPS * 8) * sizeof(float4);
 #ifndef CDF_EMU
     static CdfDeviceLatch attr_done;
     if (attr_done.first()) {
-        (void)hipFuncSetAttribute((const void*)dwconv7_kernel<TBW, TBH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)dwconv7_kernel<TBW, TBH, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
 #endif
     const long long tiles = (long long)B * cdf_cdiv(H, TBH) * cdf_cdiv(W, TBW);
-    CDF_LAUNCH((dwconv7_kernel<TBW, TBH>), dim3((unsigned)tiles, cdf_cdiv(C4, 8)), dim3(256), lds, s, x, ldx, w, ldw, bias, sbias, ld_sbias, y,
+    CDF_LAUNCH((dwconv7_kernel<TBW, TBH, BF>), dim3((unsigned)tiles, cdf_cdiv(C4, 8)), dim3(256), lds, s, x, ldx, w, ldw, bias, sbias, ld_sbias, y,
                ldy, B, H, W, C4, flip, accumulate, res, ldr);
     return cdf_check_launch("dwconv7");
 }
 
 // ================================================================================================
-extern "C" int cdf_dwconv7(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias,
-                           int ld_sbias, float* y, int ldy, int B, int H, int W, int C, int flip, int accumulate,
-                           const float* res, int ldr, void* stream) {
-    CDF_REQUIRE(!res || (ldr % 4 == 0 && (((uintptr_t)res) & 15) == 0), "cdf_dwconv7: residual must be 16B aligned with pitch %% 4 == 0");
+// io_bf16 != 0: x, y and res are bf16 tensors (pitches in bf16 elements, 8-byte aligned); w, bias, sbias stay fp32
+extern "C" int cdf_dwconv7_io(const void* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias,
+                              int ld_sbias, void* y, int ldy, int B, int H, int W, int C, int flip, int accumulate,
+                              const void* res, int ldr, int io_bf16, void* stream) {
+    const uintptr_t amask = io_bf16 ? 7 : 15;
+    CDF_REQUIRE(!res || (ldr % 4 == 0 && (((uintptr_t)res) & amask) == 0), "cdf_dwconv7: residual must be 16B aligned (bf16: 8B) with pitch %% 4 == 0");
     CDF_REQUIRE(x && w && y, "cdf_dwconv7: null pointer");
+    CDF_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y)) & amask) == 0, "cdf_dwconv7: x / y must be 16B aligned (bf16: 8B)");
     const int Cp = (C + 3) & ~3;
     CDF_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldw % 4 == 0 && ldx >= Cp && ldy >= Cp && ldw >= Cp, "cdf_dwconv7: pitches must be multiples of 4 and >= roundup4(C)");
     CDF_REQUIRE(!bias || (C % 4 == 0), "cdf_dwconv7: bias with C %% 4 != 0 needs a padded bias (pass a padded vector and C rounded up)");
@@ -477,8 +487,18 @@ extern "C" int cdf_dwconv7(const float* x, int ldx, const float* w, int ldw, con
         CDF_REQUIRE((long long)H * W < (1 << 24) && ldmax < (1 << 24) && (long long)H * W * ldmax < (1LL << 30),
                     "cdf_dwconv7: image of %d x %d pixels at pitch %lld is beyond the kernel's 32-bit per-image offsets", H, W, ldmax);
     }
-    if (W <= 16) return launch_dwconv7<16, 16>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S);
-    return launch_dwconv7<32, 8>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S);
+    if (io_bf16) {
+        if (W <= 16) return launch_dwconv7<16, 16, true>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S);
+        return launch_dwconv7<32, 8, true>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S);
+    }
+    if (W <= 16) return launch_dwconv7<16, 16, false>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S);
+    return launch_dwconv7<32, 8, false>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S);
+}
+
+extern "C" int cdf_dwconv7(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias,
+                           int ld_sbias, float* y, int ldy, int B, int H, int W, int C, int flip, int accumulate,
+                           const float* res, int ldr, void* stream) {
+    return cdf_dwconv7_io(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, C, flip, accumulate, res, ldr, 0, stream);
 }
 
 extern "C" int cdf_dwconv7_wgrad_nchunk(int H) {
@@ -489,17 +509,27 @@ extern "C" int cdf_dwconv7_wgrad_nchunk(int H) {
 }
 
 // ws >= B * nchunk * 50 * C floats; dw in the PyTorch layout [C][1][7][7]; dsb [B][ld_dsb] (overwritten)
+// io_bf16 != 0: x and dy are bf16 tensors (pitches in bf16 elements, 8-byte aligned)
+extern "C" int cdf_dwconv7_wgrad_io(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias,
+                                    float* dsb, int ld_dsb, float* ws, int B, int H, int W, int C, int accumulate, int io_bf16,
+                                    void* stream) {
+    CDF_REQUIRE(x && dy && dw && ws, "cdf_dwconv7_wgrad: null pointer");
+    CDF_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && ldx >= ((C + 3) & ~3) && lddy >= ((C + 3) & ~3) && ((((uintptr_t)x) | ((uintptr_t)dy)) & (io_bf16 ? 7 : 15)) == 0,
+                "cdf_dwconv7_wgrad: pitches must be multiples of 4 and >= roundup4(C), pointers 16B aligned (bf16: 8B)");
+    const int nchunk = cdf_dwconv7_wgrad_nchunk(H), rpc = cdf_cdiv(H, nchunk);
+    if (W >= 32) {
+        if (io_bf16) CDF_LAUNCH(dwconv7_wgrad_partial_kernel<true>, dim3(cdf_cdiv(C, 32), nchunk, B), dim3(256), 0, CDF_S, x, ldx, dy, lddy, ws, H, W, C, rpc);
+        else CDF_LAUNCH(dwconv7_wgrad_partial_kernel<false>, dim3(cdf_cdiv(C, 32), nchunk, B), dim3(256), 0, CDF_S, x, ldx, dy, lddy, ws, H, W, C, rpc);
+    } else {
+        if (io_bf16) CDF_LAUNCH(dwconv7_wgrad_partial_narrow_kernel<true>, dim3(cdf_cdiv(C, 64), nchunk, B), dim3(256), 0, CDF_S, x, ldx, dy, lddy, ws, H, W, C, rpc);
+        else CDF_LAUNCH(dwconv7_wgrad_partial_narrow_kernel<false>, dim3(cdf_cdiv(C, 64), nchunk, B), dim3(256), 0, CDF_S, x, ldx, dy, lddy, ws, H, W, C, rpc);
+    }
+    CDF_LAUNCH(dwconv7_wgrad_final_kernel, dim3(cdf_cdiv(C, 64), DW_TAPS + 1), dim3(1024), 0, CDF_S, (const float*)ws, B, nchunk, C, dw, dbias, dsb, ld_dsb, accumulate);
+    return cdf_check_launch("dwconv7_wgrad");
+}
+
 extern "C" int cdf_dwconv7_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* dbias,
                                  float* dsb, int ld_dsb, float* ws, int B, int H, int W, int C, int accumulate,
                                  void* stream) {
-    CDF_REQUIRE(x && dy && dw && ws, "cdf_dwconv7_wgrad: null pointer");
-    CDF_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && ldx >= ((C + 3) & ~3) && lddy >= ((C + 3) & ~3) && ((((uintptr_t)x) | ((uintptr_t)dy)) & 15) == 0,
-                "cdf_dwconv7_wgrad: pitches must be multiples of 4 and >= roundup4(C), pointers 16B aligned");
-    const int nchunk = cdf_dwconv7_wgrad_nchunk(H), rpc = cdf_cdiv(H, nchunk);
-    if (W >= 32)
-        CDF_LAUNCH(dwconv7_wgrad_partial_kernel, dim3(cdf_cdiv(C, 32), nchunk, B), dim3(256), 0, CDF_S, x, ldx, dy, lddy, ws, H, W, C, rpc);
-    else
-        CDF_LAUNCH(dwconv7_wgrad_partial_narrow_kernel, dim3(cdf_cdiv(C, 64), nchunk, B), dim3(256), 0, CDF_S, x, ldx, dy, lddy, ws, H, W, C, rpc);
-    CDF_LAUNCH(dwconv7_wgrad_final_kernel, dim3(cdf_cdiv(C, 64), DW_TAPS + 1), dim3(1024), 0, CDF_S, (const float*)ws, B, nchunk, C, dw, dbias, dsb, ld_dsb, accumulate);
-    return cdf_check_launch("dwconv7_wgrad");
+    return cdf_dwconv7_wgrad_io(x, ldx, dy, lddy, dw, dbias, dsb, ld_dsb, ws, B, H, W, C, accumulate, 0, stream);
 }

@@ -15,8 +15,9 @@
 // HBM-bound (8 B / element forward, 12-16 B backward).  Each wave handles 64/LP pixels at a time, and every lane keeps
 // the loads of U consecutive pixel groups in flight (unconditional: clamped address + select) -- with one load per
 // lane in flight and the 512-block grid the kernels sat at a quarter of the HBM rate.
-template <int NV>
-__global__ void __launch_bounds__(256) layernorm_c_fwd_kernel(const float* x, int ldx, float* y, int ldy, const float* g,
+// XB (bf16 activation storage): x is a bf16 tensor (pitch in bf16 elements); statistics and the output arithmetic stay fp32.
+template <int NV, bool XB>
+__global__ void __launch_bounds__(256) layernorm_c_fwd_kernel(const void* x, int ldx, float* y, int ldy, const float* g,
                                                               const float* bta, float* mean_out, float* rstd_out,
                                                               long long M, int C, int LP, float eps, unsigned short* ys_hi,
                                                               unsigned short* ys_lo, int ld_ys) {
@@ -42,7 +43,7 @@ __global__ void __launch_bounds__(256) layernorm_c_fwd_kernel(const float* x, in
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int c = (li + j * LP) * 4;
-                const float4 t = *(const float4*)(x + mc * ldx + (c < C ? c : 0));
+                const float4 t = cdf_quad_cvt(cdf_quad_ld<XB>(x, mc * ldx + (c < C ? c : 0)));
                 v[u][j] = (m < M && c < C) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -93,11 +94,18 @@ __global__ void __launch_bounds__(256) layernorm_c_fwd_kernel(const float* x, in
 }
 
 // backward: dx, and per-block partial sums of dg / db in part[block][2][C]
-template <int NV>
-__global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const float* dy, int lddy, const float* x, int ldx,
+// IO (bf16 activation storage), bits CDF_LN_*_BF16: which of dy / x / dx / add are bf16 tensors (pitches in their own elements).
+// Used: 0 (all fp32), dy | x | dx (the ConvNeXt block: dhn, h -> dh), x | dx | add (the attention block: fp32 dxn, bf16 stream).
+#define CDF_LN_DY_BF16 1
+#define CDF_LN_X_BF16 2
+#define CDF_LN_DX_BF16 4
+#define CDF_LN_ADD_BF16 8
+template <int NV, int IO>
+__global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const void* dy, int lddy, const void* x, int ldx,
                                                               const float* g, const float* mean_in, const float* rstd_in,
-                                                              float* dx, int lddx, float* part, long long M, int C,
-                                                              int LP, const float* add, int ldadd) {
+                                                              void* dx, int lddx, float* part, long long M, int C,
+                                                              int LP, const void* add, int ldadd) {
+    constexpr bool DYB = (IO & CDF_LN_DY_BF16) != 0, XB = (IO & CDF_LN_X_BF16) != 0, DXB = (IO & CDF_LN_DX_BF16) != 0, ADB = (IO & CDF_LN_ADD_BF16) != 0;
     constexpr int U = NV <= 2 ? 2 : 1;
     const bool accumulate_dx = add != nullptr;               // dx = grad + add (add == dx: accumulate in place)
     CDF_DYN_SMEM(smem);
@@ -118,7 +126,8 @@ __global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const float* dy, i
         gg[j] = *(const float4*)(g + (c < C ? c : 0));
     }
     for (long long pg0 = wave_global * U; pg0 < npg; pg0 += nwaves * U) {
-        float4 xv[U][NV], dv[U][NV], old[U][NV];
+        float4 xv[U][NV], dv[U][NV];
+        typename cdf_quad<ADB>::raw old[U][NV];
         float mean[U], rstd[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -131,10 +140,12 @@ __global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const float* dy, i
             for (int j = 0; j < NV; ++j) {
                 const int c = (li + j * LP) * 4, cc = c < C ? c : 0;
                 const bool ok = valid && c < C;
-                const float4 tx = *(const float4*)(x + mc * ldx + cc), td = *(const float4*)(dy + mc * lddy + cc);
+                const typename cdf_quad<XB>::raw rx = cdf_quad_ld<XB>(x, mc * ldx + cc);
+                const typename cdf_quad<DYB>::raw rd = cdf_quad_ld<DYB>(dy, mc * lddy + cc);
+                if (accumulate_dx) old[u][j] = cdf_quad_ld<ADB>(add, mc * ldadd + cc);     // block-uniform branch
+                const float4 tx = cdf_quad_cvt(rx), td = cdf_quad_cvt(rd);
                 xv[u][j] = ok ? tx : make_float4(mean[u], mean[u], mean[u], mean[u]);      // => xhat = 0
                 dv[u][j] = ok ? td : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (accumulate_dx) old[u][j] = *(const float4*)(add + mc * ldadd + cc);    // block-uniform branch
             }
         }
 #pragma unroll
@@ -166,8 +177,11 @@ __global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const float* dy, i
                         o.y = rstd[u] * (dg_[j].y - s1 - xh[j].y * s2);
                         o.z = rstd[u] * (dg_[j].z - s1 - xh[j].z * s2);
                         o.w = rstd[u] * (dg_[j].w - s1 - xh[j].w * s2);
-                        if (accumulate_dx) { o.x += old[u][j].x; o.y += old[u][j].y; o.z += old[u][j].z; o.w += old[u][j].w; }
-                        *(float4*)(dx + m * lddx + c) = o;
+                        if (accumulate_dx) {
+                            const float4 ov = cdf_quad_cvt(old[u][j]);
+                            o.x += ov.x; o.y += ov.y; o.z += ov.z; o.w += ov.w;
+                        }
+                        cdf_quad_st<DXB>(dx, m * lddx + c, o);
                     }
                 }
             }
@@ -465,36 +479,55 @@ extern "C" int cdf_layernorm_blocks(long long M, int C) {
     return nb < 1 ? 1 : (int)nb;
 }
 
-extern "C" int cdf_layernorm_c_fwd(const float* x, int ldx, float* y, int ldy, const float* g, const float* b,
-                                   float* mean, float* rstd, long long M, int C, float eps, void* y_hi, void* y_lo, int ld_ys,
-                                   void* stream) {
+// x_bf16 != 0: x is a bf16 tensor (pitch in bf16 elements, 8-byte aligned)
+extern "C" int cdf_layernorm_c_fwd_io(const void* x, int ldx, float* y, int ldy, const float* g, const float* b,
+                                      float* mean, float* rstd, long long M, int C, float eps, void* y_hi, void* y_lo, int ld_ys,
+                                      int x_bf16, void* stream) {
     CDF_REQUIRE((!y_hi && !y_lo) || (y_hi && ld_ys % 4 == 0 && ld_ys >= C && ((((uintptr_t)y_hi) | ((uintptr_t)y_lo)) & 7) == 0),
                 "cdf_layernorm_c_fwd: split output planes need ld_ys %% 4 == 0, ld_ys >= C, 8-byte alignment");
     CDF_REQUIRE(x && (y || y_hi) && g && b && M > 0, "cdf_layernorm_c_fwd: null / empty");
     CDF_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && (!y || ldy % 4 == 0) && C <= 1024, "cdf_layernorm_c_fwd: C=%d must be a multiple of 4 and <= 1024", C);
+    CDF_REQUIRE((((uintptr_t)x) & (x_bf16 ? 7 : 15)) == 0, "cdf_layernorm_c_fwd: x must be 16-byte aligned (bf16: 8)");
     int LP, NV;
     CDF_REQUIRE(ln_geometry(C, &LP, &NV) == CDF_OK, "cdf_layernorm_c_fwd: unsupported C=%d", C);
     const int nb = cdf_layernorm_blocks(M, C);
-#define CDF_LN_FWD(N) CDF_LAUNCH((layernorm_c_fwd_kernel<N>), dim3(nb), dim3(256), 0, CDF_S, x, ldx, y, ldy, g, b, mean, rstd, M, C, LP, eps, (unsigned short*)y_hi, (unsigned short*)y_lo, ld_ys)
-    switch (NV) {
-        case 1: CDF_LN_FWD(1); break;
-        case 2: CDF_LN_FWD(2); break;
-        case 3: CDF_LN_FWD(3); break;
-        default: CDF_LN_FWD(4); break;
+#define CDF_LN_FWD(N, XB) CDF_LAUNCH((layernorm_c_fwd_kernel<N, XB>), dim3(nb), dim3(256), 0, CDF_S, x, ldx, y, ldy, g, b, mean, rstd, M, C, LP, eps, (unsigned short*)y_hi, (unsigned short*)y_lo, ld_ys)
+#define CDF_LN_FWD_NV(XB)                  \
+    switch (NV) {                          \
+        case 1: CDF_LN_FWD(1, XB); break;  \
+        case 2: CDF_LN_FWD(2, XB); break;  \
+        case 3: CDF_LN_FWD(3, XB); break;  \
+        default: CDF_LN_FWD(4, XB); break; \
     }
+    if (x_bf16) { CDF_LN_FWD_NV(true) } else { CDF_LN_FWD_NV(false) }
+#undef CDF_LN_FWD_NV
 #undef CDF_LN_FWD
     return cdf_check_launch("layernorm_c_fwd");
 }
 
-// part: >= cdf_layernorm_blocks(M, C) * 2 * C floats
-extern "C" int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, int ldx, const float* g,
-                                   const float* mean, const float* rstd, float* dx, int lddx, const float* add, int ldadd,
-                                   float* dg, float* db, float* part, long long M, int C, int accumulate_dx, int accumulate_param,
+extern "C" int cdf_layernorm_c_fwd(const float* x, int ldx, float* y, int ldy, const float* g, const float* b,
+                                   float* mean, float* rstd, long long M, int C, float eps, void* y_hi, void* y_lo, int ld_ys,
                                    void* stream) {
+    return cdf_layernorm_c_fwd_io(x, ldx, y, ldy, g, b, mean, rstd, M, C, eps, y_hi, y_lo, ld_ys, 0, stream);
+}
+
+// part: >= cdf_layernorm_blocks(M, C) * 2 * C floats
+// io_bf16: CDF_LN_DY_BF16 (1) | CDF_LN_X_BF16 (2) | CDF_LN_DX_BF16 (4) | CDF_LN_ADD_BF16 (8) -- which tensors are bf16 (pitches in their own
+// elements, 8-byte aligned); supported combinations: 0, 7 (dy, x, dx: the ConvNeXt block) and 14 (x, dx, add: the attention block)
+extern "C" int cdf_layernorm_c_bwd_io(const void* dy, int lddy, const void* x, int ldx, const float* g,
+                                      const float* mean, const float* rstd, void* dx, int lddx, const void* add, int ldadd,
+                                      float* dg, float* db, float* part, long long M, int C, int accumulate_dx, int accumulate_param,
+                                      int io_bf16, void* stream) {
     CDF_REQUIRE(dy && x && g && mean && rstd && dx && dg && db && part && M > 0, "cdf_layernorm_c_bwd: null / empty");
     CDF_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && C <= 1024, "cdf_layernorm_c_bwd: bad C / pitch");
-    CDF_REQUIRE(!(add && accumulate_dx) && (!add || (ldadd % 4 == 0 && (((uintptr_t)add) & 15) == 0)), "cdf_layernorm_c_bwd: add and accumulate_dx exclude each other; add must be 16-byte aligned with a pitch % 4 == 0");
-    if (accumulate_dx) { add = dx; ldadd = lddx; }
+    CDF_REQUIRE(!(add && accumulate_dx) && (!add || (ldadd % 4 == 0 && (((uintptr_t)add) & ((io_bf16 & CDF_LN_ADD_BF16) ? 7 : 15)) == 0)), "cdf_layernorm_c_bwd: add and accumulate_dx exclude each other; add must be 16-byte aligned (bf16: 8) with a pitch % 4 == 0");
+    CDF_REQUIRE(io_bf16 == 0 || io_bf16 == 7 || io_bf16 == 14, "cdf_layernorm_c_bwd_io: io_bf16 = %d is not one of 0 / 7 / 14", io_bf16);
+    CDF_REQUIRE((((uintptr_t)dy) & ((io_bf16 & CDF_LN_DY_BF16) ? 7 : 15)) == 0 && (((uintptr_t)x) & ((io_bf16 & CDF_LN_X_BF16) ? 7 : 15)) == 0 &&
+                (((uintptr_t)dx) & ((io_bf16 & CDF_LN_DX_BF16) ? 7 : 15)) == 0, "cdf_layernorm_c_bwd: dy / x / dx must be 16-byte aligned (bf16: 8)");
+    if (accumulate_dx) {
+        CDF_REQUIRE(io_bf16 != 7, "cdf_layernorm_c_bwd_io: accumulate_dx (dx read back in its own type) is not instantiated for io_bf16 = 7");
+        add = dx; ldadd = lddx;
+    }
     int LP, NV;
     CDF_REQUIRE(ln_geometry(C, &LP, &NV) == CDF_OK, "cdf_layernorm_c_bwd: unsupported C=%d", C);
     const int nb = cdf_layernorm_blocks(M, C);
@@ -503,22 +536,33 @@ extern "C" int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, in
 #ifndef CDF_EMU
     static CdfDeviceLatch attr_done;
     if (attr_done.first()) {
-        (void)hipFuncSetAttribute((const void*)layernorm_c_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)layernorm_c_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)layernorm_c_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)layernorm_c_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define CDF_LN_ATTR(N, IO) (void)hipFuncSetAttribute((const void*)layernorm_c_bwd_kernel<N, IO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+        CDF_LN_ATTR(1, 0); CDF_LN_ATTR(2, 0); CDF_LN_ATTR(3, 0); CDF_LN_ATTR(4, 0);
+        CDF_LN_ATTR(1, 7); CDF_LN_ATTR(2, 7); CDF_LN_ATTR(3, 7); CDF_LN_ATTR(4, 7);
+        CDF_LN_ATTR(1, 14); CDF_LN_ATTR(2, 14); CDF_LN_ATTR(3, 14); CDF_LN_ATTR(4, 14);
+#undef CDF_LN_ATTR
     }
 #endif
-#define CDF_LN_BWD(N) CDF_LAUNCH((layernorm_c_bwd_kernel<N>), dim3(nb), dim3(256), lds, CDF_S, dy, lddy, x, ldx, g, mean, rstd, dx, lddx, part, M, C, LP, add, ldadd)
-    switch (NV) {
-        case 1: CDF_LN_BWD(1); break;
-        case 2: CDF_LN_BWD(2); break;
-        case 3: CDF_LN_BWD(3); break;
-        default: CDF_LN_BWD(4); break;
+#define CDF_LN_BWD(N, IO) CDF_LAUNCH((layernorm_c_bwd_kernel<N, IO>), dim3(nb), dim3(256), lds, CDF_S, dy, lddy, x, ldx, g, mean, rstd, dx, lddx, part, M, C, LP, add, ldadd)
+#define CDF_LN_BWD_NV(IO)                  \
+    switch (NV) {                          \
+        case 1: CDF_LN_BWD(1, IO); break;  \
+        case 2: CDF_LN_BWD(2, IO); break;  \
+        case 3: CDF_LN_BWD(3, IO); break;  \
+        default: CDF_LN_BWD(4, IO); break; \
     }
+    if (io_bf16 == 7) { CDF_LN_BWD_NV(7) } else if (io_bf16 == 14) { CDF_LN_BWD_NV(14) } else { CDF_LN_BWD_NV(0) }
+#undef CDF_LN_BWD_NV
 #undef CDF_LN_BWD
     CDF_LAUNCH(norm_param_reduce_kernel, dim3(cdf_cdiv(2 * C, 64)), dim3(1024), 0, CDF_S, (const float*)part, nb, C, dg, db, accumulate_param);
     return cdf_check_launch("layernorm_c_bwd");
+}
+
+extern "C" int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, int ldx, const float* g,
+                                   const float* mean, const float* rstd, float* dx, int lddx, const float* add, int ldadd,
+                                   float* dg, float* db, float* part, long long M, int C, int accumulate_dx, int accumulate_param,
+                                   void* stream) {
+    return cdf_layernorm_c_bwd_io(dy, lddy, x, ldx, g, mean, rstd, dx, lddx, add, ldadd, dg, db, part, M, C, accumulate_dx, accumulate_param, 0, stream);
 }
 
 extern "C" int cdf_groupnorm_nchunk(int HW) {

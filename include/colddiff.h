@@ -28,7 +28,7 @@ extern "C" {
 /* Bumped whenever an exported signature changes incompatibly (rounds 1-3 all answered 1 while arguments were added: `tiled`,
  * `onepass`, `slots`, `tune`).  cdf_abi_version() returns the value the LIBRARY was built with; a binding compares it with the
  * header it was generated from before the first call (colddiff/_lib.py does) -- a mismatched pair would read shifted arguments. */
-#define CDF_ABI_VERSION 4
+#define CDF_ABI_VERSION 5
 
 #define CDF_E_INVALID (-1)
 #define CDF_E_UNSUPPORTED (-2)
@@ -212,6 +212,20 @@ int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void*
                         int nphase, const int* phase_desc, const float* bias, const float* sbias, int ld_sbias, const float* res,
                         int ldr, float* pre, int ldp, const float* mul, int ldm, int act, int mul_mode, int accumulate,
                         void* y_hi, void* y_lo, int ld_ys, float* ws, long long ws_floats, const cdf_gemm_tuning* tune, void* stream);
+/* bf16 ACTIVATION STORAGE (the "bf16" mode BASELINE configs 3 / 5 name: bf16 operands AND bf16 tensors, fp32 accumulate / master weights /
+ * statistics).  A feature map between kernels is ONE bf16 plane [pixels][ld] -- what the GEMMs above call the "hi" plane IS the tensor
+ * (x_lo = w_lo = y_lo = NULL, y = NULL) -- and the *_io entry points below take the remaining operands in that type too.  Pitches of a
+ * bf16 operand are in bf16 elements; bf16 pointers need 8-byte alignment (GEMM operand planes 16).
+ * cdf_conv_gemm_bf16x_io: cdf_conv_gemm_bf16x with typed epilogue operands; io_bf16 = bit mask
+ *   1 (CDF_IO_RES_BF16): res is bf16;  2 (CDF_IO_PRE_BF16): pre is written as bf16;  4 (CDF_IO_MUL_BF16): mul is bf16.
+ * cdf_bf16_to_f32: y[r][c] = float(x[r][c]) (exact) for the few kernels that have no bf16-input form; the other direction is
+ *   cdf_split_bf16 with lo = NULL (round to nearest even). */
+int cdf_conv_gemm_bf16x_io(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo, int ldk,
+                           float* y, int ldy, int B, int H, int W, int Cin, int OH, int OW, int Cout, int QH, int QW, int os, int is,
+                           int nphase, const int* phase_desc, const float* bias, const float* sbias, int ld_sbias, const void* res,
+                           int ldr, void* pre, int ldp, const void* mul, int ldm, int act, int mul_mode, int accumulate, int io_bf16,
+                           void* y_hi, void* y_lo, int ld_ys, float* ws, long long ws_floats, const cdf_gemm_tuning* tune, void* stream);
+int cdf_bf16_to_f32(const void* x, int ldx, float* y, int ldy, long long rows, int C, void* stream);
 /* cdf_conv_wgrad_bf16x_is_row3 tells the caller whether a geometry takes the row-of-taps kernel (3 tap blocks per tile, one 512-thread
  * block per CU) so that it can size nsplit. */
 int cdf_conv_wgrad_bf16x_is_row3(int QH, int QW, int CA, int CB, int ntaps, int same_size_3x3, const cdf_gemm_tuning* tune);
@@ -293,6 +307,14 @@ int cdf_layernorm_c_fwd(const float* x, int ldx, float* y, int ldy, const float*
 int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, int ldx, const float* g, const float* mean,
                         const float* rstd, float* dx, int lddx, const float* add, int ldadd, float* dg, float* db, float* part,
                         long long M, int C, int accumulate_dx, int accumulate_param, void* stream);
+/* bf16 activation storage.  fwd: x_bf16 != 0 -> x is a bf16 tensor (outputs as before: fp32 y and / or the bf16 plane y_hi).
+ * bwd: io_bf16 bit mask 1 dy | 2 x | 4 dx | 8 add are bf16; instantiated: 0, 7 (dy, x, dx: ConvNeXt block) and 14 (x, dx, add: the
+ * attention block, whose own gradient dxn is fp32). */
+int cdf_layernorm_c_fwd_io(const void* x, int ldx, float* y, int ldy, const float* g, const float* b, float* mean,
+                           float* rstd, long long M, int C, float eps, void* y_hi, void* y_lo, int ld_ys, int x_bf16, void* stream);
+int cdf_layernorm_c_bwd_io(const void* dy, int lddy, const void* x, int ldx, const float* g, const float* mean,
+                           const float* rstd, void* dx, int lddx, const void* add, int ldadd, float* dg, float* db, float* part,
+                           long long M, int C, int accumulate_dx, int accumulate_param, int io_bf16, void* stream);
 /* GroupNorm(groups) [+ SiLU] (Model2.py:27-33): statistics per (sample, group) over C/groups channels
  * and all HW pixels; mean/rstd [B][groups].  fwd ws >= B*nchunk*2*C floats;
  * bwd ws >= B*nchunk*2*C + B*2*C + B*groups*2 floats, nchunk = cdf_groupnorm_nchunk(HW). */
@@ -325,6 +347,13 @@ int cdf_dwconv7(const float* x, int ldx, const float* w, int ldw, const float* b
 int cdf_dwconv7_wgrad_nchunk(int H);
 int cdf_dwconv7_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* dbias, float* dsb,
                       int ld_dsb, float* ws, int B, int H, int W, int C, int accumulate, void* stream);
+/* bf16 activation storage: io_bf16 != 0 -> x, y, res (forward / data gradient) resp. x, dy (weight gradient) are bf16 tensors; weights,
+ * biases, partial sums and the gradients written stay fp32 */
+int cdf_dwconv7_io(const void* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias, int ld_sbias,
+                   void* y, int ldy, int B, int H, int W, int C, int flip, int accumulate, const void* res, int ldr, int io_bf16,
+                   void* stream);
+int cdf_dwconv7_wgrad_io(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias, float* dsb,
+                         int ld_dsb, float* ws, int B, int H, int W, int C, int accumulate, int io_bf16, void* stream);
 
 /* ---- attention -------------------------------------------------------------------------------------
  * LinearAttention core (deblurring_diffusion_pytorch.py:176-187) on qkv [B,n,ld] = (q|k|v), each
