@@ -152,9 +152,9 @@ class CatBuf:
     transposed-conv upsampler) writes into channels [0, Cx) -- every kernel takes a pixel pitch, so neither half is ever copied
     (the round-1 `Concat` node spent two cdf_axpby passes per stage on it).  Not a tensor: autograd does not look inside."""
 
-    def __init__(self, ref, B, H, W, Cx, Ch):
+    def __init__(self, ref, B, H, W, Cx, Ch, dtype=torch.float32):
         self.Cx, self.Ch = Cx, Ch
-        self.buf = torch.empty((B, H, W, Cx + Ch), device=ref.device, dtype=torch.float32)
+        self.buf = torch.empty((B, H, W, Cx + Ch), device=ref.device, dtype=dtype)
 
     def first(self):
         return self.buf[..., :self.Cx]

@@ -397,11 +397,13 @@ def wgrad_into(gparam, wplan, xa, CA, xb, CB, s_t, s_r, s_c, gbias=None, xa_s=No
         ws = torch.empty((ns, wplan.ntaps, CA, ldo), device=dev, dtype=torch.float32)
         S = rt.stream(xa_s[0])
         bsum = torch.empty((ns, ldo), device=dev, dtype=torch.float32) if gbias is not None else None
-        L.cdf_conv_wgrad_bf16x(P(xa_s[0]), P(xa_s[1]), xa_s[0].shape[-1], P(xb_s[0]), P(xb_s[1]), xb_s[0].shape[-1], P(zero_page(dev)),
+        L.cdf_conv_wgrad_bf16x(P(xa_s[0]), P(xa_s[1]), ld_of(xa_s[0]), P(xb_s[0]), P(xb_s[1]), ld_of(xb_s[0]), P(zero_page(dev)),
                                P(ws), ldo, B, wplan.QH, wplan.QW, wplan.HA, wplan.WA, wplan.sa, wplan.HB, wplan.WB, wplan.sb, CA, CB,
                                wplan.ntaps, wplan.desc, ns, P(bsum), rt.tune_ptr(), S)
         _reduce_slabs(L, ws, gparam, ns, wplan.ntaps, CA, CB, ldo, s_t, s_r, s_c, bsum, gbias, S)
         return
+    # (bf16 activation storage: the operands of a layer too thin for the plane kernel above are widened for the kernels below)
+    xa, xb = f32_of(xa, CA), f32_of(xb, CB)
     if rt.precision != "f32" and CA >= 128 and CB >= 128 and M >= WGRAD_SP_MIN_M:   # full 128x128 tiles only; thinner layers are faster on the fp32 kernel
         # split-precision bf16 MFMA kernel: 128x128 tiles, resident twice per CU (512 slots)
         tiles = ((CA + 127) // 128) * ((CB + 127) // 128) * wplan.ntaps
@@ -438,6 +440,7 @@ def _reduce_slabs(L, ws, gparam, ns, ntaps, CA, CB, ldo, s_t, s_r, s_c, bsum, gb
 def colsum_into(gvec, x, C, nseg=1):
     """gvec[seg][c] += sum over the rows of segment seg of x (x: [..., C] pitched rows)."""
     L = rt.lib()
+    x = f32_of(x)
     ld = ld_of(x)
     rows = x.numel() // x.shape[-1]
     rps = rows // nseg
@@ -925,3 +928,116 @@ def colsum_new(x, C, nseg):
     out = torch.zeros((nseg, r4(C)), device=x.device, dtype=torch.float32)
     colsum_into(out, x, C, nseg)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# bf16 ACTIVATION STORAGE ("bf16" arithmetic mode, BASELINE configs 3 / 5): feature maps between kernels are torch.bfloat16 tensors
+# [B, H, W, C] (C % 8 == 0, unit channel stride, any pixel pitch) -- ONE plane, the GEMMs' "hi" plane IS the tensor.  fp32 stays:
+# accumulators, norm statistics, master weights, time biases, parameter gradients.  colddiff/bf16store.py holds the block-level nodes.
+# ---------------------------------------------------------------------------------------------------
+BF = torch.bfloat16
+IO_RES, IO_PRE, IO_MUL = 1, 2, 4           # include/colddiff.h: io_bf16 bits of cdf_conv_gemm_bf16x_io
+
+
+def is_bf(t):
+    return t is not None and t.dtype == BF
+
+
+def new_bf(ref, B, H, W, C):
+    assert C % 8 == 0, "bf16 feature maps keep channel counts in multiples of 8 (16-byte GEMM operand rows)"
+    return torch.empty((B, H, W, C), device=ref.device, dtype=BF)
+
+
+def to_f32(x, C=None):
+    """bf16 feature map -> fresh fp32 tensor (exact); for the few kernels without a bf16-input form."""
+    C = x.shape[-1] if C is None else C
+    y = torch.empty(x.shape[:-1] + (r4(C),), device=x.device, dtype=torch.float32)
+    rt.lib().cdf_bf16_to_f32(P(x), ld_of(x), P(y), y.shape[-1], x.numel() // x.shape[-1], r4(C), rt.stream(x))
+    return y
+
+
+def f32_of(x, C=None):
+    return to_f32(x, C) if is_bf(x) else x
+
+
+def to_bf16(x, out=None):
+    """fp32 feature map -> bf16 (round to nearest even: cdf_split_bf16 with the hi plane only); `out`: destination view (any pitch % 8)."""
+    C = x.shape[-1]
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=BF)
+    rt.lib().cdf_split_bf16(P(x), ld_of(x), P(out), 0, ld_of(out), x.numel() // C, C, rt.stream(x))
+    return out
+
+
+def conv_gemm_bf(plan, x, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None, pre=None, mul=None, act=0, mul_mode=0):
+    """The pre-split GEMM on a bf16 tensor (x IS its operand plane; wp = (hi, None) packed weights) -> bf16 output (y: optional
+    destination view).  res / mul: bf16 or fp32 tensors; pre: a bf16 (or fp32) tensor that receives the pre-activation."""
+    assert is_bf(x) and wp[1] is None and Cin % 8 == 0 and Cout % 4 == 0
+    B = x.shape[0]
+    if y is None:
+        y = torch.empty((B, plan.OH, plan.OW, Cout), device=x.device, dtype=BF)
+    ldv = lambda t: 0 if t is None else ld_of(t)
+    M = B * plan.QH * plan.QW
+    ws, nws = None, 0
+    if M <= 4096 and x.device.type != "meta":
+        ks = rt.lib().cdf_conv_gemm_bf16x_ksplit(M, Cout, plan.nphase, plan.desc[2], rt.tune_ptr())
+        if ks > 1:
+            nws = ks * M * r4(Cout)
+            ws = torch.empty((nws,), device=x.device, dtype=torch.float32)
+    io = (IO_RES if is_bf(res) else 0) | (IO_PRE if is_bf(pre) else 0) | (IO_MUL if is_bf(mul) else 0)
+    rt.lib().cdf_conv_gemm_bf16x_io(P(x), 0, ld_of(x), P(zero_page(x.device)), P(wp[0]), 0, wp[0].shape[-1], 0, Cout,
+                                    B, plan.H, plan.W, Cin, plan.OH, plan.OW, Cout, plan.QH, plan.QW, plan.os, plan.istride, plan.nphase,
+                                    plan.desc, P(bias), P(sbias), 0 if sbias is None else sbias.stride(0), P(res), ldv(res), P(pre),
+                                    ldv(pre), P(mul), ldv(mul), act, mul_mode, 0, io, P(y), 0, ld_of(y), P(ws), nws, rt.tune_ptr(), rt.stream(x))
+    return y
+
+
+def dwconv7_bf(x, wp, bias, sbias, flip=0, y=None, accumulate=0, res=None):
+    """ops.dwconv7 on bf16 tensors (x, y, res all bf16)."""
+    B, H, W, Cp = x.shape
+    assert is_bf(x) and (res is None or is_bf(res))
+    if y is None:
+        y = torch.empty((B, H, W, Cp), device=x.device, dtype=BF)
+    rt.lib().cdf_dwconv7_io(P(x), ld_of(x), P(wp), wp.shape[-1], P(bias), P(sbias), 0 if sbias is None else sbias.stride(0), P(y),
+                            ld_of(y), B, H, W, Cp, flip, accumulate, P(res), 0 if res is None else ld_of(res), 1, rt.stream(x))
+    return y
+
+
+def dwconv7_wgrad_bf(x, dy, w_param, b_param, want_dsb, dsb_out=None):
+    L = rt.lib()
+    B, H, W, Cp = x.shape
+    C = w_param.shape[0]
+    ws = torch.empty((B * L.cdf_dwconv7_wgrad_nchunk(H) * 50 * C,), device=x.device, dtype=torch.float32)
+    dsb = None
+    if want_dsb:
+        dsb = dsb_out if dsb_out is not None else torch.zeros((B, Cp), device=x.device, dtype=torch.float32)
+    L.cdf_dwconv7_wgrad_io(P(x), ld_of(x), P(dy), ld_of(dy), P(grad_of(w_param)), P(grad_of(b_param)), P(dsb),
+                           0 if dsb is None else dsb.stride(0), P(ws), B, H, W, C, 1, 1, rt.stream(x))
+    return dsb
+
+
+def layernorm_fwd_bf(x, g, b, eps, save, out_f32=False):
+    """Channel LayerNorm of a bf16 tensor -> (y, mean, rstd); y bf16 (the next GEMM's operand plane) or, out_f32, fp32."""
+    B, H, W, C = x.shape
+    M = B * H * W
+    y = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32 if out_f32 else BF)
+    mean = torch.empty((M,), device=x.device, dtype=torch.float32) if save else None
+    rstd = torch.empty((M,), device=x.device, dtype=torch.float32) if save else None
+    rt.lib().cdf_layernorm_c_fwd_io(P(x), ld_of(x), P(y) if out_f32 else 0, C, P(g), P(b), P(mean), P(rstd), M, C, eps,
+                                    0 if out_f32 else P(y), 0, 0 if out_f32 else C, 1, rt.stream(x))
+    return y, mean, rstd
+
+
+def layernorm_bwd_bf(dy, x, g_param, b_param, mean, rstd, add=None):
+    """dx (bf16) of the channel LayerNorm of the bf16 tensor x; dy bf16 (ConvNeXt block) or fp32 with a bf16 `add` (attention block:
+    dx = grad + add).  Accumulates the g / b gradients."""
+    L = rt.lib()
+    B, H, W, C = x.shape
+    M = B * H * W
+    io = 7 if is_bf(dy) else 14
+    assert is_bf(x) and (io == 14 or add is None) and (add is None or is_bf(add))
+    dx = torch.empty((B, H, W, C), device=x.device, dtype=BF)
+    part = torch.empty((L.cdf_layernorm_blocks(M, C) * 2 * C,), device=x.device, dtype=torch.float32)
+    L.cdf_layernorm_c_bwd_io(P(dy), ld_of(dy), P(x), ld_of(x), P(g_param), P(mean), P(rstd), P(dx), C, P(add),
+                             0 if add is None else ld_of(add), P(grad_of(g_param)), P(grad_of(b_param)), P(part), M, C, 0, 1, io, rt.stream(x))
+    return dx

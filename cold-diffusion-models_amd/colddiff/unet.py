@@ -13,6 +13,7 @@ import math
 import torch
 from torch import nn
 
+from . import bf16store as BFS
 from . import functions as F_
 from . import ops
 from . import runtime as rt
@@ -54,6 +55,8 @@ class Residual(nn.Module):
         self.fn = fn
 
     def forward(self, x, dest=None):    # only Residual(PreNorm(LinearAttention)) occurs in the model
+        if ops.is_bf(x):                # bf16 activation storage (colddiff/bf16store.py): the stream's type selects the node
+            return BFS.LinAttnBlockBF.apply(anchor(x), x, self, dest)
         return F_.LinAttnBlockFn.apply(anchor(x), x, self, dest)
 
 
@@ -112,6 +115,8 @@ class ConvNextBlock(nn.Module):
         if tb is None and exists(self.mlp):
             assert exists(gelu_t), "time emb must be passed in"
             tb = F_.Linear.apply(anchor(x), gelu_t, self.mlp[1])
+        if ops.is_bf(x):
+            return BFS.ConvNextBlockBF.apply(anchor(x), x, tb, self, dest)
         return F_.ConvNextBlockFn.apply(anchor(x), x, tb, self, dest)
 
 
@@ -182,6 +187,16 @@ class Unet(nn.Module):
         self.out_dim = out_dim
         self.final_conv = nn.Sequential(ConvNextBlock(dim, dim), nn.Conv2d(dim, out_dim, 1))
 
+    def _bf16_ok(self):
+        """Every block past the image-side one has channel counts a bf16 feature map can carry (multiples of 8), and the network has the
+        shape the bf16 stream is wired for (at least one up stage: the image-side level's skip is never consumed)."""
+        ok = self.__dict__.get("_bf16_ok_cached")
+        if ok is None:
+            blocks = [b for stage in self.downs for b in stage[:2]][1:] + [self.mid_block1, self.mid_block2] + \
+                     [b for stage in self.ups for b in stage[:2]] + [self.final_conv[0]]
+            ok = self.__dict__["_bf16_ok_cached"] = all(BFS.block_ok(b) for b in blocks) and len(self.downs) >= 2
+        return ok
+
     # -- time embedding: SinusoidalPosEmb -> Linear -> GELU -> Linear, then GELU once for all blocks --
     def _time(self, time, ref):
         if not exists(self.time_mlp):
@@ -213,18 +228,24 @@ class Unet(nn.Module):
                 self.__dict__["_tb_lins"] = [b.mlp[1] for b in self._tb_blocks]
             tbs = dict(zip(map(id, self._tb_blocks), F_.TimeBiasAll.apply(a, gt, self)))
         T = lambda blk: tbs.get(id(blk))
+        # bf16 activation storage ("bf16" arithmetic mode): the stream between blocks, every saved activation and every GEMM input is ONE
+        # bf16 plane from the output of the image-side block to the input of the 3-channel output conv (colddiff/bf16store.py)
+        bfs = BFS.enabled() and _CONCAT_FREE and self._bf16_ok()
+        conv = (lambda *a_: BFS.ConvFnBF.apply(*a_)) if bfs else (lambda *a_: F_.ConvFn.apply(*a_))
         h = []
         for lvl, (convnext, convnext2, attn, downsample) in enumerate(self.downs):
             x = convnext(x, gt, tb=T(convnext))
+            if bfs and lvl == 0:
+                x = BFS.ToBF16.apply(x)
             x = convnext2(x, gt, tb=T(convnext2))
             cat = None
             if _CONCAT_FREE and lvl >= len(self.downs) - nskip:
                 B_, H_, W_, C_ = x.shape
-                cat = F_.CatBuf(x, B_, H_, W_, C_, C_)
+                cat = F_.CatBuf(x, B_, H_, W_, C_, C_, dtype=x.dtype)
             x = attn(x, cat)
             h.append((x, cat))
             if not isinstance(downsample, nn.Identity):
-                x = F_.ConvFn.apply(a, x, downsample, x.shape[-1], "conv", 2, (1, 1, 1, 1))
+                x = conv(a, x, downsample, x.shape[-1], "conv", 2, (1, 1, 1, 1))
 
         x = self.mid_block1(x, gt, tb=T(self.mid_block1))
         x = self.mid_attn(x)
@@ -232,14 +253,19 @@ class Unet(nn.Module):
 
         for j, (convnext, convnext2, attn, upsample) in enumerate(self.ups):
             skip, cat = h.pop()
-            x = F_.Join.apply(x, skip, cat) if cat is not None else F_.Concat.apply(x, skip)
+            if cat is not None:
+                x = (BFS.JoinBF if bfs else F_.Join).apply(x, skip, cat)
+            else:
+                x = F_.Concat.apply(x, skip)
             x = convnext(x, gt, tb=T(convnext))
             x = convnext2(x, gt, tb=T(convnext2))
             x = attn(x)
             if not isinstance(upsample, nn.Identity):
                 nxt = h[-1][1] if j + 1 < len(self.ups) else None      # the next stage's concat buffer takes the upsampled map
-                x = F_.ConvFn.apply(a, x, upsample, x.shape[-1], "convT", 2, (1, 1, 1, 1), nxt)
+                x = conv(a, x, upsample, x.shape[-1], "convT", 2, (1, 1, 1, 1), nxt)
 
         x = self.final_conv[0](x)
+        if bfs:
+            x = BFS.ToF32.apply(x)
         x = F_.ConvFn.apply(a, x, self.final_conv[1], x.shape[-1], "conv", 1, (0, 0, 0, 0))
         return F_.ToNCHW.apply(x, self.out_dim, orig_x.float().contiguous() if self.residual else None)

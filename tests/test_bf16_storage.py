@@ -139,3 +139,110 @@ def test_conv_gemm_bf16x_io_epilogue(be, B, Cin, Cout, H):
         outs.append((pre.cpu(), yh.cpu(), yh2.cpu()))
     assert torch.equal(outs[1][0], rbf(outs[0][0])) and torch.equal(outs[1][1], outs[0][1]) and torch.equal(outs[1][2], outs[0][2])
     assert outs[0][1].float().abs().max() > 0.1
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# network level: the bf16-storage engine against the fp32 oracle, within the mode's stated tolerance (runtime.BF16_TOLERANCE -- the SAME
+# numbers as with fp32 tensors), on the simulator and on the MI355X
+# ---------------------------------------------------------------------------------------------------------------------------------------
+from test_modules import mbe, quiet  # noqa: E402,F401
+
+
+@pytest.fixture
+def bf16_mode():
+    from colddiff import runtime as rt
+    saved = rt.precision
+    rt.set_precision("bf16")
+    rt.bump_weights_epoch()
+    yield
+    rt.set_precision(saved)
+    rt.bump_weights_epoch()
+
+
+def _grad_worst(net, ref):
+    gmax = max(g.abs().max().item() for g in ref.values())
+    worst, name = 0.0, None
+    for n, p in net.named_parameters():
+        r = ref[n]
+        v = (p.grad.cpu() - r).abs().max().item() / max(r.abs().max().item(), 1e-2 * gmax)
+        if v > worst:
+            worst, name = v, n
+    return worst, name
+
+
+@pytest.mark.parametrize("dim,mults,size", [(8, (1, 2), 16), (16, (1, 2, 4), 16)])
+def test_unet_bf16_storage_vs_oracle(mbe, bf16_mode, monkeypatch, dim, mults, size):
+    """Unet forward + backward with every tensor between kernels in bf16: the stream really is bf16 (checked on the blocks' outputs and on
+    what they save), output and every gradient within BF16_TOLERANCE of the fp32 oracle."""
+    from colddiff import bf16store as BFS, ops
+    from colddiff.runtime import BF16_TOLERANCE
+    from deblurring_diffusion_pytorch import Unet
+    from oracle import cold_oracle as O
+    assert BFS.enabled()
+    torch.manual_seed(9)
+    net = quiet(Unet, dim=dim, dim_mults=mults, channels=3)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    x, t = torch.rand(2, 3, size, size) * 2 - 1, torch.tensor([1, 40])
+    gy = torch.randn(2, 3, size, size) / 1000
+    ps = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    yr = O.unet_forward(ps, x, t)
+    yr.backward(gy)
+    net = net.to(mbe.device)
+    seen = {}
+    hooks = [m.register_forward_hook(lambda mod, i, o, n=n: seen.__setitem__(n, (i[0].dtype, o.dtype)))
+             for n, m in net.named_modules() if type(m).__name__ in ("ConvNextBlock", "Residual")]
+    saved_dtypes = set()
+    with torch.autograd.graph.saved_tensors_hooks(lambda t_: (saved_dtypes.add((t_.dtype, t_.dim())), t_)[1], lambda t_: t_):
+        y = net(mbe.to(x), mbe.to(t))
+    for h in hooks:
+        h.remove()
+    y.backward(mbe.to(gy))
+    assert seen["downs.0.0"] == (torch.float32, torch.float32)                    # the image-side block: 4-channel fp32 tensors
+    assert all(v == (torch.bfloat16, torch.bfloat16) for k, v in seen.items() if k != "downs.0.0"), seen
+    assert (torch.bfloat16, 4) in saved_dtypes
+    e = (y.cpu() - yr.detach()).abs().max().item()
+    worst, name = _grad_worst(net, {k: v.grad for k, v in ps.items()})
+    print("bf16 storage", dim, mults, ": forward max-abs error", e, "worst gradient error / scale", worst, name)
+    assert e <= BF16_TOLERANCE["forward_max_abs"] and worst <= BF16_TOLERANCE["grad_rel_of_tensor_max"]
+    # the round 2-4 form of the mode (fp32 tensors, bf16 GEMM operands) is still there for A/B
+    monkeypatch.setenv("COLDDIFF_BF16_STORAGE", "0")
+    assert not BFS.enabled()
+    with torch.no_grad():
+        y0 = net(mbe.to(x), mbe.to(t))
+    assert (y0.cpu() - yr.detach()).abs().max().item() <= BF16_TOLERANCE["forward_max_abs"]
+
+
+def test_trainer_and_sampler_on_the_bf16_stream(mbe, bf16_mode, tmp_path):
+    """Two optimizer steps (fused accumulation, Adam on the fp32 master weights) and a sampler call with the bf16 stream: the loss follows
+    the fp32 oracle's within the mode's loss tolerance and the sampler's output stays within its forward tolerance per call."""
+    from colddiff.runtime import BF16_TOLERANCE
+    from denoising_diffusion_pytorch import GaussianDiffusion, Trainer, Unet
+    from oracle import cold_oracle as O
+    torch.manual_seed(0)
+    net = quiet(Unet, dim=8, dim_mults=(1, 2), channels=3).to(mbe.device)
+    diff = GaussianDiffusion(net, image_size=16, channels=3, timesteps=10, sampling_routine="x0_step_down").to(mbe.device)
+    sd0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    tr = Trainer(diff, None, image_size=16, train_batch_size=2, train_lr=2e-5, train_num_steps=2, gradient_accumulate_every=2,
+                 dataset="synthetic", results_folder=str(tmp_path / "res"))
+    g = torch.Generator().manual_seed(1)
+    batches = [[(torch.rand(2, 3, 16, 16, generator=g) * 2 - 1, torch.randn(2, 3, 16, 16, generator=g), torch.randint(0, 10, (2,), generator=g))
+                for _ in range(2)] for _ in range(2)]
+    ca, cb = O.cosine_tables(10)
+    otr = O.OracleTrainer(sd0, lambda p, x, e, t: O.loss_fn(x, O.unet_forward(p, O.noise_q_sample(x, e, t, ca, cb), t)), lr=2e-5, accumulate=2)
+    for s in range(2):
+        it = iter(batches[s])
+
+        def micro(it=it):
+            x, e, t = (mbe.to(v) for v in next(it))
+            return tr.core.prepare(x, e, t=t)
+        tr._prepare_micro = micro
+        loss = tr.train_step()
+        tr.step += 1
+        lo = otr.train_step(batches[s])
+        assert abs(loss.item() - lo) <= 5 * BF16_TOLERANCE["loss_rel"] * abs(lo), (loss.item(), lo)       # (a dim-8 net at 16 x 16: few terms)
+    noise = torch.randn(2, 3, 16, 16)
+    with torch.no_grad():
+        _, direct, _ = quiet(diff.gen_sample, batch_size=2, img=mbe.to(noise))
+        sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        rdirect = O.unet_forward(sd, noise, torch.full((2,), 9))
+    assert (direct.cpu() - rdirect).abs().max().item() <= BF16_TOLERANCE["forward_max_abs"]
