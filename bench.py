@@ -640,19 +640,24 @@ def main():
                         sample_bf16 = round(1000 * (time.perf_counter() - ts) / args.sample_batch, 2)
                 runtime.set_precision("bf16x3")
                 runtime.bump_weights_epoch()
+                from colddiff import bf16store
+                stored_bf16 = bf16store.enabled_for(model)
                 out["bf16_mode"] = {"value": round(args.batch * args.accum / dtb, 2), "unit": "img/s", "ms_per_step": round(1000 * dtb, 3),
-                                    "dtype": "bf16 GEMM operands (one MFMA per product), fp32 accumulate / master weights / norms / softmax / "
-                                             "degradation / optimizer; bf16 planes are the only stored form of LN and GELU outputs; the residual "
-                                             "stream, depthwise outputs and pre-activations stay fp32",
+                                    "dtype": "bf16 GEMM operands (one MFMA per product) AND bf16 activation storage: one bf16 plane is the only stored form of "
+                                             "every GEMM input, every activation saved for backward and the inter-block residual stream in both directions "
+                                             "(colddiff/bf16store.py); fp32: accumulators, norm statistics, softmax / context, the image-side block's "
+                                             "4-channel tensors, time biases, master weights, parameter gradients, degradation, loss, optimizer"
+                                             if stored_bf16 else
+                                             "bf16 GEMM operands (one MFMA per product), fp32 accumulate / master weights / norms / softmax / degradation / "
+                                             "optimizer; fp32 tensors between kernels (COLDDIFF_BF16_STORAGE=0: the round 2-4 form of the mode)",
+                                    "activation_storage": "bf16" if stored_bf16 else "f32",
                                     "tolerance_vs_fp32_oracle": dict(runtime.BF16_TOLERANCE, asserted_by="tests/test_gpu_parity2.py::"
-                                                                     "test_other_precision_modes_module_level[bf16] and ::test_bf16_mode_bench_shape_microstep"),
+                                                                     "test_other_precision_modes_module_level[bf16] and ::test_bf16_mode_bench_shape_fused_step "
+                                                                     "(the fused 64-image pass), tests/test_bf16_storage.py"),
                                     "sample_ms_per_img_200step": sample_bf16, "sample_batch": args.sample_batch,
-                                    # the engine AS BUILT keeps the residual stream, the depthwise output and the pre-activations in fp32
-                                    # (bf16 are the GEMM operand planes): its layer-boundary bytes are the fp32 figure; what SURVEY 8(d)'s bf16
-                                    # column would give is printed beside it, labelled as not built (the accounting must describe
-                                    # the engine that exists)
-                                    "step_roofline": step_roofline(args.batch, args.accum, 1000 * dtb, 1, act="f32"),
-                                    "step_roofline_if_bf16_activation_storage_NOT_BUILT": step_roofline(args.batch, args.accum, 1000 * dtb, 1, act="bf16")}
+                                    # the accounting describes the engine that runs: SURVEY 8(d)'s bf16 column (A_train = 549 MB / image) now that the
+                                    # tensors between kernels ARE bf16
+                                    "step_roofline": step_roofline(args.batch, args.accum, 1000 * dtb, 1, act="bf16" if stored_bf16 else "f32")}
                 mbb = measured_bytes_step("pmc_traffic_bf16.json")
                 if mbb:
                     out["bf16_mode"]["step_roofline"]["measured_hbm_bytes_step"] = mbb["bytes_step"]

@@ -31,6 +31,11 @@ def enabled():
     return rt.precision == "bf16" and os.environ.get("COLDDIFF_BF16_STORAGE", "1") != "0"
 
 
+def enabled_for(net):
+    """Does this Unet's forward run the bf16 stream right now (mode on and every block's channel counts legal)?"""
+    return enabled() and hasattr(net, "_bf16_ok") and net._bf16_ok()
+
+
 def block_ok(m):
     """A ConvNeXt block whose every tensor is a legal bf16 feature map (channel counts in multiples of 8)."""
     return m.dim % 8 == 0 and m.dim_out % 8 == 0 and m.net[1].weight.shape[0] % 8 == 0
@@ -217,27 +222,29 @@ def _attn_forward(ctx, x, m, dest):
     xn, mean, rstd = ops.layernorm_fwd_bf(x, norm.g, norm.b, norm.eps, grad_on, out_f32=True)
     ctx.m = m
     _used(ctx, norm, att.to_qkv, att.to_out)
-    xf = ops.to_f32(x)                                          # residual operand of the fp32 output product
-    ctx.qfold = dim % 4 == 0 and dim <= att.heads * 32 and att.heads <= 4 and F_._ATTN_FUSED >= 1 and F_._ATTN_QFOLD
+    ctx.qfold = dim % 8 == 0 and dim <= att.heads * 32 and att.heads <= 4 and F_._ATTN_FUSED >= 1 and F_._ATTN_QFOLD
     if ctx.qfold:
+        # (the 128- and 64-pixel levels of the CelebA net: 80 % of the attention bytes) the output product reads the residual from the bf16
+        # stream and writes its result into it (cdf_conv_gemm_io): x and y cross the boundary once each, as bf16
         if F_._ATTN_KVCTX and ops.linattn_kvctx_ok(xn, dim, att.heads):
             kv, cx, cxs, kmax, ksum = ops.linattn_kvctx(xn, dim, att.to_qkv.weight, att.heads, att.scale)
         else:
             kv = F_.kv_forward(xn, dim, att.to_qkv.weight)
             cx, cxs, kmax, ksum = ops.linattn_context(kv, att.heads, att.scale, koff=0)
-        y, Mb, Nb = ops.linattn_fold(xn, cxs, att.to_qkv.weight, att.to_out.weight, att.to_out.bias, xf, att.heads)
-        saved = (x, xn, mean, rstd, kv, Mb, cx, cxs, kmax, ksum, Nb)
+        yb, Mb, Nb = ops.linattn_fold(xn, cxs, att.to_qkv.weight, att.to_out.weight, att.to_out.bias, x, att.heads,
+                                      y=dest.second() if dest is not None else None)
+        return yb, (x, xn, mean, rstd, kv, Mb, cx, cxs, kmax, ksum, Nb)
+    xf = ops.to_f32(x)                                          # (deeper levels: the plain forms keep an fp32 residual operand)
+    qkv = F_.conv_forward(xn, dim, att.to_qkv.weight, None)
+    ctx.fused = dim % 4 == 0 and (F_._ATTN_FUSED == 2 or (F_._ATTN_FUSED == 1 and dim <= att.heads * 32))
+    if ctx.fused:
+        cx, cxs, kmax, ksum = ops.linattn_context(qkv, att.heads, att.scale)
+        y, Mb = ops.linattn_project(qkv, cxs, att.to_out.weight, att.to_out.bias, xf, att.heads)
+        saved = (x, xn, mean, rstd, qkv, Mb, cx, cxs, kmax, ksum)
     else:
-        qkv = F_.conv_forward(xn, dim, att.to_qkv.weight, None)
-        ctx.fused = dim % 4 == 0 and (F_._ATTN_FUSED == 2 or (F_._ATTN_FUSED == 1 and dim <= att.heads * 32))
-        if ctx.fused:
-            cx, cxs, kmax, ksum = ops.linattn_context(qkv, att.heads, att.scale)
-            y, Mb = ops.linattn_project(qkv, cxs, att.to_out.weight, att.to_out.bias, xf, att.heads)
-            saved = (x, xn, mean, rstd, qkv, Mb, cx, cxs, kmax, ksum)
-        else:
-            o, cx, cxs, kmax, ksum = ops.linattn_fwd(qkv, att.heads, att.scale)
-            y = F_.conv_forward(o, att.heads * 32, att.to_out.weight, att.to_out.bias, res=xf)
-            saved = (x, xn, mean, rstd, qkv, o, cx, cxs, kmax, ksum)
+        o, cx, cxs, kmax, ksum = ops.linattn_fwd(qkv, att.heads, att.scale)
+        y = F_.conv_forward(o, att.heads * 32, att.to_out.weight, att.to_out.bias, res=xf)
+        saved = (x, xn, mean, rstd, qkv, o, cx, cxs, kmax, ksum)
     yb = ops.to_bf16(y[..., :dim] if y.shape[-1] != dim else y, dest.second() if dest is not None else None)
     return yb, saved
 

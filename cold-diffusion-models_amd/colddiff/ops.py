@@ -680,6 +680,14 @@ def linattn_fold(xn, ctxs, w_qkv, w_out, b_out, res, heads, y=None):
     Nb = torch.empty((B, dim, ldw), device=xn.device, dtype=torch.float32)
     L.cdf_conv_gemm(P(wq), wq.shape[-1], P(Mb), ldw, P(Nb), ldw, 1, 1, dim, HD, 1, dim, dim, 1, dim, 1, 1, 1, _one_tap(dim).desc,
                     0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, B, 0, HD * ldw, dim * ldw, 1, 0, 0, 0, S)
+    if is_bf(res):
+        # bf16 activation storage: the residual is read from the bf16 stream and the result enters it rounded once -- no fp32 copy of either
+        if y is None:
+            y = new_bf(xn, B, H, W, dim)
+        ldx, ldy = ld_of(xn), ld_of(y)
+        L.cdf_conv_gemm_io(P(xn), ldx, P(Nb), ldw, 0, ldy, 1, 1, n, dim, 1, n, dim, 1, n, 1, 1, 1, _one_tap(n).desc,
+                           P(b_out), 0, 0, P(res), ld_of(res), 0, 0, 0, 0, 0, 0, 0, 0, B, n * ldx, dim * ldw, n * ldy, 1, 0, 0, 0, IO_RES, P(y), ldy, S)
+        return y, Mb, Nb
     if y is None:
         y = new_feat(xn, B, H, W, dim)
     ldx, ldy = ld_of(xn), ld_of(y)

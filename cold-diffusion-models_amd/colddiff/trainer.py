@@ -303,7 +303,19 @@ class Trainer(EvalMixin):
 
     # -- EMA / checkpoint --------------------------------------------------------------------------------
     def reset_parameters(self):
-        self.ema_model.load_state_dict(self.model.state_dict())
+        """ema_model.load_state_dict(model.state_dict()) (DEBLUR:1131-1132; every `update_ema_every`-th step until step_start_ema): the
+        parameters live in two flat arenas of one layout, so they are ONE device copy instead of one per tensor (238 for the CelebA net);
+        buffers go through load_state_dict's own path."""
+        a, e = getattr(self, "arena", None), getattr(self, "ema_arena", None)
+        if a is not None and e is not None and a.numel == e.numel and a.offsets == e.offsets and a.intact() and e.intact():
+            e.data.copy_(a.data)
+            bufs = dict(self.model.named_buffers())
+            with torch.no_grad():
+                for name, b in self.ema_model.named_buffers():
+                    if name in bufs and b.data_ptr() != bufs[name].data_ptr():
+                        b.copy_(bufs[name])
+        else:
+            self.ema_model.load_state_dict(self.model.state_dict())
         rt.bump_weights_epoch()
 
     def step_ema(self):

@@ -680,15 +680,45 @@ static int launch_conv(const ConvArgs& a, int batch, bool bt, hipStream_t s) {
 }
 
 // Generic gather-GEMM.  taps: int array [nphase][1 + 2 + 3*ntaps_max]... see colddiff.h
+extern "C" int cdf_conv_gemm_io(const float* x, int ldx, const float* w, int ldw, float* y, int ldy, int B, int H, int W,
+                                int Cin, int OH, int OW, int Cout, int QH, int QW, int os, int is, int nphase,
+                                const int* phase_desc, const float* bias, const float* sbias, int ld_sbias,
+                                const void* res, int ldr, void* pre, int ldp, const void* mul, int ldm, int act,
+                                int mul_mode, int accumulate, int b_trans, int batch, long long x_bs, long long w_bs,
+                                long long y_bs, int batch2, long long x_bs2, long long w_bs2, long long y_bs2, int io_bf16, void* y_hi,
+                                int ld_ys, void* stream);
+
 extern "C" int cdf_conv_gemm(const float* x, int ldx, const float* w, int ldw, float* y, int ldy, int B, int H, int W,
                              int Cin, int OH, int OW, int Cout, int QH, int QW, int os, int is, int nphase,
                              const int* phase_desc, const float* bias, const float* sbias, int ld_sbias,
                              const float* res, int ldr, float* pre, int ldp, const float* mul, int ldm, int act,
                              int mul_mode, int accumulate, int b_trans, int batch, long long x_bs, long long w_bs,
                              long long y_bs, int batch2, long long x_bs2, long long w_bs2, long long y_bs2, void* stream) {
+    return cdf_conv_gemm_io(x, ldx, w, ldw, y, ldy, B, H, W, Cin, OH, OW, Cout, QH, QW, os, is, nphase, phase_desc, bias, sbias, ld_sbias, res, ldr,
+                            pre, ldp, mul, ldm, act, mul_mode, accumulate, b_trans, batch, x_bs, w_bs, y_bs, batch2, x_bs2, w_bs2, y_bs2, 0, nullptr, 0,
+                            stream);
+}
+
+// ... with typed epilogue operands (io_bf16: CDF_IO_RES_BF16 | CDF_IO_PRE_BF16 | CDF_IO_MUL_BF16) and an optional bf16 output plane y_hi
+// (pitch ld_ys; with it y may be NULL: bf16 activation storage -- the fp32 product's result enters the bf16 stream rounded once, no fp32
+// copy).  A batched launch without a y needs the row-offset addressing (an epilogue operand, outputs that are whole rows of one tensor:
+// ldy / y_bs / y_bs2 then only describe the row offsets).
+extern "C" int cdf_conv_gemm_io(const float* x, int ldx, const float* w, int ldw, float* y, int ldy, int B, int H, int W,
+                                int Cin, int OH, int OW, int Cout, int QH, int QW, int os, int is, int nphase,
+                                const int* phase_desc, const float* bias, const float* sbias, int ld_sbias,
+                                const void* res_, int ldr, void* pre_, int ldp, const void* mul_, int ldm, int act,
+                                int mul_mode, int accumulate, int b_trans, int batch, long long x_bs, long long w_bs,
+                                long long y_bs, int batch2, long long x_bs2, long long w_bs2, long long y_bs2, int io_bf16, void* y_hi,
+                                int ld_ys, void* stream) {
+    const float* res = (const float*)res_;
+    float* pre = (float*)pre_;
+    const float* mul = (const float*)mul_;
     int rc;
+    CDF_REQUIRE((io_bf16 & ~7) == 0, "cdf_conv_gemm_io: io_bf16 has unknown bits (%d)", io_bf16);
+    CDF_REQUIRE(y || (y_hi && !accumulate), "cdf_conv_gemm_io: no output (y NULL needs y_hi and no accumulate)");
+    CDF_REQUIRE(!y_hi || (ld_ys % 4 == 0 && ld_ys >= Cout && Cout % 4 == 0 && (((uintptr_t)y_hi) & 7) == 0), "cdf_conv_gemm_io: the output plane needs Cout %% 4 == 0, ld_ys %% 4 == 0, 8-byte alignment");
     if ((rc = check_feat("cdf_conv_gemm(x)", x, ldx, Cin))) return rc;
-    if ((rc = check_feat("cdf_conv_gemm(y)", y, 4, 0))) return rc;
+    if (y && (rc = check_feat("cdf_conv_gemm(y)", y, 4, 0))) return rc;
     CDF_REQUIRE(w && (((uintptr_t)w) & 15) == 0 && ldw % 4 == 0, "cdf_conv_gemm: weights must be 16B aligned, ldw%%4==0");
     CDF_REQUIRE(ldy >= Cout, "cdf_conv_gemm: ldy < Cout");
     CDF_REQUIRE(nphase >= 1 && nphase <= 4 && phase_desc, "cdf_conv_gemm: nphase must be 1..4");
@@ -709,7 +739,9 @@ extern "C" int cdf_conv_gemm(const float* x, int ldx, const float* w, int ldw, f
                     "of y (y_bs and y_bs2 multiples of ldy) and no per-sample bias");
         a.epi_follow = 1;
     }
-    a.ys_hi = nullptr; a.ys_lo = nullptr; a.ld_ys = 0; a.io_bf = 0;
+    a.ys_hi = (unsigned short*)y_hi; a.ys_lo = nullptr; a.ld_ys = ld_ys; a.io_bf = io_bf16;
+    CDF_REQUIRE((!y_hi && !io_bf16) || a.vec, "cdf_conv_gemm_io: bf16 operands / the output plane need the vectorised epilogue (16-byte-aligned pointers, pitches %% 4, Cout %% 4)");
+    CDF_REQUIRE(y || (long long)batch * batch2 == 1 || a.epi_follow, "cdf_conv_gemm_io: a batched launch without y needs an epilogue operand (row-offset addressing)");
     batch *= batch2;
     // phase_desc: per phase [oy, ox, ntaps, (dy, dx, wi) * ntaps]
     const int* pd = phase_desc;

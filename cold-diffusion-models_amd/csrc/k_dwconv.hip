@@ -62,12 +62,15 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const void* x, int ldx,
     // (rocprofv3 FETCH_SIZE: 2.3x the tensor); an XCD now walks a contiguous run of tiles of one channel group (its 64 resident
     // blocks = one 128 x 128 image).
     const int vid = cdf_xcd_order(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
-    int t = vid % (int)gridDim.x;
+    // bf16 tensors: a block's 32 channels are HALF a 128-byte line of a 64-channel pixel, and a half-line read costs the whole line
+    // (profiles/round3_fetch_half_lines.md) -- PMC: 3.0x the tensor fetched.  The channel group is therefore the FAST index there: the
+    // blocks that read the two halves of a line are neighbours in an XCD's run and the second one finds the line in that XCD's L2.
+    int t = BF ? vid / (int)gridDim.y : vid % (int)gridDim.x;
+    const int cq0 = (BF ? vid % (int)gridDim.y : vid / (int)gridDim.x) * 8;
     const int bx = t % tiles_w;
     t /= tiles_w;
     const int by = t % tiles_h, b = t / tiles_h;
     const int X0 = bx * TBW, Y0 = by * TBH;
-    const int cq0 = (vid / (int)gridDim.x) * 8;
 
     for (int i = tid; i < DW_TAPS * 8; i += 256) {
         const int tp = i >> 3, l = i & 7;

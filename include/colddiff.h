@@ -226,6 +226,15 @@ int cdf_conv_gemm_bf16x_io(const void* x_hi, const void* x_lo, int ldx, const vo
                            int ldr, void* pre, int ldp, const void* mul, int ldm, int act, int mul_mode, int accumulate, int io_bf16,
                            void* y_hi, void* y_lo, int ld_ys, float* ws, long long ws_floats, const cdf_gemm_tuning* tune, void* stream);
 int cdf_bf16_to_f32(const void* x, int ldx, float* y, int ldy, long long rows, int C, void* stream);
+/* cdf_conv_gemm_io: the exact-fp32 GEMM (cdf_conv_gemm) with typed epilogue operands (same io_bf16 bits) and an optional bf16 output plane
+ * y_hi (pitch ld_ys; y may then be NULL): how the fp32 inside of the linear-attention block reads the bf16 stream as its residual and
+ * writes its result into it.  A batched launch without y needs an epilogue operand (outputs that are whole rows of one tensor). */
+int cdf_conv_gemm_io(const float* x, int ldx, const float* w, int ldw, float* y, int ldy, int B, int H, int W, int Cin,
+                     int OH, int OW, int Cout, int QH, int QW, int os, int is, int nphase, const int* phase_desc,
+                     const float* bias, const float* sbias, int ld_sbias, const void* res, int ldr, void* pre, int ldp,
+                     const void* mul, int ldm, int act, int mul_mode, int accumulate, int b_trans, int batch,
+                     long long x_bs, long long w_bs, long long y_bs, int batch2, long long x_bs2, long long w_bs2,
+                     long long y_bs2, int io_bf16, void* y_hi, int ld_ys, void* stream);
 /* cdf_conv_wgrad_bf16x_is_row3 tells the caller whether a geometry takes the row-of-taps kernel (3 tap blocks per tile, one 512-thread
  * block per CU) so that it can size nsplit. */
 int cdf_conv_wgrad_bf16x_is_row3(int QH, int QW, int CA, int CB, int ntaps, int same_size_3x3, const cdf_gemm_tuning* tune);
