@@ -159,7 +159,7 @@ class ConvNextBlockBF(torch.autograd.Function):
         else:
             hn, mean, rstd = h, None, None
         pre = ops.new_bf(x, B, H, W, mid) if grad_on else None
-        a = conv_fwd(hn, dim, c1.weight, c1.bias, act=ACT_GELU, pre=pre)
+        a = conv_fwd(hn, dim, c1.weight, c1.bias, act=ACT_GELU, pre=pre, pre_grad=pre is not None and F_._PRE_GRAD)   # pre = GELU'(v)
         res = conv_fwd(x, dim, m.res_conv.weight, m.res_conv.bias) if m.has_res_conv else x
         o = conv_fwd(a, mid, c2.weight, c2.bias, res=res, **({"y": dest.first()} if dest is not None else {}))
         ctx.m = m
@@ -182,7 +182,7 @@ class ConvNextBlockBF(torch.autograd.Function):
         if do.stride(-1) != 1:
             do = do.contiguous()
         dx = conv_bwd(x, dim, do, m.res_conv.weight, m.res_conv.bias, need_dx=need_dx) if m.has_res_conv else None
-        dpre = conv_bwd(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=1)            # conv2 -> (fused GELU')
+        dpre = conv_bwd(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=3 if F_._PRE_GRAD else 1)      # conv2 -> (x the stored GELU')
         dhn = conv_bwd(hn, dim, dpre, c1.weight, c1.bias)
         dh = ops.layernorm_bwd_bf(dhn, h, m.net[0].g, m.net[0].b, mean, rstd) if m.has_norm else dhn
         dsb_out = ctx.tslot[0].view(ctx.tslot[1], x.shape[-1]) if ctx.tslot is not None else None
@@ -219,10 +219,14 @@ def _attn_forward(ctx, x, m, dest):
     norm, att = m.fn.norm, m.fn.fn
     dim = x.shape[-1]
     grad_on = ctx.needs_input_grad[0]
-    xn, mean, rstd = ops.layernorm_fwd_bf(x, norm.g, norm.b, norm.eps, grad_on, out_f32=True)
+    ctx.qfold = dim % 8 == 0 and dim <= att.heads * 32 and att.heads <= 4 and F_._ATTN_FUSED >= 1 and F_._ATTN_QFOLD
+    ctx.kv_planes = bool(grad_on and ctx.qfold and F_.kv_planes_ok(x, dim, att.heads))     # k | v backward on operand planes (functions.py)
+    if ctx.kv_planes:
+        xn, mean, rstd, xnb = ops.layernorm_fwd_bf(x, norm.g, norm.b, norm.eps, grad_on, out_f32=True, planes=True)
+    else:
+        (xn, mean, rstd), xnb = ops.layernorm_fwd_bf(x, norm.g, norm.b, norm.eps, grad_on, out_f32=True), None
     ctx.m = m
     _used(ctx, norm, att.to_qkv, att.to_out)
-    ctx.qfold = dim % 8 == 0 and dim <= att.heads * 32 and att.heads <= 4 and F_._ATTN_FUSED >= 1 and F_._ATTN_QFOLD
     if ctx.qfold:
         # (the 128- and 64-pixel levels of the CelebA net: 80 % of the attention bytes) the output product reads the residual from the bf16
         # stream and writes its result into it (cdf_conv_gemm_io): x and y cross the boundary once each, as bf16
@@ -233,7 +237,7 @@ def _attn_forward(ctx, x, m, dest):
             cx, cxs, kmax, ksum = ops.linattn_context(kv, att.heads, att.scale, koff=0)
         yb, Mb, Nb = ops.linattn_fold(xn, cxs, att.to_qkv.weight, att.to_out.weight, att.to_out.bias, x, att.heads,
                                       y=dest.second() if dest is not None else None)
-        return yb, (x, xn, mean, rstd, kv, Mb, cx, cxs, kmax, ksum, Nb)
+        return yb, (x, xn, mean, rstd, kv, Mb, cx, cxs, kmax, ksum, Nb, xnb)
     xf = ops.to_f32(x)                                          # (deeper levels: the plain forms keep an fp32 residual operand)
     qkv = F_.conv_forward(xn, dim, att.to_qkv.weight, None)
     ctx.fused = dim % 4 == 0 and (F_._ATTN_FUSED == 2 or (F_._ATTN_FUSED == 1 and dim <= att.heads * 32))
@@ -255,12 +259,18 @@ def _attn_backward(ctx, dy):
         dy = dy.contiguous()
     dyf = ops.to_f32(dy)
     if ctx.qfold:
-        x, xn, mean, rstd, kv, Mb, cx, cxs, kmax, ksum, Nb = ctx.saved_tensors
+        x, xn, mean, rstd, kv, Mb, cx, cxs, kmax, ksum, Nb, xnb = ctx.saved_tensors
         dim = x.shape[-1]
         dxn, dctx, rvec = ops.linattn_fold_bwd(xn, dyf, Mb, Nb, cx, cxs, att.to_qkv.weight, att.to_out.weight, att.to_out.bias, att.heads, att.scale)
-        dkv = torch.empty(kv.shape, device=kv.device, dtype=torch.float32)
-        ops.linattn_bwd_core(kv, dctx, rvec, kmax, ksum, dkv, att.heads, koff=0)
-        F_.kv_backward(xn, dim, dkv, att.to_qkv.weight, dxn)
+        if ctx.kv_planes:
+            B_, H_, W_, C2 = kv.shape
+            dkv_s = (ops.new_bf(kv, B_, H_, W_, C2), None)
+            ops.linattn_bwd_core(kv, dctx, rvec, kmax, ksum, None, att.heads, koff=0, planes=dkv_s)
+            F_.kv_backward_planes(xn, (xnb, None), dim, dkv_s, att.to_qkv.weight, dxn)
+        else:
+            dkv = torch.empty(kv.shape, device=kv.device, dtype=torch.float32)
+            ops.linattn_bwd_core(kv, dctx, rvec, kmax, ksum, dkv, att.heads, koff=0)
+            F_.kv_backward(xn, dim, dkv, att.to_qkv.weight, dxn)
     else:
         x, xn, mean, rstd, qkv, o, cx, cxs, kmax, ksum = ctx.saved_tensors
         dim, HD = x.shape[-1], att.heads * 32

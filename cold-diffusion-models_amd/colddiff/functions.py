@@ -80,6 +80,7 @@ _ALWAYS_PRESPLIT = os.environ.get("CDF_ALWAYS_PRESPLIT", "0") != "0"
 _PRESPLIT_1X1 = os.environ.get("CDF_PRESPLIT_1X1", "0") != "0"
 _AUTO_PRESPLIT = os.environ.get("CDF_AUTO_PRESPLIT", "1") != "0"
 _SP_KMIN = int(os.environ.get("CDF_SP_KMIN", "64"))     # tuning knob: smallest K routed to the bf16 matrix cores
+_PRE_GRAD = os.environ.get("CDF_PRE_GRAD", "0") != "0"  # conv1's epilogue stores GELU'(pre) (same erf / exp evaluation as GELU); conv2's data gradient multiplies by it
 
 
 def _sp_suffix(K, N):
@@ -431,13 +432,17 @@ class ConvNextBlockFn(torch.autograd.Function):
         pre = ops.new_feat(x, B, H, W, mid) if grad_on else None
         # image-side block (dim <= 4 input channels): direct vector-ALU convolutions instead of K <= 36 GEMMs
         ctx.cin4 = _CIN4 and ops.cin4_ok(hn, dim, c1.weight) and ops.cin4_ok(x, dim, c1.weight)
+        ctx.pre_grad = False
         if ctx.cin4:
             if sp2:
                 a, a_s = ops.conv_cin4_fwd(hn, c1.weight, c1.bias, act=ACT_GELU, pre=pre, split_out=True, planes_only=lean)
             else:
                 a, a_s = ops.conv_cin4_fwd(hn, c1.weight, c1.bias, act=ACT_GELU, pre=pre), None
         elif sp2:
-            a, a_s = conv_forward(hn, dim, c1.weight, c1.bias, act=ACT_GELU, pre=pre, xs=hn_s, split_out=True, planes_only=lean)
+            # (pre-split path: the epilogue can hand back GELU'(v) in place of the pre-activation -- bit-identical to evaluating it in backward)
+            ctx.pre_grad = bool(_PRE_GRAD and grad_on and hn_s is not None and _sp_suffix(dim * 9, mid))
+            a, a_s = conv_forward(hn, dim, c1.weight, c1.bias, act=ACT_GELU, pre=pre, xs=hn_s, split_out=True, planes_only=lean,
+                                  **({"pre_grad": True} if ctx.pre_grad else {}))
         else:
             a, a_s = conv_forward(hn, dim, c1.weight, c1.bias, act=ACT_GELU, pre=pre, xs=hn_s), None
         ctx.res4 = bool(m.has_res_conv and _CIN4 and ops.cin4_ok(x, dim, m.res_conv.weight))
@@ -479,10 +484,10 @@ class ConvNextBlockFn(torch.autograd.Function):
         do_s = ops.split_bf16(do) if a_s is not None else None
         if hn_s is not None:
             lean = _LEAN and a_s is not None and a.shape[0] * a.shape[1] * a.shape[2] >= ops.WGRAD_SP_MIN_M
-            dpre, dpre_s = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=1, xs=a_s, dys=do_s, split_dx=True,
+            dpre, dpre_s = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=3 if ctx.pre_grad else 1, xs=a_s, dys=do_s, split_dx=True,
                                          planes_only=lean)
         else:
-            dpre, dpre_s = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=1, xs=a_s, dys=do_s), None
+            dpre, dpre_s = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=3 if ctx.pre_grad else 1, xs=a_s, dys=do_s), None
         if ctx.cin4:
             # weight / bias gradient by the direct kernel (reads dpre once); the data gradient in two stages (sum over the mid
             # channels per pixel as a 1x1 GEMM, then the nine shifted 3-vectors: ops.conv_cin_dgrad2) instead of a K = 9 mid
@@ -527,6 +532,26 @@ def kv_backward(xn, dim, dkv, w_qkv, dxn):
     return ops.conv_gemm(pd, dkv, 2 * HD, ops.packed(w_qkv, "kv_dgrad" + _sp_suffix(2 * HD, dim)), dim, y=dxn, accumulate=1)
 
 
+def kv_planes_ok(xn, dim, heads):
+    """The k | v projection's backward runs on pre-split operand planes: dk | dv leave the attention backward kernel AS bf16 hi / lo planes
+    (same bytes as fp32) and LayerNorm's output is kept as planes too, so the data gradient (K = 2 HD = 256 -> dim) and the weight
+    gradient are the LDS-DMA plane GEMMs instead of the in-kernel-split / exact-fp32 kernels reading 1 GB of fp32 dk | dv each at
+    128 x 128 (0.53 + 0.41 ms per step there)."""
+    B, H, W, _ = xn.shape
+    return (_KV_PLANES and rt.precision != "f32" and heads <= 4 and dim % 8 == 0 and dim >= 64 and B * H * W >= ops.WGRAD_SP_MIN_M
+            and xn.device.type != "meta")
+
+
+def kv_backward_planes(xn, xn_s, dim, dkv_s, w_qkv, dxn):
+    """kv_backward with both operands as bf16 planes: rows HD .. 3 HD of to_qkv.weight.grad += dkv^T xn;  dxn += dkv . Wkv."""
+    HD = w_qkv.shape[0] // 3
+    B, H, W, _ = xn.shape
+    _, pd, pw = _conv_plans("conv", H, W, 1, 1, (0, 0, 0, 0))
+    ops.wgrad_into(ops.grad_of(w_qkv)[HD:], pw, xn, dim, ops.shape_only(B, H, W, 2 * HD), 2 * HD, 1, 1, dim, xa_s=xn_s, xb_s=dkv_s)
+    return ops.conv_gemm_presplit(pd, dkv_s, 2 * HD, ops.packed(w_qkv, "kv_dgrad_sp"), dim, y=dxn, accumulate=1)
+
+
+_KV_PLANES = os.environ.get("CDF_KV_PLANES", "1") != "0"
 _ATTN_QFOLD = os.environ.get("CDF_ATTN_QFOLD", "1") != "0"   # q projection folded into the attention product too (dim <= heads*32)
 _ATTN_KVCTX = os.environ.get("CDF_ATTN_KVCTX", "1") != "0"   # ... with the k|v projection and the context in one kernel (ops.linattn_kvctx)
 
@@ -540,7 +565,13 @@ class LinAttnBlockFn(torch.autograd.Function):
         dim = x.shape[-1]
         grad_on = ctx.needs_input_grad[0]   # anchor: True iff autograd is recording
         ydst = {"y": dest.second()} if dest is not None else {}      # skip tensor: produced in place in its concat buffer (CatBuf)
-        xn, mean, rstd = ops.layernorm_fwd(x, norm.g, norm.b, norm.eps, grad_on)
+        ctx.qfold_possible = dim % 4 == 0 and _ATTN_FUSED >= 1 and _ATTN_QFOLD and dim <= att.heads * 32 and att.heads <= 4
+        ctx.kv_planes = bool(grad_on and ctx.qfold_possible and kv_planes_ok(x, dim, att.heads))
+        xn_s = None
+        if ctx.kv_planes:
+            xn, mean, rstd, xn_s = ops.layernorm_fwd(x, norm.g, norm.b, norm.eps, grad_on, split_out=True)
+        else:
+            xn, mean, rstd = ops.layernorm_fwd(x, norm.g, norm.b, norm.eps, grad_on)
         ctx.m = m
         _used(ctx, norm, att.to_qkv, att.to_out)
         # to_out folded into the attention product where that shrinks the batched GEMMs (dim <= heads*32: the 128- and 64-pixel
@@ -556,7 +587,7 @@ class LinAttnBlockFn(torch.autograd.Function):
                 kv = kv_forward(xn, dim, att.to_qkv.weight)
                 cx, cxs, kmax, ksum = ops.linattn_context(kv, att.heads, att.scale, koff=0)
             y, Mb, Nb = ops.linattn_fold(xn, cxs, att.to_qkv.weight, att.to_out.weight, att.to_out.bias, x, att.heads, **ydst)
-            ctx.save_for_backward(x, xn, mean, rstd, kv, Mb, cx, cxs, kmax, ksum, Nb)
+            ctx.save_for_backward(x, xn, mean, rstd, kv, Mb, cx, cxs, kmax, ksum, Nb, *(xn_s or (None, None)))
             return y
         qkv = conv_forward(xn, dim, att.to_qkv.weight, None)
         if ctx.fused:
@@ -574,13 +605,19 @@ class LinAttnBlockFn(torch.autograd.Function):
     def backward(ctx, dy):
         norm, att = ctx.m.fn.norm, ctx.m.fn.fn
         if ctx.qfold:
-            x, xn, mean, rstd, kv, Mb, cx, cxs, kmax, ksum, Nb = ctx.saved_tensors
+            x, xn, mean, rstd, kv, Mb, cx, cxs, kmax, ksum, Nb, xn_hi, xn_lo = ctx.saved_tensors
             dim = x.shape[-1]
             dxn, dctx, rvec = ops.linattn_fold_bwd(xn, dy, Mb, Nb, cx, cxs, att.to_qkv.weight, att.to_out.weight, att.to_out.bias,
                                                    att.heads, att.scale)
-            dkv = torch.empty(kv.shape, device=kv.device, dtype=torch.float32)
-            ops.linattn_bwd_core(kv, dctx, rvec, kmax, ksum, dkv, att.heads, koff=0)
-            kv_backward(xn, dim, dkv, att.to_qkv.weight, dxn)
+            if ctx.kv_planes:
+                B_, H_, W_, C2 = kv.shape
+                dkv_s = ops.split_planes_like(kv, B_, H_, W_, C2)
+                ops.linattn_bwd_core(kv, dctx, rvec, kmax, ksum, None, att.heads, koff=0, planes=dkv_s)
+                kv_backward_planes(xn, (xn_hi, xn_lo), dim, dkv_s, att.to_qkv.weight, dxn)
+            else:
+                dkv = torch.empty(kv.shape, device=kv.device, dtype=torch.float32)
+                ops.linattn_bwd_core(kv, dctx, rvec, kmax, ksum, dkv, att.heads, koff=0)
+                kv_backward(xn, dim, dkv, att.to_qkv.weight, dxn)
             dx = ops.layernorm_bwd(dxn, x, norm.g, norm.b, mean, rstd, add=dy)     # + the residual branch, same pass
             _done(ctx)
             return None, dx, None, None

@@ -257,7 +257,7 @@ def split_planes_like(ref, B, H, W, C):
 
 
 def conv_gemm_presplit(plan, xs, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None, pre=None, mul=None, act=0, mul_mode=0,
-                       accumulate=0, split_out=False, planes_only=False):
+                       accumulate=0, split_out=False, planes_only=False, pre_grad=False):
     """conv_gemm with the activation already split into bf16 hi/lo planes (xs) and (hi, lo) packed weights (wp).
     split_out: also return the output's own (hi, lo) planes, written by the same epilogue (fused cdf_split_bf16).
     planes_only (with split_out): do not materialise the fp32 output at all (a shape_only stand-in is returned)."""
@@ -276,11 +276,20 @@ def conv_gemm_presplit(plan, xs, Cin, wp, Cout, y=None, bias=None, sbias=None, r
         if ks > 1:
             nws = ks * M * r4(Cout)
             ws = torch.empty((nws,), device=hi.device, dtype=torch.float32)
-    rt.lib().cdf_conv_gemm_bf16x(P(hi), P(lo), hi.shape[-1], P(zero_page(hi.device)), P(wp[0]), P(wp[1]), wp[0].shape[-1], P(y), ld_of(y),
-                                 B, plan.H, plan.W, Cin, plan.OH, plan.OW, Cout, plan.QH, plan.QW, plan.os, plan.istride, plan.nphase,
-                                 plan.desc, P(bias), P(sbias), 0 if sbias is None else sbias.stride(0), P(res), ldv(res), P(pre),
-                                 ldv(pre), P(mul), ldv(mul), act, mul_mode, accumulate, P(ys[0]) if ys else 0, P(ys[1]) if ys else 0,
-                                 ys[0].shape[-1] if ys else 0, P(ws), nws, rt.tune_ptr(), rt.stream(hi))
+    if pre_grad:
+        # `pre` receives GELU'(v) out of the activation's own erf / exp evaluation (the backward multiplies by it: mul_mode 3)
+        assert pre is not None and act in (1, 2)
+        rt.lib().cdf_conv_gemm_bf16x_io(P(hi), P(lo), hi.shape[-1], P(zero_page(hi.device)), P(wp[0]), P(wp[1]), wp[0].shape[-1], P(y), ld_of(y),
+                                        B, plan.H, plan.W, Cin, plan.OH, plan.OW, Cout, plan.QH, plan.QW, plan.os, plan.istride, plan.nphase,
+                                        plan.desc, P(bias), P(sbias), 0 if sbias is None else sbias.stride(0), P(res), ldv(res), P(pre),
+                                        ldv(pre), P(mul), ldv(mul), act, mul_mode, accumulate, IO_PRE_GRAD, P(ys[0]) if ys else 0,
+                                        P(ys[1]) if ys else 0, ys[0].shape[-1] if ys else 0, P(ws), nws, rt.tune_ptr(), rt.stream(hi))
+    else:
+        rt.lib().cdf_conv_gemm_bf16x(P(hi), P(lo), hi.shape[-1], P(zero_page(hi.device)), P(wp[0]), P(wp[1]), wp[0].shape[-1], P(y), ld_of(y),
+                                     B, plan.H, plan.W, Cin, plan.OH, plan.OW, Cout, plan.QH, plan.QW, plan.os, plan.istride, plan.nphase,
+                                     plan.desc, P(bias), P(sbias), 0 if sbias is None else sbias.stride(0), P(res), ldv(res), P(pre),
+                                     ldv(pre), P(mul), ldv(mul), act, mul_mode, accumulate, P(ys[0]) if ys else 0, P(ys[1]) if ys else 0,
+                                     ys[0].shape[-1] if ys else 0, P(ws), nws, rt.tune_ptr(), rt.stream(hi))
     if split_out:
         return y, (ys if ys is not None else split_bf16(y))
     return y
@@ -758,14 +767,20 @@ def linattn_fold_bwd(xn, dy, Mb, Nb, ctx, ctxs, w_qkv, w_out, b_out, heads, scal
     return dxn, dctx, rvec
 
 
-def linattn_bwd_core(qkv, dctx, rvec, kmax, ksum, dqkv, heads, koff=None):
+def linattn_bwd_core(qkv, dctx, rvec, kmax, ksum, dqkv, heads, koff=None, planes=None):
     """The softmax / v part of the attention backward given dctx and rvec (dq is already in dqkv).  koff: channel offset of k | v in
-    qkv's rows and of dk | dv in dqkv's (default heads*32; 0: both are (k|v) tensors, fused kernel only)."""
+    qkv's rows and of dk | dv in dqkv's (default heads*32; 0: both are (k|v) tensors, fused kernel only).
+    planes = (hi, lo | None): dk | dv are written as bf16 operand planes instead of into dqkv (koff = 0 form, fused kernel)."""
     L = rt.lib()
     B, H, W, _ = qkv.shape
     n, HD = H * W, heads * 32
     dev, S = qkv.device, rt.stream(qkv)
     koff = HD if koff is None else koff
+    if planes is not None:
+        assert koff == 0 and heads <= 4
+        L.cdf_linattn_bwd_kv_planes(P(qkv), ld_of(qkv), 0, P(dctx), P(rvec), P(kmax), P(ksum), P(planes[0]), P(planes[1]), planes[0].shape[-1], 0,
+                                    B, n, heads, S)
+        return planes
     if (_ATTN_KV_FUSED or koff != HD) and heads <= 4:
         # one pass: P recomputed from k, dP and dv on the fp32 matrix cores, dk / dv written straight into dqkv (k_attn.hip)
         L.cdf_linattn_bwd_kv(P(qkv), ld_of(qkv), koff, P(dctx), P(rvec), P(kmax), P(ksum), P(dqkv), ld_of(dqkv), koff, B, n, heads, S)
@@ -944,7 +959,7 @@ def colsum_new(x, C, nseg):
 # accumulators, norm statistics, master weights, time biases, parameter gradients.  colddiff/bf16store.py holds the block-level nodes.
 # ---------------------------------------------------------------------------------------------------
 BF = torch.bfloat16
-IO_RES, IO_PRE, IO_MUL = 1, 2, 4           # include/colddiff.h: io_bf16 bits of cdf_conv_gemm_bf16x_io
+IO_RES, IO_PRE, IO_MUL, IO_PRE_GRAD = 1, 2, 4, 8           # include/colddiff.h: io_bf16 bits of cdf_conv_gemm_bf16x_io
 
 
 def is_bf(t):
@@ -977,7 +992,7 @@ def to_bf16(x, out=None):
     return out
 
 
-def conv_gemm_bf(plan, x, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None, pre=None, mul=None, act=0, mul_mode=0):
+def conv_gemm_bf(plan, x, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None, pre=None, mul=None, act=0, mul_mode=0, pre_grad=False):
     """The pre-split GEMM on a bf16 tensor (x IS its operand plane; wp = (hi, None) packed weights) -> bf16 output (y: optional
     destination view).  res / mul: bf16 or fp32 tensors; pre: a bf16 (or fp32) tensor that receives the pre-activation."""
     assert is_bf(x) and wp[1] is None and Cin % 8 == 0 and Cout % 4 == 0
@@ -992,7 +1007,7 @@ def conv_gemm_bf(plan, x, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None
         if ks > 1:
             nws = ks * M * r4(Cout)
             ws = torch.empty((nws,), device=x.device, dtype=torch.float32)
-    io = (IO_RES if is_bf(res) else 0) | (IO_PRE if is_bf(pre) else 0) | (IO_MUL if is_bf(mul) else 0)
+    io = (IO_RES if is_bf(res) else 0) | (IO_PRE if is_bf(pre) else 0) | (IO_MUL if is_bf(mul) else 0) | (IO_PRE_GRAD if pre_grad else 0)
     rt.lib().cdf_conv_gemm_bf16x_io(P(x), 0, ld_of(x), P(zero_page(x.device)), P(wp[0]), 0, wp[0].shape[-1], 0, Cout,
                                     B, plan.H, plan.W, Cin, plan.OH, plan.OW, Cout, plan.QH, plan.QW, plan.os, plan.istride, plan.nphase,
                                     plan.desc, P(bias), P(sbias), 0 if sbias is None else sbias.stride(0), P(res), ldv(res), P(pre),
@@ -1024,16 +1039,18 @@ def dwconv7_wgrad_bf(x, dy, w_param, b_param, want_dsb, dsb_out=None):
     return dsb
 
 
-def layernorm_fwd_bf(x, g, b, eps, save, out_f32=False):
-    """Channel LayerNorm of a bf16 tensor -> (y, mean, rstd); y bf16 (the next GEMM's operand plane) or, out_f32, fp32."""
+def layernorm_fwd_bf(x, g, b, eps, save, out_f32=False, planes=False):
+    """Channel LayerNorm of a bf16 tensor -> (y, mean, rstd); y bf16 (the next GEMM's operand plane) or, out_f32, fp32 -- with `planes`
+    additionally the bf16 plane of the same values: (y fp32, mean, rstd, y bf16)."""
     B, H, W, C = x.shape
     M = B * H * W
     y = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32 if out_f32 else BF)
+    yb = torch.empty((B, H, W, C), device=x.device, dtype=BF) if (out_f32 and planes) else None
     mean = torch.empty((M,), device=x.device, dtype=torch.float32) if save else None
     rstd = torch.empty((M,), device=x.device, dtype=torch.float32) if save else None
     rt.lib().cdf_layernorm_c_fwd_io(P(x), ld_of(x), P(y) if out_f32 else 0, C, P(g), P(b), P(mean), P(rstd), M, C, eps,
-                                    0 if out_f32 else P(y), 0, 0 if out_f32 else C, 1, rt.stream(x))
-    return y, mean, rstd
+                                    P(yb) if out_f32 else P(y), 0, 0 if (out_f32 and not planes) else C, 1, rt.stream(x))
+    return (y, mean, rstd, yb) if (out_f32 and planes) else (y, mean, rstd)
 
 
 def layernorm_bwd_bf(dy, x, g_param, b_param, mean, rstd, add=None):

@@ -145,6 +145,8 @@ __device__ __forceinline__ void cdf_st4_bf(void* base, long long off, const floa
 #define CDF_IO_RES_BF16 1    /* epilogue operand types (io_bf16 bit mask of the *_io GEMM entry points): residual read as bf16 */
 #define CDF_IO_PRE_BF16 2    /* pre-activation written as bf16 */
 #define CDF_IO_MUL_BF16 4    /* activation-gradient source read as bf16 */
+#define CDF_IO_PRE_GRAD 8    /* `pre` receives act'(v) instead of v (act = GELU / SiLU): the backward pass then multiplies by the stored
+                                value (mul_mode 3) instead of evaluating erf / exp again in the data-gradient epilogue */
 
 // ---- status codes (returned by every extern "C" entry point) -------------------------
 #define CDF_OK 0
@@ -236,6 +238,14 @@ __device__ __forceinline__ float cdf_gelu_grad(float x) {
     float e;                                                  // exp(-x^2 / 2)
     const float cdf = 0.5f * (1.0f + cdf_erf_fast(x * 0.70710678118654752440f, e));
     return cdf + x * (0.39894228040143267794f * e);
+}
+// GELU(x) and GELU'(x) from ONE erf / exp evaluation (the same expressions as cdf_gelu and cdf_gelu_grad: bit-identical values)
+__device__ __forceinline__ float cdf_gelu_both(float x, float& grad) {
+    float e;
+    const float er = cdf_erf_fast(x * 0.70710678118654752440f, e);
+    const float cdf = 0.5f * (1.0f + er);
+    grad = cdf + x * (0.39894228040143267794f * e);
+    return 0.5f * x * (1.0f + er);
 }
 __device__ __forceinline__ float cdf_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float cdf_silu(float x) { return x * cdf_sigmoid(x); }

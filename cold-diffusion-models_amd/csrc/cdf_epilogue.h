@@ -95,6 +95,22 @@ __device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += u[e];
         }
+        if (a.pre && (a.io_bf & CDF_IO_PRE_GRAD)) {
+            // `pre` receives act'(v): one erf / exp evaluation serves GELU and its derivative, and the data-gradient epilogue of the
+            // backward pass multiplies by a loaded value instead of evaluating them again (host: act is GELU or SiLU here)
+            float gr[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (a.act == 1) {
+                    v[e] = cdf_gelu_both(v[e], gr[e]);
+                } else {
+                    gr[e] = cdf_silu_grad(v[e]);
+                    v[e] = cdf_silu(v[e]);
+                }
+            }
+            if (a.io_bf & CDF_IO_PRE_BF16) cdf_st4_bf(a.pre, o_pre, gr);
+            else cdf_st4(a.pre + o_pre, gr, nval, vec);
+        } else {
         if (a.pre) {
             if (a.io_bf & CDF_IO_PRE_BF16) cdf_st4_bf(a.pre, o_pre, v);
             else cdf_st4(a.pre + o_pre, v, nval, vec);
@@ -108,6 +124,7 @@ __device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph
         } else if (a.act == 3) {                             // ReLU (the FID InceptionV3's BasicConv2d, Fid/inception.py)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f); // relu
+        }
         }
         if (a.mul_mode) {
             if (a.io_bf & CDF_IO_MUL_BF16) cdf_ld4_bf(u, a.mul, o_mul);

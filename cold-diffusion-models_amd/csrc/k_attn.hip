@@ -481,8 +481,12 @@ extern "C" int cdf_linattn_dk(const float* pn, int ldp, const float* dp, int ldd
 #define LA_TP 36                                             // LDS row pitch (floats): 16-byte aligned rows
 #define LA_TILES 8                                           // 32-pixel tiles per wave
 
+// PL: dk | dv leave as bf16 hi / lo planes (pitch ldpl, channel offset dkoff) instead of fp32 -- the operand form of the two GEMMs that
+// consume them (the k | v projection's data and weight gradients), same bytes, no split pass and no in-kernel split downstream.
+template <bool PL>
 __global__ void __launch_bounds__(256) linattn_bwd_kv_kernel(const float* qkv, int ld, const float* dctx, const float* rvec, const float* kmax,
-                                                            const float* ksum, float* dqkv, int lddq, int n, int heads, int koff, int dkoff) {
+                                                            const float* ksum, float* dqkv, int lddq, int n, int heads, int koff, int dkoff,
+                                                            unsigned short* pl_hi, unsigned short* pl_lo, int ldpl) {
     CDF_DYN_SMEM(smem_raw);
     const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, b = blockIdx.y;
     const int HD = heads * LA_D;
@@ -505,8 +509,17 @@ __global__ void __launch_bounds__(256) linattn_bwd_kv_kernel(const float* qkv, i
     const float4 ri = make_float4(1.0f / ks.x, 1.0f / ks.y, 1.0f / ks.z, 1.0f / ks.w);
     const float* kbase = qkv + (size_t)b * n * ld + koff + h * LA_D + lc;
     const float* vbase = kbase + HD;
-    float* dkbase = dqkv + (size_t)b * n * lddq + dkoff + h * LA_D + lc;
-    float* dvbase = dkbase + HD;
+    float* dkbase = PL ? nullptr : dqkv + (size_t)b * n * lddq + dkoff + h * LA_D + lc;
+    float* dvbase = PL ? nullptr : dkbase + HD;
+    const size_t plk = (size_t)b * n * ldpl + dkoff + h * LA_D + lc, plv = plk + HD;        // (PL) element offsets of dk / dv in the planes
+    auto put = [&](float* base, size_t ploff, int p, const float4& v) {
+        if constexpr (PL) {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            cdf_split_store4(pl_hi + ploff + (size_t)p * ldpl, pl_lo ? pl_lo + ploff + (size_t)p * ldpl : nullptr, vv);
+        } else {
+            *(float4*)(base + (size_t)p * lddq) = v;
+        }
+    };
     const int p_begin = blockIdx.x * (LA_D * LA_TILES);
     for (int t = 0; t < LA_TILES; ++t) {
         const int p0 = p_begin + t * LA_D;
@@ -544,7 +557,7 @@ __global__ void __launch_bounds__(256) linattn_bwd_kv_kernel(const float* qkv, i
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int p = p0 + lr + 8 * q;
-            if (p < n) *(float4*)(dkbase + (size_t)p * lddq) = *(const float4*)(so + (lr + 8 * q) * LA_TP + lc);
+            if (p < n) put(dkbase, plk, p, *(const float4*)(so + (lr + 8 * q) * LA_TP + lc));
         }
         CDF_WAVE_SYNC();
         // ---- dv = P dctx
@@ -558,7 +571,7 @@ __global__ void __launch_bounds__(256) linattn_bwd_kv_kernel(const float* qkv, i
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int p = p0 + lr + 8 * q;
-            if (p < n) *(float4*)(dvbase + (size_t)p * lddq) = *(const float4*)(so + (lr + 8 * q) * LA_TP + lc);
+            if (p < n) put(dvbase, plv, p, *(const float4*)(so + (lr + 8 * q) * LA_TP + lc));
         }
         CDF_WAVE_SYNC();                                   // the tiles are rewritten by the next trip
     }
@@ -572,8 +585,23 @@ extern "C" int cdf_linattn_bwd_kv(const float* qkv, int ld, int koff, const floa
                 ((((uintptr_t)qkv) | ((uintptr_t)dqkv) | ((uintptr_t)kmax) | ((uintptr_t)ksum)) & 15) == 0,
                 "cdf_linattn_bwd_kv: up to 4 heads; pitches / channel offsets must be multiples of 4 and hold k | v, pointers 16-byte aligned");
     const size_t lds = (size_t)heads * 3 * LA_D * LA_TP * sizeof(float);
-    CDF_LAUNCH(linattn_bwd_kv_kernel, dim3(cdf_cdiv(n, LA_D * LA_TILES), B), dim3(64 * heads), lds, CDF_S, qkv, ld, dctx, rvec, kmax, ksum, dqkv, lddq, n, heads, koff, dkoff);
+    CDF_LAUNCH(linattn_bwd_kv_kernel<false>, dim3(cdf_cdiv(n, LA_D * LA_TILES), B), dim3(64 * heads), lds, CDF_S, qkv, ld, dctx, rvec, kmax, ksum, dqkv, lddq, n,
+               heads, koff, dkoff, (unsigned short*)nullptr, (unsigned short*)nullptr, 0);
     return cdf_check_launch("linattn_bwd_kv");
+}
+
+// ... with dk | dv written as bf16 hi / lo planes [B n][ldpl] (lo nullable: single-plane bf16 mode) at channel offset dkoff
+extern "C" int cdf_linattn_bwd_kv_planes(const float* qkv, int ld, int koff, const float* dctx, const float* rvec, const float* kmax, const float* ksum,
+                                         void* dkv_hi, void* dkv_lo, int ldpl, int dkoff, int B, int n, int heads, void* stream) {
+    CDF_REQUIRE(qkv && dctx && rvec && kmax && ksum && dkv_hi && B > 0 && n > 0, "cdf_linattn_bwd_kv_planes: null pointer");
+    CDF_REQUIRE(heads >= 1 && heads <= 4 && ld % 4 == 0 && ldpl % 8 == 0 && koff >= 0 && dkoff >= 0 && koff % 4 == 0 && dkoff % 8 == 0 &&
+                ld >= koff + 2 * heads * LA_D && ldpl >= dkoff + 2 * heads * LA_D &&
+                ((((uintptr_t)qkv) | ((uintptr_t)dkv_hi) | ((uintptr_t)dkv_lo) | ((uintptr_t)kmax) | ((uintptr_t)ksum)) & 15) == 0,
+                "cdf_linattn_bwd_kv_planes: up to 4 heads; the planes' pitch / channel offset must be multiples of 8 and hold dk | dv, pointers 16-byte aligned");
+    const size_t lds = (size_t)heads * 3 * LA_D * LA_TP * sizeof(float);
+    CDF_LAUNCH(linattn_bwd_kv_kernel<true>, dim3(cdf_cdiv(n, LA_D * LA_TILES), B), dim3(64 * heads), lds, CDF_S, qkv, ld, dctx, rvec, kmax, ksum, (float*)nullptr, 0, n,
+               heads, koff, dkoff, (unsigned short*)dkv_hi, (unsigned short*)dkv_lo, ldpl);
+    return cdf_check_launch("linattn_bwd_kv_planes");
 }
 
 // dctx = scale * raw ; rvec[row] = sum_e dctx[row][e] * ctx[row][e]  (rows of LA_D = 32 entries; one 32-lane group per row)

@@ -2457,7 +2457,8 @@ extern "C" int cdf_conv_gemm_bf16x_io(const void* x_hi, const void* x_lo, int ld
     const float* res = (const float*)res_;
     float* pre = (float*)pre_;
     const float* mul = (const float*)mul_;
-    CDF_REQUIRE((io_bf16 & ~7) == 0, "cdf_conv_gemm_bf16x_io: io_bf16 has unknown bits (%d)", io_bf16);
+    CDF_REQUIRE((io_bf16 & ~15) == 0, "cdf_conv_gemm_bf16x_io: io_bf16 has unknown bits (%d)", io_bf16);
+    CDF_REQUIRE(!(io_bf16 & CDF_IO_PRE_GRAD) || (pre_ && (act == 1 || act == 2)), "cdf_conv_gemm_bf16x_io: CDF_IO_PRE_GRAD needs a pre tensor and act = GELU / SiLU");
     CDF_REQUIRE(x_hi && zero && w_hi && (y || (y_hi && !accumulate)), "cdf_conv_gemm_bf16x: null pointer");
     CDF_TUNE_CHECK(tune, "cdf_conv_gemm_bf16x");
     CDF_REQUIRE(!ws || (((uintptr_t)ws) & 15) == 0, "cdf_conv_gemm_bf16x: the split-K workspace must be 16-byte aligned");
@@ -2479,7 +2480,7 @@ extern "C" int cdf_conv_gemm_bf16x_io(const void* x_hi, const void* x_lo, int ld
     a.ys_hi = (unsigned short*)y_hi; a.ys_lo = (unsigned short*)y_lo; a.ld_ys = ld_ys;
     a.io_bf = io_bf16;
     CDF_REQUIRE(!y_hi || a.vec, "cdf_conv_gemm_bf16x: split output planes need the vectorised epilogue (aligned pointers, pitches %% 4)");
-    CDF_REQUIRE(!io_bf16 || a.vec, "cdf_conv_gemm_bf16x_io: bf16 epilogue operands need the vectorised epilogue (16-byte-aligned pointers, pitches %% 4, Cout %% 4)");
+    CDF_REQUIRE(!(io_bf16 & 7) || a.vec, "cdf_conv_gemm_bf16x_io: bf16 epilogue operands need the vectorised epilogue (16-byte-aligned pointers, pitches %% 4, Cout %% 4)");
     int rc = fill_phases(a.ph, nphase, phase_desc, "cdf_conv_gemm_bf16x");
     if (rc) return rc;
     a.ksplit = 1; a.ks_ws = ws; a.ks_ld = 0;

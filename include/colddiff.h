@@ -217,7 +217,9 @@ int cdf_conv_gemm_bf16x(const void* x_hi, const void* x_lo, int ldx, const void*
  * (x_lo = w_lo = y_lo = NULL, y = NULL) -- and the *_io entry points below take the remaining operands in that type too.  Pitches of a
  * bf16 operand are in bf16 elements; bf16 pointers need 8-byte alignment (GEMM operand planes 16).
  * cdf_conv_gemm_bf16x_io: cdf_conv_gemm_bf16x with typed epilogue operands; io_bf16 = bit mask
- *   1 (CDF_IO_RES_BF16): res is bf16;  2 (CDF_IO_PRE_BF16): pre is written as bf16;  4 (CDF_IO_MUL_BF16): mul is bf16.
+ *   1 (CDF_IO_RES_BF16): res is bf16;  2 (CDF_IO_PRE_BF16): pre is written as bf16;  4 (CDF_IO_MUL_BF16): mul is bf16;
+ *   8 (CDF_IO_PRE_GRAD, any storage type): pre receives act'(v) instead of v (act 1 / 2) -- the derivative comes out of the same erf / exp
+ *   evaluation as the activation, and the backward data gradient multiplies by it (mul_mode 3) instead of evaluating it again.
  * cdf_bf16_to_f32: y[r][c] = float(x[r][c]) (exact) for the few kernels that have no bf16-input form; the other direction is
  *   cdf_split_bf16 with lo = NULL (round to nearest even). */
 int cdf_conv_gemm_bf16x_io(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo, int ldk,
@@ -405,6 +407,10 @@ int cdf_linattn_dk(const float* pn, int ldp, const float* dp, int lddp, const fl
  * (pitch lddq).  heads <= 4. */
 int cdf_linattn_bwd_kv(const float* qkv, int ld, int koff, const float* dctx, const float* rvec, const float* kmax, const float* ksum,
                        float* dqkv, int lddq, int dkoff, int B, int n, int heads, void* stream);
+/* ... with dk | dv written as bf16 hi / lo planes [B n][ldpl] (dkv_lo nullable) instead of fp32: the operand form of the k | v projection's
+ * data- and weight-gradient GEMMs (cdf_conv_gemm_bf16x, cdf_conv_wgrad_bf16x) -- same bytes, no split downstream. */
+int cdf_linattn_bwd_kv_planes(const float* qkv, int ld, int koff, const float* dctx, const float* rvec, const float* kmax, const float* ksum,
+                              void* dkv_hi, void* dkv_lo, int ldpl, int dkoff, int B, int n, int heads, void* stream);
 /* cdf_linattn_dctx_finish: dctx[i] = scale * raw[i]; rvec[row] = sum_e dctx[row][e] * ctx[row][e] over rows of 32 (rows = B * heads * 32):
  * the tail of the fused attention backward, where raw = d(scale * ctx) comes out of a batched GEMM (see colddiff/ops.py linattn_bwd). */
 int cdf_linattn_dctx_finish(const float* raw, const float* ctx, float* dctx, float* rvec, long long rows, float scale, void* stream);

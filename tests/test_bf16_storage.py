@@ -246,3 +246,28 @@ def test_trainer_and_sampler_on_the_bf16_stream(mbe, bf16_mode, tmp_path):
         sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
         rdirect = O.unet_forward(sd, noise, torch.full((2,), 9))
     assert (direct.cpu() - rdirect).abs().max().item() <= BF16_TOLERANCE["forward_max_abs"]
+
+
+def test_stored_gelu_derivative_is_bit_identical(mbe, monkeypatch):
+    """conv1's epilogue can store GELU'(v) (out of the erf / exp evaluation GELU needs anyway) in place of the pre-activation, and conv2's
+    data gradient then multiplies by the stored value instead of evaluating erf / exp per element again: the same function of the same
+    fp32 input, so every gradient must come out bit for bit the same (parity-grade bf16x3 arithmetic, pre-split path: dim >= 64)."""
+    from colddiff import functions as F_
+    from colddiff import runtime as rt
+    from colddiff.unet import ConvNextBlock, anchor
+    assert rt.precision == "bf16x3"
+    torch.manual_seed(4)
+    blk = ConvNextBlock(64, 64, time_emb_dim=16).to(mbe.device)
+    x = mbe.to(torch.randn(2, 8, 8, 64))
+    gt = mbe.to(torch.randn(2, 16))
+    dy = mbe.to(torch.randn(2, 8, 8, 64))
+    outs = []
+    for flag in (False, True):
+        monkeypatch.setattr(F_, "_PRE_GRAD", flag)
+        for p in blk.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_()
+        y = blk(xi, gt)
+        y.backward(dy)
+        outs.append([y.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in blk.parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
