@@ -114,7 +114,10 @@ class GemmTimer:
     _SP = "bf16 MFMA, 3 MFMAs per product (hi/lo split operands, fp32 accumulate)"
     DTYPE = {"conv_igemm_sp": _SP, "conv_wgrad_sp": _SP, "conv_igemm": "f32 MFMA", "conv_wgrad": "f32 MFMA"}
     ENTRY = {"cdf_conv_gemm": "conv_igemm", "cdf_conv_gemm_bf16": "conv_igemm_sp", "cdf_conv_gemm_bf16x": "conv_igemm_sp",
-             "cdf_conv_wgrad": "conv_wgrad", "cdf_conv_wgrad_bf16": "conv_wgrad_sp", "cdf_conv_wgrad_bf16x": "conv_wgrad_sp"}
+             "cdf_conv_wgrad": "conv_wgrad", "cdf_conv_wgrad_bf16": "conv_wgrad_sp", "cdf_conv_wgrad_bf16x": "conv_wgrad_sp",
+             # the typed-operand forms (bf16 activation storage): same leading arguments as the entry points they extend
+             "cdf_conv_gemm_io": "conv_igemm", "cdf_conv_gemm_bf16x_io": "conv_igemm_sp"}
+    ALIAS = {"cdf_conv_gemm_io": "cdf_conv_gemm", "cdf_conv_gemm_bf16x_io": "cdf_conv_gemm_bf16x"}
 
     def __init__(self, lib):
         self.lib, self.enabled, self.records, self.taps = lib, False, {k: [] for k in self.PEAK}, {}
@@ -134,6 +137,7 @@ class GemmTimer:
         return self.taps[key][0]
 
     def _flops(self, kind, a):
+        kind = self.ALIAS.get(kind, kind)
         if kind == "cdf_conv_gemm_bf16x":   # (xhi,xlo,ldx,zero,whi,wlo,ldk,y,ldy,B,H,W,Cin,OH,OW,Cout,QH,QW,os,is,nphase,desc,...)
             return 2.0 * a[9] * a[16] * a[17] * self._ntaps(a[21], a[20]) * a[12] * a[15]
         if kind == "cdf_conv_wgrad_bf16x":  # (ahi,alo,lda,bhi,blo,ldb,zero,ws,ldo,B,QH,QW,HA,WA,sa,HB,WB,sb,CA,CB,ntaps,...)
@@ -150,6 +154,7 @@ class GemmTimer:
     def _bytes(self, kind, a):
         """ALGORITHMIC HBM bytes of a launch (SURVEY 8(d) counts layer-boundary tensors in fp32): input map + output map + weights,
         each once -- what `traffic` (PMC) is compared with."""
+        kind = self.ALIAS.get(kind, kind)
         if kind == "cdf_conv_gemm_bf16x":
             return 4.0 * (a[9] * a[10] * a[11] * a[12] + a[9] * a[13] * a[14] * a[15] + self._ntaps(a[21], a[20]) * a[12] * a[15])
         if kind == "cdf_conv_gemm_bf16":
@@ -196,7 +201,7 @@ class GemmTimer:
                 # projections (K = 64 ... 512 against 256 ... 1536 output channels: HBM-bound streams) -- same figures per entry point
                 sub = {}
                 for entry, label in (("cdf_conv_gemm_bf16x", "pre_split_3x3_4x4"), ("cdf_conv_gemm_bf16", "in_kernel_split_1x1_attention")):
-                    rs = [r for r in recs if r[3][0] == entry]
+                    rs = [r for r in recs if self.ALIAS.get(r[3][0], r[3][0]) == entry]
                     if not rs:
                         continue
                     m = sum(e0.elapsed_time(e1) for e0, e1, *_ in rs)
