@@ -632,6 +632,8 @@ def main():
                 # grade (tolerance below); reported beside the parity-grade `value`, never instead of it.
                 runtime.set_precision("bf16")
                 runtime.bump_weights_epoch()
+                from colddiff import bf16store
+                stored_bf16 = bf16store.enabled_for(model)       # (asked while the mode is on: which engine the timed steps below run)
                 dtb = timed_train(trainer, args.steps, args.warmup)
                 sample_bf16 = None
                 if not args.no_sample:
@@ -645,8 +647,6 @@ def main():
                         sample_bf16 = round(1000 * (time.perf_counter() - ts) / args.sample_batch, 2)
                 runtime.set_precision("bf16x3")
                 runtime.bump_weights_epoch()
-                from colddiff import bf16store
-                stored_bf16 = bf16store.enabled_for(model)
                 out["bf16_mode"] = {"value": round(args.batch * args.accum / dtb, 2), "unit": "img/s", "ms_per_step": round(1000 * dtb, 3),
                                     "dtype": "bf16 GEMM operands (one MFMA per product) AND bf16 activation storage: one bf16 plane is the only stored form of "
                                              "every GEMM input, every activation saved for backward and the inter-block residual stream in both directions "

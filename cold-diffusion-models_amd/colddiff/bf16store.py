@@ -79,18 +79,6 @@ def conv_bwd(x, Cin, dy, weight, bias, kind="conv", stride=1, pad=None, need_dx=
 
 
 # -- boundaries -------------------------------------------------------------------------------------------------------------------------
-class ToBF16(torch.autograd.Function):
-    """fp32 feature map -> bf16 (the image-side block's output entering the stream); backward widens the gradient."""
-
-    @staticmethod
-    def forward(ctx, x, out=None):
-        return ops.to_bf16(x, out)
-
-    @staticmethod
-    def backward(ctx, dy):
-        return ops.to_f32(dy), None
-
-
 class ToF32(torch.autograd.Function):
     """bf16 feature map -> fp32 (the stream leaving towards the 3-channel output conv); backward rounds the gradient."""
 
@@ -150,6 +138,12 @@ class ConvNextBlockBF(torch.autograd.Function):
         dim = m.dim
         grad_on = ctx.needs_input_grad[0]
         B, H, W, _ = x.shape
+        # an fp32 input is the image-side block's output ENTERING the stream: rounded here, and the data gradient goes back to that block
+        # in fp32 (its per-channel bias gradients are sums over every pixel of the batch of this tensor's values: rounding it at the
+        # stream's precision put them at 5 % of their scale against a 6 % bound on one seed, fp32 keeps them where fp32 tensors had them)
+        ctx.in_f32 = not ops.is_bf(x)
+        if ctx.in_f32:
+            x = ops.to_bf16(x[..., :dim] if x.shape[-1] != dim else x)
         wdw = ops.packed(m.ds_conv.weight, "dw")
         h = ops.dwconv7_bf(x, wdw, m.ds_conv.bias, tbias)
         c1, c2 = m.net[1], m.net[3]
@@ -189,7 +183,9 @@ class ConvNextBlockBF(torch.autograd.Function):
         dtb = ops.dwconv7_wgrad_bf(x, dh, m.ds_conv.weight, m.ds_conv.bias, ctx.has_t, dsb_out=dsb_out)
         if need_dx:
             wdw = ops.packed(m.ds_conv.weight, "dw")
-            if m.has_res_conv:
+            if ctx.in_f32:
+                dx = ops.dwconv7_bf(dh, wdw, None, None, flip=1, res=dx if m.has_res_conv else do, out_f32=True)
+            elif m.has_res_conv:
                 ops.dwconv7_bf(dh, wdw, None, None, flip=1, y=dx, accumulate=1)
             else:
                 dx = ops.dwconv7_bf(dh, wdw, None, None, flip=1, res=do)                # + the residual gradient, same pass

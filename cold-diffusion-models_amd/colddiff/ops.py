@@ -1015,14 +1015,14 @@ def conv_gemm_bf(plan, x, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None
     return y
 
 
-def dwconv7_bf(x, wp, bias, sbias, flip=0, y=None, accumulate=0, res=None):
-    """ops.dwconv7 on bf16 tensors (x, y, res all bf16)."""
+def dwconv7_bf(x, wp, bias, sbias, flip=0, y=None, accumulate=0, res=None, out_f32=False):
+    """ops.dwconv7 on bf16 tensors (x, y, res all bf16; out_f32: an fp32 y from bf16 x / res)."""
     B, H, W, Cp = x.shape
     assert is_bf(x) and (res is None or is_bf(res))
     if y is None:
-        y = torch.empty((B, H, W, Cp), device=x.device, dtype=BF)
+        y = torch.empty((B, H, W, Cp), device=x.device, dtype=torch.float32 if out_f32 else BF)
     rt.lib().cdf_dwconv7_io(P(x), ld_of(x), P(wp), wp.shape[-1], P(bias), P(sbias), 0 if sbias is None else sbias.stride(0), P(y),
-                            ld_of(y), B, H, W, Cp, flip, accumulate, P(res), 0 if res is None else ld_of(res), 1, rt.stream(x))
+                            ld_of(y), B, H, W, Cp, flip, accumulate, P(res), 0 if res is None else ld_of(res), 1 if is_bf(y) else 2, rt.stream(x))
     return y
 
 

@@ -109,13 +109,14 @@ class ConvNextBlock(nn.Module):
         self.has_norm = norm
         self.has_res_conv = dim != dim_out
 
-    def forward(self, x, gelu_t=None, dest=None, tb=None):
+    def forward(self, x, gelu_t=None, dest=None, tb=None, enter_bf16=False):
         """x: NHWC feature map; gelu_t: GELU(time embedding) [B, time_dim] (shared by all blocks); dest: CatBuf whose first half
-        receives the output; tb: this block's time bias when the caller computed all of them in one launch (F_.TimeBiasAll)."""
+        receives the output; tb: this block's time bias when the caller computed all of them in one launch (F_.TimeBiasAll);
+        enter_bf16: x is the fp32 output of the image-side block entering the bf16 stream in this block (bf16store.py)."""
         if tb is None and exists(self.mlp):
             assert exists(gelu_t), "time emb must be passed in"
             tb = F_.Linear.apply(anchor(x), gelu_t, self.mlp[1])
-        if ops.is_bf(x):
+        if ops.is_bf(x) or enter_bf16:
             return BFS.ConvNextBlockBF.apply(anchor(x), x, tb, self, dest)
         return F_.ConvNextBlockFn.apply(anchor(x), x, tb, self, dest)
 
@@ -236,8 +237,10 @@ class Unet(nn.Module):
         for lvl, (convnext, convnext2, attn, downsample) in enumerate(self.downs):
             x = convnext(x, gt, tb=T(convnext))
             if bfs and lvl == 0:
-                x = BFS.ToBF16.apply(x)
-            x = convnext2(x, gt, tb=T(convnext2))
+                # the image-side block's fp32 output enters the stream inside the next block (rounded there; its gradient comes back fp32)
+                x = convnext2(x, gt, tb=T(convnext2), enter_bf16=True)
+            else:
+                x = convnext2(x, gt, tb=T(convnext2))
             cat = None
             if _CONCAT_FREE and lvl >= len(self.downs) - nskip:
                 B_, H_, W_, C_ = x.shape

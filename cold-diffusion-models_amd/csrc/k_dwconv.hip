@@ -39,14 +39,17 @@ __device__ __forceinline__ void f4_fma(float4& acc, const float4& a, const float
 //     weights behind a per-component select: 448 v_cndmask and 1/8 of the FMAs per thread gone.
 // (A block walking several tiles with the next halo requested under the current tile's FMAs was built and measured: slower,
 //  218 VGPRs and no gain from the overlap -- the waves do not wait for HBM, they wait for the vector ALU.)
-// BF (bf16 activation storage): x, y and res are bf16 tensors (pitches in bf16 elements): the halo comes in as 8-byte quads and is
-// widened when it goes to LDS, the result is rounded to nearest even when it leaves; weights, biases and the arithmetic stay fp32.
-template <int TBW, int TBH, bool BF>
+// BF (bf16 activation storage): x and res are bf16 tensors (pitches in bf16 elements): the halo comes in as 8-byte quads and is
+// widened when it goes to LDS; YB: y is bf16 too (rounded to nearest even when it leaves) -- YB = false with BF = true is the one place
+// where the bf16 stream hands a gradient to fp32 tensors (the data gradient entering the image-side block).  Weights, biases and the
+// arithmetic stay fp32.
+template <int TBW, int TBH, bool BF, bool YB = BF>
 __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const void* x, int ldx, const float* w, int ldw, const float* bias,
                                                          const float* sbias, int ld_sbias, void* y, int ldy, int B, int H,
                                                          int W, int C4, int flip, int accumulate, const void* res, int ldr) {
     typedef typename cdf_quad<BF>::raw raw_t;
     typedef typename cdf_quad<BF>::elem elem_t;
+    typedef typename cdf_quad<YB>::elem yelem_t;
     constexpr int HW_ = TBW + 6, HH_ = TBH + 6;              // halo extent
     constexpr int RP = HW_ * 8 + 4;                          // row pitch in float4 (pixels x 8 channel quads + 64 B)
     constexpr int TX = TBW / 4, TY = TBH / 2;                // thread tiles
@@ -161,7 +164,7 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const void* x, int ldx,
         const float4 sv = *(const float4*)(sbias + (long long)b * ld_sbias + c);
         add.x += sv.x; add.y += sv.y; add.z += sv.z; add.w += sv.w;
     }
-    elem_t* yb = (elem_t*)y + (long long)b * H * W * ldy;
+    yelem_t* yb = (yelem_t*)y + (long long)b * H * W * ldy;
     const elem_t* rb = res ? (const elem_t*)res + (long long)b * H * W * ldr : nullptr;
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
@@ -175,14 +178,14 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const void* x, int ldx,
             if (ox >= W) break;
             float4 v = make_float4(acc[o][j].x + add.x, acc[o][j].y + add.y, acc[o][j].z + add.z, acc[o][j].w + add.w);
             if (accumulate) {
-                const float4 old = cdf_quad_cvt(cdf_quad_ld<BF>(yb, offy));
+                const float4 old = cdf_quad_cvt(cdf_quad_ld<YB>(yb, offy));
                 v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
             }
             if (res) {                                       // fused residual (e.g. dx = dy + conv^T(dh))
                 const float4 rv = cdf_quad_cvt(cdf_quad_ld<BF>(rb, offr));
                 v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             }
-            cdf_quad_st<BF>(yb, offy, v);
+            cdf_quad_st<YB>(yb, offy, v);
             offy += (unsigned)ldy;
             offr += (unsigned)ldr;
         }
@@ -457,31 +460,33 @@ __global__ void __launch_bounds__(1024) dwconv7_wgrad_final_kernel(const float* 
     }
 }
 
-template <int TBW, int TBH, bool BF>
+template <int TBW, int TBH, bool BF, bool YB = BF>
 static int launch_dwconv7(const void* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias, int ld_sbias, void* y,
                           int ldy, int B, int H, int W, int C4, int flip, int accumulate, const void* res, int ldr, hipStream_t s) {
     constexpr size_t lds = ((size_t)(TBH + 6) * ((TBW + 6) * 8 + 4) + DW_TAPS * 8) * sizeof(float4);
 #ifndef CDF_EMU
     static CdfDeviceLatch attr_done;
     if (attr_done.first()) {
-        (void)hipFuncSetAttribute((const void*)dwconv7_kernel<TBW, TBH, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)dwconv7_kernel<TBW, TBH, BF, YB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
 #endif
     const long long tiles = (long long)B * cdf_cdiv(H, TBH) * cdf_cdiv(W, TBW);
-    CDF_LAUNCH((dwconv7_kernel<TBW, TBH, BF>), dim3((unsigned)tiles, cdf_cdiv(C4, 8)), dim3(256), lds, s, x, ldx, w, ldw, bias, sbias, ld_sbias, y,
+    CDF_LAUNCH((dwconv7_kernel<TBW, TBH, BF, YB>), dim3((unsigned)tiles, cdf_cdiv(C4, 8)), dim3(256), lds, s, x, ldx, w, ldw, bias, sbias, ld_sbias, y,
                ldy, B, H, W, C4, flip, accumulate, res, ldr);
     return cdf_check_launch("dwconv7");
 }
 
 // ================================================================================================
-// io_bf16 != 0: x, y and res are bf16 tensors (pitches in bf16 elements, 8-byte aligned); w, bias, sbias stay fp32
+// io_bf16 != 0: x, y and res are bf16 tensors (pitches in bf16 elements, 8-byte aligned); io_bf16 == 2: x and res bf16, y fp32; w, bias,
+// sbias stay fp32
 extern "C" int cdf_dwconv7_io(const void* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias,
                               int ld_sbias, void* y, int ldy, int B, int H, int W, int C, int flip, int accumulate,
                               const void* res, int ldr, int io_bf16, void* stream) {
-    const uintptr_t amask = io_bf16 ? 7 : 15;
+    const uintptr_t amask = io_bf16 ? 7 : 15, ymask = io_bf16 == 1 ? 7 : 15;
+    CDF_REQUIRE(io_bf16 >= 0 && io_bf16 <= 2, "cdf_dwconv7_io: io_bf16 must be 0 (fp32), 1 (bf16) or 2 (bf16 x / res, fp32 y)");
     CDF_REQUIRE(!res || (ldr % 4 == 0 && (((uintptr_t)res) & amask) == 0), "cdf_dwconv7: residual must be 16B aligned (bf16: 8B) with pitch %% 4 == 0");
     CDF_REQUIRE(x && w && y, "cdf_dwconv7: null pointer");
-    CDF_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y)) & amask) == 0, "cdf_dwconv7: x / y must be 16B aligned (bf16: 8B)");
+    CDF_REQUIRE((((uintptr_t)x) & amask) == 0 && (((uintptr_t)y) & ymask) == 0, "cdf_dwconv7: x / y must be 16B aligned (bf16: 8B)");
     const int Cp = (C + 3) & ~3;
     CDF_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldw % 4 == 0 && ldx >= Cp && ldy >= Cp && ldw >= Cp, "cdf_dwconv7: pitches must be multiples of 4 and >= roundup4(C)");
     CDF_REQUIRE(!bias || (C % 4 == 0), "cdf_dwconv7: bias with C %% 4 != 0 needs a padded bias (pass a padded vector and C rounded up)");
@@ -489,6 +494,10 @@ extern "C" int cdf_dwconv7_io(const void* x, int ldx, const float* w, int ldw, c
         const long long ldmax = ldx > ldy ? (ldx > ldr ? ldx : ldr) : (ldy > ldr ? ldy : ldr);
         CDF_REQUIRE((long long)H * W < (1 << 24) && ldmax < (1 << 24) && (long long)H * W * ldmax < (1LL << 30),
                     "cdf_dwconv7: image of %d x %d pixels at pitch %lld is beyond the kernel's 32-bit per-image offsets", H, W, ldmax);
+    }
+    if (io_bf16 == 2) {
+        if (W <= 16) return launch_dwconv7<16, 16, true, false>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S);
+        return launch_dwconv7<32, 8, true, false>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S);
     }
     if (io_bf16) {
         if (W <= 16) return launch_dwconv7<16, 16, true>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S);

@@ -359,7 +359,8 @@ int cdf_dwconv7_wgrad_nchunk(int H);
 int cdf_dwconv7_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* dbias, float* dsb,
                       int ld_dsb, float* ws, int B, int H, int W, int C, int accumulate, void* stream);
 /* bf16 activation storage: io_bf16 != 0 -> x, y, res (forward / data gradient) resp. x, dy (weight gradient) are bf16 tensors; weights,
- * biases, partial sums and the gradients written stay fp32 */
+ * biases, partial sums and the gradients written stay fp32.  cdf_dwconv7_io with io_bf16 == 2: x and res bf16, y fp32 (the data gradient
+ * the bf16 stream hands to the fp32 tensors of the image-side block). */
 int cdf_dwconv7_io(const void* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias, int ld_sbias,
                    void* y, int ldy, int B, int H, int W, int C, int flip, int accumulate, const void* res, int ldr, int io_bf16,
                    void* stream);

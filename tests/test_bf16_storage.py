@@ -51,6 +51,11 @@ def test_dwconv7_bf16_io(be, B, C, H):
         be.L.cdf_dwconv7(P(xf), Cp, *args, P(yref), Cp, B, H, H, Cp, flip, 0, P(rf) if with_res else 0, Cp, be.stream())
         be.L.cdf_dwconv7_io(P(xb), Cp, *args, P(y), Cp, B, H, H, Cp, flip, 0, P(rb) if with_res else 0, Cp, 1, be.stream())
         assert torch.equal(y.cpu(), rbf(yref)), (flip, with_res)
+    # io_bf16 = 2: bf16 x / res, fp32 y (the data gradient handed to the image-side block's fp32 tensors): the fp32 kernel's result exactly
+    y32, yref2 = be.empty(B, H, H, Cp), be.empty(B, H, H, Cp)
+    be.L.cdf_dwconv7(P(xf), Cp, P(wp), Cp, 0, 0, 0, P(yref2), Cp, B, H, H, Cp, 1, 0, P(rf), Cp, be.stream())
+    be.L.cdf_dwconv7_io(P(xb), Cp, P(wp), Cp, 0, 0, 0, P(y32), Cp, B, H, H, Cp, 1, 0, P(rb), Cp, 2, be.stream())
+    assert torch.equal(y32.cpu(), yref2.cpu())
     # accumulate: y (bf16) += conv(x), read back in its own type
     y0 = torch.randn(B, H, H, Cp)
     yacc, yref = be.to(bf(y0)), be.to(bf(y0).float())
@@ -198,7 +203,8 @@ def test_unet_bf16_storage_vs_oracle(mbe, bf16_mode, monkeypatch, dim, mults, si
         h.remove()
     y.backward(mbe.to(gy))
     assert seen["downs.0.0"] == (torch.float32, torch.float32)                    # the image-side block: 4-channel fp32 tensors
-    assert all(v == (torch.bfloat16, torch.bfloat16) for k, v in seen.items() if k != "downs.0.0"), seen
+    assert seen["downs.0.1"] == (torch.float32, torch.bfloat16)                   # ... whose output enters the stream inside the next block
+    assert all(v == (torch.bfloat16, torch.bfloat16) for k, v in seen.items() if k not in ("downs.0.0", "downs.0.1")), seen
     assert (torch.bfloat16, 4) in saved_dtypes
     e = (y.cpu() - yr.detach()).abs().max().item()
     worst, name = _grad_worst(net, {k: v.grad for k, v in ps.items()})
@@ -271,3 +277,44 @@ def test_stored_gelu_derivative_is_bit_identical(mbe, monkeypatch):
         y.backward(dy)
         outs.append([y.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in blk.parameters()])
     assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
+@pytest.mark.parametrize("B,n,heads", [(2, 70, 4), (1, 300, 2)])
+def test_linattn_bwd_kv_planes(be, B, n, heads):
+    """cdf_linattn_bwd_kv_planes: dk | dv as bf16 hi / lo operand planes must be cdf_split_bf16 of what cdf_linattn_bwd_kv writes in fp32,
+    bit for bit (hi-only planes: the rounding of it)."""
+    torch.manual_seed(n)
+    HD = heads * 32
+    kv = be.to(torch.randn(B, n, 2 * HD))
+    k = kv[..., :HD].cpu()
+    kmax = k.max(1).values
+    ksum = torch.exp(k - kmax[:, None]).sum(1)
+    dctx, rvec = be.to(torch.randn(B, heads, 32, 32) * 0.3), be.to(torch.randn(B, HD))
+    km, ks = be.to(kmax), be.to(ksum)
+    ref = be.zeros(B, n, 2 * HD)
+    be.L.cdf_linattn_bwd_kv(P(kv), 2 * HD, 0, P(dctx), P(rvec), P(km), P(ks), P(ref), 2 * HD, 0, B, n, heads, be.stream())
+    hi, lo, hi1 = (torch.zeros(B, n, 2 * HD, dtype=torch.int16, device=be.device) for _ in range(3))
+    be.L.cdf_linattn_bwd_kv_planes(P(kv), 2 * HD, 0, P(dctx), P(rvec), P(km), P(ks), P(hi), P(lo), 2 * HD, 0, B, n, heads, be.stream())
+    be.L.cdf_linattn_bwd_kv_planes(P(kv), 2 * HD, 0, P(dctx), P(rvec), P(km), P(ks), P(hi1), 0, 2 * HD, 0, B, n, heads, be.stream())
+    rh, rl = (torch.zeros(B, n, 2 * HD, dtype=torch.int16, device=be.device) for _ in range(2))
+    be.L.cdf_split_bf16(P(ref), 2 * HD, P(rh), P(rl), 2 * HD, B * n, 2 * HD, be.stream())
+    assert torch.equal(hi.cpu(), rh.cpu()) and torch.equal(lo.cpu(), rl.cpu()) and torch.equal(hi1.cpu(), rh.cpu())
+    assert ref.abs().max().item() > 0.01
+
+
+def test_conv_gemm_io_reads_and_writes_the_bf16_stream(be):
+    """cdf_conv_gemm_io, the exact-fp32 GEMM at the attention block's boundary: a batched (per image) launch whose residual operand is a
+    bf16 tensor and whose result goes out as a bf16 plane only -- against the fp32 launch on the widened residual, rounded."""
+    from colddiff import convdesc as cd
+    torch.manual_seed(6)
+    B, n, dim = 3, 80, 64
+    xn, Nb = be.to(torch.randn(B, n, dim)), be.to(torch.randn(B, dim, dim) / 8)
+    bias, res = be.to(torch.randn(dim)), torch.randn(B, n, dim + 8)
+    desc = cd.conv_fwd(1, n, 1, 1, 1, 0, 0, 0, 0).desc
+    yref = be.empty(B, n, dim)
+    be.L.cdf_conv_gemm(P(xn), dim, P(Nb), dim, P(yref), dim, 1, 1, n, dim, 1, n, dim, 1, n, 1, 1, 1, desc, P(bias), 0, 0, P(be.to(bf(res).float())), dim + 8,
+                       0, 0, 0, 0, 0, 0, 0, 0, B, n * dim, dim * dim, n * dim, 1, 0, 0, 0, be.stream())
+    y = torch.zeros(B, n, dim + 8, dtype=torch.bfloat16, device=be.device)          # (a pitched destination: a slice of a concat buffer)
+    be.L.cdf_conv_gemm_io(P(xn), dim, P(Nb), dim, 0, dim + 8, 1, 1, n, dim, 1, n, dim, 1, n, 1, 1, 1, desc, P(bias), 0, 0, P(be.to(bf(res))), dim + 8,
+                          0, 0, 0, 0, 0, 0, 0, 0, B, n * dim, dim * dim, n * (dim + 8), 1, 0, 0, 0, 1, P(y), dim + 8, be.stream())
+    assert torch.equal(y[..., :dim].cpu(), rbf(yref)) and (y[..., dim:].cpu() == 0).all()

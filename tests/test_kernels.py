@@ -520,6 +520,9 @@ def test_pack_many_matches_single_packs(be):
     conv(33, 70, 3, False)
     conv(64, 32, 4, True, want_lo=False)
     conv(48, 20, 1, True)
+    conv(64, 96, 3, True)            # 32-aligned channel counts: the data-gradient layouts take the LDS-tiled path (source-contiguous reads)
+    conv(128, 64, 3, False)
+    conv(96, 32, 4, True)
     wl = torch.randn(50, 36)
     ents.append((wl, 1, 36, 50, 52, 0, 1, 36, False, False))                              # lin_fwd
     L, S = be.L, be.stream()
