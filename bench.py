@@ -448,6 +448,58 @@ def bandwidth_classes():
     return out
 
 
+TAIL_CLASSES = (   # (class, kernel-name prefixes) -- everything that is NOT one of the two pre-split GEMM groups
+    ("pre_split_fwd_dgrad_gemm", ("conv_igemm_halo_kernel", "conv_igemm_rowhalo_stream_kernel", "conv_igemm_spx_kernel", "conv_splitk_finish_kernel")),
+    ("pre_split_wgrad_gemm", ("conv_wgrad_row3_kernel", "conv_wgrad_spx_kernel")),
+    ("depthwise_7x7", ("dwconv7_kernel", "dwconv7_wgrad_partial")),
+    ("layernorm", ("layernorm_c_",)),
+    ("in_kernel_split_gemm", ("conv_igemm_sp_kernel", "conv_wgrad_sp_kernel", "linattn_kvctx_kernel")),
+    ("exact_fp32_gemm", ("conv_igemm_kernel", "conv_wgrad_kernel")),
+    ("splitk_and_column_reductions", ("unpack_reduce", "colsum_", "norm_param_reduce_kernel", "dwconv7_wgrad_final_kernel")),
+    ("operand_split_and_weight_packing", ("split_bf16_kernel", "widen_bf16_kernel", "pack_")),
+    ("linear_attention", ("linattn_",)),
+    ("direct_3_channel_convs", ("conv_cin4_", "tapsum3_kernel")),
+    ("time_mlp", ("linear_small", "act_", "sinusoidal_kernel")),
+    ("adam_ema", ("adam_kernel", "ema_kernel")),
+    ("copies_and_fills", ("__amd_rocclr_", "at::native")),
+)
+
+
+def tail_ms_per_step(profile_name="kernel_trace.json"):
+    """Kernel time per optimizer step by class from the committed rocprofv3 --kernel-trace of this same command (steps = adam_kernel
+    launches), and `tail_ms` = everything outside the two pre-split GEMM groups (the tail as a driver-visible number).
+    Quoted only from a profile of the kernel sources that are running."""
+    kp = _profile(profile_name)
+    if not kp:
+        return None
+    trace = json.load(open(kp))
+    prov = _provenance(kp, trace)
+    if not prov["match"]:
+        return {"stale": True, "provenance": prov}
+    steps = (trace.get("adam_kernel") or {}).get("calls") or 0
+    if not steps:
+        return None
+    per = {c: 0.0 for c, _ in TAIL_CLASSES}
+    per["other"] = 0.0
+    launches = 0
+    for name, v in trace.items():
+        if not isinstance(v, dict) or "total_ms" not in v:
+            continue
+        launches += v["calls"]
+        for c, prefixes in TAIL_CLASSES:
+            if name.startswith(prefixes):
+                per[c] += v["total_ms"]
+                break
+        else:
+            per["other"] += v["total_ms"]
+    out = {c: round(ms / steps, 3) for c, ms in per.items()}
+    gemm = out["pre_split_fwd_dgrad_gemm"] + out["pre_split_wgrad_gemm"]
+    total = sum(out.values())
+    return {"by_class_ms": out, "kernel_ms": round(total, 3), "tail_ms": round(total - gemm, 3), "dispatches_per_step": round(launches / steps, 1),
+            "steps_in_profile": steps, "source": os.path.relpath(kp, REPO) + " (rocprofv3 --kernel-trace of this command; the first steps of a run "
+            "include initialisation copies / packs)", "provenance": prov}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -595,6 +647,9 @@ def main():
         bw = bandwidth_classes()
         if bw:
             out["hbm_bound_kernel_classes"] = bw
+        tail = tail_ms_per_step()
+        if tail:
+            out["tail_ms_per_step"] = tail
         if world == 1 and not args.no_sample:
             with torch.no_grad():
                 noise = torch.randn(args.sample_batch, 3, 128, 128, device=device)
@@ -663,6 +718,9 @@ def main():
                                     # the accounting describes the engine that runs: SURVEY 8(d)'s bf16 column (A_train = 549 MB / image) now that the
                                     # tensors between kernels ARE bf16
                                     "step_roofline": step_roofline(args.batch, args.accum, 1000 * dtb, 1, act="bf16" if stored_bf16 else "f32")}
+                tb = tail_ms_per_step("kernel_trace_bf16.json")
+                if tb:
+                    out["bf16_mode"]["tail_ms_per_step"] = tb
                 mbb = measured_bytes_step("pmc_traffic_bf16.json")
                 if mbb:
                     out["bf16_mode"]["step_roofline"]["measured_hbm_bytes_step"] = mbb["bytes_step"]
