@@ -45,3 +45,21 @@ def test_bench_refuses_a_mismatched_world():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
                        env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}, cwd=REPO)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_tail_ms_per_step_reads_the_committed_trace():
+    """bench.py's `tail_ms_per_step` (the tail as a driver-visible number): classes from the newest committed
+    rocprofv3 kernel trace -- quoted only when its source digest equals the running sources', every kernel in exactly one class."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    t = b.tail_ms_per_step()
+    assert t is not None
+    if t.get("stale"):                                       # (a tree whose kernels changed after the profile was taken: nothing is quoted)
+        assert not t["provenance"]["match"]
+        return
+    cls = t["by_class_ms"]
+    assert abs(sum(cls.values()) - t["kernel_ms"]) < 0.01
+    assert abs(t["kernel_ms"] - cls["pre_split_fwd_dgrad_gemm"] - cls["pre_split_wgrad_gemm"] - t["tail_ms"]) < 0.01
+    assert cls["other"] < 0.02 * t["kernel_ms"] and t["steps_in_profile"] >= 4 and t["dispatches_per_step"] > 100
