@@ -318,3 +318,27 @@ def test_conv_gemm_io_reads_and_writes_the_bf16_stream(be):
     be.L.cdf_conv_gemm_io(P(xn), dim, P(Nb), dim, 0, dim + 8, 1, 1, n, dim, 1, n, dim, 1, n, 1, 1, 1, desc, P(bias), 0, 0, P(be.to(bf(res))), dim + 8,
                           0, 0, 0, 0, 0, 0, 0, 0, B, n * dim, dim * dim, n * (dim + 8), 1, 0, 0, 0, 1, P(y), dim + 8, be.stream())
     assert torch.equal(y[..., :dim].cpu(), rbf(yref)) and (y[..., dim:].cpu() == 0).all()
+
+
+@pytest.mark.parametrize("kw", [dict(channels=1), dict(with_time_emb=False), dict(residual=True), dict(dim_mults=(1, 2, 4, 8))])
+def test_unet_variants_on_the_bf16_stream(mbe, bf16_mode, kw):
+    """The constructor variants the reference's scripts use (one-channel MNIST net, no time embedding, residual output, four levels) on the
+    bf16 stream: forward within the mode's tolerance of the fp32 oracle, backward runs (gradients finite, every parameter reached)."""
+    from colddiff.runtime import BF16_TOLERANCE
+    from deblurring_diffusion_pytorch import Unet
+    from oracle import cold_oracle as O
+    torch.manual_seed(13)
+    args = dict(dim=8, dim_mults=(1, 2), channels=3)
+    args.update(kw)
+    net = quiet(Unet, **args)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    C = args["channels"]
+    x, t = torch.rand(2, C, 16, 16) * 2 - 1, torch.tensor([0, 7])
+    with torch.no_grad():
+        yr = O.unet_forward(sd, x, t, residual=args.get("residual", False))
+    net = net.to(mbe.device)
+    y = net(mbe.to(x), mbe.to(t))
+    assert (y.cpu() - yr).abs().max().item() <= BF16_TOLERANCE["forward_max_abs"]
+    y.backward(mbe.to(torch.randn(2, C, 16, 16) / 100))
+    for n, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
