@@ -314,10 +314,19 @@ SEC_STEPS, SEC_WARMUP = 20, 5            # secondary workloads: timed steps / wa
 SEC_TIMING = "%d timed steps after %d warm-up" % (SEC_STEPS, SEC_WARMUP)
 
 
+def _dtype_label():
+    from colddiff import runtime
+    if runtime.precision == "f32":
+        return "f32 everywhere: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) for every GEMM"
+    return "f32 storage/accumulate; dense-conv GEMM operands " + runtime.precision
+
+
 def secondary_workloads(device):
-    """BASELINE configs 1, 2, 4 and 5 on the same engine (secondary keys; the judged line stays config 3)."""
+    """BASELINE configs 1, 2, 4 and 5 on the same engine (secondary keys; the judged line stays config 3).  Every entry names its
+    arithmetic (`dtype`); configs 1 and 2 -- fp32 in BASELINE.json -- are ALSO timed in the exact-fp32 mode (`*_f32`)."""
     import contextlib
     import io
+    from colddiff import runtime
     from colddiff.trainer import Trainer
     out = {}
     quiet = lambda: contextlib.redirect_stdout(io.StringIO())
@@ -333,7 +342,7 @@ def secondary_workloads(device):
                      dataset='synthetic', results_folder=res)
     tr.quiet = True
     dt = timed_train(tr, SEC_STEPS, SEC_WARMUP)
-    out["cfg4_celeba128_deblur_train"] = {"img_per_s": round(64 / dt, 1), "ms_per_step": round(1000 * dt, 2), "timing": SEC_TIMING,
+    out["cfg4_celeba128_deblur_train"] = {"img_per_s": round(64 / dt, 1), "ms_per_step": round(1000 * dt, 2), "timing": SEC_TIMING, "dtype": _dtype_label(),
                                           "workload": "Unet(64,(1,2,4,8)) @128x128, blur Exponential_reflect T=200 k=15 std=0.01, 2 x 32 img + Adam"}
     with torch.no_grad():
         x = tr._next_batch()[:16]
@@ -345,28 +354,36 @@ def secondary_workloads(device):
             d.sample(batch_size=16, img=x)
         torch.cuda.synchronize()
         dts = time.perf_counter() - t0
-    out["cfg4_celeba128_deblur_sample"] = {"ms_per_img": round(1000 * dts / 16, 2), "batch": 16,
+    out["cfg4_celeba128_deblur_sample"] = {"ms_per_img": round(1000 * dts / 16, 2), "batch": 16, "dtype": _dtype_label(),
                                            "workload": "Algorithm 2 (x0_step_down), T=200: 200 UNet calls + D(x0,t), D(x0,t-1) blur chains (T(T+1)/2 steps each) per image"}
     del tr, d, net
     torch.cuda.empty_cache()
     # ---- config 2: CIFAR-10 deblurring, Model(ch=128,(1,2,2,2)), Special_6_routine T=50, batch 128 (cifar10_train.py) -----
-    torch.manual_seed(123457)
-    with quiet():
-        net = Model(resolution=32, in_channels=3, out_ch=3, ch=128, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,), dropout=0.1).to(device)
-        d = GaussianDiffusion(net, image_size=32, device_of_kernel='cuda', channels=3, timesteps=50, loss_type='l1', kernel_std=0.1, kernel_size=11,
-                              blur_routine='Special_6_routine', train_routine='Final', sampling_routine='x0_step_down').to(device)
-        tr = Trainer(d, None, image_size=32, train_batch_size=128, train_lr=2e-5, train_num_steps=10 ** 9, gradient_accumulate_every=2,
-                     dataset='synthetic', results_folder=res)
-    tr.quiet = True
-    dt = timed_train(tr, SEC_STEPS, SEC_WARMUP, reps=3)
-    out["cfg2_cifar10_deblur_train"] = {"img_per_s": round(256 / dt, 1), "ms_per_step": round(1000 * dt, 2), "timing": SEC_TIMING + ", median of 3",
-                                        "workload": "Model(ch=128,(1,2,2,2),attn@16,dropout 0.1) @32x32, blur Special_6_routine T=50, 2 x 128 img + Adam"}
-    del tr, d, net
-    torch.cuda.empty_cache()
+    def cfg2(key):
+        torch.manual_seed(123457)
+        with quiet():
+            net = Model(resolution=32, in_channels=3, out_ch=3, ch=128, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,), dropout=0.1).to(device)
+            d = GaussianDiffusion(net, image_size=32, device_of_kernel='cuda', channels=3, timesteps=50, loss_type='l1', kernel_std=0.1, kernel_size=11,
+                                  blur_routine='Special_6_routine', train_routine='Final', sampling_routine='x0_step_down').to(device)
+            tr = Trainer(d, None, image_size=32, train_batch_size=128, train_lr=2e-5, train_num_steps=10 ** 9, gradient_accumulate_every=2,
+                         dataset='synthetic', results_folder=res)
+        tr.quiet = True
+        dt = timed_train(tr, SEC_STEPS, SEC_WARMUP, reps=3)
+        out[key] = {"img_per_s": round(256 / dt, 1), "ms_per_step": round(1000 * dt, 2), "timing": SEC_TIMING + ", median of 3", "dtype": _dtype_label(),
+                    "workload": "Model(ch=128,(1,2,2,2),attn@16,dropout 0.1) @32x32, blur Special_6_routine T=50, 2 x 128 img + Adam"}
+        del tr, d, net
+        torch.cuda.empty_cache()
+
+    cfg2("cfg2_cifar10_deblur_train")
+    if runtime.precision != "f32":
+        with runtime.precision_scope("f32"):
+            runtime.bump_weights_epoch()
+            cfg2("cfg2_cifar10_deblur_train_f32")
+        runtime.bump_weights_epoch()
     # ---- configs 1 and 5 (the remaining BASELINE configurations; the builders are those of tools/cfgbench.py) ---------------------------
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import cfgbench
-    for cfg, key in (("1", "cfg1_mnist32_deblur_train"), ("5r", "cfg5_afhq128_resolution_train"), ("5f", "cfg5_afhq128_defading_train")):
+    def other(cfg, key):
         torch.manual_seed(123457)
         d, size, batch, desc = cfgbench.build(cfg, device)
         with quiet():
@@ -376,15 +393,23 @@ def secondary_workloads(device):
         reps = 3 if cfg == "1" else 1
         dt = timed_train(tr, SEC_STEPS, SEC_WARMUP, reps=reps)
         out[key] = {"img_per_s": round(2 * batch / dt, 1), "ms_per_step": round(1000 * dt, 2), "workload": desc + ", 2 micro-steps + Adam",
-                    "timing": SEC_TIMING + (", median of 3" if reps > 1 else "")}
+                    "timing": SEC_TIMING + (", median of 3" if reps > 1 else ""), "dtype": _dtype_label()}
         del tr, d
         torch.cuda.empty_cache()
+
+    for cfg, key in (("1", "cfg1_mnist32_deblur_train"), ("5r", "cfg5_afhq128_resolution_train"), ("5f", "cfg5_afhq128_defading_train")):
+        other(cfg, key)
+    if runtime.precision != "f32":
+        with runtime.precision_scope("f32"):
+            runtime.bump_weights_epoch()
+            other("1", "cfg1_mnist32_deblur_train_f32")
+        runtime.bump_weights_epoch()
     return out
 
 
 def _profile(name):
     """Newest committed profiles/round<N>_<name> (bench.py cannot run the profiler on itself)."""
-    for rnd in (5, 4, 3, 2, 1):
+    for rnd in (6, 5, 4, 3, 2, 1):
         path = os.path.join(REPO, "profiles", "round%d_%s" % (rnd, name))
         if os.path.exists(path):
             return path

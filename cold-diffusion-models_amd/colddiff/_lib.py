@@ -112,13 +112,15 @@ class GemmTuning:
                            ("COLDDIFF_WGRAD_ROW3", "wgrad_row3"), ("COLDDIFF_ROWHALO_STREAM", "rowhalo_stream"), ("COLDDIFF_WGRAD_SWIZZLE", "wgrad_swizzle"), ("COLDDIFF_WGRAD_STACK", "wgrad_stack"), ("COLDDIFF_RESIDENT_RESERVE", "resident_reserve")):
             if env(var):
                 v = int(env(var))
-                lo, hi = self._RANGE.get(field, (None, None))
-                if lo is not None and not lo <= v <= hi:       # named here: the library only says `bad cdf_gemm_tuning` (on every GEMM call)
-                    raise ValueError(f"{var}={v}: cdf_gemm_tuning.{field} takes {lo}..{hi}")
+                ok = self._ALLOWED.get(field)
+                if ok is not None and v not in ok:             # named here: the library only says `bad cdf_gemm_tuning` (on every GEMM call)
+                    raise ValueError(f"{var}={v}: cdf_gemm_tuning.{field} takes " + (f"{ok.start}..{ok.stop - 1}" if isinstance(ok, range) else "/".join(map(str, sorted(ok)))))
                 self.set(**{field: v})
         return self
 
-    _RANGE = {"rowhalo_stream": (0, 1), "resident_reserve": (0, 248), "halo_bm": (0, 256), "max_bm": (0, 256)}
+    # the values cdf_tune_ok (csrc/k_conv_sp.hip) accepts, field by field
+    _ALLOWED = {"rowhalo_stream": (0, 1), "resident_reserve": range(0, 249), "halo_bm": (0, 128, 256), "max_bm": (0, 128, 256),
+                "tile_bm": (0, 64, 128, 256), "tile_bn": (0, 64, 128), "halo": range(0, 128)}
 
 
 # int-returning entry points that are pure host-side queries (sizes / counts), not status codes

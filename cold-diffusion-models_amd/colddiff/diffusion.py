@@ -735,8 +735,21 @@ class ResolutionDiffusion(TwoPhase, nn.Module):
             self._sizes_cache[key] = torch.tensor(self._sizes_host, dtype=torch.int32, device=device)
         return self._sizes_cache[key]
 
-    def transform_func(self, img, i):
-        """One degradation step func[i] (RESOL:354-385)."""
+    def transform_func(self, img, dec_size, mode, do_blur=False):
+        """The reference's one-step operator with its own signature (RESOL:354-385): [3x3 blur ->] interpolate down to H - dec_size in
+        `mode` -> nearest-exact back up [-> 3x3 blur].  `func[i]` of the reference is this with the routine's (dec_size, mode, do_blur)."""
+        img = rt.check(img)
+        if do_blur:
+            taps = self._blur_taps.to(img.device)
+            img = D.blur_step(img, taps, 3, 1)
+        size = torch.tensor([img.shape[2] - int(dec_size)], dtype=torch.int32, device=img.device)
+        img = D.pixelate_chain(img, size, D.PIX_MODES[mode], step_lo=0, step_hi=0)
+        if do_blur:
+            img = D.blur_step(img, taps, 3, 1)
+        return img
+
+    def _step(self, img, i):
+        """func[i] with the step's size read from the device-resident table (no host tensor per call)."""
         img = rt.check(img)
         if self._with_blur:
             taps = self._blur_taps.to(img.device)
@@ -747,7 +760,7 @@ class ResolutionDiffusion(TwoPhase, nn.Module):
         return img
 
     def get_funcs(self):
-        return [(lambda img, i=i: self.transform_func(img, i)) for i in range(self.num_timesteps)]
+        return [(lambda img, i=i: self._step(img, i)) for i in range(self.num_timesteps)]
 
     def _degrade(self, x, nsteps, t=None, img=None):
         if not self._with_blur:
@@ -756,7 +769,7 @@ class ResolutionDiffusion(TwoPhase, nn.Module):
         prev = x
         for i in range(nsteps):
             prev = x
-            x = self.transform_func(x, i)
+            x = self._step(x, i)
         return D.x0_step_down(img, x, prev) if img is not None else x
 
     @torch.no_grad()
@@ -837,7 +850,7 @@ class ResolutionDiffusion(TwoPhase, nn.Module):
         img = rt.check(img)
         Forward = [img]
         for i in range(t):
-            img = self.transform_func(img, i)
+            img = self._step(img, i)
             Forward.append(img)
         Backward = []
         while times:
@@ -861,7 +874,7 @@ class ResolutionDiffusion(TwoPhase, nn.Module):
         max_iters = int(torch.max(t))
         x, out = x_start, torch.empty_like(x_start)
         for i in range(max_iters + 1):
-            x = self.transform_func(x, i)
+            x = self._step(x, i)
             out = torch.where((t == i).view(-1, 1, 1, 1), x, out)
         return out
 

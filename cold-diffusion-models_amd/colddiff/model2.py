@@ -161,6 +161,13 @@ class Model(nn.Module):
         self.register_buffer("_freq", freq, persistent=False)
 
     def forward(self, x, t):
+        # no-grad calls are the samplers' (iterated) ones: exact-fp32 GEMMs there (runtime.MODEL_SAMPLE_PRECISION has the why)
+        if rt.precision == "bf16x3" and rt.MODEL_SAMPLE_PRECISION == "f32" and not torch.is_grad_enabled():
+            with rt.precision_scope("f32"):
+                return self._forward(x, t)
+        return self._forward(x, t)
+
+    def _forward(self, x, t):
         rt.check(x)
         assert x.shape[2] == x.shape[3] == self.resolution
         assert self.ch % 2 == 0, "odd embedding widths (zero pad, Model2.py:22) are not used by the scripts"

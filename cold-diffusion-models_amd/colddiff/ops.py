@@ -998,7 +998,7 @@ def conv_gemm_bf(plan, x, Cin, wp, Cout, y=None, bias=None, sbias=None, res=None
     assert is_bf(x) and wp[1] is None and Cin % 8 == 0 and Cout % 4 == 0
     B = x.shape[0]
     if y is None:
-        y = torch.empty((B, plan.OH, plan.OW, Cout), device=x.device, dtype=BF)
+        y = new_bf(x, B, plan.OH, plan.OW, Cout)             # (asserts Cout % 8: a bf16 tensor must be a legal operand plane of the next GEMM)
     ldv = lambda t: 0 if t is None else ld_of(t)
     M = B * plan.QH * plan.QW
     ws, nws = None, 0

@@ -426,6 +426,7 @@ class Trainer(EvalMixin):
                 self._pending_q.append(self._launch_prepare())
         else:
             preps = [self._prepare_micro() for _ in range(acc)]
+        oom = False
         try:
             prep = tuple(torch.cat(parts) for parts in zip(*preps))
             loss = torch.mean(self.core.loss_prepared(prep))          # = the mean of the micro-batch losses (equal sizes)
@@ -436,12 +437,19 @@ class Trainer(EvalMixin):
         except torch.OutOfMemoryError:
             # FUSE_MAX_PIXELS counts pixels, not model width: a wide model / a shared device may not hold `acc` micro-batches of
             # activations where the reference's one-by-one loop fits.  Single rank only (on several ranks the others are already inside
-            # their collectives): drop what the aborted pass left, switch fusion off for this Trainer and run the SAME prepared
-            # micro-batches one after the other -- the step's data, t and noise draws are unchanged.
+            # their collectives).  Only a flag is set here: while this handler runs, the exception's traceback keeps every frame of the
+            # aborted pass alive (Unet.forward's skip list, the nodes' locals, the partial graph with its saved activations), so the retry
+            # happens AFTER the handler, when all of that has been released.
             if self.sync is not None:
                 raise
+            oom = True
+        if oom:
+            # drop what the aborted pass left, switch fusion off for this Trainer and run the SAME prepared micro-batches one after the
+            # other -- the step's data, t and noise draws are unchanged
+            import gc
             prep = loss = None
             self._fuse_off = True
+            gc.collect()
             torch.cuda.empty_cache()
             self.opt.zero_grad()
             print(f"fused accumulation of {acc} micro-batches does not fit in device memory: running them one by one from here on")
@@ -759,6 +767,30 @@ class ResolutionTrainer(Trainer):
         if dataset == 'flower':
             return AUG2
         return CENTER112
+
+    def sample_as_a_mean_blur_torch_gmm_ablation(self, torch_gmm, siz=2, ch=3, clusters=10, sample_at=6, noise=0, num_samples=6400, bs=64):
+        """RESOL:1117-1182 (this package's form of the method: the GMM is fitted on the `siz` x `siz` area-resampled degradations
+        `opt(img, t=sample_at)` of the dataset, its samples are blown up nearest-exact and handed to `gen_sample`)."""
+        import torch.nn.functional as F
+        from .evaluate import _create_folder
+        feats = [F.interpolate(self.ema_core.opt(img, t=sample_at), size=siz, mode='area').flatten(1) for img in self._dataset_batches(100)]
+        model = self._fit_gmm(torch_gmm, torch.cat(feats, dim=0), clusters, 100)
+        n = self.image_size
+        og_x = F.interpolate(model.sample(num_datapoints=num_samples).to(self.device).reshape(num_samples, 3, siz, siz).float(), size=n,
+                             mode='nearest-exact')
+        xt_folder, out_folder, dr_folder = f'{self.results_folder}_xt', f'{self.results_folder}_out', f'{self.results_folder}_dir_recons'
+        for f in (xt_folder, out_folder, dr_folder):
+            _create_folder(f)
+        cnt = 0
+        for j in range(num_samples // bs):
+            og_img = og_x[j * bs: j * bs + bs].expand(bs, ch, n, n).float().contiguous()
+            xt, direct_recons, all_images = self.ema_core.gen_sample(batch_size=bs, img=og_img, noise_level=noise)
+            for i in range(all_images.shape[0]):
+                self._save(all_images[i:i + 1], f'{out_folder}/sample-x0-{cnt}.png', nrow=1)
+                self._save(xt[i:i + 1], f'{xt_folder}/sample-x0-{cnt}.png', nrow=1)
+                self._save(direct_recons[i:i + 1], f'{dr_folder}/sample-x0-{cnt}.png', nrow=1)
+                cnt += 1
+        return cnt
 
 
 class DefadeTrainer(Trainer):
