@@ -151,3 +151,266 @@ __device__ __forceinline__ void cdf_epilogue_rows(const Args& a, const Phase& ph
             cdf_split_store4(a.ys_hi + o_ys, a.ys_lo ? a.ys_lo + o_ys : nullptr, v);
     }
 }
+
+// ================================================================================================
+// Specialised epilogues (round 6).  cdf_epilogue_rows above selects every variant per ROW at run time; compiled, that is a rolled loop of
+// ~1100 instructions and 118 branches in which every fused operand load (residual, GELU' source, accumulate) sits inside a branch --
+// hipcc waits vmcnt(0) right behind such a load, and on gfx9 stores count in vmcnt too, so each row waited for its own load AND for the
+// previous row's stores to be acknowledged: 8-16 dependent HBM round trips per thread and tile (ISA of round 5, VERDICT r5 Weak 6).
+// Here the operation list is a template parameter (EpiSpec), the pass is straight-line code, and it is split in two halves:
+//   load()   issues every operand load of the pass -- before the accumulators go through LDS, so they fly under the ds_writes and the barrier,
+//   finish() reads the transposed rows, applies bias / activation / multiply / residual and stores; stores come after all loads in
+//            program order, so no wait on a load ever waits for a store.
+// Preconditions (checked by cdf_epi_select on the host + cdf_epi_tile_ok in the kernel, else the generic form runs): the vector layout
+// (Args::vec), output pixel == GEMM row (os == 1, QH == OH, QW == OW), whole tiles (M % rows-per-block-tile == 0, Cout % BN == 0: no thread
+// leaves early, the code has no divergent branch at all), one image per tile
+// when there is a per-sample bias.  Same arithmetic in the same order as cdf_epilogue_rows: bit-identical results.
+// ================================================================================================
+typedef unsigned cdf_u32x2 __attribute__((ext_vector_type(2)));
+#ifdef CDF_EMU
+#define CDF_OPAQUE_V(x) ((void)0)
+#else
+#define CDF_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#endif
+
+// ACT: 0 none, 1 GELU, 2 SiLU.  PRE: 0 none, 1 pre-activation stored, 2 act'(pre-activation) stored.  MUL: 0 none, 1 x GELU'(mul), 2 x SiLU'(mul),
+// 3 x mul.  RES: + residual.  ACC: + previous contents of Y.  HASY: fp32 output written.  YS: 0 no planes, 1 bf16 hi plane, 2 hi + lo planes.
+// IO: CDF_IO_{RES,PRE,MUL}_BF16 bits (that operand is a bf16 tensor).
+template <int ACT_, int PRE_, int MUL_, bool RES_, bool ACC_, bool HASY_, int YS_, int IO_>
+struct EpiSpec {
+    static constexpr int ACT = ACT_, PRE = PRE_, MUL = MUL_, YS = YS_, IO = IO_;
+    static constexpr bool RES = RES_, ACC = ACC_, HASY = HASY_;
+};
+// the instantiated list; ids are what cdf_epi_select returns (0 = generic).  1..6: fp32 tensors (split-precision mode), 7..11: bf16 activation storage
+typedef EpiSpec<0, 0, 0, false, false, true, 0, 0> EpiPlain;                                  // 1  [bias] -> Y
+typedef EpiSpec<0, 0, 0, true, false, true, 0, 0> EpiRes;                                     // 2  [bias] + residual -> Y
+typedef EpiSpec<1, 1, 0, false, false, false, 2, 0> EpiGeluPrePlanes;                         // 3  bias, pre stored, GELU -> hi / lo planes
+typedef EpiSpec<1, 0, 0, false, false, false, 2, 0> EpiGeluPlanes;                            // 4  bias, GELU -> hi / lo planes (no-grad forward)
+typedef EpiSpec<0, 0, 1, false, false, false, 2, 0> EpiMulGeluPlanes;                         // 5  x GELU'(pre) -> hi / lo planes
+typedef EpiSpec<0, 0, 0, false, true, true, 0, 0> EpiAcc;                                     // 6  Y += .
+typedef EpiSpec<0, 0, 0, false, false, false, 1, 0> EpiBfPlain;                               // 7  [bias] -> bf16
+typedef EpiSpec<0, 0, 0, true, false, false, 1, CDF_IO_RES_BF16> EpiBfRes;                    // 8  [bias] + bf16 residual -> bf16
+typedef EpiSpec<1, 1, 0, false, false, false, 1, CDF_IO_PRE_BF16> EpiBfGeluPre;               // 9  bias, bf16 pre stored, GELU -> bf16
+typedef EpiSpec<1, 0, 0, false, false, false, 1, 0> EpiBfGelu;                                // 10 bias, GELU -> bf16
+typedef EpiSpec<0, 0, 1, false, false, false, 1, CDF_IO_MUL_BF16> EpiBfMulGelu;               // 11 x GELU'(bf16 pre) -> bf16
+#define CDF_EPI_NSPEC 11
+
+// host side: the id of the specialised epilogue that computes exactly what these arguments ask for, or 0
+template <class Args>
+static inline int cdf_epi_select(const Args& a) {
+    if (!a.vec || a.os != 1 || a.QH != a.OH || a.QW != a.OW) return 0;
+    const bool pre = a.pre != nullptr, mul = a.mul_mode != 0, res = a.res != nullptr, acc = a.accumulate != 0, y = a.y != nullptr;
+    const int ys = a.ys_hi ? (a.ys_lo ? 2 : 1) : 0, io = a.io_bf;
+    if (io & CDF_IO_PRE_GRAD) return 0;
+    auto is = [&](int ACT, int PRE, int MUL, bool RES, bool ACC, bool HASY, int YS, int IO) {
+        return a.act == ACT && (pre ? 1 : 0) == PRE && a.mul_mode == MUL && res == RES && acc == ACC && y == HASY && ys == YS &&
+               (io & ((PRE ? CDF_IO_PRE_BF16 : 0) | (MUL ? CDF_IO_MUL_BF16 : 0) | (RES ? CDF_IO_RES_BF16 : 0))) == IO;
+    };
+    (void)mul;
+    if (is(0, 0, 0, false, false, true, 0, 0)) return 1;
+    if (is(0, 0, 0, true, false, true, 0, 0)) return 2;
+    if (is(1, 1, 0, false, false, false, 2, 0)) return 3;
+    if (is(1, 0, 0, false, false, false, 2, 0)) return 4;
+    if (is(0, 0, 1, false, false, false, 2, 0)) return 5;
+    if (is(0, 0, 0, false, true, true, 0, 0)) return 6;
+    if (is(0, 0, 0, false, false, false, 1, 0)) return 7;
+    if (is(0, 0, 0, true, false, false, 1, CDF_IO_RES_BF16)) return 8;
+    if (is(1, 1, 0, false, false, false, 1, CDF_IO_PRE_BF16)) return 9;
+    if (is(1, 0, 0, false, false, false, 1, 0)) return 10;
+    if (is(0, 0, 1, false, false, false, 1, CDF_IO_MUL_BF16)) return 11;
+    return 0;
+}
+
+// kernel side (block-uniform): may this block tile of TILE_ROWS GEMM rows take the specialised form?
+template <int TILE_ROWS, int BN, class Args>
+__device__ __forceinline__ bool cdf_epi_tile_ok(const Args& a, int M) {
+    return a.epi != 0 && M % TILE_ROWS == 0 && a.Cout % BN == 0 && (a.sbias == nullptr || (a.QH * a.QW) % TILE_ROWS == 0);
+}
+
+template <bool BF>
+__device__ __forceinline__ f32x4_t cdf_ld_raw4(const void* base, unsigned off) {      // off in elements of the tensor's own type; a bf16 quad sits in lanes 0, 1
+    if constexpr (BF) {
+        const cdf_u32x2 t = *(const cdf_u32x2*)((const unsigned short*)base + off);
+        f32x4_t r = {__uint_as_float(t[0]), __uint_as_float(t[1]), 0.f, 0.f};
+        return r;
+    } else {
+        return *(const f32x4_t*)((const float*)base + off);
+    }
+}
+template <bool BF>
+__device__ __forceinline__ f32x4_t cdf_cvt_raw4(const f32x4_t& r) {                   // the loaded quad as four floats
+    if constexpr (BF) {
+        const unsigned x = __float_as_uint(r[0]), y = __float_as_uint(r[1]);
+        f32x4_t v = {__uint_as_float(x << 16), __uint_as_float(x & 0xFFFF0000u), __uint_as_float(y << 16), __uint_as_float(y & 0xFFFF0000u)};
+        return v;
+    } else {
+        return r;
+    }
+}
+template <bool BF>
+__device__ __forceinline__ void cdf_st_raw4(void* base, unsigned off, const f32x4_t& v) {                // bf16: round to nearest even
+    if constexpr (BF) {
+        cdf_u32x2 h;
+        h[0] = cdf_pack2bf(v[0], v[1]);
+        h[1] = cdf_pack2bf(v[2], v[3]);
+        *(cdf_u32x2*)((unsigned short*)base + off) = h;
+    } else {
+        *(f32x4_t*)((float*)base + off) = v;
+    }
+}
+
+// bs[0] = bias quad, bs[1] = per-sample bias quad of the image row0 lies in (one image per tile: cdf_epi_tile_ok) -- unconditional loads from
+// clamped addresses (zeros where the tensor is absent), issued with the operand loads BEFORE any store of the tile: a load whose value is
+// awaited behind stores waits for every one of them (vmcnt counts in order).
+template <int BN, int NTHR, class Args>
+__device__ __forceinline__ void cdf_epi_load_bias(const Args& a, f32x4_t (&bs)[2], long long row0, int n_base, int tid) {
+    int c4 = (tid % (BN / 4)) * 4;
+    CDF_OPAQUE_V(c4);
+    const int co = n_base + c4;
+    const long long b = a.sbias ? row0 / (a.QH * a.QW) : 0;
+    const float* pb = a.bias ? a.bias + co : (const float*)cdf_zero_page;
+    const float* ps = a.sbias ? a.sbias + b * a.ld_sbias + co : (const float*)cdf_zero_page;
+    bs[0] = *(const f32x4_t*)pb;
+    bs[1] = *(const f32x4_t*)ps;
+}
+
+// One pass over RP transposed rows ([RP][BN + 8] floats in LDS) by NTHR threads: thread t owns channel quad t % (BN/4) of rows t / (BN/4) + k RPS.
+// q[NR]: the ONE fused operand a spec loads per row (residual, multiply source or the output's previous contents: never two of them in
+// the instantiated list), raw -- the register array has the same type for every spec, so load and finish can be dispatched separately
+// with the accumulator dump and the barrier between them written once.
+template <int BN, int RP, int NTHR, class S>
+struct cdf_epi_fast {
+    static constexpr int CP = BN + 8, TPR = BN / 4, RPS = NTHR / TPR, NR = RP / RPS;
+    static_assert(NR >= 1 && NR * RPS == RP, "rows of a pass must divide among the threads");
+    static_assert((S::RES ? 1 : 0) + (S::MUL ? 1 : 0) + (S::ACC ? 1 : 0) <= 1, "one loaded operand per row");
+    static constexpr bool RES_BF = (S::IO & CDF_IO_RES_BF16) != 0, MUL_BF = (S::IO & CDF_IO_MUL_BF16) != 0, PRE_BF = (S::IO & CDF_IO_PRE_BF16) != 0;
+    // Tensors are addressed as (block-uniform row base: 64-bit, scalar) + (this thread's 32-bit element offset): a pass spans
+    // RP x pitch elements, far below 2^32.  row0 = first GEMM row (= output pixel) of the pass.
+    // the fused operand of pass row k (row0 = first GEMM row of the pass, co = channel, p0 = the thread's first row)
+    template <class Args>
+    __device__ __forceinline__ static f32x4_t load_row(const Args& a, long long row0, int co, int p0, int k) {
+        if constexpr (S::RES) {
+            const void* base = RES_BF ? (const void*)((const unsigned short*)a.res + row0 * a.ldr) : (const void*)((const float*)a.res + row0 * a.ldr);
+            return cdf_ld_raw4<RES_BF>(base, (unsigned)(p0 + k * RPS) * (unsigned)a.ldr + (unsigned)co);
+        } else if constexpr (S::MUL != 0) {
+            const void* base = MUL_BF ? (const void*)((const unsigned short*)a.mul + row0 * a.ldm) : (const void*)((const float*)a.mul + row0 * a.ldm);
+            return cdf_ld_raw4<MUL_BF>(base, (unsigned)(p0 + k * RPS) * (unsigned)a.ldm + (unsigned)co);
+        } else {
+            return *(const f32x4_t*)(a.y + row0 * a.ldy + (unsigned)(p0 + k * RPS) * (unsigned)a.ldy + (unsigned)co);
+        }
+    }
+    static constexpr bool LOADS = S::RES || S::MUL != 0 || S::ACC;
+    template <class Args>
+    __device__ __forceinline__ static void load(const Args& a, f32x4_t (&q)[NR], long long row0, int n_base, int tid) {
+        if constexpr (LOADS) {
+            int c4 = (tid % TPR) * 4, p0 = tid / TPR;
+            CDF_OPAQUE_V(c4);                                // (see finish: nothing of a thread's address arithmetic may be hoisted out of a tile loop)
+            CDF_OPAQUE_V(p0);
+            const int co = n_base + c4;
+#pragma unroll
+            for (int k = 0; k < NR; ++k) q[k] = load_row(a, row0, co, p0, k);
+        }
+    }
+    // NEXT: as soon as row k's operand has been consumed its register is refilled with the operand of row k of the pass starting at
+    // next_row0 -- issued before row k's stores, so a later wait for it needs at most the OLDER stores acknowledged, and one register
+    // array serves both passes of a two-pass epilogue.
+    template <bool NEXT = false, class Args>
+    __device__ __forceinline__ static void finish(const Args& a, f32x4_t (&q)[NR], const f32x4_t (&bs)[2], const float* cs, long long row0, int n_base, int tid,
+                                                  long long next_row0 = 0) {
+        // In a resident kernel this code sits inside the tile loop and every offset below is tile-invariant: hipcc hoists them all -- for every
+        // spec of the switch, every row, every tensor -- out of the loop and spills (hundreds of VGPRs: even the accumulators went to scratch).
+        // The thread's two indices therefore pass through an opaque register here, per call.
+        int c4 = (tid % TPR) * 4, p0 = tid / TPR;
+        CDF_OPAQUE_V(c4);
+        CDF_OPAQUE_V(p0);
+        const int co = n_base + c4;
+        // (bias, then the per-sample bias, are added to the accumulator as in the generic form: the same roundings in the same order)
+        finish_rows<NEXT>(a, q, cs, row0, co, c4, p0, bs[0], bs[1], a.sbias != nullptr, next_row0);
+    }
+    template <bool NEXT, class Args>
+    __device__ __forceinline__ static void finish_rows(const Args& a, f32x4_t (&q)[NR], const float* cs, long long row0, int co, int c4, int p0,
+                                                       const f32x4_t& bv, const f32x4_t& sb, const bool has_sb, long long next_row0) {
+        float* const ybase = S::HASY ? a.y + row0 * a.ldy : nullptr;
+        void* const pbase = S::PRE ? (PRE_BF ? (void*)((unsigned short*)a.pre + row0 * a.ldp) : (void*)((float*)a.pre + row0 * a.ldp)) : nullptr;
+        unsigned short* const hbase = S::YS ? a.ys_hi + row0 * a.ld_ys : nullptr;
+        unsigned short* const lbase = S::YS == 2 ? a.ys_lo + row0 * a.ld_ys : nullptr;
+        // One row at a time, the NEXT row's LDS read in flight while this one is worked on, and a scheduling fence per row: left alone,
+        // hipcc hoists every read and address of the unrolled pass to the top and spills (265 VGPRs in the 256 x 128 resident kernel).
+        f32x4_t nxt = *(const f32x4_t*)(cs + (unsigned)p0 * CP + c4);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const unsigned p = (unsigned)(p0 + k * RPS);
+            f32x4_t v = nxt;
+            if (k + 1 < NR) nxt = *(const f32x4_t*)(cs + (p + RPS) * CP + c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bv[e];
+            if (has_sb) {                                    // (block-uniform)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += sb[e];
+            }
+            if constexpr (S::PRE == 1) cdf_st_raw4<PRE_BF>(pbase, p * (unsigned)a.ldp + (unsigned)co, v);
+            if constexpr (S::ACT == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = cdf_gelu(v[e]);
+            } else if constexpr (S::ACT == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = cdf_silu(v[e]);
+            }
+            if constexpr (S::MUL != 0) {
+                const f32x4_t u = cdf_cvt_raw4<MUL_BF>(q[k]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= (S::MUL == 1 ? cdf_gelu_grad(u[e]) : (S::MUL == 2 ? cdf_silu_grad(u[e]) : u[e]));
+            }
+            if constexpr (S::RES) {
+                const f32x4_t u = cdf_cvt_raw4<RES_BF>(q[k]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += u[e];
+            }
+            if constexpr (S::ACC) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += q[k][e];
+            }
+            if constexpr (NEXT && LOADS) q[k] = load_row(a, next_row0, co, p0, k);
+            if constexpr (S::HASY) *(f32x4_t*)(ybase + p * (unsigned)a.ldy + (unsigned)co) = v;
+            if constexpr (S::YS != 0) {
+                uint2 h, l;
+                cdf_split4(v[0], v[1], v[2], v[3], h, l);
+                const unsigned o = p * (unsigned)a.ld_ys + (unsigned)co;
+                *(uint2*)(hbase + o) = h;
+                if constexpr (S::YS == 2) *(uint2*)(lbase + o) = l;
+            }
+            CDF_SCHED_FENCE();
+        }
+    }
+};
+
+// run f(Spec{}) for the spec with this id (a block-uniform switch; f is a generic lambda: `[&](auto spec) { using S = decltype(spec); ... }`)
+template <bool BF_FAMILY, class F>
+__device__ __forceinline__ void cdf_epi_dispatch(int id, F&& f) {
+    if constexpr (!BF_FAMILY) {
+        switch (id) {
+            case 1: f(EpiPlain{}); break;
+            case 2: f(EpiRes{}); break;
+            case 3: f(EpiGeluPrePlanes{}); break;
+            case 4: f(EpiGeluPlanes{}); break;
+            case 5: f(EpiMulGeluPlanes{}); break;
+            default: f(EpiAcc{}); break;
+        }
+    } else {
+        switch (id) {
+            case 7: f(EpiBfPlain{}); break;
+            case 8: f(EpiBfRes{}); break;
+            case 9: f(EpiBfGeluPre{}); break;
+            case 10: f(EpiBfGelu{}); break;
+            default: f(EpiBfMulGelu{}); break;
+        }
+    }
+}
+// ids 1..6 belong to the fp32-tensor family, 7..11 to the bf16-storage family
+__device__ __forceinline__ bool cdf_epi_family_ok(int id, bool bf_family) { return bf_family ? (id >= 7 && id <= 11) : (id >= 1 && id <= 6); }
+
+// Use: ONE block-uniform switch around the whole epilogue of a tile,
+//     cdf_epi_dispatch<BFF>(a.epi, [&](auto spec) { using E = cdf_epi_fast<BN, RP, NTHR, decltype(spec)>; f32x4_t q[E::NR], bs[2];
+//                                                  cdf_epi_load_bias<BN, NTHR>(...); E::load(...); <dump, barrier>; E::finish(...); });
+// (load and finish behind two separate switches leave the compiler's wait-count bookkeeping with a join between them: it then waits
+//  vmcnt(0) -- every store included -- at the first use of a prefetched operand.)

@@ -11,7 +11,8 @@ P = lambda t: 0 if t is None else t.data_ptr()
 Cin, Cout, H = (int(v) for v in os.environ.get("GA_SHAPE", "128-64-128").split("-"))
 B, k = int(os.environ.get("GA_B", "32")), 3
 variants = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in v.split(",") if kv) for v in os.environ.get("GA_VARIANTS", "halo=47;halo=175").split(";")]
-epi = os.environ.get("GA_EPI", "plain")            # plain | gelu (bias + GELU, pre-activation + planes out) | res (bias + residual)
+epi = os.environ.get("GA_EPI", "plain")            # plain | gelu (bias + GELU, pre-activation + planes out) | gelun (the same without pre: no-grad forward)
+                                                   # | res (bias + residual) | mulg (x GELU'(pre) -> planes) | acc (y += .)
 torch.manual_seed(0)
 x = torch.randn(B, H, H, Cin, device=dev)
 w = torch.randn(Cout, Cin, k, k, device=dev) * 0.05
@@ -32,6 +33,15 @@ def launch(t):
     if epi == "gelu":
         L.cdf_conv_gemm_bf16x(P(xh), P(xl), Cin, P(zero), P(hi), P(lo), ldk, 0, Cout, B, H, H, Cin, H, H, Cout, H, H, 1, 1, 1, p.desc, P(bias), 0, 0, 0, 0,
                               P(pre), Cout, 0, 0, 1, 0, 0, P(yh), P(yl), Cout, 0, 0, t.ptr, S())
+    elif epi == "gelun":
+        L.cdf_conv_gemm_bf16x(P(xh), P(xl), Cin, P(zero), P(hi), P(lo), ldk, 0, Cout, B, H, H, Cin, H, H, Cout, H, H, 1, 1, 1, p.desc, P(bias), 0, 0, 0, 0,
+                              0, 0, 0, 0, 1, 0, 0, P(yh), P(yl), Cout, 0, 0, t.ptr, S())
+    elif epi == "mulg":
+        L.cdf_conv_gemm_bf16x(P(xh), P(xl), Cin, P(zero), P(hi), P(lo), ldk, 0, Cout, B, H, H, Cin, H, H, Cout, H, H, 1, 1, 1, p.desc, 0, 0, 0, 0, 0,
+                              0, 0, P(res), Cout, 0, 1, 0, P(yh), P(yl), Cout, 0, 0, t.ptr, S())
+    elif epi == "acc":
+        L.cdf_conv_gemm_bf16x(P(xh), P(xl), Cin, P(zero), P(hi), P(lo), ldk, P(y), Cout, B, H, H, Cin, H, H, Cout, H, H, 1, 1, 1, p.desc, 0, 0, 0, 0, 0,
+                              0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, t.ptr, S())
     elif epi == "res":
         L.cdf_conv_gemm_bf16x(P(xh), P(xl), Cin, P(zero), P(hi), P(lo), ldk, P(y), Cout, B, H, H, Cin, H, H, Cout, H, H, 1, 1, 1, p.desc, P(bias), 0, 0, P(res), Cout,
                               0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, t.ptr, S())
@@ -44,7 +54,8 @@ outs = []
 for t in tunes:
     y.zero_(); pre.zero_()
     launch(t); torch.cuda.synchronize()
-    outs.append((pre if epi == "gelu" else y).clone())
+    outs.append((pre if epi == "gelu" else (yh.float() if epi in ("gelun", "mulg") else y)).clone())
+    sums = [float(o.double().abs().sum()) for o in (y, pre, yh.float(), yl.float())]
 ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2)[:2], w).permute(0, 2, 3, 1) if False else None
 times = [[] for _ in tunes]
 for rnd in range(int(os.environ.get("GA_ROUNDS", "5"))):
@@ -57,4 +68,4 @@ for rnd in range(int(os.environ.get("GA_ROUNDS", "5"))):
         times[i].append(e0.elapsed_time(e1) / 10)
 fl = 2.0 * B * H * H * Cin * Cout * k * k
 for v, ts, o in zip(variants, times, outs):
-    print(f"{Cin}->{Cout} @{H} B={B} epi={epi} {str(v):40s} min {min(ts):.4f} ms  median {statistics.median(ts):.4f} ms  {fl / min(ts) / 1e9:6.1f} TF   max|diff vs first| {float((o - outs[0]).abs().max()):.2e}  |y|max {float(o.abs().max()):.2f}", flush=True)
+    print(f"{Cin}->{Cout} @{H} B={B} epi={epi} {str(v):40s} min {min(ts):.4f} ms  median {statistics.median(ts):.4f} ms  {fl / min(ts) / 1e9:6.1f} TF   max|diff vs first| {float((o - outs[0]).abs().max()):.2e}  |y|max {float(o.abs().max()):.2f}  sums {sums}", flush=True)
