@@ -109,7 +109,7 @@ class GemmTuning:
             self.set(halo=v[0], halo_min_tiles=v[1] if len(v) > 1 else 1)
         for var, field in (("COLDDIFF_SPX_SPLITK", "splitk"), ("COLDDIFF_SPX_DEEP", "deep"), ("COLDDIFF_SPX_HALO_BM", "halo_bm"),
                            ("COLDDIFF_SPX_MAX_BM", "max_bm"), ("COLDDIFF_SPX_DEPHASE", "dephase"), ("COLDDIFF_SPX_SMALL_N64", "small_n64"),
-                           ("COLDDIFF_WGRAD_ROW3", "wgrad_row3"), ("COLDDIFF_ROWHALO_STREAM", "rowhalo_stream"), ("COLDDIFF_WGRAD_SWIZZLE", "wgrad_swizzle"), ("COLDDIFF_WGRAD_STACK", "wgrad_stack"), ("COLDDIFF_RESIDENT_RESERVE", "resident_reserve")):
+                           ("COLDDIFF_WGRAD_ROW3", "wgrad_row3"), ("COLDDIFF_ROWHALO_STREAM", "rowhalo_stream"), ("COLDDIFF_WGRAD_SWIZZLE", "wgrad_swizzle"), ("COLDDIFF_WGRAD_STACK", "wgrad_stack"), ("COLDDIFF_RESIDENT_RESERVE", "resident_reserve"), ("COLDDIFF_EPILOGUE", "epilogue")):
             if env(var):
                 v = int(env(var))
                 ok = self._ALLOWED.get(field)
@@ -119,7 +119,7 @@ class GemmTuning:
         return self
 
     # the values cdf_tune_ok (csrc/k_conv_sp.hip) accepts, field by field
-    _ALLOWED = {"rowhalo_stream": (0, 1), "resident_reserve": range(0, 249), "halo_bm": (0, 128, 256), "max_bm": (0, 128, 256),
+    _ALLOWED = {"rowhalo_stream": (0, 1), "epilogue": (0, 1), "resident_reserve": range(0, 249), "halo_bm": (0, 128, 256), "max_bm": (0, 128, 256),
                 "tile_bm": (0, 64, 128, 256), "tile_bn": (0, 64, 128), "halo": range(0, 128)}
 
 

@@ -239,18 +239,18 @@ struct SpxWgradArgs {
 // ---- tuning: an explicit, optional argument of the GEMM entry points (include/colddiff.h: cdf_gemm_tuning) -----------------------------
 // No mutable process-wide state: a NULL pointer means these defaults, anything else is read once per call.  The choices only select
 // between kernels / tile shapes that compute the same sums (fp32 summation order aside).
-static const cdf_gemm_tuning kTuneDefault = {(int)sizeof(cdf_gemm_tuning), 0, 0, 0, 1, 1, 1, 47, 1, 0, 1, 1, 1, 1, 1, 0};
+static const cdf_gemm_tuning kTuneDefault = {(int)sizeof(cdf_gemm_tuning), 0, 0, 0, 1, 1, 1, 47, 1, 0, 1, 1, 1, 1, 1, 0, 1};
 static inline const cdf_gemm_tuning* cdf_tune(const cdf_gemm_tuning* t) { return (t && t->size == (int)sizeof(cdf_gemm_tuning)) ? t : &kTuneDefault; }
 static inline bool cdf_tune_ok(const cdf_gemm_tuning* t) {
     if (!t) return true;
     const bool bm_ok = t->tile_bm == 0 || t->tile_bm == 64 || t->tile_bm == 128 || (t->tile_bm == 256 && (t->tile_bn == 0 || t->tile_bn == 128));
     const bool bn_ok = t->tile_bn == 0 || t->tile_bn == 64 || t->tile_bn == 128;
     return t->size == (int)sizeof(cdf_gemm_tuning) && bm_ok && bn_ok && (t->max_bm == 0 || t->max_bm == 128 || t->max_bm == 256) &&
-           (t->halo_bm == 0 || t->halo_bm == 128 || t->halo_bm == 256) && t->halo >= 0 && t->halo <= 127 && t->halo_min_tiles >= 0 && t->resident_reserve >= 0 && t->resident_reserve <= 248 && (t->rowhalo_stream == 0 || t->rowhalo_stream == 1);
+           (t->halo_bm == 0 || t->halo_bm == 128 || t->halo_bm == 256) && t->halo >= 0 && t->halo <= 127 && t->halo_min_tiles >= 0 && t->resident_reserve >= 0 && t->resident_reserve <= 248 && (t->rowhalo_stream == 0 || t->rowhalo_stream == 1) && (t->epilogue == 0 || t->epilogue == 1);
 }
 #define CDF_TUNE_CHECK(t, who)                                                                                                          \
     CDF_REQUIRE(cdf_tune_ok(t), who ": bad cdf_gemm_tuning (size %d, expected %d; tile_bm 0/64/128/256 (256 with tile_bn 0/128), tile_bn 0/64/128, " \
-                                    "max_bm 0/128/256, halo_bm 0/128/256, halo 0..127, rowhalo_stream 0/1, resident_reserve 0..248): start from cdf_gemm_tuning_default",            \
+                                    "max_bm 0/128/256, halo_bm 0/128/256, halo 0..127, rowhalo_stream 0/1, resident_reserve 0..248, epilogue 0/1): start from cdf_gemm_tuning_default",            \
                 (t) ? (t)->size : 0, (int)sizeof(cdf_gemm_tuning))
 
 static inline int cdf_num_cus() {                                     // CUs of the current device (blocks of the resident kernels), a multiple of 8 XCDs

@@ -28,7 +28,7 @@ extern "C" {
 /* Bumped whenever an exported signature changes incompatibly (rounds 1-3 all answered 1 while arguments were added: `tiled`,
  * `onepass`, `slots`, `tune`).  cdf_abi_version() returns the value the LIBRARY was built with; a binding compares it with the
  * header it was generated from before the first call (colddiff/_lib.py does) -- a mismatched pair would read shifted arguments. */
-#define CDF_ABI_VERSION 5
+#define CDF_ABI_VERSION 6
 
 #define CDF_E_INVALID (-1)
 #define CDF_E_UNSUPPORTED (-2)
@@ -188,6 +188,9 @@ typedef struct cdf_gemm_tuning {
     int resident_reserve;/* 0: CUs the resident kernels leave free (rounded up to whole rounds of the 8 XCDs).  Multi-rank training sets it: the
                             collective kernels of the gradient exchange run concurrently with backward and need CUs of their own -- a resident
                             block that finds its CU taken would run its fixed share of the tiles after everybody else */
+    int epilogue;        /* 1: the template-specialised straight-line epilogues where one matches the call (csrc/cdf_epilogue.h: operand loads
+                            issued before any store of the tile); 0: always the generic run-time-selected form.  Same arithmetic in the same
+                            order: bit-identical results (tests/test_kernels.py) -- the switch exists for that test and for A/B timing */
 } cdf_gemm_tuning;
 int cdf_gemm_tuning_default(cdf_gemm_tuning* t);
 

@@ -1162,3 +1162,102 @@ def test_linattn_bwd_kv_fused(be, B, n, heads):
     assert (out[..., :HD] == 0).all()                                   # the q block is not this kernel's
     assert err(out[..., HD:2 * HD], dk_ref) <= 2e-5 * max(1.0, dk_ref.abs().max().item())
     assert err(out[..., 2 * HD:], dv_ref) <= 2e-5 * max(1.0, dv_ref.abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------
+# specialised GEMM epilogues (csrc/cdf_epilogue.h, round 6) == the generic run-time-selected form, bit for bit
+# ---------------------------------------------------------------------------------------------
+EPI_SPECS = ["plain", "res", "gelu_pre_planes", "gelu_planes", "mulgelu_planes", "acc",
+             "bf_plain", "bf_res", "bf_gelu_pre", "bf_gelu", "bf_mulgelu"]
+
+
+def _epi_case(be, spec, B, Cin, Cout, H, sbias=False):
+    """One 3 x 3 stride-1 pre-split GEMM with the operand list of one EpiSpec, run with cdf_gemm_tuning.epilogue = 1 (specialised
+    straight-line form) and = 0 (generic): every output tensor must be identical."""
+    bf = spec.startswith("bf_")
+    torch.manual_seed(3)
+    k = 3
+    x = torch.randn(B, H, H, Cin)
+    w = torch.randn(Cout, Cin, k, k) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout)
+    sb = torch.randn(B, Cout) if sbias else None
+    other = torch.randn(B, H, H, Cout)                       # residual / GELU' source / previous contents of y
+    zero = be.zeros(16)
+    wd_ = be.to(w)
+    ldk = (Cin + 31) // 32 * 32
+    whi = torch.empty(9, Cout, ldk, dtype=torch.int16, device=be.device)
+    wlo = None if bf else torch.empty_like(whi)
+    be.L.cdf_pack_weight_bf16(P(wd_), P(whi), P(wlo), 9, Cout, Cin, ldk, 1, Cin * 9, 9, be.stream())
+    xs = _split(be, be.to(x), bf)
+    plan = cd.conv_fwd(H, H, k, k, 1, 1, 1, 1, 1)
+    as_bf = lambda t: (t.bfloat16().view(torch.int16))       # a bf16 tensor as its raw plane
+    biasd, sbd = be.to(bias), (be.to(sb) if sbias else None)
+    otherd = be.to(as_bf(other) if bf else other)
+
+    def run(epilogue):
+        be.tune.set(epilogue=epilogue)
+        y = be.to(other.clone()) if spec == "acc" else be.zeros(B, H, H, Cout)
+        pre = torch.zeros(B, H, H, Cout, dtype=torch.int16 if bf else torch.float32, device=be.device)
+        yh = torch.zeros(B, H, H, Cout, dtype=torch.int16, device=be.device)
+        yl = torch.zeros_like(yh)
+        be._keep += [pre, yh, yl]
+        a = dict(y=0, bias=P(biasd), res=0, pre=0, mul=0, act=0, mul_mode=0, acc=0, io=0, yh=0, yl=0)
+        if spec in ("plain", "res", "acc"):
+            a["y"] = P(y)
+        if spec in ("res", "bf_res"):
+            a["res"] = P(otherd)
+        if "gelu" in spec and "mul" not in spec:
+            a["act"] = 1
+        if "pre" in spec:
+            a["pre"] = P(pre)
+        if "mulgelu" in spec:
+            a["mul"], a["mul_mode"], a["bias"] = P(otherd), 1, 0
+        if spec == "acc":
+            a["acc"], a["bias"] = 1, 0
+        if "planes" in spec or bf:
+            a["yh"] = P(yh)
+            a["yl"] = 0 if bf else P(yl)
+        if bf:
+            a["io"] = {"bf_res": 1, "bf_gelu_pre": 2, "bf_mulgelu": 4}.get(spec, 0)
+        be.L.cdf_conv_gemm_bf16x_io(P(xs[0]), P(xs[1]), xs[0].shape[-1], P(zero), P(whi), P(wlo), ldk, a["y"], Cout, B, H, H, Cin, H, H, Cout, H, H, 1, 1,
+                                    1, plan.desc, a["bias"], P(sbd), Cout if sbias else 0, a["res"], Cout, a["pre"], Cout, a["mul"], Cout, a["act"],
+                                    a["mul_mode"], a["acc"], a["io"], a["yh"], a["yl"], Cout, 0, 0, be.tune.ptr, be.stream())
+        return [t.cpu().clone() for t in (y, pre, yh, yl)]
+
+    try:
+        fast, generic = run(1), run(0)
+    finally:
+        be.tune.set(epilogue=1)
+    for name, f, g in zip(("y", "pre", "y_hi", "y_lo"), fast, generic):
+        assert torch.equal(f, g), (spec, name, (f.float() - g.float()).abs().max().item())
+    assert any(t.abs().sum() > 0 for t in fast), "the launch wrote nothing"
+
+
+@pytest.mark.parametrize("spec", EPI_SPECS)
+def test_specialised_epilogue_equals_generic(be, spec):
+    # 3 x 3, 64 -> 64 channels, 16 x 16 pixels, 2 images: whole 128-pixel tiles and whole 64-wide N tiles -> the halo kernel's specialised form
+    _epi_case(be, spec, 2, 64, 64, 16)
+
+
+@pytest.mark.parametrize("spec", ["res", "gelu_pre_planes", "bf_res"])
+def test_specialised_epilogue_with_per_sample_bias(be, spec):
+    # one image per 128-row tile is what the per-sample bias needs (two tiles per image here)
+    _epi_case(be, spec, 2, 64, 64, 16, sbias=True)
+
+
+@pytest.mark.parametrize("spec", ["res", "mulgelu_planes", "bf_gelu_pre"])
+def test_specialised_epilogue_rowhalo_emu(spec):
+    """... through the resident row-halo kernel's two-pass form (operand of pass 1 refilled inside pass 0), at a simulator-sized width."""
+    from conftest import Backend
+    be = Backend("emu")
+    be.tune.set(halo=47 | 64)
+    _epi_case(be, spec, 2, 64, 64, 16)
+    _epi_case(be, spec, 1, 128, 128, 16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec", EPI_SPECS)
+@pytest.mark.parametrize("shape", [(4, 64, 128, 128), (4, 128, 64, 128), (4, 128, 256, 64), (8, 512, 256, 16)])
+def test_specialised_epilogue_equals_generic_large(spec, shape):
+    from conftest import Backend
+    _epi_case(Backend("hip"), spec, *shape)
