@@ -314,6 +314,24 @@ SEC_STEPS, SEC_WARMUP = 20, 5            # secondary workloads: timed steps / wa
 SEC_TIMING = "%d timed steps after %d warm-up" % (SEC_STEPS, SEC_WARMUP)
 
 
+# forward GFLOP per image of the three networks (SURVEY.md 8(a) [probe]); a train step = 3 x forward (fwd + dgrad + wgrad)
+_FWD_GFLOP = {"unet128": 67.41, "unet32": 4.21, "model32": 12.44}
+
+
+def _alg(net, img_per_s, mfma_per_product):
+    """Algorithmic TFLOP/s of a secondary train line and its fraction of the dense bf16 MFMA peak (x the MFMAs each product issues =
+    the matrix-pipe occupancy); exact-fp32 lines are priced against the 157.3 TFLOP/s fp32 MFMA peak."""
+    tf = 3 * _FWD_GFLOP[net] * img_per_s / 1e3
+    if mfma_per_product == 0:
+        return {"algorithmic_tflops": round(tf, 1), "frac_of_f32_mfma_peak": round(tf / 157.3, 3)}
+    return {"algorithmic_tflops": round(tf, 1), "frac_of_bf16_mfma_peak": round(tf / 2500.0, 4), "mfma_issue_frac_of_bf16_peak": round(mfma_per_product * tf / 2500.0, 4)}
+
+
+def _mpp():
+    from colddiff import runtime
+    return {"f32": 0, "bf16x3": 3, "bf16": 1}[runtime.precision]
+
+
 def _dtype_label():
     from colddiff import runtime
     if runtime.precision == "f32":
@@ -343,6 +361,7 @@ def secondary_workloads(device):
     tr.quiet = True
     dt = timed_train(tr, SEC_STEPS, SEC_WARMUP)
     out["cfg4_celeba128_deblur_train"] = {"img_per_s": round(64 / dt, 1), "ms_per_step": round(1000 * dt, 2), "timing": SEC_TIMING, "dtype": _dtype_label(),
+                                          "roofline": _alg("unet128", 64 / dt, _mpp()),
                                           "workload": "Unet(64,(1,2,4,8)) @128x128, blur Exponential_reflect T=200 k=15 std=0.01, 2 x 32 img + Adam"}
     with torch.no_grad():
         x = tr._next_batch()[:16]
@@ -370,6 +389,7 @@ def secondary_workloads(device):
         tr.quiet = True
         dt = timed_train(tr, SEC_STEPS, SEC_WARMUP, reps=3)
         out[key] = {"img_per_s": round(256 / dt, 1), "ms_per_step": round(1000 * dt, 2), "timing": SEC_TIMING + ", median of 3", "dtype": _dtype_label(),
+                    "roofline": _alg("model32", 256 / dt, _mpp()),
                     "workload": "Model(ch=128,(1,2,2,2),attn@16,dropout 0.1) @32x32, blur Special_6_routine T=50, 2 x 128 img + Adam"}
         del tr, d, net
         torch.cuda.empty_cache()
@@ -393,7 +413,8 @@ def secondary_workloads(device):
         reps = 3 if cfg == "1" else 1
         dt = timed_train(tr, SEC_STEPS, SEC_WARMUP, reps=reps)
         out[key] = {"img_per_s": round(2 * batch / dt, 1), "ms_per_step": round(1000 * dt, 2), "workload": desc + ", 2 micro-steps + Adam",
-                    "timing": SEC_TIMING + (", median of 3" if reps > 1 else ""), "dtype": _dtype_label()}
+                    "timing": SEC_TIMING + (", median of 3" if reps > 1 else ""), "dtype": _dtype_label(),
+                    "roofline": _alg("unet32" if cfg == "1" else "unet128", 2 * batch / dt, _mpp())}
         del tr, d
         torch.cuda.empty_cache()
 
