@@ -315,8 +315,19 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_row3_kernel(SpxWgradArgs a)
 #pragma unroll
     for (int e = 0; e < 8; ++e) bs_acc[e] = 0.f;
 
-    u32x4_v rah[PASS_A], ral[PASS_A], rbh, rbl;
-    auto load_global = [&](int it) {
+    // Register-staged operand chunks, TWO ahead of the one being multiplied (round 6; round 3 measured this form at +2.6 ... +10.5 % on the
+    // 128 x 128-pixel layers and dropped it for +0.2 % of the step of its day): with one chunk ahead the loads had one chunk's MFMAs to
+    // land -- 18 per wave for a 64-channel side, 0.25 us against ~1.5 us of HBM latency, and a third of that in `bf16` mode -- so the two
+    // blocks of a CU spent most of their time waiting for each other's loads.  Set s holds chunk c with c % 2 == s; chunk it + 1 goes to
+    // LDS between the two k-steps of chunk it, its registers are refilled with chunk it + 3 right behind, and the barrier orders LDS only.
+    // (128 x 64 tiles in split precision: the second register set takes the kernel from 125 to 156 VGPRs, i.e. from two resident blocks per
+    //  CU to one -- measured -2.5 % -- so that instantiation keeps ONE chunk ahead.)
+    constexpr bool X2 = !(TA == 128 && TB == 64 && NS == 3);
+    struct Regs {
+        u32x4_v ah[PASS_A], al[PASS_A], bh, bl;
+    };
+    Regs r0, r1;
+    auto load_global = [&](Regs& r, int it) {
         const int m0 = m_lo + it * BK;
 #pragma unroll
         for (int p = 0; p < PASS_A; ++p) {
@@ -324,14 +335,14 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_row3_kernel(SpxWgradArgs a)
             const bool ok = a_r[p] < nra && ax < (unsigned)W && ay < (unsigned)H && ca < a.CA;
             const long long pix = (long long)m0 + (a_sub[p] + dy) * W + a_xr[p] - 1;
             const size_t off = (size_t)(ok ? pix : 0) * (unsigned)a.lda + (unsigned)ca;
-            rah[p] = *(const u32x4_v*)(ok ? a.a_hi + off : a.zero);
-            if constexpr (NS == 3) ral[p] = *(const u32x4_v*)(ok ? a.a_lo + off : a.zero);
+            r.ah[p] = *(const u32x4_v*)(ok ? a.a_hi + off : a.zero);
+            if constexpr (NS == 3) r.al[p] = *(const u32x4_v*)(ok ? a.a_lo + off : a.zero);
         }
         {
             const bool ok = b_lane && cb < a.CB;
             const size_t off = (size_t)(m0 + (b_lane ? pb : 0)) * (unsigned)a.ldb + (unsigned)cb;
-            rbh = *(const u32x4_v*)(ok ? a.b_hi + off : a.zero);
-            if constexpr (NS == 3) rbl = *(const u32x4_v*)(ok ? a.b_lo + off : a.zero);
+            r.bh = *(const u32x4_v*)(ok ? a.b_hi + off : a.zero);
+            if constexpr (NS == 3) r.bl = *(const u32x4_v*)(ok ? a.b_lo + off : a.zero);
         }
         // next chunk (uniform scalars, selects only): 32 pixels further -- inside the row, to the next row(s), to the next image
         const int nx = x0 + (W < 32 ? 0 : 32);
@@ -340,21 +351,21 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_row3_kernel(SpxWgradArgs a)
         yc += (W < 32 ? 32 / W : 0) + wrap;
         yc = yc >= H ? yc - H : yc;
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](const Regs& r, int buf) {
         unsigned short* st = smem + buf * STAGE;
 #pragma unroll
         for (int p = 0; p < PASS_A; ++p) {
             if (a_r[p] < NRAP) {
                 const int so = a_r[p] * PITCH_A + (tid % VPR_A) * 8;
-                *(u32x4_v*)(st + so) = rah[p];
-                if constexpr (NS == 3) *(u32x4_v*)(st + PLANE_A + so) = ral[p];
+                *(u32x4_v*)(st + so) = r.ah[p];
+                if constexpr (NS == 3) *(u32x4_v*)(st + PLANE_A + so) = r.al[p];
             }
         }
         if (b_lane) {
             const int so = pb * PITCH_B + (tid % VPR_B) * 8;
-            *(u32x4_v*)(st + 2 * PLANE_A + so) = rbh;
-            if constexpr (NS == 3) *(u32x4_v*)(st + 2 * PLANE_A + PLANE_B + so) = rbl;
-            if (do_bsum) cdf_bf16x8_accum<NS>(bs_acc, rbh, rbl);
+            *(u32x4_v*)(st + 2 * PLANE_A + so) = r.bh;
+            if constexpr (NS == 3) *(u32x4_v*)(st + 2 * PLANE_A + PLANE_B + so) = r.bl;
+            if (do_bsum) cdf_bf16x8_accum<NS>(bs_acc, r.bh, r.bl);
         }
     };
 
@@ -376,47 +387,71 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_row3_kernel(SpxWgradArgs a)
     for (int i = 0; i < 3; ++i) tra[i] = (tr_row + 1 + (int)a.dax[3 * grp + i]) * PITCH_A + wa * 32 + tr_col;
     const int ks_skip = W < 32 ? 2 * PITCH_A : 0;              // k-step 1 = pixels 16..31 = the second row when W = 16
 
-    if (niter > 0) {
-        load_global(0);
-        store_lds(0);
-    }
-    __syncthreads();
-    for (int it = 0; it < niter; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < niter) load_global(it + 1);
-        const unsigned short* sa = smem + buf * STAGE;
-        const unsigned short* sb = sa + 2 * PLANE_A;
+    auto mma_ks = [&](const unsigned short* sa, const unsigned short* sb, int ks) {
+        bf16x8_v bh[NT], bl[NT];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_v bh[NT], bl[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const unsigned short* q = sb + trb + ks * 16 * PITCH_B + j * 32;
-                const bf16x4_v h0 = cdf_lds_read_tr16(q), h1 = cdf_lds_read_tr16(q + 4 * PITCH_B);
-                bh[j] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-                if constexpr (NS == 3) {
-                    const bf16x4_v l0 = cdf_lds_read_tr16(q + PLANE_B), l1 = cdf_lds_read_tr16(q + PLANE_B + 4 * PITCH_B);
-                    bl[j] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const unsigned short* q = sa + tra[i] + ks * (16 * PITCH_A + ks_skip);
-                const bf16x4_v h0 = cdf_lds_read_tr16(q), h1 = cdf_lds_read_tr16(q + 4 * PITCH_A);
-                const bf16x8_v ah = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-                bf16x8_v al;
-                if constexpr (NS == 3) {
-                    const bf16x4_v l0 = cdf_lds_read_tr16(q + PLANE_A), l1 = cdf_lds_read_tr16(q + PLANE_A + 4 * PITCH_A);
-                    al = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    cdf_mma_sp<NS>(acc[i][j], ah, al, bh[j], bl[j]);
-                }
+        for (int j = 0; j < NT; ++j) {
+            const unsigned short* q = sb + trb + ks * 16 * PITCH_B + j * 32;
+            const bf16x4_v h0 = cdf_lds_read_tr16(q), h1 = cdf_lds_read_tr16(q + 4 * PITCH_B);
+            bh[j] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            if constexpr (NS == 3) {
+                const bf16x4_v l0 = cdf_lds_read_tr16(q + PLANE_B), l1 = cdf_lds_read_tr16(q + PLANE_B + 4 * PITCH_B);
+                bl[j] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
             }
         }
-        if (it + 1 < niter) store_lds(buf ^ 1);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const unsigned short* q = sa + tra[i] + ks * (16 * PITCH_A + ks_skip);
+            const bf16x4_v h0 = cdf_lds_read_tr16(q), h1 = cdf_lds_read_tr16(q + 4 * PITCH_A);
+            const bf16x8_v ah = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            bf16x8_v al;
+            if constexpr (NS == 3) {
+                const bf16x4_v l0 = cdf_lds_read_tr16(q + PLANE_A), l1 = cdf_lds_read_tr16(q + PLANE_A + 4 * PITCH_A);
+                al = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                cdf_mma_sp<NS>(acc[i][j], ah, al, bh[j], bl[j]);
+            }
+        }
+    };
+    if constexpr (X2) {
+        // one chunk: multiply chunk `it` (stage it & 1); `nxt` holds chunk it + 1 (-> the other stage, then refilled with chunk it + 3)
+        auto step = [&](int it, Regs& nxt) {
+            const unsigned short* sa = smem + (it & 1) * STAGE;
+            const unsigned short* sb = sa + 2 * PLANE_A;
+            mma_ks(sa, sb, 0);
+            if (it + 1 < niter) store_lds(nxt, (it + 1) & 1);    // (that stage was last read in chunk it - 1: every wave is past the barrier that ended it)
+            if (it + 3 < niter) load_global(nxt, it + 3);
+            mma_ks(sa, sb, 1);
+            CDF_LDS_BARRIER();                                   // (LDS traffic only: the chunks in flight stay in flight)
+        };
+        if (niter > 0) {
+            load_global(r0, 0);
+            store_lds(r0, 0);
+            if (niter > 1) load_global(r1, 1);                   // set 1: odd chunks
+            if (niter > 2) load_global(r0, 2);                   // set 0: even chunks
+        }
         __syncthreads();
+        for (int it = 0; it < niter; it += 2) {
+            step(it, r1);
+            if (it + 1 < niter) step(it + 1, r0);
+        }
+    } else {
+        if (niter > 0) {
+            load_global(r0, 0);
+            store_lds(r0, 0);
+        }
+        __syncthreads();
+        for (int it = 0; it < niter; ++it) {
+            if (it + 1 < niter) load_global(r0, it + 1);
+            const unsigned short* sa = smem + (it & 1) * STAGE;
+            const unsigned short* sb = sa + 2 * PLANE_A;
+            mma_ks(sa, sb, 0);
+            mma_ks(sa, sb, 1);
+            if (it + 1 < niter) store_lds(r0, (it + 1) & 1);
+            __syncthreads();
+        }
     }
 
     float* red = (float*)smem_raw;
