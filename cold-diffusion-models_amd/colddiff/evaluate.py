@@ -169,7 +169,7 @@ class EvalMixin:
         cnt = 0
         while cnt < all_samples.shape[0]:
             og_img = all_samples[cnt: cnt + batch].float()
-            X_0s, X_ts = self.ema_core.all_sample(batch_size=og_img.shape[0], img=og_img, times=None)
+            X_0s, X_ts = self._all_sample(og_img.shape[0], og_img)
             for dst, z in ((orig, og_img), (blurred, X_ts[0]), (deblurred, X_0s[-1]), (direct, X_0s[0])):
                 dst.append((rep3(z.to(self.device)) + 1) * 0.5)
             cnt += og_img.shape[0]
@@ -194,3 +194,132 @@ class EvalMixin:
         _create_folder(f'{self.results_folder}/')
         for idx in range(len(self.ds)):
             self._save(self._dataset_item(idx)[None], f'{self.results_folder}/{idx}.png', nrow=1)
+
+
+class GenEvalMixin:
+    """The generation / evaluation scripts the denoising, demixing and defading-generation Trainers share (whitespace-identical upstream
+    except `sample_and_save_for_fid`): denoising_diffusion_pytorch.py:821-854, 1091-1395; demixing_diffusion_pytorch.py:806-836,
+    1080-1384; defading-generation .../defading_diffusion_pytorch.py:868-904, 1148-1452.  Same names, arguments, folders and file names;
+    the samplers they drive (`gen_sample`, `all_sample`) run on the HIP kernels, the Gaussian-mixture fit is scikit-learn on the host as
+    upstream (`GaussianMixture(n_components, random_state=0)`), pycave's `torch_gmm` goes through `EvalMixin._fit_gmm`.  Upstream calls
+    `self.ema_model.all_sample` without `.module` (an AttributeError under DataParallel): here `ema_core`.  The hard-coded sample counts
+    (6400 / 10000 / 100 per round, batches of 128 / 1000) are the defaults of trailing keyword arguments; titles and GIFs are figure code."""
+
+    def _seed_images(self, bs):
+        """The starting images `sample_and_save_for_fid` samples from, one batch (per package)."""
+        raise NotImplementedError
+
+    def sample_and_save_for_fid(self, noise=0, num_samples=6400, bs=None):
+        bs = self._fid_batch if bs is None else bs
+        out_folder = f'{self.results_folder}_out'
+        _create_folder(out_folder)
+        cnt = 0
+        for _ in range(int(num_samples / bs)):
+            og_img = self._seed_images(bs)
+            xt, direct_recons, all_images = self._gen(bs, og_img, noise)
+            for i in range(all_images.shape[0]):
+                self._save(all_images[i:i + 1], f'{out_folder}/sample-x0-{cnt}.png', nrow=1)
+                cnt += 1
+        return cnt
+
+    def _gen(self, bs, og_img, noise):
+        return self.ema_core.gen_sample(batch_size=bs, img=og_img, noise_level=noise)
+
+    def _all_sample(self, bs, og_img):
+        """(x0 estimates per step, x_t per step).  Upstream unpacks TWO values (`X_0s, X_ts = ...all_sample(...)`, copied from the deblurring
+        package) from the THREE the denoising / demixing `all_sample` returns (X1_0s, X2_0s, X_ts: DENOISE:482-515) -- a ValueError there;
+        the evident intent is the image estimates and the trajectory."""
+        res = self.ema_core.all_sample(batch_size=bs, img=og_img, times=None)
+        return res[0], res[-1]
+
+    def _dataset_vectors(self, start, end, siz=None):
+        """rows idx with start < idx <= end of the dataset (upstream's `if idx > start` / `if idx == end: break`), resampled to siz x siz
+        (bilinear) and flattened when siz is given"""
+        import torch.nn.functional as F
+        rows = []
+        for idx in range(len(self.ds)):
+            img = self._dataset_item(idx).unsqueeze(0)
+            if siz is not None:
+                img = F.interpolate(img, size=siz, mode='bilinear').flatten(1)
+            if idx > start:
+                rows.append(img[0])
+            if end is not None and idx == end:
+                break
+        return torch.stack(rows)
+
+    def _sk_gmm(self, feats, clusters):
+        from sklearn.mixture import GaussianMixture
+        return GaussianMixture(n_components=clusters, random_state=0).fit(feats.detach().float().cpu().numpy())
+
+    def _up(self, og_x, n, ch, siz):
+        import torch.nn.functional as F
+        og_x = torch.as_tensor(og_x).reshape(n, ch, siz, siz).to(self.device).float()
+        return F.interpolate(og_x, size=self.image_size, mode='bilinear').contiguous()
+
+    def sample_as_a_vector_gmm(self, start=0, end=1000, siz=64, ch=3, clusters=10, num_samples=100):
+        gm = self._sk_gmm(self._dataset_vectors(start, end, siz), clusters)
+        og_x, _ = gm.sample(n_samples=num_samples)
+        og_img = self._up(og_x, num_samples, ch, siz)
+        X_0s, X_ts = self._all_sample(1, og_img)
+        extra_path = 'vec'
+        self._save(og_img, str(self.results_folder / f'og-{start}-{end}-{siz}-{clusters}-{extra_path}.png'))
+        for i in range(len(X_0s)):
+            self._save(X_0s[i], str(self.results_folder / f'sample-{start}-{end}-{siz}-{clusters}-{i}-{extra_path}-x0.png'))
+            if i < len(X_ts):
+                self._save(X_ts[i], str(self.results_folder / f'sample-{start}-{end}-{siz}-{clusters}-{i}-{extra_path}-xt.png'))
+        return X_0s, X_ts
+
+    def sample_as_a_vector_gmm_and_save(self, start=0, end=1000, siz=64, ch=3, clusters=10, n_sample=10000, num_samples=10000):
+        gm = self._sk_gmm(self._dataset_vectors(start, end, siz), clusters)
+        folder = f'{self.results_folder}_{siz}_{clusters}/'
+        _create_folder(folder)
+        cnt = 0
+        for _ in range(int(n_sample / num_samples)):
+            og_x, _ = gm.sample(n_samples=num_samples)
+            og_img = self._up(og_x, num_samples, ch, siz)
+            X_0s, X_ts = self._all_sample(1, og_img)
+            x0s = X_0s[-1]
+            for i in range(x0s.shape[0]):
+                self._save(x0s[i:i + 1], f'{folder}sample-x0-{cnt}.png', nrow=1)
+                cnt += 1
+        return cnt
+
+    def _torch_gmm_rounds(self, torch_gmm, feats, siz, ch, clusters, n_sample, num_samples, from_blur):
+        model = self._fit_gmm(torch_gmm, feats, clusters, 1000)
+        f_x0, f_gmm, f_blur = (f'{self.results_folder}_{siz}_{clusters}/', f'{self.results_folder}_gmm_{siz}_{clusters}/',
+                               f'{self.results_folder}_gmm_blur_{siz}_{clusters}/')
+        for f in (f_x0, f_gmm, f_blur):
+            _create_folder(f)
+        cnt = 0
+        for _ in range(int(n_sample / num_samples)):
+            og_x = model.sample(num_datapoints=num_samples)
+            og_img = self._up(og_x, num_samples, ch, siz)
+            X_0s, X_ts = self._all_sample(og_img.shape[0], og_img)
+            x0s, blurs = X_0s[-1], X_ts[0]
+            for i in range(x0s.shape[0]):
+                self._save(x0s[i:i + 1], f'{f_x0}sample-x0-{cnt}.png', nrow=1)
+                self._save(og_img[i:i + 1], f'{f_gmm}sample-{cnt}.png', nrow=1)
+                self._save(blurs[i:i + 1], f'{f_blur}sample-blur-{cnt}.png', nrow=1)
+                cnt += 1
+        return cnt
+
+    def sample_as_a_vector_pytorch_gmm_and_save(self, torch_gmm, start=0, end=1000, siz=64, ch=3, clusters=10, n_sample=10000, num_samples=100):
+        return self._torch_gmm_rounds(torch_gmm, self._dataset_vectors(start, end, siz), siz, ch, clusters, n_sample, num_samples, False)
+
+    def sample_as_a_vector_from_blur_pytorch_gmm_and_save(self, torch_gmm, start=0, end=1000, siz=64, ch=3, clusters=10, n_sample=10000,
+                                                          num_samples=100):
+        # (upstream fits on the same resampled dataset vectors: the "from blur" variant differs from the one above only in its prints)
+        return self._torch_gmm_rounds(torch_gmm, self._dataset_vectors(start, end, siz), siz, ch, clusters, n_sample, num_samples, True)
+
+    def sample_from_data_save(self, start=0, end=1000, chunk=1000):
+        all_samples = self._dataset_vectors(start, end)                      # [n, C, H, W]
+        _create_folder(f'{self.results_folder}/')
+        cnt = 0
+        while cnt < all_samples.shape[0]:
+            og_img = all_samples[cnt: cnt + chunk].to(self.device).float().contiguous()
+            X_0s, X_ts = self._all_sample(og_img.shape[0], og_img)
+            x0s = X_0s[-1]
+            for i in range(x0s.shape[0]):
+                self._save(x0s[i:i + 1], f'{self.results_folder}/sample-x0-{cnt}.png', nrow=1)
+                cnt += 1
+        return cnt

@@ -19,7 +19,7 @@ import torch
 from torch.utils import data
 
 from . import flat, parallel
-from .evaluate import EvalMixin
+from .evaluate import EvalMixin, GenEvalMixin
 from . import runtime as rt
 
 
@@ -541,9 +541,16 @@ class Trainer(EvalMixin):
         parallel.milestone_barrier()
 
 
-class DemixTrainer(Trainer):
+class DemixTrainer(GenEvalMixin, Trainer):
     """Trainer of demixing_diffusion_pytorch (DEMIX:596-775): two image folders; every micro-step mixes a batch of the
     first into a batch of the second, and sampling starts from images of the second."""
+
+    @property
+    def _fid_batch(self):                      # DEMIX:818: bs = self.batch_size, seeds = the next batch of the second folder
+        return self.batch_size
+
+    def _seed_images(self, bs):
+        return self._second()[:bs]
 
     def __init__(self, diffusion_model, folder1, folder2, *, dataset=None, shuffle=True, num_workers=8, **kw):
         super().__init__(diffusion_model, folder1, dataset=dataset, shuffle=shuffle, num_workers=num_workers, **kw)
@@ -565,9 +572,17 @@ class DemixTrainer(Trainer):
         return self._second()          # DEMIX:744 draws from the second loader only
 
 
-class DefadeGenTrainer(Trainer):
+class DefadeGenTrainer(GenEvalMixin, Trainer):
     """Trainer of the defading-generation package (DEFGEN:646-810): the second image is one uniform random colour per
     sample and channel, rand(B, 3) - 0.5 spread over the image (DEFGEN:769-773)."""
+
+    @property
+    def _fid_batch(self):                      # DEFGEN:880-887: bs = self.batch_size, seeds = one random colour per image
+        return self.batch_size
+
+    def _seed_images(self, bs):
+        n = self.image_size
+        return (torch.rand((bs, 3)) - 0.5)[:, :, None, None].expand(bs, 3, n, n).to(self.device).contiguous()
 
     def __init__(self, diffusion_model, folder, **kw):
         super().__init__(diffusion_model, folder, **kw)
@@ -744,9 +759,17 @@ class DeviceLoader:
 
 
 # -- the other packages' Trainers: same loop, their own `dataset=` tables and loader options ---------------------------------
-class DenoiseTrainer(Trainer):
+class DenoiseTrainer(GenEvalMixin, Trainer):
     """denoising_diffusion_pytorch.py:620-789: `dataset == 'train'` augments, everything else is the centre crop; both datasets
     convert to RGB first (DENOISE:565, 588)."""
+    _fid_batch = 128                           # DENOISE:835-839: bs = 128, seeds = N(0, 1) images (128 x 128 upstream: the model's size here)
+
+    def _seed_images(self, bs):
+        n = self.image_size
+        return torch.randn(bs, 3, n, n).to(self.device)
+
+    def _gen(self, bs, og_img, noise):         # (DENOISE:843: gen_sample has no noise_level in this package)
+        return self.ema_core.gen_sample(batch_size=bs, img=og_img)
 
     @staticmethod
     def recipe_for(dataset):

@@ -418,6 +418,82 @@ def test_two_image_trainers(mbe, tmp_path):
     assert torch.isfinite(tr2.train_step()).item()
 
 
+def test_generation_scripts_of_the_two_image_packages(mbe, tmp_path):
+    """The generation / evaluation scripts the denoising, demixing and defading-generation Trainers share (colddiff.evaluate.GenEvalMixin;
+    DENOISE:821-854, 1091-1395 and the whitespace-identical copies): every saved image is the sampler's output for the seeds the script
+    draws -- replayed here from the same RNG state --, folders and file names as upstream."""
+    import os
+    from PIL import Image
+    from denoising_diffusion_pytorch import GaussianDiffusion, Trainer, Unet
+    from colddiff.diffusion import DefadeGenDiffusion
+    from colddiff.trainer import DefadeGenTrainer
+    S = 16
+    folder = tmp_path / "imgs"
+    folder.mkdir()
+    g = torch.Generator().manual_seed(5)
+    for i in range(6):
+        Image.fromarray((torch.rand(S, S, 3, generator=g) * 255).to(torch.uint8).numpy()).save(folder / f"{i}.png")
+    torch.manual_seed(0)
+    net = quiet(Unet, dim=8, dim_mults=(1, 2), channels=3).to(mbe.device)
+    d = GaussianDiffusion(net, image_size=S, channels=3, timesteps=3).to(mbe.device)
+    tr = quiet(Trainer, d, str(folder), image_size=S, train_batch_size=2, results_folder=str(tmp_path / "den"), device_data=False, num_workers=0)
+    saved = []
+    tr._save = lambda img, name, nrow=6: saved.append((os.path.relpath(name, tmp_path), img.detach().cpu().clone()))
+    # --- sample_and_save_for_fid: N(0, 1) seeds through gen_sample (DENOISE:835-843)
+    torch.manual_seed(21)
+    assert quiet(tr.sample_and_save_for_fid, num_samples=4, bs=2) == 4
+    torch.manual_seed(21)
+    want = []
+    for _ in range(2):
+        seeds = torch.randn(2, 3, S, S).to(mbe.device)
+        want.append(quiet(tr.ema_core.gen_sample, batch_size=2, img=seeds)[2].cpu())
+    want = torch.cat(want)
+    assert [n for n, _ in saved] == [f"den_out/sample-x0-{i}.png" for i in range(4)]
+    assert all(torch.equal(im[0], want[i]) for i, (_, im) in enumerate(saved))
+    # --- sample_from_data_save: dataset rows start < idx <= end through all_sample, last x0 saved (DENOISE:1362-1395)
+    del saved[:]
+    assert quiet(tr.sample_from_data_save, start=0, end=3) == 3
+    rows = torch.stack([tr._dataset_item(i) for i in (1, 2, 3)])
+    x0s = quiet(tr.ema_core.all_sample, batch_size=3, img=rows, times=None)[0][-1].cpu()        # (X1_0s of (X1_0s, X2_0s, X_ts))
+    assert [n for n, _ in saved] == [f"den/sample-x0-{i}.png" for i in range(3)] and all(torch.equal(im[0], x0s[i]) for i, (_, im) in enumerate(saved))
+    # --- the GMM scripts: fit on the resampled dataset vectors, sample, blow up, all_sample (DENOISE:1161-1213, 1215-1286)
+    del saved[:]
+    assert quiet(tr.sample_as_a_vector_gmm_and_save, start=-1, end=5, siz=4, clusters=2, n_sample=4, num_samples=2) == 4
+    assert [n for n, _ in saved] == [f"den_4_2/sample-x0-{i}.png" for i in range(4)] and all(im.shape == (1, 3, S, S) and torch.isfinite(im).all() for _, im in saved)
+    feats = []
+
+    class CaptureGMM:
+        def __init__(self, **kw):
+            self.kw = kw
+
+        def fit(self, x):
+            feats.append(x.detach().cpu().clone())
+
+        def sample(self, num_datapoints):
+            return torch.linspace(-1, 1, num_datapoints * 3 * 16).reshape(num_datapoints, -1)
+
+    del saved[:]
+    assert quiet(tr.sample_as_a_vector_pytorch_gmm_and_save, CaptureGMM, start=-1, end=5, siz=4, clusters=2, n_sample=2, num_samples=2) == 2
+    import torch.nn.functional as F
+    ref_feats = torch.stack([F.interpolate(tr._dataset_item(i).unsqueeze(0), size=4, mode='bilinear').flatten(1)[0] for i in range(6)]).cpu()
+    assert torch.equal(feats[0], ref_feats)
+    assert [n for n, _ in saved][:3] == ["den_4_2/sample-x0-0.png", "den_gmm_4_2/sample-0.png", "den_gmm_blur_4_2/sample-blur-0.png"]
+    X0, Xt = quiet(tr.sample_as_a_vector_gmm, start=-1, end=5, siz=4, clusters=2, num_samples=2)
+    assert len(X0) >= 1 and X0[-1].shape == (2, 3, S, S)
+    # --- defading generation: one random colour per image as the seed (DEFGEN:880-891)
+    net2 = quiet(Unet, dim=8, dim_mults=(1, 2), channels=3).to(mbe.device)
+    d2 = DefadeGenDiffusion(net2, image_size=S, channels=3, timesteps=3, kernel_std=0.3, initial_mask=2).to(mbe.device)
+    tr2 = quiet(DefadeGenTrainer, d2, None, dataset='synthetic', image_size=S, train_batch_size=2, results_folder=str(tmp_path / "gen"))
+    saved2 = []
+    tr2._save = lambda img, name, nrow=6: saved2.append(img.detach().cpu().clone())
+    torch.manual_seed(4)
+    assert quiet(tr2.sample_and_save_for_fid, noise=0, num_samples=2) == 2
+    torch.manual_seed(4)
+    seeds = (torch.rand((2, 3)) - 0.5)[:, :, None, None].expand(2, 3, S, S).to(mbe.device).contiguous()
+    want2 = quiet(tr2.ema_core.gen_sample, batch_size=2, img=seeds, noise_level=0)[2].cpu()
+    assert all(torch.equal(im[0], want2[i]) for i, im in enumerate(saved2))
+
+
 def test_defading_golden(mbe):
     from defading_diffusion_pytorch import GaussianDiffusion
     g = load("diffusion.pt")
