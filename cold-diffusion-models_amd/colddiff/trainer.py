@@ -837,3 +837,66 @@ class DefadeTrainer(Trainer):
         if dataset == 'celebA_test':
             return Recipe('DatasetCelebATest', 'sq112', 'center', False)
         return CENTER_SHORT
+
+    # ---- this package's test methods (DEFADE:814-940, 1146-1244): `all_sample` / `sample` take `faded_recon_sample=` here -------------------
+    def _frames(self, og_img, extra_path, x0_list, xt_list):
+        """og-<extra>.png, sample-<i>-<extra>-x0 / -xt.png and the two GIFs (titles are figure code)"""
+        from PIL import Image
+        self._save(og_img, str(self.results_folder / f'og-{extra_path}.png'))
+        frames_0, frames_t = [], []
+        for i in range(len(x0_list)):
+            p0, pt = str(self.results_folder / f'sample-{i}-{extra_path}-x0.png'), str(self.results_folder / f'sample-{i}-{extra_path}-xt.png')
+            self._save(x0_list[i], p0)
+            frames_0.append(p0)
+            if i < len(xt_list):
+                self._save(xt_list[i], pt)
+                frames_t.append(pt)
+        for name, frames in ((f'Gif-{extra_path}-x0.gif', frames_0), (f'Gif-{extra_path}-xt.gif', frames_t)):
+            ims = [Image.open(f).convert('RGB') for f in frames if os.path.exists(f)]
+            if ims:
+                ims[0].save(str(self.results_folder / name), save_all=True, append_images=ims[1:], duration=100, loop=0)
+        return x0_list, xt_list
+
+    def test_from_data(self, extra_path, s_times=None):                # DEFADE:814-841
+        og_img = self._next_batch()
+        x0_list, xt_list = self.ema_core.all_sample(batch_size=self.batch_size, faded_recon_sample=og_img, times=s_times)
+        return self._frames(og_img, extra_path, x0_list, xt_list)
+
+    def test_with_mixup(self, extra_path):                             # DEFADE:843-883: the mean of two batches as the start
+        og_img_1, og_img_2 = self._next_batch(), self._next_batch()
+        og_img = (og_img_1 + og_img_2) / 2
+        x0_list, xt_list = self.ema_core.all_sample(batch_size=self.batch_size, faded_recon_sample=og_img)
+        self._save(og_img_1, str(self.results_folder / f'og1-{extra_path}.png'))
+        self._save(og_img_2, str(self.results_folder / f'og2-{extra_path}.png'))
+        return self._frames(og_img, extra_path, x0_list, xt_list)
+
+    def test_from_random(self, extra_path):                            # DEFADE:885-920: a batch scaled by 0.9 as the start
+        og_img = self._next_batch() * 0.9
+        x0_list, xt_list = self.ema_core.all_sample(batch_size=self.batch_size, faded_recon_sample=og_img)
+        return self._frames(og_img, extra_path, x0_list, xt_list)
+
+    def controlled_direct_reconstruct(self, extra_path):               # DEFADE:922-940
+        torch.manual_seed(0)
+        og_img = self._next_batch()
+        xt, direct_recons, all_images = self.ema_core.sample(batch_size=self.batch_size, faded_recon_sample=og_img)
+        for name, im in (('og', og_img), ('recon', all_images), ('direct_recons', direct_recons), ('xt', xt)):
+            self._save(im, str(self.results_folder / f'sample-{name}-{extra_path}.png'))
+        self.save()
+        return xt, direct_recons, all_images
+
+    def test_from_data_save_results(self, batch_size=100, chunk=32):  # DEFADE:1146-1244: four folders of per-image PNGs
+        from .evaluate import _create_folder
+        all_samples = torch.cat(list(self._dataset_batches(batch_size)), dim=0)
+        folders = [f'{self.results_folder}_{n}/' for n in ('orig', 'blur', 'deblur', 'd_deblur')]
+        for f in folders:
+            _create_folder(f)
+        cnt = 0
+        while cnt < all_samples.shape[0]:
+            og_img = all_samples[cnt: cnt + chunk].to(self.device).float().contiguous()
+            x0_list, xt_list = self.ema_core.all_sample(batch_size=og_img.shape[0], faded_recon_sample=og_img, times=None)
+            sets = (og_img.cpu(), xt_list[0].cpu(), x0_list[-1].cpu(), x0_list[0].cpu())
+            for i in range(og_img.shape[0]):
+                for f, t in zip(folders, sets):
+                    self._save(t[i:i + 1].repeat(1, 3 // t.shape[1], 1, 1), f'{f}{cnt + i}.png', nrow=1)
+            cnt += og_img.shape[0]
+        return cnt

@@ -494,6 +494,28 @@ def test_generation_scripts_of_the_two_image_packages(mbe, tmp_path):
     assert all(torch.equal(im[0], want2[i]) for i, im in enumerate(saved2))
 
 
+def test_defading_trainer_test_methods(mbe, tmp_path):
+    """The defading package's own Trainer test methods (DEFADE:814-940, 1146-1244: `all_sample` / `sample` take `faded_recon_sample=`
+    there): what they save is what the samplers return for the batches they draw."""
+    import os
+    from defading_diffusion_pytorch import GaussianDiffusion, Trainer, Unet
+    torch.manual_seed(0)
+    net = quiet(Unet, dim=8, dim_mults=(1, 2), channels=3).to(mbe.device)
+    d = GaussianDiffusion(net, image_size=16, device_of_kernel="cuda", channels=3, timesteps=3, kernel_std=0.6, initial_mask=1,
+                          fade_routine="Incremental", sampling_routine="x0_step_down").to(mbe.device)
+    tr = quiet(Trainer, d, None, dataset='synthetic', image_size=16, train_batch_size=2, results_folder=str(tmp_path / "r"))
+    saved = {}
+    tr._save = lambda img, name, nrow=6: saved.__setitem__(os.path.relpath(name, tmp_path), img.detach().cpu().clone())
+    x0, xt = quiet(tr.test_from_data, "a")
+    assert len(x0) >= 1 and torch.equal(saved["r/sample-0-a-x0.png"], x0[0].cpu()) and "r/og-a.png" in saved
+    x0, xt = quiet(tr.test_from_random, "b")
+    assert float(saved["r/og-b.png"].abs().max()) <= 0.9 + 1e-6 and torch.equal(saved["r/sample-0-b-xt.png"], xt[0].cpu())
+    x0, xt = quiet(tr.test_with_mixup, "c")
+    assert torch.allclose(saved["r/og-c.png"], (saved["r/og1-c.png"] + saved["r/og2-c.png"]) / 2) and torch.equal(saved["r/sample-0-c-x0.png"], x0[0].cpu())
+    xt, direct, img = quiet(tr.controlled_direct_reconstruct, "d")
+    assert torch.equal(saved["r/sample-recon-d.png"], img.cpu()) and torch.equal(saved["r/sample-xt-d.png"], xt.cpu()) and os.path.exists(tmp_path / "r" / "model.pt")
+
+
 def test_defading_golden(mbe):
     from defading_diffusion_pytorch import GaussianDiffusion
     g = load("diffusion.pt")
