@@ -169,7 +169,7 @@ class EvalMixin:
         cnt = 0
         while cnt < all_samples.shape[0]:
             og_img = all_samples[cnt: cnt + batch].float()
-            X_0s, X_ts = self._all_sample(og_img.shape[0], og_img)
+            X_0s, X_ts = self.ema_core.all_sample(batch_size=og_img.shape[0], img=og_img, times=None)
             for dst, z in ((orig, og_img), (blurred, X_ts[0]), (deblurred, X_0s[-1]), (direct, X_0s[0])):
                 dst.append((rep3(z.to(self.device)) + 1) * 0.5)
             cnt += og_img.shape[0]
