@@ -124,7 +124,7 @@ class GemmTuning:
 
 
 # int-returning entry points that are pure host-side queries (sizes / counts), not status codes
-_QUERY = re.compile(r"(_blocks|_nchunk|_nsplit|_abi_version|_is_device_build|_lds_bytes|_is_row3|_ssim_tiles|_pack_entry_bytes|_pack_blocks|_kvctx_parts|_bf16x_ksplit)$")
+_QUERY = re.compile(r"(_blocks|_nchunk|_nsplit|_abi_version|_is_device_build|_lds_bytes|_is_row3|_ssim_tiles|_pack_entry_bytes|_pack_blocks|_kvctx_parts|_bf16x_ksplit|_lnbwd_ok)$")
 
 
 class CdfError(RuntimeError):

@@ -36,6 +36,22 @@ def _img(x):
     return x.contiguous().float()
 
 
+def _steps(t, B):
+    """The per-sample step table of a B-image launch.  Upstream indexes its schedules by broadcasting (`extract(a, t, x_shape)`,
+    `t[:, None, None, None]`), so a [1] step vector against B images is legal there -- the GMM scripts call all_sample(1, imgs)
+    (DENOISE:1203) -- while the kernels here read t[b] per image: expanded to B rows (int64, contiguous), any other mismatch fails as the
+    broadcast would."""
+    if t is None:
+        return None
+    if t.dim() == 0:
+        t = t.reshape(1)
+    if t.shape[0] != B:
+        if t.shape[0] != 1:
+            raise RuntimeError(f"The size of tensor a ({B}) must match the size of tensor b ({t.shape[0]}) at non-singleton dimension 0")
+        t = t.expand(B)
+    return t.to(torch.int64).contiguous()
+
+
 def blur_chain(x, taps, k, pad_mode, t=None, step_lo=0, step_hi=0, img=None, want_prev=False, collapse_step=-1, quantise=False,
                taps1d=None):
     """Apply blur steps step_lo..hi(b) (hi = t[b] or step_hi) with the plane resident in LDS.
@@ -43,6 +59,7 @@ def blur_chain(x, taps, k, pad_mode, t=None, step_lo=0, step_hi=0, img=None, wan
     taps1d ([T, C, 2, k], see separable_taps) selects the separable kernel: 2k instead of k*k FMAs per pixel."""
     x = _img(x)
     B, C, H, W = x.shape
+    t = _steps(t, B)
     y = torch.empty_like(x)
     snap = torch.empty_like(x) if want_prev else None
     img = None if img is None else _img(img)     # keep the (possibly converted) tensor alive over the launch
@@ -92,6 +109,8 @@ def plane_mean_(x):
 def mask_chain(x, masks, t=None, step_lo=0, step_hi=0, img=None, off_y=None, off_x=None, quantise=False):
     x = _img(x)
     B, C, H, W = x.shape
+    t = _steps(t, B)
+    off_y, off_x = _steps(off_y, B), _steps(off_x, B)
     y = torch.empty_like(x)
     snap = torch.empty_like(x) if img is not None else None
     img = None if img is None else _img(img)
@@ -103,6 +122,7 @@ def mask_chain(x, masks, t=None, step_lo=0, step_hi=0, img=None, off_y=None, off
 def pixelate_chain(x, sizes, mode, t=None, step_lo=0, step_hi=0, img=None):
     x = _img(x)
     B, C, H, W = x.shape
+    t = _steps(t, B)
     assert H == W, "the resolution operator works on square images (as the reference asserts)"
     y = torch.empty_like(x)
     snap = torch.empty_like(x) if img is not None else None
@@ -121,6 +141,7 @@ def x0_step_down(img, d_t, d_tm1):
 
 def noise_qsample(x0, eps, ca, cb, t):
     x0, eps = _img(x0), _img(eps)
+    t = _steps(t, x0.shape[0])
     out = torch.empty_like(x0)
     rt.lib().cdf_noise_qsample(P(x0), P(eps), P(ca), P(cb), P(t), P(out), x0.shape[0], x0[0].numel(), rt.stream(x0))
     return out
@@ -138,6 +159,7 @@ def blend_qsample(x1, x2, alphas, one_minus, t):
     """alphas[t[b]] * x1 + one_minus[t[b]] * x2 with per-pixel tables [T, 1, H, W] (or [T, H, W])."""
     x1, x2 = _img(x1), _img(x2)
     B, C, H, W = x1.shape
+    t = _steps(t, B)
     out = torch.empty_like(x1)
     rt.lib().cdf_blend_qsample(P(x1), P(x2), P(alphas), P(one_minus), P(t), P(out), B, C, H * W, rt.stream(x1))
     return out

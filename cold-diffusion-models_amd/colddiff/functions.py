@@ -80,6 +80,7 @@ _ALWAYS_PRESPLIT = os.environ.get("CDF_ALWAYS_PRESPLIT", "0") != "0"
 _PRESPLIT_1X1 = os.environ.get("CDF_PRESPLIT_1X1", "0") != "0"
 _AUTO_PRESPLIT = os.environ.get("CDF_AUTO_PRESPLIT", "1") != "0"
 _SP_KMIN = int(os.environ.get("CDF_SP_KMIN", "64"))     # tuning knob: smallest K routed to the bf16 matrix cores
+_LN_FUSE = os.environ.get("CDF_LN_FUSE", "1") != "0"  # conv1's data gradient runs the LayerNorm backward in its epilogue (ops.conv_dgrad_lnbwd)
 _PRE_GRAD = os.environ.get("CDF_PRE_GRAD", "0") != "0"  # conv1's epilogue stores GELU'(pre) (same erf / exp evaluation as GELU); conv2's data gradient multiplies by it
 
 
@@ -91,9 +92,11 @@ def _sp_suffix(K, N):
 
 
 def conv_backward(x, Cin, dy, weight, bias, kind="conv", stride=1, pad=None, need_dx=True, dx=None, dx_accumulate=0, mul=None,
-                  mul_mode=0, xs=None, dys=None, split_dx=False, planes_only=False):
+                  mul_mode=0, xs=None, dys=None, split_dx=False, planes_only=False, ln=None):
     """Gradients of conv_forward: returns dx (optionally fused with an activation-gradient multiply),
-    accumulates into weight.grad / bias.grad."""
+    accumulates into weight.grad / bias.grad.
+    ln = (h, norm, mean, rstd): x was LayerNorm(h) -- returns (d, fused): fused True => d is already dh, the LayerNorm backward ran in the
+    data-gradient GEMM's epilogue and norm.g / norm.b have their gradients; False => d is dx as usual (the caller runs ops.layernorm_bwd)."""
     k = weight.shape[-1]
     if pad is None:
         pad = (k // 2,) * 4
@@ -118,10 +121,28 @@ def conv_backward(x, Cin, dy, weight, bias, kind="conv", stride=1, pad=None, nee
     if dys is None and sfx and _ALWAYS_PRESPLIT and rt.precision != "f32" and Cout % 8 == 0 and dy.device.type != "meta":
         dys = ops.split_bf16(dy[..., :Cout] if dy.shape[-1] != Cout else dy)
     if dys is not None and sfx:
-        return ops.conv_gemm_presplit(pd, dys, Cout, wd, Cin, y=dx, mul=mul, mul_mode=mul_mode, accumulate=dx_accumulate,
-                                      split_out=split_dx, planes_only=planes_only)
+        if (ln is not None and _LN_FUSE and kind == "conv" and dx is None and mul is None and not split_dx and dys[1] is not None
+                and ops.conv_dgrad_lnbwd_ok(pd, x.shape[0], Cout, Cin)):
+            h, norm, mean, rstd = ln
+            return ops.conv_dgrad_lnbwd(pd, dys, Cout, wd, Cin, h, norm.g, norm.b, mean, rstd), True
+        g = ops.conv_gemm_presplit(pd, dys, Cout, wd, Cin, y=dx, mul=mul, mul_mode=mul_mode, accumulate=dx_accumulate,
+                                   split_out=split_dx, planes_only=planes_only)
+        return (g, False) if ln is not None else g
     g = ops.conv_gemm(pd, dy, Cout, wd, Cin, y=dx, mul=mul, mul_mode=mul_mode, accumulate=dx_accumulate)
+    if ln is not None:
+        return g, False
     return (g, ops.split_bf16(g)) if split_dx else g
+
+
+def batch_time(time, B):
+    """The per-sample tables of this engine (time bias, per-sample GEMM bias) are indexed by the image row, where the reference's
+    `h + rearrange(condition, 'b c -> b c 1 1')` (DEBLUR:160) BROADCASTS: a [1] time against a larger image batch is legal upstream (the GMM
+    scripts call `all_sample(1, imgs)`, DENOISE:1203) -- expanded here; any other mismatch fails as torch's broadcast would."""
+    if time is None or time.dim() == 0 or time.shape[0] == B:
+        return time
+    if time.shape[0] != 1:
+        raise RuntimeError(f"The size of tensor a ({B}) must match the size of tensor b ({time.shape[0]}) at non-singleton dimension 0")
+    return time.expand(B, *time.shape[1:]).contiguous()
 
 
 class ToNHWC(torch.autograd.Function):
@@ -202,6 +223,13 @@ class Concat(torch.autograd.Function):
 class Sinusoidal(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, freq, dim):
+        if t.dtype != torch.int64:
+            # the kernel reads int64 steps (every caller upstream passes torch.long: DEBLUR:393, 545); other integer types and
+            # integer-valued floats mean the same thing -- anything else would be silently truncated, so it is refused
+            if t.is_floating_point() and not bool((t == t.round()).all()):
+                raise TypeError("time steps must be integers (the embedding kernel takes int64 steps)")
+            t = t.to(torch.int64)
+        t = t.contiguous()
         out = torch.empty((t.shape[0], dim), device=freq.device, dtype=torch.float32)
         rt.lib().cdf_sinusoidal(P(t), P(freq), P(out), dim, t.shape[0], dim, rt.stream(out))
         return out
@@ -488,6 +516,7 @@ class ConvNextBlockFn(torch.autograd.Function):
                                          planes_only=lean)
         else:
             dpre, dpre_s = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=3 if ctx.pre_grad else 1, xs=a_s, dys=do_s), None
+        ln_done = False
         if ctx.cin4:
             # weight / bias gradient by the direct kernel (reads dpre once); the data gradient in two stages (sum over the mid
             # channels per pixel as a 1x1 GEMM, then the nine shifted 3-vectors: ops.conv_cin_dgrad2) instead of a K = 9 mid
@@ -499,8 +528,12 @@ class ConvNextBlockFn(torch.autograd.Function):
                 pd = _conv_plans("conv", hn.shape[1], hn.shape[2], 3, 1, (1, 1, 1, 1))[1]
                 dhn = ops.conv_gemm(pd, dpre, mid, ops.packed(c1.weight, "conv_dgrad"), dim)
         else:
-            dhn = conv_backward(hn, dim, dpre, c1.weight, c1.bias, xs=hn_s, dys=dpre_s)
-        if m.has_norm:
+            dhn = conv_backward(hn, dim, dpre, c1.weight, c1.bias, xs=hn_s, dys=dpre_s, ln=(h, m.net[0], mean, rstd) if m.has_norm else None)
+            if m.has_norm:
+                dhn, ln_done = dhn
+        if ln_done:
+            dh = dhn
+        elif m.has_norm:
             dh = ops.layernorm_bwd(dhn, h, m.net[0].g, m.net[0].b, mean, rstd)
         else:
             dh = dhn

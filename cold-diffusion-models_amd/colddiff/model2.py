@@ -172,6 +172,7 @@ class Model(nn.Module):
         assert x.shape[2] == x.shape[3] == self.resolution
         assert self.ch % 2 == 0, "odd embedding widths (zero pad, Model2.py:22) are not used by the scripts"
         a = anchor(x)
+        t = F_.batch_time(t, x.shape[0])
         temb = F_.Sinusoidal.apply(t.contiguous(), self._freq, self.ch)
         temb = F_.Linear.apply(a, temb, self.temb.dense[0])
         temb = F_.Act.apply(temb, F_.ACT_SILU)

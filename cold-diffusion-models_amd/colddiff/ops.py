@@ -295,6 +295,26 @@ def conv_gemm_presplit(plan, xs, Cin, wp, Cout, y=None, bias=None, sbias=None, r
     return y
 
 
+def conv_dgrad_lnbwd_ok(plan, B, Cin, Cout):
+    """The data-gradient GEMM can run the LayerNorm backward in its epilogue (include/colddiff.h: cdf_conv_gemm_bf16x_lnbwd)."""
+    return bool(plan.os == 1 and plan.istride == 1 and plan.OH == plan.H and plan.OW == plan.W and
+                rt.lib().cdf_conv_gemm_bf16x_lnbwd_ok(B, plan.H, plan.W, Cin, Cout, plan.nphase, plan.desc[2]))
+
+
+def conv_dgrad_lnbwd(plan, dys, Cin, wp, Cout, h, g_param, b_param, mean, rstd):
+    """dh = LayerNorm'(h)[conv_dgrad(dy)] in one launch: dys = dy's (hi, lo) planes (Cin channels), wp = the (hi, lo) data-gradient
+    packing, Cout = the LayerNorm's width; accumulates the g / b gradients into the parameters."""
+    hi, lo = dys
+    B = hi.shape[0]
+    dh = torch.empty((B, plan.H, plan.W, Cout), device=hi.device, dtype=torch.float32)
+    M = B * plan.H * plan.W
+    part = torch.empty((M // 64 * 2 * Cout,), device=hi.device, dtype=torch.float32)
+    rt.lib().cdf_conv_gemm_bf16x_lnbwd(P(hi), P(lo), hi.shape[-1], P(zero_page(hi.device)), P(wp[0]), P(wp[1]), wp[0].shape[-1],
+                                       B, plan.H, plan.W, Cin, Cout, plan.desc, P(h), ld_of(h), P(mean), P(rstd), P(g_param), P(dh), Cout,
+                                       P(grad_of(g_param)), P(grad_of(b_param)), P(part), rt.tune_ptr(), rt.stream(hi))
+    return dh
+
+
 def cin4_ok(x, Cin, weight, stride=1):
     """The direct small-Cin kernels apply: <= 4 input channels held with pitch 4, k in {1, 3}, stride 1, Cout = 4 * 2^j <= 256."""
     Cout, _, k, k2 = weight.shape

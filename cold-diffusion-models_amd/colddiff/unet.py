@@ -214,6 +214,7 @@ class Unet(nn.Module):
         assert x.shape[2] % 8 == 0 and x.shape[3] % 8 == 0, "Unet needs H, W divisible by 8"
         orig_x = x
         a = anchor(x)
+        time = F_.batch_time(time, x.shape[0])
         gt = self._time(time, x)
         x = F_.ToNHWC.apply(x.float())
         # Skip connections without copies (DEBLUR:266, 274): the skip tensor of every level an up stage consumes is produced INSIDE its

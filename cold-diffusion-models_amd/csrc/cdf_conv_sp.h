@@ -57,6 +57,10 @@ __device__ __forceinline__ void cdf_sp_epilogue(const Args& a, const SpPhase& ph
                 for (int r = 0; r < 16; ++r)
                     cs[(wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * TN + j * 32 + l31] = acc[i][j][r];
     };
+    if (a.epi == CDF_EPI_LNBWD) {                            // (block-uniform; the host guarantees whole tiles and Cout == BN)
+        cdf_epi_lnbwd<BM, BN, NTHR>(a, cs, tile_m, tid, dump);
+        return;
+    }
     if (fast) {
         const long long trow = (long long)tile_m * BM;
         cdf_epi_dispatch<BFF>(a.epi, [&](auto spec) {
@@ -93,6 +97,11 @@ struct SpArgs {
     int ld_ys;
     int io_bf;                     // CDF_IO_*_BF16 bits (cdf_epilogue.h)
     int epi;                       // id of the specialised epilogue (cdf_epi_select; 0: the generic run-time-selected form)
+    const float* ln_x;             // epi == CDF_EPI_LNBWD: LayerNorm input h (pitch ld_lnx), its statistics [M], the partial-sum output [tiles][2][Cout]
+    const float* ln_mean;
+    const float* ln_rstd;
+    float* ln_part;
+    int ld_lnx;
     SpPhase ph[4];
 };
 
@@ -205,6 +214,11 @@ struct SpxArgs {
     int ks_ld;
     int io_bf;                     // CDF_IO_*_BF16 bits (cdf_epilogue.h): res / pre / mul are bf16 tensors (bf16 activation storage)
     int epi;                       // id of the specialised epilogue (cdf_epi_select; 0: the generic run-time-selected form)
+    const float* ln_x;             // epi == CDF_EPI_LNBWD: LayerNorm input h (pitch ld_lnx), its statistics [M], the partial-sum output [tiles][2][Cout]
+    const float* ln_mean;
+    const float* ln_rstd;
+    float* ln_part;
+    int ld_lnx;
     SpPhase ph[4];
 };
 

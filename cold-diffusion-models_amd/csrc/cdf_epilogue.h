@@ -414,3 +414,78 @@ __device__ __forceinline__ bool cdf_epi_family_ok(int id, bool bf_family) { retu
 //                                                  cdf_epi_load_bias<BN, NTHR>(...); E::load(...); <dump, barrier>; E::finish(...); });
 // (load and finish behind two separate switches leave the compiler's wait-count bookkeeping with a join between them: it then waits
 //  vmcnt(0) -- every store included -- at the first use of a prefetched operand.)
+
+// ================================================================================================
+// Channel-LayerNorm backward inside the data-gradient epilogue (round 6; epilogue id 12, fp32 tensors).
+// conv1 of a ConvNeXt block reads LayerNorm(h): its data gradient dy = d(LN output) went to HBM (512 B per pixel at 128 channels) only to be
+// read back by layernorm_c_bwd next to h.  Where ONE N tile holds every channel of its pixels (Cout == BN: 64 or 128 channels) the row of
+// the staging tile IS a pixel's whole dy, so the epilogue applies the LayerNorm backward itself (deblurring_diffusion_pytorch.py:111-121):
+//     xh = (h - mean) rstd,  gy = dy g,  dh = rstd (gy - mean_c(gy) - xh mean_c(gy xh)),   dg += dy xh,  db += dy  (summed over the tile)
+// -- the same expressions, in the same order per pixel, as layernorm_c_bwd_kernel; the channel sums run over the BN / 4 lanes of a row
+// (wave shuffles), the parameter-gradient partials leave as ln_part[tile][2][BN] for cdf_norm_param_reduce.  h, mean and rstd are
+// requested before the accumulators go through LDS.  Args: ln_x / ld_lnx (h), ln_mean, ln_rstd ([M]), bias = the LayerNorm gain g (a data
+// gradient has no bias of its own), y / ldy = dh, ln_part.
+// ================================================================================================
+#define CDF_EPI_LNBWD 12
+template <int BM, int BN, int NTHR, class Args, class Dump>
+__device__ __forceinline__ void cdf_epi_lnbwd(const Args& a, float* cs, int tile_m, int tid, Dump&& dump) {
+    constexpr int CP = BN + 8, TPR = BN / 4, RPS = NTHR / TPR, NR = BM / RPS;
+    static_assert(NR >= 1 && NR * RPS == BM && (TPR & (TPR - 1)) == 0 && TPR <= 64, "rows divide among the threads; a row is a power-of-two lane group");
+    int c4 = (tid % TPR) * 4, p0 = tid / TPR;
+    CDF_OPAQUE_V(c4);
+    CDF_OPAQUE_V(p0);
+    const long long row0 = (long long)tile_m * BM;
+    const f32x4_t g = *(const f32x4_t*)(a.bias + c4);
+    const float* xb = a.ln_x + row0 * a.ld_lnx;
+    const float* mb = a.ln_mean + row0;
+    const float* rb = a.ln_rstd + row0;
+    f32x4_t x[NR];
+    float mean[NR], rstd[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const unsigned r = (unsigned)(p0 + k * RPS);
+        x[k] = *(const f32x4_t*)(xb + r * (unsigned)a.ld_lnx + (unsigned)c4);
+        mean[k] = mb[r];
+        rstd[k] = rb[r];
+    }
+    dump();
+    CDF_LDS_BARRIER();                                       // (LDS only: the operand loads stay in flight)
+    float* const ybase = a.y + row0 * a.ldy;
+    const float inv_c = 1.0f / (float)BN;
+    f32x4_t dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t nxt = *(const f32x4_t*)(cs + (unsigned)p0 * CP + c4);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const unsigned p = (unsigned)(p0 + k * RPS);
+        const f32x4_t d = nxt;
+        if (k + 1 < NR) nxt = *(const f32x4_t*)(cs + (p + RPS) * CP + c4);
+        f32x4_t xh, gy, o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xh[e] = (x[k][e] - mean[k]) * rstd[k];
+            dg[e] += d[e] * xh[e];
+            db[e] += d[e];
+            gy[e] = d[e] * g[e];
+        }
+        float s1 = (gy[0] + gy[1]) + (gy[2] + gy[3]);
+        float s2 = (gy[0] * xh[0] + gy[1] * xh[1]) + (gy[2] * xh[2] + gy[3] * xh[3]);
+        s1 = cdf_group_sum(s1, TPR) * inv_c;
+        s2 = cdf_group_sum(s2, TPR) * inv_c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd[k] * (gy[e] - s1 - xh[e] * s2);
+        *(f32x4_t*)(ybase + p * (unsigned)a.ldy + (unsigned)c4) = o;
+        CDF_SCHED_FENCE();
+    }
+    // parameter-gradient partials of the tile: the RPS row groups folded through LDS in a fixed order (deterministic)
+    CDF_LDS_BARRIER();                                       // every thread is done with the staging rows
+    float* red = cs;                                         // [RPS][2][BN]
+    *(f32x4_t*)(red + ((unsigned)p0 * 2 + 0) * BN + c4) = dg;
+    *(f32x4_t*)(red + ((unsigned)p0 * 2 + 1) * BN + c4) = db;
+    CDF_LDS_BARRIER();
+    for (int e = tid; e < 2 * BN; e += NTHR) {
+        float t = 0.f;
+#pragma unroll 4
+        for (int r = 0; r < RPS; ++r) t += red[r * 2 * BN + e];
+        a.ln_part[(long long)tile_m * 2 * BN + e] = t;
+    }
+}

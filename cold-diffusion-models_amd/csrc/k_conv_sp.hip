@@ -693,6 +693,7 @@ extern "C" int cdf_conv_gemm_bf16(const float* x, int ldx, const void* w_hi, con
     a.vec = cdf_epi_vec_ok(Cout, y, ldy, bias, sbias, ld_sbias, res, ldr, pre, ldp, mul, ldm);
     a.ys_hi = nullptr; a.ys_lo = nullptr; a.ld_ys = 0; a.io_bf = 0;
     a.epi = cdf_epi_select(a);
+    a.ln_x = nullptr; a.ln_mean = nullptr; a.ln_rstd = nullptr; a.ln_part = nullptr; a.ld_lnx = 0;
     const int* pd = phase_desc;
     for (int p = 0; p < nphase; ++p) {
         a.ph[p].oy = pd[0]; a.ph[p].ox = pd[1]; a.ph[p].ntaps = pd[2];

@@ -356,7 +356,7 @@ extern "C" int cdf_conv_gemm_bf16x_ksplit(int M, int Cout, int nphase, int ntaps
 
 template <int NS>
 static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cout, int QH, int QW, int os, int is, int nphase, long long ks_ws_floats,
-                               const cdf_gemm_tuning& T, hipStream_t s) {
+                               const cdf_gemm_tuning& T, hipStream_t s, int* bm_out = nullptr) {
     // Tile choice: 64-wide N for Cout <= 64 (no half-empty MFMA columns); 64-row M tiles when 128-row tiles would
     // leave most of the 256 CUs x 2 resident blocks idle (deep, small-image layers: M = 8192 at 16 x 16); the 8-wave
     // 256 x 128 tile (3 stages, one block per CU) when it still gives every CU at least ~2 tiles.
@@ -411,10 +411,12 @@ static int dispatch_gemm_bf16x(SpxArgs& a, int B, int H, int W, int Cin, int Cou
                 // (at 128-pixel width only next to 64-wide weight stages)
                 const bool bm256 = (W <= 64 || n64) && T.halo_bm != 128 && H % (256 / W) == 0 && M % 256 == 0 &&
                                    (T.halo_bm == 256 || (long long)(M / 256) * cdf_cdiv(Cout, n64 ? 64 : 128) >= 256);
+                if (bm_out) *bm_out = bm256 ? 256 : 128;
                 return cdf_launch_igemm_halo(NS, W, n64, bm256 ? 256 : 128, a, M, s);
             }
         }
     }
+    if (bm_out) *bm_out = bm;                               // (the generic kernels below take the row tile chosen above)
     if (m256) return launch_igemm_spx<NS, 256, 128, 4, 2, 3>(a, M, s);
     // Grids that do not even give every CU one 64-row tile (the 4 x 4 / 8 x 8-pixel levels of the 32 x 32 configurations, small
     // sampling batches): a block's life is its K loop, and with two stages every step waited out a whole DMA round trip (144 steps
@@ -491,6 +493,7 @@ extern "C" int cdf_conv_gemm_bf16x_io(const void* x_hi, const void* x_lo, int ld
     a.ys_hi = (unsigned short*)y_hi; a.ys_lo = (unsigned short*)y_lo; a.ld_ys = ld_ys;
     a.io_bf = io_bf16;
     a.epi = cdf_tune(tune)->epilogue ? cdf_epi_select(a) : 0;
+    a.ln_x = nullptr; a.ln_mean = nullptr; a.ln_rstd = nullptr; a.ln_part = nullptr; a.ld_lnx = 0;
     CDF_REQUIRE(!y_hi || a.vec, "cdf_conv_gemm_bf16x: split output planes need the vectorised epilogue (aligned pointers, pitches %% 4)");
     CDF_REQUIRE(!(io_bf16 & 7) || a.vec, "cdf_conv_gemm_bf16x_io: bf16 epilogue operands need the vectorised epilogue (16-byte-aligned pointers, pitches %% 4, Cout %% 4)");
     int rc = fill_phases(a.ph, nphase, phase_desc, "cdf_conv_gemm_bf16x");
@@ -500,3 +503,45 @@ extern "C" int cdf_conv_gemm_bf16x_io(const void* x_hi, const void* x_lo, int ld
                 : dispatch_gemm_bf16x<1>(a, B, H, W, Cin, Cout, QH, QW, os, is, nphase, ws ? ws_floats : 0, *cdf_tune(tune), CDF_S);
 }
 
+
+// Data gradient of a 3 x 3 stride-1 "same" convolution whose INPUT was a channel LayerNorm's output, with that LayerNorm's backward applied in
+// the epilogue (cdf_epilogue.h: cdf_epi_lnbwd): dh = LayerNorm'(h; mean, rstd, g)[conv_dgrad(dy)], dg / db (+)= the parameter gradients.
+// Needs one N tile to hold every channel (Cout = the LayerNorm's width = 64 or 128) and whole row tiles (M % 256 == 0);
+// cdf_conv_gemm_bf16x_lnbwd_ok tells.  part: >= (M / 64) * 2 * Cout floats of scratch.
+extern "C" int cdf_conv_gemm_bf16x_lnbwd_ok(int B, int H, int W, int Cin, int Cout, int nphase, int ntaps) {
+    const long long M = (long long)B * H * W;
+    return (Cout == 64 || Cout == 128) && nphase == 1 && ntaps == 9 && M % 256 == 0 && M < (1ll << 31) && Cin % 32 == 0 && Cin >= 64;
+}
+extern "C" int cdf_conv_gemm_bf16x_lnbwd(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo, int ldk,
+                                         int B, int H, int W, int Cin, int Cout, const int* phase_desc, const float* ln_x, int ld_lnx,
+                                         const float* ln_mean, const float* ln_rstd, const float* ln_g, float* dh, int lddh, float* dg, float* db,
+                                         float* part, const cdf_gemm_tuning* tune, void* stream) {
+    CDF_REQUIRE(x_hi && zero && w_hi && phase_desc && ln_x && ln_mean && ln_rstd && ln_g && dh && dg && db && part, "cdf_conv_gemm_bf16x_lnbwd: null pointer");
+    CDF_TUNE_CHECK(tune, "cdf_conv_gemm_bf16x_lnbwd");
+    CDF_REQUIRE((x_lo != nullptr) == (w_lo != nullptr), "cdf_conv_gemm_bf16x_lnbwd: pass both lo planes or neither");
+    CDF_REQUIRE(cdf_conv_gemm_bf16x_lnbwd_ok(B, H, W, Cin, Cout, 1, phase_desc[2]), "cdf_conv_gemm_bf16x_lnbwd: needs a 3 x 3 stride-1 layer with 64 or 128 output channels, B*H*W %% 256 == 0");
+    CDF_REQUIRE(((((uintptr_t)x_hi) | ((uintptr_t)x_lo) | ((uintptr_t)zero) | ((uintptr_t)w_hi) | ((uintptr_t)w_lo) | ((uintptr_t)ln_x) | ((uintptr_t)ln_g) | ((uintptr_t)dh)) & 15) == 0 &&
+                ldx % 8 == 0 && ldx >= Cin && ldk % 32 == 0 && ldk >= Cin && ld_lnx % 4 == 0 && ld_lnx >= Cout && lddh % 4 == 0 && lddh >= Cout,
+                "cdf_conv_gemm_bf16x_lnbwd: alignment / pitches");
+    SpxArgs a;
+    a.x_hi = (const unsigned short*)x_hi; a.x_lo = (const unsigned short*)x_lo; a.zero = (const unsigned short*)zero;
+    a.w_hi = (const unsigned short*)w_hi; a.w_lo = (const unsigned short*)w_lo; a.y = dh;
+    a.bias = ln_g; a.sbias = nullptr; a.res = nullptr; a.pre = nullptr; a.mul = nullptr;
+    a.ldx = ldx; a.ldk = ldk; a.ldy = lddh; a.ld_sbias = 0; a.ldr = 0; a.ldp = 0; a.ldm = 0;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.OH = H; a.OW = W; a.Cout = Cout; a.QH = H; a.QW = W; a.os = 1; a.is = 1;
+    a.act = 0; a.mul_mode = 0; a.accumulate = 0; a.nphase = 1; a.vec = 1;
+    a.ys_hi = nullptr; a.ys_lo = nullptr; a.ld_ys = 0; a.io_bf = 0;
+    a.epi = CDF_EPI_LNBWD;
+    a.ln_x = ln_x; a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.ln_part = part; a.ld_lnx = ld_lnx;
+    int rc = fill_phases(a.ph, 1, phase_desc, "cdf_conv_gemm_bf16x_lnbwd");
+    if (rc) return rc;
+    a.ksplit = 1; a.ks_ws = nullptr; a.ks_ld = 0;
+    // every kernel but the resident two-pass one runs the whole-tile epilogue this form lives in; N tiles as wide as the layer
+    cdf_gemm_tuning T = *cdf_tune(tune);
+    T.rowhalo_stream = 0; T.small_n64 = 0; T.tile_bn = 0; T.splitk = 0;
+    int bm = 0;
+    rc = x_lo ? dispatch_gemm_bf16x<3>(a, B, H, W, Cin, Cout, H, W, 1, 1, 1, 0, T, CDF_S, &bm) : dispatch_gemm_bf16x<1>(a, B, H, W, Cin, Cout, H, W, 1, 1, 1, 0, T, CDF_S, &bm);
+    if (rc) return rc;
+    CDF_REQUIRE(bm == 64 || bm == 128 || bm == 256, "cdf_conv_gemm_bf16x_lnbwd: the dispatcher reported no row tile");
+    return cdf_norm_param_reduce(part, (int)((long long)B * H * W / bm), Cout, dg, db, 1, stream);
+}

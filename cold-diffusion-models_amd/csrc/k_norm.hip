@@ -558,6 +558,14 @@ extern "C" int cdf_layernorm_c_bwd_io(const void* dy, int lddy, const void* x, i
     return cdf_check_launch("layernorm_c_bwd");
 }
 
+// dg[c] (+)= sum_b part[b][0][c], db[c] (+)= sum_b part[b][1][c]: the second stage of every LayerNorm backward (also behind the fused
+// data-gradient epilogue, cdf_conv_gemm_bf16x_lnbwd)
+extern "C" int cdf_norm_param_reduce(const float* part, int nblocks, int C, float* dg, float* db, int accumulate, void* stream) {
+    CDF_REQUIRE(part && dg && db && nblocks > 0 && C > 0, "cdf_norm_param_reduce: bad args");
+    CDF_LAUNCH(norm_param_reduce_kernel, dim3(cdf_cdiv(2 * C, 64)), dim3(1024), 0, CDF_S, part, nblocks, C, dg, db, accumulate);
+    return cdf_check_launch("norm_param_reduce");
+}
+
 extern "C" int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, int ldx, const float* g,
                                    const float* mean, const float* rstd, float* dx, int lddx, const float* add, int ldadd,
                                    float* dg, float* db, float* part, long long M, int C, int accumulate_dx, int accumulate_param,

@@ -231,6 +231,17 @@ int cdf_conv_gemm_bf16x_io(const void* x_hi, const void* x_lo, int ldx, const vo
                            int ldr, void* pre, int ldp, const void* mul, int ldm, int act, int mul_mode, int accumulate, int io_bf16,
                            void* y_hi, void* y_lo, int ld_ys, float* ws, long long ws_floats, const cdf_gemm_tuning* tune, void* stream);
 int cdf_bf16_to_f32(const void* x, int ldx, float* y, int ldy, long long rows, int C, void* stream);
+/* cdf_conv_gemm_bf16x_lnbwd (round 6): the data gradient of a 3 x 3 stride-1 convolution that read a channel LayerNorm's output, with that
+ * LayerNorm's backward applied in the epilogue -- dh = LN'(h; mean, rstd, g)[conv_dgrad(dy)], dg / db += the parameter gradients -- so the
+ * gradient with respect to the LayerNorm output never goes to HBM (deblurring_diffusion_pytorch.py:111-121, 149-151).  x = the dy planes,
+ * w = the data-gradient packing of the weight, Cin = dy's channels, Cout = the LayerNorm's width; ln_x = h (pitch ld_lnx), ln_mean / ln_rstd [B*H*W].
+ * cdf_conv_gemm_bf16x_lnbwd_ok: 1 if the geometry qualifies (one N tile holds every channel: Cout 64 or 128; whole row tiles:
+ * B*H*W % 256 == 0; nine taps).  part: >= (B*H*W / 64) * 2 * Cout floats.  Same expressions per pixel as cdf_layernorm_c_bwd. */
+int cdf_conv_gemm_bf16x_lnbwd_ok(int B, int H, int W, int Cin, int Cout, int nphase, int ntaps);
+int cdf_conv_gemm_bf16x_lnbwd(const void* x_hi, const void* x_lo, int ldx, const void* zero, const void* w_hi, const void* w_lo, int ldk,
+                              int B, int H, int W, int Cin, int Cout, const int* phase_desc, const float* ln_x, int ld_lnx,
+                              const float* ln_mean, const float* ln_rstd, const float* ln_g, float* dh, int lddh, float* dg, float* db,
+                              float* part, const cdf_gemm_tuning* tune, void* stream);
 /* cdf_conv_gemm_io: the exact-fp32 GEMM (cdf_conv_gemm) with typed epilogue operands (same io_bf16 bits) and an optional bf16 output plane
  * y_hi (pitch ld_ys; y may then be NULL): how the fp32 inside of the linear-attention block reads the bf16 stream as its residual and
  * writes its result into it.  A batched launch without y needs an epilogue operand (outputs that are whole rows of one tensor). */
@@ -318,6 +329,7 @@ int cdf_layernorm_c_fwd(const float* x, int ldx, float* y, int ldy, const float*
                         float* rstd, long long M, int C, float eps, void* y_hi, void* y_lo, int ld_ys, void* stream);
 /* add (nullable, pitch ldadd): dx = grad + add -- the residual branch of Residual(PreNorm(..)) added in the same pass instead of a
  * copy + accumulate; accumulate_dx = 1 is the same with add = dx (the two exclude each other). */
+int cdf_norm_param_reduce(const float* part, int nblocks, int C, float* dg, float* db, int accumulate, void* stream);
 int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, int ldx, const float* g, const float* mean,
                         const float* rstd, float* dx, int lddx, const float* add, int ldadd, float* dg, float* db, float* part,
                         long long M, int C, int accumulate_dx, int accumulate_param, void* stream);

@@ -1255,6 +1255,71 @@ def test_specialised_epilogue_rowhalo_emu(spec):
     _epi_case(be, spec, 1, 128, 128, 16)
 
 
+def _lnbwd_case(be, B, Cmid, C, H, tune=None):
+    """cdf_conv_gemm_bf16x_lnbwd (data gradient of the 3 x 3 convolution behind a channel LayerNorm, with the LayerNorm backward in the
+    epilogue) against the two launches it replaces: the same GEMM writing dhn, then cdf_layernorm_c_bwd."""
+    torch.manual_seed(5)
+    dy = torch.randn(B, H, H, Cmid)
+    w = torch.randn(C, Cmid, 3, 3) / math.sqrt(Cmid * 9)     # (already in data-gradient orientation: rows = the LayerNorm's channels)
+    h = torch.randn(B, H, H, C) * 1.5 + 0.3
+    g = torch.randn(C)
+    M = B * H * H
+    mean = h.mean(-1).reshape(M)
+    rstd = (h.var(-1, unbiased=False) + 1e-5).rsqrt().reshape(M)
+    zero = be.zeros(16)
+    ldk = (Cmid + 31) // 32 * 32
+    whi = torch.empty(9, C, ldk, dtype=torch.int16, device=be.device)
+    wlo = torch.empty_like(whi)
+    be.L.cdf_pack_weight_bf16(P(be.to(w)), P(whi), P(wlo), 9, C, Cmid, ldk, 1, Cmid * 9, 9, be.stream())
+    xs = _split(be, be.to(dy), False)
+    plan = cd.conv_fwd(H, H, 3, 3, 1, 1, 1, 1, 1)
+    assert be.L.cdf_conv_gemm_bf16x_lnbwd_ok(B, H, H, Cmid, C, plan.nphase, plan.desc[2])
+    hd, gd, md, rd = be.to(h), be.to(g), be.to(mean), be.to(rstd)
+    old = {k: be.tune.get(k) for k in (tune or {})}
+    be.tune.set(**(tune or {}))
+    try:
+        # reference pair
+        dhn = be.zeros(B, H, H, C)
+        be.L.cdf_conv_gemm_bf16x(P(xs[0]), P(xs[1]), xs[0].shape[-1], P(zero), P(whi), P(wlo), ldk, P(dhn), C, B, H, H, Cmid, H, H, C, H, H, 1, 1, 1,
+                                 plan.desc, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, be.tune.ptr, be.stream())
+        dh0, dg0, db0 = be.zeros(B, H, H, C), be.zeros(C), be.zeros(C)
+        part0 = be.zeros(be.L.cdf_layernorm_blocks(M, C) * 2 * C)
+        be.L.cdf_layernorm_c_bwd(P(dhn), C, P(hd), C, P(gd), P(md), P(rd), P(dh0), C, 0, 0, P(dg0), P(db0), P(part0), M, C, 0, 0, be.stream())
+        # fused; parameter gradients ACCUMULATE (the reference pair above wrote into zeros: start from a known non-zero value)
+        dh1, dg1, db1 = be.zeros(B, H, H, C), be.to(torch.full((C,), 2.0)), be.to(torch.full((C,), -3.0))
+        part1 = be.zeros(M // 64 * 2 * C)
+        be.L.cdf_conv_gemm_bf16x_lnbwd(P(xs[0]), P(xs[1]), xs[0].shape[-1], P(zero), P(whi), P(wlo), ldk, B, H, H, Cmid, C, plan.desc, P(hd), C,
+                                       P(md), P(rd), P(gd), P(dh1), C, P(dg1), P(db1), P(part1), be.tune.ptr, be.stream())
+    finally:
+        be.tune.set(**old)
+    dh0, dh1 = dh0.cpu(), dh1.cpu()
+    scale = dh0.abs().max().item()
+    assert scale > 0
+    # same GEMM sums (possibly another tile shape => another summation order), same per-pixel expressions: fp32 rounding apart
+    assert (dh0 - dh1).abs().max().item() <= 2e-5 * scale, (dh0 - dh1).abs().max().item() / scale
+    for a0, a1, off in ((dg0, dg1, 2.0), (db0, db1, -3.0)):
+        a0, a1 = a0.cpu(), a1.cpu() - off
+        assert (a0 - a1).abs().max().item() <= 2e-5 * max(1.0, a0.abs().max().item()) * math.sqrt(M / 256), (a0 - a1).abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 64, 16), (1, 256, 128, 16), (4, 128, 64, 16)])
+def test_conv_dgrad_with_layernorm_backward_epilogue(be, shape):
+    _lnbwd_case(be, *shape)
+
+
+def test_conv_dgrad_with_layernorm_backward_epilogue_generic_kernels(be):
+    # halo = 0: the generic (non-resident) kernels' tiles -- 64 / 128 rows at these sizes
+    _lnbwd_case(be, 2, 128, 64, 16, tune=dict(halo=0))
+    _lnbwd_case(be, 1, 128, 128, 16, tune=dict(halo=0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4, 128, 64, 128), (4, 256, 128, 64), (32, 128, 64, 128), (2, 256, 128, 32)])
+def test_conv_dgrad_with_layernorm_backward_epilogue_large(shape):
+    from conftest import Backend
+    _lnbwd_case(Backend("hip"), *shape)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("spec", EPI_SPECS)
 @pytest.mark.parametrize("shape", [(4, 64, 128, 128), (4, 128, 64, 128), (4, 128, 256, 64), (8, 512, 256, 16)])

@@ -418,6 +418,37 @@ def test_two_image_trainers(mbe, tmp_path):
     assert torch.isfinite(tr2.train_step()).item()
 
 
+def test_time_of_one_row_broadcasts_over_the_image_batch(mbe):
+    """DEBLUR:160 adds the time condition by torch broadcasting, so a [1] time against B images is legal upstream (the GMM scripts call
+    all_sample(1, imgs), DENOISE:1203); this engine indexes its per-sample tables by image row -- the [1] time must be expanded, not read
+    past its end -- and any other mismatch must fail like the broadcast would."""
+    from deblurring_diffusion_pytorch import Model, Unet
+    torch.manual_seed(2)
+    x = mbe.to(torch.randn(3, 3, 16, 16))
+    for net in (quiet(Unet, dim=8, dim_mults=(1, 2), channels=3), Model(resolution=16, in_channels=3, out_ch=3, ch=32, ch_mult=(1, 2), num_res_blocks=1,
+                                                                        attn_resolutions=(8,), dropout=0.0)):
+        net = net.to(mbe.device).eval()
+        with torch.no_grad():
+            t1 = mbe.to(torch.tensor([2.0]))
+            assert torch.equal(net(x, t1), net(x, t1.expand(3).contiguous()))
+            with pytest.raises(RuntimeError, match="must match the size"):
+                net(x, mbe.to(torch.tensor([1.0, 2.0])))
+
+
+def test_step_vector_of_one_row_broadcasts_in_the_degradation_ops(mbe):
+    """... and the same for the schedule lookups (`extract(a, t, x_shape)` upstream): all_sample(1, imgs) hands [1]-row steps to B-image launches."""
+    from colddiff import degrade as D
+    torch.manual_seed(4)
+    x0, eps = mbe.to(torch.randn(3, 3, 8, 8)), mbe.to(torch.randn(3, 3, 8, 8))
+    ca, cb = mbe.to(torch.rand(5)), mbe.to(torch.rand(5))
+    t1 = mbe.to(torch.tensor([3]))
+    assert torch.equal(D.noise_qsample(x0, eps, ca, cb, t1), D.noise_qsample(x0, eps, ca, cb, t1.expand(3).contiguous()))
+    al = mbe.to(torch.rand(5, 1, 8, 8))
+    assert torch.equal(D.blend_qsample(x0, eps, al, 1 - al, t1), D.blend_qsample(x0, eps, al, 1 - al, t1.expand(3).contiguous()))
+    with pytest.raises(RuntimeError, match="must match the size"):
+        D.noise_qsample(x0, eps, ca, cb, mbe.to(torch.tensor([1, 2])))
+
+
 def test_generation_scripts_of_the_two_image_packages(mbe, tmp_path):
     """The generation / evaluation scripts the denoising, demixing and defading-generation Trainers share (colddiff.evaluate.GenEvalMixin;
     DENOISE:821-854, 1091-1395 and the whitespace-identical copies): every saved image is the sampler's output for the seeds the script
