@@ -469,13 +469,12 @@ def _reduce_slabs(L, ws, gparam, ns, ntaps, CA, CB, ldo, s_t, s_r, s_c, bsum, gb
 def colsum_into(gvec, x, C, nseg=1):
     """gvec[seg][c] += sum over the rows of segment seg of x (x: [..., C] pitched rows)."""
     L = rt.lib()
-    x = f32_of(x)
     ld = ld_of(x)
     rows = x.numel() // x.shape[-1]
     rps = rows // nseg
     nch = L.cdf_colsum_nchunk(rps)
     ws = torch.empty((nseg * nch * C,), device=x.device, dtype=torch.float32)
-    L.cdf_colsum(P(x), P(gvec), P(ws), nseg, rps, C, ld, gvec.stride(0) if gvec.dim() == 2 else C, 1, rt.stream(x))
+    L.cdf_colsum_io(P(x), P(gvec), P(ws), nseg, rps, C, ld, gvec.stride(0) if gvec.dim() == 2 else C, 1, 1 if is_bf(x) else 0, rt.stream(x))
 
 
 def copy_feat(src, C=None):

@@ -110,6 +110,8 @@ __device__ __forceinline__ void cdf_split_store4(unsigned short* hi, unsigned sh
 // Offsets are in ELEMENTS of the tensor's own type.
 template <bool BF> struct cdf_quad { typedef float4 raw; typedef float elem; };
 template <> struct cdf_quad<true> { typedef uint2 raw; typedef unsigned short elem; };
+__device__ __forceinline__ float cdf_widen(float v) { return v; }                                        // one element of either type as a float
+__device__ __forceinline__ float cdf_widen(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
 __device__ __forceinline__ float4 cdf_quad_cvt(const float4& r) { return r; }
 __device__ __forceinline__ float4 cdf_quad_cvt(const uint2& r) {
     return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xFFFF0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xFFFF0000u));

@@ -613,24 +613,28 @@ __global__ void __launch_bounds__(256) unpack_reduce_tiled_kernel(const float* w
 //   stage 1: part[(seg*nchunk + chunk)][c] = sum_{r in chunk of segment} x[r*ld + c]
 //   stage 2: out[seg][c] (+)= sum_chunk part
 // grid1 = (ceil(C/64), nseg, nchunk); block = 256 = 4 row-lanes x 64 channels
-__global__ void colsum_partial_kernel(const float* x, float* part, int rows_per_seg, int rows_per_chunk, int C, int ld) {
+template <bool BF>                                          // BF: x is a bf16 tensor (ld in bf16 elements), widened as it is read
+__global__ void colsum_partial_kernel(const void* xv, float* part, int rows_per_seg, int rows_per_chunk, int C, int ld) {
+    typedef typename cdf_quad<BF>::elem elem_t;
+    const elem_t* x = (const elem_t*)xv;
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     const int r0 = blockIdx.z * rows_per_chunk;
     int r1 = r0 + rows_per_chunk;
     if (r1 > rows_per_seg) r1 = rows_per_seg;
-    const float* p = x + (long long)blockIdx.y * rows_per_seg * ld;
+    const elem_t* p = x + (long long)blockIdx.y * rows_per_seg * ld;
     float s = 0.f;
     if (c < C) {
         // 8 independent rows in flight per lane (a one-load-per-trip loop crawled at 0.6 TB/s)
-        float t[8];
+        elem_t t[8];
         int r = r0 + rl;
         for (; r + 28 < r1; r += 32) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) t[u] = p[(long long)(r + 4 * u) * ld + c];
-            s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+            s += ((cdf_widen(t[0]) + cdf_widen(t[1])) + (cdf_widen(t[2]) + cdf_widen(t[3]))) +
+                 ((cdf_widen(t[4]) + cdf_widen(t[5])) + (cdf_widen(t[6]) + cdf_widen(t[7])));
         }
-        for (; r < r1; r += 4) s += p[(long long)r * ld + c];
+        for (; r < r1; r += 4) s += cdf_widen(p[(long long)r * ld + c]);
     }
     red[rl][threadIdx.x & 63] = s;
     __syncthreads();
@@ -962,12 +966,19 @@ extern "C" int cdf_colsum_nchunk(int rows_per_seg) {
 }
 
 // ws: >= nseg * cdf_colsum_nchunk(rows_per_seg) * C floats
-extern "C" int cdf_colsum(const float* x, float* out, float* ws, int nseg, int rows_per_seg, int C, int ld, int ldo,
-                          int accumulate, void* stream) {
+extern "C" int cdf_colsum_io(const void* x, float* out, float* ws, int nseg, int rows_per_seg, int C, int ld, int ldo,
+                             int accumulate, int x_bf16, void* stream) {
     CDF_REQUIRE(x && out && ws && nseg > 0 && rows_per_seg > 0 && C > 0 && ld >= C && ldo >= C, "cdf_colsum: bad args");
     const int nchunk = cdf_colsum_nchunk(rows_per_seg);
     const int rpc = cdf_cdiv(rows_per_seg, nchunk);
-    CDF_LAUNCH(colsum_partial_kernel, dim3(cdf_cdiv(C, 64), nseg, nchunk), dim3(256), 0, CDF_S, x, ws, rows_per_seg, rpc, C, ld);
+    if (x_bf16)
+        CDF_LAUNCH(colsum_partial_kernel<true>, dim3(cdf_cdiv(C, 64), nseg, nchunk), dim3(256), 0, CDF_S, x, ws, rows_per_seg, rpc, C, ld);
+    else
+        CDF_LAUNCH(colsum_partial_kernel<false>, dim3(cdf_cdiv(C, 64), nseg, nchunk), dim3(256), 0, CDF_S, x, ws, rows_per_seg, rpc, C, ld);
     CDF_LAUNCH(colsum_final_kernel, dim3(cdf_cdiv(C, 64), nseg), dim3(1024), 0, CDF_S, (const float*)ws, out, nchunk, C, ldo, accumulate);
     return cdf_check_launch("colsum");
+}
+extern "C" int cdf_colsum(const float* x, float* out, float* ws, int nseg, int rows_per_seg, int C, int ld, int ldo,
+                          int accumulate, void* stream) {
+    return cdf_colsum_io(x, out, ws, nseg, rows_per_seg, C, ld, ldo, accumulate, 0, stream);
 }

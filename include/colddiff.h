@@ -319,6 +319,9 @@ int cdf_unpack_reduce_bias(const float* ws, float* g, int nsplit, int T, int R, 
 int cdf_colsum_nchunk(int rows_per_seg);
 int cdf_colsum(const float* x, float* out, float* ws, int nseg, int rows_per_seg, int C, int ld, int ldo,
                int accumulate, void* stream);
+/* cdf_colsum_io: x_bf16 != 0 reads x as a bf16 tensor (ld in bf16 elements; the bias gradient of a transposed convolution on the bf16 stream) */
+int cdf_colsum_io(const void* x, float* out, float* ws, int nseg, int rows_per_seg, int C, int ld, int ldo,
+                  int accumulate, int x_bf16, void* stream);
 
 /* ---- normalisation ------------------------------------------------------------------------------
  * channel LayerNorm (deblurring_diffusion_pytorch.py:111-121): per-pixel over C, biased variance,

@@ -340,6 +340,11 @@ def test_colsum(be):
     ws, out = be.empty(3 * nch * 70), be.zeros(3, 72)
     be.L.cdf_colsum(P(be.to(x)), P(out), P(ws), 3, 700, 70, 72, 72, 0, be.stream())
     assert err(out[:, :70], x[..., :70].sum(1)) <= 2e-4
+    # bf16 input (cdf_colsum_io): the same sums of the widened values
+    xb = x.bfloat16()
+    out2 = be.zeros(3, 72)
+    be.L.cdf_colsum_io(P(be.to(xb.view(torch.int16))), P(out2), P(ws), 3, 700, 70, 72, 72, 0, 1, be.stream())
+    assert err(out2[:, :70], xb.float()[..., :70].sum(1)) <= 2e-4
 
 
 # ---------------------------------------------------------------------------------------------
