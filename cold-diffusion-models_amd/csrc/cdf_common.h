@@ -133,6 +133,59 @@ __device__ __forceinline__ void cdf_quad_st(void* base, Off off, const float4& v
         *(float4*)((float*)base + off) = v;
     }
 }
+// ---- range-checked loads (buffer instructions) ------------------------------------------------------
+// A raw buffer resource over [base, base + bytes), base wave-uniform: a load whose byte offset falls outside returns zeros WITHOUT touching
+// memory.  An out-of-image element of a stencil then costs one select on its offset (CDF_BUF_OOB) instead of clamps on both coordinates, a
+// 64-bit address per lane and a select per loaded component.  The simulator build checks the range by hand.
+#define CDF_BUF_OOB 0xFFFFFFFFu
+#ifdef CDF_EMU
+struct cdf_buf { const char* base; unsigned bytes; };
+static inline cdf_buf cdf_make_buf(const void* p, unsigned bytes) { return cdf_buf{(const char*)p, bytes}; }
+static inline float4 cdf_buf_ld(const cdf_buf& b, unsigned off, const float4*) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned long long)off + 16 <= b.bytes) v = *(const float4*)(b.base + off);
+    return v;
+}
+static inline uint2 cdf_buf_ld(const cdf_buf& b, unsigned off, const uint2*) {
+    uint2 v = make_uint2(0u, 0u);
+    if ((unsigned long long)off + 8 <= b.bytes) v = *(const uint2*)(b.base + off);
+    return v;
+}
+static inline void cdf_buf_st(const cdf_buf& b, unsigned off, const float4& v) {
+    if ((unsigned long long)off + 16 <= b.bytes) *(float4*)(b.base + off) = v;
+}
+static inline void cdf_buf_st(const cdf_buf& b, unsigned off, const uint2& v) {
+    if ((unsigned long long)off + 8 <= b.bytes) *(uint2*)(b.base + off) = v;
+}
+#else
+typedef __amdgpu_buffer_rsrc_t cdf_buf;
+__device__ __forceinline__ cdf_buf cdf_make_buf(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);     // (dword 3: raw buffer, 32-bit data format)
+}
+__device__ __forceinline__ float4 cdf_buf_ld(const cdf_buf& b, unsigned off, const float4*) {
+    typedef int i4_t __attribute__((ext_vector_type(4)));
+    const i4_t v = __builtin_amdgcn_raw_buffer_load_b128(b, (int)off, 0, 0);
+    return make_float4(__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3]));
+}
+__device__ __forceinline__ uint2 cdf_buf_ld(const cdf_buf& b, unsigned off, const uint2*) {
+    typedef int i2_t __attribute__((ext_vector_type(2)));
+    const i2_t v = __builtin_amdgcn_raw_buffer_load_b64(b, (int)off, 0, 0);
+    return make_uint2((unsigned)v[0], (unsigned)v[1]);
+}
+__device__ __forceinline__ void cdf_buf_st(const cdf_buf& b, unsigned off, const float4& v) {        // (out of range: dropped)
+    typedef int i4_t __attribute__((ext_vector_type(4)));
+    const i4_t t = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(t, b, (int)off, 0, 0);
+}
+__device__ __forceinline__ void cdf_buf_st(const cdf_buf& b, unsigned off, const uint2& v) {
+    typedef int i2_t __attribute__((ext_vector_type(2)));
+    const i2_t t = {(int)v.x, (int)v.y};
+    __builtin_amdgcn_raw_buffer_store_b64(t, b, (int)off, 0, 0);
+}
+#endif
+// a float4 in the tensor's storage type (bf16: rounded to nearest even), for the buffer stores
+__device__ __forceinline__ float4 cdf_quad_raw(const float4& v, const float4*) { return v; }
+__device__ __forceinline__ uint2 cdf_quad_raw(const float4& v, const uint2*) { return make_uint2(cdf_pack2bf(v.x, v.y), cdf_pack2bf(v.z, v.w)); }
 // runtime-selected forms for the GEMM epilogues (the flag is a kernel argument: a scalar branch)
 __device__ __forceinline__ void cdf_ld4_bf(float* v, const void* base, long long off) {
     const float4 t = cdf_quad_cvt(*(const uint2*)((const unsigned short*)base + off));

@@ -4,6 +4,7 @@
 // HBM-bound (49 MAC per element): each thread produces a 4-pixel x 4-channel strip so that one
 // 10x7 window of float4 loads feeds 196 float4 FMAs; lanes run along channels (coalesced 16 B).
 // Weights are packed [49][Cp] (cdf_pack_weight with R=1), Cp = C rounded up to 4, zero padded.
+#include <type_traits>
 #include "cdf_common.h"
 #include "colddiff.h"
 
@@ -88,8 +89,13 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const void* x, int ldx,
     constexpr int NHALO = HH_ * HW_ * 8, NIT = (NHALO + 255) / 256;
     constexpr int STEP_Y = 32 / HW_, STEP_X = 32 % HW_;      // 32 pixels further in the [HH_][HW_] halo
     const int l_ = tid & 7;
-    const unsigned lc4 = (unsigned)(((cq0 + l_) < C4 ? cq0 + l_ : 0) * 4);
+    const unsigned lc4 = (unsigned)((cq0 + l_) * 4);
     const bool lok = (cq0 + l_) < C4;
+    // Round 6: the halo comes in through range-checked buffer loads over the image (cdf_buf): an element outside the image (or a channel quad
+    // past C4) asks for offset CDF_BUF_OOB and gets zeros without a memory access -- no coordinate clamps, no per-component selects when the
+    // values go to LDS, 32-bit offsets against a scalar base (the global-load form spent as many vector instructions on those as on the
+    // 784 packed FMAs).
+    const cdf_buf xr = cdf_make_buf(xb, (unsigned)H * (unsigned)W * (unsigned)ldx * (unsigned)sizeof(elem_t));
     raw_t hv[NIT];
     {
         int hy = 0, hx = tid >> 3;                           // (tid >> 3 < 32 <= HW_)
@@ -97,9 +103,9 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const void* x, int ldx,
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {                      // every load requested before anything is used
             const int iy = Y0 + hy - 3, ix = X0 + hx - 3;
-            const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-            const unsigned off = __umul24(__umul24((unsigned)iyc, (unsigned)W) + (unsigned)ixc, (unsigned)ldx) + lc4;
-            hv[k] = cdf_quad_ld<BF>(xb, off);
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && lok && hy < HH_;
+            const unsigned off = (__umul24(__umul24((unsigned)iy, (unsigned)W) + (unsigned)ix, (unsigned)ldx) + lc4) * (unsigned)sizeof(elem_t);
+            hv[k] = cdf_buf_ld(xr, ok ? off : CDF_BUF_OOB, (const raw_t*)nullptr);
             hy += STEP_Y;
             hx += STEP_X;
             if (hx >= HW_) { hx -= HW_; ++hy; }
@@ -110,9 +116,7 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const void* x, int ldx,
         if (hx >= HW_) { hx -= HW_; ++hy; }
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
-            const int iy = Y0 + hy - 3, ix = X0 + hx - 3;
-            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W && lok;
-            if (hy < HH_) halo[__umul24((unsigned)hy, (unsigned)RP) + hx * 8 + l_] = ok ? cdf_quad_cvt(hv[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hy < HH_) halo[__umul24((unsigned)hy, (unsigned)RP) + hx * 8 + l_] = cdf_quad_cvt(hv[k]);
             hy += STEP_Y;
             hx += STEP_X;
             if (hx >= HW_) { hx -= HW_; ++hy; }
@@ -129,32 +133,90 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const void* x, int ldx,
     for (int o = 0; o < 2; ++o)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[o][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // halo row y0 + r feeds output row o through kernel row ky = r - o: r = 0 only o = 0, r = 7 only o = 1, r = 1..6 both
-    auto row_step = [&](int r, bool do0, bool do1) {
+    // halo row y0 + r feeds output row o through kernel row ky = r - o: r = 0 only o = 0, r = 7 only o = 1, r = 1..6 both.
+    // Kernel row ky is therefore used twice, at r = ky (output row 0) and r = ky + 1 (output row 1): it is read from LDS ONCE and
+    // kept for the next step (two register sets alternating, the loop walks two halo rows per trip so that no set is ever copied) --
+    // 49 weight reads per thread instead of 98, 129 ds_read_b128 against 784 packed FMAs where 178 had the LDS pipe (4 cycles per
+    // read, one pipe for the four SIMDs) as busy as the vector ALUs (round 6).
+    auto load_w = [&](float4 (&wv)[DW_K], int ky) {
+        const float4* wrow = wl + ky * DW_K * 8 + l8;
+#pragma unroll
+        for (int kx = 0; kx < DW_K; ++kx) wv[kx] = wrow[kx * 8];
+    };
+    auto row_step = [&](int r, const float4 (&w0)[DW_K], const float4 (&w1)[DW_K], bool do0, bool do1) {   // w0 / w1: kernel rows r / r - 1
         float4 win[10];
         const float4* hrow = halo + (y0 + r) * RP + x0 * 8 + l8;
 #pragma unroll
         for (int q = 0; q < 10; ++q) win[q] = hrow[q * 8];
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            if (!(o == 0 ? do0 : do1)) continue;            // (compile-time per call site)
-            const float4* wrow = wl + (r - o) * DW_K * 8 + l8;
+        for (int kx = 0; kx < DW_K; ++kx) {
 #pragma unroll
-            for (int kx = 0; kx < DW_K; ++kx) {
-                const float4 wv = wrow[kx * 8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) f4_fma(acc[o][j], win[kx + j], wv);
+            for (int j = 0; j < 4; ++j) {
+                if (do0) f4_fma(acc[0][j], win[kx + j], w0[kx]);       // (compile-time per call site)
+                if (do1) f4_fma(acc[1][j], win[kx + j], w1[kx]);
             }
         }
     };
-    row_step(0, true, false);
+    float4 wA[DW_K], wB[DW_K];
+    load_w(wA, 0);
+    row_step(0, wA, wA, true, false);
     // rolled on purpose: unrolled, hipcc hoists all window + weight reads to the top and spills
 #pragma unroll 1
-    for (int r = 1; r < 7; ++r) row_step(r, true, true);
-    row_step(7, false, true);
+    for (int r = 1; r < 7; r += 2) {
+        load_w(wB, r);
+        row_step(r, wB, wA, true, true);
+        load_w(wA, r + 1);
+        row_step(r + 1, wA, wB, true, true);
+    }
+    row_step(7, wA, wA, false, true);
 
-    if (cq >= C4) return;
-    const int c = cq * 4;
+    // outputs (and the fused `+= y`, `+ res` operands) through buffer resources over the image too: a pixel past the image edge or a channel
+    // quad past C4 is one select on the offset, the store is dropped by the range check.  Every operand is requested before the first store
+    // (stores count in vmcnt on gfx9: a load behind a store waits for its acknowledgement).  Requested AHEAD of the FMAs instead (64 more
+    // live registers) the launch itself gains another 3 % and the training step LOSES 1.2 % -- the GEMMs around it slow down by more than
+    // this kernel gains (profiles/round6_dwconv_buffer_ab.txt; measured three times in one call, unexplained: not kept)
+    typedef typename cdf_quad<YB>::raw yraw_t;
+    const int c = (cq < C4 ? cq : 0) * 4;
+    const unsigned img_px = (unsigned)H * (unsigned)W;
+    const cdf_buf yr = cdf_make_buf((const yelem_t*)y + (long long)b * H * W * ldy, img_px * (unsigned)ldy * (unsigned)sizeof(yelem_t));
+    const cdf_buf rr = cdf_make_buf(res ? (const elem_t*)res + (long long)b * H * W * ldr : (const elem_t*)x, res ? img_px * (unsigned)ldr * (unsigned)sizeof(elem_t) : 0u);
+    unsigned offy[2][4], offr[2][4];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int oy = Y0 + y0 + o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ox = X0 + x0 + j;
+            const bool ok = oy < H && ox < W && cq < C4;
+            const unsigned pix = __umul24((unsigned)oy, (unsigned)W) + (unsigned)ox;
+            offy[o][j] = ok ? (__umul24(pix, (unsigned)ldy) + (unsigned)c) * (unsigned)sizeof(yelem_t) : CDF_BUF_OOB;
+            offr[o][j] = ok ? (__umul24(pix, (unsigned)ldr) + (unsigned)c) * (unsigned)sizeof(elem_t) : CDF_BUF_OOB;
+        }
+    }
+    // (one register array when y and res have the same storage type -- the engine passes `+= y` or `+ res`, never both; if both do
+    //  come, y is read after the FMAs instead)
+    constexpr bool SAME = sizeof(raw_t) == sizeof(yraw_t);
+    raw_t opv[2][4];                                         // res, or (SAME, no res) the old y
+    yraw_t oldv[2][4];
+    if (res) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) opv[o][j] = cdf_buf_ld(rr, offr[o][j], (const raw_t*)nullptr);
+    } else if (SAME && accumulate) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) opv[o][j] = cdf_buf_ld(yr, offy[o][j], (const raw_t*)nullptr);
+    }
+    if constexpr (!SAME) {
+        if (accumulate) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) oldv[o][j] = cdf_buf_ld(yr, offy[o][j], (const yraw_t*)nullptr);
+        }
+    }
     float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias) {
         const float4 bv = *(const float4*)(bias + c);
@@ -164,31 +226,45 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const void* x, int ldx,
         const float4 sv = *(const float4*)(sbias + (long long)b * ld_sbias + c);
         add.x += sv.x; add.y += sv.y; add.z += sv.z; add.w += sv.w;
     }
-    yelem_t* yb = (yelem_t*)y + (long long)b * H * W * ldy;
-    const elem_t* rb = res ? (const elem_t*)res + (long long)b * H * W * ldr : nullptr;
+    // OLD: 0 none, 1 the old y sits in opv (same storage type, no res), 2 in oldv -- one straight-line copy per case (a run-time choice
+    // between the two arrays would put both into scratch memory)
+    auto finish = [&](auto old_tag) {
+        constexpr int OLD = decltype(old_tag)::value;
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-        const int oy = Y0 + y0 + o;
-        if (oy >= H) break;
-        const unsigned pix0 = __umul24((unsigned)oy, (unsigned)W) + (unsigned)(X0 + x0);
-        unsigned offy = __umul24(pix0, (unsigned)ldy) + (unsigned)c, offr = __umul24(pix0, (unsigned)ldr) + (unsigned)c;
+        for (int o = 0; o < 2; ++o) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ox = X0 + x0 + j;
-            if (ox >= W) break;
-            float4 v = make_float4(acc[o][j].x + add.x, acc[o][j].y + add.y, acc[o][j].z + add.z, acc[o][j].w + add.w);
-            if (accumulate) {
-                const float4 old = cdf_quad_cvt(cdf_quad_ld<YB>(yb, offy));
-                v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+            for (int j = 0; j < 4; ++j) {
+                float4 v = make_float4(acc[o][j].x + add.x, acc[o][j].y + add.y, acc[o][j].z + add.z, acc[o][j].w + add.w);
+                if constexpr (OLD == 1) {
+                    const float4 old = cdf_quad_cvt(opv[o][j]);
+                    v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                } else if constexpr (OLD == 2) {
+                    const float4 old = cdf_quad_cvt(oldv[o][j]);
+                    v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                    if (res) {
+                        const float4 rv = cdf_quad_cvt(opv[o][j]);
+                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    }
+                } else if (res) {                            // fused residual (e.g. dx = dy + conv^T(dh))
+                    const float4 rv = cdf_quad_cvt(opv[o][j]);
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+                cdf_buf_st(yr, offy[o][j], cdf_quad_raw(v, (const yraw_t*)nullptr));
             }
-            if (res) {                                       // fused residual (e.g. dx = dy + conv^T(dh))
-                const float4 rv = cdf_quad_cvt(cdf_quad_ld<BF>(rb, offr));
-                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-            }
-            cdf_quad_st<YB>(yb, offy, v);
-            offy += (unsigned)ldy;
-            offr += (unsigned)ldr;
         }
+    };
+    if (!accumulate) {
+        finish(std::integral_constant<int, 0>{});
+    } else if (SAME && !res) {
+        finish(std::integral_constant<int, 1>{});
+    } else {
+        if constexpr (SAME) {                                // both operands with one storage type: y is read here, behind the FMAs
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) oldv[o][j] = cdf_buf_ld(yr, offy[o][j], (const yraw_t*)nullptr);
+        }
+        finish(std::integral_constant<int, 2>{});
     }
 }
 

@@ -437,6 +437,13 @@ def test_dwconv7(be, B, C, H):
     dxr = be.empty(B, H, H, Cp)
     be.L.cdf_dwconv7(P(dyn), Cp, P(wp), Cp, 0, 0, 0, P(dxr), Cp, B, H, H, Cp, 1, 0, P(be.to(rs)), Cp, be.stream())     # fused residual
     assert err(dxr[..., :C], dx[..., :C].cpu() + rs[..., :C]) <= 1e-6
+    dxa = be.to(rs.clone())                                                                                     # += old contents
+    be.L.cdf_dwconv7(P(dyn), Cp, P(wp), Cp, 0, 0, 0, P(dxa), Cp, B, H, H, Cp, 1, 1, 0, 0, be.stream())
+    assert err(dxa[..., :C], dx[..., :C].cpu() + rs[..., :C]) <= 1e-6
+    rs2 = torch.randn(B, H, H, Cp)
+    dxb = be.to(rs.clone())                                                                                     # both at once
+    be.L.cdf_dwconv7(P(dyn), Cp, P(wp), Cp, 0, 0, 0, P(dxb), Cp, B, H, H, Cp, 1, 1, P(be.to(rs2)), Cp, be.stream())
+    assert err(dxb[..., :C], dx[..., :C].cpu() + rs[..., :C] + rs2[..., :C]) <= 2e-6
     nch = be.L.cdf_dwconv7_wgrad_nchunk(H)
     ws, dw, dbias, dsb = be.empty(B * nch * 50 * C), be.zeros(C, 1, 7, 7), be.zeros(C), be.zeros(B, Cp)
     be.L.cdf_dwconv7_wgrad(P(xn), Cp, P(dyn), Cp, P(dw), P(dbias), P(dsb), Cp, P(ws), B, H, H, C, 0, be.stream())
