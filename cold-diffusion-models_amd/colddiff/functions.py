@@ -193,7 +193,9 @@ class Join(torch.autograd.Function):
         assert a.data_ptr() == cat.buf.data_ptr() and b.data_ptr() == cat.buf.data_ptr() + 4 * cat.Cx and a.shape[-1] == cat.Cx and \
             b.shape[-1] == cat.Ch and ops.ld_of(a) == cat.Cx + cat.Ch and ops.ld_of(b) == cat.Cx + cat.Ch, "Join: the halves are not the two slices of this CatBuf"
         ctx.Ca = cat.Cx
-        return cat.buf.view(cat.buf.shape)              # (a fresh tensor object over the same storage)
+        out = cat.buf.view(cat.buf.shape)               # (a fresh tensor object over the same storage)
+        out._cdf_grad_f32 = True                        # (its gradient is handed on as channel-slice views: planes of the whole would be wasted)
+        return out
 
     @staticmethod
     def backward(ctx, d):
@@ -421,7 +423,7 @@ class ConvFn(torch.autograd.Function):
         x, x_hi, x_lo = ctx.saved_tensors
         Cin, kind, stride, pad = ctx.cfg
         xs = (x_hi, x_lo) if ctx.has_xs else None
-        dys = ops.split_bf16(dy) if xs is not None else None
+        dys = ops.split_or_planes(dy) if xs is not None else None
         dx = conv_backward(x, Cin, dy, ctx.mod.weight, ctx.mod.bias, kind, stride, pad, need_dx=ctx.needs_input_grad[1], xs=xs, dys=dys)
         _done(ctx)
         return None, dx, None, None, None, None, None, None
@@ -485,6 +487,9 @@ class ConvNextBlockFn(torch.autograd.Function):
         _used(ctx, m.ds_conv, m.net[0] if m.has_norm else None, c1, c2, m.res_conv if m.has_res_conv else None)
         ctx.has_t = tbias is not None
         ctx.tslot = getattr(tbias, "_cdf_gslot", None) if tbias is not None else None
+        # the data gradient of this block goes to a GEMM as bf16 planes when its input came from a ConvNeXt block or a strided conv (not from
+        # an attention block or a skip join, whose backward passes read fp32): written by the depthwise data-gradient kernel itself
+        ctx.dx_planes = bool(grad_on and ops.want_grad_planes(x.shape[-1]) and not getattr(x, "_cdf_grad_f32", False))
         ctx.split = (hn_s is not None, a_s is not None)
         ctx.save_for_backward(x, h, hn if m.has_norm else None, mean, rstd, pre, a, *(hn_s or (None, None)), *(a_s or (None, None)))
         return o
@@ -509,7 +514,7 @@ class ConvNextBlockFn(torch.autograd.Function):
             dx = conv_backward(x, dim, do, m.res_conv.weight, m.res_conv.bias, need_dx=need_dx)
         # (without a res_conv the residual gradient is `do` itself: added by the depthwise data-gradient kernel below)
         # conv2 -> (fused GELU') -> conv1
-        do_s = ops.split_bf16(do) if a_s is not None else None
+        do_s = ops.split_or_planes(do) if a_s is not None else None       # (planes written by the producer of `do`, else cdf_split_bf16)
         if hn_s is not None:
             lean = _LEAN and a_s is not None and a.shape[0] * a.shape[1] * a.shape[2] >= ops.WGRAD_SP_MIN_M
             dpre, dpre_s = conv_backward(a, mid, do, c2.weight, c2.bias, mul=pre, mul_mode=3 if ctx.pre_grad else 1, xs=a_s, dys=do_s, split_dx=True,
@@ -541,9 +546,9 @@ class ConvNextBlockFn(torch.autograd.Function):
         dtb = ops.dwconv7_wgrad(x, dh, m.ds_conv.weight, m.ds_conv.bias, ctx.has_t, dsb_out=dsb_out)
         if need_dx:
             if m.has_res_conv:
-                ops.dwconv7(dh, ops.packed(m.ds_conv.weight, "dw"), None, None, flip=1, y=dx, accumulate=1)
+                dx = ops.dwconv7(dh, ops.packed(m.ds_conv.weight, "dw"), None, None, flip=1, y=dx, accumulate=1, planes=ctx.dx_planes)
             else:
-                dx = ops.dwconv7(dh, ops.packed(m.ds_conv.weight, "dw"), None, None, flip=1, res=do)
+                dx = ops.dwconv7(dh, ops.packed(m.ds_conv.weight, "dw"), None, None, flip=1, res=do, planes=ctx.dx_planes)
         _done(ctx)
         return None, dx, dtb, None, None
 
@@ -621,6 +626,7 @@ class LinAttnBlockFn(torch.autograd.Function):
                 cx, cxs, kmax, ksum = ops.linattn_context(kv, att.heads, att.scale, koff=0)
             y, Mb, Nb = ops.linattn_fold(xn, cxs, att.to_qkv.weight, att.to_out.weight, att.to_out.bias, x, att.heads, **ydst)
             ctx.save_for_backward(x, xn, mean, rstd, kv, Mb, cx, cxs, kmax, ksum, Nb, *(xn_s or (None, None)))
+            y._cdf_grad_f32 = True                    # (this block's backward reads its incoming gradient as fp32)
             return y
         qkv = conv_forward(xn, dim, att.to_qkv.weight, None)
         if ctx.fused:
@@ -628,10 +634,12 @@ class LinAttnBlockFn(torch.autograd.Function):
             cx, cxs, kmax, ksum = ops.linattn_context(qkv, att.heads, att.scale)
             y, Mb = ops.linattn_project(qkv, cxs, att.to_out.weight, att.to_out.bias, x, att.heads, **ydst)
             ctx.save_for_backward(x, xn, mean, rstd, qkv, Mb, cx, cxs, kmax, ksum)
+            y._cdf_grad_f32 = True
             return y
         o, cx, cxs, kmax, ksum = ops.linattn_fwd(qkv, att.heads, att.scale)
         y = conv_forward(o, att.heads * 32, att.to_out.weight, att.to_out.bias, res=x, **ydst)
         ctx.save_for_backward(x, xn, mean, rstd, qkv, o, cx, cxs, kmax, ksum)
+        y._cdf_grad_f32 = True
         return y
 
     @staticmethod
@@ -651,7 +659,7 @@ class LinAttnBlockFn(torch.autograd.Function):
                 dkv = torch.empty(kv.shape, device=kv.device, dtype=torch.float32)
                 ops.linattn_bwd_core(kv, dctx, rvec, kmax, ksum, dkv, att.heads, koff=0)
                 kv_backward(xn, dim, dkv, att.to_qkv.weight, dxn)
-            dx = ops.layernorm_bwd(dxn, x, norm.g, norm.b, mean, rstd, add=dy)     # + the residual branch, same pass
+            dx = ops.layernorm_bwd(dxn, x, norm.g, norm.b, mean, rstd, add=dy, planes=ops.want_grad_planes(dim))     # + the residual branch, same pass
             _done(ctx)
             return None, dx, None, None
         x, xn, mean, rstd, qkv, o, cx, cxs, kmax, ksum = ctx.saved_tensors
@@ -665,7 +673,7 @@ class LinAttnBlockFn(torch.autograd.Function):
             do = conv_backward(o, HD, dy, att.to_out.weight, att.to_out.bias)
             dqkv = ops.linattn_bwd(qkv, do, cx, cxs, kmax, ksum, att.heads, att.scale)
         dxn = conv_backward(xn, dim, dqkv, att.to_qkv.weight, None)
-        dx = ops.layernorm_bwd(dxn, x, norm.g, norm.b, mean, rstd, add=dy)
+        dx = ops.layernorm_bwd(dxn, x, norm.g, norm.b, mean, rstd, add=dy, planes=ops.want_grad_planes(dim))
         _done(ctx)
         return None, dx, None, None
 

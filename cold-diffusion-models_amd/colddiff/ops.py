@@ -4,6 +4,7 @@ Feature maps are NHWC views ``[B, H, W, C]`` with unit channel stride and an arb
 (``t.stride(-2)``), so a channel slice of a wider buffer is a valid operand.  Tensors whose logical
 channel count is not a multiple of 4 are stored padded to 4 with zero pad channels.
 """
+import os
 import weakref
 
 import torch
@@ -246,6 +247,36 @@ def split_bf16(x):
     lo = f(x.shape[:-1] + (ld,), device=x.device, dtype=torch.int16) if rt.precision == "bf16x3" else None
     rt.lib().cdf_split_bf16(P(x), ld_of(x), P(hi), P(lo), ld, x.numel() // C, C, rt.stream(x))
     return hi, lo
+
+
+# A backward kernel whose result feeds the next block's GEMMs can write it as bf16 planes too (cdf_dwconv7_planes, cdf_layernorm_c_bwd_planes):
+# the planes ride on the gradient tensor through the autograd engine (`_cdf_planes`, with the tensor's version counter -- the engine sums
+# gradients IN PLACE when a tensor has several consumers, which bumps it) and the consumer takes them instead of launching cdf_split_bf16.
+GRAD_PLANES = os.environ.get("CDF_GRAD_PLANES", "1") != "0"
+
+
+def want_grad_planes(C):
+    return GRAD_PLANES and rt.precision == "bf16x3" and C % 8 == 0 and C >= 64
+
+
+def attach_planes(t, planes):
+    t._cdf_planes = (planes, t._version)
+    return t
+
+
+def grad_planes(t):
+    """The (hi, lo) planes a producer attached to this very tensor, if they still describe its contents."""
+    rec = getattr(t, "_cdf_planes", None)
+    if rec is None or rec[1] != t._version:
+        return None
+    hi = rec[0][0]
+    if hi.shape != t.shape or hi.device != t.device or not t.is_contiguous() or rec[0][1] is None:
+        return None
+    return rec[0]
+
+
+def split_or_planes(t):
+    return grad_planes(t) or split_bf16(t)
 
 
 def split_planes_like(ref, B, H, W, C):
@@ -511,9 +542,10 @@ def layernorm_fwd(x, g, b, eps, save, split_out=False, planes_only=False):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, g_param, b_param, mean, rstd, dx=None, add=None):
+def layernorm_bwd(dy, x, g_param, b_param, mean, rstd, dx=None, add=None, planes=False):
     """returns dx (accumulating into `dx` if given; add: a second tensor added in the same pass -- the residual gradient of
-    Residual(PreNorm(..)) --, into a new dx); accumulates g/b gradients into the params."""
+    Residual(PreNorm(..)) --, into a new dx); accumulates g/b gradients into the params.
+    planes: dx also as bf16 (hi, lo) planes, attached to it (attach_planes)."""
     L = rt.lib()
     B, H, W, C = x.shape
     M = B * H * W
@@ -522,16 +554,28 @@ def layernorm_bwd(dy, x, g_param, b_param, mean, rstd, dx=None, add=None):
     if dx is None:
         dx = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
     part = torch.empty((L.cdf_layernorm_blocks(M, C) * 2 * C,), device=x.device, dtype=torch.float32)
+    if planes and C % 8 == 0 and dx.is_contiguous():
+        ps = split_planes_like(x, B, H, W, C)
+        L.cdf_layernorm_c_bwd_planes(P(dy), ld_of(dy), P(x), ld_of(x), P(g_param), P(mean), P(rstd), P(dx), ld_of(dx), P(add),
+                                     0 if add is None else ld_of(add), P(grad_of(g_param)), P(grad_of(b_param)), P(part), M, C, acc, 1,
+                                     P(ps[0]), P(ps[1]), C, rt.stream(x))
+        return attach_planes(dx, ps)
     L.cdf_layernorm_c_bwd(P(dy), ld_of(dy), P(x), ld_of(x), P(g_param), P(mean), P(rstd), P(dx), ld_of(dx), P(add),
                           0 if add is None else ld_of(add), P(grad_of(g_param)), P(grad_of(b_param)), P(part), M, C, acc, 1, rt.stream(x))
     return dx
 
 
-def dwconv7(x, wp, bias, sbias, flip=0, y=None, accumulate=0, res=None):
-    """y = dwconv(x) [+ bias + sbias] [+ old y] [+ res]"""
+def dwconv7(x, wp, bias, sbias, flip=0, y=None, accumulate=0, res=None, planes=False):
+    """y = dwconv(x) [+ bias + sbias] [+ old y] [+ res];  planes: y also as bf16 (hi, lo) planes, attached to it (attach_planes)"""
     B, H, W, Cp = x.shape
     if y is None:
         y = torch.empty((B, H, W, Cp), device=x.device, dtype=torch.float32)
+    if planes and Cp % 8 == 0 and y.is_contiguous():
+        ps = split_planes_like(x, B, H, W, Cp)
+        rt.lib().cdf_dwconv7_planes(P(x), ld_of(x), P(wp), wp.shape[-1], P(bias), P(sbias), 0 if sbias is None else sbias.stride(0), P(y),
+                                    ld_of(y), B, H, W, Cp, flip, accumulate, P(res), 0 if res is None else ld_of(res), P(ps[0]), P(ps[1]), Cp,
+                                    rt.stream(x))
+        return attach_planes(y, ps)
     rt.lib().cdf_dwconv7(P(x), ld_of(x), P(wp), wp.shape[-1], P(bias), P(sbias), 0 if sbias is None else sbias.stride(0), P(y),
                          ld_of(y), B, H, W, Cp, flip, accumulate, P(res), 0 if res is None else ld_of(res), rt.stream(x))
     return y

@@ -47,7 +47,8 @@ __device__ __forceinline__ void f4_fma(float4& acc, const float4& a, const float
 template <int TBW, int TBH, bool BF, bool YB = BF>
 __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const void* x, int ldx, const float* w, int ldw, const float* bias,
                                                          const float* sbias, int ld_sbias, void* y, int ldy, int B, int H,
-                                                         int W, int C4, int flip, int accumulate, const void* res, int ldr) {
+                                                         int W, int C4, int flip, int accumulate, const void* res, int ldr,
+                                                         void* y_hi, void* y_lo, int ld_ys) {
     typedef typename cdf_quad<BF>::raw raw_t;
     typedef typename cdf_quad<BF>::elem elem_t;
     typedef typename cdf_quad<YB>::elem yelem_t;
@@ -180,6 +181,10 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const void* x, int ldx,
     const unsigned img_px = (unsigned)H * (unsigned)W;
     const cdf_buf yr = cdf_make_buf((const yelem_t*)y + (long long)b * H * W * ldy, img_px * (unsigned)ldy * (unsigned)sizeof(yelem_t));
     const cdf_buf rr = cdf_make_buf(res ? (const elem_t*)res + (long long)b * H * W * ldr : (const elem_t*)x, res ? img_px * (unsigned)ldr * (unsigned)sizeof(elem_t) : 0u);
+    // (fp32 y only) the output also as bf16 hi / lo planes -- the GEMM operand form its consumer would otherwise produce with cdf_split_bf16
+    const bool planes = !YB && y_hi != nullptr;
+    const cdf_buf hr = cdf_make_buf(planes ? (const unsigned short*)y_hi + (long long)b * H * W * ld_ys : (const unsigned short*)x, planes ? img_px * (unsigned)ld_ys * 2u : 0u);
+    const cdf_buf lr = cdf_make_buf(planes ? (const unsigned short*)y_lo + (long long)b * H * W * ld_ys : (const unsigned short*)x, planes ? img_px * (unsigned)ld_ys * 2u : 0u);
     unsigned offy[2][4], offr[2][4];
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
@@ -250,6 +255,16 @@ __global__ void __launch_bounds__(256, 2) dwconv7_kernel(const void* x, int ldx,
                     v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                 }
                 cdf_buf_st(yr, offy[o][j], cdf_quad_raw(v, (const yraw_t*)nullptr));
+                if constexpr (!YB) {
+                    if (planes) {
+                        uint2 h2, l2;
+                        cdf_split4(v.x, v.y, v.z, v.w, h2, l2);
+                        const int oy = Y0 + y0 + o, ox = X0 + x0 + j;
+                        const unsigned offp = (oy < H && ox < W && cq < C4) ? (__umul24(__umul24((unsigned)oy, (unsigned)W) + (unsigned)ox, (unsigned)ld_ys) + (unsigned)c) * 2u : CDF_BUF_OOB;
+                        cdf_buf_st(hr, offp, h2);
+                        cdf_buf_st(lr, offp, l2);
+                    }
+                }
             }
         }
     };
@@ -538,7 +553,8 @@ __global__ void __launch_bounds__(1024) dwconv7_wgrad_final_kernel(const float* 
 
 template <int TBW, int TBH, bool BF, bool YB = BF>
 static int launch_dwconv7(const void* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias, int ld_sbias, void* y,
-                          int ldy, int B, int H, int W, int C4, int flip, int accumulate, const void* res, int ldr, hipStream_t s) {
+                          int ldy, int B, int H, int W, int C4, int flip, int accumulate, const void* res, int ldr, hipStream_t s,
+                          void* y_hi = nullptr, void* y_lo = nullptr, int ld_ys = 0) {
     constexpr size_t lds = ((size_t)(TBH + 6) * ((TBW + 6) * 8 + 4) + DW_TAPS * 8) * sizeof(float4);
 #ifndef CDF_EMU
     static CdfDeviceLatch attr_done;
@@ -548,20 +564,22 @@ static int launch_dwconv7(const void* x, int ldx, const float* w, int ldw, const
 #endif
     const long long tiles = (long long)B * cdf_cdiv(H, TBH) * cdf_cdiv(W, TBW);
     CDF_LAUNCH((dwconv7_kernel<TBW, TBH, BF, YB>), dim3((unsigned)tiles, cdf_cdiv(C4, 8)), dim3(256), lds, s, x, ldx, w, ldw, bias, sbias, ld_sbias, y,
-               ldy, B, H, W, C4, flip, accumulate, res, ldr);
+               ldy, B, H, W, C4, flip, accumulate, res, ldr, y_hi, y_lo, ld_ys);
     return cdf_check_launch("dwconv7");
 }
 
 // ================================================================================================
 // io_bf16 != 0: x, y and res are bf16 tensors (pitches in bf16 elements, 8-byte aligned); io_bf16 == 2: x and res bf16, y fp32; w, bias,
 // sbias stay fp32
-extern "C" int cdf_dwconv7_io(const void* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias,
+static int dwconv7_entry(const void* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias,
                               int ld_sbias, void* y, int ldy, int B, int H, int W, int C, int flip, int accumulate,
-                              const void* res, int ldr, int io_bf16, void* stream) {
+                              const void* res, int ldr, int io_bf16, void* y_hi, void* y_lo, int ld_ys, void* stream) {
     const uintptr_t amask = io_bf16 ? 7 : 15, ymask = io_bf16 == 1 ? 7 : 15;
     CDF_REQUIRE(io_bf16 >= 0 && io_bf16 <= 2, "cdf_dwconv7_io: io_bf16 must be 0 (fp32), 1 (bf16) or 2 (bf16 x / res, fp32 y)");
     CDF_REQUIRE(!res || (ldr % 4 == 0 && (((uintptr_t)res) & amask) == 0), "cdf_dwconv7: residual must be 16B aligned (bf16: 8B) with pitch %% 4 == 0");
     CDF_REQUIRE(x && w && y, "cdf_dwconv7: null pointer");
+    CDF_REQUIRE((y_hi != nullptr) == (y_lo != nullptr) && (!y_hi || (io_bf16 == 0 && ld_ys % 4 == 0 && ld_ys >= ((C + 3) & ~3) && ((((uintptr_t)y_hi) | ((uintptr_t)y_lo)) & 7) == 0 && ld_ys < (1 << 24))),
+                "cdf_dwconv7_planes: both planes or neither, fp32 y only, 8-byte aligned, pitch %% 4 == 0");
     CDF_REQUIRE((((uintptr_t)x) & amask) == 0 && (((uintptr_t)y) & ymask) == 0, "cdf_dwconv7: x / y must be 16B aligned (bf16: 8B)");
     const int Cp = (C + 3) & ~3;
     CDF_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldw % 4 == 0 && ldx >= Cp && ldy >= Cp && ldw >= Cp, "cdf_dwconv7: pitches must be multiples of 4 and >= roundup4(C)");
@@ -579,8 +597,19 @@ extern "C" int cdf_dwconv7_io(const void* x, int ldx, const float* w, int ldw, c
         if (W <= 16) return launch_dwconv7<16, 16, true>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S);
         return launch_dwconv7<32, 8, true>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S);
     }
-    if (W <= 16) return launch_dwconv7<16, 16, false>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S);
-    return launch_dwconv7<32, 8, false>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S);
+    if (W <= 16) return launch_dwconv7<16, 16, false>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S, y_hi, y_lo, ld_ys);
+    return launch_dwconv7<32, 8, false>(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, Cp / 4, flip, accumulate, res, ldr, CDF_S, y_hi, y_lo, ld_ys);
+}
+extern "C" int cdf_dwconv7_io(const void* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias,
+                              int ld_sbias, void* y, int ldy, int B, int H, int W, int C, int flip, int accumulate,
+                              const void* res, int ldr, int io_bf16, void* stream) {
+    return dwconv7_entry(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, C, flip, accumulate, res, ldr, io_bf16, nullptr, nullptr, 0, stream);
+}
+// fp32 tensors, and y ALSO as bf16 hi / lo planes (pitch ld_ys): the data-gradient pass hands its result to a GEMM in that form
+extern "C" int cdf_dwconv7_planes(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias, int ld_sbias, float* y, int ldy,
+                                  int B, int H, int W, int C, int flip, int accumulate, const float* res, int ldr, void* y_hi, void* y_lo, int ld_ys,
+                                  void* stream) {
+    return dwconv7_entry(x, ldx, w, ldw, bias, sbias, ld_sbias, y, ldy, B, H, W, C, flip, accumulate, res, ldr, 0, y_hi, y_lo, ld_ys, stream);
 }
 
 extern "C" int cdf_dwconv7(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias,

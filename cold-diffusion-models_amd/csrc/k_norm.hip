@@ -104,7 +104,7 @@ template <int NV, int IO>
 __global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const void* dy, int lddy, const void* x, int ldx,
                                                               const float* g, const float* mean_in, const float* rstd_in,
                                                               void* dx, int lddx, float* part, long long M, int C,
-                                                              int LP, const void* add, int ldadd) {
+                                                              int LP, const void* add, int ldadd, unsigned short* ph, unsigned short* pl, int ldp) {
     constexpr bool DYB = (IO & CDF_LN_DY_BF16) != 0, XB = (IO & CDF_LN_X_BF16) != 0, DXB = (IO & CDF_LN_DX_BF16) != 0, ADB = (IO & CDF_LN_ADD_BF16) != 0;
     constexpr int U = NV <= 2 ? 2 : 1;
     const bool accumulate_dx = add != nullptr;               // dx = grad + add (add == dx: accumulate in place)
@@ -182,6 +182,10 @@ __global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const void* dy, in
                             o.x += ov.x; o.y += ov.y; o.z += ov.z; o.w += ov.w;
                         }
                         cdf_quad_st<DXB>(dx, m * lddx + c, o);
+                        if (!DXB && ph) {                    // also as bf16 hi / lo planes (the consumer's GEMM operand: fused cdf_split_bf16)
+                            const float ov4[4] = {o.x, o.y, o.z, o.w};
+                            cdf_split_store4(ph + m * ldp + c, pl + m * ldp + c, ov4);
+                        }
                     }
                 }
             }
@@ -514,11 +518,13 @@ extern "C" int cdf_layernorm_c_fwd(const float* x, int ldx, float* y, int ldy, c
 // part: >= cdf_layernorm_blocks(M, C) * 2 * C floats
 // io_bf16: CDF_LN_DY_BF16 (1) | CDF_LN_X_BF16 (2) | CDF_LN_DX_BF16 (4) | CDF_LN_ADD_BF16 (8) -- which tensors are bf16 (pitches in their own
 // elements, 8-byte aligned); supported combinations: 0, 7 (dy, x, dx: the ConvNeXt block) and 14 (x, dx, add: the attention block)
-extern "C" int cdf_layernorm_c_bwd_io(const void* dy, int lddy, const void* x, int ldx, const float* g,
+static int ln_bwd_launch(const void* dy, int lddy, const void* x, int ldx, const float* g,
                                       const float* mean, const float* rstd, void* dx, int lddx, const void* add, int ldadd,
                                       float* dg, float* db, float* part, long long M, int C, int accumulate_dx, int accumulate_param,
-                                      int io_bf16, void* stream) {
+                                      int io_bf16, void* dx_hi, void* dx_lo, int ld_planes, void* stream) {
     CDF_REQUIRE(dy && x && g && mean && rstd && dx && dg && db && part && M > 0, "cdf_layernorm_c_bwd: null / empty");
+    CDF_REQUIRE((dx_hi != nullptr) == (dx_lo != nullptr) && (!dx_hi || (io_bf16 == 0 && ld_planes % 4 == 0 && ld_planes >= C && ((((uintptr_t)dx_hi) | ((uintptr_t)dx_lo)) & 7) == 0)),
+                "cdf_layernorm_c_bwd_planes: both planes or neither, fp32 tensors only, 8-byte aligned, pitch %% 4 == 0");
     CDF_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && C <= 1024, "cdf_layernorm_c_bwd: bad C / pitch");
     CDF_REQUIRE(!(add && accumulate_dx) && (!add || (ldadd % 4 == 0 && (((uintptr_t)add) & ((io_bf16 & CDF_LN_ADD_BF16) ? 7 : 15)) == 0)), "cdf_layernorm_c_bwd: add and accumulate_dx exclude each other; add must be 16-byte aligned (bf16: 8) with a pitch % 4 == 0");
     CDF_REQUIRE(io_bf16 == 0 || io_bf16 == 7 || io_bf16 == 14, "cdf_layernorm_c_bwd_io: io_bf16 = %d is not one of 0 / 7 / 14", io_bf16);
@@ -543,7 +549,7 @@ extern "C" int cdf_layernorm_c_bwd_io(const void* dy, int lddy, const void* x, i
 #undef CDF_LN_ATTR
     }
 #endif
-#define CDF_LN_BWD(N, IO) CDF_LAUNCH((layernorm_c_bwd_kernel<N, IO>), dim3(nb), dim3(256), lds, CDF_S, dy, lddy, x, ldx, g, mean, rstd, dx, lddx, part, M, C, LP, add, ldadd)
+#define CDF_LN_BWD(N, IO) CDF_LAUNCH((layernorm_c_bwd_kernel<N, IO>), dim3(nb), dim3(256), lds, CDF_S, dy, lddy, x, ldx, g, mean, rstd, dx, lddx, part, M, C, LP, add, ldadd, (unsigned short*)dx_hi, (unsigned short*)dx_lo, ld_planes)
 #define CDF_LN_BWD_NV(IO)                  \
     switch (NV) {                          \
         case 1: CDF_LN_BWD(1, IO); break;  \
@@ -564,6 +570,19 @@ extern "C" int cdf_norm_param_reduce(const float* part, int nblocks, int C, floa
     CDF_REQUIRE(part && dg && db && nblocks > 0 && C > 0, "cdf_norm_param_reduce: bad args");
     CDF_LAUNCH(norm_param_reduce_kernel, dim3(cdf_cdiv(2 * C, 64)), dim3(1024), 0, CDF_S, part, nblocks, C, dg, db, accumulate);
     return cdf_check_launch("norm_param_reduce");
+}
+
+extern "C" int cdf_layernorm_c_bwd_io(const void* dy, int lddy, const void* x, int ldx, const float* g,
+                                      const float* mean, const float* rstd, void* dx, int lddx, const void* add, int ldadd,
+                                      float* dg, float* db, float* part, long long M, int C, int accumulate_dx, int accumulate_param,
+                                      int io_bf16, void* stream) {
+    return ln_bwd_launch(dy, lddy, x, ldx, g, mean, rstd, dx, lddx, add, ldadd, dg, db, part, M, C, accumulate_dx, accumulate_param, io_bf16, nullptr, nullptr, 0, stream);
+}
+// ... and dx ALSO as bf16 hi / lo planes (fp32 tensors): what the consumer of this gradient would otherwise produce with cdf_split_bf16
+extern "C" int cdf_layernorm_c_bwd_planes(const float* dy, int lddy, const float* x, int ldx, const float* g, const float* mean, const float* rstd,
+                                          float* dx, int lddx, const float* add, int ldadd, float* dg, float* db, float* part, long long M, int C,
+                                          int accumulate_dx, int accumulate_param, void* dx_hi, void* dx_lo, int ld_planes, void* stream) {
+    return ln_bwd_launch(dy, lddy, x, ldx, g, mean, rstd, dx, lddx, add, ldadd, dg, db, part, M, C, accumulate_dx, accumulate_param, 0, dx_hi, dx_lo, ld_planes, stream);
 }
 
 extern "C" int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, int ldx, const float* g,

@@ -333,6 +333,11 @@ int cdf_layernorm_c_fwd(const float* x, int ldx, float* y, int ldy, const float*
 /* add (nullable, pitch ldadd): dx = grad + add -- the residual branch of Residual(PreNorm(..)) added in the same pass instead of a
  * copy + accumulate; accumulate_dx = 1 is the same with add = dx (the two exclude each other). */
 int cdf_norm_param_reduce(const float* part, int nblocks, int C, float* dg, float* db, int accumulate, void* stream);
+/* cdf_layernorm_c_bwd_planes (round 6): cdf_layernorm_c_bwd whose dx is ALSO written as bf16 hi / lo planes (pitch ld_planes, the cdf_split_bf16 of the
+ * stored value) for the GEMMs that consume this gradient. */
+int cdf_layernorm_c_bwd_planes(const float* dy, int lddy, const float* x, int ldx, const float* g, const float* mean, const float* rstd,
+                               float* dx, int lddx, const float* add, int ldadd, float* dg, float* db, float* part, long long M, int C,
+                               int accumulate_dx, int accumulate_param, void* dx_hi, void* dx_lo, int ld_planes, void* stream);
 int cdf_layernorm_c_bwd(const float* dy, int lddy, const float* x, int ldx, const float* g, const float* mean,
                         const float* rstd, float* dx, int lddx, const float* add, int ldadd, float* dg, float* db, float* part,
                         long long M, int C, int accumulate_dx, int accumulate_param, void* stream);
@@ -373,6 +378,11 @@ int cdf_groupnorm_bwd(const float* dy, int lddy, const float* x, int ldx, const 
 int cdf_dwconv7(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias, int ld_sbias,
                 float* y, int ldy, int B, int H, int W, int C, int flip, int accumulate,
                 const float* res, int ldr, void* stream);
+/* cdf_dwconv7_planes (round 6): cdf_dwconv7 on fp32 tensors whose result is ALSO written as bf16 hi / lo planes (pitch ld_ys in bf16 elements, the
+ * cdf_split_bf16 of the stored value): the data-gradient pass hands its result to the next block's GEMMs in that form. */
+int cdf_dwconv7_planes(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* sbias, int ld_sbias, float* y, int ldy,
+                       int B, int H, int W, int C, int flip, int accumulate, const float* res, int ldr, void* y_hi, void* y_lo, int ld_ys,
+                       void* stream);
 int cdf_dwconv7_wgrad_nchunk(int H);
 int cdf_dwconv7_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* dbias, float* dsb,
                       int ld_dsb, float* ws, int B, int H, int W, int C, int accumulate, void* stream);

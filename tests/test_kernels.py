@@ -381,6 +381,12 @@ def test_layernorm_c(be, M, C):
         be.L.cdf_layernorm_c_fwd(P(xd), C, P(y2), C, P(gd), P(bd), 0, 0, M, C, 1e-5, P(yh), P(yl), C, be.stream())
         rh, rl = _split(be, y2)
         assert torch.equal(y2.cpu(), y.cpu()) and torch.equal(yh.cpu(), rh.cpu()) and torch.equal(yl.cpu(), rl.cpu())
+        # ... and the backward's dx (cdf_layernorm_c_bwd_planes, with the residual operand): same dx, planes = its cdf_split_bf16
+        dx4, ph, pl = be.empty(M, C), torch.zeros(M, C, dtype=torch.int16, device=be.device), torch.zeros(M, C, dtype=torch.int16, device=be.device)
+        be.L.cdf_layernorm_c_bwd_planes(P(be.to(dy)), C, P(xd), C, P(gd), P(mo), P(ro), P(dx4), C, P(addd), C + 4, P(dg), P(db), P(part), M, C, 0, 0,
+                                        P(ph), P(pl), C, be.stream())
+        rh, rl = _split(be, dx4)
+        assert torch.equal(dx4.cpu(), dx2.cpu()) and torch.equal(ph.cpu(), rh.cpu()) and torch.equal(pl.cpu(), rl.cpu())
 
 
 @pytest.mark.parametrize("B,HW,C,silu", [(2, 16, 32, 1), (3, 64, 64, 1), (1, 16, 128, 0), (2, 300, 96, 1)])
@@ -444,6 +450,13 @@ def test_dwconv7(be, B, C, H):
     dxb = be.to(rs.clone())                                                                                     # both at once
     be.L.cdf_dwconv7(P(dyn), Cp, P(wp), Cp, 0, 0, 0, P(dxb), Cp, B, H, H, Cp, 1, 1, P(be.to(rs2)), Cp, be.stream())
     assert err(dxb[..., :C], dx[..., :C].cpu() + rs[..., :C] + rs2[..., :C]) <= 2e-6
+    if Cp % 8 == 0:
+        # cdf_dwconv7_planes: the same result, also as bf16 hi / lo planes = cdf_split_bf16 of it, bit for bit
+        dxp = be.empty(B, H, H, Cp)
+        ph, pl = torch.zeros(B, H, H, Cp, dtype=torch.int16, device=be.device), torch.zeros(B, H, H, Cp, dtype=torch.int16, device=be.device)
+        be.L.cdf_dwconv7_planes(P(dyn), Cp, P(wp), Cp, 0, 0, 0, P(dxp), Cp, B, H, H, Cp, 1, 0, P(be.to(rs)), Cp, P(ph), P(pl), Cp, be.stream())
+        rh, rl = _split(be, dxp.view(-1, Cp))
+        assert torch.equal(dxp.cpu(), dxr.cpu()) and torch.equal(ph.cpu().view(-1, Cp), rh.cpu()) and torch.equal(pl.cpu().view(-1, Cp), rl.cpu())
     nch = be.L.cdf_dwconv7_wgrad_nchunk(H)
     ws, dw, dbias, dsb = be.empty(B * nch * 50 * C), be.zeros(C, 1, 7, 7), be.zeros(C), be.zeros(B, Cp)
     be.L.cdf_dwconv7_wgrad(P(xn), Cp, P(dyn), Cp, P(dw), P(dbias), P(dsb), Cp, P(ws), B, H, H, C, 0, be.stream())

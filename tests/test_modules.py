@@ -70,6 +70,44 @@ def test_unet_golden(mbe):
     grad_check(net.named_parameters(), g["grads"])
 
 
+def test_gradient_planes_ride_on_the_gradient_tensors(mbe, monkeypatch):
+    """Round 6: the depthwise data-gradient kernel and the attention block's LayerNorm backward write their result as bf16 hi / lo planes too
+    and attach them to the gradient tensor; the consuming block takes them instead of launching cdf_split_bf16.  Same planes => every
+    parameter gradient and the input gradient must be BIT-identical with the mechanism on and off, the planes must really be taken (fewer
+    split launches), and a gradient the engine summed in place (two consumers) must not be served stale planes."""
+    from deblurring_diffusion_pytorch import Unet
+    from colddiff import ops
+    torch.manual_seed(3)
+    net = quiet(Unet, dim=64, dim_mults=(1, 2, 4), channels=3).to(mbe.device)       # (attention blocks in the folded AND the plain form)
+    x = mbe.to(torch.randn(2, 3, 16, 16))
+    t = mbe.to(torch.tensor([3, 7]))
+    gy = mbe.to(torch.randn(2, 3, 16, 16))
+    calls = []
+    real_split, real_take = ops.split_bf16, ops.grad_planes
+    monkeypatch.setattr(ops, "split_bf16", lambda v: (calls.append("split"), real_split(v))[1])
+    monkeypatch.setattr(ops, "grad_planes", lambda v: (lambda r: (calls.append("taken") if r is not None else None, r)[1])(real_take(v)))
+
+    def run(on):
+        monkeypatch.setattr(ops, "GRAD_PLANES", on)
+        del calls[:]
+        net.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        net(xi, t).backward(gy)
+        return [xi.grad.clone()] + [p.grad.clone() for p in net.parameters()], calls.count("split"), calls.count("taken")
+
+    g_on, splits_on, taken_on = run(True)
+    g_off, splits_off, taken_off = run(False)
+    assert taken_off == 0 and taken_on >= 4, (taken_on, taken_off)
+    assert splits_on == splits_off - taken_on, (splits_on, splits_off, taken_on)
+    assert all(torch.equal(a, b) for a, b in zip(g_on, g_off))
+    # a tensor whose contents changed after the planes were attached (the engine's in-place gradient sum) is not served
+    v = mbe.to(torch.randn(1, 4, 4, 64))
+    ops.attach_planes(v, real_split(v))
+    assert real_take(v) is not None
+    v.add_(1.0)
+    assert real_take(v) is None
+
+
 @pytest.mark.parametrize("dim,H", [(16, 12), (160, 8), (64, 16)])
 def test_linear_attention_block_all_forms(mbe, dim, H):
     """Residual(PreNorm(LinearAttention)) in its three arithmetic forms -- plain (per-head products + to_out conv), to_out folded into a
