@@ -316,8 +316,13 @@ __global__ void __launch_bounds__(256, 2) dwconv7_wgrad_partial_kernel(const voi
     typedef typename cdf_quad<BF>::elem elem_t;
     const elem_t* xb = (const elem_t*)x + (long long)b * H * W * ldx;
     const elem_t* db = (const elem_t*)dy + (long long)b * H * W * lddy;
-    const int lq = (cq0 + l8) < C4 ? cq0 + l8 : 0;           // (clamped channel quad for the loads; masked when stored)
     const bool qok = (cq0 + l8) < C4;
+    const unsigned lc4 = (unsigned)((cq0 + l8) * 4);
+    // Round 6: both operands through range-checked buffer resources over the image (cdf_buf, as in dwconv7_kernel): an element outside the
+    // image / the chunk / the channel count asks for CDF_BUF_OOB and arrives as zeros -- no clamps, no selects at the LDS store, 32-bit
+    // offsets (24 x 24-bit products: the host checks H W pitch < 2^30) instead of 64-bit lane addresses.
+    const cdf_buf xr = cdf_make_buf(xb, (unsigned)H * (unsigned)W * (unsigned)ldx * (unsigned)sizeof(elem_t));
+    const cdf_buf dr = cdf_make_buf(db, (unsigned)H * (unsigned)W * (unsigned)lddy * (unsigned)sizeof(elem_t));
 
     float4 acc[DW_K], dsum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -331,35 +336,34 @@ __global__ void __launch_bounds__(256, 2) dwconv7_wgrad_partial_kernel(const voi
             const int X0 = tx * DWG_TW;
             raw_t hx[NXI], hd[NDI];
 #pragma unroll
-            for (int k = 0; k < NXI; ++k) {                  // unconditional loads from clamped addresses; masks applied at the LDS store
-                const int i = tid + 256 * k, p = i >> 3;
+            for (int k = 0; k < NXI; ++k) {                  // every load requested before anything is used
+                const int p = (tid >> 3) + 32 * k;
                 const int hy = p / HWX, hxx = p - hy * HWX;
                 const int iy = y0 + hy - 3, ix = X0 + hxx - 3;
-                const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-                hx[k] = cdf_quad_ld<BF>(xb, ((long long)iyc * W + ixc) * ldx + lq * 4);
+                const bool ok = qok && p < NX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const unsigned off = (__umul24(__umul24((unsigned)iy, (unsigned)W) + (unsigned)ix, (unsigned)ldx) + lc4) * (unsigned)sizeof(elem_t);
+                hx[k] = cdf_buf_ld(xr, ok ? off : CDF_BUF_OOB, (const raw_t*)nullptr);
             }
 #pragma unroll
             for (int k = 0; k < NDI; ++k) {
-                const int i = tid + 256 * k, p = i >> 3;
+                const int p = (tid >> 3) + 32 * k;
                 const int ty = p / DWG_TW, px = p - ty * DWG_TW;
                 const int iy = y0 + ty, ix = X0 + px;
-                const int iyc = iy >= H ? H - 1 : iy, ixc = ix >= W ? W - 1 : ix;
-                hd[k] = cdf_quad_ld<BF>(db, ((long long)iyc * W + ixc) * lddy + lq * 4);
+                const bool ok = qok && iy < yb && ix < W;    // rows past the chunk belong to the next block
+                const unsigned off = (__umul24(__umul24((unsigned)iy, (unsigned)W) + (unsigned)ix, (unsigned)lddy) + lc4) * (unsigned)sizeof(elem_t);
+                hd[k] = cdf_buf_ld(dr, ok ? off : CDF_BUF_OOB, (const raw_t*)nullptr);
             }
 #pragma unroll
             for (int k = 0; k < NXI; ++k) {
-                const int i = tid + 256 * k, p = i >> 3;
+                const int p = (tid >> 3) + 32 * k;
                 const int hy = p / HWX, hxx = p - hy * HWX;
-                const int iy = y0 + hy - 3, ix = X0 + hxx - 3;
-                const bool ok = qok && iy >= 0 && iy < H && ix >= 0 && ix < W;
-                if (p < NX) xs[hy * RPX + hxx * 8 + l8] = ok ? cdf_quad_cvt(hx[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < NX) xs[hy * RPX + hxx * 8 + l8] = cdf_quad_cvt(hx[k]);
             }
 #pragma unroll
             for (int k = 0; k < NDI; ++k) {
-                const int i = tid + 256 * k, p = i >> 3;
+                const int p = (tid >> 3) + 32 * k;
                 const int ty = p / DWG_TW, px = p - ty * DWG_TW;
-                const bool ok = qok && y0 + ty < yb && X0 + px < W;          // rows past the chunk belong to the next block
-                ds[ty * RPD + px * 8 + l8] = ok ? cdf_quad_cvt(hd[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ds[ty * RPD + px * 8 + l8] = cdf_quad_cvt(hd[k]);
             }
             __syncthreads();
             if (busy) {
@@ -633,6 +637,11 @@ extern "C" int cdf_dwconv7_wgrad_io(const void* x, int ldx, const void* dy, int 
     CDF_REQUIRE(x && dy && dw && ws, "cdf_dwconv7_wgrad: null pointer");
     CDF_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && ldx >= ((C + 3) & ~3) && lddy >= ((C + 3) & ~3) && ((((uintptr_t)x) | ((uintptr_t)dy)) & (io_bf16 ? 7 : 15)) == 0,
                 "cdf_dwconv7_wgrad: pitches must be multiples of 4 and >= roundup4(C), pointers 16B aligned (bf16: 8B)");
+    {   // the wide kernel's per-image element offsets are 24 x 24-bit products kept in 32 bits
+        const long long ldmax = ldx > lddy ? ldx : lddy;
+        CDF_REQUIRE(W < 32 || ((long long)H * W < (1 << 24) && ldmax < (1 << 24) && (long long)H * W * ldmax < (1LL << 30)),
+                    "cdf_dwconv7_wgrad: image of %d x %d pixels at pitch %lld is beyond the kernel's 32-bit per-image offsets", H, W, ldmax);
+    }
     const int nchunk = cdf_dwconv7_wgrad_nchunk(H), rpc = cdf_cdiv(H, nchunk);
     if (W >= 32) {
         if (io_bf16) CDF_LAUNCH(dwconv7_wgrad_partial_kernel<true>, dim3(cdf_cdiv(C, 32), nchunk, B), dim3(256), 0, CDF_S, x, ldx, dy, lddy, ws, H, W, C, rpc);
